@@ -1,0 +1,139 @@
+/*
+ * tiatoolbox_amd -- C ABI of the MI355X (gfx950) hot-path library  (libtiatoolbox_amd.so)
+ *
+ * Every entry point takes raw DEVICE pointers + sizes + a hipStream_t (passed as void*).
+ * No allocation, no synchronisation, no exceptions cross this boundary; each call
+ * enqueues kernels on `stream` and returns 0 (TIA_OK) or a negative TIA_E* code.
+ *
+ * The reference (tiatoolbox v2.0.1) is pure Python; the "FFI" a maintainer would add is
+ * a ctypes binding.  Each entry point cites the reference call
+ * site(s) it replaces as `file:line` relative to /root/reference/tiatoolbox/.
+ */
+#ifndef TIATOOLBOX_AMD_H
+#define TIATOOLBOX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TIA_OK 0
+#define TIA_EINVAL (-1)   /* bad argument (null pointer, non-positive size, bad mode)   */
+#define TIA_ELAUNCH (-2)  /* hipLaunch / runtime failure (hipGetLastError() != success)  */
+#define TIA_ESIZE (-3)    /* size outside what the kernel supports                        */
+
+#define TIA_ABI_VERSION 1
+int tia_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Stain tables (device buffer, built once by the host; layout = struct tia_stain_tables).
+ * od_lut[v]      = max(-ln(max(v,1)/255), 1e-6)            utils/transforms.py:229-231
+ * ty[c][v]       = C[3+c] * sRGBGammaTab_b[v]   (Y row of OpenCV's 8-bit RGB2Lab)
+ *                  -> L channel for get_luminosity_tissue_mask, utils/misc.py:281-283
+ * ------------------------------------------------------------------------------------- */
+typedef struct tia_stain_tables {
+    double od_lut[256];
+    float od_lut_f32[256];
+    int32_t ty[3][256];
+} tia_stain_tables;
+
+/* Per-patch statistics record: TIA_STATS_STRIDE doubles per patch. */
+#define TIA_STATS_STRIDE 48
+#define TIA_ST_STAIN 0    /* [6]  source stain matrix, rows H,E unit norm  (stainextract.py:177-227) */
+#define TIA_ST_MAXC 6     /* [2]  99th pct of source concentrations        (stainnorm.py:103)        */
+#define TIA_ST_NTISSUE 8  /*      tissue pixel count                                                   */
+#define TIA_ST_PLOW 9     /*      contrast-enhancer p_low                   (utils/misc.py:434-437)   */
+#define TIA_ST_PHIGH 10   /*      contrast-enhancer p_high                                             */
+#define TIA_ST_MINPHI 11  /*      percentile(phi, 100-ap)                   (stainextract.py:217)     */
+#define TIA_ST_MAXPHI 12  /*      percentile(phi, ap)                       (stainextract.py:218)     */
+#define TIA_ST_COV 13     /* [6]  OD covariance xx,xy,xz,yy,yz,zz (ddof=1)  (stainextract.py:202)     */
+#define TIA_ST_EVEC 19    /* [6]  principal eigenvectors v1[3], v2[3] after sign fix (:205-208)       */
+#define TIA_ST_FLAGS 25   /*      bit0: empty tissue mask; bit1: degenerate (n<2 / non-finite)        */
+#define TIA_ST_PINV 26    /* [6]  pinv(S^T) as P[j*2+i], C_i = sum_j OD_j P[j][i] (stainnorm.py:65)   */
+#define TIA_ST_M 32       /* [9]  M[j*3+c] = sum_i P[j][i]*(maxC_t[i]/maxC_s[i])*S_t[i][c]            */
+#define TIA_ST_SCALE 41   /* [2]  maxC_target / maxC_source                 (stainnorm.py:104)        */
+
+#define TIA_FLAG_EMPTY_MASK 1
+#define TIA_FLAG_DEGENERATE 2
+
+#define TIA_MODE_MACENKO 0 /* estimate the stain matrix per patch (MacenkoExtractor)       */
+#define TIA_MODE_FIXED 1   /* stain matrix given (Custom / Ruifrok / Vahadane-apply)        */
+
+typedef struct tia_stain_params {
+    double q_img_lo;        /* contrast_enhancer low percentile / 100   (0.02) */
+    double q_img_hi;        /* contrast_enhancer high percentile / 100  (0.98) */
+    double q_phi_lo;        /* (100 - angular_percentile) / 100          (0.01) */
+    double q_phi_hi;        /* angular_percentile / 100                  (0.99) */
+    double q_conc;          /* concentration percentile / 100            (0.99) */
+    double stain_fixed[6];  /* TIA_MODE_FIXED: the 2x3 stain matrix                          */
+    double target_stain[6]; /* fitted target stain matrix (for TIA_ST_M); ignored if !has_target */
+    double target_maxc[2];  /* fitted target maxC                                            */
+    int32_t y_thr;          /* tissue <=> descaled Y index < y_thr (from luminosity threshold) */
+    int32_t mode;           /* TIA_MODE_*                                                    */
+    int32_t has_target;     /* 1: also emit TIA_ST_M / TIA_ST_SCALE                          */
+    int32_t zero_to_one;    /* 1: treat byte 0 as 1 in the mask path (rgb2od's in-place edit
+                               seen by StainAugmentor.fit, stainaugment.py:163-175)          */
+} tia_stain_params;
+
+/*
+ * Per-patch stain statistics for a batch of NHWC uint8 patches (one workgroup per patch).
+ * Replaces, per patch: MacenkoExtractor.get_stain_matrix (tools/stainextract.py:177-227,
+ * incl. utils/misc.py:261-290,405-444 and utils/transforms.py:209-231), the lstsq of
+ * StainNormalizer.get_concentrations (tools/stainnorm.py:49-66) as a closed-form
+ * pseudo-inverse, and np.percentile(C, 99, axis=0) (tools/stainnorm.py:81-85,103).
+ *   d_img    [n,h,w,3] uint8     d_tables  tia_stain_tables     d_stats [n,TIA_STATS_STRIDE] f64
+ */
+int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
+                       const tia_stain_tables* d_tables, const tia_stain_params* params,
+                       double* d_stats, void* stream);
+
+/* Output kinds of tia_stain_apply_u8 */
+#define TIA_OUT_U8 0       /* uint8 NHWC, astype(uint8) truncation   (stainnorm.py:110-113)          */
+#define TIA_OUT_F32 1      /* float32 NHWC: the pre-cast float in [0,255] (parity instrumentation)   */
+#define TIA_OUT_F64 2      /* float64 NHWC: idem, f64                                                  */
+#define TIA_OUT_UNIT_F16 3 /* half NHWC = uint8(trunc)/255 : ToTensor() of the normalised patch       */
+#define TIA_OUT_UNIT_BF16 4
+#define TIA_OUT_UNIT_F32 5
+
+#define TIA_MATH_F64 0 /* reference order of operations in f64 (stainnorm.py:102-107)             */
+#define TIA_MATH_F32 1 /* fused 3x3 matrix in f32: |err| <= 1e-4 on the pre-cast float            */
+
+/*
+ * out = 255*exp(-(OD(img) . pinv . diag(scale) . S_target)), clipped to [0,255].
+ * Streaming kernel: 1 read + 1 write per pixel.  Replaces tools/stainnorm.py:102-113.
+ * Reads TIA_ST_M / TIA_ST_PINV / TIA_ST_SCALE from d_stats (produced with has_target=1).
+ */
+int tia_stain_apply_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
+                       const tia_stain_tables* d_tables, const double* d_stats,
+                       const double* target_stain /* host, [6] */, void* d_out, int32_t out_kind,
+                       int32_t math, void* stream);
+
+/*
+ * Concentrations C[n*h*w, 2] (f64) of every pixel w.r.t. the per-patch TIA_ST_PINV.
+ * Replaces StainNormalizer.get_concentrations (tools/stainnorm.py:49-66).
+ */
+int tia_stain_concentrations_f64(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
+                                 const tia_stain_tables* d_tables, const double* d_stats,
+                                 double* d_conc, void* stream);
+
+/*
+ * StainAugmentor.augment (tools/stainaugment.py:177-206): C[mask,i] = C[mask,i]*alpha[i]+beta[i]
+ * (all pixels if augment_background), out = uint8(clip(255*exp(-C.S),0,255)).  S = per-patch
+ * TIA_ST_STAIN, mask from TIA_ST_PLOW/PHIGH + tables.  d_alpha_beta: [n,4] f64 = a0,a1,b0,b1.
+ */
+int tia_stain_augment_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
+                         const tia_stain_tables* d_tables, const double* d_stats,
+                         const double* d_alpha_beta, int32_t y_thr, int32_t augment_background,
+                         int32_t zero_to_one, uint8_t* d_out, void* stream);
+
+/* Luminosity tissue mask (utils/misc.py:261-290) as uint8 0/1 [n,h,w]; needs TIA_ST_PLOW/PHIGH. */
+int tia_luminosity_mask_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
+                           const tia_stain_tables* d_tables, const double* d_stats, int32_t y_thr,
+                           int32_t zero_to_one, uint8_t* d_mask, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIATOOLBOX_AMD_H */

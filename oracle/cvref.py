@@ -1,0 +1,161 @@
+"""Restatements of the OpenCV primitives the reference's hot path calls.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  OpenCV (``opencv-python>=4.6.0``,
+reference ``requirements/requirements.txt:19``) is not vendored under
+``/root/reference`` and is not installable here, so these follow the published
+algorithm of OpenCV 4.x ``modules/imgproc/src/color_lab.cpp`` / ``color_yuv``/
+``color_rgb`` (8-bit fixed-point paths).  **Parity with the real library is
+unpinned**: verify every table when ``cv2`` is importable.
+
+Reference call sites: ``tiatoolbox/utils/misc.py:281`` (RGB2LAB for the luminosity
+mask), ``tiatoolbox/tools/stainnorm.py:309,340`` (Reinhard), ``tiatoolbox/tools/
+tissuemask.py:129,160,291`` (RGB2GRAY).
+"""
+
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+
+GAMMA_SHIFT = 3
+LAB_SHIFT = 12
+LAB_SHIFT2 = LAB_SHIFT + GAMMA_SHIFT
+LAB_CBRT_TAB_SIZE_B = 256 * 3 // 2 * (1 << GAMMA_SHIFT)  # 3072
+
+# sRGB -> XYZ (D65) as used by OpenCV (color_lab.cpp: sRGB2XYZ_D65, D65 white point)
+_SRGB2XYZ_D65 = np.array(
+    [0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227],
+    dtype=np.float64,
+)
+_D65 = np.array([0.950456, 1.0, 1.088754], dtype=np.float64)
+
+
+def _cv_round(x: np.ndarray) -> np.ndarray:
+    """cvRound: round half to even."""
+    return np.rint(x).astype(np.int64)
+
+
+def _cv_cbrt_f32(x32: np.ndarray) -> np.ndarray:
+    """cv::cbrt(softfloat): exponent split + quartic rational polynomial (f64), cast to f32.
+
+    Follows OpenCV ``modules/core/src/mathfuncs_core``/``softfloat.cpp`` ``cubeRoot``.
+    """
+    x32 = np.asarray(x32, dtype=np.float32)
+    bits = x32.view(np.int32).astype(np.int64)
+    ix = bits & 0x7FFFFFFF
+    s = bits & 0x80000000
+    ex = (ix >> 23) - 127
+    # C remainder (truncation toward zero), then forced negative
+    shx = np.fmod(ex, 3).astype(np.int64)
+    shx = shx - np.where(shx >= 0, 3, 0)
+    ex3 = (ex - shx) // 3  # exact division
+    frbits = (ix & ((1 << 23) - 1)) | ((shx + 127) << 23)
+    fr = frbits.astype(np.int32).view(np.float32).astype(np.float64)
+    num = ((((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr
+             + 119.1654824285581628956914143) * fr + 13.43250139086239872172837314) * fr
+           + 0.1636161226585754240958355063)
+    den = ((((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr
+             + 168.5254414101568283957668343) * fr + 33.9905941350215598754191872) * fr + 1.0)
+    r32 = (num / den).astype(np.float32)
+    rbits = r32.view(np.int32).astype(np.int64)
+    out = (rbits + (ex3 << 23) + s)
+    out = np.where(ix != 0, out, 0)
+    return (out & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+
+
+@functools.lru_cache(maxsize=1)
+def lab_tables() -> dict[str, np.ndarray]:
+    """Build OpenCV's 8-bit Lab tables (``initLabTabs`` + ``RGB2Lab_b`` ctor)."""
+    f32 = np.float32
+    i = np.arange(256)
+    x = (i.astype(f32) / f32(255.0)).astype(f32)
+    xd = x.astype(np.float64)
+    g = np.where(xd <= 0.04045, xd / 12.92, np.power((xd + 0.055) / 1.055, 2.4))
+    g32 = g.astype(f32)
+    srgb_gamma = _cv_round((f32(255 * (1 << GAMMA_SHIFT)) * g32).astype(f32))
+    linear_gamma = i * (1 << GAMMA_SHIFT)
+
+    j = np.arange(LAB_CBRT_TAB_SIZE_B)
+    cb_scale = (f32(1.0) / (f32(255.0) * f32(1 << GAMMA_SHIFT))).astype(f32)
+    xj = (cb_scale * j.astype(f32)).astype(f32)
+    lthresh = (f32(216.0) / f32(24389.0)).astype(f32)
+    lscale = (f32(841.0) / f32(108.0)).astype(f32)
+    lbias = (f32(16.0) / f32(116.0)).astype(f32)
+    # mulAdd(x, lscale, lbias) is a fused multiply-add in f32
+    lin = (xj.astype(np.float64) * np.float64(lscale) + np.float64(lbias)).astype(f32)
+    with np.errstate(all="ignore"):
+        cb = _cv_cbrt_f32(xj)
+    val = np.where(xj < lthresh, lin, cb).astype(f32)
+    cbrt_tab = _cv_round((f32(1 << LAB_SHIFT2) * val).astype(f32))
+
+    coeffs = np.empty(9, dtype=np.int64)
+    for r in range(3):
+        for c in range(3):
+            coeffs[r * 3 + c] = int(np.rint((1 << LAB_SHIFT) * _SRGB2XYZ_D65[r * 3 + c] / _D65[r]))
+    return {
+        "srgb_gamma": srgb_gamma.astype(np.int64),
+        "linear_gamma": linear_gamma.astype(np.int64),
+        "cbrt": cbrt_tab.astype(np.int64),
+        "coeffs": coeffs,
+    }
+
+
+L_SCALE = (116 * 255 + 50) // 100  # 296
+L_SHIFT = -((16 * 255 * (1 << LAB_SHIFT2) + 50) // 100)
+
+
+def _descale(x: np.ndarray, n: int) -> np.ndarray:
+    return (x + (1 << (n - 1))) >> n
+
+
+def rgb2lab_u8(img: np.ndarray) -> np.ndarray:
+    """``cv2.cvtColor(img, cv2.COLOR_RGB2LAB)`` for uint8 input (``RGB2Lab_b``)."""
+    img = np.asarray(img)
+    if img.dtype != np.uint8 or img.shape[-1] != 3:
+        msg = "rgb2lab_u8 expects HxWx3 uint8"
+        raise ValueError(msg)
+    t = lab_tables()
+    tab, cb, c = t["srgb_gamma"], t["cbrt"], t["coeffs"]
+    r = tab[img[..., 0]]
+    g = tab[img[..., 1]]
+    b = tab[img[..., 2]]
+    fx = cb[_descale(r * c[0] + g * c[1] + b * c[2], LAB_SHIFT)]
+    fy = cb[_descale(r * c[3] + g * c[4] + b * c[5], LAB_SHIFT)]
+    fz = cb[_descale(r * c[6] + g * c[7] + b * c[8], LAB_SHIFT)]
+    big_l = _descale(L_SCALE * fy + L_SHIFT, LAB_SHIFT2)
+    a = _descale(500 * (fx - fy) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2)
+    bb = _descale(200 * (fy - fz) + 128 * (1 << LAB_SHIFT2), LAB_SHIFT2)
+    out = np.stack([big_l, a, bb], axis=-1)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def lab_l_from_y_table() -> np.ndarray:
+    """L (uint8) as a function of the descaled Y index 0..3071 (helper for host code)."""
+    t = lab_tables()
+    fy = t["cbrt"]
+    return np.clip(_descale(L_SCALE * fy + L_SHIFT, LAB_SHIFT2), 0, 255).astype(np.uint8)
+
+
+def rgb2gray_u8(img: np.ndarray) -> np.ndarray:
+    """``cv2.cvtColor(img, cv2.COLOR_RGB2GRAY)`` uint8: 15-bit fixed point (OpenCV 4.x).
+
+    ``(R*9798 + G*19235 + B*3735 + 2^14) >> 15`` (``color_rgb``: ``RGB2Gray<uchar>``,
+    ``gray_shift = 15``, coefficients ``RY15=9798, GY15=19235, BY15=3735``).
+    """
+    img = np.asarray(img)
+    r = img[..., 0].astype(np.int64)
+    g = img[..., 1].astype(np.int64)
+    b = img[..., 2].astype(np.int64)
+    return ((r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15).astype(np.uint8)
+
+
+def mean_std_dev(chan: np.ndarray) -> tuple[float, float]:
+    """``cv2.meanStdDev`` on one channel: f64 mean and *population* standard deviation."""
+    x = np.asarray(chan, dtype=np.float64).ravel()
+    n = x.size
+    s = float(x.sum())
+    sq = float((x * x).sum())
+    mean = s / n
+    var = max(sq / n - mean * mean, 0.0)
+    return mean, float(np.sqrt(var))

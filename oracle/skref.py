@@ -1,0 +1,106 @@
+"""Restatements of the scikit-image primitives the reference's hot path calls.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  scikit-image (``>=0.26.0``,
+reference ``requirements/requirements.txt:27``) is not under ``/root/reference`` and is
+not installable here; these follow its published algorithms.
+"""
+
+from __future__ import annotations
+
+import heapq
+
+import numpy as np
+
+
+def rescale_intensity(image: np.ndarray, in_range: tuple, out_range: tuple) -> np.ndarray:
+    """``skimage.exposure.rescale_intensity(image, in_range=(lo,hi), out_range=(a,b))``.
+
+    With an explicit tuple ``out_range`` the output dtype is float64; arithmetic is
+    ``clip -> (x-imin)/(imax-imin) -> x*(omax-omin)+omin`` in float64.  Pinned by the
+    reference golden ``tests/test_utils.py:882-911`` (via ``contrast_enhancer``).
+    Call site: ``tiatoolbox/utils/misc.py:439-443``.
+    """
+    imin, imax = float(in_range[0]), float(in_range[1])
+    omin, omax = float(out_range[0]), float(out_range[1])
+    x = np.clip(np.asarray(image, dtype=np.float64), imin, imax)
+    if imin != imax:
+        x = (x - imin) / (imax - imin)
+        return x * (omax - omin) + omin
+    return np.clip(x, omin, omax)
+
+
+def threshold_otsu_u8(image: np.ndarray) -> int:
+    """``skimage.filters.threshold_otsu`` for an integer (uint8) image.
+
+    ``histogram(image, nbins=256, source_range='image')`` on integer input yields one
+    bin per integer in ``[min, max]`` (bin centres = the integers); threshold = centre
+    of ``argmax(w1[:-1] * w2[1:] * (mean1[:-1] - mean2[1:])**2)``.  If the image has a
+    single value that value is returned.  Call site: ``tiatoolbox/tools/tissuemask.py:134``.
+    """
+    image = np.asarray(image)
+    first = image.reshape(-1)[0]
+    if np.all(image == first):
+        return int(first)
+    lo, hi = int(image.min()), int(image.max())
+    counts = np.bincount(image.ravel().astype(np.int64) - lo, minlength=hi - lo + 1).astype(np.float64)
+    centers = np.arange(lo, hi + 1, dtype=np.float64)
+    weight1 = np.cumsum(counts)
+    weight2 = np.cumsum(counts[::-1])[::-1]
+    mean1 = np.cumsum(counts * centers) / weight1
+    mean2 = (np.cumsum((counts * centers)[::-1]) / weight2[::-1])[::-1]
+    variance12 = weight1[:-1] * weight2[1:] * (mean1[:-1] - mean2[1:]) ** 2
+    idx = int(np.argmax(variance12))
+    return int(centers[idx])
+
+
+def remove_small_objects_labels(lab: np.ndarray, max_size: int) -> np.ndarray:
+    """``skimage.morphology.remove_small_objects(label_image, max_size=s)``.
+
+    Zeroes every label whose pixel count is ``<= max_size`` (no relabelling).  Call
+    sites: ``tiatoolbox/models/architecture/hovernet.py:544,614``.
+    """
+    out = lab.copy()
+    counts = np.bincount(out.ravel())
+    small = counts <= max_size
+    small[0] = False
+    out[small[out]] = 0
+    return out
+
+
+def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """``skimage.segmentation.watershed(image, markers, mask=mask)`` (connectivity 1).
+
+    Priority flood (``_watershed_cy.watershed_raveled``): a heap keyed by
+    ``(value, age)``; every marker pixel (raster order) is pushed with its own value;
+    a popped pixel visits its neighbours in raveled offset order (up, left, right,
+    down); each unlabelled in-mask neighbour takes the popped pixel's label and is
+    pushed with its own image value and the next age.  Call site:
+    ``tiatoolbox/models/architecture/hovernet.py:616``.
+    """
+    image = np.asarray(image, dtype=np.float64)
+    h, w = image.shape
+    out = np.where(mask, markers, 0).astype(np.int32)
+    maskb = np.asarray(mask, dtype=bool)
+    heap: list = []
+    age = 0
+    flat_out = out.ravel()
+    flat_img = image.ravel()
+    flat_mask = maskb.ravel()
+    for idx in np.flatnonzero(flat_out):
+        heapq.heappush(heap, (flat_img[idx], age, int(idx)))
+        age += 1
+    while heap:
+        _, _, idx = heapq.heappop(heap)
+        r, c = divmod(idx, w)
+        lab = flat_out[idx]
+        for dr, dc in ((-1, 0), (0, -1), (0, 1), (1, 0)):
+            rr, cc = r + dr, c + dc
+            if rr < 0 or rr >= h or cc < 0 or cc >= w:
+                continue
+            n = rr * w + cc
+            if flat_out[n] != 0 or not flat_mask[n]:
+                continue
+            flat_out[n] = lab
+            heapq.heappush(heap, (flat_img[n], age, n))
+            age += 1
+    return out

@@ -1,0 +1,93 @@
+"""Generate golden vectors by running the REAL reference (``/root/reference``) here.
+
+Run in the build container only:  ``python tests/golden/make_golden.py``.
+Third-party primitives that are absent (cv2 / skimage) are bound to the oracle's
+restatements by ``_refshim``; everything else is the reference's own code.  Outputs are
+small ``.npz`` fixtures committed next to this script; ``tests/test_oracle_golden.py``
+checks the oracle against them and the ``-m gpu`` tests check the HIP path against both.
+"""
+
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import _refshim  # noqa: E402
+
+_refshim.install()
+
+from PIL import Image  # noqa: E402
+
+from tiatoolbox_amd.utils import synth  # noqa: E402
+
+
+def _import_reference():
+    import importlib
+
+    for _ in range(2):  # first import can trip over a lazy transformers import
+        try:
+            return (importlib.import_module("tiatoolbox.tools.stainnorm"),
+                    importlib.import_module("tiatoolbox.utils.misc"),
+                    importlib.import_module("tiatoolbox.tools.stainaugment"))
+        except ModuleNotFoundError:
+            continue
+    raise RuntimeError("cannot import the reference")
+
+
+def stain_goldens() -> None:
+    stainnorm, misc, stainaugment = _import_reference()
+    target_full = np.array(Image.open(_refshim.REFERENCE / "tiatoolbox/data/target_image.png"))[..., :3]
+    target = np.ascontiguousarray(target_full[:256, :256])
+    np.save(HERE / "target_crop_256.npy", target)
+    rng = np.random.default_rng(2)
+    crops = []
+    for _ in range(3):
+        y, x = rng.integers(0, 1000 - 128, 2)
+        crops.append(target_full[y:y + 128, x:x + 128])
+    crops = np.ascontiguousarray(np.stack(crops))
+    he = synth.g_he(3, 96, 96, seed=11)
+    out = {"real_crops": crops, "he_seed": np.array(11)}
+
+    for method in ("macenko", "ruifrok", "custom"):
+        sm = np.array([[0.60, 0.72, 0.34], [0.10, 0.95, 0.29]]) if method == "custom" else None
+        norm = stainnorm.get_normalizer(method, stain_matrix=sm)
+        norm.fit(target.copy())
+        out[f"{method}_stain_matrix_target"] = norm.stain_matrix_target
+        out[f"{method}_maxC_target"] = norm.maxC_target
+        out[f"{method}_stain_matrix_target_RGB"] = norm.stain_matrix_target_RGB
+        out[f"{method}_target_conc_head"] = norm.target_concentrations[:64]
+        out[f"{method}_real"] = np.stack([norm.transform(c.copy()) for c in crops])
+        out[f"{method}_he"] = np.stack([norm.transform(c.copy()) for c in he])
+        if method == "macenko":
+            out["macenko_src_sm_real"] = np.stack([norm.extractor.get_stain_matrix(c.copy()) for c in crops])
+
+    out["ce_real"] = np.stack([misc.contrast_enhancer(c.copy(), low_p=2, high_p=98) for c in crops])
+    out["mask08_real"] = np.stack([misc.get_luminosity_tissue_mask(c.copy(), threshold=0.8) for c in crops])
+    out["mask085_he"] = np.stack([misc.get_luminosity_tissue_mask(c.copy(), threshold=0.85) for c in he])
+
+    # StainAugmentor with injected (alpha, beta) per stain channel (reference draws them unseeded)
+    ab = np.array([[1.25, 0.9, 0.1, -0.05], [0.7, 1.3, -0.15, 0.12]])
+    aug_out = []
+    for k, (a0, a1, b0, b1) in enumerate(ab):
+        seq = iter([(a0, b0), (a1, b1)])
+        aug = stainaugment.StainAugmentor(method="macenko", sigma1=0.4, sigma2=0.2, augment_background=bool(k))
+
+        def fake_params(self=aug, seq=seq):
+            self.alpha, self.beta = next(seq)
+            return {}
+
+        aug.get_params = fake_params
+        aug.fit(crops[k].copy(), threshold=0.85)
+        aug_out.append(aug.augment())
+    out["augment_ab"] = ab
+    out["augment_real"] = np.stack(aug_out)
+    np.savez_compressed(HERE / "stain_golden.npz", **out)
+    print("wrote stain_golden.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    stain_goldens()

@@ -1,0 +1,102 @@
+"""ctypes binding of the C-ABI library (``include/tiatoolbox_amd.h``).
+
+The product path has **no CPU fallback**: if the HIP library cannot be loaded, or a call
+is made without a GPU tensor, it raises.  ``torch`` is used only for device memory and
+streams.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+from . import build as _build
+
+TIA_STATS_STRIDE = 48
+ST_STAIN, ST_MAXC, ST_NTISSUE, ST_PLOW, ST_PHIGH = 0, 6, 8, 9, 10
+ST_MINPHI, ST_MAXPHI, ST_COV, ST_EVEC, ST_FLAGS, ST_PINV, ST_M, ST_SCALE = 11, 12, 13, 19, 25, 26, 32, 41
+FLAG_EMPTY_MASK, FLAG_DEGENERATE = 1, 2
+MODE_MACENKO, MODE_FIXED = 0, 1
+OUT_U8, OUT_F32, OUT_F64, OUT_UNIT_F16, OUT_UNIT_BF16, OUT_UNIT_F32 = 0, 1, 2, 3, 4, 5
+MATH_F64, MATH_F32 = 0, 1
+
+_ERRORS = {-1: "TIA_EINVAL (bad argument)", -2: "TIA_ELAUNCH (HIP launch failed)",
+           -3: "TIA_ESIZE (size not supported)"}
+
+
+class StainTables(C.Structure):
+    _fields_ = [("od_lut", C.c_double * 256), ("od_lut_f32", C.c_float * 256),
+                ("ty", (C.c_int32 * 256) * 3)]
+
+
+class StainParams(C.Structure):
+    _fields_ = [
+        ("q_img_lo", C.c_double), ("q_img_hi", C.c_double), ("q_phi_lo", C.c_double),
+        ("q_phi_hi", C.c_double), ("q_conc", C.c_double), ("stain_fixed", C.c_double * 6),
+        ("target_stain", C.c_double * 6), ("target_maxc", C.c_double * 2), ("y_thr", C.c_int32),
+        ("mode", C.c_int32), ("has_target", C.c_int32), ("zero_to_one", C.c_int32),
+    ]
+
+
+class HipLibraryError(RuntimeError):
+    """The HIP extension is missing or a kernel launch failed."""
+
+
+_LIB = None
+
+_I64, _I32, _P = C.c_int64, C.c_int32, C.c_void_p
+
+_SIGNATURES = {
+    "tia_abi_version": ([], C.c_int),
+    "tia_stain_stats_u8": ([_P, _I64, _I64, _I64, _P, C.POINTER(StainParams), _P, _P], C.c_int),
+    "tia_stain_apply_u8": ([_P, _I64, _I64, _I64, _P, _P, C.POINTER(C.c_double), _P, _I32, _I32, _P], C.c_int),
+    "tia_stain_concentrations_f64": ([_P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
+    "tia_stain_augment_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P], C.c_int),
+    "tia_luminosity_mask_u8": ([_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _P, _P], C.c_int),
+}
+
+
+def lib_path() -> Path:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load ``libtiatoolbox_amd.so`` (built in-tree by ``__graft_entry__.build()``)."""
+    global _LIB  # noqa: PLW0603
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not path.exists():
+        msg = (f"{path} not found: the HIP extension is not built. Run "
+               "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+               "There is no CPU fallback.")
+        raise HipLibraryError(msg)
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as exc:  # missing ROCm runtime etc.
+        msg = f"cannot load {path}: {exc}"
+        raise HipLibraryError(msg) from exc
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = f"{what} failed: {_ERRORS.get(rc, rc)}"
+        raise HipLibraryError(msg)
+
+
+def current_stream() -> C.c_void_p:
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, name: str = "tensor") -> None:
+    if not t.is_cuda:
+        msg = f"{name} must live on the GPU (cuda:N == HIP device); there is no CPU fallback."
+        raise HipLibraryError(msg)

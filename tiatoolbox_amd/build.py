@@ -1,0 +1,53 @@
+"""Build recipe for ``libtiatoolbox_amd.so`` (hipcc, gfx950 only, in-tree)."""
+
+from __future__ import annotations
+
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIB_DIR = PKG / "lib"
+LIB_PATH = LIB_DIR / "libtiatoolbox_amd.so"
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-shared",
+    "-fno-gpu-rdc",
+    "-Wno-unused-result",
+]
+
+
+def sources() -> list[Path]:
+    return sorted(CSRC.glob("*.hip"))
+
+
+def needs_build() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    deps = [*sources(), *CSRC.glob("*.hpp"), *(ROOT / "include").glob("*.h")]
+    return any(p.stat().st_mtime > t for p in deps)
+
+
+def build(*, force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source into one shared library (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", f"-I{CSRC}",
+           *[str(s) for s in sources()], "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

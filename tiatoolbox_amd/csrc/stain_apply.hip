@@ -1,0 +1,407 @@
+// Streaming per-pixel stain kernels on gfx950 (1 read + 1 write per pixel).
+//   stain_apply   : out = 255*exp(-(OD . M))            tools/stainnorm.py:102-113
+//   concentrations: C = OD . pinv                         tools/stainnorm.py:49-66
+//   augment       : C[mask]*alpha+beta, recompose         tools/stainaugment.py:177-206
+//   luminosity mask                                       utils/misc.py:261-290
+// Layout: NHWC uint8 in; lanes read 12 contiguous bytes (4 whole pixels) so a wave covers 768
+// contiguous bytes per load and no pixel straddles two lanes.  The OD look-up table lives in
+// LDS, replicated once per bank (lut[v][lane&31]) so data-dependent look-ups never conflict.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace tia {
+
+constexpr int AT = 256;  // threads per block for the streaming kernels
+
+struct StainT {
+    double s[6];
+};
+
+// ---- per-block folded luminance tables (same arithmetic as stain_stats P1) --------------------
+__device__ __forceinline__ void build_ty(int (*ty)[256], const tia_stain_tables* __restrict__ tab,
+                                         double plow, double phigh, bool z1) {
+    for (int tid = threadIdx.x; tid < 256; tid += blockDim.x) {
+        int v = tid;
+        if (z1 && v == 0) v = 1;
+        int ce = v;
+        if (phigh > plow) {
+            double x = (double)v;
+            x = x < plow ? plow : (x > phigh ? phigh : x);
+            x = (x - plow) / (phigh - plow);
+            x = x * 255.0 + 0.0;
+            ce = (int)x;
+        }
+        ty[0][tid] = tab->ty[0][ce];
+        ty[1][tid] = tab->ty[1][ce];
+        ty[2][tid] = tab->ty[2][ce];
+    }
+}
+
+// ---- output writers -----------------------------------------------------------------------------
+template <int OUT>
+struct Out;
+
+template <>
+struct Out<TIA_OUT_U8> {
+    using T = uint8_t;
+    template <class F>
+    static __device__ __forceinline__ T cvt(F v) { return (T)(unsigned)v; }  // astype(uint8): truncation
+};
+template <>
+struct Out<TIA_OUT_F32> {
+    using T = float;
+    template <class F>
+    static __device__ __forceinline__ T cvt(F v) { return (float)v; }
+};
+template <>
+struct Out<TIA_OUT_F64> {
+    using T = double;
+    template <class F>
+    static __device__ __forceinline__ T cvt(F v) { return (double)v; }
+};
+// ToTensor() of the truncated uint8: float32(u8)/255, then rounded to the storage type
+template <>
+struct Out<TIA_OUT_UNIT_F32> {
+    using T = float;
+    template <class F>
+    static __device__ __forceinline__ T cvt(F v) { return __fdiv_rn((float)(unsigned)v, 255.0f); }
+};
+template <>
+struct Out<TIA_OUT_UNIT_F16> {
+    using T = __half;
+    template <class F>
+    static __device__ __forceinline__ T cvt(F v) { return __float2half_rn(__fdiv_rn((float)(unsigned)v, 255.0f)); }
+};
+template <>
+struct Out<TIA_OUT_UNIT_BF16> {
+    using T = __hip_bfloat16;
+    template <class F>
+    static __device__ __forceinline__ T cvt(F v) { return __float2bfloat16(__fdiv_rn((float)(unsigned)v, 255.0f)); }
+};
+
+template <class T, int BYTES = sizeof(T) * 12>
+struct Pack12 {
+    alignas(16) T v[12];
+};
+
+template <class T>
+__device__ __forceinline__ void store12(T* __restrict__ dst, const Pack12<T>& pk) {
+    constexpr int bytes = sizeof(T) * 12;
+    if constexpr (bytes == 12) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(pk.v);
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+        d[0] = w[0];
+        d[1] = w[1];
+        d[2] = w[2];
+    } else if constexpr (bytes == 24) {
+        const uint2* w = reinterpret_cast<const uint2*>(pk.v);
+        uint2* d = reinterpret_cast<uint2*>(dst);
+        d[0] = w[0];
+        d[1] = w[1];
+        d[2] = w[2];
+    } else {
+        const uint4* w = reinterpret_cast<const uint4*>(pk.v);
+        uint4* d = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+        for (int i = 0; i < bytes / 16; ++i) d[i] = w[i];
+    }
+}
+
+// ---- stain apply ---------------------------------------------------------------------------------
+template <int MATH>
+struct ApplyCtx;
+
+// f32: fused 3x3 matrix, pre-scaled by -log2(e); hardware exp2.
+template <>
+struct ApplyCtx<TIA_MATH_F32> {
+    float m[9];
+    const float* lut;  // bank-private: lut[v*32 + (lane&31)]
+    int bank;
+    __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, float (&o)[3]) const {
+        const float x = lut[r * 32 + bank], y = lut[g * 32 + bank], z = lut[b * 32 + bank];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float u = __builtin_fmaf(z, m[6 + c], __builtin_fmaf(y, m[3 + c], x * m[c]));
+            float v = 255.0f * __builtin_amdgcn_exp2f(u);
+            v = v > 255.0f ? 255.0f : v;  // trans[trans > 255] = 255
+            v = v < 0.0f ? 0.0f : v;      // trans[trans < 0] = 0
+            o[c] = v;
+        }
+    }
+};
+
+// f64: the reference's order of operations (concentrations, rescale, recomposition, exp).
+template <>
+struct ApplyCtx<TIA_MATH_F64> {
+    double p[6], sc[2], st[6];
+    const double* lut;
+    __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, double (&o)[3]) const {
+        const double x = lut[r], y = lut[g], z = lut[b];
+        double c0 = x * p[0] + y * p[2] + z * p[4];
+        double c1 = x * p[1] + y * p[3] + z * p[5];
+        c0 *= sc[0];
+        c1 *= sc[1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double t = c0 * st[c] + c1 * st[3 + c];
+            double v = 255.0 * exp(-1.0 * t);
+            v = v > 255.0 ? 255.0 : v;
+            v = v < 0.0 ? 0.0 : v;
+            o[c] = v;
+        }
+    }
+};
+
+template <int MATH, int OUT>
+__global__ __launch_bounds__(AT) void stain_apply_kernel(const uint8_t* __restrict__ img, long hw,
+                                                          const tia_stain_tables* __restrict__ tab,
+                                                          const double* __restrict__ stats, StainT tgt,
+                                                          void* __restrict__ out_v) {
+    using O = Out<OUT>;
+    using T = typename O::T;
+    using F = typename std::conditional<MATH == TIA_MATH_F32, float, double>::type;
+    constexpr int LUTN = (MATH == TIA_MATH_F32) ? 256 * 32 : 256;
+    __shared__ F lut[LUTN];
+
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    ApplyCtx<MATH> ctx;
+    if constexpr (MATH == TIA_MATH_F32) {
+        for (int i = threadIdx.x; i < LUTN; i += AT) lut[i] = tab->od_lut_f32[i >> 5];
+        const double nl2e = -1.4426950408889634;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ctx.m[i] = (float)(st[TIA_ST_M + i] * nl2e);
+        ctx.lut = lut;
+        ctx.bank = threadIdx.x & 31;
+    } else {
+        for (int i = threadIdx.x; i < LUTN; i += AT) lut[i] = tab->od_lut[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            ctx.p[i] = st[TIA_ST_PINV + i];
+            ctx.st[i] = tgt.s[i];
+        }
+        ctx.sc[0] = st[TIA_ST_SCALE + 0];
+        ctx.sc[1] = st[TIA_ST_SCALE + 1];
+        ctx.lut = lut;
+    }
+    __syncthreads();
+
+    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
+    T* dst = reinterpret_cast<T*>(out_v) + (size_t)patch * (size_t)hw * 3u;
+
+    if ((hw & 3) == 0) {
+        const long ng = hw >> 2;
+        const long stride = (long)gridDim.x * AT;
+#pragma unroll 2
+        for (long g = (long)blockIdx.x * AT + threadIdx.x; g < ng; g += stride) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(src + g * 12);
+            const uint32_t a = q[0], b = q[1], c = q[2];
+            F o[4][3];
+            ctx.pixel(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u, o[0]);
+            ctx.pixel(a >> 24, b & 255u, (b >> 8) & 255u, o[1]);
+            ctx.pixel((b >> 16) & 255u, b >> 24, c & 255u, o[2]);
+            ctx.pixel((c >> 8) & 255u, (c >> 16) & 255u, c >> 24, o[3]);
+            Pack12<T> pk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) pk.v[i * 3 + ch] = O::cvt(o[i][ch]);
+            store12<T>(dst + g * 12, pk);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * AT + threadIdx.x; i < hw; i += (long)gridDim.x * AT) {
+            F o[3];
+            ctx.pixel(src[3 * i], src[3 * i + 1], src[3 * i + 2], o);
+            dst[3 * i + 0] = O::cvt(o[0]);
+            dst[3 * i + 1] = O::cvt(o[1]);
+            dst[3 * i + 2] = O::cvt(o[2]);
+        }
+    }
+}
+
+// ---- concentrations ------------------------------------------------------------------------------
+__global__ __launch_bounds__(AT) void stain_conc_kernel(const uint8_t* __restrict__ img, long hw,
+                                                         const tia_stain_tables* __restrict__ tab,
+                                                         const double* __restrict__ stats,
+                                                         double* __restrict__ conc) {
+    __shared__ double lut[256];
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    for (int i = threadIdx.x; i < 256; i += AT) lut[i] = tab->od_lut[i];
+    double p[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p[i] = st[TIA_ST_PINV + i];
+    __syncthreads();
+    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
+    double2* dst = reinterpret_cast<double2*>(conc) + (size_t)patch * (size_t)hw;
+    for (long i = (long)blockIdx.x * AT + threadIdx.x; i < hw; i += (long)gridDim.x * AT) {
+        const double x = lut[src[3 * i]], y = lut[src[3 * i + 1]], z = lut[src[3 * i + 2]];
+        double2 c;
+        c.x = x * p[0] + y * p[2] + z * p[4];
+        c.y = x * p[1] + y * p[3] + z * p[5];
+        dst[i] = c;
+    }
+}
+
+// ---- augment + luminosity mask ----------------------------------------------------------------------
+template <bool MASK_ONLY>
+__global__ __launch_bounds__(AT) void stain_augment_kernel(const uint8_t* __restrict__ img, long hw,
+                                                            const tia_stain_tables* __restrict__ tab,
+                                                            const double* __restrict__ stats,
+                                                            const double* __restrict__ alpha_beta,
+                                                            int y_thr, int augment_background, int z1,
+                                                            uint8_t* __restrict__ out) {
+    __shared__ double lut[256];
+    __shared__ int ty[3][256];
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    for (int i = threadIdx.x; i < 256; i += AT) lut[i] = tab->od_lut[i];
+    build_ty(ty, tab, st[TIA_ST_PLOW], st[TIA_ST_PHIGH], z1 != 0);
+    double p[6], sm[6], al[2] = {1.0, 1.0}, be[2] = {0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        p[i] = st[TIA_ST_PINV + i];
+        sm[i] = st[TIA_ST_STAIN + i];
+    }
+    if (!MASK_ONLY) {
+        al[0] = alpha_beta[patch * 4 + 0];
+        al[1] = alpha_beta[patch * 4 + 1];
+        be[0] = alpha_beta[patch * 4 + 2];
+        be[1] = alpha_beta[patch * 4 + 3];
+    }
+    __syncthreads();
+    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
+    for (long i = (long)blockIdx.x * AT + threadIdx.x; i < hw; i += (long)gridDim.x * AT) {
+        const uint32_t r = src[3 * i], g = src[3 * i + 1], b = src[3 * i + 2];
+        const int t = ty[0][r] + ty[1][g] + ty[2][b];
+        const bool tissue = ((t + (1 << 11)) >> 12) < y_thr;
+        if (MASK_ONLY) {
+            out[(size_t)patch * (size_t)hw + i] = tissue ? 1 : 0;
+        } else {
+            const double x = lut[r], y = lut[g], z = lut[b];
+            double c0 = x * p[0] + y * p[2] + z * p[4];
+            double c1 = x * p[1] + y * p[3] + z * p[5];
+            if (tissue || augment_background) {
+                c0 *= al[0];
+                c0 += be[0];
+                c1 *= al[1];
+                c1 += be[1];
+            }
+            uint8_t* d = out + ((size_t)patch * (size_t)hw + i) * 3u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double tt = c0 * sm[c] + c1 * sm[3 + c];
+                double v = 255.0 * exp(-1.0 * tt);
+                v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);  // np.clip(., 0, 255)
+                d[c] = (uint8_t)(unsigned)v;
+            }
+        }
+    }
+}
+
+static inline unsigned blocks_x(long work_items, long n_patches) {
+    // enough workgroups to fill 256 CUs several times over, but few per patch when the batch is
+    // large so the per-block table set-up is amortised.
+    long per_block = (long)AT * 4;
+    long maxb = (work_items + per_block - 1) / per_block;
+    long want = (4096 + n_patches - 1) / n_patches;
+    long b = want < maxb ? want : maxb;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+template <int MATH>
+static int launch_apply(const uint8_t* d_img, int64_t n, long hw, const tia_stain_tables* tab,
+                        const double* stats, const StainT& tgt, void* out, int out_kind,
+                        hipStream_t stream) {
+    const long ng = (hw & 3) == 0 ? (hw >> 2) : hw;
+    dim3 grid(blocks_x(ng, n), (unsigned)n);
+#define TIA_LAUNCH(OUTK)                                                                              \
+    case OUTK:                                                                                        \
+        hipLaunchKernelGGL((stain_apply_kernel<MATH, OUTK>), grid, dim3(AT), 0, stream, d_img, hw,   \
+                           tab, stats, tgt, out);                                                     \
+        break;
+    switch (out_kind) {
+        TIA_LAUNCH(TIA_OUT_U8)
+        TIA_LAUNCH(TIA_OUT_F32)
+        TIA_LAUNCH(TIA_OUT_F64)
+        TIA_LAUNCH(TIA_OUT_UNIT_F16)
+        TIA_LAUNCH(TIA_OUT_UNIT_BF16)
+        TIA_LAUNCH(TIA_OUT_UNIT_F32)
+        default:
+            return TIA_EINVAL;
+    }
+#undef TIA_LAUNCH
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+}  // namespace tia
+
+static bool bad_dims(int64_t n, int64_t h, int64_t w) {
+    return n <= 0 || h <= 0 || w <= 0 || n > 65535;
+}
+
+extern "C" int tia_abi_version(void) { return TIA_ABI_VERSION; }
+
+extern "C" int tia_stain_apply_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
+                                   const tia_stain_tables* d_tables, const double* d_stats,
+                                   const double* target_stain, void* d_out, int32_t out_kind,
+                                   int32_t math, void* stream) {
+    if (!d_img || !d_tables || !d_stats || !d_out) return TIA_EINVAL;
+    if (bad_dims(n, h, w)) return n > 65535 ? TIA_ESIZE : TIA_EINVAL;
+    tia::StainT tgt{};
+    if (math == TIA_MATH_F64) {
+        if (!target_stain) return TIA_EINVAL;
+        for (int i = 0; i < 6; ++i) tgt.s[i] = target_stain[i];
+        return tia::launch_apply<TIA_MATH_F64>(d_img, n, (long)h * w, d_tables, d_stats, tgt, d_out,
+                                               out_kind, (hipStream_t)stream);
+    }
+    if (math == TIA_MATH_F32)
+        return tia::launch_apply<TIA_MATH_F32>(d_img, n, (long)h * w, d_tables, d_stats, tgt, d_out,
+                                               out_kind, (hipStream_t)stream);
+    return TIA_EINVAL;
+}
+
+extern "C" int tia_stain_concentrations_f64(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
+                                             const tia_stain_tables* d_tables, const double* d_stats,
+                                             double* d_conc, void* stream) {
+    if (!d_img || !d_tables || !d_stats || !d_conc) return TIA_EINVAL;
+    if (bad_dims(n, h, w)) return n > 65535 ? TIA_ESIZE : TIA_EINVAL;
+    const long hw = (long)h * w;
+    dim3 grid(tia::blocks_x(hw, n), (unsigned)n);
+    hipLaunchKernelGGL(tia::stain_conc_kernel, grid, dim3(tia::AT), 0, (hipStream_t)stream, d_img, hw,
+                       d_tables, d_stats, d_conc);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_stain_augment_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
+                                     const tia_stain_tables* d_tables, const double* d_stats,
+                                     const double* d_alpha_beta, int32_t y_thr,
+                                     int32_t augment_background, int32_t zero_to_one, uint8_t* d_out,
+                                     void* stream) {
+    if (!d_img || !d_tables || !d_stats || !d_alpha_beta || !d_out) return TIA_EINVAL;
+    if (bad_dims(n, h, w)) return n > 65535 ? TIA_ESIZE : TIA_EINVAL;
+    const long hw = (long)h * w;
+    dim3 grid(tia::blocks_x(hw, n), (unsigned)n);
+    hipLaunchKernelGGL((tia::stain_augment_kernel<false>), grid, dim3(tia::AT), 0, (hipStream_t)stream,
+                       d_img, hw, d_tables, d_stats, d_alpha_beta, y_thr, augment_background,
+                       zero_to_one, d_out);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_luminosity_mask_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
+                                       const tia_stain_tables* d_tables, const double* d_stats,
+                                       int32_t y_thr, int32_t zero_to_one, uint8_t* d_mask,
+                                       void* stream) {
+    if (!d_img || !d_tables || !d_stats || !d_mask) return TIA_EINVAL;
+    if (bad_dims(n, h, w)) return n > 65535 ? TIA_ESIZE : TIA_EINVAL;
+    const long hw = (long)h * w;
+    dim3 grid(tia::blocks_x(hw, n), (unsigned)n);
+    hipLaunchKernelGGL((tia::stain_augment_kernel<true>), grid, dim3(tia::AT), 0, (hipStream_t)stream,
+                       d_img, hw, d_tables, d_stats, (const double*)nullptr, y_thr, 0, zero_to_one,
+                       d_mask);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}

@@ -1,0 +1,671 @@
+// Per-patch stain statistics on gfx950: one 1024-thread workgroup per patch, all per-patch
+// state in LDS, per-patch statistics in f64.  See include/tiatoolbox_amd.h for the contract
+// and DESIGN.md ("stain_stats") for the pass structure:
+//   P1 byte histogram -> contrast-enhancer percentiles -> folded luminance tables
+//   P2 tissue mask + OD moments (f64) -> covariance -> 3x3 eigen-decomposition
+//   P3/P4 exact angular percentiles (histogram refine + LDS bitonic select)
+//   P5/P6 exact 99th percentile of both stain concentrations
+// Reference: tools/stainextract.py:177-227, tools/stainnorm.py:49-66,81-85,103,
+//            utils/misc.py:261-290,405-444, utils/transforms.py:209-231.
+#include "common.hpp"
+
+// numpy evaluates these expressions without fused multiply-add; keep the per-patch
+// statistics free of contraction so table entries / lerps round exactly as the reference.
+#pragma clang fp contract(off)
+
+namespace tia {
+
+constexpr int NT = 512;          // threads per workgroup (8 waves, 2 per SIMD: 256 VGPRs each)
+constexpr int NW = NT / 64;
+constexpr int NB = 8192;         // histogram bins per selection target per level
+constexpr int CAP = 2048;        // candidates sorted in LDS
+constexpr int MAXLEVEL = 6;      // 8192^5 > 2^64: deeper levels cannot split an f64 range further
+constexpr int BPT = NB / NT;     // bins per thread in the scan
+
+struct SelState {
+    double lo[2][MAXLEVEL + 1];
+    double scale[2][MAXLEVEL + 1];
+    int sel[2][MAXLEVEL + 1];
+    int level[2];
+    int collapsed[2];
+    int need_hist[2];
+    unsigned long long r[2];
+    unsigned long long cnt[2];
+    unsigned ncand[2];
+    unsigned long long above_key[2];
+    unsigned long long member_key[2];
+};
+
+struct Smem {
+    double od[256];
+    int ty[3][256];
+    unsigned hist[256];
+    unsigned cum[256];
+    unsigned bins[2][NB];
+    double cand[2][CAP];
+    double red[NW][12];
+    unsigned wtot[NW];
+    SelState st;
+    double bc[40];
+    unsigned long long ubc[8];
+    int ibc[8];
+};
+
+// ---------------------------------------------------------------------------------------
+// block-wide helpers (all threads must call)
+// ---------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], Smem& s) {
+    static_assert(N <= 12, "reduction scratch too small");
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double w = wave_sum(v[i]);
+        if (lane_id() == 0) s.red[wave_id()][i] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+        for (int w = 0; w < NW; ++w) acc += s.red[w][i];  // fixed order: deterministic
+        v[i] = acc;
+    }
+    __syncthreads();
+}
+
+// numpy's _lerp (numpy/lib/_function_base_impl.py): a + (b-a)*t, or b - (b-a)*(1-t) for t>=0.5
+__device__ __forceinline__ double np_lerp(double a, double b, double t) {
+    const double d = b - a;
+    return (t >= 0.5) ? (b - d * (1.0 - t)) : (a + d * t);
+}
+
+// numpy 'linear' percentile index: vi=(n-1)*q; prev=floor(vi), next=prev+1 (clamped), gamma
+__device__ __forceinline__ void np_index(unsigned long long n, double q, unsigned long long& prev,
+                                         unsigned long long& next, double& gamma) {
+    const double vi = (double)(n - 1) * q;
+    if (vi >= (double)(n - 1)) {
+        // numpy (_get_indexes): both neighbours become the last element, so the lerp weight is moot
+        prev = next = n - 1;
+        gamma = 0.0;
+        return;
+    }
+    const double fl = floor(vi);
+    prev = (unsigned long long)fl;
+    next = prev + 1;
+    gamma = vi - fl;
+}
+
+__device__ __forceinline__ int bin_of(double x, double lo, double scale) {
+    const double d = (x - lo) * scale;
+    if (!(d >= 0.0)) return 0;
+    if (d >= (double)NB) return NB - 1;
+    return (int)d;
+}
+
+// Find the bin holding 0-based rank r in bins[NB]; thread that owns it publishes
+// (bin, rank-within-bin, bin count) through ibc/ubc.  All threads call; result visible after return.
+__device__ __forceinline__ void find_bin(const unsigned* __restrict__ bins, unsigned long long r,
+                                         Smem& s, int slot) {
+    unsigned local[BPT];
+    unsigned sum = 0;
+    const int base = threadIdx.x * BPT;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+        local[i] = bins[base + i];
+        sum += local[i];
+    }
+    unsigned incl = wave_incl_scan_u32(sum);
+    if (lane_id() == 63) s.wtot[wave_id()] = incl;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (int w = 0; w < wave_id(); ++w) before += s.wtot[w];
+    before += incl - sum;
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+        if (r >= before && r < before + local[i]) {
+            s.ibc[slot] = base + i;
+            s.ubc[slot * 2 + 0] = r - before;
+            s.ubc[slot * 2 + 1] = local[i];
+        }
+        before += local[i];
+    }
+    __syncthreads();
+}
+
+// Exact order statistics sorted[k] and sorted[k+1] (k+1 clamped to n-1) for up to two targets in
+// one sweep family.  `valf(idx,r,g,b,x)` returns a 2-bit validity mask and fills x[0], x[1].
+// Multi-level linear-histogram refinement over pixel passes until the bin holding rank k has
+// <= CAP members, then one collect pass + an LDS bitonic sort.  Everything is exact: the bin
+// function is monotone in x, so bins partition the sorted order.
+template <class VF>
+__device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem& s,
+                        const unsigned long long (&k)[2], const unsigned long long (&n)[2],
+                        const double (&lo0)[2], const double (&hi0)[2], bool shared_values,
+                        double (&vprev)[2], double (&vnext)[2]) {
+    SelState& st = s.st;
+    if (threadIdx.x < 2) {
+        const int t = threadIdx.x;
+        st.level[t] = 0;
+        st.cnt[t] = n[t];
+        st.r[t] = k[t];
+        st.lo[t][0] = lo0[t];
+        const double sc = (double)NB / (hi0[t] - lo0[t]);
+        const bool ok = (hi0[t] > lo0[t]) && (sc > 0.0) && (sc < 1.0e300);
+        st.scale[t][0] = ok ? sc : 0.0;
+        st.collapsed[t] = ok ? 0 : 1;
+    }
+    __syncthreads();
+
+    for (int iter = 0; iter < MAXLEVEL; ++iter) {
+        if (threadIdx.x < 2) {
+            const int t = threadIdx.x;
+            st.need_hist[t] = (st.cnt[t] > (unsigned long long)CAP && !st.collapsed[t] &&
+                               st.level[t] < MAXLEVEL) ? 1 : 0;
+        }
+        __syncthreads();
+        const int nh0 = st.need_hist[0], nh1 = st.need_hist[1];
+        if (!nh0 && !nh1) break;
+        const int lv0 = st.level[0], lv1 = st.level[1];
+        // one shared histogram while both targets still see the same values and the same binning
+        const bool shared = shared_values && nh0 && nh1 && lv0 == 0 && lv1 == 0;
+        for (int i = threadIdx.x; i < NB; i += NT) {
+            s.bins[0][i] = 0;
+            s.bins[1][i] = 0;
+        }
+        __syncthreads();
+        for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+            double x[2];
+            const unsigned vm = valf(idx, r, g, b, x);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int nh = t ? nh1 : nh0;
+                const int lv = t ? lv1 : lv0;
+                if (!nh || !((vm >> t) & 1u)) continue;
+                if (shared && t == 1) continue;
+                bool member = true;
+                for (int l = 0; l < lv; ++l) {
+                    if (bin_of(x[t], st.lo[t][l], st.scale[t][l]) != st.sel[t][l]) {
+                        member = false;
+                        break;
+                    }
+                }
+                if (member) atomicAdd(&s.bins[t][bin_of(x[t], st.lo[t][lv], st.scale[t][lv])], 1u);
+            }
+        });
+        __syncthreads();
+        for (int t = 0; t < 2; ++t) {
+            if (!(t ? nh1 : nh0)) continue;
+            const unsigned* hb = (shared && t == 1) ? s.bins[0] : s.bins[t];
+            find_bin(hb, st.r[t], s, t);
+            if (threadIdx.x == 0) {
+                const int lv = st.level[t];
+                const int b = s.ibc[t];
+                st.sel[t][lv] = b;
+                st.r[t] = s.ubc[t * 2 + 0];
+                st.cnt[t] = s.ubc[t * 2 + 1];
+                const double lo = st.lo[t][lv], sc = st.scale[t][lv];
+                const double nlo = lo + (double)b / sc;
+                const double nhi = lo + (double)(b + 1) / sc;
+                const double nsc = (double)NB / (nhi - nlo);
+                const bool ok = (nhi > nlo) && (nsc > 0.0) && (nsc < 1.0e300);
+                st.lo[t][lv + 1] = nlo;
+                st.scale[t][lv + 1] = ok ? nsc : 0.0;
+                if (!ok) st.collapsed[t] = 1;
+                st.level[t] = lv + 1;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- collect pass ------------------------------------------------------------------
+    if (threadIdx.x < 2) {
+        const int t = threadIdx.x;
+        st.ncand[t] = 0;
+        st.above_key[t] = ~0ull;
+        st.member_key[t] = ~0ull;
+    }
+    __syncthreads();
+    {
+        const int lv[2] = {st.level[0], st.level[1]};
+        const bool store[2] = {st.cnt[0] <= (unsigned long long)CAP, st.cnt[1] <= (unsigned long long)CAP};
+        unsigned long long amin[2] = {~0ull, ~0ull}, mmin[2] = {~0ull, ~0ull};
+        for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+            double x[2];
+            const unsigned vm = valf(idx, r, g, b, x);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (!((vm >> t) & 1u)) continue;
+                int cls = 0;  // 0 member, 1 above, -1 below
+                for (int l = 0; l < lv[t]; ++l) {
+                    const int bb = bin_of(x[t], st.lo[t][l], st.scale[t][l]);
+                    if (bb != st.sel[t][l]) {
+                        cls = bb > st.sel[t][l] ? 1 : -1;
+                        break;
+                    }
+                }
+                const unsigned long long key = f64_key(x[t]);
+                if (cls == 0) {
+                    mmin[t] = key < mmin[t] ? key : mmin[t];
+                    if (store[t]) {
+                        const unsigned pos = atomicAdd(&st.ncand[t], 1u);
+                        if (pos < (unsigned)CAP) s.cand[t][pos] = x[t];
+                    }
+                } else if (cls > 0) {
+                    amin[t] = key < amin[t] ? key : amin[t];
+                }
+            }
+        });
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned long long a = wave_min_u64(amin[t]);
+            const unsigned long long m = wave_min_u64(mmin[t]);
+            if (lane_id() == 0) {
+                atomicMin(&st.above_key[t], a);
+                atomicMin(&st.member_key[t], m);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- sort candidates (both targets at once) and pick -----------------------------------
+    unsigned pmax = 2;
+    for (int t = 0; t < 2; ++t) {
+        if (st.cnt[t] <= (unsigned long long)CAP) {
+            unsigned c = (unsigned)st.cnt[t];
+            unsigned pp = 2;
+            while (pp < c) pp <<= 1;
+            pmax = pp > pmax ? pp : pmax;
+        }
+    }
+    for (int t = 0; t < 2; ++t) {
+        if (st.cnt[t] <= (unsigned long long)CAP) {
+            for (unsigned i = (unsigned)st.cnt[t] + threadIdx.x; i < pmax; i += NT)
+                s.cand[t][i] = __longlong_as_double(0x7ff0000000000000ll);  // +inf padding
+        }
+    }
+    __syncthreads();
+    for (unsigned kk = 2; kk <= pmax; kk <<= 1) {
+        for (unsigned j = kk >> 1; j > 0; j >>= 1) {
+            for (unsigned i = threadIdx.x; i < pmax; i += NT) {
+                const unsigned partner = i ^ j;
+                if (partner > i) {
+                    const bool asc = (i & kk) == 0;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        if (st.cnt[t] > (unsigned long long)CAP) continue;
+                        const double a = s.cand[t][i], b = s.cand[t][partner];
+                        if ((a > b) == asc) {
+                            s.cand[t][i] = b;
+                            s.cand[t][partner] = a;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (n[t] == 0) {
+            vprev[t] = vnext[t] = 0.0;
+            continue;
+        }
+        const unsigned long long r = st.r[t], c = st.cnt[t];
+        const bool has_next = (k[t] + 1 < n[t]);
+        const double above = key_f64(st.above_key[t]);
+        if (c <= (unsigned long long)CAP) {
+            vprev[t] = s.cand[t][r];
+            vnext[t] = !has_next ? vprev[t] : ((r + 1 < c) ? s.cand[t][r + 1] : above);
+        } else {
+            const double m = key_f64(st.member_key[t]);  // collapsed range: members identical
+            vprev[t] = m;
+            vnext[t] = !has_next ? m : ((r + 1 < c) ? m : above);
+        }
+    }
+    __syncthreads();
+}
+
+// 3x3 symmetric eigen-decomposition (cyclic Jacobi, f64).  a = xx,xy,xz,yy,yz,zz.
+// Outputs eigenvalues w[3] (unsorted) and eigenvectors as columns of v[3][3].
+__device__ void jacobi3(const double (&a6)[6], double (&w)[3], double (&v)[3][3]) {
+    double a[3][3] = {{a6[0], a6[1], a6[2]}, {a6[1], a6[3], a6[4]}, {a6[2], a6[4], a6[5]}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+        if (off <= 1e-300 || off <= 1e-22 * diag) break;
+        for (int p = 0; p < 2; ++p) {
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = a[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0);
+                const double sn = t * c;
+                const double app = a[p][p], aqq = a[q][q];
+                a[p][p] = app - t * apq;
+                a[q][q] = aqq + t * apq;
+                a[p][q] = a[q][p] = 0.0;
+                const int r = 3 - p - q;
+                const double arp = a[r][p], arq = a[r][q];
+                a[r][p] = a[p][r] = c * arp - sn * arq;
+                a[r][q] = a[q][r] = sn * arp + c * arq;
+                for (int i = 0; i < 3; ++i) {
+                    const double vip = v[i][p], viq = v[i][q];
+                    v[i][p] = c * vip - sn * viq;
+                    v[i][q] = sn * vip + c * viq;
+                }
+            }
+        }
+    }
+    w[0] = a[0][0];
+    w[1] = a[1][1];
+    w[2] = a[2][2];
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restrict__ img, long hw,
+                                                          const tia_stain_tables* __restrict__ tab,
+                                                          tia_stain_params prm,
+                                                          double* __restrict__ stats) {
+    __shared__ Smem s;
+    const uint8_t* p = img + (size_t)blockIdx.x * (size_t)hw * 3u;
+    double* out = stats + (size_t)blockIdx.x * TIA_STATS_STRIDE;
+    const int tid = threadIdx.x;
+    const bool z1 = prm.zero_to_one != 0;
+
+    if (tid < TIA_STATS_STRIDE) out[tid] = 0.0;
+    if (tid < 256) s.od[tid] = tab->od_lut[tid];
+
+    // ---- P1: histogram of all bytes (per-wave private copies in the bins area) ---------------
+    unsigned* wh = &s.bins[0][0] + wave_id() * 256;
+    for (int i = tid; i < NW * 256; i += NT) (&s.bins[0][0])[i] = 0;
+    __syncthreads();
+    for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
+        if (z1) {
+            r = r ? r : 1u;
+            g = g ? g : 1u;
+            b = b ? b : 1u;
+        }
+        atomicAdd(&wh[r], 1u);
+        atomicAdd(&wh[g], 1u);
+        atomicAdd(&wh[b], 1u);
+    });
+    __syncthreads();
+    if (tid < 256) {
+        unsigned h = 0;
+        for (int w = 0; w < NW; ++w) h += (&s.bins[0][0])[w * 256 + tid];
+        s.hist[tid] = h;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        unsigned c = 0;
+        for (int i = 0; i <= tid; ++i) c += s.hist[i];
+        s.cum[tid] = c;
+    }
+    __syncthreads();
+    {
+        const unsigned long long nbytes = (unsigned long long)hw * 3ull;
+        unsigned long long kp[2], kn[2];
+        double gm[2];
+        np_index(nbytes, prm.q_img_lo, kp[0], kn[0], gm[0]);
+        np_index(nbytes, prm.q_img_hi, kp[1], kn[1], gm[1]);
+        if (tid < 256) {
+            const unsigned long long c1 = s.cum[tid], c0 = tid ? s.cum[tid - 1] : 0;
+            if (c0 <= kp[0] && kp[0] < c1) s.ibc[0] = tid;
+            if (c0 <= kn[0] && kn[0] < c1) s.ibc[1] = tid;
+            if (c0 <= kp[1] && kp[1] < c1) s.ibc[2] = tid;
+            if (c0 <= kn[1] && kn[1] < c1) s.ibc[3] = tid;
+            if (c0 == 0 && c1 > 0) s.ibc[4] = tid;                                 // min byte
+            if (c1 == (unsigned)nbytes && c0 < (unsigned)nbytes) s.ibc[5] = tid;  // max byte
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // uint8 subtraction b-a is non-negative here (sorted), so no wrap-around to mimic
+            double plow = np_lerp((double)s.ibc[0], (double)s.ibc[1], gm[0]);
+            double phigh = np_lerp((double)s.ibc[2], (double)s.ibc[3], gm[1]);
+            if (plow >= phigh) {
+                plow = (double)s.ibc[4];
+                phigh = (double)s.ibc[5];
+            }
+            s.bc[0] = plow;
+            s.bc[1] = phigh;
+            out[TIA_ST_PLOW] = plow;
+            out[TIA_ST_PHIGH] = phigh;
+        }
+        __syncthreads();
+    }
+    const int bmin = s.ibc[4], bmax = s.ibc[5];
+    if (tid < 256) {
+        // contrast_enhancer LUT (utils/misc.py:438-444 + skimage rescale_intensity), folded into
+        // the Y-row luminance tables: ty[c][v] = C[3+c]*sRGBGamma[ce(v)]
+        const double plow = s.bc[0], phigh = s.bc[1];
+        int v = tid;
+        if (z1 && v == 0) v = 1;
+        int ce = v;
+        if (phigh > plow) {
+            double x = (double)v;
+            x = x < plow ? plow : (x > phigh ? phigh : x);
+            x = (x - plow) / (phigh - plow);
+            x = x * 255.0 + 0.0;
+            ce = (int)x;
+        }
+        s.ty[0][tid] = tab->ty[0][ce];
+        s.ty[1][tid] = tab->ty[1][ce];
+        s.ty[2][tid] = tab->ty[2][ce];
+    }
+    __syncthreads();
+
+    const int y_thr = prm.y_thr;
+    auto is_tissue = [&](uint32_t r, uint32_t g, uint32_t b) -> bool {
+        const int t = s.ty[0][r] + s.ty[1][g] + s.ty[2][b];
+        return ((t + (1 << 11)) >> 12) < y_thr;
+    };
+
+    double S[6];  // source stain matrix rows H,E
+    unsigned flags = 0;
+
+    if (prm.mode == TIA_MODE_MACENKO) {
+        // ---- P2: tissue mask + OD moments -----------------------------------------------------
+        double acc[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i] = 0.0;
+        for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
+            if (is_tissue(r, g, b)) {
+                const double x = s.od[r], y = s.od[g], z = s.od[b];
+                acc[0] += 1.0;
+                acc[1] += x;
+                acc[2] += y;
+                acc[3] += z;
+                acc[4] += x * x;
+                acc[5] += x * y;
+                acc[6] += x * z;
+                acc[7] += y * y;
+                acc[8] += y * z;
+                acc[9] += z * z;
+            }
+        });
+        block_sum(acc, s);
+        const double nt = acc[0];
+        const unsigned long long n_tissue = (unsigned long long)nt;
+        if (n_tissue == 0) {
+            if (tid == 0) {
+                out[TIA_ST_NTISSUE] = 0.0;
+                out[TIA_ST_FLAGS] = (double)TIA_FLAG_EMPTY_MASK;
+            }
+            return;  // uniform across the block
+        }
+        if (n_tissue < 2) flags |= TIA_FLAG_DEGENERATE;
+        if (tid == 0) {
+            const double mx = acc[1] / nt, my = acc[2] / nt, mz = acc[3] / nt;
+            const double f = 1.0 / (nt - 1.0);
+            double cov[6];
+            cov[0] = (acc[4] - nt * mx * mx) * f;
+            cov[1] = (acc[5] - nt * mx * my) * f;
+            cov[2] = (acc[6] - nt * mx * mz) * f;
+            cov[3] = (acc[7] - nt * my * my) * f;
+            cov[4] = (acc[8] - nt * my * mz) * f;
+            cov[5] = (acc[9] - nt * mz * mz) * f;
+            double w[3], v[3][3];
+            jacobi3(cov, w, v);
+            // eigh: ascending eigenvalues; reference takes columns [2,1] = largest, 2nd largest
+            int i0 = 0, i1 = 1, i2 = 2;
+            if (w[i0] < w[i1]) { int t = i0; i0 = i1; i1 = t; }
+            if (w[i0] < w[i2]) { int t = i0; i0 = i2; i2 = t; }
+            if (w[i1] < w[i2]) { int t = i1; i1 = i2; i2 = t; }
+            double e1[3] = {v[0][i0], v[1][i0], v[2][i0]};
+            double e2[3] = {v[0][i1], v[1][i1], v[2][i1]};
+            if (e1[0] < 0) { e1[0] = -e1[0]; e1[1] = -e1[1]; e1[2] = -e1[2]; }
+            if (e2[0] < 0) { e2[0] = -e2[0]; e2[1] = -e2[1]; e2[2] = -e2[2]; }
+            for (int i = 0; i < 6; ++i) out[TIA_ST_COV + i] = cov[i];
+            for (int i = 0; i < 3; ++i) {
+                s.bc[2 + i] = e1[i];
+                s.bc[5 + i] = e2[i];
+                out[TIA_ST_EVEC + i] = e1[i];
+                out[TIA_ST_EVEC + 3 + i] = e2[i];
+            }
+            out[TIA_ST_NTISSUE] = nt;
+        }
+        __syncthreads();
+        const double e1x = s.bc[2], e1y = s.bc[3], e1z = s.bc[4];
+        const double e2x = s.bc[5], e2y = s.bc[6], e2z = s.bc[7];
+
+        // ---- P3/P4: exact percentiles of phi = atan2(od.e2, od.e1) over tissue pixels ------------
+        unsigned long long kp[2], kn[2], nn[2] = {n_tissue, n_tissue};
+        double gm[2];
+        np_index(n_tissue, prm.q_phi_lo, kp[0], kn[0], gm[0]);
+        np_index(n_tissue, prm.q_phi_hi, kp[1], kn[1], gm[1]);
+        const double lo0[2] = {-3.2, -3.2}, hi0[2] = {3.2, 3.2};
+        double vp[2], vn[2];
+        select2(p, hw,
+                [&](long, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
+                    if (!is_tissue(r, g, b)) return 0u;
+                    const double ox = s.od[r], oy = s.od[g], oz = s.od[b];
+                    const double p0 = ox * e1x + oy * e1y + oz * e1z;
+                    const double p1 = ox * e2x + oy * e2y + oz * e2z;
+                    x[0] = x[1] = atan2(p1, p0);
+                    return 3u;
+                },
+                s, kp, nn, lo0, hi0, true, vp, vn);
+        if (tid == 0) {
+            const double min_phi = np_lerp(vp[0], vn[0], gm[0]);
+            const double max_phi = np_lerp(vp[1], vn[1], gm[1]);
+            out[TIA_ST_MINPHI] = min_phi;
+            out[TIA_ST_MAXPHI] = max_phi;
+            const double c1 = cos(min_phi), s1 = sin(min_phi), c2 = cos(max_phi), s2 = sin(max_phi);
+            double v1[3] = {e1x * c1 + e2x * s1, e1y * c1 + e2y * s1, e1z * c1 + e2z * s1};
+            double v2[3] = {e1x * c2 + e2x * s2, e1y * c2 + e2y * s2, e1z * c2 + e2z * s2};
+            const bool first = v1[0] > v2[0];
+            const double* h = first ? v1 : v2;
+            const double* e = first ? v2 : v1;
+            const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+            const double ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+            for (int i = 0; i < 3; ++i) {
+                s.bc[8 + i] = h[i] / nh;
+                s.bc[11 + i] = e[i] / ne;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) S[i] = s.bc[8 + i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) S[i] = prm.stain_fixed[i];
+    }
+
+    // ---- pseudo-inverse: C = OD . P,  P = S^T (S S^T)^-1  (lstsq of stainnorm.py:65) ----------
+    double P[6];
+    {
+        const double a = S[0] * S[0] + S[1] * S[1] + S[2] * S[2];
+        const double bb = S[0] * S[3] + S[1] * S[4] + S[2] * S[5];
+        const double d = S[3] * S[3] + S[4] * S[4] + S[5] * S[5];
+        const double det = a * d - bb * bb;
+        const double g00 = d / det, g01 = -bb / det, g11 = a / det;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            P[j * 2 + 0] = S[j] * g00 + S[3 + j] * g01;
+            P[j * 2 + 1] = S[j] * g01 + S[3 + j] * g11;
+        }
+    }
+
+    // ---- P5/P6: exact percentile of both concentration channels over ALL pixels ----------------
+    double maxc[2];
+    {
+        const unsigned long long npx = (unsigned long long)hw;
+        unsigned long long kp[2], kn[2], nn[2] = {npx, npx};
+        double gm[2];
+        np_index(npx, prm.q_conc, kp[0], kn[0], gm[0]);
+        kp[1] = kp[0];
+        kn[1] = kn[0];
+        gm[1] = gm[0];
+        // rigorous value bounds from the byte range: od in [od(bmax), od(bmin)]
+        const double oa = s.od[bmax], ob = s.od[bmin];
+        double lo0[2], hi0[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            double lo = 0.0, hi = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double c = P[j * 2 + t];
+                const double u = c * oa, w = c * ob;
+                lo += u < w ? u : w;
+                hi += u < w ? w : u;
+            }
+            const double pad = 1e-9 * (fabs(lo) + fabs(hi)) + 1e-12;
+            lo0[t] = lo - pad;
+            hi0[t] = hi + pad;
+        }
+        double vp[2], vn[2];
+        select2(p, hw,
+                [&](long, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
+                    const double ox = s.od[r], oy = s.od[g], oz = s.od[b];
+                    x[0] = ox * P[0] + oy * P[2] + oz * P[4];
+                    x[1] = ox * P[1] + oy * P[3] + oz * P[5];
+                    return 3u;
+                },
+                s, kp, nn, lo0, hi0, false, vp, vn);
+        maxc[0] = np_lerp(vp[0], vn[0], gm[0]);
+        maxc[1] = np_lerp(vp[1], vn[1], gm[1]);
+    }
+
+    if (tid == 0) {
+        for (int i = 0; i < 6; ++i) {
+            out[TIA_ST_STAIN + i] = S[i];
+            out[TIA_ST_PINV + i] = P[i];
+        }
+        out[TIA_ST_MAXC + 0] = maxc[0];
+        out[TIA_ST_MAXC + 1] = maxc[1];
+        bool finite = true;
+        for (int i = 0; i < 6; ++i) finite = finite && isfinite(S[i]) && isfinite(P[i]);
+        finite = finite && isfinite(maxc[0]) && isfinite(maxc[1]);
+        if (!finite) flags |= TIA_FLAG_DEGENERATE;
+        if (prm.has_target) {
+            const double sc0 = prm.target_maxc[0] / maxc[0], sc1 = prm.target_maxc[1] / maxc[1];
+            out[TIA_ST_SCALE + 0] = sc0;
+            out[TIA_ST_SCALE + 1] = sc1;
+            for (int j = 0; j < 3; ++j)
+                for (int c = 0; c < 3; ++c)
+                    out[TIA_ST_M + j * 3 + c] = P[j * 2 + 0] * sc0 * prm.target_stain[c] +
+                                                P[j * 2 + 1] * sc1 * prm.target_stain[3 + c];
+        }
+        out[TIA_ST_FLAGS] = (double)flags;
+    }
+}
+
+}  // namespace tia
+
+extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
+                                   const tia_stain_tables* d_tables, const tia_stain_params* params,
+                                   double* d_stats, void* stream) {
+    if (!d_img || !d_tables || !params || !d_stats) return TIA_EINVAL;
+    if (n <= 0 || h <= 0 || w <= 0) return TIA_EINVAL;
+    if (params->mode != TIA_MODE_MACENKO && params->mode != TIA_MODE_FIXED) return TIA_EINVAL;
+    const long hw = (long)h * (long)w;
+    if ((unsigned long long)hw * 3ull >= 0xffffffffull) return TIA_ESIZE;  // 32-bit histogram counts
+    if (n > 0x7fffffffll) return TIA_ESIZE;
+    hipLaunchKernelGGL(tia::stain_stats_kernel, dim3((unsigned)n), dim3(tia::NT), 0,
+                       (hipStream_t)stream, d_img, hw, d_tables, *params, d_stats);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}

@@ -1,0 +1,172 @@
+"""Batched device entry points for the stain path (thin wrappers over the C ABI).
+
+Everything here takes/returns ``torch`` CUDA tensors (NHWC uint8 patch batches) and
+enqueues on the current HIP stream without synchronising.  The NumPy-facing classes in
+``stainextract.py`` / ``stainnorm.py`` / ``stainaugment.py`` are built on these.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from tiatoolbox_amd import _lib
+from tiatoolbox_amd.utils import cvtables
+
+_TABLES: dict[int, torch.Tensor] = {}
+_MAX_GRID_Y = 65535
+
+
+def tables(device: torch.device) -> torch.Tensor:
+    """Device copy of ``tia_stain_tables`` (uploaded once per device)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _TABLES:
+        host = _lib.StainTables()
+        od = cvtables.od_lut()
+        C.memmove(host.od_lut, od.ctypes.data, od.nbytes)
+        od32 = od.astype(np.float32)
+        C.memmove(host.od_lut_f32, od32.ctypes.data, od32.nbytes)
+        ty = np.ascontiguousarray(cvtables.ty_tables())
+        C.memmove(host.ty, ty.ctypes.data, ty.nbytes)
+        raw = np.frombuffer(bytes(host), dtype=np.uint8).copy()
+        _TABLES[idx] = torch.from_numpy(raw).to(torch.device("cuda", idx))
+    return _TABLES[idx]
+
+
+def as_batch(img: torch.Tensor) -> torch.Tensor:
+    """Validate an NHWC uint8 CUDA batch (contiguous)."""
+    _lib.require_cuda(img, "image batch")
+    if img.dtype != torch.uint8 or img.dim() != 4 or img.shape[-1] != 3:
+        msg = f"expected a uint8 NHWC batch with 3 channels, got {tuple(img.shape)} {img.dtype}"
+        raise ValueError(msg)
+    return img.contiguous()
+
+
+def make_params(*, mode: int, luminosity_threshold: float = 0.8, angular_percentile: float = 99,
+                stain_fixed: np.ndarray | None = None, target_stain: np.ndarray | None = None,
+                target_maxc: np.ndarray | None = None, zero_to_one: bool = False) -> _lib.StainParams:
+    p = _lib.StainParams()
+    # np.percentile divides q by 100 in float64 (numpy/lib/_function_base_impl.py: percentile)
+    p.q_img_lo = float(np.true_divide(2, 100))
+    p.q_img_hi = float(np.true_divide(98, 100))
+    p.q_phi_lo = float(np.true_divide(100 - angular_percentile, 100))
+    p.q_phi_hi = float(np.true_divide(angular_percentile, 100))
+    p.q_conc = float(np.true_divide(99, 100))
+    p.y_thr = cvtables.y_threshold(luminosity_threshold)
+    p.mode = mode
+    p.zero_to_one = int(zero_to_one)
+    if stain_fixed is not None:
+        sf = np.asarray(stain_fixed, dtype=np.float64)
+        if sf.shape != (2, 3):
+            msg = "The batched normaliser needs a (2, 3) stain matrix."
+            raise ValueError(msg)
+        p.stain_fixed[:] = sf.ravel().tolist()
+    if target_stain is not None:
+        p.has_target = 1
+        p.target_stain[:] = np.asarray(target_stain, dtype=np.float64).ravel().tolist()
+        p.target_maxc[:] = np.asarray(target_maxc, dtype=np.float64).ravel().tolist()
+    return p
+
+
+def stain_stats(img: torch.Tensor, params: _lib.StainParams) -> torch.Tensor:
+    """Per-patch statistics ``[N, 48]`` float64 (see ``include/tiatoolbox_amd.h``)."""
+    img = as_batch(img)
+    n, h, w, _ = img.shape
+    stats = torch.empty((n, _lib.TIA_STATS_STRIDE), dtype=torch.float64, device=img.device)
+    tab = tables(img.device)
+    with torch.cuda.device(img.device):
+        rc = _lib.load().tia_stain_stats_u8(img.data_ptr(), n, h, w, tab.data_ptr(), C.byref(params),
+                                            stats.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "tia_stain_stats_u8")
+    return stats
+
+
+_OUT_DTYPES = {
+    _lib.OUT_U8: torch.uint8, _lib.OUT_F32: torch.float32, _lib.OUT_F64: torch.float64,
+    _lib.OUT_UNIT_F16: torch.float16, _lib.OUT_UNIT_BF16: torch.bfloat16, _lib.OUT_UNIT_F32: torch.float32,
+}
+
+
+def stain_apply(img: torch.Tensor, stats: torch.Tensor, target_stain: np.ndarray, *,
+                out_kind: int = _lib.OUT_U8, math: int = _lib.MATH_F64,
+                out: torch.Tensor | None = None) -> torch.Tensor:
+    img = as_batch(img)
+    n, h, w, _ = img.shape
+    if out is None:
+        out = torch.empty((n, h, w, 3), dtype=_OUT_DTYPES[out_kind], device=img.device)
+    tab = tables(img.device)
+    ts = (C.c_double * 6)(*np.asarray(target_stain, dtype=np.float64).ravel().tolist())
+    lib = _lib.load()
+    with torch.cuda.device(img.device):
+        for s in range(0, n, _MAX_GRID_Y):
+            m = min(_MAX_GRID_Y, n - s)
+            rc = lib.tia_stain_apply_u8(img[s:s + m].data_ptr(), m, h, w, tab.data_ptr(),
+                                        stats[s:s + m].data_ptr(), ts, out[s:s + m].data_ptr(),
+                                        out_kind, math, _lib.current_stream())
+            _lib.check(rc, "tia_stain_apply_u8")
+    return out
+
+
+def concentrations(img: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
+    img = as_batch(img)
+    n, h, w, _ = img.shape
+    out = torch.empty((n, h * w, 2), dtype=torch.float64, device=img.device)
+    tab = tables(img.device)
+    lib = _lib.load()
+    with torch.cuda.device(img.device):
+        for s in range(0, n, _MAX_GRID_Y):
+            m = min(_MAX_GRID_Y, n - s)
+            rc = lib.tia_stain_concentrations_f64(img[s:s + m].data_ptr(), m, h, w, tab.data_ptr(),
+                                                  stats[s:s + m].data_ptr(), out[s:s + m].data_ptr(),
+                                                  _lib.current_stream())
+            _lib.check(rc, "tia_stain_concentrations_f64")
+    return out
+
+
+def luminosity_mask(img: torch.Tensor, stats: torch.Tensor, y_thr: int, *, zero_to_one: bool = False) -> torch.Tensor:
+    img = as_batch(img)
+    n, h, w, _ = img.shape
+    out = torch.empty((n, h, w), dtype=torch.uint8, device=img.device)
+    tab = tables(img.device)
+    lib = _lib.load()
+    with torch.cuda.device(img.device):
+        for s in range(0, n, _MAX_GRID_Y):
+            m = min(_MAX_GRID_Y, n - s)
+            rc = lib.tia_luminosity_mask_u8(img[s:s + m].data_ptr(), m, h, w, tab.data_ptr(),
+                                            stats[s:s + m].data_ptr(), y_thr, int(zero_to_one),
+                                            out[s:s + m].data_ptr(), _lib.current_stream())
+            _lib.check(rc, "tia_luminosity_mask_u8")
+    return out.bool()
+
+
+def augment(img: torch.Tensor, stats: torch.Tensor, alpha_beta: torch.Tensor, y_thr: int, *,
+            augment_background: bool, zero_to_one: bool) -> torch.Tensor:
+    img = as_batch(img)
+    n, h, w, _ = img.shape
+    _lib.require_cuda(alpha_beta, "alpha_beta")
+    ab = alpha_beta.to(torch.float64).contiguous()
+    out = torch.empty_like(img)
+    tab = tables(img.device)
+    lib = _lib.load()
+    with torch.cuda.device(img.device):
+        for s in range(0, n, _MAX_GRID_Y):
+            m = min(_MAX_GRID_Y, n - s)
+            rc = lib.tia_stain_augment_u8(img[s:s + m].data_ptr(), m, h, w, tab.data_ptr(),
+                                          stats[s:s + m].data_ptr(), ab[s:s + m].data_ptr(), y_thr,
+                                          int(augment_background), int(zero_to_one),
+                                          out[s:s + m].data_ptr(), _lib.current_stream())
+            _lib.check(rc, "tia_stain_augment_u8")
+    return out
+
+
+def raise_on_flags(stats: torch.Tensor) -> None:
+    """Data-dependent errors detected on the device, raised like the reference does."""
+    flags = stats[:, _lib.ST_FLAGS].to(torch.int64)
+    empty = torch.nonzero(flags & _lib.FLAG_EMPTY_MASK).flatten()
+    if empty.numel():
+        msg = "Empty tissue mask computed."
+        if stats.shape[0] > 1:
+            msg += f" (patch indices {empty.tolist()[:16]})"
+        raise ValueError(msg)  # utils/misc.py:286-288
