@@ -1,0 +1,84 @@
+"""Model registry (API of reference ``tiatoolbox/models/architecture/__init__.py:70-178``).
+
+Only the entries of the benchmark configs are registered.  Pretrained weights live on the
+HuggingFace hub (``TIACentre/TIAToolbox_pretrained_weights``), unreachable from here: pass a
+local ``.pth`` via ``weights=``; otherwise the model keeps its seeded random initialisation
+and a warning is logged.  Parameter names match the reference so its files load unchanged.
+"""
+
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+
+import torch
+
+from tiatoolbox_amd.models.dataset.classification import predefined_preproc_func
+from tiatoolbox_amd.models.engine.io_config import (
+    IOInstanceSegmentorConfig,
+    IOPatchPredictorConfig,
+    IOSegmentorConfig,
+)
+
+logger = logging.getLogger("tiatoolbox_amd")
+
+# mirrors tiatoolbox/data/pretrained_model.yaml (:15-28, :594-614, :642-672)
+PRETRAINED_INFO = {
+    "resnet18-kather100k": {
+        "architecture": ("vanilla.CNNModel", {"backbone": "resnet18", "num_classes": 9}),
+        "ioconfig": (IOPatchPredictorConfig, {
+            "patch_input_shape": [224, 224], "stride_shape": [224, 224],
+            "input_resolutions": [{"resolution": 0.5, "units": "mpp"}]}),
+        "dataset": "kather100k",
+    },
+    "resnet34-kather100k": {
+        "architecture": ("vanilla.CNNModel", {"backbone": "resnet34", "num_classes": 9}),
+        "ioconfig": (IOPatchPredictorConfig, {
+            "patch_input_shape": [224, 224], "stride_shape": [224, 224],
+            "input_resolutions": [{"resolution": 0.5, "units": "mpp"}]}),
+        "dataset": "kather100k",
+    },
+    "resnet50-kather100k": {
+        "architecture": ("vanilla.CNNModel", {"backbone": "resnet50", "num_classes": 9}),
+        "ioconfig": (IOPatchPredictorConfig, {
+            "patch_input_shape": [224, 224], "stride_shape": [224, 224],
+            "input_resolutions": [{"resolution": 0.5, "units": "mpp"}]}),
+        "dataset": "kather100k",
+    },
+}
+
+
+def _create(arch: str, kwargs: dict):
+    mod_name, cls_name = arch.split(".")
+    import importlib
+
+    mod = importlib.import_module(f"tiatoolbox_amd.models.architecture.{mod_name}")
+    return getattr(mod, cls_name)(**kwargs)
+
+
+def get_pretrained_model(pretrained_model: str | None = None, pretrained_weights: str | Path | None = None,
+                         *, seed: int = 0):
+    """Return ``(model, ioconfig)`` for a registered name (ref. :70-178)."""
+    if not isinstance(pretrained_model, str):
+        msg = "pretrained_model must be a string."
+        raise TypeError(msg)
+    if pretrained_model not in PRETRAINED_INFO:
+        msg = f"Pretrained model `{pretrained_model}` does not exist."
+        raise ValueError(msg)
+    info = PRETRAINED_INFO[pretrained_model]
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        model = _create(*info["architecture"])
+    finally:
+        torch.random.set_rng_state(gen_state)
+    if info.get("dataset"):
+        model.preproc_func = predefined_preproc_func(info["dataset"])
+    if pretrained_weights is not None:
+        model.load_weights_from_file(pretrained_weights)
+    else:
+        logger.warning("No local weights for `%s` (the HuggingFace hub is unreachable): using the seeded "
+                       "random initialisation. Pass `weights=<path to .pth>` for the pretrained model.",
+                       pretrained_model)
+    cfg_cls, cfg_kwargs = info["ioconfig"]
+    return model, cfg_cls(**cfg_kwargs)

@@ -1,0 +1,289 @@
+"""Engine base class (API of reference ``tiatoolbox/models/engine/engine_abc.py``).
+
+Keeps the reference's constructor / ``run()`` signature, kwargs-as-attributes behaviour,
+validation errors and ``dict`` output, but the inner loop is device-first: patches are
+uploaded in large pinned chunks, pre-processing (stain normalisation, ``ToTensor``) runs
+batched on the GPU, outputs stay resident in HBM and are copied back once at the end.
+With ``torch.distributed`` initialised (one process per GPU) the patch list is sharded
+across ranks and the per-patch outputs are all-gathered (RCCL).
+"""
+
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from tiatoolbox_amd import distributed as tdist
+from tiatoolbox_amd.models.architecture import get_pretrained_model
+from tiatoolbox_amd.models.dataset.dataset_abc import PatchDataset
+from tiatoolbox_amd.models.engine.io_config import ModelIOConfigABC
+from tiatoolbox_amd.models.models_abc import load_torch_model
+
+logger = logging.getLogger("tiatoolbox_amd")
+
+_DTYPES = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16,
+           "fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+class EngineABC:
+    """Abstract engine: model + ioconfig + ``run()`` (ref. :136-1885)."""
+
+    def __init__(self, model, batch_size: int = 8, num_workers: int = 0, weights=None, *,
+                 device: str = "cpu", verbose: bool = False) -> None:
+        self.images = None
+        self.masks = None
+        self.patch_mode = None
+        self.device = device
+        self.model, self.ioconfig = self._initialize_model_ioconfig(model=model, weights=weights)
+        self.model.to(device=self.device)
+        self._ioconfig = self.ioconfig
+        self.batch_size = batch_size
+        self.labels = None
+        self.num_workers = num_workers
+        self.patch_input_shape = None
+        self.input_resolutions = None
+        self.return_labels = False
+        self.stride_shape = None
+        self.verbose = verbose
+        self.dataloader = None
+        self.drop_keys: list = []
+        self.output_type = None
+        # MI355X extensions (plain attributes, settable through run(**kwargs) like every other)
+        self.compute_dtype = "float32"    # arithmetic type of the CNN forward
+        self.distributed = True           # shard over ranks when torch.distributed is initialised
+        self._fast_model = None
+        self._fast_key = None
+
+    # ------------------------------------------------------------------ model / ioconfig
+    @staticmethod
+    def _initialize_model_ioconfig(model, weights):
+        """Resolve a registry name or take an ``nn.Module`` as is (ref. :338-387)."""
+        if not isinstance(model, (str, torch.nn.Module)):
+            msg = "Input model must be a string or 'torch.nn.Module'."
+            raise TypeError(msg)
+        if isinstance(model, str):
+            return get_pretrained_model(model, weights)
+        if weights is not None:
+            model = load_torch_model(model=model, weights=weights)
+        return model, None
+
+    def _get_model_attr(self, name: str):
+        model = self.model.module if hasattr(self.model, "module") else self.model
+        return getattr(model, name)
+
+    def _load_ioconfig(self, ioconfig):
+        if self.ioconfig is None and ioconfig is None:
+            msg = "Please provide a valid ModelIOConfigABC. No default ModelIOConfigABC found."
+            raise ValueError(msg)
+        if ioconfig and isinstance(ioconfig, ModelIOConfigABC):
+            self.ioconfig = ioconfig
+        return self.ioconfig
+
+    def _update_ioconfig(self, ioconfig, patch_input_shape, stride_shape, input_resolutions):
+        config_flag = (patch_input_shape is None, input_resolutions is None)
+        if isinstance(ioconfig, ModelIOConfigABC):
+            return ioconfig
+        if self.ioconfig is None and any(config_flag):
+            msg = ("Must provide either `ioconfig` or `patch_input_shape` and `input_resolutions`.")
+            raise ValueError(msg)
+        if stride_shape is None:
+            stride_shape = patch_input_shape
+        if self.ioconfig:
+            cfg = self.ioconfig
+            if patch_input_shape is not None:
+                cfg.patch_input_shape = patch_input_shape
+            if input_resolutions is not None:
+                cfg.input_resolutions = input_resolutions
+            if stride_shape is not None:
+                cfg.stride_shape = stride_shape
+            return cfg
+        return ModelIOConfigABC(input_resolutions=input_resolutions, patch_input_shape=patch_input_shape,
+                                stride_shape=stride_shape, output_resolutions=[])
+
+    # ----------------------------------------------------------------------- validation
+    @staticmethod
+    def _validate_images_masks(images):
+        """ref. :1121-1159"""
+        if not isinstance(images, (list, np.ndarray)):
+            msg = "Input must be a list of file paths or a numpy array."
+            raise TypeError(msg)
+        if isinstance(images, np.ndarray) and images.ndim != 4:  # noqa: PLR2004
+            msg = ("The input numpy array should be four dimensional."
+                   "The shape of the numpy array should be NHWC.")
+            raise ValueError(msg)
+        if isinstance(images, np.ndarray):
+            return images
+        return [Path(image) if isinstance(image, str) else image for image in images]
+
+    @staticmethod
+    def _validate_input_numbers(images, masks=None, labels=None) -> None:
+        """ref. :1161-1209"""
+        if masks is None and labels is None:
+            return
+        len_images = len(images)
+        if masks is not None and len_images != len(masks):
+            msg = f"len(masks) is not equal to len(images) : {len(masks)} != {len(images)}"
+            raise ValueError(msg)
+        if labels is not None and len_images != len(labels):
+            msg = f"len(labels) is not equal to len(images) : {len(labels)} != {len(images)}"
+            raise ValueError(msg)
+
+    def _update_run_params(self, images, masks=None, input_resolutions=None, patch_input_shape=None,
+                           save_dir=None, ioconfig=None, output_type: str = "dict", *, overwrite: bool = False,
+                           patch_mode: bool, **kwargs):
+        """ref. :1211-1372: every kwarg becomes an attribute on the engine (and persists)."""
+        for key in kwargs:
+            setattr(self, key, kwargs.get(key))
+        if input_resolutions:
+            self.input_resolutions = input_resolutions
+        if patch_input_shape is not None:
+            self.patch_input_shape = patch_input_shape
+        if not self.return_labels:
+            self.drop_keys.append("label")
+        self.patch_mode = patch_mode
+        self._validate_input_numbers(images=images, masks=masks, labels=self.labels)
+        if output_type.lower() not in ["dict", "zarr", "qupath", "annotationstore"]:
+            msg = "output_type must be 'dict' or 'zarr', 'qupath' or 'annotationstore'."
+            raise TypeError(msg)
+        self.output_type = output_type
+        if save_dir is not None and output_type.lower() == "dict":
+            self.output_type = "zarr"
+        if save_dir is None and output_type.lower() in ["zarr", "qupath", "annotationstore"]:
+            msg = f"Please provide save_dir for output_type={output_type}"
+            raise ValueError(msg)
+        if self.output_type.lower() != "dict":
+            msg = (f"output_type={self.output_type!r} needs zarr / the annotation store, which are outside "
+                   "the accelerated hot path; use output_type='dict'.")
+            raise NotImplementedError(msg)
+        if not patch_mode and save_dir is None:
+            msg = "Input WSIs detected but no save directory provided. Please provide a 'save_dir'."
+            raise OSError(msg)
+        self.images = self._validate_images_masks(images=images)
+        if masks is not None:
+            self.masks = self._validate_images_masks(images=masks)
+        self._ioconfig = self._load_ioconfig(ioconfig=ioconfig)
+        self.model = self.model.to(device=self.device)
+        self._ioconfig = self._update_ioconfig(ioconfig, self.patch_input_shape, self.stride_shape,
+                                               self.input_resolutions)
+        return save_dir
+
+    # ------------------------------------------------------------------------ inference
+    def get_dataloader(self, images, labels=None, ioconfig=None, **_):
+        """Patch mode: a :class:`PatchDataset` carrying the model's ``preproc_func`` (ref. :397-480)."""
+        shape = ioconfig.patch_input_shape if ioconfig is not None else None
+        ds = PatchDataset(inputs=images, labels=labels, patch_input_shape=shape)
+        ds.preproc_func = self._get_model_attr("preproc_func")
+        return ds
+
+    def _inference_model(self, dtype: torch.dtype):
+        """The module used for the forward pass: parameters in ``dtype``, channels-last (MIOpen NHWC)."""
+        if dtype == torch.float32 and torch.device(self.device).type != "cuda":
+            return self.model
+        key = (dtype, str(self.device), id(self.model))
+        if self._fast_key != key:
+            import copy
+
+            m = copy.deepcopy(self.model).to(device=self.device)
+            m = m.to(dtype=dtype) if dtype != torch.float32 else m
+            if torch.device(self.device).type == "cuda":
+                m = m.to(memory_format=torch.channels_last)
+            m.eval()
+            self._fast_model, self._fast_key = m, key
+        return self._fast_model
+
+    def _preprocess_batch(self, dataset: PatchDataset, lo: int, hi: int, dtype: torch.dtype) -> torch.Tensor:
+        """Raw patches [lo,hi) -> model-ready NHWC tensor on ``self.device``."""
+        dev = torch.device(self.device)
+        hook = dataset.preproc_func
+        if isinstance(dataset.inputs, np.ndarray):
+            dataset.check_shape(dataset.inputs.shape[1:])
+            raw = np.ascontiguousarray(dataset.inputs[lo:hi])
+        else:
+            raw = np.stack([dataset.raw(i) for i in range(lo, hi)])
+        from tiatoolbox_amd.tools.stainnorm import StainNormalizer
+
+        device_batch = getattr(hook, "device_batch", None)
+        bound_norm = getattr(hook, "__self__", None)
+        if dev.type == "cuda" and raw.dtype == np.uint8 and (
+                device_batch is not None or isinstance(bound_norm, StainNormalizer)):
+            t = torch.from_numpy(raw)
+            t = t.pin_memory().to(dev, non_blocking=True) if raw.nbytes > (1 << 20) else t.to(dev)
+            if device_batch is not None:
+                return device_batch(t, dtype)
+            # bare `model.preproc_func = normalizer.transform`: the reference then feeds 0..255 floats
+            return bound_norm.transform(t).to(dtype)
+        if device_batch is not None and dev.type != "cuda" and not hasattr(hook, "normalizer"):
+            return device_batch(torch.from_numpy(raw), dtype)
+        # arbitrary user hook: per patch on the host, exactly like Dataset.__getitem__ in the reference
+        items = [torch.as_tensor(np.asarray(hook(p))) for p in raw]
+        return torch.stack(items).to(dev)
+
+    def infer_patches(self, dataloader: PatchDataset, *, return_coordinates: bool = False) -> dict:
+        """Forward every patch; results stay on the device until the end (ref. :505-588)."""
+        n = len(dataloader)
+        dtype = _DTYPES[str(self.compute_dtype).replace("torch.", "")]
+        model = self._inference_model(dtype)
+        infer_batch = self._get_model_attr("infer_batch")
+        rank, world_size = tdist.world() if self.distributed else (0, 1)
+        lo, hi = tdist.shard_bounds(n, rank, world_size)
+        outs = []
+        for s in range(lo, hi, self.batch_size):
+            e = min(s + self.batch_size, hi)
+            batch = self._preprocess_batch(dataloader, s, e, dtype)
+            outs.append(infer_batch(model, batch, device=self.device))
+        if outs and isinstance(outs[0], torch.Tensor):
+            local = torch.cat(outs)
+        elif outs:
+            local = torch.from_numpy(np.concatenate(outs))
+        else:
+            local = torch.empty((0, getattr(self._get_model_attr("num_classes"), "real", 1)))
+        if world_size > 1:
+            if not outs:  # empty shard: need the row shape from a peer-independent source
+                probe = infer_batch(model, self._preprocess_batch(dataloader, 0, 1, dtype), device=self.device)
+                probe = probe if isinstance(probe, torch.Tensor) else torch.from_numpy(probe)
+                local = probe[:0]
+            if torch.device(self.device).type == "cuda":
+                local = local.to(self.device)
+            local = tdist.all_gather_rows(local, n)
+        raw_predictions = {"probabilities": local}
+        if self.return_labels and dataloader.labels is not None:
+            raw_predictions["labels"] = np.asarray(dataloader.labels).reshape(-1)
+        if return_coordinates:
+            raw_predictions["coordinates"] = np.zeros((n, 4), dtype=np.int64)
+        return raw_predictions
+
+    def post_process_patches(self, raw_predictions: dict, **_) -> dict:
+        return raw_predictions
+
+    def save_predictions(self, processed_predictions: dict, output_type: str, **_):
+        """``dict`` output: computed NumPy arrays, dropped keys removed (ref. :650-767)."""
+        out = {}
+        for key, val in processed_predictions.items():
+            if key in self.drop_keys:
+                continue
+            out[key] = val.cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+        return out
+
+    def _run_patch_mode(self, output_type: str, save_dir, **kwargs):
+        self.dataloader = self.get_dataloader(images=self.images, labels=self.labels, ioconfig=self._ioconfig)
+        raw = self.infer_patches(dataloader=self.dataloader,
+                                 return_coordinates=output_type.lower() in ["annotationstore", "qupath"])
+        processed = self.post_process_patches(raw_predictions=raw, **kwargs)
+        return self.save_predictions(processed_predictions=processed, output_type=output_type, **kwargs)
+
+    def run(self, images, *, masks=None, input_resolutions=None, patch_input_shape=None, ioconfig=None,
+            patch_mode: bool = True, save_dir=None, overwrite: bool = False, output_type: str = "dict", **kwargs):
+        """Run the engine on patches (ref. :1684-1829)."""
+        save_dir = self._update_run_params(
+            images=images, masks=masks, input_resolutions=input_resolutions, patch_input_shape=patch_input_shape,
+            save_dir=save_dir, ioconfig=ioconfig, overwrite=overwrite, patch_mode=patch_mode,
+            output_type=output_type, **kwargs)
+        if patch_mode:
+            return self._run_patch_mode(output_type=self.output_type, save_dir=save_dir, **kwargs)
+        msg = "WSI mode is provided by the engines that implement it (SemanticSegmentor)."
+        raise NotImplementedError(msg)
+
+    predict = run  # tiatoolbox 1.x name, still used by the reference's example notebooks
