@@ -120,7 +120,7 @@ def test_gpu_macenko_prenorm_pipeline(patches, target_image):
     eng2 = PatchPredictor("resnet18-kather100k", batch_size=4, device="cuda")
     eng2.model.preproc_func = StainNormPreproc(norm)
     got2 = eng2.run(patches, patch_mode=True, return_probabilities=True)
-    assert np.array_equal(got2["probabilities"], got["probabilities"])
+    np.testing.assert_allclose(got2["probabilities"], got["probabilities"], atol=1e-6)  # MIOpen solver choice may differ
     # bare `preproc_func = normalizer.transform` feeds 0..255 floats, as in the reference
     eng3 = PatchPredictor("resnet18-kather100k", batch_size=4, device="cuda")
     eng3.model.preproc_func = norm.transform

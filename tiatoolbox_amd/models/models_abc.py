@@ -66,14 +66,27 @@ class ModelABC(ABC, nn.Module):
             raise ValueError(msg)
         self._postproc = self.postproc if func is None else func
 
-    def to(self, device: str = "cpu", dtype: torch.dtype | None = None, *, non_blocking: bool = False):
-        """Move the model (ref. :204-237).
+    def to(self, device=None, dtype: torch.dtype | None = None, *, non_blocking: bool = False,
+           memory_format=None):
+        """Move / cast the model (ref. :204-237).
 
         The reference wraps the model in single-process ``nn.DataParallel`` when several GPUs
-        are visible; here multi-GPU is one process per GPU (see ``tiatoolbox_amd.distributed``),
-        so ``to`` never wraps.
+        are visible; here multi-GPU is one process per GPU (``tiatoolbox_amd.distributed``), so
+        ``to`` never wraps.  A ``torch.dtype`` as first argument and ``memory_format`` are passed
+        through to ``nn.Module.to``.
         """
-        return super().to(torch.device(device), dtype=dtype, non_blocking=non_blocking)
+        if isinstance(device, torch.dtype):
+            device, dtype = None, device
+        elif device is None and dtype is None and memory_format is None:
+            device = "cpu"  # bare ``model.to()``: the reference's default
+        kwargs = {"non_blocking": non_blocking}
+        if dtype is not None:
+            kwargs["dtype"] = dtype
+        if memory_format is not None:
+            kwargs["memory_format"] = memory_format
+        if device is not None:
+            kwargs["device"] = torch.device(device)
+        return super().to(**kwargs)
 
     def load_weights_from_file(self, weights: str | Path):
         saved_state_dict = torch.load(weights, map_location="cpu")
