@@ -37,7 +37,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--patches", type=int, default=4096, help="patches per GPU per step")
     ap.add_argument("--patch-size", type=int, default=224)
-    ap.add_argument("--micro-batch", type=int, default=512, help="CNN forward batch")
+    ap.add_argument("--micro-batch", type=int, default=1024, help="CNN forward batch")
     ap.add_argument("--dtype", default=os.environ.get("TIA_BENCH_DTYPE", "float16"),
                     choices=["float32", "float16", "bfloat16"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"],
@@ -129,7 +129,9 @@ def main() -> None:
 
     logging.getLogger("tiatoolbox_amd").setLevel(logging.ERROR)
     model, _ = get_pretrained_model("resnet18-kather100k")
-    model_dev = model.to(device)
+    from tiatoolbox_amd.models.architecture.fused import fuse_cnn_model
+
+    model_dev = fuse_cnn_model(model).to(device)  # eval copy, BatchNorm folded into the convolutions
     if dtype != torch.float32:
         model_dev = model_dev.to(dtype)
     model_dev = model_dev.to(memory_format=torch.channels_last).eval()

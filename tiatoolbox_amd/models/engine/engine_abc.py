@@ -54,6 +54,7 @@ class EngineABC:
         # MI355X extensions (plain attributes, settable through run(**kwargs) like every other)
         self.compute_dtype = "float32"    # arithmetic type of the CNN forward
         self.distributed = True           # shard over ranks when torch.distributed is initialised
+        self.fold_batchnorm = True        # inference copy with BN folded into the convolutions
         self._fast_model = None
         self._fast_key = None
 
@@ -182,11 +183,16 @@ class EngineABC:
         """The module used for the forward pass: parameters in ``dtype``, channels-last (MIOpen NHWC)."""
         if dtype == torch.float32 and torch.device(self.device).type != "cuda":
             return self.model
-        key = (dtype, str(self.device), id(self.model))
+        key = (dtype, str(self.device), id(self.model), self.fold_batchnorm)
         if self._fast_key != key:
             import copy
 
-            m = copy.deepcopy(self.model).to(device=self.device)
+            m = copy.deepcopy(self.model)
+            if self.fold_batchnorm and hasattr(m, "feat_extract"):
+                from tiatoolbox_amd.models.architecture.fused import fuse_cnn_model
+
+                m = fuse_cnn_model(m)
+            m = m.to(device=self.device)
             m = m.to(dtype=dtype) if dtype != torch.float32 else m
             if torch.device(self.device).type == "cuda":
                 m = m.to(memory_format=torch.channels_last)
