@@ -39,8 +39,8 @@ typedef struct tia_stain_tables {
     int32_t ty[3][256];
 } tia_stain_tables;
 
-/* Per-patch statistics record: TIA_STATS_STRIDE doubles per patch. */
-#define TIA_STATS_STRIDE 48
+/* Per-patch statistics record: TIA_STATS_STRIDE doubles per patch (512 B, cache-line aligned). */
+#define TIA_STATS_STRIDE 64
 #define TIA_ST_STAIN 0    /* [6]  source stain matrix, rows H,E unit norm  (stainextract.py:177-227) */
 #define TIA_ST_MAXC 6     /* [2]  99th pct of source concentrations        (stainnorm.py:103)        */
 #define TIA_ST_NTISSUE 8  /*      tissue pixel count                                                   */
@@ -54,6 +54,7 @@ typedef struct tia_stain_tables {
 #define TIA_ST_PINV 26    /* [6]  pinv(S^T) as P[j*2+i], C_i = sum_j OD_j P[j][i] (stainnorm.py:65)   */
 #define TIA_ST_M 32       /* [9]  M[j*3+c] = sum_i P[j][i]*(maxC_t[i]/maxC_s[i])*S_t[i][c]            */
 #define TIA_ST_SCALE 41   /* [2]  maxC_target / maxC_source                 (stainnorm.py:104)        */
+#define TIA_ST_CYCLES 48  /* [16] shader-clock cycles per phase (instrumentation; see stain_stats.hip) */
 
 #define TIA_FLAG_EMPTY_MASK 1
 #define TIA_FLAG_DEGENERATE 2

@@ -26,6 +26,9 @@ p = norm.extractor.stats_params(target_stain=norm.stain_matrix_target, target_ma
 stats = dev.stain_stats(x, p)
 t = timeit(lambda: dev.stain_stats(x, p))
 print(f"stats   n={n} {h}x{w}: {t:.3f} ms  -> {n/t*1e3:,.0f} patches/s, {t/n*1e3:.2f} us/patch")
+cyc = dev.stain_stats(x, p)[:, _lib.ST_CYCLES:_lib.ST_CYCLES+16].mean(0).cpu().numpy()
+names = ["P1","LUT","P2","EIG","SEL_HIST","SEL_FIND","SEL_COLLECT","SEL_SORT","PHI_TOTAL","CONC_TOTAL","TOTAL","clv0","clv1","ccnt0","ccnt1","philv"]
+print("  cycles/patch:", ", ".join(f"{k}={v:,.0f}" for k, v in zip(names, cyc)))
 pr = norm.extractor.stats_params(target_stain=norm.stain_matrix_target, target_maxc=norm.maxC_target)
 pr.mode = _lib.MODE_FIXED; pr.stain_fixed[:] = [0.65,0.70,0.29,0.07,0.99,0.11]
 t = timeit(lambda: dev.stain_stats(x, pr))
@@ -36,4 +39,4 @@ for math, mname in ((_lib.MATH_F32, "f32"), (_lib.MATH_F64, "f64")):
         out = dev.stain_apply(x, stats, norm.stain_matrix_target, out_kind=ok, math=math)
         t = timeit(lambda: dev.stain_apply(x, stats, norm.stain_matrix_target, out_kind=ok, math=math, out=out))
         b = n*h*w*3*(1 + out.element_size())
-        print(f"apply {mname}->{oname}: {t:.3f} ms  {b/t/1e9:.1f} GB/s ({b/t/1e9/8000*100:.1f}% of 8 TB/s)  {n/t*1e3:,.0f} patches/s")
+        print(f"apply {mname}->{oname}: {t:.3f} ms  {b/t/1e6:.1f} GB/s ({b/t/1e6/8000*100:.1f}% of 8 TB/s)  {n/t*1e3:,.0f} patches/s")

@@ -12,7 +12,8 @@ from pathlib import Path
 
 from . import build as _build
 
-TIA_STATS_STRIDE = 48
+TIA_STATS_STRIDE = 64
+ST_CYCLES = 48
 ST_STAIN, ST_MAXC, ST_NTISSUE, ST_PLOW, ST_PHIGH = 0, 6, 8, 9, 10
 ST_MINPHI, ST_MAXPHI, ST_COV, ST_EVEC, ST_FLAGS, ST_PINV, ST_M, ST_SCALE = 11, 12, 13, 19, 25, 26, 32, 41
 FLAG_EMPTY_MASK, FLAG_DEGENERATE = 1, 2

@@ -44,24 +44,112 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
     return v;
 }
 
+// LDS histogram increment that survives value spikes (white background, saturated pixels).
+// `WaveGroup` says whether every active lane of the wave is looking at the same 12 bytes in this
+// iteration (one ballot per 4 pixels); if so one lane adds the population count instead of 64
+// serialised same-address atomics.
+struct WaveGroup {
+    bool uniform;
+    int leader;
+    unsigned count;
+};
+__device__ __forceinline__ void hist_add(unsigned* bins, int bin, bool valid, const WaveGroup& wg) {
+    if (!valid) return;
+    if (wg.uniform) {
+        if (lane_id() == wg.leader) atomicAdd(&bins[bin], wg.count);
+    } else {
+        atomicAdd(&bins[bin], 1u);
+    }
+}
+
 // Visit every pixel of one HWC uint8 image with `f(idx, r, g, b)`; block-strided.
 // Fast path reads 12 contiguous bytes (4 pixels) per lane as three dwords: lanes of a wave
 // cover 768 contiguous bytes per iteration (coalesced), and pixels never straddle lanes.
+// The next group's dwords are requested before the current group is processed (software
+// prefetch), so the L2/HBM latency hides behind the per-pixel arithmetic even at 2-4 waves/SIMD.
 template <int NT, class F>
 __device__ __forceinline__ void for_each_pixel(const uint8_t* __restrict__ p, long hw, F&& f) {
     if (((hw & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
         const long ng = hw >> 2;
-        for (long g = threadIdx.x; g < ng; g += NT) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(p + g * 12);
-            const uint32_t a = q[0], b = q[1], c = q[2];
+        const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
+        long g = threadIdx.x;
+        uint32_t a = 0, b = 0, c = 0;
+        if (g < ng) {
+            a = q[g * 3 + 0];
+            b = q[g * 3 + 1];
+            c = q[g * 3 + 2];
+        }
+        while (g < ng) {
+            const long gn = g + NT;
+            uint32_t na = 0, nb = 0, nc = 0;
+            if (gn < ng) {
+                na = q[gn * 3 + 0];
+                nb = q[gn * 3 + 1];
+                nc = q[gn * 3 + 2];
+            }
             f(g * 4 + 0, a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
             f(g * 4 + 1, a >> 24, b & 255u, (b >> 8) & 255u);
             f(g * 4 + 2, (b >> 16) & 255u, b >> 24, c & 255u);
             f(g * 4 + 3, (c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
+            a = na;
+            b = nb;
+            c = nc;
+            g = gn;
         }
     } else {
         for (long i = threadIdx.x; i < hw; i += NT) {
             f(i, (uint32_t)p[3 * i], (uint32_t)p[3 * i + 1], (uint32_t)p[3 * i + 2]);
+        }
+    }
+}
+
+// Same sweep, additionally telling `f` whether the wave's lanes all hold identical pixels.
+template <int NT, class F>
+__device__ __forceinline__ void for_each_pixel_w(const uint8_t* __restrict__ p, long hw, F&& f) {
+    if (((hw & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
+        const long ng = hw >> 2;
+        const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
+        long g = threadIdx.x;
+        uint32_t a = 0, b = 0, c = 0;
+        if (g < ng) {
+            a = q[g * 3 + 0];
+            b = q[g * 3 + 1];
+            c = q[g * 3 + 2];
+        }
+        while (g < ng) {
+            const long gn = g + NT;
+            uint32_t na = 0, nb = 0, nc = 0;
+            if (gn < ng) {
+                na = q[gn * 3 + 0];
+                nb = q[gn * 3 + 1];
+                nc = q[gn * 3 + 2];
+            }
+#ifndef TIA_UNIFORM
+#define TIA_UNIFORM 1
+#endif
+            WaveGroup wg{false, 0, 1u};
+            if (TIA_UNIFORM) {
+                const unsigned long long act = __ballot(1);
+                wg.leader = __ffsll((long long)act) - 1;
+                const uint32_t a0 = __builtin_amdgcn_readlane(a, wg.leader);
+                const uint32_t b0 = __builtin_amdgcn_readlane(b, wg.leader);
+                const uint32_t c0 = __builtin_amdgcn_readlane(c, wg.leader);
+                wg.uniform = __ballot(a == a0 && b == b0 && c == c0) == act;
+                wg.count = (unsigned)__popcll(act);
+            }
+            f(g * 4 + 0, a & 255u, (a >> 8) & 255u, (a >> 16) & 255u, wg);
+            f(g * 4 + 1, a >> 24, b & 255u, (b >> 8) & 255u, wg);
+            f(g * 4 + 2, (b >> 16) & 255u, b >> 24, c & 255u, wg);
+            f(g * 4 + 3, (c >> 8) & 255u, (c >> 16) & 255u, c >> 24, wg);
+            a = na;
+            b = nb;
+            c = nc;
+            g = gn;
+        }
+    } else {
+        WaveGroup wg{false, 0, 1u};
+        for (long i = threadIdx.x; i < hw; i += NT) {
+            f(i, (uint32_t)p[3 * i], (uint32_t)p[3 * i + 1], (uint32_t)p[3 * i + 2], wg);
         }
     }
 }

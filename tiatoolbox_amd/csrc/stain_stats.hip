@@ -1,9 +1,10 @@
-// Per-patch stain statistics on gfx950: one 1024-thread workgroup per patch, all per-patch
+// Per-patch stain statistics on gfx950: one 512-thread workgroup per patch (two resident per CU), all per-patch
 // state in LDS, per-patch statistics in f64.  See include/tiatoolbox_amd.h for the contract
 // and DESIGN.md ("stain_stats") for the pass structure:
 //   P1 byte histogram -> contrast-enhancer percentiles -> folded luminance tables
 //   P2 tissue mask + OD moments (f64) -> covariance -> 3x3 eigen-decomposition
-//   P3/P4 exact angular percentiles (histogram refine + LDS bitonic select)
+//   P3/P4 exact angular percentiles (histogram refine + LDS bitonic select) on a monotone
+//         pseudo-angle key (one f64 division per pixel instead of atan2)
 //   P5/P6 exact 99th percentile of both stain concentrations
 // Reference: tools/stainextract.py:177-227, tools/stainnorm.py:49-66,81-85,103,
 //            utils/misc.py:261-290,405-444, utils/transforms.py:209-231.
@@ -15,17 +16,24 @@
 
 namespace tia {
 
-constexpr int NT = 512;          // threads per workgroup (8 waves, 2 per SIMD: 256 VGPRs each)
+constexpr int NT = 512;          // threads per workgroup; two workgroups per CU (4 waves/SIMD, 128 VGPRs)
 constexpr int NW = NT / 64;
-constexpr int NB = 8192;         // histogram bins per selection target per level
-constexpr int CAP = 2048;        // candidates sorted in LDS
-constexpr int MAXLEVEL = 6;      // 8192^5 > 2^64: deeper levels cannot split an f64 range further
+constexpr int NB = 4096;         // histogram bins per selection target per level
+constexpr int CAP = 1024;        // candidates sorted in LDS
+constexpr int MAXLEVEL = 7;      // 4096^6 > 2^64: deeper levels cannot split an f64 range further
 constexpr int BPT = NB / NT;     // bins per thread in the scan
+// Optional LDS tissue-mask bit cache (P2 writes, P3/P4 read).  Measured neutral on MI355X (the
+// three int table look-ups it saves are not the bottleneck), so it is off by default.
+#ifndef TIA_MASKBITS
+#define TIA_MASKBITS 0
+#endif
+constexpr int MASK_WORDS = TIA_MASKBITS ? 2048 : 1;  // up to 65536 pixels (256x256)
 
 struct SelState {
     double lo[2][MAXLEVEL + 1];
     double scale[2][MAXLEVEL + 1];
     int sel[2][MAXLEVEL + 1];
+    double olo[2], ohi[2];  // rigorous bounds of the current member set (edge bins are open-ended)
     int level[2];
     int collapsed[2];
     int need_hist[2];
@@ -40,23 +48,40 @@ struct Smem {
     double od[256];
     int ty[3][256];
     unsigned hist[256];
+    unsigned hist3[3][256];
     unsigned cum[256];
     unsigned bins[2][NB];
     double cand[2][CAP];
-    double red[NW][12];
+    double red[NW][16];
     unsigned wtot[NW];
     SelState st;
     double bc[40];
+    double chm[6];      // per-channel sum(od), sum(od^2) over all pixels
+    double chx[3];      // cross sums sum(od_r od_g), sum(od_r od_b), sum(od_g od_b) over all pixels
     unsigned long long ubc[8];
     int ibc[8];
+    unsigned mbits[MASK_WORDS];  // tissue mask bits of the patch (when it fits)
+    long long tm[16];   // per-phase cycle accumulators (thread 0)
+    long long tlast;
 };
+
+// phase timing: thread 0 adds the shader-clock cycles since the previous stamp to slot `i`
+__device__ __forceinline__ void stamp(Smem& s, int i) {
+    if (threadIdx.x == 0) {
+        const long long now = clock64();
+        s.tm[i] += now - s.tlast;
+        s.tlast = now;
+    }
+}
+enum { TM_P1 = 0, TM_LUT, TM_P2, TM_EIG, TM_SEL_HIST, TM_SEL_FIND, TM_SEL_COLLECT, TM_SEL_SORT, TM_PHI_TOTAL,
+       TM_CONC_TOTAL, TM_TOTAL };
 
 // ---------------------------------------------------------------------------------------
 // block-wide helpers (all threads must call)
 // ---------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void block_sum(double (&v)[N], Smem& s) {
-    static_assert(N <= 12, "reduction scratch too small");
+    static_assert(N <= 16, "reduction scratch too small");
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         double w = wave_sum(v[i]);
@@ -137,10 +162,11 @@ __device__ __forceinline__ void find_bin(const unsigned* __restrict__ bins, unsi
 // <= CAP members, then one collect pass + an LDS bitonic sort.  Everything is exact: the bin
 // function is monotone in x, so bins partition the sorted order.
 template <class VF>
-__device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem& s,
+__device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem& s,
                         const unsigned long long (&k)[2], const unsigned long long (&n)[2],
-                        const double (&lo0)[2], const double (&hi0)[2], bool shared_values,
-                        double (&vprev)[2], double (&vnext)[2]) {
+                        const double (&lo0)[2], const double (&hi0)[2], const double (&olo0)[2],
+                        const double (&ohi0)[2], bool shared_values, double (&vprev)[2],
+                        double (&vnext)[2]) {
     SelState& st = s.st;
     if (threadIdx.x < 2) {
         const int t = threadIdx.x;
@@ -148,6 +174,8 @@ __device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem&
         st.cnt[t] = n[t];
         st.r[t] = k[t];
         st.lo[t][0] = lo0[t];
+        st.olo[t] = olo0[t];
+        st.ohi[t] = ohi0[t];
         const double sc = (double)NB / (hi0[t] - lo0[t]);
         const bool ok = (hi0[t] > lo0[t]) && (sc > 0.0) && (sc < 1.0e300);
         st.scale[t][0] = ok ? sc : 0.0;
@@ -164,6 +192,7 @@ __device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem&
         __syncthreads();
         const int nh0 = st.need_hist[0], nh1 = st.need_hist[1];
         if (!nh0 && !nh1) break;
+        stamp(s, TM_SEL_SORT);
         const int lv0 = st.level[0], lv1 = st.level[1];
         // one shared histogram while both targets still see the same values and the same binning
         const bool shared = shared_values && nh0 && nh1 && lv0 == 0 && lv1 == 0;
@@ -172,26 +201,35 @@ __device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem&
             s.bins[1][i] = 0;
         }
         __syncthreads();
-        for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+        // values outside the histogram window belong to the (open-ended) edge bins; they are counted
+        // in registers so that e.g. a large background population does not serialise on one address
+        unsigned below[2] = {0, 0}, above[2] = {0, 0};
+        for_each_pixel_w<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b, const WaveGroup& wg) {
             double x[2];
             const unsigned vm = valf(idx, r, g, b, x);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int nh = t ? nh1 : nh0;
                 const int lv = t ? lv1 : lv0;
-                if (!nh || !((vm >> t) & 1u)) continue;
-                if (shared && t == 1) continue;
-                bool member = true;
-                for (int l = 0; l < lv; ++l) {
-                    if (bin_of(x[t], st.lo[t][l], st.scale[t][l]) != st.sel[t][l]) {
-                        member = false;
-                        break;
-                    }
-                }
-                if (member) atomicAdd(&s.bins[t][bin_of(x[t], st.lo[t][lv], st.scale[t][lv])], 1u);
+                if (!nh || (shared && t == 1)) continue;  // wave-uniform
+                bool member = ((vm >> t) & 1u) != 0;
+                for (int l = 0; l < lv && member; ++l)
+                    member = bin_of(x[t], st.lo[t][l], st.scale[t][l]) == st.sel[t][l];
+                const double d = (x[t] - st.lo[t][lv]) * st.scale[t][lv];
+                const bool lowv = member && !(d >= 0.0);
+                const bool highv = member && (d >= (double)NB);
+                below[t] += lowv ? 1u : 0u;
+                above[t] += highv ? 1u : 0u;
+                hist_add(s.bins[t], (int)d, member && !lowv && !highv, wg);
             }
         });
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (below[t]) atomicAdd(&s.bins[t][0], below[t]);
+            if (above[t]) atomicAdd(&s.bins[t][NB - 1], above[t]);
+        }
         __syncthreads();
+        stamp(s, TM_SEL_HIST);
         for (int t = 0; t < 2; ++t) {
             if (!(t ? nh1 : nh0)) continue;
             const unsigned* hb = (shared && t == 1) ? s.bins[0] : s.bins[t];
@@ -203,8 +241,11 @@ __device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem&
                 st.r[t] = s.ubc[t * 2 + 0];
                 st.cnt[t] = s.ubc[t * 2 + 1];
                 const double lo = st.lo[t][lv], sc = st.scale[t][lv];
-                const double nlo = lo + (double)b / sc;
-                const double nhi = lo + (double)(b + 1) / sc;
+                // edge bins also hold everything clamped into them: extend to the rigorous bound
+                const double nlo = (b == 0) ? st.olo[t] : lo + (double)b / sc;
+                const double nhi = (b == NB - 1) ? st.ohi[t] : lo + (double)(b + 1) / sc;
+                st.olo[t] = nlo;
+                st.ohi[t] = nhi;
                 const double nsc = (double)NB / (nhi - nlo);
                 const bool ok = (nhi > nlo) && (nsc > 0.0) && (nsc < 1.0e300);
                 st.lo[t][lv + 1] = nlo;
@@ -214,6 +255,7 @@ __device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem&
             }
             __syncthreads();
         }
+        stamp(s, TM_SEL_FIND);
     }
 
     // ---- collect pass ------------------------------------------------------------------
@@ -227,7 +269,8 @@ __device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem&
     {
         const int lv[2] = {st.level[0], st.level[1]};
         const bool store[2] = {st.cnt[0] <= (unsigned long long)CAP, st.cnt[1] <= (unsigned long long)CAP};
-        unsigned long long amin[2] = {~0ull, ~0ull}, mmin[2] = {~0ull, ~0ull};
+        const double inf = __longlong_as_double(0x7ff0000000000000ll);
+        double amin[2] = {inf, inf}, mmin[2] = {inf, inf};
         for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
             double x[2];
             const unsigned vm = valf(idx, r, g, b, x);
@@ -242,22 +285,22 @@ __device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem&
                         break;
                     }
                 }
-                const unsigned long long key = f64_key(x[t]);
                 if (cls == 0) {
-                    mmin[t] = key < mmin[t] ? key : mmin[t];
                     if (store[t]) {
                         const unsigned pos = atomicAdd(&st.ncand[t], 1u);
                         if (pos < (unsigned)CAP) s.cand[t][pos] = x[t];
+                    } else {
+                        mmin[t] = x[t] < mmin[t] ? x[t] : mmin[t];
                     }
                 } else if (cls > 0) {
-                    amin[t] = key < amin[t] ? key : amin[t];
+                    amin[t] = x[t] < amin[t] ? x[t] : amin[t];
                 }
             }
         });
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const unsigned long long a = wave_min_u64(amin[t]);
-            const unsigned long long m = wave_min_u64(mmin[t]);
+            const unsigned long long a = wave_min_u64(f64_key(amin[t]));
+            const unsigned long long m = wave_min_u64(f64_key(mmin[t]));
             if (lane_id() == 0) {
                 atomicMin(&st.above_key[t], a);
                 atomicMin(&st.member_key[t], m);
@@ -265,6 +308,7 @@ __device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem&
         }
     }
     __syncthreads();
+    stamp(s, TM_SEL_COLLECT);
 
     // ---- sort candidates (both targets at once) and pick -----------------------------------
     unsigned pmax = 2;
@@ -322,6 +366,32 @@ __device__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem&
         }
     }
     __syncthreads();
+    stamp(s, TM_SEL_SORT);
+}
+
+// Monotone pseudo-angle: strictly increasing in atan2(y, x) over (-pi, pi], range [-2, 2].
+//   x >= 0:  r            (phi in [-pi/2, pi/2]),   r = y / (|x| + |y|)
+//   x <  0:  2 - r (y>=0) or -2 - r (y<0)
+// Ordering pixels by this key orders them by phi, so the order statistics are selected on the
+// key (1 division) and only the two selected values per percentile are turned back into angles.
+__device__ __forceinline__ double pseudo_angle(double y, double x) {
+    const double d = fabs(x) + fabs(y);
+    if (!(d > 0.0)) return 0.0;  // atan2(0, 0) = 0
+    const double r = y / d;
+    if (x >= 0.0) return r;
+    return (y >= 0.0) ? (2.0 - r) : (-2.0 - r);
+}
+__device__ double angle_of_key(double k) {
+    // inverse of pseudo_angle: (|x|, y) proportional to (1 - |r|, r)
+    if (k > 1.0) {
+        const double r = 2.0 - k;
+        return atan2(r, -(1.0 - fabs(r)));
+    }
+    if (k < -1.0) {
+        const double r = -2.0 - k;
+        return atan2(r, -(1.0 - fabs(r)));
+    }
+    return atan2(k, 1.0 - fabs(k));
 }
 
 // 3x3 symmetric eigen-decomposition (cyclic Jacobi, f64).  a = xx,xy,xz,yy,yz,zz.
@@ -366,7 +436,7 @@ __device__ void jacobi3(const double (&a6)[6], double (&w)[3], double (&v)[3][3]
 // ---------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restrict__ img, long hw,
+__global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __restrict__ img, long hw,
                                                           const tia_stain_tables* __restrict__ tab,
                                                           tia_stain_params prm,
                                                           double* __restrict__ stats) {
@@ -378,26 +448,46 @@ __global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restri
 
     if (tid < TIA_STATS_STRIDE) out[tid] = 0.0;
     if (tid < 256) s.od[tid] = tab->od_lut[tid];
+    if (tid == 0) {
+        for (int i = 0; i < 16; ++i) s.tm[i] = 0;
+        s.tlast = clock64();
+    }
+    const long long t_begin = clock64();
 
-    // ---- P1: histogram of all bytes (per-wave private copies in the bins area) ---------------
-    unsigned* wh = &s.bins[0][0] + wave_id() * 256;
-    for (int i = tid; i < NW * 256; i += NT) (&s.bins[0][0])[i] = 0;
+    // ---- P1: per-channel byte histograms (per-wave private copies in the bins area) ------------
+    unsigned* wh = &s.bins[0][0] + wave_id() * 768;
+    for (int i = tid; i < NW * 768; i += NT) (&s.bins[0][0])[i] = 0;
     __syncthreads();
-    for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
+    for_each_pixel_w<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b, const WaveGroup& wg) {
         if (z1) {
             r = r ? r : 1u;
             g = g ? g : 1u;
             b = b ? b : 1u;
         }
-        atomicAdd(&wh[r], 1u);
-        atomicAdd(&wh[g], 1u);
-        atomicAdd(&wh[b], 1u);
+        hist_add(wh, (int)r, true, wg);
+        hist_add(wh + 256, (int)g, true, wg);
+        hist_add(wh + 512, (int)b, true, wg);
     });
     __syncthreads();
+    stamp(s, TM_P1);
+    {
+    double chm[6] = {0, 0, 0, 0, 0, 0};  // per-channel sum(od), sum(od^2) over ALL pixels
     if (tid < 256) {
-        unsigned h = 0;
-        for (int w = 0; w < NW; ++w) h += (&s.bins[0][0])[w * 256 + tid];
-        s.hist[tid] = h;
+        unsigned tot = 0;
+        const double o = s.od[tid];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            unsigned h = 0;
+            for (int w = 0; w < NW; ++w) h += (&s.bins[0][0])[w * 768 + c * 256 + tid];
+            s.hist3[c][tid] = h;
+            tot += h;
+            chm[c] = (double)h * o;
+            chm[3 + c] = (double)h * o * o;
+        }
+        s.hist[tid] = tot;
+    }
+    block_sum(chm, s);
+    if (tid < 6) s.chm[tid] = chm[tid];
     }
     __syncthreads();
     if (tid < 256) {
@@ -458,10 +548,21 @@ __global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restri
     }
     __syncthreads();
 
+    stamp(s, TM_LUT);
     const int y_thr = prm.y_thr;
     auto is_tissue = [&](uint32_t r, uint32_t g, uint32_t b) -> bool {
         const int t = s.ty[0][r] + s.ty[1][g] + s.ty[2][b];
         return ((t + (1 << 11)) >> 12) < y_thr;
+    };
+    // P2 records the mask as bits in LDS; later passes test a bit instead of three table look-ups
+    const bool use_bits = TIA_MASKBITS && hw <= (long)MASK_WORDS * 32;
+    if (use_bits && prm.mode == TIA_MODE_MACENKO) {
+        for (int i = tid; i < MASK_WORDS; i += NT) s.mbits[i] = 0;
+        __syncthreads();
+    }
+    auto is_tissue_cached = [&](long idx, uint32_t r, uint32_t g, uint32_t b) -> bool {
+        if (use_bits) return (s.mbits[idx >> 5] >> (idx & 31)) & 1u;
+        return is_tissue(r, g, b);
     };
 
     double S[6];  // source stain matrix rows H,E
@@ -469,12 +570,16 @@ __global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restri
 
     if (prm.mode == TIA_MODE_MACENKO) {
         // ---- P2: tissue mask + OD moments -----------------------------------------------------
-        double acc[10];
+        double acc[13];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) acc[i] = 0.0;
-        for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
+        for (int i = 0; i < 13; ++i) acc[i] = 0.0;
+        for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+            const double x = s.od[r], y = s.od[g], z = s.od[b];
+            acc[10] += x * y;  // all-pixel cross moments: exact variance of the concentrations
+            acc[11] += x * z;
+            acc[12] += y * z;
             if (is_tissue(r, g, b)) {
-                const double x = s.od[r], y = s.od[g], z = s.od[b];
+                if (use_bits) atomicOr(&s.mbits[idx >> 5], 1u << (idx & 31));
                 acc[0] += 1.0;
                 acc[1] += x;
                 acc[2] += y;
@@ -488,6 +593,8 @@ __global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restri
             }
         });
         block_sum(acc, s);
+        if (tid < 3) s.chx[tid] = acc[10 + tid];
+        stamp(s, TM_P2);
         const double nt = acc[0];
         const unsigned long long n_tissue = (unsigned long long)nt;
         if (n_tissue == 0) {
@@ -529,29 +636,35 @@ __global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restri
             out[TIA_ST_NTISSUE] = nt;
         }
         __syncthreads();
+        stamp(s, TM_EIG);
         const double e1x = s.bc[2], e1y = s.bc[3], e1z = s.bc[4];
         const double e2x = s.bc[5], e2y = s.bc[6], e2z = s.bc[7];
 
-        // ---- P3/P4: exact percentiles of phi = atan2(od.e2, od.e1) over tissue pixels ------------
+        // ---- P3/P4: exact percentiles of phi = atan2(od.e2, od.e1) over tissue pixels, selected on
+        //      the monotone pseudo-angle key ------------------------------------------------------
         unsigned long long kp[2], kn[2], nn[2] = {n_tissue, n_tissue};
         double gm[2];
         np_index(n_tissue, prm.q_phi_lo, kp[0], kn[0], gm[0]);
         np_index(n_tissue, prm.q_phi_hi, kp[1], kn[1], gm[1]);
-        const double lo0[2] = {-3.2, -3.2}, hi0[2] = {3.2, 3.2};
+        const double lo0[2] = {-2.0009765625, -2.0009765625}, hi0[2] = {2.0009765625, 2.0009765625};
         double vp[2], vn[2];
         select2(p, hw,
-                [&](long, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
-                    if (!is_tissue(r, g, b)) return 0u;
+                [&](long idx, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
+                    if (!is_tissue_cached(idx, r, g, b)) return 0u;
                     const double ox = s.od[r], oy = s.od[g], oz = s.od[b];
                     const double p0 = ox * e1x + oy * e1y + oz * e1z;
                     const double p1 = ox * e2x + oy * e2y + oz * e2z;
-                    x[0] = x[1] = atan2(p1, p0);
+                    x[0] = x[1] = pseudo_angle(p1, p0);
                     return 3u;
                 },
-                s, kp, nn, lo0, hi0, true, vp, vn);
+                s, kp, nn, lo0, hi0, lo0, hi0, true, vp, vn);
         if (tid == 0) {
-            const double min_phi = np_lerp(vp[0], vn[0], gm[0]);
-            const double max_phi = np_lerp(vp[1], vn[1], gm[1]);
+            s.tm[TM_PHI_TOTAL] = clock64() - t_begin;
+            s.tm[15] = s.st.level[0] * 1000000 + s.st.level[1] * 100000 + (long long)s.st.cnt[0] + (long long)s.st.cnt[1] * 0;
+        }
+        if (tid == 0) {
+            const double min_phi = np_lerp(angle_of_key(vp[0]), angle_of_key(vn[0]), gm[0]);
+            const double max_phi = np_lerp(angle_of_key(vp[1]), angle_of_key(vn[1]), gm[1]);
             out[TIA_ST_MINPHI] = min_phi;
             out[TIA_ST_MAXPHI] = max_phi;
             const double c1 = cos(min_phi), s1 = sin(min_phi), c2 = cos(max_phi), s2 = sin(max_phi);
@@ -573,6 +686,17 @@ __global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restri
     } else {
 #pragma unroll
         for (int i = 0; i < 6; ++i) S[i] = prm.stain_fixed[i];
+        double acc[3] = {0.0, 0.0, 0.0};
+        for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
+            const double x = s.od[r], y = s.od[g], z = s.od[b];
+            acc[0] += x * y;
+            acc[1] += x * z;
+            acc[2] += y * z;
+        });
+        block_sum(acc, s);
+        if (tid < 3) s.chx[tid] = acc[tid];
+        __syncthreads();
+        stamp(s, TM_P2);
     }
 
     // ---- pseudo-inverse: C = OD . P,  P = S^T (S S^T)^-1  (lstsq of stainnorm.py:65) ----------
@@ -602,20 +726,45 @@ __global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restri
         gm[1] = gm[0];
         // rigorous value bounds from the byte range: od in [od(bmax), od(bmin)]
         const double oa = s.od[bmax], ob = s.od[bmin];
-        double lo0[2], hi0[2];
+        double lo0[2], hi0[2], olo0[2], ohi0[2];
+        const double inv_n = 1.0 / (double)hw;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            double lo = 0.0, hi = 0.0;
+            double lo = 0.0, hi = 0.0, mu = 0.0;
+            double mj[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const double c = P[j * 2 + t];
                 const double u = c * oa, w = c * ob;
                 lo += u < w ? u : w;
                 hi += u < w ? w : u;
+                mj[j] = s.chm[j] * inv_n;
+                mu += c * mj[j];
             }
+            // exact variance of C_t over all pixels: P^T Cov P (diagonal terms from the per-channel
+            // histograms, cross terms from the moment pass)
+            const double cxx = s.chm[3] * inv_n - mj[0] * mj[0], cyy = s.chm[4] * inv_n - mj[1] * mj[1];
+            const double czz = s.chm[5] * inv_n - mj[2] * mj[2];
+            const double cxy = s.chx[0] * inv_n - mj[0] * mj[1], cxz = s.chx[1] * inv_n - mj[0] * mj[2];
+            const double cyz = s.chx[2] * inv_n - mj[1] * mj[2];
+            const double p0 = P[0 + t], p1 = P[2 + t], p2 = P[4 + t];
+            double var = p0 * p0 * cxx + p1 * p1 * cyy + p2 * p2 * czz +
+                         2.0 * (p0 * p1 * cxy + p0 * p2 * cxz + p1 * p2 * cyz);
+            var = var > 0.0 ? var : 0.0;
+            const double sg = sqrt(var) * 1.000001 + 1e-12 * (fabs(mu) + 1.0);
             const double pad = 1e-9 * (fabs(lo) + fabs(hi)) + 1e-12;
-            lo0[t] = lo - pad;
-            hi0[t] = hi + pad;
+            olo0[t] = lo - pad;
+            ohi0[t] = hi + pad;
+            // histogram window: Chebyshev keeps the 99th percentile inside mu + 12 sigma
+            double wlo = mu - 8.0 * sg, whi = mu + 12.0 * sg;
+            wlo = wlo > olo0[t] ? wlo : olo0[t];
+            whi = whi < ohi0[t] ? whi : ohi0[t];
+            if (!(whi > wlo)) {
+                wlo = olo0[t];
+                whi = ohi0[t];
+            }
+            lo0[t] = wlo;
+            hi0[t] = whi;
         }
         double vp[2], vn[2];
         select2(p, hw,
@@ -625,7 +774,13 @@ __global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restri
                     x[1] = ox * P[1] + oy * P[3] + oz * P[5];
                     return 3u;
                 },
-                s, kp, nn, lo0, hi0, false, vp, vn);
+                s, kp, nn, lo0, hi0, olo0, ohi0, false, vp, vn);
+        if (tid == 0) {
+            s.tm[11] = s.st.level[0];
+            s.tm[12] = s.st.level[1];
+            s.tm[13] = (long long)s.st.cnt[0];
+            s.tm[14] = (long long)s.st.cnt[1];
+        }
         maxc[0] = np_lerp(vp[0], vn[0], gm[0]);
         maxc[1] = np_lerp(vp[1], vn[1], gm[1]);
     }
@@ -651,6 +806,9 @@ __global__ __launch_bounds__(NT) void stain_stats_kernel(const uint8_t* __restri
                                                 P[j * 2 + 1] * sc1 * prm.target_stain[3 + c];
         }
         out[TIA_ST_FLAGS] = (double)flags;
+        s.tm[TM_TOTAL] = clock64() - t_begin;
+        s.tm[TM_CONC_TOTAL] = s.tm[TM_TOTAL] - s.tm[TM_PHI_TOTAL];
+        for (int i = 0; i < 16; ++i) out[TIA_ST_CYCLES + i] = (double)s.tm[i];
     }
 }
 
