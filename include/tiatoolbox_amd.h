@@ -134,6 +134,51 @@ int tia_luminosity_mask_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w
                            const tia_stain_tables* d_tables, const double* d_stats, int32_t y_thr,
                            int32_t zero_to_one, uint8_t* d_mask, void* stream);
 
+
+/* =======================================================================================
+ * Image primitives shared by the tissue maskers (tools/tissuemask.py) and the HoVer-Net
+ * post-processing (models/architecture/hovernet.py:502-616).  All images are [n,h,w] planes.
+ * ===================================================================================== */
+
+/* cv2.cvtColor(COLOR_RGB2GRAY) 8-bit: (R*9798 + G*19235 + B*3735 + 2^14) >> 15
+ * (tools/tissuemask.py:129,160,291).  d_img [npix,3] -> d_gray [npix]. */
+int tia_rgb2gray_u8(const uint8_t* d_img, int64_t npix, uint8_t* d_gray, void* stream);
+
+/* 256-bin histogram of bytes, ACCUMULATED into d_hist[256] (zero it first); feeds
+ * skimage.filters.threshold_otsu (tools/tissuemask.py:131-134). */
+int tia_hist256_u8(const uint8_t* d_data, int64_t n, uint32_t* d_hist, void* stream);
+
+/* mask = (gray < thr) as 0/1 bytes; with is_rgb the grey conversion is fused
+ * (tools/tissuemask.py:156-162, 288-296). */
+int tia_threshold_lt_u8(const uint8_t* d_src, int64_t npix, int32_t is_rgb, int32_t thr,
+                        uint8_t* d_mask, void* stream);
+
+/* Connected-component labelling of n binary planes (non-zero = foreground), connectivity 4 or 8.
+ * Labels are 1..K per plane, numbered in raster order of each component's first pixel
+ * (= scipy.ndimage.label, hovernet.py:543,607; cv2.connectedComponentsWithStats labelling,
+ * tissuemask.py:297).  d_labels [n,h,w] i32, d_count [n] i32, d_ws: n*h*w i32 scratch. */
+int tia_ccl_label_i32(const uint8_t* d_mask, int64_t n, int64_t h, int64_t w, int32_t connectivity,
+                      int32_t* d_labels, int32_t* d_count, int32_t* d_ws, void* stream);
+
+/* Zero every label whose pixel count is < min_keep (no relabelling):
+ * skimage remove_small_objects(max_size=s) == min_keep = s+1 (hovernet.py:544,614);
+ * MorphologicalMasker min_region_size == min_keep (tissuemask.py:297-301).
+ * d_ws: n*(h*w+1) i32 scratch (per-label areas). */
+int tia_label_area_filter_i32(int32_t* d_labels, int64_t n, int64_t h, int64_t w, int32_t min_keep,
+                              int32_t* d_ws, void* stream);
+
+/* Binary morphology with an arbitrary structuring element given as n_off (dy,dx) int32 pairs
+ * relative to the anchor.  op 0 = dilate (outside = 0), 1 = erode (outside = 1), i.e. OpenCV's
+ * morphologyEx with the default border value (tissuemask.py:303; hovernet.py:605-606). */
+int tia_binary_morph_u8(const uint8_t* d_src, int64_t n, int64_t h, int64_t w, const int32_t* d_offsets,
+                        int32_t n_off, int32_t op, uint8_t* d_dst, void* stream);
+
+/* scipy.ndimage.binary_fill_holes with the default (4-connected) structure (hovernet.py:604):
+ * background components not connected to the border become foreground.
+ * d_ws: (2*n*h*w + n) i32 scratch. */
+int tia_fill_holes_u8(const uint8_t* d_mask, int64_t n, int64_t h, int64_t w, uint8_t* d_out,
+                      int32_t* d_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,3 +159,92 @@ def mean_std_dev(chan: np.ndarray) -> tuple[float, float]:
     mean = s / n
     var = max(sq / n - mean * mean, 0.0)
     return mean, float(np.sqrt(var))
+
+
+# ------------------------------------------------------------------------------ morphology / CC
+def get_structuring_element_ellipse(ksize: tuple[int, int]) -> np.ndarray:
+    """``cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (w, h))`` (OpenCV ``morph.dispatch.cpp``).
+
+    Row ``i``: ``dy = i - r``; ``dx = round(c*sqrt((r*r - dy*dy)/r^2))``; ones on
+    ``[max(c-dx,0), min(c+dx+1, w))`` with ``r = h//2``, ``c = w//2``; ``(1,1)`` is a rectangle.
+    Call sites: ``tools/tissuemask.py:268``, ``models/architecture/hovernet.py:605``.
+    """
+    w, h = int(ksize[0]), int(ksize[1])
+    elem = np.zeros((h, w), dtype=np.uint8)
+    if (w, h) == (1, 1):
+        elem[:] = 1
+        return elem
+    r, c = h // 2, w // 2
+    inv_r2 = 1.0 / (r * r) if r else 0.0
+    for i in range(h):
+        dy = i - r
+        if abs(dy) <= r:
+            dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * inv_r2)))
+            j1, j2 = max(c - dx, 0), min(c + dx + 1, w)
+            elem[i, j1:j2] = 1
+    return elem
+
+
+def _morph(mask: np.ndarray, kernel: np.ndarray, *, erode: bool) -> np.ndarray:
+    """Binary erode/dilate with anchor at the kernel centre; OpenCV default border
+    (erode: outside counts as 1, dilate: outside counts as 0)."""
+    kh, kw = kernel.shape
+    ay, ax = kh // 2, kw // 2
+    h, w = mask.shape
+    src = mask != 0
+    out = np.ones((h, w), bool) if erode else np.zeros((h, w), bool)
+    for i in range(kh):
+        for j in range(kw):
+            if not kernel[i, j]:
+                continue
+            dy, dx = i - ay, j - ax
+            shifted = np.full((h, w), erode, dtype=bool)
+            ys, ye = max(0, -dy), min(h, h - dy)
+            xs, xe = max(0, -dx), min(w, w - dx)
+            if ys < ye and xs < xe:
+                shifted[ys:ye, xs:xe] = src[ys + dy:ye + dy, xs + dx:xe + dx]
+            out = (out & shifted) if erode else (out | shifted)
+    return out.astype(np.uint8)
+
+
+def morphology_ex(mask: np.ndarray, op: str, kernel: np.ndarray) -> np.ndarray:
+    """``cv2.morphologyEx`` for binary uint8 images: ``"DILATE"``, ``"ERODE"``, ``"OPEN"``."""
+    mask = np.asarray(mask)
+    if mask.ndim == 3 and mask.shape[-1] == 1:
+        mask = mask[..., 0]
+    if op == "DILATE":
+        return _morph(mask, kernel, erode=False)
+    if op == "ERODE":
+        return _morph(mask, kernel, erode=True)
+    if op == "OPEN":
+        return _morph(_morph(mask, kernel, erode=True), kernel, erode=False)
+    raise NotImplementedError(op)
+
+
+def connected_components_with_stats(mask: np.ndarray, connectivity: int = 8):
+    """``cv2.connectedComponentsWithStats``: ``(n, labels, stats, centroids)``; ``stats[:, -1]`` = area.
+    Labels follow the raster order of each component's first pixel (``scipy.ndimage.label``)."""
+    from scipy import ndimage
+
+    mask = np.asarray(mask)
+    if mask.ndim == 3 and mask.shape[-1] == 1:
+        mask = mask[..., 0]
+    structure = np.ones((3, 3), int) if connectivity == 8 else None
+    labels, n = ndimage.label(mask != 0, structure=structure)
+    stats = np.zeros((n + 1, 5), dtype=np.int32)
+    stats[:, 4] = np.bincount(labels.ravel(), minlength=n + 1)
+    return n + 1, labels.astype(np.int32), stats, None
+
+
+# names used by tests/golden/_refshim.py to stand in for the cv2 functions
+def getStructuringElement(shape, ksize):  # noqa: N802
+    assert shape == "ELLIPSE"
+    return get_structuring_element_ellipse(tuple(int(k) for k in ksize))
+
+
+def morphologyEx(src, op, kernel):  # noqa: N802
+    return morphology_ex(src, op, kernel)
+
+
+def connectedComponentsWithStats(mask, connectivity=8):  # noqa: N802
+    return connected_components_with_stats(mask, connectivity)

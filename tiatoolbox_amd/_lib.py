@@ -54,6 +54,13 @@ _SIGNATURES = {
     "tia_stain_concentrations_f64": ([_P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
     "tia_stain_augment_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P], C.c_int),
     "tia_luminosity_mask_u8": ([_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _P, _P], C.c_int),
+    "tia_rgb2gray_u8": ([_P, _I64, _P, _P], C.c_int),
+    "tia_hist256_u8": ([_P, _I64, _P, _P], C.c_int),
+    "tia_threshold_lt_u8": ([_P, _I64, _I32, _I32, _P, _P], C.c_int),
+    "tia_ccl_label_i32": ([_P, _I64, _I64, _I64, _I32, _P, _P, _P, _P], C.c_int),
+    "tia_label_area_filter_i32": ([_P, _I64, _I64, _I64, _I32, _P, _P], C.c_int),
+    "tia_binary_morph_u8": ([_P, _I64, _I64, _I64, _P, _I32, _I32, _P, _P], C.c_int),
+    "tia_fill_holes_u8": ([_P, _I64, _I64, _I64, _P, _P, _P], C.c_int),
 }
 
 

@@ -1,0 +1,331 @@
+// Image primitives on gfx950: grey conversion, byte histogram, thresholding, connected-component
+// labelling (union-find with atomicMin, raster-ordered relabel), label-area filtering, binary
+// morphology with an arbitrary structuring element, hole filling.
+// Reference call sites: tools/tissuemask.py:99-164,270-306; models/architecture/hovernet.py:541-545,
+// 604-614 (scipy.ndimage.label / binary_fill_holes, skimage remove_small_objects, cv2.morphologyEx).
+#include "common.hpp"
+
+namespace tia {
+
+constexpr int BT = 256;
+
+static inline unsigned nblocks(long n, int per = BT, long cap = 65535L * 16) {
+    long b = (n + per - 1) / per;
+    if (b > cap) b = cap;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+// ---- grey / histogram / threshold ----------------------------------------------------------------------
+__device__ __forceinline__ uint32_t gray_of(uint32_t r, uint32_t g, uint32_t b) {
+    return (r * 9798u + g * 19235u + b * 3735u + (1u << 14)) >> 15;
+}
+
+__global__ __launch_bounds__(BT) void rgb2gray_kernel(const uint8_t* __restrict__ img, long npix,
+                                                       uint8_t* __restrict__ gray) {
+    const long ng = npix >> 2;
+    const long stride = (long)gridDim.x * BT;
+    const bool fast = ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(gray)) & 3) == 0;
+    if (fast) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(img);
+        uint32_t* o = reinterpret_cast<uint32_t*>(gray);
+        for (long g = (long)blockIdx.x * BT + threadIdx.x; g < ng; g += stride) {
+            const uint32_t a = q[g * 3], b = q[g * 3 + 1], c = q[g * 3 + 2];
+            const uint32_t g0 = gray_of(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
+            const uint32_t g1 = gray_of(a >> 24, b & 255u, (b >> 8) & 255u);
+            const uint32_t g2 = gray_of((b >> 16) & 255u, b >> 24, c & 255u);
+            const uint32_t g3 = gray_of((c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
+            o[g] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+        }
+        for (long i = ng * 4 + (long)blockIdx.x * BT + threadIdx.x; i < npix; i += stride)
+            gray[i] = (uint8_t)gray_of(img[3 * i], img[3 * i + 1], img[3 * i + 2]);
+    } else {
+        for (long i = (long)blockIdx.x * BT + threadIdx.x; i < npix; i += stride)
+            gray[i] = (uint8_t)gray_of(img[3 * i], img[3 * i + 1], img[3 * i + 2]);
+    }
+}
+
+__global__ __launch_bounds__(BT) void hist256_kernel(const uint8_t* __restrict__ data, long n,
+                                                      uint32_t* __restrict__ hist) {
+    __shared__ unsigned h[4][256];  // one private copy per wave
+    for (int i = threadIdx.x; i < 1024; i += BT) (&h[0][0])[i] = 0;
+    __syncthreads();
+    unsigned* mine = h[wave_id()];
+    const long stride = (long)gridDim.x * BT;
+    const long nw = ((reinterpret_cast<uintptr_t>(data) & 3) == 0) ? (n >> 2) : 0;
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(data);
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < nw; i += stride) {
+        const uint32_t v = q[i];
+        atomicAdd(&mine[v & 255u], 1u);
+        atomicAdd(&mine[(v >> 8) & 255u], 1u);
+        atomicAdd(&mine[(v >> 16) & 255u], 1u);
+        atomicAdd(&mine[v >> 24], 1u);
+    }
+    for (long i = nw * 4 + (long)blockIdx.x * BT + threadIdx.x; i < n; i += stride) atomicAdd(&mine[data[i]], 1u);
+    __syncthreads();
+    const unsigned t = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+    if (t) atomicAdd(&hist[threadIdx.x], t);
+}
+
+__global__ __launch_bounds__(BT) void threshold_lt_kernel(const uint8_t* __restrict__ src, long npix, int is_rgb,
+                                                           int thr, uint8_t* __restrict__ mask) {
+    const long stride = (long)gridDim.x * BT;
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < npix; i += stride) {
+        const int g = is_rgb ? (int)gray_of(src[3 * i], src[3 * i + 1], src[3 * i + 2]) : (int)src[i];
+        mask[i] = g < thr ? 1 : 0;
+    }
+}
+
+// ---- connected components ------------------------------------------------------------------------------
+__device__ __forceinline__ int uf_find(const int* __restrict__ L, int i) {
+    int p = L[i];
+    while (p != i) {
+        i = p;
+        p = L[i];
+    }
+    return i;
+}
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+    while (true) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&L[a], b);  // hook the larger root under the smaller index
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// INVERT: label the background (zero pixels) instead (used by fill-holes)
+template <bool INVERT>
+__global__ __launch_bounds__(BT) void ccl_init_kernel(const uint8_t* __restrict__ mask, long hw, int* __restrict__ L) {
+    const uint8_t* m = mask + (size_t)blockIdx.y * hw;
+    int* l = L + (size_t)blockIdx.y * hw;
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
+        const bool fg = INVERT ? (m[i] == 0) : (m[i] != 0);
+        l[i] = fg ? (int)i : -1;
+    }
+}
+
+__global__ __launch_bounds__(BT) void ccl_merge_kernel(int* __restrict__ L, int h, int w, int conn8) {
+    const long hw = (long)h * w;
+    int* l = L + (size_t)blockIdx.y * hw;
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
+        if (l[i] < 0) continue;
+        const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        if (x > 0 && l[i - 1] >= 0) uf_union(l, (int)i, (int)i - 1);
+        if (y > 0) {
+            if (l[i - w] >= 0) uf_union(l, (int)i, (int)(i - w));
+            if (conn8) {
+                if (x > 0 && l[i - w - 1] >= 0) uf_union(l, (int)i, (int)(i - w - 1));
+                if (x < w - 1 && l[i - w + 1] >= 0) uf_union(l, (int)i, (int)(i - w + 1));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BT) void ccl_flatten_kernel(int* __restrict__ L, long hw) {
+    int* l = L + (size_t)blockIdx.y * hw;
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT)
+        if (l[i] >= 0) l[i] = uf_find(l, (int)i);
+}
+
+// One workgroup per plane: rank the roots (pixels with L[i]==i) in raster order.
+// rank[root] = 1-based component number; count[plane] = number of components.
+__global__ __launch_bounds__(1024) void ccl_rank_kernel(const int* __restrict__ L, long hw, int* __restrict__ rank,
+                                                         int* __restrict__ count) {
+    __shared__ unsigned wtot[16];
+    const int* l = L + (size_t)blockIdx.x * hw;
+    int* r = rank + (size_t)blockIdx.x * hw;
+    const long chunk = (hw + 1023) / 1024;
+    const long lo = (long)threadIdx.x * chunk, hi = lo + chunk < hw ? lo + chunk : hw;
+    unsigned c = 0;
+    for (long i = lo; i < hi; ++i) c += (l[i] == (int)i) ? 1u : 0u;
+    const unsigned incl = wave_incl_scan_u32(c);
+    if (lane_id() == 63) wtot[wave_id()] = incl;
+    __syncthreads();
+    unsigned before = incl - c;
+    for (int wv = 0; wv < wave_id(); ++wv) before += wtot[wv];
+    for (long i = lo; i < hi; ++i)
+        if (l[i] == (int)i) r[i] = (int)(++before);
+    if (threadIdx.x == 1023) count[blockIdx.x] = (int)before;
+}
+
+__global__ __launch_bounds__(BT) void ccl_apply_rank_kernel(const int* __restrict__ L, const int* __restrict__ rank,
+                                                             long hw, int* __restrict__ labels) {
+    const size_t off = (size_t)blockIdx.y * hw;
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
+        const int root = L[off + i];
+        labels[off + i] = root >= 0 ? rank[off + root] : 0;
+    }
+}
+
+static int ccl_run(const uint8_t* d_mask, long n, int h, int w, int conn, int* d_labels, int* d_count, int* d_ws,
+                   bool invert, hipStream_t st) {
+    const long hw = (long)h * w;
+    dim3 grid(nblocks(hw, BT, 4096), (unsigned)n);
+    // d_labels doubles as the union-find array; d_ws holds the ranks
+    if (invert)
+        hipLaunchKernelGGL(ccl_init_kernel<true>, grid, dim3(BT), 0, st, d_mask, hw, d_labels);
+    else
+        hipLaunchKernelGGL(ccl_init_kernel<false>, grid, dim3(BT), 0, st, d_mask, hw, d_labels);
+    hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(BT), 0, st, d_labels, h, w, conn == 8 ? 1 : 0);
+    hipLaunchKernelGGL(ccl_flatten_kernel, grid, dim3(BT), 0, st, d_labels, hw);
+    hipLaunchKernelGGL(ccl_rank_kernel, dim3((unsigned)n), dim3(1024), 0, st, d_labels, hw, d_ws, d_count);
+    // in-place: labels[i] = rank[root]; safe because rank lives in d_ws and roots are read before written
+    // only within the same element (labels[i] is overwritten after reading L[i] == labels[i]); other threads
+    // still need L[root] == root semantics?  No: apply reads L[i] only (already flattened).
+    hipLaunchKernelGGL(ccl_apply_rank_kernel, grid, dim3(BT), 0, st, d_labels, d_ws, hw, d_labels);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+// ---- label areas -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BT) void area_count_kernel(const int* __restrict__ labels, long hw, int* __restrict__ areas) {
+    const size_t off = (size_t)blockIdx.y * hw;
+    int* a = areas + (size_t)blockIdx.y * (hw + 1);
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
+        const int l = labels[off + i];
+        if (l > 0) atomicAdd(&a[l], 1);
+    }
+}
+__global__ __launch_bounds__(BT) void area_filter_kernel(int* __restrict__ labels, long hw, const int* __restrict__ areas,
+                                                          int min_keep) {
+    const size_t off = (size_t)blockIdx.y * hw;
+    const int* a = areas + (size_t)blockIdx.y * (hw + 1);
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
+        const int l = labels[off + i];
+        if (l > 0 && a[l] < min_keep) labels[off + i] = 0;
+    }
+}
+
+// ---- binary morphology -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BT) void morph_kernel(const uint8_t* __restrict__ src, int h, int w,
+                                                    const int* __restrict__ offs, int n_off, int op,
+                                                    uint8_t* __restrict__ dst) {
+    const long hw = (long)h * w;
+    const uint8_t* s = src + (size_t)blockIdx.y * hw;
+    uint8_t* d = dst + (size_t)blockIdx.y * hw;
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
+        const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        bool any = false, all = true;
+        for (int k = 0; k < n_off; ++k) {
+            const int yy = y + offs[2 * k], xx = x + offs[2 * k + 1];
+            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;  // dilate: outside = 0; erode: outside = 1
+            const bool v = s[(long)yy * w + xx] != 0;
+            any = any || v;
+            all = all && v;
+        }
+        d[i] = (op == 0 ? any : all) ? 1 : 0;
+    }
+}
+
+// ---- fill holes ------------------------------------------------------------------------------------------------
+// after CCL of the background: mark background components that touch the border
+__global__ __launch_bounds__(BT) void border_mark_kernel(const int* __restrict__ labels, int h, int w, int* __restrict__ flag) {
+    const long hw = (long)h * w;
+    const int* l = labels + (size_t)blockIdx.y * hw;
+    int* f = flag + (size_t)blockIdx.y * hw;
+    const long nb = 2L * w + 2L * h;
+    for (long k = (long)blockIdx.x * BT + threadIdx.x; k < nb; k += (long)gridDim.x * BT) {
+        long i;
+        if (k < w) i = k;
+        else if (k < 2L * w) i = (long)(h - 1) * w + (k - w);
+        else if (k < 2L * w + h) i = (k - 2L * w) * w;
+        else i = (k - 2L * w - h) * w + (w - 1);
+        const int lab = l[i];
+        if (lab > 0) f[lab - 1] = 1;
+    }
+}
+__global__ __launch_bounds__(BT) void fill_apply_kernel(const uint8_t* __restrict__ mask, const int* __restrict__ labels,
+                                                         const int* __restrict__ flag, long hw, uint8_t* __restrict__ out) {
+    const size_t off = (size_t)blockIdx.y * hw;
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
+        const int lab = labels[off + i];  // > 0 only on background pixels
+        const bool hole = lab > 0 && flag[off + lab - 1] == 0;
+        out[off + i] = (mask[off + i] != 0 || hole) ? 1 : 0;
+    }
+}
+
+}  // namespace tia
+
+using namespace tia;
+
+static bool bad3(int64_t n, int64_t h, int64_t w) {
+    return n <= 0 || h <= 0 || w <= 0 || n > 65535 || h * w > 0x7fffffffLL;
+}
+
+extern "C" int tia_rgb2gray_u8(const uint8_t* d_img, int64_t npix, uint8_t* d_gray, void* stream) {
+    if (!d_img || !d_gray || npix <= 0) return TIA_EINVAL;
+    hipLaunchKernelGGL(rgb2gray_kernel, dim3(nblocks(npix >> 2 ? npix >> 2 : 1)), dim3(BT), 0, (hipStream_t)stream, d_img,
+                       (long)npix, d_gray);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_hist256_u8(const uint8_t* d_data, int64_t n, uint32_t* d_hist, void* stream) {
+    if (!d_data || !d_hist || n <= 0) return TIA_EINVAL;
+    hipLaunchKernelGGL(hist256_kernel, dim3(nblocks(n >> 2 ? n >> 2 : 1, BT, 2048)), dim3(BT), 0, (hipStream_t)stream,
+                       d_data, (long)n, d_hist);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_threshold_lt_u8(const uint8_t* d_src, int64_t npix, int32_t is_rgb, int32_t thr, uint8_t* d_mask,
+                                    void* stream) {
+    if (!d_src || !d_mask || npix <= 0) return TIA_EINVAL;
+    hipLaunchKernelGGL(threshold_lt_kernel, dim3(nblocks(npix)), dim3(BT), 0, (hipStream_t)stream, d_src, (long)npix,
+                       is_rgb, thr, d_mask);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_ccl_label_i32(const uint8_t* d_mask, int64_t n, int64_t h, int64_t w, int32_t connectivity,
+                                  int32_t* d_labels, int32_t* d_count, int32_t* d_ws, void* stream) {
+    if (!d_mask || !d_labels || !d_count || !d_ws) return TIA_EINVAL;
+    if (bad3(n, h, w)) return TIA_ESIZE;
+    if (connectivity != 4 && connectivity != 8) return TIA_EINVAL;
+    return ccl_run(d_mask, n, (int)h, (int)w, connectivity, d_labels, d_count, d_ws, false, (hipStream_t)stream);
+}
+
+extern "C" int tia_label_area_filter_i32(int32_t* d_labels, int64_t n, int64_t h, int64_t w, int32_t min_keep,
+                                          int32_t* d_ws, void* stream) {
+    if (!d_labels || !d_ws) return TIA_EINVAL;
+    if (bad3(n, h, w)) return TIA_ESIZE;
+    const long hw = (long)h * w;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(d_ws, 0, (size_t)n * (hw + 1) * sizeof(int32_t), st) != hipSuccess) return TIA_ELAUNCH;
+    dim3 grid(nblocks(hw, BT, 4096), (unsigned)n);
+    hipLaunchKernelGGL(area_count_kernel, grid, dim3(BT), 0, st, d_labels, hw, d_ws);
+    hipLaunchKernelGGL(area_filter_kernel, grid, dim3(BT), 0, st, d_labels, hw, d_ws, min_keep);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_binary_morph_u8(const uint8_t* d_src, int64_t n, int64_t h, int64_t w, const int32_t* d_offsets,
+                                    int32_t n_off, int32_t op, uint8_t* d_dst, void* stream) {
+    if (!d_src || !d_dst || !d_offsets || n_off <= 0 || (op != 0 && op != 1)) return TIA_EINVAL;
+    if (bad3(n, h, w)) return TIA_ESIZE;
+    dim3 grid(nblocks((long)h * w, BT, 4096), (unsigned)n);
+    hipLaunchKernelGGL(morph_kernel, grid, dim3(BT), 0, (hipStream_t)stream, d_src, (int)h, (int)w, d_offsets, n_off,
+                       op, d_dst);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_fill_holes_u8(const uint8_t* d_mask, int64_t n, int64_t h, int64_t w, uint8_t* d_out,
+                                  int32_t* d_ws, void* stream) {
+    if (!d_mask || !d_out || !d_ws) return TIA_EINVAL;
+    if (bad3(n, h, w)) return TIA_ESIZE;
+    const long hw = (long)h * w;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* labels = d_ws;
+    int32_t* aux = d_ws + (size_t)n * hw;        // ranks, then border flags
+    int32_t* counts = d_ws + 2 * (size_t)n * hw;  // [n] component counts (unused by the caller)
+    const int rc = ccl_run(d_mask, n, (int)h, (int)w, 4, labels, counts, aux, true, st);
+    if (rc != TIA_OK) return rc;
+    if (hipMemsetAsync(aux, 0, (size_t)n * hw * sizeof(int32_t), st) != hipSuccess) return TIA_ELAUNCH;
+    dim3 gb(nblocks(2L * (h + w), BT, 64), (unsigned)n);
+    hipLaunchKernelGGL(border_mark_kernel, gb, dim3(BT), 0, st, labels, (int)h, (int)w, aux);
+    dim3 grid(nblocks(hw, BT, 4096), (unsigned)n);
+    hipLaunchKernelGGL(fill_apply_kernel, grid, dim3(BT), 0, st, d_mask, labels, aux, hw, d_out);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}

@@ -1,0 +1,155 @@
+"""Tissue maskers (API of reference ``tiatoolbox/tools/tissuemask.py``).
+
+``OtsuTissueMasker``: grey conversion + one global 256-bin histogram on the GPU, Otsu's
+threshold from the 256 counts on the host, thresholding fused with the grey conversion.
+``MorphologicalMasker``: + 8-connected component labelling, small-region removal and
+elliptical dilation, all on the GPU.  uint8 RGB / single-channel inputs take the HIP path;
+other dtypes (the reference's own known-answer test feeds 0/1 floats) are histogrammed with
+torch on the device (256 linear bins, as scikit-image does for float images).
+"""
+
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+
+from tiatoolbox_amd.tools import _img_device as img
+from tiatoolbox_amd.utils import _tensors
+
+
+def objective_power2mpp(objective_power):
+    """Reference ``utils/misc.py:346-374``."""
+    return 10.0 / np.array(objective_power)
+
+
+def _otsu_from_counts(counts: np.ndarray, centers: np.ndarray) -> float:
+    """Otsu's threshold from a histogram (scikit-image ``threshold_otsu`` arithmetic)."""
+    counts = counts.astype(np.float64)
+    weight1 = np.cumsum(counts)
+    weight2 = np.cumsum(counts[::-1])[::-1]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mean1 = np.cumsum(counts * centers) / weight1
+        mean2 = (np.cumsum((counts * centers)[::-1]) / weight2[::-1])[::-1]
+    variance12 = weight1[:-1] * weight2[1:] * (mean1[:-1] - mean2[1:]) ** 2
+    return centers[int(np.nanargmax(variance12))]
+
+
+class TissueMasker(ABC):
+    """Tissue masker base class (ref. :14-72)."""
+
+    @abstractmethod
+    def fit(self, images, masks=None) -> None:
+        ...
+
+    @abstractmethod
+    def transform(self, images):
+        ...
+
+    def fit_transform(self, images, **kwargs):
+        self.fit(images, masks=None, **kwargs)
+        return self.transform(images)
+
+
+def _to_device_images(images) -> tuple[torch.Tensor, bool]:
+    """List / array of images -> one device tensor [N,H,W,C]; flag = result as NumPy."""
+    if isinstance(images, torch.Tensor):
+        t = images if images.is_cuda else images.to(_tensors.default_device())
+        return t, False
+    arr = np.asarray(images)
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(_tensors.default_device()), True
+
+
+class OtsuTissueMasker(TissueMasker):
+    """Otsu threshold over all pixels of all images (ref. :75-164)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.threshold = None
+        self.fitted = False
+
+    def fit(self, images, masks=None) -> None:  # noqa: ARG002
+        images_shape = tuple(images.shape) if isinstance(images, torch.Tensor) else np.shape(images)
+        if len(images_shape) != 4:  # noqa: PLR2004
+            msg = (f"Expected 4 dimensional input shape (N, height, width, 3) "
+                   f"but received shape of {images_shape}.")
+            raise ValueError(msg)
+        t, _ = _to_device_images(images)
+        if t.dtype == torch.uint8:
+            grey = img.rgb2gray(t) if t.shape[-1] == 3 else t[..., 0].contiguous()  # noqa: PLR2004
+            counts = img.hist256(grey).cpu().numpy().astype(np.int64)
+            nz = np.flatnonzero(counts)
+            if nz.size == 1:
+                self.threshold = int(nz[0])
+            else:
+                lo, hi = int(nz[0]), int(nz[-1])
+                self.threshold = int(_otsu_from_counts(counts[lo:hi + 1], np.arange(lo, hi + 1, dtype=np.float64)))
+        else:
+            grey = t[..., 0].to(torch.float64)
+            lo, hi = float(grey.min()), float(grey.max())
+            if lo == hi:
+                self.threshold = lo
+            else:
+                counts = torch.histc(grey, bins=256, min=lo, max=hi).cpu().numpy()
+                edges = np.linspace(lo, hi, 257)
+                self.threshold = float(_otsu_from_counts(counts, (edges[:-1] + edges[1:]) / 2.0))
+        self.fitted = True
+
+    def _masks(self, t: torch.Tensor) -> torch.Tensor:
+        if t.dtype == torch.uint8:
+            is_rgb = t.dim() == 4 and t.shape[-1] == 3  # noqa: PLR2004
+            src = t if is_rgb else (t[..., 0].contiguous() if t.dim() == 4 else t)  # noqa: PLR2004
+            # grey < threshold with an integer grey: equivalent integer bound
+            thr = int(np.ceil(self.threshold)) if float(self.threshold) != int(self.threshold) else int(self.threshold)
+            return img.threshold_lt(src, thr, is_rgb=is_rgb)
+        grey = t[..., 0] if t.dim() == 4 else t  # noqa: PLR2004
+        return (grey < self.threshold).to(torch.uint8)
+
+    def transform(self, images):
+        if not self.fitted:
+            msg = "Fit must be called before transform."
+            raise SyntaxError(msg)
+        t, as_numpy = _to_device_images(images)
+        masks = self._masks(t).bool()
+        return masks.cpu().numpy() if as_numpy else masks
+
+
+class MorphologicalMasker(OtsuTissueMasker):
+    """Otsu + small-region removal (8-connected) + elliptical dilation (ref. :167-306)."""
+
+    def __init__(self, *, mpp=None, power=None, kernel_size=None, min_region_size=None) -> None:
+        super().__init__()
+        self.min_region_size = min_region_size
+        self.threshold = None
+        if sum(arg is not None for arg in [mpp, power, kernel_size]) > 1:
+            msg = "Only one of mpp, power, kernel_size can be given."
+            raise ValueError(msg)
+        if all(arg is None for arg in [mpp, power, kernel_size]):
+            kernel_size = np.array([1, 1])
+        if power is not None:
+            mpp = objective_power2mpp(power)
+        if mpp is not None:
+            mpp_array = np.array(mpp)
+            if mpp_array.size != 2:  # noqa: PLR2004
+                mpp_array = mpp_array.repeat(2)
+            kernel_size = np.max([32 / mpp_array, np.array([1, 1])], axis=0)
+        kernel_size_array = np.array(kernel_size)
+        if kernel_size_array.size != 2:  # noqa: PLR2004
+            kernel_size_array = kernel_size_array.repeat(2)
+        self.kernel_size = tuple(np.round(kernel_size_array).astype(int))
+        self.kernel = img.get_structuring_element_ellipse(self.kernel_size)
+        if self.min_region_size is None:
+            self.min_region_size = int(np.sum(self.kernel))
+
+    def transform(self, images):
+        if not self.fitted:
+            msg = "Fit must be called before transform."
+            raise SyntaxError(msg)
+        t, as_numpy = _to_device_images(images)
+        mask = self._masks(t)
+        labels, _ = img.ccl_label(mask, connectivity=8)
+        img.label_area_filter(labels, int(self.min_region_size))
+        keep = (labels > 0).to(torch.uint8)
+        out = img.binary_morph(keep, img.offsets_of(self.kernel, keep.device), "dilate").bool()
+        return out.cpu().numpy() if as_numpy else out
