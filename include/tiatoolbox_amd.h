@@ -179,6 +179,40 @@ int tia_binary_morph_u8(const uint8_t* d_src, int64_t n, int64_t h, int64_t w, c
 int tia_fill_holes_u8(const uint8_t* d_mask, int64_t n, int64_t h, int64_t w, uint8_t* d_out,
                       int32_t* d_ws, void* stream);
 
+
+/* =======================================================================================
+ * HoVer-Net post-processing (models/architecture/hovernet.py:502-748)
+ * ===================================================================================== */
+
+/* Bytes of scratch tia_hover_proc_np_hv_f32 needs for n planes of h x w. */
+size_t tia_hover_workspace_bytes(int64_t n, int64_t h, int64_t w);
+
+/*
+ * HoVerNet._proc_np_hv (hovernet.py:502-616) for n patches/tiles at once:
+ * binarise np>=0.5 -> 4-connected labelling -> drop objects <= 9 px -> min-max normalise the
+ * h/v maps (f32) -> Sobel ksize (CV_64F, separable, REFLECT_101) -> normalise (f32) ->
+ * energy / distance maps (f64) -> 3x3 Gaussian -> marker = blb - (overall>=0.4), fill holes,
+ * 5x5 elliptical opening, labelling, drop objects < obj_size -> marker-controlled watershed
+ * (priority flood, one independent flood per mask blob).
+ *   d_np [n,h,w] f32   d_hv [n,h,w,2] f32   d_inst [n,h,w] i32 (instance ids = marker ids)
+ *   d_ninst [n] i32 (number of marker labels = max possible id)
+ */
+int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, int64_t n, int64_t h, int64_t w,
+                             int32_t ksize, int32_t obj_size, int32_t* d_inst, int32_t* d_ninst,
+                             void* d_ws, size_t ws_bytes, void* stream);
+
+/*
+ * Per-instance statistics for HoVerNet.get_instance_info (hovernet.py:670-748): for every id in
+ * 1..max_inst of every plane: pixel count, bounding box (x_min,y_min,x_max,y_max inclusive),
+ * sum of x, sum of y, and the histogram of d_type (uint8, may be NULL) over its pixels.
+ *   d_stats [n, max_inst+1, 8] i64 = area, xmin, ymin, xmax, ymax, sumx, sumy, 0
+ *   d_types [n, max_inst+1, num_types] i32
+ * Both must be zero-initialised except xmin/ymin which the call initialises itself.
+ */
+int tia_hover_instance_stats(const int32_t* d_inst, const uint8_t* d_type, int64_t n, int64_t h, int64_t w,
+                             int32_t max_inst, int32_t num_types, int64_t* d_stats, int32_t* d_types,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -248,3 +248,119 @@ def morphologyEx(src, op, kernel):  # noqa: N802
 
 def connectedComponentsWithStats(mask, connectivity=8):  # noqa: N802
     return connected_components_with_stats(mask, connectivity)
+
+
+# ------------------------------------------------------------------------ filtering (HoVer-Net)
+def normalize_minmax_to_f32(src: np.ndarray) -> np.ndarray:
+    """``cv2.normalize(src, None, alpha=0, beta=1, norm_type=NORM_MINMAX, dtype=CV_32F)``.
+
+    ``scale = 1/(max-min)`` (0 when ``max-min < DBL_EPSILON``), ``shift = -min*scale``, then
+    ``convertTo``: float32 sources are scaled in float32 arithmetic, float64 sources in float64
+    and then rounded to float32.  No fused multiply-add is assumed (unverifiable here; see
+    DESIGN.md "parity unpinned").  Call sites: ``models/architecture/hovernet.py:547-590``.
+    """
+    src = np.asarray(src)
+    smin, smax = float(src.min()), float(src.max())
+    rng = smax - smin
+    scale = 1.0 / rng if rng > np.finfo(np.float64).eps else 0.0
+    shift = 0.0 - smin * scale
+    if src.dtype == np.float32:
+        a, b = np.float32(scale), np.float32(shift)
+        return (src * a).astype(np.float32) + b
+    return (src.astype(np.float64) * scale + shift).astype(np.float32)
+
+
+def _reflect101(idx: np.ndarray, n: int) -> np.ndarray:
+    """OpenCV BORDER_REFLECT_101 index mapping (gfedcb|abcdefgh|gfedcba)."""
+    if n == 1:
+        return np.zeros_like(idx)
+    period = 2 * (n - 1)
+    idx = np.mod(idx, period)
+    return np.where(idx >= n, period - idx, idx)
+
+
+def sobel_kernels(ksize: int, dx: int, dy: int) -> tuple[np.ndarray, np.ndarray]:
+    """``cv2.getDerivKernels`` for Sobel with ``ksize > 3`` (``getSobelKernels``): integer kernels
+    built by repeated [1,1] smoothing and [-1,1] differencing; returned as float64 (kx, ky)."""
+    out = []
+    for order in (dx, dy):
+        ker = np.zeros(ksize + 1, dtype=np.int64)
+        ker[0] = 1
+        for _ in range(ksize - order - 1):
+            oldval = ker[0]
+            for j in range(1, ksize + 1):
+                newval = ker[j] + ker[j - 1]
+                ker[j - 1] = oldval
+                oldval = newval
+        for _ in range(order):
+            oldval = -ker[0]
+            for j in range(1, ksize + 1):
+                newval = ker[j - 1] - ker[j]
+                ker[j - 1] = oldval
+                oldval = newval
+        out.append(ker[:ksize].astype(np.float64))
+    return out[0], out[1]
+
+
+def _row_filter(src: np.ndarray, kx: np.ndarray) -> np.ndarray:
+    """OpenCV ``RowFilter<ST,double>``: ``s = kx[0]*S[0]; s += kx[k]*S[k]`` for k ascending (f64)."""
+    h, w = src.shape
+    anchor = len(kx) // 2
+    cols = _reflect101(np.arange(w)[None, :] + (np.arange(len(kx))[:, None] - anchor), w)
+    s64 = src.astype(np.float64)
+    acc = kx[0] * s64[:, cols[0]]
+    for k in range(1, len(kx)):
+        acc = acc + kx[k] * s64[:, cols[k]]
+    return acc
+
+
+def _column_filter(buf: np.ndarray, ky: np.ndarray, *, symmetric: bool) -> np.ndarray:
+    """OpenCV ``SymmColumnFilter``: centre tap then paired taps ``ky[k]*(S[+k] +/- S[-k])``."""
+    h, w = buf.shape
+    c = len(ky) // 2
+    rows = np.arange(h)
+    if symmetric:
+        acc = ky[c] * buf[rows, :] + 0.0
+    else:
+        acc = np.zeros_like(buf)
+    for k in range(1, c + 1):
+        up = buf[_reflect101(rows + k, h), :]
+        dn = buf[_reflect101(rows - k, h), :]
+        acc = acc + ky[c + k] * ((up + dn) if symmetric else (up - dn))
+    return acc
+
+
+def sobel_f64(src: np.ndarray, dx: int, dy: int, ksize: int) -> np.ndarray:
+    """``cv2.Sobel(src, cv2.CV_64F, dx, dy, ksize=ksize)`` (``ksize > 3``; BORDER_REFLECT_101).
+
+    Separable: generic row filter with ``kx`` (sequential taps, f64), then the (anti)symmetric
+    column filter with ``ky``.  Call sites: ``hovernet.py:568-569``.
+    """
+    kx, ky = sobel_kernels(ksize, dx, dy)
+    buf = _row_filter(np.asarray(src), kx)
+    return _column_filter(buf, ky, symmetric=(dy % 2 == 0))
+
+
+def gaussian_blur3_f64(src: np.ndarray) -> np.ndarray:
+    """``cv2.GaussianBlur(src, (3, 3), 0)`` for float64: fixed kernel [1/4, 1/2, 1/4], separable,
+    symmetric small filters ``S[0]*k0 + (S[-1] + S[1])*k1``, BORDER_REFLECT_101 (``hovernet.py:598``)."""
+    src = np.asarray(src, dtype=np.float64)
+    h, w = src.shape
+    k0, k1 = 0.5, 0.25
+    xs = np.arange(w)
+    row = src * k0 + (src[:, _reflect101(xs - 1, w)] + src[:, _reflect101(xs + 1, w)]) * k1
+    ys = np.arange(h)
+    return row * k0 + (row[_reflect101(ys - 1, h), :] + row[_reflect101(ys + 1, h), :]) * k1
+
+
+def normalize(src, dst=None, alpha=0, beta=1, norm_type=None, dtype=None):  # noqa: ARG001
+    return normalize_minmax_to_f32(src)
+
+
+def Sobel(src, ddepth, dx, dy, ksize=3):  # noqa: N802, ARG001
+    return sobel_f64(src, dx, dy, ksize)
+
+
+def GaussianBlur(src, ksize, sigma):  # noqa: N802, ARG001
+    assert tuple(ksize) == (3, 3) and sigma == 0
+    return gaussian_blur3_f64(src)

@@ -1,0 +1,124 @@
+"""CPU oracle: HoVer-Net post-processing (restates ``tiatoolbox/models/architecture/hovernet.py``).
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  ``proc_np_hv`` follows ``_proc_np_hv``
+(:502-616) line by line with the cv2 / skimage primitives restated in ``cvref`` / ``skref`` and
+scipy's own ``ndimage.label`` / ``binary_fill_holes``; ``get_instance_info`` follows :618-748
+(without the OpenCV contour polygon, which is outside this round's scope).
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+from scipy import ndimage
+
+from . import cvref, skref
+
+
+def proc_np_hv(np_map: np.ndarray, hv_map: np.ndarray, scale_factor: float = 1, *, debug: dict | None = None) -> np.ndarray:
+    blb_raw = np_map[..., 0]
+    h_dir_raw = hv_map[..., 0]
+    v_dir_raw = hv_map[..., 1]
+
+    blb = np.array(blb_raw >= 0.5, dtype=np.int32)
+    blb = ndimage.label(blb)[0]
+    blb = skref.remove_small_objects_labels(blb, max_size=9)
+    blb[blb > 0] = 1
+
+    h_dir = cvref.normalize_minmax_to_f32(h_dir_raw)
+    v_dir = cvref.normalize_minmax_to_f32(v_dir_raw)
+
+    ksize = int((20 * scale_factor) + 1)
+    obj_size = math.ceil(10 * (scale_factor**2))
+
+    sobel_h = cvref.sobel_f64(h_dir, 1, 0, ksize)
+    sobel_v = cvref.sobel_f64(v_dir, 0, 1, ksize)
+    sobel_h = 1 - cvref.normalize_minmax_to_f32(sobel_h)
+    sobel_v = 1 - cvref.normalize_minmax_to_f32(sobel_v)
+
+    overall = np.maximum(sobel_h, sobel_v)
+    overall = overall - (1 - blb)
+    overall[overall < 0] = 0
+
+    dist = (1.0 - overall) * blb
+    dist = -cvref.gaussian_blur3_f64(dist)
+
+    overall = np.array(overall >= 0.4, dtype=np.int32)
+
+    marker = blb - overall
+    marker[marker < 0] = 0
+    marker = ndimage.binary_fill_holes(marker).astype("uint8")
+    kernel = cvref.get_structuring_element_ellipse((5, 5))
+    marker = cvref.morphology_ex(marker, "OPEN", kernel)
+    marker = ndimage.label(marker)[0]
+    marker = skref.remove_small_objects_labels(marker, max_size=obj_size - 1)
+    if debug is not None:
+        debug.update(blb=blb, dist=dist, marker=marker, sobel_h=sobel_h, sobel_v=sobel_v)
+    return skref.watershed(dist, markers=marker, mask=blb)
+
+
+def get_bounding_box(img: np.ndarray) -> np.ndarray:
+    rows = np.any(img, axis=1)
+    cols = np.any(img, axis=0)
+    r_min, r_max = np.where(rows)[0][[0, -1]]
+    c_min, c_max = np.where(cols)[0][[0, -1]]
+    return np.array([c_min, r_min, c_max + 1, r_max + 1])
+
+
+def get_instance_info(pred_inst: np.ndarray, pred_type: np.ndarray | None = None,
+                      offset: tuple[int, int] = (0, 0)) -> dict:
+    """``hovernet.py:618-748`` minus ``contours``: box, centroid (raw moments of the cropped
+    binary mask + top-left), majority type and its probability."""
+    offset = np.asarray(offset)
+    info = {}
+    for inst_id in np.unique(pred_inst)[1:]:
+        inst_map = pred_inst == inst_id
+        box = get_bounding_box(inst_map)
+        tl = box[:2] + offset
+        crop = inst_map[box[1]:box[3], box[0]:box[2]].astype(np.uint8)
+        ys, xs = np.nonzero(crop)
+        m00, m10, m01 = float(crop.sum()), float(xs.sum()), float(ys.sum())
+        centroid = np.array([m10 / m00, m01 / m00]) + tl
+        out_box = box.copy()
+        out_box[:2] += offset
+        out_box[2:] += offset
+        info[int(inst_id)] = {"box": out_box, "centroid": centroid, "prob": None, "type": None}
+        if pred_type is not None:
+            inst_type = pred_type[box[1]:box[3], box[0]:box[2]][crop.astype(bool)]
+            type_list, type_pixels = np.unique(inst_type, return_counts=True)
+            pairs = sorted(zip(type_list, type_pixels), key=lambda x: x[1], reverse=True)
+            top = pairs[0][0]
+            if top == 0 and len(pairs) > 1:
+                top = pairs[1][0]
+            counts = {v[0]: v[1] for v in pairs}
+            info[int(inst_id)]["type"] = int(top)
+            info[int(inst_id)]["prob"] = float(counts[top] / (np.sum(crop) + 1.0e-6))
+    return info
+
+
+def synth_maps(n: int, h: int, w: int, seed: int = 0, n_blobs: int = 30, num_types: int = 6):
+    """Synthetic HoVer-Net head outputs: ``np`` = union of Gaussian blobs,
+    ``hv`` = per-blob normalised x/y ramps in [-1, 1] plus noise, ``tp`` = blob class."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    np_map = np.zeros((n, h, w, 1), np.float32)
+    hv = np.zeros((n, h, w, 2), np.float32)
+    tp = np.zeros((n, h, w, 1), np.float32)
+    for i in range(n):
+        best = np.zeros((h, w), np.float32)
+        for _ in range(n_blobs):
+            cy, cx = rng.uniform(4, h - 4), rng.uniform(4, w - 4)
+            ry, rx = rng.uniform(3.5, 9.0, 2)
+            d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
+            p = np.exp(-0.5 * d * 2.0).astype(np.float32)
+            upd = p > best
+            best = np.where(upd, p, best)
+            hv[i, ..., 0] = np.where(upd, np.clip((xx - cx) / rx, -1, 1), hv[i, ..., 0])
+            hv[i, ..., 1] = np.where(upd, np.clip((yy - cy) / ry, -1, 1), hv[i, ..., 1])
+            tp[i, ..., 0] = np.where(upd & (p > 0.3), rng.integers(1, num_types), tp[i, ..., 0])
+        np_map[i, ..., 0] = best
+        hv[i] *= (best > 0.2)[..., None]
+    np_map += rng.normal(0, 0.02, np_map.shape).astype(np.float32)
+    hv += rng.normal(0, 0.02, hv.shape).astype(np.float32)
+    return np.clip(np_map, 0, 1).astype(np.float32), hv.astype(np.float32), tp

@@ -67,14 +67,28 @@ def remove_small_objects_labels(lab: np.ndarray, max_size: int) -> np.ndarray:
     return out
 
 
+class _HeapItem:
+    """skimage's heap orders items by (value, age) only (``heap_general.pxi``: ``smaller``)."""
+
+    __slots__ = ("value", "age", "index")
+
+    def __init__(self, value: float, age: int, index: int) -> None:
+        self.value, self.age, self.index = value, age, index
+
+    def __lt__(self, other: "_HeapItem") -> bool:
+        if self.value != other.value:
+            return self.value < other.value
+        return self.age < other.age
+
+
 def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.ndarray:
     """``skimage.segmentation.watershed(image, markers, mask=mask)`` (connectivity 1).
 
-    Priority flood (``_watershed_cy.watershed_raveled``): a heap keyed by
-    ``(value, age)``; every marker pixel (raster order) is pushed with its own value;
-    a popped pixel visits its neighbours in raveled offset order (up, left, right,
-    down); each unlabelled in-mask neighbour takes the popped pixel's label and is
-    pushed with its own image value and the next age.  Call site:
+    Priority flood (``_watershed_cy.watershed_raveled``): a binary heap (same sift procedures as
+    CPython's ``heapq``) ordered by ``(value, age)``; every marker pixel (raster order) is pushed
+    with its own value and age 0; a popped pixel visits its neighbours in raveled offset order
+    (up, left, right, down); each unlabelled in-mask neighbour takes the popped pixel's label and
+    is pushed with its own image value and the next age.  Call site:
     ``tiatoolbox/models/architecture/hovernet.py:616``.
     """
     image = np.asarray(image, dtype=np.float64)
@@ -87,10 +101,9 @@ def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.nd
     flat_img = image.ravel()
     flat_mask = maskb.ravel()
     for idx in np.flatnonzero(flat_out):
-        heapq.heappush(heap, (flat_img[idx], age, int(idx)))
-        age += 1
+        heapq.heappush(heap, _HeapItem(flat_img[idx], 0, int(idx)))
     while heap:
-        _, _, idx = heapq.heappop(heap)
+        idx = heapq.heappop(heap).index
         r, c = divmod(idx, w)
         lab = flat_out[idx]
         for dr, dc in ((-1, 0), (0, -1), (0, 1), (1, 0)):
@@ -100,7 +113,7 @@ def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.nd
             n = rr * w + cc
             if flat_out[n] != 0 or not flat_mask[n]:
                 continue
-            flat_out[n] = lab
-            heapq.heappush(heap, (flat_img[n], age, n))
             age += 1
+            flat_out[n] = lab
+            heapq.heappush(heap, _HeapItem(flat_img[n], age, n))
     return out

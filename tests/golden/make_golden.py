@@ -122,8 +122,39 @@ def mask_goldens() -> None:
     print("wrote mask_golden.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
+def hover_goldens() -> None:
+    """HoVerNet._proc_np_hv / get_instance_info of the real reference on synthetic head outputs."""
+    from oracle import hovernet as oh
+
+    hov = _ref_import("tiatoolbox.models.architecture.hovernet")
+    out = {}
+    for tag, (h, w, seed, nb) in {"a": (164, 164, 1, 30), "b": (96, 120, 2, 12)}.items():
+        npm, hv, tp = oh.synth_maps(2, h, w, seed=seed, n_blobs=nb)
+        insts, boxes, cents, types, probs, ids = [], [], [], [], [], []
+        for i in range(2):
+            inst = hov.HoVerNet._proc_np_hv(npm[i], hv[i])
+            insts.append(inst)
+            pred_type = np.around(tp[i]).astype("uint8")[..., 0]
+            info = hov.HoVerNet.get_instance_info(inst, pred_type, verbose=False)
+            ids.append(np.array(list(info.keys())))
+            boxes.append(np.array([v["box"] for v in info.values()]))
+            cents.append(np.array([v["centroid"] for v in info.values()]))
+            types.append(np.array([v["type"] for v in info.values()]))
+            probs.append(np.array([v["prob"] for v in info.values()]))
+        out[f"{tag}_shape"] = np.array([h, w, seed, nb])
+        out[f"{tag}_inst"] = np.stack(insts)
+        for i in range(2):
+            out[f"{tag}_ids{i}"], out[f"{tag}_box{i}"], out[f"{tag}_cent{i}"] = ids[i], boxes[i], cents[i]
+            out[f"{tag}_type{i}"], out[f"{tag}_prob{i}"] = types[i], probs[i]
+    np.savez_compressed(HERE / "hover_golden.npz", **out)
+    print("wrote hover_golden.npz:", {k: getattr(v, "shape", None) for k, v in out.items() if "inst" in k},
+          [int(out[f"{t}_inst"].max()) for t in "ab"])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stain", "mask"]
+    which = sys.argv[1:] or ["stain", "mask", "hover"]
+    if "hover" in which:
+        hover_goldens()
     if "stain" in which:
         stain_goldens()
     if "mask" in which:

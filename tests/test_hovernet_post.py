@@ -1,0 +1,127 @@
+"""HoVer-Net post-processing: oracle vs the real reference (CPU), HIP vs oracle (GPU, bit-exact labels)."""
+
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import hovernet as oh
+
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD / "hover_golden.npz")
+
+
+def _maps(gold, tag):
+    h, w, seed, nb = (int(v) for v in gold[f"{tag}_shape"])
+    return oh.synth_maps(2, h, w, seed=seed, n_blobs=nb)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_matches_real_reference(gold, tag):
+    npm, hv, tp = _maps(gold, tag)
+    for i in range(2):
+        inst = oh.proc_np_hv(npm[i], hv[i])
+        assert np.array_equal(inst, gold[f"{tag}_inst"][i])
+        info = oh.get_instance_info(inst, np.around(tp[i]).astype("uint8")[..., 0])
+        assert np.array_equal(np.array(list(info)), gold[f"{tag}_ids{i}"])
+        assert np.array_equal(np.array([v["box"] for v in info.values()]), gold[f"{tag}_box{i}"])
+        np.testing.assert_array_equal(np.array([v["centroid"] for v in info.values()]), gold[f"{tag}_cent{i}"])
+        assert np.array_equal(np.array([v["type"] for v in info.values()]), gold[f"{tag}_type{i}"])
+        np.testing.assert_array_equal(np.array([v["prob"] for v in info.values()]), gold[f"{tag}_prob{i}"])
+
+
+def test_sobel_kernels_known_values():
+    from oracle import cvref
+
+    kx, ky = cvref.sobel_kernels(5, 1, 0)
+    assert kx.tolist() == [-1, -2, 0, 2, 1] and ky.tolist() == [1, 4, 6, 4, 1]   # OpenCV docs: 5x5 Sobel
+    kx, ky = cvref.sobel_kernels(21, 1, 0)
+    assert ky[10] == 184756 and kx[0] == -1 and kx[-1] == 1 and kx[10] == 0      # C(20,10); antisymmetric
+    assert cvref.get_structuring_element_ellipse((5, 5)).tolist() == [
+        [0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_proc_np_hv_bit_exact(gold, tag):
+    """Instance label maps must equal the reference's (golden) and the oracle's, pixel for pixel."""
+    import torch
+
+    from tiatoolbox_amd.models.architecture import _hover_device as hd
+
+    npm, hv, tp = _maps(gold, tag)
+    inst, nmark = hd.proc_np_hv(torch.from_numpy(npm).cuda(), torch.from_numpy(hv).cuda())
+    got = inst.cpu().numpy()
+    assert got.dtype == np.int32
+    for i in range(2):
+        assert np.array_equal(got[i], gold[f"{tag}_inst"][i]), f"plane {i}: {(got[i] != gold[f'{tag}_inst'][i]).sum()} px differ"
+        assert int(nmark[i]) >= got[i].max()
+    # instance info
+    pred_type = torch.from_numpy(np.around(tp).astype("uint8")[..., 0]).cuda()
+    stats, types = hd.instance_stats(inst, pred_type, int(nmark.max()), num_types=8)
+    for i in range(2):
+        info = hd.info_from_stats(stats[i].cpu().numpy(), types[i].cpu().numpy())
+        assert np.array_equal(np.array(list(info)), gold[f"{tag}_ids{i}"])
+        assert np.array_equal(np.array([v["box"] for v in info.values()]), gold[f"{tag}_box{i}"])
+        np.testing.assert_array_equal(np.array([v["centroid"] for v in info.values()]), gold[f"{tag}_cent{i}"])
+        assert np.array_equal(np.array([v["type"] for v in info.values()]), gold[f"{tag}_type{i}"])
+        np.testing.assert_array_equal(np.array([v["prob"] for v in info.values()]), gold[f"{tag}_prob{i}"])
+
+
+@pytest.mark.gpu
+def test_hip_proc_np_hv_vs_oracle_more_shapes():
+    import torch
+
+    from tiatoolbox_amd.models.architecture import _hover_device as hd
+
+    for (h, w, seed, nb) in ((64, 80, 5, 6), (164, 164, 6, 60), (256, 256, 7, 90), (33, 47, 8, 3)):
+        npm, hv, _ = oh.synth_maps(3, h, w, seed=seed, n_blobs=nb)
+        inst, _ = hd.proc_np_hv(torch.from_numpy(npm).cuda(), torch.from_numpy(hv).cuda())
+        got = inst.cpu().numpy()
+        for i in range(3):
+            exp = oh.proc_np_hv(npm[i], hv[i])
+            assert np.array_equal(got[i], exp), (h, w, i, int((got[i] != exp).sum()))
+    # empty / full planes
+    z = torch.zeros((2, 40, 40, 1), device="cuda")
+    inst, n = hd.proc_np_hv(z, torch.zeros((2, 40, 40, 2), device="cuda"))
+    assert int(inst.abs().sum()) == 0 and int(n.sum()) == 0
+    one = torch.ones((1, 40, 40, 1), device="cuda")
+    hvr = torch.rand((1, 40, 40, 2), device="cuda", generator=torch.Generator("cuda").manual_seed(0))
+    inst, _ = hd.proc_np_hv(one, hvr)
+    exp = oh.proc_np_hv(one[0].cpu().numpy(), hvr[0].cpu().numpy())
+    assert np.array_equal(inst[0].cpu().numpy(), exp)
+
+
+@pytest.mark.gpu
+def test_hip_proc_np_hv_large_tile_properties():
+    """1024x1024 tile (WSI-mode tile size): labels stay inside the mask, every marker id floods a
+    connected region, result is deterministic, and a 2x2 mosaic of independent tiles gives the
+    per-tile results (blobs never interact across the zero gutter)."""
+    import torch
+    from scipy import ndimage
+
+    from tiatoolbox_amd.models.architecture import _hover_device as hd
+
+    npm, hv, _ = oh.synth_maps(4, 500, 500, seed=11, n_blobs=400)
+    big_np = np.zeros((1, 1024, 1024, 1), np.float32)
+    big_hv = np.zeros((1, 1024, 1024, 2), np.float32)
+    for k, (y, x) in enumerate(((0, 0), (0, 512), (512, 0), (512, 512))):
+        big_np[0, y + 6:y + 506, x + 6:x + 506] = npm[k]
+        big_hv[0, y + 6:y + 506, x + 6:x + 506] = hv[k]
+    a, _ = hd.proc_np_hv(torch.from_numpy(big_np).cuda(), torch.from_numpy(big_hv).cuda())
+    b, _ = hd.proc_np_hv(torch.from_numpy(big_np).cuda(), torch.from_numpy(big_hv).cuda())
+    assert torch.equal(a, b)
+    lab = a[0].cpu().numpy()
+    mask = ndimage.label(big_np[0, ..., 0] >= 0.5)[0]
+    assert np.all((lab > 0) <= (mask > 0))
+    ids = np.unique(lab)[1:]
+    assert len(ids) > 200
+    for i in ids[:: max(1, len(ids) // 40)]:
+        assert ndimage.label(lab == i)[1] == 1

@@ -1,0 +1,524 @@
+// HoVer-Net post-processing on gfx950 (reference: models/architecture/hovernet.py:502-748).
+// Dense stages are one-thread-per-pixel kernels over [n,h,w] planes; the watershed is a
+// priority flood run independently per connected mask blob (the global skimage heap restricted
+// to one blob pops in the same order as a private heap, because a blob's entries are only ever
+// inserted by pops of that blob), one lane per blob with its heap segment in global memory.
+#include "common.hpp"
+
+#pragma clang fp contract(off)  // OpenCV/NumPy evaluate these expressions without contraction
+
+namespace tia {
+
+constexpr int HT = 256;
+
+static inline unsigned hblocks(long n, int per = HT, long cap = 4096) {
+    long b = (n + per - 1) / per;
+    if (b > cap) b = cap;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    i %= period;
+    if (i < 0) i += period;
+    return i >= n ? period - i : i;
+}
+
+__global__ __launch_bounds__(256) void np_threshold_kernel(const float* __restrict__ np_map, long n, uint8_t* __restrict__ mask) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) mask[i] = np_map[i] >= 0.5f ? 1 : 0;
+}
+
+// ---- per-plane min / max ---------------------------------------------------------------------------------
+// out[plane*2] = min, out[plane*2+1] = max (as f64).  `stride`/`offset` address interleaved channels.
+template <class T>
+__global__ __launch_bounds__(1024) void minmax_kernel(const T* __restrict__ src, long hw, int stride, int offset,
+                                                       double* __restrict__ out) {
+    __shared__ double smin[16], smax[16];
+    const T* s = src + (size_t)blockIdx.x * hw * stride + offset;
+    double mn = 1.0 / 0.0, mx = -1.0 / 0.0;
+    for (long i = threadIdx.x; i < hw; i += 1024) {
+        const double v = (double)s[i * stride];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_down(mn, o, 64), b = __shfl_down(mx, o, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (lane_id() == 0) {
+        smin[wave_id()] = mn;
+        smax[wave_id()] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) {
+            mn = smin[i] < mn ? smin[i] : mn;
+            mx = smax[i] > mx ? smax[i] : mx;
+        }
+        out[blockIdx.x * 2] = mn;
+        out[blockIdx.x * 2 + 1] = mx;
+    }
+}
+
+// cv2.normalize(NORM_MINMAX, 0..1): scale = 1/(max-min) (0 if the range is < DBL_EPSILON), shift = -min*scale
+__device__ __forceinline__ void norm_params(const double* __restrict__ mm, double& scale, double& shift) {
+    const double rng = mm[1] - mm[0];
+    scale = rng > 2.220446049250313e-16 ? 1.0 / rng : 0.0;
+    shift = 0.0 - mm[0] * scale;
+}
+
+// ---- Sobel (separable, f64 accumulate) -----------------------------------------------------------------------
+// Row pass over the min-max-normalised f32 map (normalisation in f32 arithmetic, as convertTo does for
+// CV_32F sources): buf = sum_k kx[k] * S[x + k - anchor], taps in ascending order.
+__global__ __launch_bounds__(HT) void sobel_row_kernel(const float* __restrict__ hv, int channel, int h, int w,
+                                                        const double* __restrict__ mm, const double* __restrict__ kx,
+                                                        int ksize, double* __restrict__ buf) {
+    const long hw = (long)h * w;
+    const float* src = hv + (size_t)blockIdx.y * hw * 2 + channel;
+    double* dst = buf + (size_t)blockIdx.y * hw;
+    double scale, shift;
+    norm_params(mm + blockIdx.y * 2, scale, shift);
+    const float a = (float)scale, b = (float)shift;
+    const int anchor = ksize / 2;
+    for (long i = (long)blockIdx.x * HT + threadIdx.x; i < hw; i += (long)gridDim.x * HT) {
+        const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        const float* row = src + (size_t)y * w * 2;
+        double acc = 0.0;
+        for (int k = 0; k < ksize; ++k) {
+            const int xx = reflect101(x + k - anchor, w);
+            const float v = row[(size_t)xx * 2] * a + b;
+            const double t = kx[k] * (double)v;
+            acc = (k == 0) ? t : acc + t;
+        }
+        dst[i] = acc;
+    }
+}
+
+// Column pass, OpenCV SymmColumnFilter: centre tap, then ky[c+k]*(S[+k] +/- S[-k]).
+__global__ __launch_bounds__(HT) void sobel_col_kernel(const double* __restrict__ buf, int h, int w,
+                                                        const double* __restrict__ ky, int ksize, int symmetric,
+                                                        double* __restrict__ out) {
+    const long hw = (long)h * w;
+    const double* src = buf + (size_t)blockIdx.y * hw;
+    double* dst = out + (size_t)blockIdx.y * hw;
+    const int c = ksize / 2;
+    for (long i = (long)blockIdx.x * HT + threadIdx.x; i < hw; i += (long)gridDim.x * HT) {
+        const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        double acc = symmetric ? (ky[c] * src[i] + 0.0) : 0.0;
+        for (int k = 1; k <= c; ++k) {
+            const double up = src[(long)reflect101(y + k, h) * w + x];
+            const double dn = src[(long)reflect101(y - k, h) * w + x];
+            acc = acc + ky[c + k] * (symmetric ? (up + dn) : (up - dn));
+        }
+        dst[i] = acc;
+    }
+}
+
+// ---- energy landscape (hovernet.py:571-603) ---------------------------------------------------------------------
+__global__ __launch_bounds__(HT) void energy_kernel(const double* __restrict__ sob_h, const double* __restrict__ sob_v,
+                                                     const double* __restrict__ mm_h, const double* __restrict__ mm_v,
+                                                     const int* __restrict__ blob, long hw, double* __restrict__ dist0,
+                                                     uint8_t* __restrict__ marker0) {
+    const size_t off = (size_t)blockIdx.y * hw;
+    double sh_s, sh_b, sv_s, sv_b;
+    norm_params(mm_h + blockIdx.y * 2, sh_s, sh_b);
+    norm_params(mm_v + blockIdx.y * 2, sv_s, sv_b);
+    for (long i = (long)blockIdx.x * HT + threadIdx.x; i < hw; i += (long)gridDim.x * HT) {
+        const int blb = blob[off + i] > 0 ? 1 : 0;
+        const float nh = (float)(sob_h[off + i] * sh_s + sh_b);  // f64 -> f32 convertTo
+        const float nv = (float)(sob_v[off + i] * sv_s + sv_b);
+        const float sh = 1.0f - nh, sv = 1.0f - nv;              // 1 - float32
+        const float ov32 = sh > sv ? sh : sv;                    // np.maximum (float32)
+        double overall = (double)ov32 - (double)(1 - blb);       // float32 - int32 -> float64
+        if (overall < 0.0) overall = 0.0;
+        dist0[off + i] = (1.0 - overall) * (double)blb;
+        int mk = blb - (overall >= 0.4 ? 1 : 0);
+        marker0[off + i] = mk < 0 ? 0 : (uint8_t)mk;
+    }
+}
+
+// dist = -GaussianBlur(dist0, (3,3), 0): [1/4,1/2,1/4] separable, S0*k0 + (S-1 + S+1)*k1, REFLECT_101
+__global__ __launch_bounds__(HT) void gauss3_neg_kernel(const double* __restrict__ src, int h, int w,
+                                                         double* __restrict__ dst) {
+    const long hw = (long)h * w;
+    const double* s = src + (size_t)blockIdx.y * hw;
+    double* d = dst + (size_t)blockIdx.y * hw;
+    for (long i = (long)blockIdx.x * HT + threadIdx.x; i < hw; i += (long)gridDim.x * HT) {
+        const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+        double r[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double* row = s + (long)reflect101(y + j - 1, h) * w;
+            r[j] = row[x] * 0.5 + (row[xm] + row[xp]) * 0.25;
+        }
+        d[i] = -(r[1] * 0.5 + (r[0] + r[2]) * 0.25);
+    }
+}
+
+// ---- watershed -----------------------------------------------------------------------------------------------------
+struct HeapItem {
+    double value;
+    int age;
+    int index;
+};
+__device__ __forceinline__ bool heap_smaller(const HeapItem& a, const HeapItem& b) {
+    if (a.value != b.value) return a.value < b.value;
+    return a.age < b.age;
+}
+// skimage heap_general.pxi: push = append + sift towards the root
+__device__ __forceinline__ void heap_push(HeapItem* __restrict__ hp, int& items, const HeapItem& e) {
+    int pos = items++;
+    hp[pos] = e;
+    while (pos > 0) {
+        const int parent = (pos - 1) >> 1;
+        const HeapItem p = hp[parent];
+        if (!heap_smaller(e, p)) break;
+        hp[pos] = p;
+        pos = parent;
+    }
+    hp[pos] = e;
+}
+// pop = take root, move the last item to the root, bubble the smaller child up to a leaf, sift back
+__device__ __forceinline__ HeapItem heap_pop(HeapItem* __restrict__ hp, int& items) {
+    const HeapItem top = hp[0];
+    --items;
+    if (items == 0) return top;
+    const HeapItem last = hp[items];
+    int pos = 0, child = 1;
+    while (child < items) {
+        const int right = child + 1;
+        if (right < items && !heap_smaller(hp[child], hp[right])) child = right;
+        hp[pos] = hp[child];
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    while (pos > 0) {
+        const int parent = (pos - 1) >> 1;
+        const HeapItem p = hp[parent];
+        if (!heap_smaller(last, p)) break;
+        hp[pos] = p;
+        pos = parent;
+    }
+    hp[pos] = last;
+    return top;
+}
+
+// inst = where(mask, markers, 0); blob bounding boxes
+__global__ __launch_bounds__(HT) void ws_init_kernel(const int* __restrict__ blob, const int* __restrict__ marker, int h, int w,
+                                                      int* __restrict__ inst, int* __restrict__ bbox) {
+    const long hw = (long)h * w;
+    const size_t off = (size_t)blockIdx.y * hw;
+    int* bb = bbox + (size_t)blockIdx.y * (hw + 1) * 4;
+    for (long i = (long)blockIdx.x * HT + threadIdx.x; i < hw; i += (long)gridDim.x * HT) {
+        const int b = blob[off + i];
+        inst[off + i] = b > 0 ? marker[off + i] : 0;
+        if (b > 0) {
+            const int y = (int)(i / w), x = (int)(i - (long)y * w);
+            atomicMin(&bb[b * 4 + 0], y);
+            atomicMax(&bb[b * 4 + 1], y);
+            atomicMin(&bb[b * 4 + 2], x);
+            atomicMax(&bb[b * 4 + 3], x);
+        }
+    }
+}
+__global__ __launch_bounds__(HT) void bbox_reset_kernel(int* __restrict__ bbox, long n_entries) {
+    for (long i = (long)blockIdx.x * HT + threadIdx.x; i < n_entries; i += (long)gridDim.x * HT) {
+        bbox[i * 4 + 0] = 0x7fffffff;
+        bbox[i * 4 + 1] = -1;
+        bbox[i * 4 + 2] = 0x7fffffff;
+        bbox[i * 4 + 3] = -1;
+    }
+}
+
+// heap segment offsets: exclusive scan over labels of (area if the blob survived the size filter)
+__global__ __launch_bounds__(1024) void ws_offsets_kernel(const int* __restrict__ areas, const int* __restrict__ count, long hw,
+                                                           int min_keep, int* __restrict__ offs) {
+    __shared__ unsigned wtot[16];
+    const int* a = areas + (size_t)blockIdx.x * (hw + 1);
+    int* o = offs + (size_t)blockIdx.x * (hw + 1);
+    const long k = (long)count[blockIdx.x] + 1;  // labels 0..count
+    const long chunk = (k + 1023) / 1024;
+    const long lo = (long)threadIdx.x * chunk, hi = lo + chunk < k ? lo + chunk : k;
+    unsigned c = 0;
+    for (long i = lo; i < hi; ++i) c += (i > 0 && a[i] >= min_keep) ? (unsigned)a[i] : 0u;
+    const unsigned incl = wave_incl_scan_u32(c);
+    if (lane_id() == 63) wtot[wave_id()] = incl;
+    __syncthreads();
+    unsigned before = incl - c;
+    for (int wv = 0; wv < wave_id(); ++wv) before += wtot[wv];
+    for (long i = lo; i < hi; ++i) {
+        o[i] = (int)before;
+        before += (i > 0 && a[i] >= min_keep) ? (unsigned)a[i] : 0u;
+    }
+}
+
+__global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ blob, const double* __restrict__ dist,
+                                                       const int* __restrict__ areas, const int* __restrict__ offs,
+                                                       const int* __restrict__ count, const int* __restrict__ bbox, int h, int w,
+                                                       int min_keep, HeapItem* __restrict__ heaps, int* __restrict__ inst) {
+    const long hw = (long)h * w;
+    const int plane = blockIdx.y;
+    const int label = blockIdx.x * 64 + threadIdx.x + 1;
+    if (label > count[plane]) return;
+    const int area = areas[(size_t)plane * (hw + 1) + label];
+    if (area < min_keep) return;
+    const size_t off = (size_t)plane * hw;
+    const int* bl = blob + off;
+    const double* ds = dist + off;
+    int* out = inst + off;
+    HeapItem* hp = heaps + off + offs[(size_t)plane * (hw + 1) + label];
+    const int* bb = bbox + ((size_t)plane * (hw + 1) + label) * 4;
+    const int y0 = bb[0], y1 = bb[1], x0 = bb[2], x1 = bb[3];
+    int items = 0, age = 0;
+    // initial queue: the blob's marker pixels in raster order, all with age 0 (as skimage does)
+    for (int y = y0; y <= y1; ++y) {
+        for (int x = x0; x <= x1; ++x) {
+            const long i = (long)y * w + x;
+            if (bl[i] == label && out[i] != 0) {
+                HeapItem e;
+                e.value = ds[i];
+                e.age = 0;
+                e.index = (int)i;
+                heap_push(hp, items, e);
+            }
+        }
+    }
+    while (items > 0) {
+        const HeapItem e = heap_pop(hp, items);
+        const int lab = out[e.index];
+        const int y = e.index / w, x = e.index - y * w;
+        // neighbour order of skimage's raveled offsets for connectivity 1: up, left, right, down
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int yy = y + (j == 0 ? -1 : (j == 3 ? 1 : 0));
+            const int xx = x + (j == 1 ? -1 : (j == 2 ? 1 : 0));
+            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+            const long ni = (long)yy * w + xx;
+            if (bl[ni] <= 0 || out[ni] != 0) continue;
+            ++age;
+            out[ni] = lab;
+            HeapItem ne;
+            ne.value = ds[ni];
+            ne.age = age;
+            ne.index = (int)ni;
+            heap_push(hp, items, ne);
+        }
+    }
+}
+
+// ---- instance statistics ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HT) void inst_stats_init_kernel(long long* __restrict__ stats, long n_entries) {
+    for (long i = (long)blockIdx.x * HT + threadIdx.x; i < n_entries; i += (long)gridDim.x * HT) {
+        stats[i * 8 + 1] = 0x7fffffffLL;
+        stats[i * 8 + 2] = 0x7fffffffLL;
+        stats[i * 8 + 3] = -1;
+        stats[i * 8 + 4] = -1;
+    }
+}
+__global__ __launch_bounds__(HT) void inst_stats_kernel(const int* __restrict__ inst, const uint8_t* __restrict__ type, int h, int w,
+                                                         int max_inst, int num_types, long long* __restrict__ stats,
+                                                         int* __restrict__ types) {
+    const long hw = (long)h * w;
+    const size_t off = (size_t)blockIdx.y * hw;
+    long long* st = stats + (size_t)blockIdx.y * (max_inst + 1) * 8;
+    int* ty = types ? types + (size_t)blockIdx.y * (max_inst + 1) * num_types : nullptr;
+    for (long i = (long)blockIdx.x * HT + threadIdx.x; i < hw; i += (long)gridDim.x * HT) {
+        const int id = inst[off + i];
+        if (id <= 0 || id > max_inst) continue;
+        const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        long long* s = st + (size_t)id * 8;
+        atomicAdd((unsigned long long*)&s[0], 1ull);
+        atomicMin(&s[1], (long long)x);
+        atomicMin(&s[2], (long long)y);
+        atomicMax(&s[3], (long long)x);
+        atomicMax(&s[4], (long long)y);
+        atomicAdd((unsigned long long*)&s[5], (unsigned long long)x);
+        atomicAdd((unsigned long long*)&s[6], (unsigned long long)y);
+        if (ty && type) {
+            const int t = type[off + i];
+            if (t < num_types) atomicAdd(&ty[(size_t)id * num_types + t], 1);
+        }
+    }
+}
+
+__global__ void sobel_taps_kernel(double* __restrict__ kd, double* __restrict__ ks, int ksize) {
+    // getSobelKernels: order-1 (derivative) and order-0 (smoothing) integer taps, exact in f64
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int order = 0; order < 2; ++order) {
+        long long ker[64];
+        for (int i = 0; i <= ksize; ++i) ker[i] = 0;
+        ker[0] = 1;
+        for (int i = 0; i < ksize - order - 1; ++i) {
+            long long oldval = ker[0];
+            for (int j = 1; j <= ksize; ++j) {
+                const long long newval = ker[j] + ker[j - 1];
+                ker[j - 1] = oldval;
+                oldval = newval;
+            }
+        }
+        for (int i = 0; i < order; ++i) {
+            long long oldval = -ker[0];
+            for (int j = 1; j <= ksize; ++j) {
+                const long long newval = ker[j - 1] - ker[j];
+                ker[j - 1] = oldval;
+                oldval = newval;
+            }
+        }
+        double* dst = order ? kd : ks;
+        for (int i = 0; i < ksize; ++i) dst[i] = (double)ker[i];
+    }
+}
+
+struct HoverWs {
+    size_t total;
+    size_t blb_mask, tmp_a, tmp_b, blob_lab, mark_lab, ws_int, bbox, offs, cnt_blob, rowbuf, sob_h, sob_v, dist0, dist, heaps,
+        mm, taps, se_offs;
+};
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static HoverWs hover_layout(long n, long hw) {
+    HoverWs L{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o = align256(o + bytes);
+        return at;
+    };
+    L.blb_mask = take((size_t)n * hw);
+    L.tmp_a = take((size_t)n * hw);
+    L.tmp_b = take((size_t)n * hw);
+    L.blob_lab = take((size_t)n * hw * 4);
+    L.mark_lab = take((size_t)n * hw * 4);
+    L.ws_int = take(((size_t)2 * n * hw + 2 * n + (size_t)n * (hw + 1)) * 4);  // CCL / fill-holes / area scratch
+    L.bbox = take((size_t)n * (hw + 1) * 16);
+    L.offs = take((size_t)n * (hw + 1) * 4);
+    L.cnt_blob = take((size_t)n * 4 * 2);
+    L.rowbuf = take((size_t)n * hw * 8);
+    L.sob_h = take((size_t)n * hw * 8);
+    L.sob_v = take((size_t)n * hw * 8);
+    L.dist0 = take((size_t)n * hw * 8);
+    L.dist = take((size_t)n * hw * 8);
+    L.heaps = take((size_t)n * hw * sizeof(HeapItem));
+    L.mm = take((size_t)n * 2 * 8 * 4);
+    L.taps = take(64 * 8 * 2);
+    L.se_offs = take(64 * 8);
+    L.total = o;
+    return L;
+}
+
+}  // namespace tia
+
+using namespace tia;
+
+extern "C" size_t tia_hover_workspace_bytes(int64_t n, int64_t h, int64_t w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    return hover_layout((long)n, (long)h * w).total;
+}
+
+extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, int64_t n, int64_t h, int64_t w,
+                                         int32_t ksize, int32_t obj_size, int32_t* d_inst, int32_t* d_ninst, void* d_ws,
+                                         size_t ws_bytes, void* stream) {
+    if (!d_np || !d_hv || !d_inst || !d_ninst || !d_ws) return TIA_EINVAL;
+    if (n <= 0 || h <= 0 || w <= 0 || n > 65535 || ksize < 5 || ksize > 31 || (ksize & 1) == 0) return TIA_EINVAL;
+    const long hw = (long)h * w;
+    if (hw > 0x3fffffffL) return TIA_ESIZE;
+    const HoverWs L = hover_layout((long)n, hw);
+    if (ws_bytes < L.total) return TIA_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)d_ws;
+    uint8_t* blb_mask = (uint8_t*)(base + L.blb_mask);
+    uint8_t* tmp_a = (uint8_t*)(base + L.tmp_a);
+    uint8_t* tmp_b = (uint8_t*)(base + L.tmp_b);
+    int* blob_lab = (int*)(base + L.blob_lab);
+    int* mark_lab = (int*)(base + L.mark_lab);
+    int* ws_int = (int*)(base + L.ws_int);
+    int* bbox = (int*)(base + L.bbox);
+    int* offs = (int*)(base + L.offs);
+    int* cnt_blob = (int*)(base + L.cnt_blob);
+    double* rowbuf = (double*)(base + L.rowbuf);
+    double* sob_h = (double*)(base + L.sob_h);
+    double* sob_v = (double*)(base + L.sob_v);
+    double* dist0 = (double*)(base + L.dist0);
+    double* dist = (double*)(base + L.dist);
+    HeapItem* heaps = (HeapItem*)(base + L.heaps);
+    double* mm = (double*)(base + L.mm);  // [4][n][2]: h raw, v raw, sobel h, sobel v
+    double* taps = (double*)(base + L.taps);
+    int* se_offs = (int*)(base + L.se_offs);
+    int* areas = ws_int;  // tia_label_area_filter_i32 leaves the per-label areas here
+
+    dim3 grid(hblocks(hw), (unsigned)n);
+    int rc;
+    // 1. blb = remove_small_objects(label(np >= 0.5), max_size=9) > 0
+    hipLaunchKernelGGL(np_threshold_kernel, dim3(hblocks((long)n * hw, HT, 65535)), dim3(HT), 0, st, d_np, (long)n * hw, blb_mask);
+    rc = tia_ccl_label_i32(blb_mask, n, h, w, 4, blob_lab, cnt_blob, ws_int, st);
+    if (rc != TIA_OK) return rc;
+    rc = tia_label_area_filter_i32(blob_lab, n, h, w, 10, ws_int, st);  // areas stay in ws_int
+    if (rc != TIA_OK) return rc;
+    // blob bounding boxes + heap offsets need the areas: do them before ws_int is reused
+    hipLaunchKernelGGL(bbox_reset_kernel, dim3(hblocks((long)n * (hw + 1), HT, 65535)), dim3(HT), 0, st, bbox, (long)n * (hw + 1));
+    hipLaunchKernelGGL(ws_offsets_kernel, dim3((unsigned)n), dim3(1024), 0, st, areas, cnt_blob, hw, 10, offs);
+    // ws_int is scratch for the marker pipeline below: park the blob areas in `dist` (unused until step 5)
+    int* areas_keep = (int*)dist;
+    if (hipMemcpyAsync(areas_keep, areas, (size_t)n * (hw + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return TIA_ELAUNCH;
+
+    // 2. Sobel of the normalised h / v maps
+    hipLaunchKernelGGL(sobel_taps_kernel, dim3(1), dim3(64), 0, st, taps, taps + 64, ksize);
+    hipLaunchKernelGGL(minmax_kernel<float>, dim3((unsigned)n), dim3(1024), 0, st, d_hv, hw, 2, 0, mm);
+    hipLaunchKernelGGL(minmax_kernel<float>, dim3((unsigned)n), dim3(1024), 0, st, d_hv, hw, 2, 1, mm + 2 * n);
+    // h: dx=1 -> kx = derivative taps, ky = smoothing taps (symmetric column filter)
+    hipLaunchKernelGGL(sobel_row_kernel, grid, dim3(HT), 0, st, d_hv, 0, (int)h, (int)w, mm, taps, ksize, rowbuf);
+    hipLaunchKernelGGL(sobel_col_kernel, grid, dim3(HT), 0, st, rowbuf, (int)h, (int)w, taps + 64, ksize, 1, sob_h);
+    // v: dy=1 -> kx = smoothing taps, ky = derivative taps (antisymmetric column filter)
+    hipLaunchKernelGGL(sobel_row_kernel, grid, dim3(HT), 0, st, d_hv, 1, (int)h, (int)w, mm + 2 * n, taps + 64, ksize, rowbuf);
+    hipLaunchKernelGGL(sobel_col_kernel, grid, dim3(HT), 0, st, rowbuf, (int)h, (int)w, taps, ksize, 0, sob_v);
+    hipLaunchKernelGGL(minmax_kernel<double>, dim3((unsigned)n), dim3(1024), 0, st, sob_h, hw, 1, 0, mm + 4 * n);
+    hipLaunchKernelGGL(minmax_kernel<double>, dim3((unsigned)n), dim3(1024), 0, st, sob_v, hw, 1, 0, mm + 6 * n);
+
+    // 3. energy, marker seed
+    hipLaunchKernelGGL(energy_kernel, grid, dim3(HT), 0, st, sob_h, sob_v, mm + 4 * n, mm + 6 * n, blob_lab, hw, dist0, tmp_a);
+
+    // 4. marker = label(open5x5(fill_holes(marker0))), small objects removed
+    rc = tia_fill_holes_u8(tmp_a, n, h, w, tmp_b, ws_int, st);
+    if (rc != TIA_OK) return rc;
+    {
+        // 5x5 ellipse: rows 00100 / 11111 / 11111 / 11111 / 00100 (cv2.getStructuringElement)
+        static const int host_offs[17 * 2] = {-2, 0,  -1, -2, -1, -1, -1, 0, -1, 1, -1, 2, 0, -2, 0, -1, 0, 0,
+                                              0,  1,  0,  2,  1,  -2, 1,  -1, 1, 0, 1,  1, 1, 2,  2, 0};
+        if (hipMemcpyAsync(se_offs, host_offs, sizeof(host_offs), hipMemcpyHostToDevice, st) != hipSuccess) return TIA_ELAUNCH;
+    }
+    rc = tia_binary_morph_u8(tmp_b, n, h, w, se_offs, 17, 1, tmp_a, st);
+    if (rc != TIA_OK) return rc;
+    rc = tia_binary_morph_u8(tmp_a, n, h, w, se_offs, 17, 0, tmp_b, st);
+    if (rc != TIA_OK) return rc;
+    rc = tia_ccl_label_i32(tmp_b, n, h, w, 4, mark_lab, d_ninst, ws_int, st);
+    if (rc != TIA_OK) return rc;
+    rc = tia_label_area_filter_i32(mark_lab, n, h, w, obj_size, ws_int, st);
+    if (rc != TIA_OK) return rc;
+
+    // 5. watershed(dist, markers, mask = blb)
+    // areas_keep lives in `dist`: move it to ws_int (free again) before dist is written
+    if (hipMemcpyAsync(ws_int, areas_keep, (size_t)n * (hw + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return TIA_ELAUNCH;
+    hipLaunchKernelGGL(gauss3_neg_kernel, grid, dim3(HT), 0, st, dist0, (int)h, (int)w, dist);
+    hipLaunchKernelGGL(ws_init_kernel, grid, dim3(HT), 0, st, blob_lab, mark_lab, (int)h, (int)w, d_inst, bbox);
+    const long max_labels = hw / 2 + 2;
+    dim3 fgrid((unsigned)((max_labels + 63) / 64), (unsigned)n);
+    hipLaunchKernelGGL(ws_flood_kernel, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w, 10,
+                       heaps, d_inst);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_hover_instance_stats(const int32_t* d_inst, const uint8_t* d_type, int64_t n, int64_t h, int64_t w,
+                                         int32_t max_inst, int32_t num_types, int64_t* d_stats, int32_t* d_types, void* stream) {
+    if (!d_inst || !d_stats || n <= 0 || h <= 0 || w <= 0 || n > 65535 || max_inst < 0) return TIA_EINVAL;
+    if (d_type && (!d_types || num_types <= 0)) return TIA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const long entries = (long)n * (max_inst + 1);
+    hipLaunchKernelGGL(inst_stats_init_kernel, dim3(hblocks(entries, HT, 65535)), dim3(HT), 0, st, (long long*)d_stats, entries);
+    dim3 grid(hblocks((long)h * w), (unsigned)n);
+    hipLaunchKernelGGL(inst_stats_kernel, grid, dim3(HT), 0, st, d_inst, d_type, (int)h, (int)w, max_inst, num_types,
+                       (long long*)d_stats, d_type ? d_types : (int*)nullptr);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}

@@ -1,0 +1,88 @@
+"""Device wrappers for the HoVer-Net post-processing kernels."""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from tiatoolbox_amd import _lib
+
+
+def proc_np_hv(np_map: torch.Tensor, hv_map: torch.Tensor, *, ksize: int = 21, obj_size: int = 10):
+    """Batched ``_proc_np_hv``: ``np_map [N,H,W(,1)]``, ``hv_map [N,H,W,2]`` float32 CUDA tensors.
+
+    Returns ``(inst [N,H,W] int32, n_markers [N] int32)``.
+    """
+    _lib.require_cuda(np_map, "np_map")
+    _lib.require_cuda(hv_map, "hv_map")
+    if np_map.dim() == 4:
+        np_map = np_map[..., 0]
+    np_map = np_map.to(torch.float32).contiguous()
+    hv_map = hv_map.to(torch.float32).contiguous()
+    n, h, w = np_map.shape
+    if hv_map.shape != (n, h, w, 2):
+        msg = f"hv_map must be [N,H,W,2], got {tuple(hv_map.shape)}"
+        raise ValueError(msg)
+    lib = _lib.load()
+    inst = torch.empty((n, h, w), dtype=torch.int32, device=np_map.device)
+    ninst = torch.empty(n, dtype=torch.int32, device=np_map.device)
+    with torch.cuda.device(np_map.device):
+        for s in range(0, n, 4096):  # bounded scratch (~100 B per pixel per plane)
+            m = min(4096, n - s)
+            nbytes = lib.tia_hover_workspace_bytes(m, h, w)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=np_map.device)
+            rc = lib.tia_hover_proc_np_hv_f32(np_map[s:s + m].data_ptr(), hv_map[s:s + m].data_ptr(), m, h, w, ksize,
+                                              obj_size, inst[s:s + m].data_ptr(), ninst[s:s + m].data_ptr(),
+                                              ws.data_ptr(), nbytes, _lib.current_stream())
+            _lib.check(rc, "tia_hover_proc_np_hv_f32")
+    return inst, ninst
+
+
+def instance_stats(inst: torch.Tensor, type_map: torch.Tensor | None, max_inst: int, num_types: int = 0):
+    """Per-instance area / bbox / coordinate sums (int64 ``[N, max_inst+1, 8]``) and type histograms."""
+    _lib.require_cuda(inst, "inst")
+    inst = inst.contiguous()
+    n, h, w = inst.shape
+    stats = torch.zeros((n, max_inst + 1, 8), dtype=torch.int64, device=inst.device)
+    types = None
+    tptr = 0
+    if type_map is not None:
+        type_map = type_map.to(torch.uint8).contiguous()
+        types = torch.zeros((n, max_inst + 1, num_types), dtype=torch.int32, device=inst.device)
+        tptr = type_map.data_ptr()
+    with torch.cuda.device(inst.device):
+        rc = _lib.load().tia_hover_instance_stats(inst.data_ptr(), tptr, n, h, w, int(max_inst), int(num_types),
+                                                  stats.data_ptr(), types.data_ptr() if types is not None else 0,
+                                                  _lib.current_stream())
+    _lib.check(rc, "tia_hover_instance_stats")
+    return stats, types
+
+
+def info_from_stats(stats: np.ndarray, types: np.ndarray | None, offset=(0, 0)) -> dict:
+    """Assemble the reference's per-instance dict (hovernet.py:670-748) from the device statistics.
+
+    ``centroid`` reproduces ``cv2.moments``: ``m10/m00 + x_min`` with the raw moments of the cropped
+    mask (exact integers), ``type``: most frequent value, ties to the smaller class, background (0)
+    replaced by the runner-up, ``prob = votes / (area + 1e-6)``.
+    """
+    offset = np.asarray(offset)
+    info = {}
+    for inst_id in np.flatnonzero(stats[:, 0] > 0):
+        area, xmin, ymin, xmax, ymax, sumx, sumy, _ = (int(v) for v in stats[inst_id])
+        tl = np.array([xmin, ymin]) + offset
+        centroid = np.array([float(sumx - area * xmin) / float(area), float(sumy - area * ymin) / float(area)]) + tl
+        box = np.array([xmin, ymin, xmax + 1, ymax + 1])
+        box[:2] += offset
+        box[2:] += offset
+        entry = {"box": box, "centroid": centroid, "prob": None, "type": None}
+        if types is not None:
+            votes = types[inst_id]
+            present = np.flatnonzero(votes)
+            order = sorted(present, key=lambda t: votes[t], reverse=True)  # stable: ties keep ascending class
+            top = order[0]
+            if top == 0 and len(order) > 1:
+                top = order[1]
+            entry["type"] = int(top)
+            entry["prob"] = float(votes[top] / (area + 1.0e-6))
+        info[int(inst_id)] = entry
+    return info
