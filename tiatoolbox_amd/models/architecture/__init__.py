@@ -45,6 +45,18 @@ PRETRAINED_INFO = {
             "input_resolutions": [{"resolution": 0.5, "units": "mpp"}]}),
         "dataset": "kather100k",
     },
+    "hovernet_fast-pannuke": {
+        "architecture": ("hovernet.HoVerNet", {
+            "num_types": 6, "mode": "fast",
+            "nuc_type_dict": {0: "Background", 1: "Neoplastic", 2: "Inflammatory", 3: "Connective", 4: "Dead",
+                              5: "Non-Neoplastic Epithelial"}}),
+        "ioconfig": (IOInstanceSegmentorConfig, {
+            "input_resolutions": [{"units": "mpp", "resolution": 0.25}],
+            "output_resolutions": [{"units": "mpp", "resolution": 0.25}] * 3,
+            "margin": 128, "tile_shape": [1024, 1024], "patch_input_shape": [256, 256],
+            "patch_output_shape": [164, 164], "stride_shape": [164, 164],
+            "save_resolution": {"units": "mpp", "resolution": 0.25}, "ignore_index": 0}),
+    },
 }
 
 

@@ -240,20 +240,21 @@ class EngineABC:
             e = min(s + self.batch_size, hi)
             batch = self._preprocess_batch(dataloader, s, e, dtype)
             outs.append(infer_batch(model, batch, device=self.device))
-        if outs and isinstance(outs[0], torch.Tensor):
-            local = torch.cat(outs)
-        elif outs:
-            local = torch.from_numpy(np.concatenate(outs))
-        else:
-            local = torch.empty((0, getattr(self._get_model_attr("num_classes"), "real", 1)))
-        if world_size > 1:
-            if not outs:  # empty shard: need the row shape from a peer-independent source
-                probe = infer_batch(model, self._preprocess_batch(dataloader, 0, 1, dtype), device=self.device)
-                probe = probe if isinstance(probe, torch.Tensor) else torch.from_numpy(probe)
-                local = probe[:0]
-            if torch.device(self.device).type == "cuda":
-                local = local.to(self.device)
-            local = tdist.all_gather_rows(local, n)
+        if not outs:  # empty shard: a one-patch probe supplies the row shapes
+            probe = infer_batch(model, self._preprocess_batch(dataloader, 0, 1, dtype), device=self.device)
+            outs = [tuple(p[:0] for p in probe) if isinstance(probe, tuple) else probe[:0]]
+        multi_head = isinstance(outs[0], tuple)
+        heads = list(zip(*outs)) if multi_head else [outs]
+        gathered = []
+        for chunks in heads:
+            chunks = [c if isinstance(c, torch.Tensor) else torch.from_numpy(np.asarray(c)) for c in chunks]
+            local = torch.cat(chunks)
+            if world_size > 1:
+                if torch.device(self.device).type == "cuda":
+                    local = local.to(self.device)
+                local = tdist.all_gather_rows(local, n)
+            gathered.append(local)
+        local = tuple(gathered) if multi_head else gathered[0]
         raw_predictions = {"probabilities": local}
         if self.return_labels and dataloader.labels is not None:
             raw_predictions["labels"] = np.asarray(dataloader.labels).reshape(-1)
