@@ -213,6 +213,32 @@ int tia_hover_instance_stats(const int32_t* d_inst, const uint8_t* d_type, int64
                              int32_t max_inst, int32_t num_types, int64_t* d_stats, int32_t* d_types,
                              void* stream);
 
+
+/* =======================================================================================
+ * Semantic-segmentation stitching (models/engine/semantic_segmentor.py:1141-1263,1398-1534)
+ * ===================================================================================== */
+
+/*
+ * Horizontal merge of one patch row (merge_batch_to_canvas / merge_horizontal): every pixel of the
+ * row canvas sums, in patch order, the blocks covering it; all-zero blocks are skipped
+ * (:1178-1179); x-extents are clipped to the canvas width.
+ *   d_blocks [n,oh,ow,c] f32   d_xs [n] i32 (output x0 of each block, ascending)
+ *   d_row [oh,W,c] f32 (overwritten)   d_cnt [oh,W] u8 (overwritten)   d_flags [n] i32 scratch
+ */
+int tia_canvas_row_merge_f32(const float* d_blocks, const int32_t* d_xs, int64_t n, int64_t oh, int64_t ow,
+                             int64_t c, int64_t width, float* d_row, uint8_t* d_cnt, int32_t* d_flags,
+                             void* stream);
+
+/*
+ * Vertical merge + normalisation + argmax for canvas rows [y_begin, y_end)
+ * (merge_vertical_chunkwise + post_process_wsi): value = rowA[y-ysA] (+ rowB[y-ysB] where the next
+ * patch row overlaps), prob = value / max(count,1) (f32), prediction = argmax over channels (uint8).
+ * d_row_b may be NULL.  d_probs ([H,W,c] f32) may be NULL.
+ */
+int tia_canvas_finalize_f32(const float* d_row_a, const uint8_t* d_cnt_a, int64_t ys_a, const float* d_row_b,
+                            const uint8_t* d_cnt_b, int64_t ys_b, int64_t oh, int64_t width, int64_t c,
+                            int64_t y_begin, int64_t y_end, float* d_probs, uint8_t* d_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

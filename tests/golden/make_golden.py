@@ -151,8 +151,40 @@ def hover_goldens() -> None:
           [int(out[f"{t}_inst"].max()) for t in "ab"])
 
 
+def grid_goldens() -> None:
+    """PatchExtractor.get_coordinates / filter_coordinates and merge_batch_to_canvas of the real reference."""
+    pe = _ref_import("tiatoolbox.tools.patchextraction")
+    wsr = _ref_import("tiatoolbox.wsicore.wsireader")
+    out = {}
+    cases = {"a": ((2000, 1500), (1024, 1024), (512, 512), (450, 450)), "b": ((333, 777), (64, 48), (32, 24), (20, 17)),
+             "c": ((500, 500), (100, 100), (100, 100), (100, 100))}
+    rng = np.random.default_rng(5)
+    for tag, (img, pin, pout, stride) in cases.items():
+        i_b, o_b = pe.PatchExtractor.get_coordinates(patch_output_shape=pout, image_shape=img, patch_input_shape=pin,
+                                                     stride_shape=stride)
+        out[f"{tag}_args"] = np.array([img, pin, pout, stride])
+        out[f"{tag}_in"], out[f"{tag}_out"] = i_b, o_b
+        mask = (rng.random((max(img[1] // 16, 4), max(img[0] // 16, 4))) < 0.35).astype(np.uint8)
+        reader = object.__new__(wsr.VirtualWSIReader)
+        reader.img = mask
+        out[f"{tag}_mask"] = mask
+        for ratio in (0.0, 0.4):
+            out[f"{tag}_keep{int(ratio * 10)}"] = pe.PatchExtractor.filter_coordinates(reader, o_b, img, min_mask_ratio=ratio)
+    ss = _ref_import("tiatoolbox.models.engine.semantic_segmentor")
+    blocks = rng.random((5, 16, 16, 3)).astype(np.float32)
+    blocks[2] = 0
+    locs = np.array([[0, 0, 16, 16], [12, 0, 28, 16], [24, 0, 40, 16], [36, 0, 52, 16], [48, 0, 64, 16]])
+    locs[:, 2] = np.minimum(locs[:, 2], 60)
+    canvas, count = ss.merge_batch_to_canvas(blocks, locs, (16, 60, 3))
+    out["merge_blocks"], out["merge_locs"], out["merge_canvas"], out["merge_count"] = blocks, locs, canvas, count
+    np.savez_compressed(HERE / "grid_golden.npz", **out)
+    print("wrote grid_golden.npz", len(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stain", "mask", "hover"]
+    which = sys.argv[1:] or ["stain", "mask", "hover", "grid"]
+    if "grid" in which:
+        grid_goldens()
     if "hover" in which:
         hover_goldens()
     if "stain" in which:

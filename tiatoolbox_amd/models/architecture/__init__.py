@@ -45,6 +45,15 @@ PRETRAINED_INFO = {
             "input_resolutions": [{"resolution": 0.5, "units": "mpp"}]}),
         "dataset": "kather100k",
     },
+    "fcn_resnet50_unet-bcss": {
+        "architecture": ("unet.UNetModel", {"num_input_channels": 3, "num_output_channels": 5, "encoder": "resnet50",
+                                            "decoder_block": [3, 3]}),
+        "ioconfig": (IOSegmentorConfig, {
+            "input_resolutions": [{"units": "mpp", "resolution": 0.25}],
+            "output_resolutions": [{"units": "mpp", "resolution": 0.25}],
+            "patch_input_shape": [1024, 1024], "patch_output_shape": [512, 512], "stride_shape": [450, 450],
+            "save_resolution": {"units": "mpp", "resolution": 0.25}, "ignore_index": 0}),
+    },
     "hovernet_fast-pannuke": {
         "architecture": ("hovernet.HoVerNet", {
             "num_types": 6, "mode": "fast",

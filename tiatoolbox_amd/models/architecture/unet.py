@@ -1,0 +1,154 @@
+"""ResNet-50 / plain UNet segmentation model (API + parameter names of reference
+``tiatoolbox/models/architecture/unet.py``).
+
+Encoder = torchvision-style ResNet-50 (attributes ``conv1, bn1, layer1..4, fc`` so reference
+``backbone.*`` keys load strictly); decoder = additive (or concatenated) skips with nearest x2
+upsampling.  ``infer_batch``: softmax -> bilinear x2 -> centre crop to half the input size, NHWC.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F  # noqa: N812
+from torch import nn
+
+from tiatoolbox_amd.models.architecture.hovernet import UpSample2x
+from tiatoolbox_amd.models.architecture.resnet import resnet_children
+from tiatoolbox_amd.models.architecture.utils import argmax_last_axis, centre_crop
+from tiatoolbox_amd.models.models_abc import ModelABC
+
+
+class ResNetEncoder(nn.Module):
+    """ResNet returning the features of every down-sampling level (ref. :24-97)."""
+
+    def __init__(self, num_input_channels: int = 3, name: str = "resnet50") -> None:
+        super().__init__()
+        conv1, bn1, relu, maxpool, l1, l2, l3, l4 = resnet_children(name)
+        if num_input_channels != 3:  # noqa: PLR2004
+            conv1 = nn.Conv2d(num_input_channels, 64, 7, stride=2, padding=3)
+        self.conv1, self.bn1, self.relu, self.maxpool = conv1, bn1, relu, maxpool
+        self.layer1, self.layer2, self.layer3, self.layer4 = l1, l2, l3, l4
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(2048 if name in ("resnet50", "resnet101") else 512, 1000)  # unused; keeps the key set
+
+    def forward(self, x: torch.Tensor) -> list[torch.Tensor]:
+        x0 = x = self.relu(self.bn1(self.conv1(x)))
+        x1 = x = self.layer1(self.maxpool(x))
+        x2 = x = self.layer2(x)
+        x3 = x = self.layer3(x)
+        return [x0, x1, x2, x3, self.layer4(x)]
+
+    @staticmethod
+    def resnet50(num_input_channels: int) -> "ResNetEncoder":
+        return ResNetEncoder(num_input_channels, "resnet50")
+
+
+class UnetEncoder(nn.Module):
+    """Plain conv-BN-ReLU x2 + average-pool encoder (ref. :100-190)."""
+
+    def __init__(self, num_input_channels: int, layer_output_channels: list[int]) -> None:
+        super().__init__()
+        self.blocks = nn.ModuleList()
+        ch = num_input_channels
+        for out_ch in layer_output_channels:
+            self.blocks.append(nn.ModuleList([
+                nn.Sequential(nn.Conv2d(ch, out_ch, 3, 1, padding=1, bias=False), nn.BatchNorm2d(out_ch), nn.ReLU(),
+                              nn.Conv2d(out_ch, out_ch, 3, 1, padding=1, bias=False), nn.BatchNorm2d(out_ch), nn.ReLU()),
+                nn.AvgPool2d(2, stride=2)]))
+            ch = out_ch
+
+    def forward(self, x: torch.Tensor) -> list[torch.Tensor]:
+        feats = []
+        for block in self.blocks:
+            x = block[0](x)
+            feats.append(x)
+            x = block[1](x)
+        return feats
+
+
+def create_block(kernels: list, input_ch: int, output_ch: int, *, pre_activation: bool) -> list:
+    """Conv stack with same padding, pre- or post-activation (ref. :193-240)."""
+    layers: list[nn.Module] = []
+    for ksize in kernels:
+        conv = nn.Conv2d(input_ch, output_ch, (ksize, ksize), padding=int((ksize - 1) // 2), bias=False)
+        if pre_activation:
+            layers += [nn.BatchNorm2d(input_ch), nn.ReLU(), conv]
+        else:
+            layers += [conv, nn.BatchNorm2d(output_ch), nn.ReLU()]
+        input_ch = output_ch
+    return layers
+
+
+class UNetModel(ModelABC):
+    """UNet with a ResNet-50 (or plain) encoder (ref. :243-476)."""
+
+    def __init__(self, num_input_channels: int = 2, num_output_channels: int = 2, encoder: str = "resnet50",
+                 encoder_levels: list[int] | None = None, decoder_block: tuple[int] | None = None,
+                 skip_type: str = "add") -> None:
+        super().__init__()
+        if encoder.lower() not in {"resnet50", "unet"}:
+            msg = f"Unknown encoder `{encoder}`"
+            raise ValueError(msg)
+        encoder_levels = encoder_levels or [64, 128, 256, 512, 1024]
+        decoder_block = decoder_block or [3, 3]
+        pre_activation = None
+        if encoder == "resnet50":
+            pre_activation = True
+            self.backbone = ResNetEncoder.resnet50(num_input_channels)
+        if encoder == "unet":
+            pre_activation = False
+            self.backbone = UnetEncoder(num_input_channels, encoder_levels)
+        if skip_type.lower() not in {"add", "concat"}:
+            msg = f"Unknown type of skip connection: `{skip_type}`"
+            raise ValueError(msg)
+        self.skip_type = skip_type.lower()
+        with torch.no_grad():
+            down_ch = [v.shape[1] for v in self.backbone(torch.rand([1, num_input_channels, 256, 256]))][::-1]
+        self.conv1x1 = nn.Conv2d(down_ch[0], down_ch[1], (1, 1), bias=False)
+        self.uplist = nn.ModuleList()
+        next_up_ch = None
+        for idx, ch in enumerate(down_ch[1:]):
+            next_up_ch = down_ch[idx + 2] if idx + 2 < len(down_ch) else ch
+            in_ch = ch * 2 if self.skip_type == "concat" else ch
+            self.uplist.append(nn.Sequential(*create_block(decoder_block, in_ch, next_up_ch, pre_activation=pre_activation)))
+        self.clf = nn.Conv2d(next_up_ch, num_output_channels, (1, 1), bias=True)
+        self.upsample2x = UpSample2x()
+
+    @staticmethod
+    def _transform(image: torch.Tensor) -> torch.Tensor:
+        return image / 255.0
+
+    def forward(self, imgs: torch.Tensor, *args, **kwargs) -> torch.Tensor:  # noqa: ARG002
+        en_list = self.backbone(self._transform(imgs))
+        x = self.conv1x1(en_list[-1])
+        en_list = en_list[:-1]
+        for idx in range(1, len(en_list) + 1):
+            y = en_list[-idx]
+            up = self.upsample2x(x)
+            x = up + y if self.skip_type == "add" else torch.cat([up, y], dim=1)
+            x = self.uplist[idx - 1](x)
+        return self.clf(x)
+
+    @staticmethod
+    def infer_batch(model: nn.Module, batch_data, *, device: str):
+        """softmax -> bilinear x2 -> centre crop (h//2, w//2) -> NHWC float32 (ref. :420-468)."""
+        on_device = isinstance(batch_data, torch.Tensor) and batch_data.is_cuda
+        if not isinstance(batch_data, torch.Tensor):
+            batch_data = torch.as_tensor(np.asarray(batch_data))
+        param = next(model.parameters())
+        imgs = batch_data.to(device).to(param.dtype).permute(0, 3, 1, 2)
+        if torch.device(device).type == "cuda":
+            imgs = imgs.contiguous(memory_format=torch.channels_last)
+        _, _, h, w = imgs.shape
+        model.eval()
+        with torch.inference_mode():
+            probs = F.softmax(model(imgs).float(), 1)
+            probs = F.interpolate(probs, scale_factor=2, mode="bilinear", align_corners=False)
+            probs = centre_crop(probs, [h // 2, w // 2])
+            output = probs.permute(0, 2, 3, 1).contiguous()
+        return output if on_device else output.cpu().numpy()
+
+    @staticmethod
+    def postproc(image):
+        return argmax_last_axis(image=image)

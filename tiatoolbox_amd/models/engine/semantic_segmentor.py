@@ -1,0 +1,191 @@
+"""Semantic segmentation engine (API of reference ``tiatoolbox/models/engine/semantic_segmentor.py``).
+
+Patch mode = PatchPredictor with dense outputs.  WSI mode stitches overlapping patch outputs into a
+whole-slide prediction entirely on the GPU: per patch row a gather kernel merges the row
+(``tia_canvas_row_merge_f32``), consecutive rows are added over their overlap, normalised by the
+count and arg-maxed (``tia_canvas_finalize_f32``) -- the reference's ``merge_horizontal`` /
+``merge_vertical_chunkwise`` arithmetic, bit for bit, without the 5 MiB/patch device->host copies.
+Patch rows are sharded over ranks when ``torch.distributed`` is initialised.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from tiatoolbox_amd import _lib, distributed as tdist
+from tiatoolbox_amd.models.engine.patch_predictor import PatchPredictor
+from tiatoolbox_amd.tools.patchextraction import PatchExtractor
+from tiatoolbox_amd.wsicore import ArrayWSIReader
+
+
+def merge_batch_to_canvas(blocks, output_locations, merged_shape):
+    """Row merge of the reference (:1141-1183) on the GPU; NumPy in/out for API compatibility.
+
+    Blocks must share one shape and one ``ys`` (a patch row), as in every call the reference makes.
+    """
+    blocks_t = torch.as_tensor(np.asarray(blocks, dtype=np.float32))
+    locs = np.asarray(output_locations).reshape(-1, 4).astype(np.int64)
+    h, w, c = merged_shape
+    from tiatoolbox_amd.utils._tensors import default_device
+
+    dev = default_device()
+    if blocks_t.shape[0] == 0:
+        return np.zeros(merged_shape, dtype=np.asarray(blocks).dtype), np.zeros((h, w, 1), dtype=np.uint8)
+    order = np.argsort(locs[:, 0], kind="stable")
+    row, cnt = _row_merge(blocks_t[order].to(dev), locs[order, 0], w)
+    canvas = row[:h].cpu().numpy().astype(np.asarray(blocks).dtype)
+    return canvas, cnt[:h].cpu().numpy()[..., None]
+
+
+def _row_merge(blocks: torch.Tensor, xs: np.ndarray, width: int) -> tuple[torch.Tensor, torch.Tensor]:
+    n, oh, ow, c = blocks.shape
+    blocks = blocks.contiguous()
+    row = torch.empty((oh, width, c), dtype=torch.float32, device=blocks.device)
+    cnt = torch.empty((oh, width), dtype=torch.uint8, device=blocks.device)
+    flags = torch.empty(n, dtype=torch.int32, device=blocks.device)
+    xs_t = torch.as_tensor(np.asarray(xs, dtype=np.int32)).to(blocks.device)
+    with torch.cuda.device(blocks.device):
+        rc = _lib.load().tia_canvas_row_merge_f32(blocks.data_ptr(), xs_t.data_ptr(), n, oh, ow, c, width, row.data_ptr(),
+                                                  cnt.data_ptr(), flags.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "tia_canvas_row_merge_f32")
+    return row, cnt
+
+
+def _finalize(row_a, cnt_a, ys_a, row_b, cnt_b, ys_b, y0, y1, probs, pred) -> None:
+    oh, width, c = row_a.shape
+    with torch.cuda.device(row_a.device):
+        rc = _lib.load().tia_canvas_finalize_f32(
+            row_a.data_ptr(), cnt_a.data_ptr(), int(ys_a), row_b.data_ptr() if row_b is not None else 0,
+            cnt_b.data_ptr() if cnt_b is not None else 0, int(ys_b), oh, width, c, int(y0), int(y1),
+            probs.data_ptr() if probs is not None else 0, pred.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "tia_canvas_finalize_f32")
+
+
+class SemanticSegmentor(PatchPredictor):
+    """Semantic segmentation of patches or whole (in-memory) slides (ref. :136-1821)."""
+
+    def __init__(self, model, batch_size: int = 8, num_workers: int = 0, weights=None, *, device: str = "cpu",
+                 verbose: bool = True) -> None:
+        super().__init__(model=model, batch_size=batch_size, num_workers=num_workers, weights=weights, device=device,
+                         verbose=verbose)
+        self.auto_get_mask = True
+        self.fold_batchnorm = False  # the decoder is pre-activation (BN before conv): keep the module as is
+
+    # ------------------------------------------------------------------------------ WSI mode
+    def get_coordinates(self, reader: ArrayWSIReader, mask_reader: ArrayWSIReader | None):
+        cfg = self._ioconfig
+        w, h = reader.slide_dimensions
+        in_b, out_b = PatchExtractor.get_coordinates(
+            patch_output_shape=tuple(cfg.patch_output_shape[::-1]), image_shape=(w, h),
+            patch_input_shape=tuple(cfg.patch_input_shape[::-1]), stride_shape=tuple(cfg.stride_shape[::-1]))
+        keep = np.ones(len(in_b), dtype=bool)
+        if mask_reader is not None:
+            keep = PatchExtractor.filter_coordinates(mask_reader, out_b, (w, h), min_mask_ratio=0)
+        return in_b, out_b, keep
+
+    def infer_wsi(self, reader: ArrayWSIReader, mask_reader: ArrayWSIReader | None = None, *,
+                  return_probabilities: bool = False) -> dict:
+        """Tile, infer and stitch one slide; returns device tensors."""
+        dev = torch.device(self.device)
+        if dev.type != "cuda":
+            msg = "WSI-mode stitching runs on the GPU (device='cuda'); there is no CPU fallback."
+            raise _lib.HipLibraryError(msg)
+        from tiatoolbox_amd.models.engine.engine_abc import _DTYPES
+
+        dtype = _DTYPES[str(self.compute_dtype).replace("torch.", "")]
+        model = self._inference_model(dtype)
+        infer_batch = self._get_model_attr("infer_batch")
+        w, h = reader.slide_dimensions
+        in_b, out_b, keep = self.get_coordinates(reader, mask_reader)
+        row_ys = np.unique(out_b[:, 1])
+        oh = int(self._ioconfig.patch_output_shape[0])
+        rank, world = tdist.world() if self.distributed else (0, 1)
+        r_lo, r_hi = tdist.shard_bounds(len(row_ys), rank, world)
+        pred = torch.zeros((h, w), dtype=torch.uint8, device=dev)
+        probs = None
+        n_ch = None
+        prev = None  # (row, cnt, ys)
+        # one extra leading row so the band's first canvas rows see their upper neighbour
+        for ri in range(max(r_lo - 1, 0), r_hi):
+            ys = int(row_ys[ri])
+            sel = np.flatnonzero((out_b[:, 1] == ys) & keep)
+            if len(sel):
+                outs = []
+                for s in range(0, len(sel), self.batch_size):
+                    idx = sel[s:s + self.batch_size]
+                    outs.append(infer_batch(model, reader.read_bounds_batch(in_b[idx]), device=self.device))
+                blocks = torch.cat(outs)
+                n_ch = blocks.shape[-1]
+                if return_probabilities and probs is None:
+                    probs = torch.zeros((h, w, n_ch), dtype=torch.float32, device=dev)
+                row, cnt = _row_merge(blocks, out_b[sel, 0], w)
+            else:
+                if n_ch is None:
+                    probe = infer_batch(model, reader.read_bounds_batch(in_b[:1]), device=self.device)
+                    n_ch = probe.shape[-1]
+                row = torch.zeros((oh, w, n_ch), dtype=torch.float32, device=dev)
+                cnt = torch.zeros((oh, w), dtype=torch.uint8, device=dev)
+            if ri >= r_lo:
+                y1 = min(int(row_ys[ri + 1]) if ri + 1 < len(row_ys) else ys + oh, h)
+                if prev is None:
+                    _finalize(row, cnt, ys, None, None, 0, ys, y1, probs, pred)
+                else:
+                    _finalize(prev[0], prev[1], prev[2], row, cnt, ys, ys, y1, probs, pred)
+            prev = (row, cnt, ys)
+        if world > 1:  # each rank owns a horizontal band; exchange the uint8 bands
+            band = torch.zeros_like(pred)
+            y_lo = int(row_ys[r_lo]) if r_lo < len(row_ys) else h
+            y_hi = min(int(row_ys[r_hi]) if r_hi < len(row_ys) else h, h)
+            band[y_lo:y_hi] = pred[y_lo:y_hi]
+            torch.distributed.all_reduce(band, op=torch.distributed.ReduceOp.MAX)
+            pred = band
+        out = {"predictions": pred, "coordinates": out_b[keep]}
+        if return_probabilities and probs is not None:
+            out["probabilities"] = probs
+        return out
+
+    def run(self, images, *, masks=None, input_resolutions=None, patch_input_shape=None, ioconfig=None,
+            patch_mode: bool = True, save_dir=None, overwrite: bool = False, output_type: str = "dict", **kwargs):
+        """Patch mode: as PatchPredictor.  WSI mode: ``images`` is a list of ``ArrayWSIReader`` / HxWx3 arrays;
+        returns ``{"predictions": [HxW uint8 ...], ...}`` (or ``.npy`` files under ``save_dir``)."""
+        if patch_mode:
+            return super().run(images, masks=masks, input_resolutions=input_resolutions,
+                               patch_input_shape=patch_input_shape, ioconfig=ioconfig, patch_mode=True,
+                               save_dir=save_dir, overwrite=overwrite, output_type=output_type, **kwargs)
+        for key, val in kwargs.items():
+            setattr(self, key, val)
+        if not isinstance(images, (list, tuple)):
+            msg = "Input must be a list of file paths or a numpy array."
+            raise TypeError(msg)
+        self._validate_input_numbers(images=images, masks=masks)
+        self._ioconfig = self._load_ioconfig(ioconfig=ioconfig)
+        self.model = self.model.to(device=self.device)
+        results: dict = {"predictions": [], "coordinates": []}
+        for i, image in enumerate(images):
+            reader = image if isinstance(image, ArrayWSIReader) else ArrayWSIReader(image)
+            mask_reader = None
+            if masks is not None:
+                m = masks[i]
+                mask_reader = m if isinstance(m, ArrayWSIReader) else ArrayWSIReader(m, mode="bool")
+            elif self.auto_get_mask:
+                mask_reader = reader.tissue_mask(resolution=1.25, units="power")
+            out = self.infer_wsi(reader, mask_reader, return_probabilities=bool(self.return_probabilities))
+            results["predictions"].append(out["predictions"].cpu().numpy())
+            results["coordinates"].append(out["coordinates"])
+            if "probabilities" in out:
+                results.setdefault("probabilities", []).append(out["probabilities"].cpu().numpy())
+        if save_dir is not None:
+            from pathlib import Path
+
+            save_dir = Path(save_dir)
+            save_dir.mkdir(parents=True, exist_ok=overwrite or True)
+            paths = {}
+            for i, p in enumerate(results["predictions"]):
+                path = save_dir / f"{i}.predictions.npy"
+                np.save(path, p)
+                paths[i] = path
+            return paths
+        return results
+
+    predict = run
