@@ -239,6 +239,36 @@ int tia_canvas_finalize_f32(const float* d_row_a, const uint8_t* d_cnt_a, int64_
                             const uint8_t* d_cnt_b, int64_t ys_b, int64_t oh, int64_t width, int64_t c,
                             int64_t y_begin, int64_t y_end, float* d_probs, uint8_t* d_pred, void* stream);
 
+
+/* =======================================================================================
+ * Reinhard colour normalisation (tools/stainnorm.py:222-367): OpenCV 8-bit RGB<->Lab
+ * ===================================================================================== */
+
+/* Fixed-point tables of OpenCV's RGB2Lab_b / Lab2RGBinteger (built on the host once). */
+typedef struct tia_lab_tables {
+    uint16_t gamma[256];      /* sRGBGammaTab_b                                   */
+    uint16_t cbrt[3072];      /* LabCbrtTab_b                                     */
+    uint16_t lab_y[256];      /* LabToYF_b[2*i]                                   */
+    uint16_t lab_ify[256];    /* LabToYF_b[2*i+1]                                 */
+    uint8_t inv_gamma[4096];  /* sRGBInvGammaTab_b                                */
+    int32_t c_fwd[9];         /* 12-bit sRGB->XYZ/whitepoint                      */
+    int32_t c_inv[9];         /* 12-bit XYZ*whitepoint->sRGB                      */
+} tia_lab_tables;
+
+/* Per-image histograms of the 8-bit Lab channels, ACCUMULATED into d_hist [n,3,256] u32
+ * (cv2.cvtColor(RGB2LAB) + cv2.meanStdDev, stainnorm.py:309-315,362-364). */
+int tia_lab_hist_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w, const tia_lab_tables* d_tables,
+                    uint32_t* d_hist, void* stream);
+
+/* out = LAB2RGB(lut[c][ RGB2LAB(img)[c] ]) with one 3x256 uint8 LUT per image: the whole
+ * ReinhardNormalizer.transform per-pixel chain (stainnorm.py:272-340) folded into tables. */
+int tia_reinhard_apply_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w, const tia_lab_tables* d_tables,
+                          const uint8_t* d_lut /* [n,3,256] */, uint8_t* d_out, void* stream);
+
+/* cv2.cvtColor 8-bit RGB2LAB (dir 0) / LAB2RGB (dir 1) of npix pixels. */
+int tia_lab_convert_u8(const uint8_t* d_src, int64_t npix, const tia_lab_tables* d_tables, int32_t dir,
+                       uint8_t* d_dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

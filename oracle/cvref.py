@@ -364,3 +364,71 @@ def Sobel(src, ddepth, dx, dy, ksize=3):  # noqa: N802, ARG001
 def GaussianBlur(src, ksize, sigma):  # noqa: N802, ARG001
     assert tuple(ksize) == (3, 3) and sigma == 0
     return gaussian_blur3_f64(src)
+
+
+# ----------------------------------------------------------------------------- Lab -> RGB (8-bit)
+LAB_BASE_SHIFT = 14
+LAB_BASE = 1 << LAB_BASE_SHIFT
+INV_GAMMA_SHIFT = 12
+INV_GAMMA_TAB_SIZE = 1 << INV_GAMMA_SHIFT
+MIN_AB_VALUE = -8145
+_XYZ2SRGB_D65 = np.array([3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311])
+
+
+def _trunc_div(a, b: int):
+    """C integer division (truncation toward zero) for NumPy integer arrays."""
+    a = np.asarray(a, dtype=np.int64)
+    q = np.abs(a) // b
+    return np.where(a < 0, -q, q)
+
+
+def ab_to_xz(i):
+    """``abToXZ_b[i - minABvalue]`` of OpenCV's ``initLabTabs`` computed directly (C integer arithmetic)."""
+    i = np.asarray(i, dtype=np.int64)
+    lin = _trunc_div(i * 108, 841) - (LAB_BASE * 16 // 116 * 108 // 841)
+    cub = _trunc_div(_trunc_div(i * i, LAB_BASE) * i, LAB_BASE)
+    return np.where(i <= 3390, lin, cub)
+
+
+@functools.lru_cache(maxsize=1)
+def lab2rgb_tables() -> dict[str, np.ndarray]:
+    """``LabToYF_b``, ``sRGBInvGammaTab_b`` and the 12-bit XYZ->sRGB coefficients (``Lab2RGBinteger``)."""
+    f32 = np.float32
+    i = np.arange(256)
+    base = f32(LAB_BASE)
+    y_lo = np.rint((i * LAB_BASE * 20 * 9).astype(f32) / f32(17 * 29 * 29 * 29))
+    ify_lo = np.rint(base * (f32(16) / f32(116) + (i * 5).astype(f32) / f32(3 * 17 * 29)).astype(f32))
+    fy = ((i * 100 * LAB_BASE).astype(f32) / f32(255 * 116) + f32(16 * LAB_BASE) / f32(116)).astype(f32)
+    ify_hi = np.rint(fy)
+    y_hi = np.rint(((fy * fy).astype(f32) * fy).astype(f32) / f32(float(LAB_BASE) * LAB_BASE))
+    lab_to_y = np.where(i <= 20, y_lo, y_hi).astype(np.int64)
+    lab_to_ify = np.where(i <= 20, ify_lo, ify_hi).astype(np.int64)
+    x = (np.arange(INV_GAMMA_TAB_SIZE).astype(f32) / f32(INV_GAMMA_TAB_SIZE - 1)).astype(np.float64)
+    inv = np.where(x <= 0.0031308, x * 12.92, 1.055 * np.power(x, 1.0 / 2.4) - 0.055)
+    inv_gamma = np.rint((f32(255.0) * inv.astype(f32)).astype(f32)).astype(np.int64)
+    coeffs = np.array([int(np.rint((1 << LAB_SHIFT) * _XYZ2SRGB_D65[r * 3 + k] * _D65[k])) for r in range(3) for k in range(3)],
+                      dtype=np.int64)
+    return {"y": lab_to_y, "ify": lab_to_ify, "inv_gamma": inv_gamma, "coeffs": coeffs}
+
+
+def lab2rgb_u8(lab: np.ndarray) -> np.ndarray:
+    """``cv2.cvtColor(lab, cv2.COLOR_LAB2RGB)`` for uint8 input: OpenCV 4.x ``Lab2RGBinteger``
+    (14-bit fixed point, inverse-gamma table of 4096 entries).  **Parity unpinned** (see module doc)."""
+    lab = np.asarray(lab)
+    t = lab2rgb_tables()
+    ll = lab[..., 0].astype(np.int64)
+    aa = lab[..., 1].astype(np.int64)
+    bb = lab[..., 2].astype(np.int64)
+    y = t["y"][ll]
+    ify = t["ify"][ll]
+    adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * LAB_BASE // 500
+    bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * LAB_BASE // 200 + 1
+    x = ab_to_xz(ify + adiv)
+    z = ab_to_xz(ify - bdiv)
+    c = t["coeffs"]
+    shift = LAB_SHIFT + (LAB_BASE_SHIFT - INV_GAMMA_SHIFT)
+    out = []
+    for r in range(3):
+        v = _descale(c[r * 3] * x + c[r * 3 + 1] * y + c[r * 3 + 2] * z, shift)
+        out.append(t["inv_gamma"][np.clip(v, 0, INV_GAMMA_TAB_SIZE - 1)])
+    return np.clip(np.stack(out, axis=-1), 0, 255).astype(np.uint8)

@@ -181,8 +181,28 @@ def grid_goldens() -> None:
     print("wrote grid_golden.npz", len(out))
 
 
+def reinhard_goldens() -> None:
+    """ReinhardNormalizer of the real reference (cv2 colour conversions bound to the oracle's restatements)."""
+    stainnorm, _, _ = _import_reference()
+    gold = np.load(HERE / "stain_golden.npz")
+    target = np.load(HERE / "target_crop_256.npy")
+    crops = gold["real_crops"]
+    he = synth.g_he(3, 96, 96, seed=int(gold["he_seed"]))
+    norm = stainnorm.get_normalizer("reinhard")
+    norm.fit(target.copy())
+    out = {"target_means": np.array(norm.target_means), "target_stds": np.array(norm.target_stds),
+           "real": np.stack([norm.transform(c.copy()) for c in crops]), "he": np.stack([norm.transform(c.copy()) for c in he])}
+    ms = [norm.get_mean_std(c.copy()) for c in crops]
+    out["real_means"] = np.array([m[0] for m in ms])
+    out["real_stds"] = np.array([m[1] for m in ms])
+    np.savez_compressed(HERE / "reinhard_golden.npz", **out)
+    print("wrote reinhard_golden.npz", out["target_means"], out["target_stds"])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stain", "mask", "hover", "grid"]
+    which = sys.argv[1:] or ["stain", "mask", "hover", "grid", "reinhard"]
+    if "reinhard" in which:
+        reinhard_goldens()
     if "grid" in which:
         grid_goldens()
     if "hover" in which:

@@ -39,6 +39,12 @@ class StainParams(C.Structure):
     ]
 
 
+class LabTables(C.Structure):
+    _fields_ = [("gamma", C.c_uint16 * 256), ("cbrt", C.c_uint16 * 3072), ("lab_y", C.c_uint16 * 256),
+                ("lab_ify", C.c_uint16 * 256), ("inv_gamma", C.c_uint8 * 4096), ("c_fwd", C.c_int32 * 9),
+                ("c_inv", C.c_int32 * 9)]
+
+
 class HipLibraryError(RuntimeError):
     """The HIP extension is missing or a kernel launch failed."""
 
@@ -65,6 +71,9 @@ _SIGNATURES = {
     "tia_hover_proc_np_hv_f32": ([_P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P, C.c_size_t, _P], C.c_int),
     "tia_canvas_row_merge_f32": ([_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
     "tia_canvas_finalize_f32": ([_P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P], C.c_int),
+    "tia_lab_hist_u8": ([_P, _I64, _I64, _I64, _P, _P, _P], C.c_int),
+    "tia_reinhard_apply_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
+    "tia_lab_convert_u8": ([_P, _I64, _P, _I32, _P, _P], C.c_int),
     "tia_hover_instance_stats": ([_P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P], C.c_int),
 }
 

@@ -93,3 +93,29 @@ def ty_tables() -> np.ndarray:
     """``ty[c][v] = C[3+c] * gamma_tab[v]``: the Y row of RGB2Lab_b, one table per channel."""
     t = lab_tables()
     return np.stack([t["coeffs"][3 + c] * t["gamma"] for c in range(3)]).astype(np.int32)
+
+
+# ---------------------------------------------------------------- OpenCV Lab2RGBinteger tables
+_XYZ2RGB = (3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311)
+LAB_BASE = 1 << 14
+INV_GAMMA_TAB_SIZE = 1 << 12
+
+
+@functools.lru_cache(maxsize=1)
+def lab_inverse_tables() -> dict[str, np.ndarray]:
+    """``LabToYF_b`` (y, ify), ``sRGBInvGammaTab_b`` and the 12-bit XYZ->sRGB coefficients."""
+    f32 = np.float32
+    i = np.arange(256)
+    y_lo = np.rint((i * LAB_BASE * 20 * 9).astype(f32) / f32(17 * 29 * 29 * 29))
+    ify_lo = np.rint(f32(LAB_BASE) * (f32(16) / f32(116) + (i * 5).astype(f32) / f32(3 * 17 * 29)).astype(f32))
+    fy = ((i * 100 * LAB_BASE).astype(f32) / f32(255 * 116) + f32(16 * LAB_BASE) / f32(116)).astype(f32)
+    y_hi = np.rint(((fy * fy).astype(f32) * fy).astype(f32) / f32(float(LAB_BASE) * LAB_BASE))
+    x = (np.arange(INV_GAMMA_TAB_SIZE).astype(f32) / f32(INV_GAMMA_TAB_SIZE - 1)).astype(np.float64)
+    inv = np.where(x <= 0.0031308, x * 12.92, 1.055 * np.power(x, 1.0 / 2.4) - 0.055)
+    return {
+        "y": np.where(i <= 20, y_lo, y_hi).astype(np.int64),
+        "ify": np.where(i <= 20, ify_lo, np.rint(fy)).astype(np.int64),
+        "inv_gamma": np.rint((f32(255.0) * inv.astype(f32)).astype(f32)).astype(np.int64),
+        "coeffs": np.array([round((1 << LAB_SHIFT) * _XYZ2RGB[r * 3 + k] * _WHITE[k]) for r in range(3) for k in range(3)],
+                           dtype=np.int64),
+    }
