@@ -9,6 +9,8 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "common.hpp"
 
 #pragma clang fp contract(off)
@@ -16,6 +18,10 @@
 namespace tia {
 
 constexpr int AT = 256;  // threads per block for the streaming kernels
+#ifndef TIA_LUT_REP
+#define TIA_LUT_REP 8
+#endif
+constexpr int REP = TIA_LUT_REP;  // copies of the f32 OD table in LDS (one per bank when 32)
 
 struct StainT {
     double s[6];
@@ -63,24 +69,35 @@ struct Out<TIA_OUT_F64> {
     template <class F>
     static __device__ __forceinline__ T cvt(F v) { return (double)v; }
 };
-// ToTensor() of the truncated uint8: float32(u8)/255, then rounded to the storage type
+// ToTensor() of the truncated uint8: float32(u8)/255, then rounded to the storage type.
+// x/255 for the 256 possible bytes: q = x*(1/255f) followed by one Markstein correction step
+// (e = fma(-255,q,x); q' = fma(e,1/255f,q)) is the correctly rounded float32 quotient for every byte,
+// and for the 16-bit storage types the uncorrected product already rounds to the same half/bfloat16
+// (checked exhaustively on the host, tests/test_stain_gpu.py::test_unit_outputs_equal_totensor).
+__device__ __forceinline__ float trunc_nonneg(float v) { return floorf(v); }
+__device__ __forceinline__ float trunc_nonneg(double v) { return (float)floor(v); }
+__device__ __forceinline__ float unit_q(float x) { return x * 0.00392156885936856269836425781250f; }
 template <>
 struct Out<TIA_OUT_UNIT_F32> {
     using T = float;
     template <class F>
-    static __device__ __forceinline__ T cvt(F v) { return __fdiv_rn((float)(unsigned)v, 255.0f); }
+    static __device__ __forceinline__ T cvt(F v) {
+        const float x = trunc_nonneg(v), r = 0.00392156885936856269836425781250f;
+        const float q = x * r;
+        return __builtin_fmaf(__builtin_fmaf(-255.0f, q, x), r, q);
+    }
 };
 template <>
 struct Out<TIA_OUT_UNIT_F16> {
     using T = __half;
     template <class F>
-    static __device__ __forceinline__ T cvt(F v) { return __float2half_rn(__fdiv_rn((float)(unsigned)v, 255.0f)); }
+    static __device__ __forceinline__ T cvt(F v) { return __float2half_rn(unit_q(trunc_nonneg(v))); }
 };
 template <>
 struct Out<TIA_OUT_UNIT_BF16> {
     using T = __hip_bfloat16;
     template <class F>
-    static __device__ __forceinline__ T cvt(F v) { return __float2bfloat16(__fdiv_rn((float)(unsigned)v, 255.0f)); }
+    static __device__ __forceinline__ T cvt(F v) { return __float2bfloat16(unit_q(trunc_nonneg(v))); }
 };
 
 template <class T, int BYTES = sizeof(T) * 12>
@@ -94,20 +111,21 @@ __device__ __forceinline__ void store12(T* __restrict__ dst, const Pack12<T>& pk
     if constexpr (bytes == 12) {
         const uint32_t* w = reinterpret_cast<const uint32_t*>(pk.v);
         uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-        d[0] = w[0];
-        d[1] = w[1];
-        d[2] = w[2];
+        __builtin_nontemporal_store(w[0], d);
+        __builtin_nontemporal_store(w[1], d + 1);
+        __builtin_nontemporal_store(w[2], d + 2);
     } else if constexpr (bytes == 24) {
-        const uint2* w = reinterpret_cast<const uint2*>(pk.v);
-        uint2* d = reinterpret_cast<uint2*>(dst);
-        d[0] = w[0];
-        d[1] = w[1];
-        d[2] = w[2];
+        const unsigned long long* w = reinterpret_cast<const unsigned long long*>(pk.v);
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
+        __builtin_nontemporal_store(w[0], d);
+        __builtin_nontemporal_store(w[1], d + 1);
+        __builtin_nontemporal_store(w[2], d + 2);
     } else {
-        const uint4* w = reinterpret_cast<const uint4*>(pk.v);
-        uint4* d = reinterpret_cast<uint4*>(dst);
+        using v4 = __attribute__((ext_vector_type(4))) unsigned;
+        const v4* w = reinterpret_cast<const v4*>(pk.v);
+        v4* d = reinterpret_cast<v4*>(dst);
 #pragma unroll
-        for (int i = 0; i < bytes / 16; ++i) d[i] = w[i];
+        for (int i = 0; i < bytes / 16; ++i) __builtin_nontemporal_store(w[i], d + i);
     }
 }
 
@@ -122,7 +140,7 @@ struct ApplyCtx<TIA_MATH_F32> {
     const float* lut;  // bank-private: lut[v*32 + (lane&31)]
     int bank;
     __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, float (&o)[3]) const {
-        const float x = lut[r * 32 + bank], y = lut[g * 32 + bank], z = lut[b * 32 + bank];
+        const float x = lut[r * REP + bank], y = lut[g * REP + bank], z = lut[b * REP + bank];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float u = __builtin_fmaf(z, m[6 + c], __builtin_fmaf(y, m[3 + c], x * m[c]));
@@ -164,19 +182,19 @@ __global__ __launch_bounds__(AT) void stain_apply_kernel(const uint8_t* __restri
     using O = Out<OUT>;
     using T = typename O::T;
     using F = typename std::conditional<MATH == TIA_MATH_F32, float, double>::type;
-    constexpr int LUTN = (MATH == TIA_MATH_F32) ? 256 * 32 : 256;
+    constexpr int LUTN = (MATH == TIA_MATH_F32) ? 256 * REP : 256;
     __shared__ F lut[LUTN];
 
     const long patch = blockIdx.y;
     const double* st = stats + patch * TIA_STATS_STRIDE;
     ApplyCtx<MATH> ctx;
     if constexpr (MATH == TIA_MATH_F32) {
-        for (int i = threadIdx.x; i < LUTN; i += AT) lut[i] = tab->od_lut_f32[i >> 5];
+        for (int i = threadIdx.x; i < LUTN; i += AT) lut[i] = tab->od_lut_f32[i / REP];
         const double nl2e = -1.4426950408889634;
 #pragma unroll
         for (int i = 0; i < 9; ++i) ctx.m[i] = (float)(st[TIA_ST_M + i] * nl2e);
         ctx.lut = lut;
-        ctx.bank = threadIdx.x & 31;
+        ctx.bank = threadIdx.x & (REP - 1);
     } else {
         for (int i = threadIdx.x; i < LUTN; i += AT) lut[i] = tab->od_lut[i];
 #pragma unroll
@@ -196,21 +214,35 @@ __global__ __launch_bounds__(AT) void stain_apply_kernel(const uint8_t* __restri
     if ((hw & 3) == 0) {
         const long ng = hw >> 2;
         const long stride = (long)gridDim.x * AT;
-#pragma unroll 2
-        for (long g = (long)blockIdx.x * AT + threadIdx.x; g < ng; g += stride) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(src + g * 12);
-            const uint32_t a = q[0], b = q[1], c = q[2];
-            F o[4][3];
-            ctx.pixel(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u, o[0]);
-            ctx.pixel(a >> 24, b & 255u, (b >> 8) & 255u, o[1]);
-            ctx.pixel((b >> 16) & 255u, b >> 24, c & 255u, o[2]);
-            ctx.pixel((c >> 8) & 255u, (c >> 16) & 255u, c >> 24, o[3]);
-            Pack12<T> pk;
+        constexpr int U = (MATH == TIA_MATH_F32) ? 4 : 2;  // independent 12-byte groups in flight per lane
+        for (long g0 = (long)blockIdx.x * AT + threadIdx.x; g0 < ng; g0 += stride * U) {
+            uint32_t a[U], b[U], c[U];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int u = 0; u < U; ++u) {
+                const long g = g0 + u * stride;
+                if (g < ng) {
+                    const uint32_t* q = reinterpret_cast<const uint32_t*>(src + g * 12);
+                    a[u] = __builtin_nontemporal_load(q);
+                    b[u] = __builtin_nontemporal_load(q + 1);
+                    c[u] = __builtin_nontemporal_load(q + 2);
+                }
+            }
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) pk.v[i * 3 + ch] = O::cvt(o[i][ch]);
-            store12<T>(dst + g * 12, pk);
+            for (int u = 0; u < U; ++u) {
+                const long g = g0 + u * stride;
+                if (g >= ng) break;
+                F o[4][3];
+                ctx.pixel(a[u] & 255u, (a[u] >> 8) & 255u, (a[u] >> 16) & 255u, o[0]);
+                ctx.pixel(a[u] >> 24, b[u] & 255u, (b[u] >> 8) & 255u, o[1]);
+                ctx.pixel((b[u] >> 16) & 255u, b[u] >> 24, c[u] & 255u, o[2]);
+                ctx.pixel((c[u] >> 8) & 255u, (c[u] >> 16) & 255u, c[u] >> 24, o[3]);
+                Pack12<T> pk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) pk.v[i * 3 + ch] = O::cvt(o[i][ch]);
+                store12<T>(dst + g * 12, pk);
+            }
         }
     } else {
         for (long i = (long)blockIdx.x * AT + threadIdx.x; i < hw; i += (long)gridDim.x * AT) {
@@ -220,6 +252,92 @@ __global__ __launch_bounds__(AT) void stain_apply_kernel(const uint8_t* __restri
             dst[3 * i + 1] = O::cvt(o[1]);
             dst[3 * i + 2] = O::cvt(o[2]);
         }
+    }
+}
+
+// ---- wide variant: 16-byte global accesses through a wave-private LDS transpose -------------------
+// A wave owns 3072 contiguous input bytes (1024 pixels) per step: three fully coalesced 16 B/lane
+// loads land in LDS linearly, each lane then reads back ITS 48 contiguous bytes (16 whole pixels;
+// the 12-dword lane stride makes the three ds_read_b128 conflict-free), computes, writes its
+// 48*sizeof(T) output bytes back to LDS and the wave stores them as coalesced 16 B/lane rows.
+// 12-byte loads / 8-byte stores plateau at ~4.4 TB/s on MI355X; 16-byte accesses are what the
+// memory path is built for (MI355X_MICROARCH.md: 8-B accesses run at 0.54-0.70x the 16-B rate).
+template <int OUT>
+__global__ __launch_bounds__(AT) void stain_apply_wide_kernel(const uint8_t* __restrict__ img, long hw,
+                                                               const tia_stain_tables* __restrict__ tab,
+                                                               const double* __restrict__ stats,
+                                                               void* __restrict__ out_v) {
+    using O = Out<OUT>;
+    using T = typename O::T;
+    constexpr int TS = sizeof(T);
+    static_assert(TS == 1 || TS == 2, "wide path is for 1- and 2-byte outputs");
+    constexpr int CHUNK = 3072;                     // input bytes per wave step
+    __shared__ float lut[256 * REP];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[AT / 64][CHUNK * TS];
+    using v4 = __attribute__((ext_vector_type(4))) unsigned;
+
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    ApplyCtx<TIA_MATH_F32> ctx;
+    for (int i = threadIdx.x; i < 256 * REP; i += AT) lut[i] = tab->od_lut_f32[i / REP];
+    const double nl2e = -1.4426950408889634;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ctx.m[i] = (float)(st[TIA_ST_M + i] * nl2e);
+    ctx.lut = lut;
+    ctx.bank = threadIdx.x & (REP - 1);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint8_t* mine = stage[wv];
+    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
+    uint8_t* dst = reinterpret_cast<uint8_t*>(out_v) + (size_t)patch * (size_t)hw * 3u * TS;
+    const long nchunks = hw * 3 / CHUNK;
+    const long wstride = (long)gridDim.x * (AT / 64);
+    for (long c = (long)blockIdx.x * (AT / 64) + wv; c < nchunks; c += wstride) {
+        const v4* gsrc = reinterpret_cast<const v4*>(src + c * CHUNK);
+        v4 in[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in[k] = __builtin_nontemporal_load(gsrc + k * 64 + lane);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<v4*>(mine + k * 1024 + lane * 16) = in[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t w[12];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const v4 t = *reinterpret_cast<const v4*>(mine + lane * 48 + j * 16);
+            w[j * 4 + 0] = t.x;
+            w[j * 4 + 1] = t.y;
+            w[j * 4 + 2] = t.z;
+            w[j * 4 + 3] = t.w;
+        }
+        __builtin_amdgcn_wave_barrier();  // everyone has read its pixels before the region is reused
+        alignas(16) T res[48];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // four groups of 4 pixels (12 bytes = 3 dwords each)
+            const uint32_t a = w[q * 3], b = w[q * 3 + 1], cc = w[q * 3 + 2];
+            float o[4][3];
+            ctx.pixel(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u, o[0]);
+            ctx.pixel(a >> 24, b & 255u, (b >> 8) & 255u, o[1]);
+            ctx.pixel((b >> 16) & 255u, b >> 24, cc & 255u, o[2]);
+            ctx.pixel((cc >> 8) & 255u, (cc >> 16) & 255u, cc >> 24, o[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) res[q * 12 + i * 3 + ch] = O::cvt(o[i][ch]);
+        }
+        const v4* rv = reinterpret_cast<const v4*>(res);
+#pragma unroll
+        for (int j = 0; j < 3 * TS; ++j) *reinterpret_cast<v4*>(mine + lane * 48 * TS + j * 16) = rv[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        v4* gdst = reinterpret_cast<v4*>(dst + c * CHUNK * TS);
+#pragma unroll
+        for (int k = 0; k < 3 * TS; ++k) {
+            const v4 t = *reinterpret_cast<const v4*>(mine + k * 1024 + lane * 16);
+            __builtin_nontemporal_store(t, gdst + k * 64 + lane);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -308,7 +426,12 @@ static inline unsigned blocks_x(long work_items, long n_patches) {
     // large so the per-block table set-up is amortised.
     long per_block = (long)AT * 4;
     long maxb = (work_items + per_block - 1) / per_block;
-    long want = (4096 + n_patches - 1) / n_patches;
+    static long target = 0;
+    if (target == 0) {
+        const char* e = getenv("TIA_APPLY_BLOCKS");
+        target = e ? atol(e) : 4096;
+    }
+    long want = (target + n_patches - 1) / n_patches;
     long b = want < maxb ? want : maxb;
     return (unsigned)(b < 1 ? 1 : b);
 }
@@ -319,6 +442,24 @@ static int launch_apply(const uint8_t* d_img, int64_t n, long hw, const tia_stai
                         hipStream_t stream) {
     const long ng = (hw & 3) == 0 ? (hw >> 2) : hw;
     dim3 grid(blocks_x(ng, n), (unsigned)n);
+    if constexpr (MATH == TIA_MATH_F32) {
+        const bool aligned = ((reinterpret_cast<uintptr_t>(d_img) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+        if ((hw * 3) % 3072 == 0 && aligned &&
+            (out_kind == TIA_OUT_U8 || out_kind == TIA_OUT_UNIT_F16 || out_kind == TIA_OUT_UNIT_BF16)) {
+            const long nchunks = hw * 3 / 3072;
+            long bx = (nchunks + 3) / 4;                       // one step per wave ...
+            const long want = (4096 + (long)n - 1) / (long)n;  // ... unless the batch already fills the chip
+            if (bx > want) bx = want;
+            dim3 wgrid((unsigned)(bx < 1 ? 1 : bx), (unsigned)n);
+            if (out_kind == TIA_OUT_U8)
+                hipLaunchKernelGGL((stain_apply_wide_kernel<TIA_OUT_U8>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, out);
+            else if (out_kind == TIA_OUT_UNIT_F16)
+                hipLaunchKernelGGL((stain_apply_wide_kernel<TIA_OUT_UNIT_F16>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, out);
+            else
+                hipLaunchKernelGGL((stain_apply_wide_kernel<TIA_OUT_UNIT_BF16>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, out);
+            return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+        }
+    }
 #define TIA_LAUNCH(OUTK)                                                                              \
     case OUTK:                                                                                        \
         hipLaunchKernelGGL((stain_apply_kernel<MATH, OUTK>), grid, dim3(AT), 0, stream, d_img, hw,   \
