@@ -269,6 +269,25 @@ int tia_reinhard_apply_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
 int tia_lab_convert_u8(const uint8_t* d_src, int64_t npix, const tia_lab_tables* d_tables, int32_t dir,
                        uint8_t* d_dst, void* stream);
 
+
+/* =======================================================================================
+ * CNN epilogues (NHWC activations).  The convolutions themselves run in MIOpen; with BatchNorm
+ * folded into the weights every conv is followed by bias (+ residual) + ReLU, which PyTorch
+ * executes as 2-3 separate full-tensor passes (models/architecture/vanilla.py:300-316 forward).
+ * ===================================================================================== */
+#define TIA_DT_F32 0
+#define TIA_DT_F16 1
+#define TIA_DT_BF16 2
+
+/* In place: x[r,c] = act(x[r,c] + bias[c] (+ residual[r,c])), one pass.  c % 8 == 0. */
+int tia_bias_act_nhwc(void* d_x, const void* d_bias, const void* d_residual, int64_t rows, int64_t c,
+                      int32_t dtype, int32_t relu, void* stream);
+
+/* out = maxpool3x3/s2/p1(relu(x + bias)) for the ResNet stem, one pass.
+ * x [n,h,w,c] -> out [n,(h+1)/2,(w+1)/2,c].  c % 8 == 0. */
+int tia_bias_relu_maxpool_nhwc(const void* d_x, const void* d_bias, int64_t n, int64_t h, int64_t w,
+                               int64_t c, int32_t dtype, void* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,13 +18,13 @@ def timeit(fn, reps=5, warm=2):
 
 m, _ = get_pretrained_model("resnet18-kather100k"); m.eval()
 n = 4096
-for dtype in (torch.float16, torch.float32):
+for dtype in (torch.float16, torch.bfloat16, torch.float32):
     x = torch.rand(n, 224, 224, 3, device="cuda").to(dtype)
-    variants = {"plain": m, "folded": fuse_cnn_model(m, epilogue_fusion=False), "fused": fuse_cnn_model(m)}
+    variants = {"plain": m, "folded": fuse_cnn_model(m, epilogue_fusion=False), "hip": fuse_cnn_model(m, epilogue_fusion="hip")}
     ref = None
     for name, mod in variants.items():
         mod = mod.to("cuda").to(dtype).to(memory_format=torch.channels_last).eval()
-        for mb in (256, 512, 1024):
+        for mb in (512, 1024):
             def run():
                 with torch.inference_mode():
                     return [mod(x[s:s+mb].permute(0,3,1,2)) for s in range(0, n, mb)]

@@ -129,3 +129,48 @@ def test_gpu_macenko_prenorm_pipeline(patches, target_image):
     exp3.model.preproc_func = lambda im: ref_norm.transform(im.copy())
     exp3 = exp3.run(patches, patch_mode=True, return_probabilities=True)
     np.testing.assert_allclose(got3["probabilities"], exp3["probabilities"], atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float16", "bfloat16"])
+def test_hip_epilogue_kernels_match_torch(dtype):
+    """bias(+residual)+ReLU and the stem's bias+ReLU+maxpool vs the unfused torch ops (fp32: bit-exact)."""
+    import torch.nn.functional as F  # noqa: N812
+
+    from tiatoolbox_amd.models.architecture.fused import hip_bias_act_, hip_bias_relu_maxpool
+
+    dt = getattr(torch, dtype)
+    g = torch.Generator("cuda").manual_seed(0)
+    x = torch.randn((3, 64, 37, 41), device="cuda", generator=g).to(dt).contiguous(memory_format=torch.channels_last)
+    r = torch.randn((3, 64, 37, 41), device="cuda", generator=g).to(dt).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(64, device="cuda", generator=g).to(dt)
+    exp = F.relu((x.float() + b.float().view(1, -1, 1, 1)) + r.float()).to(dt)
+    got = hip_bias_act_(x.clone(memory_format=torch.channels_last), b, r)
+    assert torch.equal(got, exp)
+    exp2 = (x.float() + b.float().view(1, -1, 1, 1)).to(dt)
+    assert torch.equal(hip_bias_act_(x.clone(memory_format=torch.channels_last), b, relu=False), exp2)
+    exp3 = F.max_pool2d(F.relu(x.float() + b.float().view(1, -1, 1, 1)), 3, 2, 1).to(dt)
+    got3 = hip_bias_relu_maxpool(x, b)
+    assert got3.shape == exp3.shape and torch.equal(got3, exp3)
+
+
+@pytest.mark.gpu
+def test_hip_fused_resnet_matches_plain_model(patches):
+    from tiatoolbox_amd.models.architecture import get_pretrained_model
+    from tiatoolbox_amd.models.architecture.fused import fuse_cnn_model
+
+    model, _ = get_pretrained_model("resnet18-kather100k")
+    for mod in model.modules():  # non-trivial BN statistics
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.1)
+    x = (torch.from_numpy(patches).float() / 255).permute(0, 3, 1, 2)
+    with torch.inference_mode():
+        ref = model.eval()(x)
+        hip = fuse_cnn_model(model, epilogue_fusion="hip").cuda().to(memory_format=torch.channels_last)
+        got = hip(x.cuda().contiguous(memory_format=torch.channels_last)).cpu()
+        got16 = hip.half()(x.cuda().half().contiguous(memory_format=torch.channels_last)).float().cpu()
+    assert (got - ref).abs().max() < 1e-4
+    assert (got16 - ref).abs().max() < 5e-3

@@ -1,0 +1,213 @@
+// Fused CNN epilogues on gfx950 for NHWC activations (fp32 / fp16 / bf16), HBM-bound:
+//   bias_act      : x = relu(x + bias[c] (+ residual))           1 read (+1) + 1 write, in place
+//   stem epilogue : out = maxpool3x3s2p1(relu(x + bias[c]))      reads the conv1 output once
+// 16 bytes per lane per access (8 halves / 4 floats); consecutive lanes walk the channel axis so a
+// wave covers 1 KiB of contiguous NHWC memory per instruction.  Arithmetic in fp32, same order as
+// the unfused torch ops ((x + b) + r, then max(.,0)).
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace tia {
+
+constexpr int ET = 256;
+using u4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <class T>
+struct Vec;  // 16-byte vector of T <-> float lanes
+template <>
+struct Vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void unpack(const u4& v, float (&f)[8]) {
+        f[0] = __uint_as_float(v.x);
+        f[1] = __uint_as_float(v.y);
+        f[2] = __uint_as_float(v.z);
+        f[3] = __uint_as_float(v.w);
+    }
+    static __device__ __forceinline__ u4 pack(const float (&f)[8]) {
+        u4 v;
+        v.x = __float_as_uint(f[0]);
+        v.y = __float_as_uint(f[1]);
+        v.z = __float_as_uint(f[2]);
+        v.w = __float_as_uint(f[3]);
+        return v;
+    }
+};
+template <>
+struct Vec<__half> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(const u4& v, float (&f)[8]) {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __half2float(__ushort_as_half((unsigned short)(w[i] & 0xffffu)));
+            f[2 * i + 1] = __half2float(__ushort_as_half((unsigned short)(w[i] >> 16)));
+        }
+    }
+    static __device__ __forceinline__ u4 pack(const float (&f)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = (unsigned)__half_as_ushort(__float2half_rn(f[2 * i])) |
+                   ((unsigned)__half_as_ushort(__float2half_rn(f[2 * i + 1])) << 16);
+        u4 v;
+        v.x = w[0];
+        v.y = w[1];
+        v.z = w[2];
+        v.w = w[3];
+        return v;
+    }
+};
+template <>
+struct Vec<__hip_bfloat16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(const u4& v, float (&f)[8]) {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ unsigned bf(float x) {  // round to nearest even
+        unsigned u = __float_as_uint(x);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return u >> 16;
+    }
+    static __device__ __forceinline__ u4 pack(const float (&f)[8]) {
+        u4 v;
+        v.x = bf(f[0]) | (bf(f[1]) << 16);
+        v.y = bf(f[2]) | (bf(f[3]) << 16);
+        v.z = bf(f[4]) | (bf(f[5]) << 16);
+        v.w = bf(f[6]) | (bf(f[7]) << 16);
+        return v;
+    }
+};
+
+template <class T, bool RES>
+__global__ __launch_bounds__(ET) void bias_act_kernel(u4* __restrict__ x, const u4* __restrict__ bias, const u4* __restrict__ res,
+                                                       long nvec, int cvec, int relu) {
+    constexpr int N = Vec<T>::N;
+    const long stride = (long)gridDim.x * ET;
+    for (long i = (long)blockIdx.x * ET + threadIdx.x; i < nvec; i += stride) {
+        float a[8], b[8], r[8];
+        const u4 xv = x[i];
+        Vec<T>::unpack(xv, a);
+        Vec<T>::unpack(bias[i % cvec], b);
+        if (RES) Vec<T>::unpack(__builtin_nontemporal_load(res + i), r);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            float v = a[k] + b[k];
+            if (RES) v = v + r[k];
+            a[k] = (relu && !(v > 0.0f)) ? 0.0f : v;
+        }
+        x[i] = Vec<T>::pack(a);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(ET) void stem_pool_kernel(const u4* __restrict__ x, const u4* __restrict__ bias, int h, int w, int cvec,
+                                                        int ho, int wo, long nvec_out, u4* __restrict__ out) {
+    constexpr int N = Vec<T>::N;
+    const long stride = (long)gridDim.x * ET;
+    for (long i = (long)blockIdx.x * ET + threadIdx.x; i < nvec_out; i += stride) {
+        const int cv = (int)(i % cvec);
+        long t = i / cvec;
+        const int ox = (int)(t % wo);
+        t /= wo;
+        const int oy = (int)(t % ho);
+        const long img = t / ho;
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = -3.4028234663852886e38f;
+        // max over the valid 3x3 window of the raw conv output: +bias and ReLU are monotone, so they
+        // commute with the maximum and are applied once afterwards
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = 2 * oy + dy;
+            if (yy < 0 || yy >= h) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = 2 * ox + dx;
+                if (xx < 0 || xx >= w) continue;
+                float a[8];
+                Vec<T>::unpack(x[((img * h + yy) * w + xx) * cvec + cv], a);
+#pragma unroll
+                for (int k = 0; k < N; ++k) m[k] = a[k] > m[k] ? a[k] : m[k];
+            }
+        }
+        float b[8];
+        Vec<T>::unpack(bias[cv], b);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float v = m[k] + b[k];
+            m[k] = v > 0.0f ? v : 0.0f;
+        }
+        out[i] = Vec<T>::pack(m);
+    }
+}
+
+static inline unsigned eblocks(long n) {
+    long b = (n + ET - 1) / ET;
+    if (b > 256L * 32) b = 256L * 32;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+template <class T>
+static int launch_bias_act(void* x, const void* bias, const void* res, long rows, long c, int relu, hipStream_t st) {
+    constexpr int N = Vec<T>::N;
+    if (c % N) return TIA_EINVAL;
+    const long nvec = rows * c / N;
+    if (res)
+        hipLaunchKernelGGL((bias_act_kernel<T, true>), dim3(eblocks(nvec)), dim3(ET), 0, st, (u4*)x, (const u4*)bias, (const u4*)res,
+                           nvec, (int)(c / N), relu);
+    else
+        hipLaunchKernelGGL((bias_act_kernel<T, false>), dim3(eblocks(nvec)), dim3(ET), 0, st, (u4*)x, (const u4*)bias, (const u4*)nullptr,
+                           nvec, (int)(c / N), relu);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+template <class T>
+static int launch_stem(const void* x, const void* bias, long n, long h, long w, long c, void* out, hipStream_t st) {
+    constexpr int N = Vec<T>::N;
+    if (c % N) return TIA_EINVAL;
+    const long ho = (h + 1) / 2, wo = (w + 1) / 2;
+    const long nvec = n * ho * wo * c / N;
+    hipLaunchKernelGGL((stem_pool_kernel<T>), dim3(eblocks(nvec)), dim3(ET), 0, st, (const u4*)x, (const u4*)bias, (int)h, (int)w,
+                       (int)(c / N), (int)ho, (int)wo, nvec, (u4*)out);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+}  // namespace tia
+
+using namespace tia;
+
+extern "C" int tia_bias_act_nhwc(void* d_x, const void* d_bias, const void* d_residual, int64_t rows, int64_t c, int32_t dtype,
+                                  int32_t relu, void* stream) {
+    if (!d_x || !d_bias || rows <= 0 || c <= 0) return TIA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_bias) | reinterpret_cast<uintptr_t>(d_residual)) & 15)
+        return TIA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case TIA_DT_F32: return launch_bias_act<float>(d_x, d_bias, d_residual, rows, c, relu, st);
+        case TIA_DT_F16: return launch_bias_act<__half>(d_x, d_bias, d_residual, rows, c, relu, st);
+        case TIA_DT_BF16: return launch_bias_act<__hip_bfloat16>(d_x, d_bias, d_residual, rows, c, relu, st);
+        default: return TIA_EINVAL;
+    }
+}
+
+extern "C" int tia_bias_relu_maxpool_nhwc(const void* d_x, const void* d_bias, int64_t n, int64_t h, int64_t w, int64_t c,
+                                           int32_t dtype, void* d_out, void* stream) {
+    if (!d_x || !d_bias || !d_out || n <= 0 || h <= 0 || w <= 0 || c <= 0) return TIA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_bias) | reinterpret_cast<uintptr_t>(d_out)) & 15)
+        return TIA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case TIA_DT_F32: return launch_stem<float>(d_x, d_bias, n, h, w, c, d_out, st);
+        case TIA_DT_F16: return launch_stem<__half>(d_x, d_bias, n, h, w, c, d_out, st);
+        case TIA_DT_BF16: return launch_stem<__hip_bfloat16>(d_x, d_bias, n, h, w, c, d_out, st);
+        default: return TIA_EINVAL;
+    }
+}

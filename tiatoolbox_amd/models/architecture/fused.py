@@ -107,16 +107,118 @@ class FusedResNet(nn.Module):
         return self.blocks(x)
 
 
-def fuse_cnn_model(model: nn.Module, *, epilogue_fusion: bool = False) -> nn.Module:
+# ------------------------------------------------------------------------------------------------
+# HIP epilogues: conv (MIOpen, no bias) -> one fused bias (+ residual) + ReLU pass (cnn_epilogue.hip)
+# ------------------------------------------------------------------------------------------------
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _nhwc_ptr_ok(t: torch.Tensor) -> bool:
+    return t.is_cuda and t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and t.dtype in _DT
+
+
+def hip_bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: torch.Tensor | None = None, *, relu: bool = True) -> torch.Tensor:
+    """In place ``x = relu(x + bias[c] (+ residual))`` on an NCHW tensor stored channels-last."""
+    from tiatoolbox_amd import _lib
+
+    if not _nhwc_ptr_ok(x) or (residual is not None and not _nhwc_ptr_ok(residual)):
+        msg = "hip_bias_act_ expects channels-last CUDA tensors (fp32/fp16/bf16)."
+        raise ValueError(msg)
+    n, c, h, w = x.shape
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_bias_act_nhwc(x.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else 0,
+                                           n * h * w, c, _DT[x.dtype], int(relu), _lib.current_stream())
+    _lib.check(rc, "tia_bias_act_nhwc")
+    return x
+
+
+def hip_bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """``maxpool3x3/s2/p1(relu(x + bias))`` of a channels-last tensor, one pass."""
+    from tiatoolbox_amd import _lib
+
+    if not _nhwc_ptr_ok(x):
+        msg = "hip_bias_relu_maxpool expects a channels-last CUDA tensor (fp32/fp16/bf16)."
+        raise ValueError(msg)
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, (h + 1) // 2, (w + 1) // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_bias_relu_maxpool_nhwc(x.data_ptr(), bias.data_ptr(), n, h, w, c, _DT[x.dtype], out.data_ptr(),
+                                                    _lib.current_stream())
+    _lib.check(rc, "tia_bias_relu_maxpool_nhwc")
+    return out
+
+
+def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
+
+
+class _HipBasic(nn.Module):
+    def __init__(self, blk: BasicBlock) -> None:
+        super().__init__()
+        self.conv1, self.conv2 = blk.conv1, blk.conv2
+        self.down = blk.downsample[0] if blk.downsample is not None else None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.down is None:
+            identity = x
+        else:
+            identity = hip_bias_act_(_conv_nobias(x, self.down), self.down.bias, relu=False)
+        out = hip_bias_act_(_conv_nobias(x, self.conv1), self.conv1.bias)
+        return hip_bias_act_(_conv_nobias(out, self.conv2), self.conv2.bias, identity)
+
+
+class _HipBottleneck(nn.Module):
+    def __init__(self, blk: Bottleneck) -> None:
+        super().__init__()
+        self.conv1, self.conv2, self.conv3 = blk.conv1, blk.conv2, blk.conv3
+        self.down = blk.downsample[0] if blk.downsample is not None else None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.down is None:
+            identity = x
+        else:
+            identity = hip_bias_act_(_conv_nobias(x, self.down), self.down.bias, relu=False)
+        out = hip_bias_act_(_conv_nobias(x, self.conv1), self.conv1.bias)
+        out = hip_bias_act_(_conv_nobias(out, self.conv2), self.conv2.bias)
+        return hip_bias_act_(_conv_nobias(out, self.conv3), self.conv3.bias, identity)
+
+
+class HipFusedResNet(nn.Module):
+    """ResNet trunk: MIOpen convolutions + hand-written HIP epilogues (BN folded, channels-last, CUDA only)."""
+
+    def __init__(self, trunk: nn.Sequential) -> None:
+        super().__init__()
+        folded = fold_conv_bn(trunk)
+        self.stem = folded[0]
+        blocks = []
+        for layer in list(folded)[4:]:
+            for blk in layer:
+                blocks.append(_HipBasic(blk) if isinstance(blk, BasicBlock) else _HipBottleneck(blk))
+        self.blocks = nn.Sequential(*blocks)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        x = hip_bias_relu_maxpool(_conv_nobias(x, self.stem), self.stem.bias)
+        return self.blocks(x)
+
+
+def fuse_cnn_model(model: nn.Module, *, epilogue_fusion: bool | str = False) -> nn.Module:
     """Derived inference copy of a ``CNNModel``/``CNNBackbone`` with BN folded into the convolutions.
 
     ``epilogue_fusion=True`` additionally routes through ``aten::miopen_convolution_relu`` /
     ``_add_relu``.  Measured on MI355X (ROCm 7.2, MIOpen via torch 2.10): those entry points fall
     back to a *naive* convolution kernel for NHWC fp16 (22 s per 4096-patch pass vs 55 ms), so the
-    default is off; BN folding alone gives 70.8 -> 54.5 ms.
+    default is off; BN folding alone gives 70.8 -> 54.5 ms.  ``epilogue_fusion="hip"`` keeps MIOpen for
+    the convolutions (without bias) and runs bias (+ residual) + ReLU (and the stem's max-pool) as the
+    hand-written single-pass kernels of ``csrc/cnn_epilogue.hip`` (CUDA/HIP tensors only).
     """
     fused = copy.deepcopy(model).eval()
     trunk = fused.feat_extract
     if isinstance(trunk, nn.Sequential) and len(trunk) == 8 and isinstance(trunk[0], nn.Conv2d):
-        fused.feat_extract = FusedResNet(trunk) if epilogue_fusion else fold_conv_bn(trunk)
+        if epilogue_fusion == "hip":
+            fused.feat_extract = HipFusedResNet(trunk)
+        else:
+            fused.feat_extract = FusedResNet(trunk) if epilogue_fusion else fold_conv_bn(trunk)
     return fused
