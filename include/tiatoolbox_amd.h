@@ -85,10 +85,14 @@ typedef struct tia_stain_params {
  * StainNormalizer.get_concentrations (tools/stainnorm.py:49-66) as a closed-form
  * pseudo-inverse, and np.percentile(C, 99, axis=0) (tools/stainnorm.py:81-85,103).
  *   d_img    [n,h,w,3] uint8     d_tables  tia_stain_tables     d_stats [n,TIA_STATS_STRIDE] f64
+ *   d_ws     optional scratch of tia_stain_stats_workspace_bytes(n,h,w) bytes (8-byte aligned): a
+ *            per-pixel histogram-bin cache that lets the selection's collect passes skip the value
+ *            computation; with NULL / too little space the kernel recomputes (same results).
  */
+size_t tia_stain_stats_workspace_bytes(int64_t n, int64_t h, int64_t w);
 int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
                        const tia_stain_tables* d_tables, const tia_stain_params* params,
-                       double* d_stats, void* stream);
+                       double* d_stats, void* d_ws, size_t ws_bytes, void* stream);
 
 /* Output kinds of tia_stain_apply_u8 */
 #define TIA_OUT_U8 0       /* uint8 NHWC, astype(uint8) truncation   (stainnorm.py:110-113)          */

@@ -55,7 +55,8 @@ _I64, _I32, _P = C.c_int64, C.c_int32, C.c_void_p
 
 _SIGNATURES = {
     "tia_abi_version": ([], C.c_int),
-    "tia_stain_stats_u8": ([_P, _I64, _I64, _I64, _P, C.POINTER(StainParams), _P, _P], C.c_int),
+    "tia_stain_stats_workspace_bytes": ([_I64, _I64, _I64], C.c_size_t),
+    "tia_stain_stats_u8": ([_P, _I64, _I64, _I64, _P, C.POINTER(StainParams), _P, _P, C.c_size_t, _P], C.c_int),
     "tia_stain_apply_u8": ([_P, _I64, _I64, _I64, _P, _P, C.POINTER(C.c_double), _P, _I32, _I32, _P], C.c_int),
     "tia_stain_concentrations_f64": ([_P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
     "tia_stain_augment_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _P], C.c_int),

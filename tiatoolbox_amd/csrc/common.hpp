@@ -5,6 +5,10 @@
 
 #include "tiatoolbox_amd.h"
 
+#ifndef TIA_UNIFORM
+#define TIA_UNIFORM 1
+#endif
+
 namespace tia {
 
 constexpr int kWave = 64;
@@ -152,6 +156,57 @@ __device__ __forceinline__ void for_each_pixel_w(const uint8_t* __restrict__ p, 
             f(i, (uint32_t)p[3 * i], (uint32_t)p[3 * i + 1], (uint32_t)p[3 * i + 2], wg);
         }
     }
+}
+
+// Group-level sweep for straight-line kernels: `f(g, a, b, c, wg)` receives the three dwords holding
+// pixels 4g..4g+3 (bytes r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3).  Requires hw % 4 == 0 and a
+// 4-byte aligned image (check with `groups_ok`).  Next group's dwords are prefetched.
+__device__ __forceinline__ bool groups_ok(const uint8_t* p, long hw) {
+    return ((hw & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 3) == 0);
+}
+template <int NT, class F>
+__device__ __forceinline__ void for_each_group(const uint8_t* __restrict__ p, long hw, F&& f) {
+    const long ng = hw >> 2;
+    const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
+    long g = threadIdx.x;
+    uint32_t a = 0, b = 0, c = 0;
+    if (g < ng) {
+        a = q[g * 3 + 0];
+        b = q[g * 3 + 1];
+        c = q[g * 3 + 2];
+    }
+    while (g < ng) {
+        const long gn = g + NT;
+        uint32_t na = 0, nb = 0, nc = 0;
+        if (gn < ng) {
+            na = q[gn * 3 + 0];
+            nb = q[gn * 3 + 1];
+            nc = q[gn * 3 + 2];
+        }
+        WaveGroup wg{false, 0, 1u};
+        if (TIA_UNIFORM) {
+            const unsigned long long act = __ballot(1);
+            wg.leader = __ffsll((long long)act) - 1;
+            const uint32_t a0 = __builtin_amdgcn_readlane(a, wg.leader);
+            const uint32_t b0 = __builtin_amdgcn_readlane(b, wg.leader);
+            const uint32_t c0 = __builtin_amdgcn_readlane(c, wg.leader);
+            wg.uniform = __ballot(a == a0 && b == b0 && c == c0) == act;
+            wg.count = (unsigned)__popcll(act);
+        }
+        f(g, a, b, c, wg);
+        a = na;
+        b = nb;
+        c = nc;
+        g = gn;
+    }
+}
+// channel bytes of the four pixels of a group
+__device__ __forceinline__ void unpack_group(uint32_t a, uint32_t b, uint32_t c, uint32_t (&r)[4], uint32_t (&g)[4],
+                                             uint32_t (&bl)[4]) {
+    r[0] = a & 255u;          g[0] = (a >> 8) & 255u;   bl[0] = (a >> 16) & 255u;
+    r[1] = a >> 24;           g[1] = b & 255u;          bl[1] = (b >> 8) & 255u;
+    r[2] = (b >> 16) & 255u;  g[2] = b >> 24;           bl[2] = c & 255u;
+    r[3] = (c >> 8) & 255u;   g[3] = (c >> 16) & 255u;  bl[3] = c >> 24;
 }
 
 }  // namespace tia

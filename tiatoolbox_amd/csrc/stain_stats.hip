@@ -40,12 +40,20 @@ struct SelState {
     unsigned long long r[2];
     unsigned long long cnt[2];
     unsigned ncand[2];
+    int fast;          // 1: collect through the per-pixel bin cache
+    int sel_hi[2];     // last bin collected on the fast path (next non-empty bin when k+1 leaves the bin)
     unsigned long long above_key[2];
     unsigned long long member_key[2];
 };
 
+#ifndef TIA_OD_REP
+#define TIA_OD_REP 1
+#endif
+constexpr int ODR = TIA_OD_REP;  // copies of the f64 OD table: lane l reads copy l%ODR, which spreads the
+                                 // data-dependent look-ups over the LDS banks (the kernel is LDS-bound)
+
 struct Smem {
-    double od[256];
+    double od[256 * ODR];
     int ty[3][256];
     unsigned hist[256];
     unsigned hist3[3][256];
@@ -161,13 +169,18 @@ __device__ __forceinline__ void find_bin(const unsigned* __restrict__ bins, unsi
 // Multi-level linear-histogram refinement over pixel passes until the bin holding rank k has
 // <= CAP members, then one collect pass + an LDS bitonic sort.  Everything is exact: the bin
 // function is monotone in x, so bins partition the sorted order.
-template <class VF>
-__device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, Smem& s,
+template <class VF, class H0>
+__device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, VF&& valf, H0&& hist0, Smem& s,
                         const unsigned long long (&k)[2], const unsigned long long (&n)[2],
                         const double (&lo0)[2], const double (&hi0)[2], const double (&olo0)[2],
-                        const double (&ohi0)[2], bool shared_values, double (&vprev)[2],
-                        double (&vnext)[2]) {
+                        const double (&ohi0)[2], bool shared_values, uint16_t* __restrict__ bincache,
+                        double (&vprev)[2], double (&vnext)[2]) {
     SelState& st = s.st;
+    // `bincache` ([2][hw] uint16, may be null): the level-0 bin of every pixel, written by the first
+    // histogram pass, lets the collect pass skip the value computation for everything but the few
+    // members of the selected bin(s).
+    const bool can_cache = bincache != nullptr && (hw & 3) == 0;
+    if (threadIdx.x == 0) st.fast = 0;
     if (threadIdx.x < 2) {
         const int t = threadIdx.x;
         st.level[t] = 0;
@@ -204,6 +217,12 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
         // values outside the histogram window belong to the (open-ended) edge bins; they are counted
         // in registers so that e.g. a large background population does not serialise on one address
         unsigned below[2] = {0, 0}, above[2] = {0, 0};
+        const bool write_cache = can_cache && iter == 0;
+        unsigned long long codes[2] = {0ull, 0ull};
+        // straight-line level-0 pass supplied by the caller (4 pixels per step, all table look-ups issued
+        // together); the generic per-pixel loop below handles every other case
+        const bool handled = write_cache && nh0 && nh1 && hist0(below, above);
+        if (!handled)
         for_each_pixel_w<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b, const WaveGroup& wg) {
             double x[2];
             const unsigned vm = valf(idx, r, g, b, x);
@@ -221,6 +240,14 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
                 below[t] += lowv ? 1u : 0u;
                 above[t] += highv ? 1u : 0u;
                 hist_add(s.bins[t], (int)d, member && !lowv && !highv, wg);
+                if (write_cache) {
+                    const unsigned code = !member ? 0xffffu : (lowv ? 0u : (highv ? (unsigned)(NB - 1) : (unsigned)(int)d));
+                    codes[t] |= (unsigned long long)code << (16 * (int)(idx & 3));
+                    if ((idx & 3) == 3) {
+                        *reinterpret_cast<unsigned long long*>(bincache + (size_t)t * hw + (idx - 3)) = codes[t];
+                        codes[t] = 0ull;
+                    }
+                }
             }
         });
 #pragma unroll
@@ -255,7 +282,49 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
             }
             __syncthreads();
         }
-        stamp(s, TM_SEL_FIND);
+        // fast path: exactly one histogram level for every target that needed one -> the cached bins are
+        // exactly the membership test.  If rank k is the last member of its bin, the bin holding k+1 (the
+        // next non-empty one) is collected too, so no separate "minimum above" search is needed.
+        if (write_cache && nh0 && nh1) {
+            if (threadIdx.x < 2) st.sel_hi[threadIdx.x] = NB;
+            __syncthreads();
+            bool want[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                want[t] = st.level[t] == 1 && st.cnt[t] <= (unsigned long long)CAP && st.r[t] + 1 == st.cnt[t] &&
+                          k[t] + 1 < n[t];
+                if (want[t]) {
+                    const unsigned* hb = (shared && t == 1) ? s.bins[0] : s.bins[t];
+                    const int sel = st.sel[t][0];
+                    int first = NB;
+                    for (int i = threadIdx.x * BPT; i < threadIdx.x * BPT + BPT; ++i)
+                        if (i > sel && hb[i] != 0 && i < first) first = i;
+                    if (first < NB) atomicMin(&st.sel_hi[t], first);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int ok = 1;
+                for (int t = 0; t < 2; ++t) {
+                    if (st.level[t] != 1 || st.cnt[t] > (unsigned long long)CAP) ok = 0;
+                    if (want[t]) {
+                        const unsigned* hb = (shared && t == 1) ? s.bins[0] : s.bins[t];
+                        if (st.sel_hi[t] >= NB || st.cnt[t] + hb[st.sel_hi[t]] > (unsigned long long)CAP) ok = 0;
+                        else st.cnt[t] += hb[st.sel_hi[t]];
+                    } else {
+                        st.sel_hi[t] = st.sel[t][0];
+                    }
+                }
+                st.fast = ok;
+                if (!ok)  // restore the counts the generic path expects
+                    for (int t = 0; t < 2; ++t)
+                        if (want[t] && st.sel_hi[t] < NB) {
+                            const unsigned* hb = (shared && t == 1) ? s.bins[0] : s.bins[t];
+                            if (st.cnt[t] > hb[st.sel[t][0]]) st.cnt[t] = hb[st.sel[t][0]];
+                        }
+            }
+            __syncthreads();
+        }
     }
 
     // ---- collect pass ------------------------------------------------------------------
@@ -266,7 +335,50 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
         st.member_key[t] = ~0ull;
     }
     __syncthreads();
-    {
+    if (st.fast) {
+        // group-level sweep over the cached bins only: pixel bytes are fetched for the (rare) members
+        const int slo[2] = {st.sel[0][0], st.sel[1][0]}, shi[2] = {st.sel_hi[0], st.sel_hi[1]};
+        const unsigned long long* c0p = reinterpret_cast<const unsigned long long*>(bincache);
+        const unsigned long long* c1p = shared_values ? c0p : reinterpret_cast<const unsigned long long*>(bincache + (size_t)hw);
+        const long ng = hw >> 2;
+        constexpr int CU4 = 4;  // independent code loads in flight per lane (the loop is pure latency otherwise)
+        for (long g0 = threadIdx.x; g0 < ng; g0 += (long)NT * CU4) {
+            unsigned long long q0[CU4], q1[CU4];
+#pragma unroll
+            for (int u = 0; u < CU4; ++u) {
+                const long g = g0 + (long)u * NT;
+                q0[u] = g < ng ? c0p[g] : ~0ull;
+                q1[u] = shared_values ? q0[u] : (g < ng ? c1p[g] : ~0ull);
+            }
+#pragma unroll
+            for (int u = 0; u < CU4; ++u) {
+                const long g = g0 + (long)u * NT;
+                unsigned hit = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int a0 = (int)((q0[u] >> (16 * i)) & 0xffffu), a1 = (int)((q1[u] >> (16 * i)) & 0xffffu);
+                    hit |= (a0 >= slo[0] && a0 <= shi[0]) ? (1u << i) : 0u;
+                    hit |= (a1 >= slo[1] && a1 <= shi[1]) ? (16u << i) : 0u;
+                }
+                if (hit) {
+                    for (int i = 0; i < 4; ++i) {
+                        if (!((hit >> i) & 0x11u)) continue;
+                        const long idx = g * 4 + i;
+                        double x[2];
+                        valf(idx, (uint32_t)p[3 * idx], (uint32_t)p[3 * idx + 1], (uint32_t)p[3 * idx + 2], x);
+                        if ((hit >> i) & 1u) {
+                            const unsigned pos = atomicAdd(&st.ncand[0], 1u);
+                            if (pos < (unsigned)CAP) s.cand[0][pos] = x[0];
+                        }
+                        if ((hit >> i) & 16u) {
+                            const unsigned pos = atomicAdd(&st.ncand[1], 1u);
+                            if (pos < (unsigned)CAP) s.cand[1][pos] = x[1];
+                        }
+                    }
+                }
+            }
+        }
+    } else {
         const int lv[2] = {st.level[0], st.level[1]};
         const bool store[2] = {st.cnt[0] <= (unsigned long long)CAP, st.cnt[1] <= (unsigned long long)CAP};
         const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -439,15 +551,19 @@ __device__ void jacobi3(const double (&a6)[6], double (&w)[3], double (&v)[3][3]
 __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __restrict__ img, long hw,
                                                           const tia_stain_tables* __restrict__ tab,
                                                           tia_stain_params prm,
-                                                          double* __restrict__ stats) {
+                                                          double* __restrict__ stats,
+                                                          uint16_t* __restrict__ binws) {
     __shared__ Smem s;
     const uint8_t* p = img + (size_t)blockIdx.x * (size_t)hw * 3u;
     double* out = stats + (size_t)blockIdx.x * TIA_STATS_STRIDE;
+    uint16_t* bincache = binws ? binws + (size_t)blockIdx.x * (size_t)hw * 2u : nullptr;
     const int tid = threadIdx.x;
     const bool z1 = prm.zero_to_one != 0;
 
     if (tid < TIA_STATS_STRIDE) out[tid] = 0.0;
-    if (tid < 256) s.od[tid] = tab->od_lut[tid];
+    for (int i = tid; i < 256 * ODR; i += NT) s.od[i] = tab->od_lut[i / ODR];
+    const int odl = tid & (ODR - 1);
+#define OD(v) s.od[(v) * ODR + odl]
     if (tid == 0) {
         for (int i = 0; i < 16; ++i) s.tm[i] = 0;
         s.tlast = clock64();
@@ -458,6 +574,24 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
     unsigned* wh = &s.bins[0][0] + wave_id() * 768;
     for (int i = tid; i < NW * 768; i += NT) (&s.bins[0][0])[i] = 0;
     __syncthreads();
+    const bool grp = groups_ok(p, hw);
+    if (grp) {
+        for_each_group<NT>(p, hw, [&](long, uint32_t a, uint32_t b, uint32_t c, const WaveGroup& wg) {
+            uint32_t rr[4], gg[4], bb[4];
+            unpack_group(a, b, c, rr, gg, bb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (z1) {
+                    rr[i] = rr[i] ? rr[i] : 1u;
+                    gg[i] = gg[i] ? gg[i] : 1u;
+                    bb[i] = bb[i] ? bb[i] : 1u;
+                }
+                hist_add(wh, (int)rr[i], true, wg);
+                hist_add(wh + 256, (int)gg[i], true, wg);
+                hist_add(wh + 512, (int)bb[i], true, wg);
+            }
+        });
+    } else
     for_each_pixel_w<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b, const WaveGroup& wg) {
         if (z1) {
             r = r ? r : 1u;
@@ -474,7 +608,7 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
     double chm[6] = {0, 0, 0, 0, 0, 0};  // per-channel sum(od), sum(od^2) over ALL pixels
     if (tid < 256) {
         unsigned tot = 0;
-        const double o = s.od[tid];
+        const double o = OD(tid);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             unsigned h = 0;
@@ -490,10 +624,14 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
     if (tid < 6) s.chm[tid] = chm[tid];
     }
     __syncthreads();
-    if (tid < 256) {
-        unsigned c = 0;
-        for (int i = 0; i <= tid; ++i) c += s.hist[i];
-        s.cum[tid] = c;
+    if (tid < 64) {  // inclusive prefix over 256 bins: 4 consecutive bins per lane + one wave scan
+        const unsigned h0 = s.hist[tid * 4], h1 = s.hist[tid * 4 + 1], h2 = s.hist[tid * 4 + 2], h3 = s.hist[tid * 4 + 3];
+        const unsigned incl = wave_incl_scan_u32(h0 + h1 + h2 + h3);
+        const unsigned base = incl - (h0 + h1 + h2 + h3);
+        s.cum[tid * 4] = base + h0;
+        s.cum[tid * 4 + 1] = base + h0 + h1;
+        s.cum[tid * 4 + 2] = base + h0 + h1 + h2;
+        s.cum[tid * 4 + 3] = incl;
     }
     __syncthreads();
     {
@@ -573,8 +711,41 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
         double acc[13];
 #pragma unroll
         for (int i = 0; i < 13; ++i) acc[i] = 0.0;
+        if (grp && !use_bits) {
+            for_each_group<NT>(p, hw, [&](long, uint32_t a, uint32_t b, uint32_t c, const WaveGroup&) {
+                uint32_t rr[4], gg[4], bb[4];
+                unpack_group(a, b, c, rr, gg, bb);
+                double x[4], y[4], z[4];
+                int lum[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // every look-up of the group is in flight before the first use
+                    x[i] = OD(rr[i]);
+                    y[i] = OD(gg[i]);
+                    z[i] = OD(bb[i]);
+                    lum[i] = s.ty[0][rr[i]] + s.ty[1][gg[i]] + s.ty[2][bb[i]];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[10] += x[i] * y[i];
+                    acc[11] += x[i] * z[i];
+                    acc[12] += y[i] * z[i];
+                    if (((lum[i] + (1 << 11)) >> 12) < y_thr) {
+                        acc[0] += 1.0;
+                        acc[1] += x[i];
+                        acc[2] += y[i];
+                        acc[3] += z[i];
+                        acc[4] += x[i] * x[i];
+                        acc[5] += x[i] * y[i];
+                        acc[6] += x[i] * z[i];
+                        acc[7] += y[i] * y[i];
+                        acc[8] += y[i] * z[i];
+                        acc[9] += z[i] * z[i];
+                    }
+                }
+            });
+        } else
         for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
-            const double x = s.od[r], y = s.od[g], z = s.od[b];
+            const double x = OD(r), y = OD(g), z = OD(b);
             acc[10] += x * y;  // all-pixel cross moments: exact variance of the concentrations
             acc[11] += x * z;
             acc[12] += y * z;
@@ -651,13 +822,49 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
         select2(p, hw,
                 [&](long idx, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
                     if (!is_tissue_cached(idx, r, g, b)) return 0u;
-                    const double ox = s.od[r], oy = s.od[g], oz = s.od[b];
+                    const double ox = OD(r), oy = OD(g), oz = OD(b);
                     const double p0 = ox * e1x + oy * e1y + oz * e1z;
                     const double p1 = ox * e2x + oy * e2y + oz * e2z;
                     x[0] = x[1] = pseudo_angle(p1, p0);
                     return 3u;
                 },
-                s, kp, nn, lo0, hi0, lo0, hi0, true, vp, vn);
+                [&](unsigned (&below)[2], unsigned (&above)[2]) -> bool {
+                    if (!grp || use_bits) return false;
+                    const double lo = s.st.lo[0][0], sc = s.st.scale[0][0];
+                    unsigned bl = 0, ab = 0;
+                    for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup& wg) {
+                        uint32_t rr[4], gg[4], bb[4];
+                        unpack_group(a, b, c, rr, gg, bb);
+                        double ox[4], oy[4], oz[4];
+                        int lum[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            ox[i] = OD(rr[i]);
+                            oy[i] = OD(gg[i]);
+                            oz[i] = OD(bb[i]);
+                            lum[i] = s.ty[0][rr[i]] + s.ty[1][gg[i]] + s.ty[2][bb[i]];
+                        }
+                        unsigned long long codes = 0ull;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool tissue = ((lum[i] + (1 << 11)) >> 12) < y_thr;
+                            const double p0 = ox[i] * e1x + oy[i] * e1y + oz[i] * e1z;
+                            const double p1 = ox[i] * e2x + oy[i] * e2y + oz[i] * e2z;
+                            const double d = (pseudo_angle(p1, p0) - lo) * sc;
+                            const bool low = !(d >= 0.0), high = d >= (double)NB;
+                            const int bin = low ? 0 : (high ? NB - 1 : (int)d);
+                            bl += (tissue && low) ? 1u : 0u;
+                            ab += (tissue && high) ? 1u : 0u;
+                            hist_add(s.bins[0], bin, tissue && !low && !high, wg);
+                            codes |= (unsigned long long)(tissue ? (unsigned)bin : 0xffffu) << (16 * i);
+                        }
+                        *reinterpret_cast<unsigned long long*>(bincache + g * 4) = codes;
+                    });
+                    below[0] = bl;
+                    above[0] = ab;
+                    return true;
+                },
+                s, kp, nn, lo0, hi0, lo0, hi0, true, bincache, vp, vn);
         if (tid == 0) {
             s.tm[TM_PHI_TOTAL] = clock64() - t_begin;
             s.tm[15] = s.st.level[0] * 1000000 + s.st.level[1] * 100000 + (long long)s.st.cnt[0] + (long long)s.st.cnt[1] * 0;
@@ -688,7 +895,7 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
         for (int i = 0; i < 6; ++i) S[i] = prm.stain_fixed[i];
         double acc[3] = {0.0, 0.0, 0.0};
         for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
-            const double x = s.od[r], y = s.od[g], z = s.od[b];
+            const double x = OD(r), y = OD(g), z = OD(b);
             acc[0] += x * y;
             acc[1] += x * z;
             acc[2] += y * z;
@@ -725,7 +932,7 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
         kn[1] = kn[0];
         gm[1] = gm[0];
         // rigorous value bounds from the byte range: od in [od(bmax), od(bmin)]
-        const double oa = s.od[bmax], ob = s.od[bmin];
+        const double oa = OD(bmax), ob = OD(bmin);
         double lo0[2], hi0[2], olo0[2], ohi0[2];
         const double inv_n = 1.0 / (double)hw;
 #pragma unroll
@@ -769,12 +976,53 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
         double vp[2], vn[2];
         select2(p, hw,
                 [&](long, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
-                    const double ox = s.od[r], oy = s.od[g], oz = s.od[b];
+                    const double ox = OD(r), oy = OD(g), oz = OD(b);
                     x[0] = ox * P[0] + oy * P[2] + oz * P[4];
                     x[1] = ox * P[1] + oy * P[3] + oz * P[5];
                     return 3u;
                 },
-                s, kp, nn, lo0, hi0, olo0, ohi0, false, vp, vn);
+                [&](unsigned (&below)[2], unsigned (&above)[2]) -> bool {
+                    if (!grp) return false;
+                    const double l0 = s.st.lo[0][0], s0 = s.st.scale[0][0], l1 = s.st.lo[1][0], s1 = s.st.scale[1][0];
+                    unsigned bl0 = 0, ab0 = 0, bl1 = 0, ab1 = 0;
+                    for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup& wg) {
+                        uint32_t rr[4], gg[4], bb[4];
+                        unpack_group(a, b, c, rr, gg, bb);
+                        double ox[4], oy[4], oz[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            ox[i] = OD(rr[i]);
+                            oy[i] = OD(gg[i]);
+                            oz[i] = OD(bb[i]);
+                        }
+                        unsigned long long code0 = 0ull, code1 = 0ull;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const double d0 = ((ox[i] * P[0] + oy[i] * P[2] + oz[i] * P[4]) - l0) * s0;
+                            const double d1 = ((ox[i] * P[1] + oy[i] * P[3] + oz[i] * P[5]) - l1) * s1;
+                            const bool low0 = !(d0 >= 0.0), high0 = d0 >= (double)NB;
+                            const bool low1 = !(d1 >= 0.0), high1 = d1 >= (double)NB;
+                            const int b0 = low0 ? 0 : (high0 ? NB - 1 : (int)d0);
+                            const int b1 = low1 ? 0 : (high1 ? NB - 1 : (int)d1);
+                            bl0 += low0 ? 1u : 0u;
+                            ab0 += high0 ? 1u : 0u;
+                            bl1 += low1 ? 1u : 0u;
+                            ab1 += high1 ? 1u : 0u;
+                            hist_add(s.bins[0], b0, !low0 && !high0, wg);
+                            hist_add(s.bins[1], b1, !low1 && !high1, wg);
+                            code0 |= (unsigned long long)(unsigned)b0 << (16 * i);
+                            code1 |= (unsigned long long)(unsigned)b1 << (16 * i);
+                        }
+                        *reinterpret_cast<unsigned long long*>(bincache + g * 4) = code0;
+                        *reinterpret_cast<unsigned long long*>(bincache + (size_t)hw + g * 4) = code1;
+                    });
+                    below[0] = bl0;
+                    above[0] = ab0;
+                    below[1] = bl1;
+                    above[1] = ab1;
+                    return true;
+                },
+                s, kp, nn, lo0, hi0, olo0, ohi0, false, bincache, vp, vn);
         if (tid == 0) {
             s.tm[11] = s.st.level[0];
             s.tm[12] = s.st.level[1];
@@ -814,16 +1062,26 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
 
 }  // namespace tia
 
+extern "C" size_t tia_stain_stats_workspace_bytes(int64_t n, int64_t h, int64_t w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    return (size_t)n * (size_t)h * (size_t)w * 2u * sizeof(uint16_t);
+}
+
 extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
                                    const tia_stain_tables* d_tables, const tia_stain_params* params,
-                                   double* d_stats, void* stream) {
+                                   double* d_stats, void* d_ws, size_t ws_bytes, void* stream) {
     if (!d_img || !d_tables || !params || !d_stats) return TIA_EINVAL;
     if (n <= 0 || h <= 0 || w <= 0) return TIA_EINVAL;
     if (params->mode != TIA_MODE_MACENKO && params->mode != TIA_MODE_FIXED) return TIA_EINVAL;
     const long hw = (long)h * (long)w;
     if ((unsigned long long)hw * 3ull >= 0xffffffffull) return TIA_ESIZE;  // 32-bit histogram counts
     if (n > 0x7fffffffll) return TIA_ESIZE;
+    // the per-pixel bin cache is optional: without (enough) workspace the kernel recomputes values
+    uint16_t* binws = (d_ws && ws_bytes >= tia_stain_stats_workspace_bytes(n, h, w) &&
+                       (reinterpret_cast<uintptr_t>(d_ws) & 7) == 0)
+                          ? (uint16_t*)d_ws
+                          : nullptr;
     hipLaunchKernelGGL(tia::stain_stats_kernel, dim3((unsigned)n), dim3(tia::NT), 0,
-                       (hipStream_t)stream, d_img, hw, d_tables, *params, d_stats);
+                       (hipStream_t)stream, d_img, hw, d_tables, *params, d_stats, binws);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

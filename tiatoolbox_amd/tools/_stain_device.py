@@ -35,6 +35,19 @@ def tables(device: torch.device) -> torch.Tensor:
     return _TABLES[idx]
 
 
+_WS: dict[int, torch.Tensor] = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch per device (kernels on one stream are ordered, so it can be shared)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cur = _WS.get(idx)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=torch.device("cuda", idx))
+        _WS[idx] = cur
+    return cur
+
+
 def as_batch(img: torch.Tensor) -> torch.Tensor:
     """Validate an NHWC uint8 CUDA batch (contiguous)."""
     _lib.require_cuda(img, "image batch")
@@ -76,9 +89,12 @@ def stain_stats(img: torch.Tensor, params: _lib.StainParams) -> torch.Tensor:
     n, h, w, _ = img.shape
     stats = torch.empty((n, _lib.TIA_STATS_STRIDE), dtype=torch.float64, device=img.device)
     tab = tables(img.device)
+    lib = _lib.load()
+    ws_bytes = lib.tia_stain_stats_workspace_bytes(n, h, w)
+    ws = _workspace(img.device, ws_bytes)
     with torch.cuda.device(img.device):
-        rc = _lib.load().tia_stain_stats_u8(img.data_ptr(), n, h, w, tab.data_ptr(), C.byref(params),
-                                            stats.data_ptr(), _lib.current_stream())
+        rc = lib.tia_stain_stats_u8(img.data_ptr(), n, h, w, tab.data_ptr(), C.byref(params), stats.data_ptr(),
+                                    ws.data_ptr(), ws_bytes, _lib.current_stream())
     _lib.check(rc, "tia_stain_stats_u8")
     return stats
 
