@@ -74,14 +74,25 @@ def cpu_baseline(target, patches, model_cpu, sample: int) -> dict:
     import torch
 
     cores = os.cpu_count() or 1
-    sample = min(max(sample, min(cores, 256)), len(patches))
+    sample = min(max(sample, 4 * min(cores, 256)), len(patches))
     cnn_threads = min(cores, 64)
     sub = [np.ascontiguousarray(p) for p in patches[:sample]]
-    with mp.get_context("spawn").Pool(cores) as pool:
-        pool.map(cpu_norm_worker, [(target, sub[0])] * cores)  # start workers, fit the target once each
-        t0 = time.perf_counter()
-        normed = pool.map(cpu_norm_worker, [(target, p) for p in sub], chunksize=1)
-        t_norm = time.perf_counter() - t0
+    # one BLAS/OpenMP thread per worker process: the pool already uses every core
+    thread_vars = ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS", "NUMEXPR_NUM_THREADS")
+    saved = {k: os.environ.get(k) for k in thread_vars}
+    os.environ.update(dict.fromkeys(thread_vars, "1"))
+    try:
+        with mp.get_context("spawn").Pool(cores) as pool:
+            pool.map(cpu_norm_worker, [(target, sub[0])] * cores)  # start workers, fit the target once each
+            t0 = time.perf_counter()
+            normed = pool.map(cpu_norm_worker, [(target, p) for p in sub], chunksize=1)
+            t_norm = time.perf_counter() - t0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     torch.set_num_threads(cnn_threads)
     x = torch.from_numpy(np.stack(normed)).float().div(255).permute(0, 3, 1, 2).contiguous()
     model_cpu.eval()
