@@ -217,6 +217,25 @@ int tia_hover_instance_stats(const int32_t* d_inst, const uint8_t* d_type, int64
                              int32_t max_inst, int32_t num_types, int64_t* d_stats, int32_t* d_types,
                              void* stream);
 
+/*
+ * Contour polygon of every instance: cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0]
+ * of the instance's binary mask (hovernet.py:685-692) = the top-level outer border found last in
+ * raster order, vertices where the 8-connected chain code changes, counter-clockwise on screen
+ * starting at the border's first pixel in raster order.  One lane follows the borders of one instance.
+ *   scan : d_stats from tia_hover_instance_stats; d_mark = n*h*w bytes of scratch;
+ *          d_meta [n, max_inst+1, 4] i32 = start x, start y, vertex count, offset of the first vertex
+ *          (exclusive prefix sum over the whole table); d_total[0] = number of vertices of all instances.
+ *   write: d_points [capacity, 2] i32 (x, y) in image coordinates; instances whose vertices would not
+ *          fit in `capacity` are left unwritten (pass capacity = *d_total).
+ * The reference drops instances with fewer than 3 vertices (hovernet.py:695-699); that is the caller's job.
+ */
+int tia_hover_contour_scan(const int32_t* d_inst, int64_t n, int64_t h, int64_t w, int32_t max_inst,
+                           const int64_t* d_stats, int8_t* d_mark, int32_t* d_meta, int64_t* d_total,
+                           void* stream);
+int tia_hover_contour_write(const int32_t* d_inst, int64_t n, int64_t h, int64_t w, int32_t max_inst,
+                            const int64_t* d_stats, const int32_t* d_meta, int64_t capacity,
+                            int32_t* d_points, void* stream);
+
 
 /* =======================================================================================
  * Semantic-segmentation stitching (models/engine/semantic_segmentor.py:1141-1263,1398-1534)

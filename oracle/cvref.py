@@ -432,3 +432,103 @@ def lab2rgb_u8(lab: np.ndarray) -> np.ndarray:
         v = _descale(c[r * 3] * x + c[r * 3 + 1] * y + c[r * 3 + 2] * z, shift)
         out.append(t["inv_gamma"][np.clip(v, 0, INV_GAMMA_TAB_SIZE - 1)])
     return np.clip(np.stack(out, axis=-1), 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------ findContours (Suzuki-Abe)
+# 8-neighbourhood chain codes of OpenCV (x right, y down): 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE
+_CODE_DXY = ((1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1))
+
+
+def _follow_border(f: np.ndarray, x0: int, y0: int, nbd: int, *, is_hole: bool, simple: bool = True) -> list:
+    """Border following of one border (Suzuki & Abe 1985, step 3; OpenCV ``icvFetchContour``).
+
+    ``f`` is the zero-padded int image (0 background, 1 unvisited foreground, +-k visited), ``x0,y0``
+    the padded coordinates of the start pixel.  Marks ``-nbd`` where the right neighbour is a
+    zero pixel examined by the search, ``nbd`` on other yet unmarked pixels.  With ``simple`` a point is
+    emitted only where the chain code changes (``CHAIN_APPROX_SIMPLE``).  Returned points are in
+    padded coordinates.
+    """
+    s_end = s = 0 if is_hole else 4
+    while True:  # first non-zero neighbour clockwise from the start direction
+        s = (s - 1) & 7
+        x1, y1 = x0 + _CODE_DXY[s][0], y0 + _CODE_DXY[s][1]
+        if f[y1, x1] != 0 or s == s_end:
+            break
+    if f[y1, x1] == 0:  # isolated pixel
+        f[y0, x0] = -nbd
+        return [(x0, y0)]
+    pts = []
+    x3, y3 = x0, y0
+    prev_s = s ^ 4
+    while True:
+        s_end = s
+        while True:  # counter-clockwise search from the direction after the one we came from
+            s += 1
+            x4, y4 = x3 + _CODE_DXY[s & 7][0], y3 + _CODE_DXY[s & 7][1]
+            if f[y4, x4] != 0:
+                break
+        passed_east = s > 8  # direction 0 (== 8 unwrapped) was examined and found zero
+        s &= 7
+        if passed_east:
+            f[y3, x3] = -nbd
+        elif f[y3, x3] == 1:
+            f[y3, x3] = nbd
+        if s != prev_s or not simple:
+            pts.append((x3, y3))
+            prev_s = s
+        if (x4, y4) == (x0, y0) and (x3, y3) == (x1, y1):
+            break
+        x3, y3 = x4, y4
+        s = (s + 4) & 7
+    return pts
+
+
+def find_contours_tree(mask: np.ndarray) -> list[dict]:
+    """All borders of a binary image with their topology, in raster order of discovery.
+
+    ``cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)`` restated from Suzuki & Abe's
+    algorithm 1 (the one OpenCV implements).  Each entry: ``points`` (k,2) int32 ``(x, y)``,
+    ``is_hole``, ``parent`` (index into the list, -1 = frame).  **Parity unpinned** (no cv2 here);
+    structural known answers are asserted in ``tests/test_oracle_golden.py``.
+    """
+    m = np.asarray(mask) != 0
+    h, w = m.shape
+    f = np.zeros((h + 2, w + 2), dtype=np.int64)
+    f[1:-1, 1:-1] = m
+    borders: list[dict] = []  # border k+2 <-> borders[k]; border 1 = frame (a hole border)
+    for y in range(1, h + 1):
+        lnbd = 1
+        for x in range(1, w + 2):
+            p, prev = f[y, x], f[y, x - 1]
+            start = None
+            if p == 1 and prev == 0:
+                start, is_hole = (x, y), False
+            elif p == 0 and prev >= 1:
+                start, is_hole = (x - 1, y), True
+                if prev > 1:
+                    lnbd = int(prev)
+            if start is not None:
+                # parent (Suzuki & Abe, table 1): same kind as the last border met -> share its parent,
+                # otherwise that border is the parent; the frame (index -1) behaves as a hole border
+                lnbd_hole = True if lnbd == 1 else borders[lnbd - 2]["is_hole"]
+                lnbd_parent = -1 if lnbd == 1 else borders[lnbd - 2]["parent"]
+                parent = lnbd_parent if lnbd_hole == is_hole else lnbd - 2
+                nbd = len(borders) + 2
+                pts = _follow_border(f, start[0], start[1], nbd, is_hole=is_hole)
+                borders.append({"points": np.array(pts, dtype=np.int32).reshape(-1, 2) - 1,
+                                "is_hole": is_hole, "parent": parent})
+                p = f[y, x]
+            if p not in (0, 1):
+                lnbd = abs(int(p))
+    return borders
+
+
+def first_contour(mask: np.ndarray) -> np.ndarray:
+    """``cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)[0][0]`` squeezed to (k, 2).
+
+    OpenCV links every new border at the *front* of its parent's child list
+    (``cvInsertNodeIntoTree``) and enumerates the tree in pre-order, so element 0 is the top-level
+    outer border that was discovered **last** in raster order.  Call site: ``hovernet.py:685-692``.
+    """
+    tops = [b for b in find_contours_tree(mask) if not b["is_hole"] and b["parent"] == -1]
+    return tops[-1]["points"]

@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  ``proc_np_hv`` follows ``_proc_np_hv``
 (:502-616) line by line with the cv2 / skimage primitives restated in ``cvref`` / ``skref`` and
 scipy's own ``ndimage.label`` / ``binary_fill_holes``; ``get_instance_info`` follows :618-748
-(without the OpenCV contour polygon, which is outside this round's scope).
+(contour polygons through ``cvref.first_contour``, the Suzuki-Abe restatement of ``cv2.findContours``).
 """
 
 from __future__ import annotations
@@ -68,8 +68,9 @@ def get_bounding_box(img: np.ndarray) -> np.ndarray:
 
 def get_instance_info(pred_inst: np.ndarray, pred_type: np.ndarray | None = None,
                       offset: tuple[int, int] = (0, 0)) -> dict:
-    """``hovernet.py:618-748`` minus ``contours``: box, centroid (raw moments of the cropped
-    binary mask + top-left), majority type and its probability."""
+    """``hovernet.py:618-748``: box, centroid (raw moments of the cropped binary mask + top-left),
+    contour (``cvref.first_contour``; instances with fewer than 3 vertices are dropped, :695-699),
+    majority type and its probability."""
     offset = np.asarray(offset)
     info = {}
     for inst_id in np.unique(pred_inst)[1:]:
@@ -79,11 +80,15 @@ def get_instance_info(pred_inst: np.ndarray, pred_type: np.ndarray | None = None
         crop = inst_map[box[1]:box[3], box[0]:box[2]].astype(np.uint8)
         ys, xs = np.nonzero(crop)
         m00, m10, m01 = float(crop.sum()), float(xs.sum()), float(ys.sum())
+        contour = cvref.first_contour(crop).astype(np.int32)
+        if contour.shape[0] < 3:  # noqa: PLR2004
+            continue
+        contour = contour + tl[None].astype(np.int32)
         centroid = np.array([m10 / m00, m01 / m00]) + tl
         out_box = box.copy()
         out_box[:2] += offset
         out_box[2:] += offset
-        info[int(inst_id)] = {"box": out_box, "centroid": centroid, "prob": None, "type": None}
+        info[int(inst_id)] = {"box": out_box, "centroid": centroid, "contours": contour, "prob": None, "type": None}
         if pred_type is not None:
             inst_type = pred_type[box[1]:box[3], box[0]:box[2]][crop.astype(bool)]
             type_list, type_pixels = np.unique(inst_type, return_counts=True)

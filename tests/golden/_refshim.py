@@ -132,10 +132,8 @@ def install() -> None:
         return {"m00": float(len(xs)), "m10": float(xs.sum()), "m01": float(ys.sum())}
 
     def find_contours(img, mode, method):  # noqa: ARG001
-        """Placeholder polygon (bounding-box corners): contour parity is outside this round."""
-        ys, xs = np.nonzero(img)
-        box = np.array([[[xs.min(), ys.min()]], [[xs.max(), ys.min()]], [[xs.max(), ys.max()]], [[xs.min(), ys.max()]]])
-        return [box], None
+        """``(contours, hierarchy)``; only element 0 is populated faithfully (all the reference reads)."""
+        return [cvref.first_contour(img)[:, None, :]], None
 
     cv2.moments = moments
     cv2.findContours = find_contours

@@ -130,7 +130,7 @@ def hover_goldens() -> None:
     out = {}
     for tag, (h, w, seed, nb) in {"a": (164, 164, 1, 30), "b": (96, 120, 2, 12)}.items():
         npm, hv, tp = oh.synth_maps(2, h, w, seed=seed, n_blobs=nb)
-        insts, boxes, cents, types, probs, ids = [], [], [], [], [], []
+        insts, boxes, cents, types, probs, ids, polys = [], [], [], [], [], [], []
         for i in range(2):
             inst = hov.HoVerNet._proc_np_hv(npm[i], hv[i])
             insts.append(inst)
@@ -141,11 +141,15 @@ def hover_goldens() -> None:
             cents.append(np.array([v["centroid"] for v in info.values()]))
             types.append(np.array([v["type"] for v in info.values()]))
             probs.append(np.array([v["prob"] for v in info.values()]))
+            polys.append([v["contours"] for v in info.values()])
         out[f"{tag}_shape"] = np.array([h, w, seed, nb])
         out[f"{tag}_inst"] = np.stack(insts)
         for i in range(2):
             out[f"{tag}_ids{i}"], out[f"{tag}_box{i}"], out[f"{tag}_cent{i}"] = ids[i], boxes[i], cents[i]
             out[f"{tag}_type{i}"], out[f"{tag}_prob{i}"] = types[i], probs[i]
+            # polygons (through the shim's findContours = oracle.cvref.first_contour; cv2 itself is absent)
+            out[f"{tag}_polylen{i}"] = np.array([len(c) for c in polys[i]])
+            out[f"{tag}_poly{i}"] = np.concatenate(polys[i]).astype(np.int32)
     np.savez_compressed(HERE / "hover_golden.npz", **out)
     print("wrote hover_golden.npz:", {k: getattr(v, "shape", None) for k, v in out.items() if "inst" in k},
           [int(out[f"{t}_inst"].max()) for t in "ab"])

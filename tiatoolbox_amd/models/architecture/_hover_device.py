@@ -58,8 +58,38 @@ def instance_stats(inst: torch.Tensor, type_map: torch.Tensor | None, max_inst: 
     return stats, types
 
 
-def info_from_stats(stats: np.ndarray, types: np.ndarray | None, offset=(0, 0)) -> dict:
+def contours(inst: torch.Tensor, stats: torch.Tensor, max_inst: int):
+    """Contour polygon of every instance (``cv2.findContours(...)[0][0]``, hovernet.py:685-692).
+
+    Returns ``(meta, points)`` on the host: ``meta [N, max_inst+1, 4]`` int32 = start x/y, vertex count,
+    offset into ``points [total, 2]`` int32 ``(x, y)``.
+    """
+    _lib.require_cuda(inst, "inst")
+    inst = inst.contiguous()
+    n, h, w = inst.shape
+    dev = inst.device
+    meta = torch.empty((n, max_inst + 1, 4), dtype=torch.int32, device=dev)
+    mark = torch.empty((n, h, w), dtype=torch.int8, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.tia_hover_contour_scan(inst.data_ptr(), n, h, w, int(max_inst), stats.data_ptr(), mark.data_ptr(),
+                                        meta.data_ptr(), total.data_ptr(), _lib.current_stream())
+        _lib.check(rc, "tia_hover_contour_scan")
+        cap = int(total.item())  # the polygon buffer is sized by the data: one scalar read-back
+        points = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        rc = lib.tia_hover_contour_write(inst.data_ptr(), n, h, w, int(max_inst), stats.data_ptr(), meta.data_ptr(),
+                                         cap, points.data_ptr(), _lib.current_stream())
+        _lib.check(rc, "tia_hover_contour_write")
+    return meta.cpu().numpy(), points.cpu().numpy()
+
+
+def info_from_stats(stats: np.ndarray, types: np.ndarray | None, offset=(0, 0), *,
+                    meta: np.ndarray | None = None, points: np.ndarray | None = None) -> dict:
     """Assemble the reference's per-instance dict (hovernet.py:670-748) from the device statistics.
+
+    ``contours``: the instance's slice of ``points``; instances whose polygon has fewer than 3 vertices are
+    dropped like the reference does (hovernet.py:695-699).
 
     ``centroid`` reproduces ``cv2.moments``: ``m10/m00 + x_min`` with the raw moments of the cropped
     mask (exact integers), ``type``: most frequent value, ties to the smaller class, background (0)
@@ -69,12 +99,18 @@ def info_from_stats(stats: np.ndarray, types: np.ndarray | None, offset=(0, 0)) 
     info = {}
     for inst_id in np.flatnonzero(stats[:, 0] > 0):
         area, xmin, ymin, xmax, ymax, sumx, sumy, _ = (int(v) for v in stats[inst_id])
+        contour = None
+        if meta is not None:
+            _, _, npts, first = (int(v) for v in meta[inst_id])
+            if npts < 3:  # noqa: PLR2004
+                continue
+            contour = points[first:first + npts].astype(np.int32) + offset[None]
         tl = np.array([xmin, ymin]) + offset
         centroid = np.array([float(sumx - area * xmin) / float(area), float(sumy - area * ymin) / float(area)]) + tl
         box = np.array([xmin, ymin, xmax + 1, ymax + 1])
         box[:2] += offset
         box[2:] += offset
-        entry = {"box": box, "centroid": centroid, "prob": None, "type": None}
+        entry = {"box": box, "centroid": centroid, "contours": contour, "prob": None, "type": None}
         if types is not None:
             votes = types[inst_id]
             present = np.flatnonzero(votes)

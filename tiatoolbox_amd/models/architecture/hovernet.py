@@ -139,6 +139,14 @@ class ResidualBlock(nn.Module):
         return self.blk_bna(prev_feat)
 
 
+def _contour_column(polys: list) -> np.ndarray:
+    """Object array with one ``(k, 2)`` int32 polygon per instance (what ``DataFrame.to_numpy`` yields, ref. :913-931)."""
+    col = np.empty(len(polys), dtype=object)
+    for i, poly in enumerate(polys):
+        col[i] = poly
+    return col
+
+
 class HoVerNet(ModelABC):
     """HoVer-Net: pre-act ResNet-50 encoder, three dense decoders (``tp``/``np``/``hv``) (ref. :264-932)."""
 
@@ -258,10 +266,8 @@ class HoVerNet(ModelABC):
 
     @staticmethod
     def get_instance_info(pred_inst, pred_type=None, offset=(0, 0), *, verbose: bool = True) -> dict:  # noqa: ARG004
-        """Per-instance ``box`` / ``centroid`` / ``type`` / ``prob`` (ref. :618-748) from device statistics.
-
-        ``contours`` (OpenCV polygon tracing) is not produced in this round.
-        """
+        """Per-instance ``box`` / ``centroid`` / ``contours`` / ``type`` / ``prob`` (ref. :618-748): statistics and
+        border following run on the device, only the dict is assembled on the host."""
         as_numpy = not isinstance(pred_inst, torch.Tensor)
         from tiatoolbox_amd.utils._tensors import default_device
 
@@ -275,7 +281,9 @@ class HoVerNet(ModelABC):
             num_types = int(tmap.max()) + 1
         max_inst = int(inst.max())
         stats, types = hd.instance_stats(inst, tmap, max_inst, num_types)
-        return hd.info_from_stats(stats[0].cpu().numpy(), types[0].cpu().numpy() if types is not None else None, offset)
+        meta, points = hd.contours(inst, stats, max_inst)
+        return hd.info_from_stats(stats[0].cpu().numpy(), types[0].cpu().numpy() if types is not None else None, offset,
+                                  meta=meta[0], points=points)
 
     def postproc(self, raw_maps: list, offset: tuple[int, int] = (0, 0)) -> tuple[dict, ...]:
         """Post-process one patch/tile (ref. :751-859): instance map + instance table."""
@@ -300,7 +308,7 @@ class HoVerNet(ModelABC):
             table = {
                 "box": np.array([v["box"] for v in info.values()]),
                 "centroid": np.array([v["centroid"] for v in info.values()]),
-                "contours": np.empty(shape=0),
+                "contours": _contour_column([v["contours"] for v in info.values()]),
                 "prob": np.array([v["prob"] for v in info.values()], dtype=object),
                 "type": np.array([v["type"] for v in info.values()], dtype=object),
             }
@@ -313,9 +321,12 @@ class HoVerNet(ModelABC):
         if tp_map is not None:
             tmap = torch.round(tp_map).to(torch.uint8).reshape(inst.shape)
             num_types = max(int(self.num_types or 0), int(tmap.max()) + 1)
-        stats, types = hd.instance_stats(inst, tmap, int(nmark.max()), num_types)
+        max_inst = int(nmark.max())
+        stats, types = hd.instance_stats(inst, tmap, max_inst, num_types)
+        meta, points = hd.contours(inst, stats, max_inst)
         stats_h = stats.cpu().numpy()
         types_h = types.cpu().numpy() if types is not None else None
         inst_h = inst.cpu().numpy()
-        return [self._pack(inst_h[i], hd.info_from_stats(stats_h[i], types_h[i] if types_h is not None else None))
+        return [self._pack(inst_h[i], hd.info_from_stats(stats_h[i], types_h[i] if types_h is not None else None,
+                                                         meta=meta[i], points=points))
                 for i in range(inst.shape[0])]
