@@ -104,7 +104,7 @@ def info_from_stats(stats: np.ndarray, types: np.ndarray | None, offset=(0, 0), 
             _, _, npts, first = (int(v) for v in meta[inst_id])
             if npts < 3:  # noqa: PLR2004
                 continue
-            contour = points[first:first + npts].astype(np.int32) + offset[None]
+            contour = (points[first:first + npts] + offset[None]).astype(np.int32)
         tl = np.array([xmin, ymin]) + offset
         centroid = np.array([float(sumx - area * xmin) / float(area), float(sumy - area * ymin) / float(area)]) + tl
         box = np.array([xmin, ymin, xmax + 1, ymax + 1])
