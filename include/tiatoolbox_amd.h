@@ -288,6 +288,16 @@ int tia_lab_hist_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w, const
 int tia_reinhard_apply_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w, const tia_lab_tables* d_tables,
                           const uint8_t* d_lut /* [n,3,256] */, uint8_t* d_out, void* stream);
 
+/* Per-image Lab statistics and the 3x256 LUTs of tia_reinhard_apply_u8 from the histograms of
+ * tia_lab_hist_u8, entirely on the device (stainnorm.py:277-292,336-339,362-367):
+ * mean / population std of the float32 channels (cv2.meanStdDev) in f64, then the reference's float32
+ * chain per Lab byte.  d_chan_vals [3,256] f32 = channel value of every Lab byte (L/2.55, a-128, b-128);
+ * target_means / target_stds: host pointers to 3 doubles each (copied at launch).
+ * d_meanstd [n,6] f64 (means then stds) and d_flags [n] i32 (bit 0: a zero std, where the reference raises
+ * ZeroDivisionError) are optional outputs; d_flags must be zero-initialised. */
+int tia_reinhard_luts(const uint32_t* d_hist, int64_t n, const float* d_chan_vals, const double* target_means,
+                      const double* target_stds, uint8_t* d_lut, double* d_meanstd, int32_t* d_flags, void* stream);
+
 /* cv2.cvtColor 8-bit RGB2LAB (dir 0) / LAB2RGB (dir 1) of npix pixels. */
 int tia_lab_convert_u8(const uint8_t* d_src, int64_t npix, const tia_lab_tables* d_tables, int32_t dir,
                        uint8_t* d_dst, void* stream);

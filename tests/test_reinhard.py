@@ -80,3 +80,46 @@ def test_hip_reinhard_matches_reference_goldens(gold, target_image, images):
     assert np.array_equal(c1, e1) and np.array_equal(c2, e2) and np.array_equal(c3, e3)
     assert np.array_equal(norm.merge_back(c1.copy(), c2.copy(), c3.copy()),
                           ostain.ReinhardNormalizer.merge_back(e1.copy(), e2.copy(), e3.copy()))
+
+
+@pytest.mark.gpu
+def test_hip_reinhard_device_luts_match_host_arithmetic():
+    """tia_reinhard_luts (statistics + float32 LUT chain on the device) == the NumPy evaluation of the same
+    expressions (``ReinhardNormalizer._mean_std`` / ``_luts``), bit for bit, incl. the zero-std error."""
+    import ctypes as C
+
+    import torch
+
+    from tiatoolbox_amd import _lib
+    from tiatoolbox_amd.tools import reinhard as rh
+
+    rng = np.random.default_rng(5)
+    n = 300
+    hist = np.zeros((n, 3, 256), np.int64)
+    for i in range(n):
+        for c in range(3):
+            lo, hi = sorted(rng.integers(0, 256, 2))
+            hi = max(hi, lo + 2)
+            vals = rng.integers(lo, hi, rng.integers(50, 60000))
+            hist[i, c] = np.bincount(vals, minlength=256)
+    norm = rh.ReinhardNormalizer()
+    norm.target_means, norm.target_stds = (63.123456789, 7.25, -4.875), (11.0625, 5.3, 6.789)
+    means, stds = norm._mean_std(hist)  # noqa: SLF001
+    exp = norm._luts(means, stds)       # noqa: SLF001
+    dev = torch.device("cuda")
+    hist_d = torch.from_numpy(hist.astype(np.int32)).to(dev)
+    luts = torch.empty((n, 3, 256), dtype=torch.uint8, device=dev)
+    ms = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    flags = torch.zeros(n, dtype=torch.int32, device=dev)
+    tm, ts = (C.c_double * 3)(*norm.target_means), (C.c_double * 3)(*norm.target_stds)
+    rc = _lib.load().tia_reinhard_luts(hist_d.data_ptr(), n, rh._channel_values_device(dev).data_ptr(), tm, ts,  # noqa: SLF001
+                                       luts.data_ptr(), ms.data_ptr(), flags.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "tia_reinhard_luts")
+    got_ms = ms.cpu().numpy()
+    assert np.array_equal(got_ms[:, :3], means) and np.array_equal(got_ms[:, 3:], stds)
+    assert np.array_equal(luts.cpu().numpy(), exp)
+    assert int(flags.sum()) == 0
+    flat = np.full((4, 4, 3), 200, np.uint8)
+    norm.fit(np.random.default_rng(0).integers(0, 255, (16, 16, 3), dtype=np.uint8))
+    with pytest.raises(ZeroDivisionError):
+        norm.transform(flat)

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "tia_canvas_finalize_f32": ([_P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P], C.c_int),
     "tia_lab_hist_u8": ([_P, _I64, _I64, _I64, _P, _P, _P], C.c_int),
     "tia_reinhard_apply_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
+    "tia_reinhard_luts": ([_P, _I64, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "tia_lab_convert_u8": ([_P, _I64, _P, _I32, _P, _P], C.c_int),
     "tia_bias_act_nhwc": ([_P, _P, _P, _I64, _I64, _I32, _I32, _P], C.c_int),
     "tia_bias_relu_maxpool_nhwc": ([_P, _P, _I64, _I64, _I64, _I64, _I32, _P, _P], C.c_int),

@@ -30,37 +30,84 @@ __global__ __launch_bounds__(256) void np_threshold_kernel(const float* __restri
 }
 
 // ---- per-plane min / max ---------------------------------------------------------------------------------
-// out[plane*2] = min, out[plane*2+1] = max (as f64).  `stride`/`offset` address interleaved channels.
-template <class T>
-__global__ __launch_bounds__(1024) void minmax_kernel(const T* __restrict__ src, long hw, int stride, int offset,
-                                                       double* __restrict__ out) {
-    __shared__ double smin[16], smax[16];
-    const T* s = src + (size_t)blockIdx.x * hw * stride + offset;
-    double mn = 1.0 / 0.0, mx = -1.0 / 0.0;
-    for (long i = threadIdx.x; i < hw; i += 1024) {
-        const double v = (double)s[i * stride];
-        mn = v < mn ? v : mn;
-        mx = v > mx ? v : mx;
+// out[plane*2] = min, out[plane*2+1] = max (as f64) of two maps per launch.  One workgroup per plane,
+// coalesced sweeps with four loads in flight; NaNs are never selected (v < mn / v > mx comparisons).
+struct MinMax2 {
+    double v[4];  // min0, max0, min1, max1
+    __device__ void init() {
+        v[0] = v[2] = 1.0 / 0.0;
+        v[1] = v[3] = -1.0 / 0.0;
     }
+    __device__ void add(double a, double b) {
+        v[0] = a < v[0] ? a : v[0];
+        v[1] = a > v[1] ? a : v[1];
+        v[2] = b < v[2] ? b : v[2];
+        v[3] = b > v[3] ? b : v[3];
+    }
+    __device__ void merge(const double o[4]) {
+        v[0] = o[0] < v[0] ? o[0] : v[0];
+        v[1] = o[1] > v[1] ? o[1] : v[1];
+        v[2] = o[2] < v[2] ? o[2] : v[2];
+        v[3] = o[3] > v[3] ? o[3] : v[3];
+    }
+};
+__device__ __forceinline__ void minmax2_finish(MinMax2 m, double* __restrict__ out0, double* __restrict__ out1) {
+    __shared__ double red[16][4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const double a = __shfl_down(mn, o, 64), b = __shfl_down(mx, o, 64);
-        mn = a < mn ? a : mn;
-        mx = b > mx ? b : mx;
+        double t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = __shfl_down(m.v[k], o, 64);
+        m.merge(t);
     }
     if (lane_id() == 0) {
-        smin[wave_id()] = mn;
-        smax[wave_id()] = mx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave_id()][k] = m.v[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < 16; ++i) {
-            mn = smin[i] < mn ? smin[i] : mn;
-            mx = smax[i] > mx ? smax[i] : mx;
-        }
-        out[blockIdx.x * 2] = mn;
-        out[blockIdx.x * 2 + 1] = mx;
+        for (int i = 1; i < 16; ++i) m.merge(red[i]);
+        out0[blockIdx.x * 2] = m.v[0];
+        out0[blockIdx.x * 2 + 1] = m.v[1];
+        out1[blockIdx.x * 2] = m.v[2];
+        out1[blockIdx.x * 2 + 1] = m.v[3];
     }
+}
+// both channels of the interleaved (h, v) map
+__global__ __launch_bounds__(1024) void minmax_hv_kernel(const float* __restrict__ hv, long hw, double* __restrict__ out_h,
+                                                          double* __restrict__ out_v) {
+    const float2* s = reinterpret_cast<const float2*>(hv + (size_t)blockIdx.x * hw * 2);
+    MinMax2 m;
+    m.init();
+    long i = threadIdx.x;
+    for (; i + 3072 < hw; i += 4096) {
+        const float2 a = s[i], b = s[i + 1024], c = s[i + 2048], d = s[i + 3072];
+        m.add((double)a.x, (double)a.y);
+        m.add((double)b.x, (double)b.y);
+        m.add((double)c.x, (double)c.y);
+        m.add((double)d.x, (double)d.y);
+    }
+    for (; i < hw; i += 1024) {
+        const float2 a = s[i];
+        m.add((double)a.x, (double)a.y);
+    }
+    minmax2_finish(m, out_h, out_v);
+}
+// two f64 planes
+__global__ __launch_bounds__(1024) void minmax_pair_kernel(const double* __restrict__ pa, const double* __restrict__ pb, long hw,
+                                                            double* __restrict__ out_a, double* __restrict__ out_b) {
+    const double* a = pa + (size_t)blockIdx.x * hw;
+    const double* b = pb + (size_t)blockIdx.x * hw;
+    MinMax2 m;
+    m.init();
+    long i = threadIdx.x;
+    for (; i + 1024 < hw; i += 2048) {
+        const double a0 = a[i], b0 = b[i], a1 = a[i + 1024], b1 = b[i + 1024];
+        m.add(a0, b0);
+        m.add(a1, b1);
+    }
+    for (; i < hw; i += 1024) m.add(a[i], b[i]);
+    minmax2_finish(m, out_a, out_b);
 }
 
 // cv2.normalize(NORM_MINMAX, 0..1): scale = 1/(max-min) (0 if the range is < DBL_EPSILON), shift = -min*scale
@@ -70,11 +117,16 @@ __device__ __forceinline__ void norm_params(const double* __restrict__ mm, doubl
     shift = 0.0 - mm[0] * scale;
 }
 
+// Filter taps travel as a kernel argument (scalar loads; exact small integers in f64).
+struct SobelTaps {
+    double v[32];
+};
+
 // ---- Sobel (separable, f64 accumulate) -----------------------------------------------------------------------
 // Row pass over the min-max-normalised f32 map (normalisation in f32 arithmetic, as convertTo does for
 // CV_32F sources): buf = sum_k kx[k] * S[x + k - anchor], taps in ascending order.
 __global__ __launch_bounds__(HT) void sobel_row_kernel(const float* __restrict__ hv, int channel, int h, int w,
-                                                        const double* __restrict__ mm, const double* __restrict__ kx,
+                                                        const double* __restrict__ mm, const SobelTaps kx,
                                                         int ksize, double* __restrict__ buf) {
     const long hw = (long)h * w;
     const float* src = hv + (size_t)blockIdx.y * hw * 2 + channel;
@@ -90,7 +142,7 @@ __global__ __launch_bounds__(HT) void sobel_row_kernel(const float* __restrict__
         for (int k = 0; k < ksize; ++k) {
             const int xx = reflect101(x + k - anchor, w);
             const float v = row[(size_t)xx * 2] * a + b;
-            const double t = kx[k] * (double)v;
+            const double t = kx.v[k] * (double)v;
             acc = (k == 0) ? t : acc + t;
         }
         dst[i] = acc;
@@ -99,7 +151,7 @@ __global__ __launch_bounds__(HT) void sobel_row_kernel(const float* __restrict__
 
 // Column pass, OpenCV SymmColumnFilter: centre tap, then ky[c+k]*(S[+k] +/- S[-k]).
 __global__ __launch_bounds__(HT) void sobel_col_kernel(const double* __restrict__ buf, int h, int w,
-                                                        const double* __restrict__ ky, int ksize, int symmetric,
+                                                        const SobelTaps ky, int ksize, int symmetric,
                                                         double* __restrict__ out) {
     const long hw = (long)h * w;
     const double* src = buf + (size_t)blockIdx.y * hw;
@@ -107,11 +159,11 @@ __global__ __launch_bounds__(HT) void sobel_col_kernel(const double* __restrict_
     const int c = ksize / 2;
     for (long i = (long)blockIdx.x * HT + threadIdx.x; i < hw; i += (long)gridDim.x * HT) {
         const int y = (int)(i / w), x = (int)(i - (long)y * w);
-        double acc = symmetric ? (ky[c] * src[i] + 0.0) : 0.0;
+        double acc = symmetric ? (ky.v[c] * src[i] + 0.0) : 0.0;
         for (int k = 1; k <= c; ++k) {
             const double up = src[(long)reflect101(y + k, h) * w + x];
             const double dn = src[(long)reflect101(y - k, h) * w + x];
-            acc = acc + ky[c + k] * (symmetric ? (up + dn) : (up - dn));
+            acc = acc + ky.v[c + k] * (symmetric ? (up + dn) : (up - dn));
         }
         dst[i] = acc;
     }
@@ -169,45 +221,82 @@ __device__ __forceinline__ bool heap_smaller(const HeapItem& a, const HeapItem& 
     if (a.value != b.value) return a.value < b.value;
     return a.age < b.age;
 }
+// One lane owns one heap.  Nodes 0..HEAP_LDS-1 (the top six levels, where every sift passes) live in LDS,
+// lane-interleaved; deeper nodes in the lane's global segment.  A nucleus-sized blob's frontier rarely
+// exceeds 63 entries, so the sifts are LDS-latency bound instead of L2-latency bound.
+constexpr int HEAP_LDS = 63;
+struct LaneHeap {
+    double (*val)[64];
+    int (*age)[64];
+    int (*idx)[64];
+    HeapItem* glob;
+    int lane;
+    __device__ __forceinline__ HeapItem get(int i) const {
+        if (i < HEAP_LDS) {
+            HeapItem e;
+            e.value = val[i][lane];
+            e.age = age[i][lane];
+            e.index = idx[i][lane];
+            return e;
+        }
+        return glob[i];
+    }
+    __device__ __forceinline__ void put(int i, const HeapItem& e) const {
+        if (i < HEAP_LDS) {
+            val[i][lane] = e.value;
+            age[i][lane] = e.age;
+            idx[i][lane] = e.index;
+        } else {
+            glob[i] = e;
+        }
+    }
+};
 // skimage heap_general.pxi: push = append + sift towards the root
-__device__ __forceinline__ void heap_push(HeapItem* __restrict__ hp, int& items, const HeapItem& e) {
+__device__ __forceinline__ void heap_push(const LaneHeap& hp, int& items, const HeapItem& e) {
     int pos = items++;
-    hp[pos] = e;
     while (pos > 0) {
         const int parent = (pos - 1) >> 1;
-        const HeapItem p = hp[parent];
+        const HeapItem p = hp.get(parent);
         if (!heap_smaller(e, p)) break;
-        hp[pos] = p;
+        hp.put(pos, p);
         pos = parent;
     }
-    hp[pos] = e;
+    hp.put(pos, e);
 }
 // pop = take root, move the last item to the root, bubble the smaller child up to a leaf, sift back
-__device__ __forceinline__ HeapItem heap_pop(HeapItem* __restrict__ hp, int& items) {
-    const HeapItem top = hp[0];
+__device__ __forceinline__ HeapItem heap_pop(const LaneHeap& hp, int& items) {
+    const HeapItem top = hp.get(0);
     --items;
     if (items == 0) return top;
-    const HeapItem last = hp[items];
+    const HeapItem last = hp.get(items);
     int pos = 0, child = 1;
     while (child < items) {
         const int right = child + 1;
-        if (right < items && !heap_smaller(hp[child], hp[right])) child = right;
-        hp[pos] = hp[child];
+        HeapItem c = hp.get(child);
+        if (right < items) {
+            const HeapItem r = hp.get(right);
+            if (!heap_smaller(c, r)) {
+                child = right;
+                c = r;
+            }
+        }
+        hp.put(pos, c);
         pos = child;
         child = 2 * pos + 1;
     }
     while (pos > 0) {
         const int parent = (pos - 1) >> 1;
-        const HeapItem p = hp[parent];
+        const HeapItem p = hp.get(parent);
         if (!heap_smaller(last, p)) break;
-        hp[pos] = p;
+        hp.put(pos, p);
         pos = parent;
     }
-    hp[pos] = last;
+    hp.put(pos, last);
     return top;
 }
 
-// inst = where(mask, markers, 0); blob bounding boxes
+// inst = where(mask, markers, 0) with mask pixels still to be flooded marked -1 (so the flood needs a single
+// load per neighbour; every -1 is gone when the flood ends); blob bounding boxes
 __global__ __launch_bounds__(HT) void ws_init_kernel(const int* __restrict__ blob, const int* __restrict__ marker, int h, int w,
                                                       int* __restrict__ inst, int* __restrict__ bbox) {
     const long hw = (long)h * w;
@@ -215,7 +304,8 @@ __global__ __launch_bounds__(HT) void ws_init_kernel(const int* __restrict__ blo
     int* bb = bbox + (size_t)blockIdx.y * (hw + 1) * 4;
     for (long i = (long)blockIdx.x * HT + threadIdx.x; i < hw; i += (long)gridDim.x * HT) {
         const int b = blob[off + i];
-        inst[off + i] = b > 0 ? marker[off + i] : 0;
+        const int mk = b > 0 ? marker[off + i] : 0;
+        inst[off + i] = b > 0 ? (mk > 0 ? mk : -1) : 0;
         if (b > 0) {
             const int y = (int)(i / w), x = (int)(i - (long)y * w);
             atomicMin(&bb[b * 4 + 0], y);
@@ -260,6 +350,9 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
                                                        const int* __restrict__ areas, const int* __restrict__ offs,
                                                        const int* __restrict__ count, const int* __restrict__ bbox, int h, int w,
                                                        int min_keep, HeapItem* __restrict__ heaps, int* __restrict__ inst) {
+    __shared__ double s_val[HEAP_LDS][64];
+    __shared__ int s_age[HEAP_LDS][64];
+    __shared__ int s_idx[HEAP_LDS][64];
     const long hw = (long)h * w;
     const int plane = blockIdx.y;
     const int label = blockIdx.x * 64 + threadIdx.x + 1;
@@ -270,7 +363,7 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
     const int* bl = blob + off;
     const double* ds = dist + off;
     int* out = inst + off;
-    HeapItem* hp = heaps + off + offs[(size_t)plane * (hw + 1) + label];
+    const LaneHeap hp{s_val, s_age, s_idx, heaps + off + offs[(size_t)plane * (hw + 1) + label], (int)threadIdx.x};
     const int* bb = bbox + ((size_t)plane * (hw + 1) + label) * 4;
     const int y0 = bb[0], y1 = bb[1], x0 = bb[2], x1 = bb[3];
     int items = 0, age = 0;
@@ -278,7 +371,7 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
     for (int y = y0; y <= y1; ++y) {
         for (int x = x0; x <= x1; ++x) {
             const long i = (long)y * w + x;
-            if (bl[i] == label && out[i] != 0) {
+            if (bl[i] == label && out[i] > 0) {
                 HeapItem e;
                 e.value = ds[i];
                 e.age = 0;
@@ -287,24 +380,42 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
             }
         }
     }
+    if (items == 0) {  // a blob without markers stays background
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                const long i = (long)y * w + x;
+                if (bl[i] == label) out[i] = 0;
+            }
+        return;
+    }
     while (items > 0) {
         const HeapItem e = heap_pop(hp, items);
         const int lab = out[e.index];
         const int y = e.index / w, x = e.index - y * w;
-        // neighbour order of skimage's raveled offsets for connectivity 1: up, left, right, down
+        // neighbour order of skimage's raveled offsets for connectivity 1: up, left, right, down.
+        // The four neighbours are distinct pixels only this lane can change: fetch state and value of all
+        // of them before acting, so one memory latency covers the whole step.
+        long ni[4];
+        int state[4];
+        double dv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int yy = y + (j == 0 ? -1 : (j == 3 ? 1 : 0));
             const int xx = x + (j == 1 ? -1 : (j == 2 ? 1 : 0));
-            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
-            const long ni = (long)yy * w + xx;
-            if (bl[ni] <= 0 || out[ni] != 0) continue;
+            const bool inb = yy >= 0 && yy < h && xx >= 0 && xx < w;
+            ni[j] = inb ? (long)yy * w + xx : (long)e.index;
+            state[j] = inb ? out[ni[j]] : 0;
+            dv[j] = ds[ni[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (state[j] != -1) continue;  // outside the mask, or labelled already
             ++age;
-            out[ni] = lab;
+            out[ni[j]] = lab;
             HeapItem ne;
-            ne.value = ds[ni];
+            ne.value = dv[j];
             ne.age = age;
-            ne.index = (int)ni;
+            ne.index = (int)ni[j];
             heap_push(hp, items, ne);
         }
     }
@@ -319,6 +430,8 @@ __global__ __launch_bounds__(HT) void inst_stats_init_kernel(long long* __restri
         stats[i * 8 + 4] = -1;
     }
 }
+// Runs of equal (id, type) along a row are merged across the lanes of a wave (ballot), so the atomics are
+// issued once per run instead of once per pixel.
 __global__ __launch_bounds__(HT) void inst_stats_kernel(const int* __restrict__ inst, const uint8_t* __restrict__ type, int h, int w,
                                                          int max_inst, int num_types, long long* __restrict__ stats,
                                                          int* __restrict__ types) {
@@ -326,28 +439,33 @@ __global__ __launch_bounds__(HT) void inst_stats_kernel(const int* __restrict__ 
     const size_t off = (size_t)blockIdx.y * hw;
     long long* st = stats + (size_t)blockIdx.y * (max_inst + 1) * 8;
     int* ty = types ? types + (size_t)blockIdx.y * (max_inst + 1) * num_types : nullptr;
-    for (long i = (long)blockIdx.x * HT + threadIdx.x; i < hw; i += (long)gridDim.x * HT) {
-        const int id = inst[off + i];
-        if (id <= 0 || id > max_inst) continue;
+    const int lane = lane_id();
+    for (long base = (long)blockIdx.x * HT; base < hw; base += (long)gridDim.x * HT) {  // uniform trip count
+        const long i = base + threadIdx.x;
+        int id = i < hw ? inst[off + i] : 0;
+        if (id < 0 || id > max_inst) id = 0;
+        const int t = (ty && type && id > 0) ? (int)type[off + i] : 0;
         const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        const int pid = __shfl_up(id, 1), pt = __shfl_up(t, 1);
+        const bool head = lane == 0 || id != pid || t != pt || x == 0;
+        const unsigned long long heads = __ballot(head);
+        if (!head || id == 0) continue;
+        const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+        const long long len = (above ? __builtin_ctzll(above) : 64) - lane;
         long long* s = st + (size_t)id * 8;
-        atomicAdd((unsigned long long*)&s[0], 1ull);
+        atomicAdd((unsigned long long*)&s[0], (unsigned long long)len);
         atomicMin(&s[1], (long long)x);
         atomicMin(&s[2], (long long)y);
-        atomicMax(&s[3], (long long)x);
+        atomicMax(&s[3], (long long)x + len - 1);
         atomicMax(&s[4], (long long)y);
-        atomicAdd((unsigned long long*)&s[5], (unsigned long long)x);
-        atomicAdd((unsigned long long*)&s[6], (unsigned long long)y);
-        if (ty && type) {
-            const int t = type[off + i];
-            if (t < num_types) atomicAdd(&ty[(size_t)id * num_types + t], 1);
-        }
+        atomicAdd((unsigned long long*)&s[5], (unsigned long long)(len * x + len * (len - 1) / 2));
+        atomicAdd((unsigned long long*)&s[6], (unsigned long long)(len * y));
+        if (ty && type && t < num_types) atomicAdd(&ty[(size_t)id * num_types + t], (int)len);
     }
 }
 
-__global__ void sobel_taps_kernel(double* __restrict__ kd, double* __restrict__ ks, int ksize) {
-    // getSobelKernels: order-1 (derivative) and order-0 (smoothing) integer taps, exact in f64
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// getSobelKernels (OpenCV deriv.cpp): order-1 (derivative) and order-0 (smoothing) integer taps
+static void sobel_taps_host(int ksize, SobelTaps& kd, SobelTaps& ks) {
     for (int order = 0; order < 2; ++order) {
         long long ker[64];
         for (int i = 0; i <= ksize; ++i) ker[i] = 0;
@@ -368,8 +486,8 @@ __global__ void sobel_taps_kernel(double* __restrict__ kd, double* __restrict__ 
                 oldval = newval;
             }
         }
-        double* dst = order ? kd : ks;
-        for (int i = 0; i < ksize; ++i) dst[i] = (double)ker[i];
+        SobelTaps& dst = order ? kd : ks;
+        for (int i = 0; i < 32; ++i) dst.v[i] = i < ksize ? (double)ker[i] : 0.0;
     }
 }
 
@@ -445,7 +563,6 @@ extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, in
     double* dist = (double*)(base + L.dist);
     HeapItem* heaps = (HeapItem*)(base + L.heaps);
     double* mm = (double*)(base + L.mm);  // [4][n][2]: h raw, v raw, sobel h, sobel v
-    double* taps = (double*)(base + L.taps);
     int* se_offs = (int*)(base + L.se_offs);
     int* areas = ws_int;  // tia_label_area_filter_i32 leaves the per-label areas here
 
@@ -465,17 +582,16 @@ extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, in
     if (hipMemcpyAsync(areas_keep, areas, (size_t)n * (hw + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return TIA_ELAUNCH;
 
     // 2. Sobel of the normalised h / v maps
-    hipLaunchKernelGGL(sobel_taps_kernel, dim3(1), dim3(64), 0, st, taps, taps + 64, ksize);
-    hipLaunchKernelGGL(minmax_kernel<float>, dim3((unsigned)n), dim3(1024), 0, st, d_hv, hw, 2, 0, mm);
-    hipLaunchKernelGGL(minmax_kernel<float>, dim3((unsigned)n), dim3(1024), 0, st, d_hv, hw, 2, 1, mm + 2 * n);
+    SobelTaps kd, ks;
+    sobel_taps_host(ksize, kd, ks);
+    hipLaunchKernelGGL(minmax_hv_kernel, dim3((unsigned)n), dim3(1024), 0, st, d_hv, hw, mm, mm + 2 * n);
     // h: dx=1 -> kx = derivative taps, ky = smoothing taps (symmetric column filter)
-    hipLaunchKernelGGL(sobel_row_kernel, grid, dim3(HT), 0, st, d_hv, 0, (int)h, (int)w, mm, taps, ksize, rowbuf);
-    hipLaunchKernelGGL(sobel_col_kernel, grid, dim3(HT), 0, st, rowbuf, (int)h, (int)w, taps + 64, ksize, 1, sob_h);
+    hipLaunchKernelGGL(sobel_row_kernel, grid, dim3(HT), 0, st, d_hv, 0, (int)h, (int)w, mm, kd, ksize, rowbuf);
+    hipLaunchKernelGGL(sobel_col_kernel, grid, dim3(HT), 0, st, rowbuf, (int)h, (int)w, ks, ksize, 1, sob_h);
     // v: dy=1 -> kx = smoothing taps, ky = derivative taps (antisymmetric column filter)
-    hipLaunchKernelGGL(sobel_row_kernel, grid, dim3(HT), 0, st, d_hv, 1, (int)h, (int)w, mm + 2 * n, taps + 64, ksize, rowbuf);
-    hipLaunchKernelGGL(sobel_col_kernel, grid, dim3(HT), 0, st, rowbuf, (int)h, (int)w, taps, ksize, 0, sob_v);
-    hipLaunchKernelGGL(minmax_kernel<double>, dim3((unsigned)n), dim3(1024), 0, st, sob_h, hw, 1, 0, mm + 4 * n);
-    hipLaunchKernelGGL(minmax_kernel<double>, dim3((unsigned)n), dim3(1024), 0, st, sob_v, hw, 1, 0, mm + 6 * n);
+    hipLaunchKernelGGL(sobel_row_kernel, grid, dim3(HT), 0, st, d_hv, 1, (int)h, (int)w, mm + 2 * n, ks, ksize, rowbuf);
+    hipLaunchKernelGGL(sobel_col_kernel, grid, dim3(HT), 0, st, rowbuf, (int)h, (int)w, kd, ksize, 0, sob_v);
+    hipLaunchKernelGGL(minmax_pair_kernel, dim3((unsigned)n), dim3(1024), 0, st, sob_h, sob_v, hw, mm + 4 * n, mm + 6 * n);
 
     // 3. energy, marker seed
     hipLaunchKernelGGL(energy_kernel, grid, dim3(HT), 0, st, sob_h, sob_v, mm + 4 * n, mm + 6 * n, blob_lab, hw, dist0, tmp_a);

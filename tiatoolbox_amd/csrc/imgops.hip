@@ -136,23 +136,52 @@ __global__ __launch_bounds__(BT) void ccl_flatten_kernel(int* __restrict__ L, lo
 
 // One workgroup per plane: rank the roots (pixels with L[i]==i) in raster order.
 // rank[root] = 1-based component number; count[plane] = number of components.
+// The plane is swept in coalesced 4096-pixel tiles (4 consecutive pixels per lane) with a running
+// total; wave scan + per-wave totals in LDS (double-buffered: one barrier per tile).
 __global__ __launch_bounds__(1024) void ccl_rank_kernel(const int* __restrict__ L, long hw, int* __restrict__ rank,
                                                          int* __restrict__ count) {
-    __shared__ unsigned wtot[16];
+    __shared__ unsigned wtot[2][16];
     const int* l = L + (size_t)blockIdx.x * hw;
     int* r = rank + (size_t)blockIdx.x * hw;
-    const long chunk = (hw + 1023) / 1024;
-    const long lo = (long)threadIdx.x * chunk, hi = lo + chunk < hw ? lo + chunk : hw;
-    unsigned c = 0;
-    for (long i = lo; i < hi; ++i) c += (l[i] == (int)i) ? 1u : 0u;
-    const unsigned incl = wave_incl_scan_u32(c);
-    if (lane_id() == 63) wtot[wave_id()] = incl;
-    __syncthreads();
-    unsigned before = incl - c;
-    for (int wv = 0; wv < wave_id(); ++wv) before += wtot[wv];
-    for (long i = lo; i < hi; ++i)
-        if (l[i] == (int)i) r[i] = (int)(++before);
-    if (threadIdx.x == 1023) count[blockIdx.x] = (int)before;
+    const bool vec = (hw & 3) == 0;  // plane base and every tile offset are then 16-byte aligned
+    const int t = threadIdx.x, wv = wave_id();
+    unsigned running = 0;
+    int buf = 0;
+    for (long base = 0; base < hw; base += 4096, buf ^= 1) {
+        const long i0 = base + 4L * t;
+        int v[4] = {-1, -1, -1, -1};
+        if (vec) {
+            if (i0 < hw) {
+                const int4 q = *reinterpret_cast<const int4*>(l + i0);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k < hw) v[k] = l[i0 + k];
+        }
+        unsigned f[4], c = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[k] = (v[k] == (int)(i0 + k)) ? 1u : 0u;
+            c += f[k];
+        }
+        const unsigned incl = wave_incl_scan_u32(c);
+        if (lane_id() == 63) wtot[buf][wv] = incl;
+        __syncthreads();
+        unsigned before = running + incl - c, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned x = wtot[buf][q];
+            before += q < wv ? x : 0u;
+            tot += x;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (f[k]) r[i0 + k] = (int)(++before);
+        running += tot;
+    }
+    if (t == 0) count[blockIdx.x] = (int)running;
 }
 
 __global__ __launch_bounds__(BT) void ccl_apply_rank_kernel(const int* __restrict__ L, const int* __restrict__ rank,
@@ -184,12 +213,44 @@ static int ccl_run(const uint8_t* d_mask, long n, int h, int w, int conn, int* d
 }
 
 // ---- label areas -----------------------------------------------------------------------------------------
+// Areas by run aggregation: a lane holds 4 consecutive pixels; lanes whose 4 pixels carry one label merge
+// with their neighbours through a ballot (one atomic per run of lanes instead of one per pixel -- large
+// components would otherwise serialise millions of atomics on one address).
 __global__ __launch_bounds__(BT) void area_count_kernel(const int* __restrict__ labels, long hw, int* __restrict__ areas) {
-    const size_t off = (size_t)blockIdx.y * hw;
+    const int* lb = labels + (size_t)blockIdx.y * hw;
     int* a = areas + (size_t)blockIdx.y * (hw + 1);
-    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
-        const int l = labels[off + i];
-        if (l > 0) atomicAdd(&a[l], 1);
+    const bool vec = (hw & 3) == 0;
+    const int lane = lane_id();
+    const long stride = (long)gridDim.x * BT * 4;
+    for (long base = (long)blockIdx.x * BT * 4; base < hw; base += stride) {  // uniform trip count per block
+        const long i0 = base + 4L * threadIdx.x;
+        int v[4] = {0, 0, 0, 0};
+        if (vec) {
+            if (i0 < hw) {
+                const int4 q = *reinterpret_cast<const int4*>(lb + i0);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k < hw) v[k] = lb[i0 + k];
+        }
+        const bool uniform = v[0] == v[1] && v[1] == v[2] && v[2] == v[3];
+        const int key = uniform ? v[0] : -1;
+        const int prev = __shfl_up(key, 1);
+        const bool head = lane == 0 || key != prev || key < 0;
+        const unsigned long long heads = __ballot(head);
+        if (uniform) {
+            if (head && key > 0) {
+                const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+                const int next = above ? __builtin_ctzll(above) : 64;
+                atomicAdd(&a[key], 4 * (next - lane));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v[k] > 0) atomicAdd(&a[v[k]], 1);
+        }
     }
 }
 __global__ __launch_bounds__(BT) void area_filter_kernel(int* __restrict__ labels, long hw, const int* __restrict__ areas,

@@ -3,6 +3,8 @@
 // cv2.meanStdDev).  Per pixel everything is integer table look-ups + integer MACs: HBM-bound.
 #include "common.hpp"
 
+#pragma clang fp contract(off)  // the LUT arithmetic restates NumPy float32/float64 expressions term by term
+
 namespace tia {
 
 constexpr int LT = 256;
@@ -126,6 +128,69 @@ __global__ __launch_bounds__(LT) void reinhard_apply_kernel(const uint8_t* __res
     }
 }
 
+// Per-image statistics and look-up tables of ReinhardNormalizer.transform (stainnorm.py:277-292, 336-339) from
+// the Lab byte histograms: cv2.meanStdDev of the float32 channels == moments of 256 weighted values (f64,
+// summed in NumPy's pairwise order for 256 elements so host and device agree to the bit), then the float32
+// chain ((chan - mean) * (t_std / std) + t_mean), back to Lab bytes (x2.55 or +128, clip, truncate).
+struct ReinhardTarget {
+    double mean[3];
+    double stdv[3];
+};
+__device__ __forceinline__ double np_pairwise_256(const double* __restrict__ a) {
+    double total = 0.0;
+    for (int half = 0; half < 2; ++half) {
+        const double* p = a + half * 128;
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = p[j];
+        for (int i = 8; i < 128; i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += p[i + j];
+        const double part = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        total = half == 0 ? part : total + part;
+    }
+    return total;
+}
+__global__ __launch_bounds__(256) void reinhard_lut_kernel(const uint32_t* __restrict__ hist, const float* __restrict__ chan_vals,
+                                                           const ReinhardTarget tgt, uint8_t* __restrict__ lut,
+                                                           double* __restrict__ meanstd, int* __restrict__ flags) {
+    __shared__ double prod[3][2][256];
+    __shared__ double stat[3][2];  // mean, std
+    const uint32_t* hs = hist + (size_t)blockIdx.x * 768;
+    const int v = threadIdx.x;
+    for (int c = 0; c < 3; ++c) {
+        const double val = (double)chan_vals[c * 256 + v];
+        const double hv = (double)hs[c * 256 + v] * val;
+        prod[c][0][v] = hv;
+        prod[c][1][v] = hv * val;
+    }
+    __syncthreads();
+    if (v < 3) {
+        long long cnt = 0;
+        for (int i = 0; i < 256; ++i) cnt += hs[v * 256 + i];
+        const double n = (double)cnt;
+        const double mean = np_pairwise_256(prod[v][0]) / n;
+        double var = np_pairwise_256(prod[v][1]) / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double sd = sqrt(var);
+        stat[v][0] = mean;
+        stat[v][1] = sd;
+        if (meanstd) {
+            meanstd[(size_t)blockIdx.x * 6 + v] = mean;
+            meanstd[(size_t)blockIdx.x * 6 + 3 + v] = sd;
+        }
+        if (flags && sd == 0.0) atomicOr(&flags[blockIdx.x], 1);
+    }
+    __syncthreads();
+    for (int c = 0; c < 3; ++c) {
+        const float mean32 = (float)stat[c][0];
+        const float ratio32 = (float)(tgt.stdv[c] / stat[c][1]);
+        const float tmean32 = (float)tgt.mean[c];
+        float norm = (chan_vals[c * 256 + v] - mean32) * ratio32 + tmean32;
+        norm = c == 0 ? norm * 2.55f : norm + 128.0f;
+        norm = norm < 0.0f ? 0.0f : (norm > 255.0f ? 255.0f : norm);  // NaN (std == 0) falls through; flagged above
+        lut[(size_t)blockIdx.x * 768 + c * 256 + v] = (uint8_t)(int)norm;
+    }
+}
+
 __global__ __launch_bounds__(LT) void lab_convert_kernel(const uint8_t* __restrict__ src, long npix, const tia_lab_tables* __restrict__ tab,
                                                           int dir, uint8_t* __restrict__ dst) {
     __shared__ LabLds s;
@@ -168,6 +233,20 @@ extern "C" int tia_reinhard_apply_u8(const uint8_t* d_img, int64_t n, int64_t h,
     const long hw = (long)h * w;
     hipLaunchKernelGGL(reinhard_apply_kernel, dim3(lab_blocks(hw >> 2 ? hw >> 2 : 1, n), (unsigned)n), dim3(LT), 0,
                        (hipStream_t)stream, d_img, hw, d_tables, d_lut, d_out);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_reinhard_luts(const uint32_t* d_hist, int64_t n, const float* d_chan_vals, const double* target_means,
+                                 const double* target_stds, uint8_t* d_lut, double* d_meanstd, int32_t* d_flags,
+                                 void* stream) {
+    if (!d_hist || !d_chan_vals || !target_means || !target_stds || !d_lut || n <= 0 || n > 2147483647LL) return TIA_EINVAL;
+    ReinhardTarget t;
+    for (int c = 0; c < 3; ++c) {
+        t.mean[c] = target_means[c];
+        t.stdv[c] = target_stds[c];
+    }
+    hipLaunchKernelGGL(reinhard_lut_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, d_hist, d_chan_vals, t, d_lut,
+                       d_meanstd, d_flags);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 

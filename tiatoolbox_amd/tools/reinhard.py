@@ -60,6 +60,16 @@ def _channel_values() -> np.ndarray:
     return np.stack([c1, c2, c2.copy()])
 
 
+_CHAN_DEV: dict[int, torch.Tensor] = {}
+
+
+def _channel_values_device(device: torch.device) -> torch.Tensor:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _CHAN_DEV:
+        _CHAN_DEV[idx] = torch.from_numpy(np.ascontiguousarray(_channel_values())).to(torch.device("cuda", idx))
+    return _CHAN_DEV[idx]
+
+
 class ReinhardNormalizer(StainNormalizer):
     """Reinhard colour normaliser (ref. :222-367)."""
 
@@ -93,17 +103,19 @@ class ReinhardNormalizer(StainNormalizer):
     def _luts(self, means: np.ndarray, stds: np.ndarray) -> np.ndarray:
         """Per-image 3x256 uint8 tables: the reference's float32 chain (:283-292, 336-339) per Lab byte."""
         chan = _channel_values()                                  # float32 [3,256]
-        luts = np.empty((means.shape[0], 3, 256), dtype=np.uint8)
-        for i in range(means.shape[0]):
-            for c in range(3):
-                norm = ((chan[c] - float(means[i, c])) * (self.target_stds[c] / float(stds[i, c]))) + self.target_means[c]
-                if c == 0:
-                    norm *= 2.55
-                else:
-                    norm += 128.0
-                with np.errstate(invalid="ignore"):
-                    luts[i, c] = np.clip(norm, 0, 255).astype(np.uint8)
-        return luts
+        if np.any(stds == 0):
+            msg = "float division by zero"                        # the reference divides Python floats (:281-290)
+            raise ZeroDivisionError(msg)
+        # Python-float scalars meet float32 arrays: each scalar is rounded to float32, the ops are float32
+        f32 = np.float32
+        mean32 = means.astype(f32)[..., None]
+        ratio32 = (np.asarray(self.target_stds, dtype=np.float64)[None] / stds).astype(f32)[..., None]
+        tmean32 = np.asarray(self.target_means, dtype=np.float64).astype(f32)[None, :, None]
+        norm = (chan[None] - mean32) * ratio32 + tmean32
+        norm[:, 0] *= f32(2.55)
+        norm[:, 1:] += f32(128.0)
+        with np.errstate(invalid="ignore"):
+            return np.clip(norm, 0, 255).astype(np.uint8)
 
     # ------------------------------------------------------------------------------------- API
     @staticmethod
@@ -135,15 +147,32 @@ class ReinhardNormalizer(StainNormalizer):
         self.target_means, self.target_stds = self.get_mean_std(target)
 
     def transform(self, img):
+        """Histogram -> per-image LUTs -> fused RGB->Lab->LUT->RGB apply: three launches, no host round trip."""
         batch, kind = _tensors.to_device_batch(img)
-        means, stds = self._mean_std(self._lab_hist(batch))
-        luts = torch.from_numpy(self._luts(means, stds)).to(batch.device)
-        out = torch.empty_like(batch)
         n, h, w, _ = batch.shape
-        with torch.cuda.device(batch.device):
+        dev = batch.device
+        hist = torch.zeros((n, 3, 256), dtype=torch.int32, device=dev)
+        luts = torch.empty((n, 3, 256), dtype=torch.uint8, device=dev)
+        flags = torch.zeros(n, dtype=torch.int32, device=dev)
+        out = torch.empty_like(batch)
+        tmeans = (C.c_double * 3)(*[float(v) for v in self.target_means])
+        tstds = (C.c_double * 3)(*[float(v) for v in self.target_stds])
+        lib = _lib.load()
+        tabs = lab_tables(dev).data_ptr()
+        with torch.cuda.device(dev):
             for s in range(0, n, 65535):
                 m = min(65535, n - s)
-                rc = _lib.load().tia_reinhard_apply_u8(batch[s:s + m].data_ptr(), m, h, w, lab_tables(batch.device).data_ptr(),
-                                                       luts[s:s + m].data_ptr(), out[s:s + m].data_ptr(), _lib.current_stream())
+                rc = lib.tia_lab_hist_u8(batch[s:s + m].data_ptr(), m, h, w, tabs, hist[s:s + m].data_ptr(), _lib.current_stream())
+                _lib.check(rc, "tia_lab_hist_u8")
+            rc = lib.tia_reinhard_luts(hist.data_ptr(), n, _channel_values_device(dev).data_ptr(), tmeans, tstds,
+                                       luts.data_ptr(), 0, flags.data_ptr(), _lib.current_stream())
+            _lib.check(rc, "tia_reinhard_luts")
+            for s in range(0, n, 65535):
+                m = min(65535, n - s)
+                rc = lib.tia_reinhard_apply_u8(batch[s:s + m].data_ptr(), m, h, w, tabs, luts[s:s + m].data_ptr(),
+                                               out[s:s + m].data_ptr(), _lib.current_stream())
                 _lib.check(rc, "tia_reinhard_apply_u8")
+        if bool(flags.any()):
+            msg = "float division by zero"  # the reference divides Python floats (stainnorm.py:281-290)
+            raise ZeroDivisionError(msg)
         return _tensors.from_device(out, kind)
