@@ -99,7 +99,7 @@ def test_hip_reinhard_device_luts_match_host_arithmetic():
     for i in range(n):
         for c in range(3):
             lo, hi = sorted(rng.integers(0, 256, 2))
-            hi = max(hi, lo + 2)
+            lo, hi = min(lo, 253), min(max(hi, lo + 2), 256)
             vals = rng.integers(lo, hi, rng.integers(50, 60000))
             hist[i, c] = np.bincount(vals, minlength=256)
     norm = rh.ReinhardNormalizer()

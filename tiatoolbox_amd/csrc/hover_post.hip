@@ -3,6 +3,8 @@
 // priority flood run independently per connected mask blob (the global skimage heap restricted
 // to one blob pops in the same order as a private heap, because a blob's entries are only ever
 // inserted by pops of that blob), one lane per blob with its heap segment in global memory.
+#include <cstdlib>
+
 #include "common.hpp"
 
 #pragma clang fp contract(off)  // OpenCV/NumPy evaluate these expressions without contraction
@@ -222,78 +224,13 @@ __device__ __forceinline__ bool heap_smaller(const HeapItem& a, const HeapItem& 
     return a.age < b.age;
 }
 // One lane owns one heap.  Nodes 0..HEAP_LDS-1 (the top six levels, where every sift passes) live in LDS,
-// lane-interleaved; deeper nodes in the lane's global segment.  A nucleus-sized blob's frontier rarely
-// exceeds 63 entries, so the sifts are LDS-latency bound instead of L2-latency bound.
-constexpr int HEAP_LDS = 63;
-struct LaneHeap {
-    double (*val)[64];
-    int (*age)[64];
-    int (*idx)[64];
-    HeapItem* glob;
-    int lane;
-    __device__ __forceinline__ HeapItem get(int i) const {
-        if (i < HEAP_LDS) {
-            HeapItem e;
-            e.value = val[i][lane];
-            e.age = age[i][lane];
-            e.index = idx[i][lane];
-            return e;
-        }
-        return glob[i];
-    }
-    __device__ __forceinline__ void put(int i, const HeapItem& e) const {
-        if (i < HEAP_LDS) {
-            val[i][lane] = e.value;
-            age[i][lane] = e.age;
-            idx[i][lane] = e.index;
-        } else {
-            glob[i] = e;
-        }
-    }
-};
-// skimage heap_general.pxi: push = append + sift towards the root
-__device__ __forceinline__ void heap_push(const LaneHeap& hp, int& items, const HeapItem& e) {
-    int pos = items++;
-    while (pos > 0) {
-        const int parent = (pos - 1) >> 1;
-        const HeapItem p = hp.get(parent);
-        if (!heap_smaller(e, p)) break;
-        hp.put(pos, p);
-        pos = parent;
-    }
-    hp.put(pos, e);
-}
-// pop = take root, move the last item to the root, bubble the smaller child up to a leaf, sift back
-__device__ __forceinline__ HeapItem heap_pop(const LaneHeap& hp, int& items) {
-    const HeapItem top = hp.get(0);
-    --items;
-    if (items == 0) return top;
-    const HeapItem last = hp.get(items);
-    int pos = 0, child = 1;
-    while (child < items) {
-        const int right = child + 1;
-        HeapItem c = hp.get(child);
-        if (right < items) {
-            const HeapItem r = hp.get(right);
-            if (!heap_smaller(c, r)) {
-                child = right;
-                c = r;
-            }
-        }
-        hp.put(pos, c);
-        pos = child;
-        child = 2 * pos + 1;
-    }
-    while (pos > 0) {
-        const int parent = (pos - 1) >> 1;
-        const HeapItem p = hp.get(parent);
-        if (!heap_smaller(last, p)) break;
-        hp.put(pos, p);
-        pos = parent;
-    }
-    hp.put(pos, last);
-    return top;
-}
+// lane-interleaved (one ds_read_b128 per node); deeper nodes in the lane's global segment.  A nucleus-sized
+// blob's frontier rarely exceeds 63 entries, so the sifts are LDS-latency bound instead of L2-latency bound.
+// The accessors are lambdas over the kernel's own __shared__ array so that the compiler keeps LDS
+// addressing (a pointer smuggled through a struct degrades to flat loads).
+// out of line on purpose: keeps the rare global path from being merged with the LDS path into flat accesses
+__device__ __noinline__ HeapItem heap_glob_get(const HeapItem* __restrict__ g, int i) { return g[i]; }
+__device__ __noinline__ void heap_glob_put(HeapItem* __restrict__ g, int i, const HeapItem& e) { g[i] = e; }
 
 // inst = where(mask, markers, 0) with mask pixels still to be flooded marked -1 (so the flood needs a single
 // load per neighbour; every -1 is gone when the flood ends); blob bounding boxes
@@ -302,16 +239,26 @@ __global__ __launch_bounds__(HT) void ws_init_kernel(const int* __restrict__ blo
     const long hw = (long)h * w;
     const size_t off = (size_t)blockIdx.y * hw;
     int* bb = bbox + (size_t)blockIdx.y * (hw + 1) * 4;
-    for (long i = (long)blockIdx.x * HT + threadIdx.x; i < hw; i += (long)gridDim.x * HT) {
-        const int b = blob[off + i];
-        const int mk = b > 0 ? marker[off + i] : 0;
-        inst[off + i] = b > 0 ? (mk > 0 ? mk : -1) : 0;
-        if (b > 0) {
-            const int y = (int)(i / w), x = (int)(i - (long)y * w);
+    const int lane = lane_id();
+    for (long base = (long)blockIdx.x * HT; base < hw; base += (long)gridDim.x * HT) {  // uniform trip count
+        const long i = base + threadIdx.x;
+        const int b = i < hw ? blob[off + i] : 0;
+        const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        if (i < hw) {
+            const int mk = b > 0 ? marker[off + i] : 0;
+            inst[off + i] = b > 0 ? (mk > 0 ? mk : -1) : 0;
+        }
+        // bounding boxes: one set of atomics per horizontal run of a blob within the wave
+        const int pb = __shfl_up(b, 1);
+        const bool head = lane == 0 || b != pb || x == 0;
+        const unsigned long long heads = __ballot(head);
+        if (head && b > 0) {
+            const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+            const int len = (above ? __builtin_ctzll(above) : 64) - lane;
             atomicMin(&bb[b * 4 + 0], y);
             atomicMax(&bb[b * 4 + 1], y);
             atomicMin(&bb[b * 4 + 2], x);
-            atomicMax(&bb[b * 4 + 3], x);
+            atomicMax(&bb[b * 4 + 3], x + len - 1);
         }
     }
 }
@@ -346,24 +293,85 @@ __global__ __launch_bounds__(1024) void ws_offsets_kernel(const int* __restrict_
     }
 }
 
+template <int HEAP_LDS>
 __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ blob, const double* __restrict__ dist,
                                                        const int* __restrict__ areas, const int* __restrict__ offs,
                                                        const int* __restrict__ count, const int* __restrict__ bbox, int h, int w,
                                                        int min_keep, HeapItem* __restrict__ heaps, int* __restrict__ inst) {
-    __shared__ double s_val[HEAP_LDS][64];
-    __shared__ int s_age[HEAP_LDS][64];
-    __shared__ int s_idx[HEAP_LDS][64];
+    __shared__ HeapItem s_heap[HEAP_LDS > 0 ? HEAP_LDS : 1][64];
+    const int lane = threadIdx.x;
     const long hw = (long)h * w;
     const int plane = blockIdx.y;
-    const int label = blockIdx.x * 64 + threadIdx.x + 1;
-    if (label > count[plane]) return;
+    // the grid is capped (every workgroup pins 63 KB of LDS): lanes stride over the plane's blob labels
+    for (int label = blockIdx.x * 64 + threadIdx.x + 1; label <= count[plane]; label += gridDim.x * 64) {
     const int area = areas[(size_t)plane * (hw + 1) + label];
-    if (area < min_keep) return;
+    if (area < min_keep) continue;
     const size_t off = (size_t)plane * hw;
     const int* bl = blob + off;
     const double* ds = dist + off;
     int* out = inst + off;
-    const LaneHeap hp{s_val, s_age, s_idx, heaps + off + offs[(size_t)plane * (hw + 1) + label], (int)threadIdx.x};
+    HeapItem* glob = heaps + off + offs[(size_t)plane * (hw + 1) + label];
+    auto HEAP_GET = [&](int i) -> HeapItem {
+        if constexpr (HEAP_LDS > 0) {
+            if (i < HEAP_LDS) return s_heap[i][lane];
+            return heap_glob_get(glob, i);
+        } else {
+            return glob[i];
+        }
+    };
+    auto HEAP_PUT = [&](int i, const HeapItem& e) {
+        if constexpr (HEAP_LDS > 0) {
+            if (i < HEAP_LDS)
+                s_heap[i][lane] = e;
+            else
+                heap_glob_put(glob, i, e);
+        } else {
+            glob[i] = e;
+        }
+    };
+    // skimage heap_general.pxi: push = append + sift towards the root
+    auto heap_push = [&](int& items, const HeapItem& e) {
+        int pos = items++;
+        while (pos > 0) {
+            const int parent = (pos - 1) >> 1;
+            const HeapItem p = HEAP_GET(parent);
+            if (!heap_smaller(e, p)) break;
+            HEAP_PUT(pos, p);
+            pos = parent;
+        }
+        HEAP_PUT(pos, e);
+    };
+    // pop = take root, move the last item to the root, bubble the smaller child up to a leaf, sift back
+    auto heap_pop = [&](int& items) {
+        const HeapItem top = HEAP_GET(0);
+        --items;
+        if (items == 0) return top;
+        const HeapItem last = HEAP_GET(items);
+        int pos = 0, child = 1;
+        while (child < items) {
+            const int right = child + 1;
+            HeapItem c = HEAP_GET(child);
+            if (right < items) {
+                const HeapItem r = HEAP_GET(right);
+                if (!heap_smaller(c, r)) {
+                    child = right;
+                    c = r;
+                }
+            }
+            HEAP_PUT(pos, c);
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        while (pos > 0) {
+            const int parent = (pos - 1) >> 1;
+            const HeapItem p = HEAP_GET(parent);
+            if (!heap_smaller(last, p)) break;
+            HEAP_PUT(pos, p);
+            pos = parent;
+        }
+        HEAP_PUT(pos, last);
+        return top;
+    };
     const int* bb = bbox + ((size_t)plane * (hw + 1) + label) * 4;
     const int y0 = bb[0], y1 = bb[1], x0 = bb[2], x1 = bb[3];
     int items = 0, age = 0;
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
                 e.value = ds[i];
                 e.age = 0;
                 e.index = (int)i;
-                heap_push(hp, items, e);
+                heap_push(items, e);
             }
         }
     }
@@ -386,10 +394,10 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
                 const long i = (long)y * w + x;
                 if (bl[i] == label) out[i] = 0;
             }
-        return;
+        continue;
     }
     while (items > 0) {
-        const HeapItem e = heap_pop(hp, items);
+        const HeapItem e = heap_pop(items);
         const int lab = out[e.index];
         const int y = e.index / w, x = e.index - y * w;
         // neighbour order of skimage's raveled offsets for connectivity 1: up, left, right, down.
@@ -416,9 +424,10 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
             ne.value = dv[j];
             ne.age = age;
             ne.index = (int)ni[j];
-            heap_push(hp, items, ne);
+            heap_push(items, ne);
         }
     }
+    }  // labels of this lane
 }
 
 // ---- instance statistics ----------------------------------------------------------------------------------------------
@@ -620,9 +629,21 @@ extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, in
     hipLaunchKernelGGL(gauss3_neg_kernel, grid, dim3(HT), 0, st, dist0, (int)h, (int)w, dist);
     hipLaunchKernelGGL(ws_init_kernel, grid, dim3(HT), 0, st, blob_lab, mark_lab, (int)h, (int)w, d_inst, bbox);
     const long max_labels = hw / 2 + 2;
-    dim3 fgrid((unsigned)((max_labels + 63) / 64), (unsigned)n);
-    hipLaunchKernelGGL(ws_flood_kernel, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w, 10,
-                       heaps, d_inst);
+    long fx = (max_labels + 63) / 64, fcap = 4096 / n > 4 ? 4096 / n : 4;
+    dim3 fgrid((unsigned)(fx < fcap ? fx : fcap), (unsigned)n);
+    static const int lds_nodes = [] {
+        const char* e = getenv("TIA_FLOOD_LDS");  // developer switch: 0 = heap entirely in global memory
+        return e ? atoi(e) : 63;
+    }();
+    if (lds_nodes >= 63)
+        hipLaunchKernelGGL(ws_flood_kernel<63>, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w,
+                           10, heaps, d_inst);
+    else if (lds_nodes >= 15)
+        hipLaunchKernelGGL(ws_flood_kernel<15>, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w,
+                           10, heaps, d_inst);
+    else
+        hipLaunchKernelGGL(ws_flood_kernel<0>, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w,
+                           10, heaps, d_inst);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 

@@ -69,7 +69,33 @@ __global__ __launch_bounds__(BT) void hist256_kernel(const uint8_t* __restrict__
 __global__ __launch_bounds__(BT) void threshold_lt_kernel(const uint8_t* __restrict__ src, long npix, int is_rgb,
                                                            int thr, uint8_t* __restrict__ mask) {
     const long stride = (long)gridDim.x * BT;
-    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < npix; i += stride) {
+    const bool fast = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(mask)) & 3) == 0;
+    long done = 0;
+    if (fast) {  // 4 pixels per lane: 3 (or 1) dword loads, 1 dword store
+        const long ng = npix >> 2;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(src);
+        uint32_t* o = reinterpret_cast<uint32_t*>(mask);
+        for (long g = (long)blockIdx.x * BT + threadIdx.x; g < ng; g += stride) {
+            uint32_t g0, g1, g2, g3;
+            if (is_rgb) {
+                const uint32_t a = q[g * 3], b = q[g * 3 + 1], c = q[g * 3 + 2];
+                g0 = gray_of(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
+                g1 = gray_of(a >> 24, b & 255u, (b >> 8) & 255u);
+                g2 = gray_of((b >> 16) & 255u, b >> 24, c & 255u);
+                g3 = gray_of((c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
+            } else {
+                const uint32_t a = q[g];
+                g0 = a & 255u;
+                g1 = (a >> 8) & 255u;
+                g2 = (a >> 16) & 255u;
+                g3 = a >> 24;
+            }
+            o[g] = ((int)g0 < thr ? 1u : 0u) | ((int)g1 < thr ? 1u << 8 : 0u) | ((int)g2 < thr ? 1u << 16 : 0u) |
+                   ((int)g3 < thr ? 1u << 24 : 0u);
+        }
+        done = ng * 4;
+    }
+    for (long i = done + (long)blockIdx.x * BT + threadIdx.x; i < npix; i += stride) {
         const int g = is_rgb ? (int)gray_of(src[3 * i], src[3 * i + 1], src[3 * i + 2]) : (int)src[i];
         mask[i] = g < thr ? 1 : 0;
     }
@@ -100,14 +126,33 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
     }
 }
 
+// Initial forest: every foreground pixel points at the first pixel of its horizontal run, cut at row starts
+// and at 64-pixel (wave) boundaries -- one ballot per wave, no memory traffic.  The merge pass then only
+// has to (a) re-join runs cut at a wave boundary and (b) hook vertically / diagonally adjacent runs once
+// per overlap, instead of issuing a union per pixel and neighbour.
 // INVERT: label the background (zero pixels) instead (used by fill-holes)
 template <bool INVERT>
-__global__ __launch_bounds__(BT) void ccl_init_kernel(const uint8_t* __restrict__ mask, long hw, int* __restrict__ L) {
+__global__ __launch_bounds__(BT) void ccl_init_kernel(const uint8_t* __restrict__ mask, long hw, int w, int* __restrict__ L) {
     const uint8_t* m = mask + (size_t)blockIdx.y * hw;
     int* l = L + (size_t)blockIdx.y * hw;
-    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
-        const bool fg = INVERT ? (m[i] == 0) : (m[i] != 0);
-        l[i] = fg ? (int)i : -1;
+    const int lane = lane_id();
+    const long stride = (long)gridDim.x * BT;
+    const long rounds = (hw + stride - 1) / stride;  // same trip count for every lane: the ballots need whole waves
+    for (long r = 0; r < rounds; ++r) {
+        const long i = r * stride + (long)blockIdx.x * BT + threadIdx.x;
+        const bool inb = i < hw;
+        const bool fg = inb && (INVERT ? (m[i] == 0) : (m[i] != 0));
+        const int x = inb ? (int)(i % w) : 0;
+        const bool prev_fg = __shfl_up((int)fg, 1) != 0;
+        const bool start = fg && (lane == 0 || x == 0 || !prev_fg);
+        const unsigned long long starts = __ballot(start);
+        if (!inb) continue;
+        if (fg) {
+            const unsigned long long below = starts & ((2ull << lane) - 1ull);  // a start exists at or below a fg lane
+            l[i] = (int)(i - lane + (63 - __builtin_clzll(below)));
+        } else {
+            l[i] = -1;
+        }
     }
 }
 
@@ -117,13 +162,17 @@ __global__ __launch_bounds__(BT) void ccl_merge_kernel(int* __restrict__ L, int 
     for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
         if (l[i] < 0) continue;
         const int y = (int)(i / w), x = (int)(i - (long)y * w);
-        if (x > 0 && l[i - 1] >= 0) uf_union(l, (int)i, (int)i - 1);
-        if (y > 0) {
-            if (l[i - w] >= 0) uf_union(l, (int)i, (int)(i - w));
-            if (conn8) {
-                if (x > 0 && l[i - w - 1] >= 0) uf_union(l, (int)i, (int)(i - w - 1));
-                if (x < w - 1 && l[i - w + 1] >= 0) uf_union(l, (int)i, (int)(i - w + 1));
-            }
+        const bool left = x > 0 && l[i - 1] >= 0;
+        if (left && (i & 63) == 0) uf_union(l, (int)i, (int)i - 1);  // run cut at a wave boundary by the init pass
+        if (y == 0) continue;
+        const bool up = l[i - w] >= 0;
+        const bool upleft = x > 0 && l[i - w - 1] >= 0;
+        if (up) {
+            // first column of the overlap between this run and the run above
+            if (!left || !upleft) uf_union(l, (int)i, (int)(i - w));
+        } else if (conn8) {
+            if (upleft && !left) uf_union(l, (int)i, (int)(i - w - 1));
+            if (x < w - 1 && l[i - w + 1] >= 0 && !(l[i + 1] >= 0)) uf_union(l, (int)i, (int)(i - w + 1));
         }
     }
 }
@@ -199,9 +248,9 @@ static int ccl_run(const uint8_t* d_mask, long n, int h, int w, int conn, int* d
     dim3 grid(nblocks(hw, BT, 4096), (unsigned)n);
     // d_labels doubles as the union-find array; d_ws holds the ranks
     if (invert)
-        hipLaunchKernelGGL(ccl_init_kernel<true>, grid, dim3(BT), 0, st, d_mask, hw, d_labels);
+        hipLaunchKernelGGL(ccl_init_kernel<true>, grid, dim3(BT), 0, st, d_mask, hw, w, d_labels);
     else
-        hipLaunchKernelGGL(ccl_init_kernel<false>, grid, dim3(BT), 0, st, d_mask, hw, d_labels);
+        hipLaunchKernelGGL(ccl_init_kernel<false>, grid, dim3(BT), 0, st, d_mask, hw, w, d_labels);
     hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(BT), 0, st, d_labels, h, w, conn == 8 ? 1 : 0);
     hipLaunchKernelGGL(ccl_flatten_kernel, grid, dim3(BT), 0, st, d_labels, hw);
     hipLaunchKernelGGL(ccl_rank_kernel, dim3((unsigned)n), dim3(1024), 0, st, d_labels, hw, d_ws, d_count);
