@@ -223,15 +223,9 @@ __device__ __forceinline__ bool heap_smaller(const HeapItem& a, const HeapItem& 
     if (a.value != b.value) return a.value < b.value;
     return a.age < b.age;
 }
-// One lane owns one heap.  Nodes 0..HEAP_LDS-1 (the top six levels, where every sift passes) live in LDS,
-// lane-interleaved (one ds_read_b128 per node); deeper nodes in the lane's global segment.  A nucleus-sized
-// blob's frontier rarely exceeds 63 entries, so the sifts are LDS-latency bound instead of L2-latency bound.
-// The accessors are lambdas over the kernel's own __shared__ array so that the compiler keeps LDS
-// addressing (a pointer smuggled through a struct degrades to flat loads).
-// out of line on purpose: keeps the rare global path from being merged with the LDS path into flat accesses
-__device__ __noinline__ HeapItem heap_glob_get(const HeapItem* __restrict__ g, int i) { return g[i]; }
-__device__ __noinline__ void heap_glob_put(HeapItem* __restrict__ g, int i, const HeapItem& e) { g[i] = e; }
-
+// One lane owns one heap, kept in the lane's global-memory segment.  (Keeping the top levels of every
+// heap in LDS was measured and lost: 5.6 ms -> 8.0 ms per 256 x 164^2 batch; the extra branches and the 63 KB
+// LDS footprint cost more than the L2 round trips they save.)
 // inst = where(mask, markers, 0) with mask pixels still to be flooded marked -1 (so the flood needs a single
 // load per neighbour; every -1 is gone when the flood ends); blob bounding boxes
 __global__ __launch_bounds__(HT) void ws_init_kernel(const int* __restrict__ blob, const int* __restrict__ marker, int h, int w,
@@ -293,17 +287,15 @@ __global__ __launch_bounds__(1024) void ws_offsets_kernel(const int* __restrict_
     }
 }
 
-template <int HEAP_LDS>
 __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ blob, const double* __restrict__ dist,
                                                        const int* __restrict__ areas, const int* __restrict__ offs,
                                                        const int* __restrict__ count, const int* __restrict__ bbox, int h, int w,
                                                        int min_keep, HeapItem* __restrict__ heaps, int* __restrict__ inst) {
-    __shared__ HeapItem s_heap[HEAP_LDS > 0 ? HEAP_LDS : 1][64];
-    const int lane = threadIdx.x;
     const long hw = (long)h * w;
-    const int plane = blockIdx.y;
-    // the grid is capped (every workgroup pins 63 KB of LDS): lanes stride over the plane's blob labels
-    for (int label = blockIdx.x * 64 + threadIdx.x + 1; label <= count[plane]; label += gridDim.x * 64) {
+    // Plane index fastest: workgroups go round-robin to the 8 XCDs in launch order, and in a batch of patches
+    // only the first label chunk of every plane has work -- with the chunk index fastest all of it lands on one XCD.
+    const int plane = blockIdx.x;
+    for (int label = blockIdx.y * 64 + threadIdx.x + 1; label <= count[plane]; label += gridDim.y * 64) {
     const int area = areas[(size_t)plane * (hw + 1) + label];
     if (area < min_keep) continue;
     const size_t off = (size_t)plane * hw;
@@ -311,65 +303,47 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
     const double* ds = dist + off;
     int* out = inst + off;
     HeapItem* glob = heaps + off + offs[(size_t)plane * (hw + 1) + label];
-    auto HEAP_GET = [&](int i) -> HeapItem {
-        if constexpr (HEAP_LDS > 0) {
-            if (i < HEAP_LDS) return s_heap[i][lane];
-            return heap_glob_get(glob, i);
-        } else {
-            return glob[i];
-        }
-    };
-    auto HEAP_PUT = [&](int i, const HeapItem& e) {
-        if constexpr (HEAP_LDS > 0) {
-            if (i < HEAP_LDS)
-                s_heap[i][lane] = e;
-            else
-                heap_glob_put(glob, i, e);
-        } else {
-            glob[i] = e;
-        }
-    };
     // skimage heap_general.pxi: push = append + sift towards the root
     auto heap_push = [&](int& items, const HeapItem& e) {
         int pos = items++;
         while (pos > 0) {
             const int parent = (pos - 1) >> 1;
-            const HeapItem p = HEAP_GET(parent);
+            const HeapItem p = glob[parent];
             if (!heap_smaller(e, p)) break;
-            HEAP_PUT(pos, p);
+            glob[pos] = p;
             pos = parent;
         }
-        HEAP_PUT(pos, e);
+        glob[pos] = e;
     };
     // pop = take root, move the last item to the root, bubble the smaller child up to a leaf, sift back
     auto heap_pop = [&](int& items) {
-        const HeapItem top = HEAP_GET(0);
+        const HeapItem top = glob[0];
         --items;
         if (items == 0) return top;
-        const HeapItem last = HEAP_GET(items);
+        const HeapItem last = glob[items];
         int pos = 0, child = 1;
         while (child < items) {
             const int right = child + 1;
-            HeapItem c = HEAP_GET(child);
+            HeapItem c = glob[child];
             if (right < items) {
-                const HeapItem r = HEAP_GET(right);
+                const HeapItem r = glob[right];
                 if (!heap_smaller(c, r)) {
                     child = right;
                     c = r;
                 }
             }
-            HEAP_PUT(pos, c);
+            glob[pos] = c;
             pos = child;
             child = 2 * pos + 1;
         }
         while (pos > 0) {
             const int parent = (pos - 1) >> 1;
-            const HeapItem p = HEAP_GET(parent);
+            const HeapItem p = glob[parent];
             if (!heap_smaller(last, p)) break;
-            HEAP_PUT(pos, p);
+            glob[pos] = p;
             pos = parent;
         }
-        HEAP_PUT(pos, last);
+        glob[pos] = last;
         return top;
     };
     const int* bb = bbox + ((size_t)plane * (hw + 1) + label) * 4;
@@ -629,21 +603,10 @@ extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, in
     hipLaunchKernelGGL(gauss3_neg_kernel, grid, dim3(HT), 0, st, dist0, (int)h, (int)w, dist);
     hipLaunchKernelGGL(ws_init_kernel, grid, dim3(HT), 0, st, blob_lab, mark_lab, (int)h, (int)w, d_inst, bbox);
     const long max_labels = hw / 2 + 2;
-    long fx = (max_labels + 63) / 64, fcap = 4096 / n > 4 ? 4096 / n : 4;
-    dim3 fgrid((unsigned)(fx < fcap ? fx : fcap), (unsigned)n);
-    static const int lds_nodes = [] {
-        const char* e = getenv("TIA_FLOOD_LDS");  // developer switch: 0 = heap entirely in global memory
-        return e ? atoi(e) : 63;
-    }();
-    if (lds_nodes >= 63)
-        hipLaunchKernelGGL(ws_flood_kernel<63>, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w,
-                           10, heaps, d_inst);
-    else if (lds_nodes >= 15)
-        hipLaunchKernelGGL(ws_flood_kernel<15>, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w,
-                           10, heaps, d_inst);
-    else
-        hipLaunchKernelGGL(ws_flood_kernel<0>, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w,
-                           10, heaps, d_inst);
+    long fx = (max_labels + 63) / 64, fcap = 65536 / n > 4 ? 65536 / n : 4;  // lanes stride over labels beyond the cap
+    dim3 fgrid((unsigned)n, (unsigned)(fx < fcap ? fx : fcap));
+    hipLaunchKernelGGL(ws_flood_kernel, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w, 10,
+                       heaps, d_inst);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 

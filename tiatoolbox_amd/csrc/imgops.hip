@@ -185,7 +185,7 @@ __global__ __launch_bounds__(BT) void ccl_flatten_kernel(int* __restrict__ L, lo
 
 // One workgroup per plane: rank the roots (pixels with L[i]==i) in raster order.
 // rank[root] = 1-based component number; count[plane] = number of components.
-// The plane is swept in coalesced 4096-pixel tiles (4 consecutive pixels per lane) with a running
+// The plane is swept in coalesced 8192-pixel tiles (8 consecutive pixels per lane) with a running
 // total; wave scan + per-wave totals in LDS (double-buffered: one barrier per tile).
 __global__ __launch_bounds__(1024) void ccl_rank_kernel(const int* __restrict__ L, long hw, int* __restrict__ rank,
                                                          int* __restrict__ count) {
@@ -196,22 +196,26 @@ __global__ __launch_bounds__(1024) void ccl_rank_kernel(const int* __restrict__ 
     const int t = threadIdx.x, wv = wave_id();
     unsigned running = 0;
     int buf = 0;
-    for (long base = 0; base < hw; base += 4096, buf ^= 1) {
-        const long i0 = base + 4L * t;
-        int v[4] = {-1, -1, -1, -1};
+    for (long base = 0; base < hw; base += 8192, buf ^= 1) {
+        const long i0 = base + 8L * t;
+        int v[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
         if (vec) {
             if (i0 < hw) {
                 const int4 q = *reinterpret_cast<const int4*>(l + i0);
                 v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
             }
+            if (i0 + 4 < hw) {
+                const int4 q = *reinterpret_cast<const int4*>(l + i0 + 4);
+                v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 8; ++k)
                 if (i0 + k < hw) v[k] = l[i0 + k];
         }
-        unsigned f[4], c = 0;
+        unsigned f[8], c = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             f[k] = (v[k] == (int)(i0 + k)) ? 1u : 0u;
             c += f[k];
         }
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(1024) void ccl_rank_kernel(const int* __restrict__ 
             tot += x;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 8; ++k)
             if (f[k]) r[i0 + k] = (int)(++before);
         running += tot;
     }
@@ -263,14 +267,16 @@ static int ccl_run(const uint8_t* d_mask, long n, int h, int w, int conn, int* d
 
 // ---- label areas -----------------------------------------------------------------------------------------
 // Areas by run aggregation: a lane holds 4 consecutive pixels; lanes whose 4 pixels carry one label merge
-// with their neighbours through a ballot (one atomic per run of lanes instead of one per pixel -- large
-// components would otherwise serialise millions of atomics on one address).
+// with their neighbours through a ballot (one update per run of lanes instead of one per pixel), and every
+// lane keeps the last (label, count) it was about to add in registers across iterations, flushing only when
+// the label changes -- a slide-sized component would otherwise serialise ~10^5 atomics on one address.
 __global__ __launch_bounds__(BT) void area_count_kernel(const int* __restrict__ labels, long hw, int* __restrict__ areas) {
     const int* lb = labels + (size_t)blockIdx.y * hw;
     int* a = areas + (size_t)blockIdx.y * (hw + 1);
     const bool vec = (hw & 3) == 0;
     const int lane = lane_id();
     const long stride = (long)gridDim.x * BT * 4;
+    int ckey = 0, ccnt = 0;
     for (long base = (long)blockIdx.x * BT * 4; base < hw; base += stride) {  // uniform trip count per block
         const long i0 = base + 4L * threadIdx.x;
         int v[4] = {0, 0, 0, 0};
@@ -292,8 +298,14 @@ __global__ __launch_bounds__(BT) void area_count_kernel(const int* __restrict__ 
         if (uniform) {
             if (head && key > 0) {
                 const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
-                const int next = above ? __builtin_ctzll(above) : 64;
-                atomicAdd(&a[key], 4 * (next - lane));
+                const int add = 4 * ((above ? __builtin_ctzll(above) : 64) - lane);
+                if (key == ckey) {
+                    ccnt += add;
+                } else {
+                    if (ccnt) atomicAdd(&a[ckey], ccnt);
+                    ckey = key;
+                    ccnt = add;
+                }
             }
         } else {
 #pragma unroll
@@ -301,6 +313,7 @@ __global__ __launch_bounds__(BT) void area_count_kernel(const int* __restrict__ 
                 if (v[k] > 0) atomicAdd(&a[v[k]], 1);
         }
     }
+    if (ccnt) atomicAdd(&a[ckey], ccnt);
 }
 __global__ __launch_bounds__(BT) void area_filter_kernel(int* __restrict__ labels, long hw, const int* __restrict__ areas,
                                                           int min_keep) {
@@ -406,7 +419,9 @@ extern "C" int tia_label_area_filter_i32(int32_t* d_labels, int64_t n, int64_t h
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(d_ws, 0, (size_t)n * (hw + 1) * sizeof(int32_t), st) != hipSuccess) return TIA_ELAUNCH;
     dim3 grid(nblocks(hw, BT, 4096), (unsigned)n);
-    hipLaunchKernelGGL(area_count_kernel, grid, dim3(BT), 0, st, d_labels, hw, d_ws);
+    // few workgroups per plane (many iterations per lane) so the per-lane run cache gets to merge
+    dim3 cgrid(nblocks(hw, BT * 4 * 16, n >= 64 ? 8 : 64), (unsigned)n);
+    hipLaunchKernelGGL(area_count_kernel, cgrid, dim3(BT), 0, st, d_labels, hw, d_ws);
     hipLaunchKernelGGL(area_filter_kernel, grid, dim3(BT), 0, st, d_labels, hw, d_ws, min_keep);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
