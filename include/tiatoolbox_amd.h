@@ -127,11 +127,13 @@ int tia_stain_concentrations_f64(const uint8_t* d_img, int64_t n, int64_t h, int
  * StainAugmentor.augment (tools/stainaugment.py:177-206): C[mask,i] = C[mask,i]*alpha[i]+beta[i]
  * (all pixels if augment_background), out = uint8(clip(255*exp(-C.S),0,255)).  S = per-patch
  * TIA_ST_STAIN, mask from TIA_ST_PLOW/PHIGH + tables.  d_alpha_beta: [n,4] f64 = a0,a1,b0,b1.
+ * math = TIA_MATH_F64: the reference's float64 arithmetic; TIA_MATH_F32: float32 with hardware exp2 and
+ * 16-byte global accesses (needs h*w*3 % 3072 == 0 and 16-byte aligned buffers, else TIA_ESIZE).
  */
 int tia_stain_augment_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
                          const tia_stain_tables* d_tables, const double* d_stats,
                          const double* d_alpha_beta, int32_t y_thr, int32_t augment_background,
-                         int32_t zero_to_one, uint8_t* d_out, void* stream);
+                         int32_t zero_to_one, uint8_t* d_out, int32_t math, void* stream);
 
 /* Luminosity tissue mask (utils/misc.py:261-290) as uint8 0/1 [n,h,w]; needs TIA_ST_PLOW/PHIGH. */
 int tia_luminosity_mask_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,

@@ -139,6 +139,8 @@ def sec_stain_misc():
     ab = torch.rand((n, 4), device="cuda", dtype=torch.float64) * 0.2 + 0.9
     report("stain_augment, 4096x224^2", timeit(lambda: dev.augment(x, stats, ab, p.y_thr, augment_background=False, zero_to_one=False)),
            2 * x.numel())
+    report("stain_augment f32 / 16-byte accesses", timeit(lambda: dev.augment(x, stats, ab, p.y_thr, augment_background=False,
+                                                                        zero_to_one=False, math=_lib.MATH_F32)), 2 * x.numel())
     report("luminosity_mask", timeit(lambda: dev.luminosity_mask(x, stats, p.y_thr)), x.numel() * 4 // 3)
 
 

@@ -251,6 +251,28 @@ def test_stain_augmentor_matches_reference_golden(gold):
     assert aug.source_concentrations.shape == (128 * 128, 2) and aug.tissue_mask.shape == (128 * 128,)
 
 
+def test_stain_augmentor_f32_fast_path(gold, he_patches):
+    """precision='f32' (16-byte-access kernel): within one grey level of the float64 path on < 1e-3 of the
+    bytes, for tissue-only and background-included augmentation, batched device input."""
+    import torch
+
+    from tiatoolbox_amd.tools.stainaugment import StainAugmentor
+
+    crops = gold["real_crops"]              # 128x128: 128*128*3 % 3072 == 0
+    for k, ab in enumerate(gold["augment_ab"]):
+        aug = StainAugmentor(method="macenko", augment_background=bool(k), precision="f32")
+        aug.fit(crops[k], threshold=0.85)
+        assert aug._fast_path_ok()  # noqa: SLF001
+        _u8_close(aug.augment(alpha_beta=ab), gold["augment_real"][k], max_rate=1e-3)
+    odd = StainAugmentor(method="macenko", precision="f32")
+    odd.fit(he_patches[0][:50, :50], threshold=0.85)      # 50*50*3 is not a chunk multiple: f64 kernel
+    assert not odd._fast_path_ok()  # noqa: SLF001
+    assert odd.augment(alpha_beta=np.array([1.1, 0.9, 0.01, -0.01])).shape == (50, 50, 3)
+    with pytest.raises(ValueError, match="precision"):
+        StainAugmentor(precision="f16")
+    del torch
+
+
 def test_vahadane_pipeline_runs_and_matches_oracle_given_same_dictionary(he_patches):
     """Vahadane: the dictionary solve is scikit-learn's (as in the reference); everything around it is
     HIP.  With a fixed random_state both sides use the same solver, tolerance 1e-1 mean-abs like the

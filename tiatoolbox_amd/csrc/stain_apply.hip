@@ -341,6 +341,119 @@ __global__ __launch_bounds__(AT) void stain_apply_wide_kernel(const uint8_t* __r
     }
 }
 
+// ---- augment, f32 / 16-byte-access variant -------------------------------------------------------
+// Same data movement as stain_apply_wide_kernel; per pixel: concentrations (6 FMA), tissue test on the
+// folded luminance tables, alpha/beta on the selected pixels, recomposition with the source stain matrix
+// pre-scaled by -log2(e), hardware exp2.  uint8 output (tools/stainaugment.py:177-206).
+struct AugCtx {
+    float p[6], s[6], al[2], be[2];
+    const float* lut;
+    const int (*ty)[256];
+    int bank, y_thr, augment_background;
+    __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, float (&o)[3]) const {
+        const float x = lut[r * REP + bank], y = lut[g * REP + bank], z = lut[b * REP + bank];
+        const int t = ty[0][r] + ty[1][g] + ty[2][b];
+        const bool sel = augment_background || (((t + (1 << 11)) >> 12) < y_thr);
+        float c0 = __builtin_fmaf(z, p[4], __builtin_fmaf(y, p[2], x * p[0]));
+        float c1 = __builtin_fmaf(z, p[5], __builtin_fmaf(y, p[3], x * p[1]));
+        c0 = __builtin_fmaf(c0, sel ? al[0] : 1.0f, sel ? be[0] : 0.0f);
+        c1 = __builtin_fmaf(c1, sel ? al[1] : 1.0f, sel ? be[1] : 0.0f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = 255.0f * __builtin_amdgcn_exp2f(__builtin_fmaf(c1, s[3 + c], c0 * s[c]));
+            v = v > 255.0f ? 255.0f : v;
+            o[c] = v < 0.0f ? 0.0f : v;
+        }
+    }
+};
+
+__global__ __launch_bounds__(AT) void stain_augment_wide_kernel(const uint8_t* __restrict__ img, long hw,
+                                                                 const tia_stain_tables* __restrict__ tab,
+                                                                 const double* __restrict__ stats,
+                                                                 const double* __restrict__ alpha_beta, int y_thr,
+                                                                 int augment_background, int z1,
+                                                                 uint8_t* __restrict__ out) {
+    constexpr int CHUNK = 3072;
+    __shared__ float lut[256 * REP];
+    __shared__ int ty[3][256];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[AT / 64][CHUNK];
+    using v4 = __attribute__((ext_vector_type(4))) unsigned;
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    for (int i = threadIdx.x; i < 256 * REP; i += AT) lut[i] = tab->od_lut_f32[i / REP];
+    build_ty(ty, tab, st[TIA_ST_PLOW], st[TIA_ST_PHIGH], z1 != 0);
+    AugCtx ctx;
+    const double nl2e = -1.4426950408889634;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        ctx.p[i] = (float)st[TIA_ST_PINV + i];
+        ctx.s[i] = (float)(st[TIA_ST_STAIN + i] * nl2e);
+    }
+    ctx.al[0] = (float)alpha_beta[patch * 4 + 0];
+    ctx.al[1] = (float)alpha_beta[patch * 4 + 1];
+    ctx.be[0] = (float)alpha_beta[patch * 4 + 2];
+    ctx.be[1] = (float)alpha_beta[patch * 4 + 3];
+    ctx.lut = lut;
+    ctx.ty = ty;
+    ctx.bank = threadIdx.x & (REP - 1);
+    ctx.y_thr = y_thr;
+    ctx.augment_background = augment_background;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint8_t* mine = stage[wv];
+    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
+    uint8_t* dst = out + (size_t)patch * (size_t)hw * 3u;
+    const long nchunks = hw * 3 / CHUNK;
+    const long wstride = (long)gridDim.x * (AT / 64);
+    for (long c = (long)blockIdx.x * (AT / 64) + wv; c < nchunks; c += wstride) {
+        const v4* gsrc = reinterpret_cast<const v4*>(src + c * CHUNK);
+        v4 in[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in[k] = __builtin_nontemporal_load(gsrc + k * 64 + lane);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<v4*>(mine + k * 1024 + lane * 16) = in[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t w[12];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const v4 t = *reinterpret_cast<const v4*>(mine + lane * 48 + j * 16);
+            w[j * 4 + 0] = t.x;
+            w[j * 4 + 1] = t.y;
+            w[j * 4 + 2] = t.z;
+            w[j * 4 + 3] = t.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        alignas(16) uint8_t res[48];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t a = w[q * 3], b = w[q * 3 + 1], cc = w[q * 3 + 2];
+            float o[4][3];
+            ctx.pixel(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u, o[0]);
+            ctx.pixel(a >> 24, b & 255u, (b >> 8) & 255u, o[1]);
+            ctx.pixel((b >> 16) & 255u, b >> 24, cc & 255u, o[2]);
+            ctx.pixel((cc >> 8) & 255u, (cc >> 16) & 255u, cc >> 24, o[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) res[q * 12 + i * 3 + ch] = (uint8_t)(unsigned)o[i][ch];
+        }
+        const v4* rv = reinterpret_cast<const v4*>(res);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<v4*>(mine + lane * 48 + j * 16) = rv[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        v4* gdst = reinterpret_cast<v4*>(dst + c * CHUNK);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const v4 t = *reinterpret_cast<const v4*>(mine + k * 1024 + lane * 16);
+            __builtin_nontemporal_store(t, gdst + k * 64 + lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- concentrations ------------------------------------------------------------------------------
 __global__ __launch_bounds__(AT) void stain_conc_kernel(const uint8_t* __restrict__ img, long hw,
                                                          const tia_stain_tables* __restrict__ tab,
@@ -522,10 +635,24 @@ extern "C" int tia_stain_augment_u8(const uint8_t* d_img, int64_t n, int64_t h, 
                                      const tia_stain_tables* d_tables, const double* d_stats,
                                      const double* d_alpha_beta, int32_t y_thr,
                                      int32_t augment_background, int32_t zero_to_one, uint8_t* d_out,
-                                     void* stream) {
+                                     int32_t math, void* stream) {
     if (!d_img || !d_tables || !d_stats || !d_alpha_beta || !d_out) return TIA_EINVAL;
+    if (math != TIA_MATH_F64 && math != TIA_MATH_F32) return TIA_EINVAL;
     if (bad_dims(n, h, w)) return n > 65535 ? TIA_ESIZE : TIA_EINVAL;
     const long hw = (long)h * w;
+    if (math == TIA_MATH_F32) {
+        // the f32 path exists only in the 16-byte-access form: whole 3072-byte chunks, 16-byte aligned buffers
+        const bool aligned = ((reinterpret_cast<uintptr_t>(d_img) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
+        if ((hw * 3) % 3072 != 0 || !aligned) return TIA_ESIZE;
+        const long nchunks = hw * 3 / 3072;
+        long bx = (nchunks + 3) / 4;
+        const long want = (4096 + (long)n - 1) / (long)n;
+        if (bx > want) bx = want;
+        hipLaunchKernelGGL(tia::stain_augment_wide_kernel, dim3((unsigned)(bx < 1 ? 1 : bx), (unsigned)n), dim3(tia::AT), 0,
+                           (hipStream_t)stream, d_img, hw, d_tables, d_stats, d_alpha_beta, y_thr, augment_background,
+                           zero_to_one, d_out);
+        return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+    }
     dim3 grid(tia::blocks_x(hw, n), (unsigned)n);
     hipLaunchKernelGGL((tia::stain_augment_kernel<false>), grid, dim3(tia::AT), 0, (hipStream_t)stream,
                        d_img, hw, d_tables, d_stats, d_alpha_beta, y_thr, augment_background,

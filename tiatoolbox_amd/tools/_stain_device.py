@@ -158,7 +158,7 @@ def luminosity_mask(img: torch.Tensor, stats: torch.Tensor, y_thr: int, *, zero_
 
 
 def augment(img: torch.Tensor, stats: torch.Tensor, alpha_beta: torch.Tensor, y_thr: int, *,
-            augment_background: bool, zero_to_one: bool) -> torch.Tensor:
+            augment_background: bool, zero_to_one: bool, math: int = _lib.MATH_F64) -> torch.Tensor:
     img = as_batch(img)
     n, h, w, _ = img.shape
     _lib.require_cuda(alpha_beta, "alpha_beta")
@@ -172,7 +172,7 @@ def augment(img: torch.Tensor, stats: torch.Tensor, alpha_beta: torch.Tensor, y_
             rc = lib.tia_stain_augment_u8(img[s:s + m].data_ptr(), m, h, w, tab.data_ptr(),
                                           stats[s:s + m].data_ptr(), ab[s:s + m].data_ptr(), y_thr,
                                           int(augment_background), int(zero_to_one),
-                                          out[s:s + m].data_ptr(), _lib.current_stream())
+                                          out[s:s + m].data_ptr(), math, _lib.current_stream())
             _lib.check(rc, "tia_stain_augment_u8")
     return out
 

@@ -41,8 +41,12 @@ class StainAugmentor(ImageOnlyTransform):
 
     def __init__(self, method: str = "vahadane", stain_matrix: np.ndarray | None = None, sigma1: float = 0.4,
                  sigma2: float = 0.2, p: float = 0.5, *, augment_background: bool = False,
-                 always_apply: bool = False) -> None:
+                 always_apply: bool = False, precision: str = "f64") -> None:
         super().__init__(always_apply=always_apply, p=p)
+        if precision not in {"f64", "f32"}:
+            msg = "precision must be 'f64' (the reference's arithmetic) or 'f32' (fast path)."
+            raise ValueError(msg)
+        self.precision = precision
         self.augment_background = augment_background
         self.sigma1 = sigma1
         self.sigma2 = sigma2
@@ -115,8 +119,13 @@ class StainAugmentor(ImageOnlyTransform):
                 msg = "Empty tissue mask computed."
                 raise ValueError(msg)
         out = dev.augment(self._batch, self._stats, torch.from_numpy(ab).to(self._batch.device), self._y_thr,
-                          augment_background=self.augment_background, zero_to_one=True)
+                          augment_background=self.augment_background, zero_to_one=True,
+                          math=_lib.MATH_F32 if self._fast_path_ok() else _lib.MATH_F64)
         return _tensors.from_device(out, self._kind)
+
+    def _fast_path_ok(self) -> bool:
+        """f32 / 16-byte-access kernel: whole 3072-byte chunks per image (any H*W multiple of 1024)."""
+        return self.precision == "f32" and (self._batch.shape[1] * self._batch.shape[2] * 3) % 3072 == 0
 
     def apply(self, img, **params):  # noqa: ARG002
         """``fit`` + ``augment`` (ref. :208-228)."""
