@@ -105,6 +105,14 @@ __device__ __forceinline__ void block_sum(double (&v)[N], Smem& s) {
     __syncthreads();
 }
 
+// Projections and moment accumulations use explicit fused multiply-adds: f64 runs at half rate on gfx950 and
+// these sweeps are VALU-bound, so a*b+c as one instruction is a third fewer issue slots.  The reference's
+// BLAS dot products fix no particular rounding order either; what matters is that the histogram pass and
+// the collect pass evaluate a pixel's key with the SAME instruction sequence, hence one shared helper.
+__device__ __forceinline__ double dot3(double x, double y, double z, double a, double b, double c) {
+    return __builtin_fma(z, c, __builtin_fma(y, b, x * a));
+}
+
 // numpy's _lerp (numpy/lib/_function_base_impl.py): a + (b-a)*t, or b - (b-a)*(1-t) for t>=0.5
 __device__ __forceinline__ double np_lerp(double a, double b, double t) {
     const double d = b - a;
@@ -726,41 +734,41 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc[10] += x[i] * y[i];
-                    acc[11] += x[i] * z[i];
-                    acc[12] += y[i] * z[i];
+                    acc[10] = __builtin_fma(x[i], y[i], acc[10]);
+                    acc[11] = __builtin_fma(x[i], z[i], acc[11]);
+                    acc[12] = __builtin_fma(y[i], z[i], acc[12]);
                     if (((lum[i] + (1 << 11)) >> 12) < y_thr) {
                         acc[0] += 1.0;
                         acc[1] += x[i];
                         acc[2] += y[i];
                         acc[3] += z[i];
-                        acc[4] += x[i] * x[i];
-                        acc[5] += x[i] * y[i];
-                        acc[6] += x[i] * z[i];
-                        acc[7] += y[i] * y[i];
-                        acc[8] += y[i] * z[i];
-                        acc[9] += z[i] * z[i];
+                        acc[4] = __builtin_fma(x[i], x[i], acc[4]);
+                        acc[5] = __builtin_fma(x[i], y[i], acc[5]);
+                        acc[6] = __builtin_fma(x[i], z[i], acc[6]);
+                        acc[7] = __builtin_fma(y[i], y[i], acc[7]);
+                        acc[8] = __builtin_fma(y[i], z[i], acc[8]);
+                        acc[9] = __builtin_fma(z[i], z[i], acc[9]);
                     }
                 }
             });
         } else
         for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
             const double x = OD(r), y = OD(g), z = OD(b);
-            acc[10] += x * y;  // all-pixel cross moments: exact variance of the concentrations
-            acc[11] += x * z;
-            acc[12] += y * z;
+            acc[10] = __builtin_fma(x, y, acc[10]);  // all-pixel cross moments: exact variance of the concentrations
+            acc[11] = __builtin_fma(x, z, acc[11]);
+            acc[12] = __builtin_fma(y, z, acc[12]);
             if (is_tissue(r, g, b)) {
                 if (use_bits) atomicOr(&s.mbits[idx >> 5], 1u << (idx & 31));
                 acc[0] += 1.0;
                 acc[1] += x;
                 acc[2] += y;
                 acc[3] += z;
-                acc[4] += x * x;
-                acc[5] += x * y;
-                acc[6] += x * z;
-                acc[7] += y * y;
-                acc[8] += y * z;
-                acc[9] += z * z;
+                acc[4] = __builtin_fma(x, x, acc[4]);
+                acc[5] = __builtin_fma(x, y, acc[5]);
+                acc[6] = __builtin_fma(x, z, acc[6]);
+                acc[7] = __builtin_fma(y, y, acc[7]);
+                acc[8] = __builtin_fma(y, z, acc[8]);
+                acc[9] = __builtin_fma(z, z, acc[9]);
             }
         });
         block_sum(acc, s);
@@ -823,8 +831,8 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
                 [&](long idx, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
                     if (!is_tissue_cached(idx, r, g, b)) return 0u;
                     const double ox = OD(r), oy = OD(g), oz = OD(b);
-                    const double p0 = ox * e1x + oy * e1y + oz * e1z;
-                    const double p1 = ox * e2x + oy * e2y + oz * e2z;
+                    const double p0 = dot3(ox, oy, oz, e1x, e1y, e1z);
+                    const double p1 = dot3(ox, oy, oz, e2x, e2y, e2z);
                     x[0] = x[1] = pseudo_angle(p1, p0);
                     return 3u;
                 },
@@ -848,8 +856,8 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const bool tissue = ((lum[i] + (1 << 11)) >> 12) < y_thr;
-                            const double p0 = ox[i] * e1x + oy[i] * e1y + oz[i] * e1z;
-                            const double p1 = ox[i] * e2x + oy[i] * e2y + oz[i] * e2z;
+                            const double p0 = dot3(ox[i], oy[i], oz[i], e1x, e1y, e1z);
+                            const double p1 = dot3(ox[i], oy[i], oz[i], e2x, e2y, e2z);
                             const double d = (pseudo_angle(p1, p0) - lo) * sc;
                             const bool low = !(d >= 0.0), high = d >= (double)NB;
                             const int bin = low ? 0 : (high ? NB - 1 : (int)d);
@@ -896,9 +904,9 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
         double acc[3] = {0.0, 0.0, 0.0};
         for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
             const double x = OD(r), y = OD(g), z = OD(b);
-            acc[0] += x * y;
-            acc[1] += x * z;
-            acc[2] += y * z;
+            acc[0] = __builtin_fma(x, y, acc[0]);
+            acc[1] = __builtin_fma(x, z, acc[1]);
+            acc[2] = __builtin_fma(y, z, acc[2]);
         });
         block_sum(acc, s);
         if (tid < 3) s.chx[tid] = acc[tid];
@@ -977,8 +985,8 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
         select2(p, hw,
                 [&](long, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
                     const double ox = OD(r), oy = OD(g), oz = OD(b);
-                    x[0] = ox * P[0] + oy * P[2] + oz * P[4];
-                    x[1] = ox * P[1] + oy * P[3] + oz * P[5];
+                    x[0] = dot3(ox, oy, oz, P[0], P[2], P[4]);
+                    x[1] = dot3(ox, oy, oz, P[1], P[3], P[5]);
                     return 3u;
                 },
                 [&](unsigned (&below)[2], unsigned (&above)[2]) -> bool {
@@ -998,8 +1006,8 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
                         unsigned long long code0 = 0ull, code1 = 0ull;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const double d0 = ((ox[i] * P[0] + oy[i] * P[2] + oz[i] * P[4]) - l0) * s0;
-                            const double d1 = ((ox[i] * P[1] + oy[i] * P[3] + oz[i] * P[5]) - l1) * s1;
+                            const double d0 = (dot3(ox[i], oy[i], oz[i], P[0], P[2], P[4]) - l0) * s0;
+                            const double d1 = (dot3(ox[i], oy[i], oz[i], P[1], P[3], P[5]) - l1) * s1;
                             const bool low0 = !(d0 >= 0.0), high0 = d0 >= (double)NB;
                             const bool low1 = !(d1 >= 0.0), high1 = d1 >= (double)NB;
                             const int b0 = low0 ? 0 : (high0 ? NB - 1 : (int)d0);
