@@ -579,6 +579,8 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
     const long long t_begin = clock64();
 
     // ---- P1: per-channel byte histograms (per-wave private copies in the bins area) ------------
+    // (Two copies per wave -- even / odd lanes -- were measured: no change, 79.7 k cycles either way; the pass
+    //  sits on the LDS atomic issue rate, ~11 cycles per wave instruction per CU, not on address conflicts.)
     unsigned* wh = &s.bins[0][0] + wave_id() * 768;
     for (int i = tid; i < NW * 768; i += NT) (&s.bins[0][0])[i] = 0;
     __syncthreads();
