@@ -126,6 +126,8 @@ def main() -> None:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # MIOpen's solver search (done once per convolution shape during warm-up): 43 -> 36 ms for resnet18 fp16
+    torch.backends.cudnn.benchmark = os.environ.get("TIA_MIOPEN_FIND", "1") == "1"
     dtype = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}[args.dtype]
     n, hw = args.patches, args.patch_size
 
