@@ -138,6 +138,16 @@ def install() -> None:
     cv2.moments = moments
     cv2.findContours = find_contours
 
+    # shapely: only axis-aligned boxes, an STRtree of boxes and box.contains(box) are used (tile merging)
+    import shapely
+    import shapely.strtree
+
+    from oracle import geomref
+
+    shapely.box = geomref.box
+    shapely.STRtree = geomref.STRtree
+    shapely.strtree.STRtree = geomref.STRtree
+
     import skimage.exposure
     import skimage.filters
     import skimage.morphology

@@ -155,6 +155,87 @@ def hover_goldens() -> None:
           [int(out[f"{t}_inst"].max()) for t in "ab"])
 
 
+def tile_goldens() -> None:
+    """WSI tile-mode merge of instance predictions: the real reference's tile sets, margin rules, id stitching and
+    offset handling (``multi_task_segmentor.py:1078-1287,1362-1554,2833-3297``) driven exactly like
+    ``_process_tile_mode`` drives them, with the real ``HoVerNet.postproc`` per tile (shapely replaced by the
+    axis-aligned stand-ins of ``oracle/geomref.py``)."""
+    from types import SimpleNamespace
+
+    from oracle import hovernet as oh
+
+    mts = _ref_import("tiatoolbox.models.engine.multi_task_segmentor")
+    hov = _ref_import("tiatoolbox.models.architecture.hovernet")
+    ioc = _ref_import("tiatoolbox.models.engine.io_config")
+    sem = _ref_import("tiatoolbox.models.engine.semantic_segmentor")
+    out = {}
+    res = {"units": "mpp", "resolution": 0.25}
+    for tag, (rh, rw, seed, nb, tile, margin, pad) in {
+            "a": (820, 750, 3, 420, 400, 32, (41, 82, 0, 0)),
+            "b": (700, 1000, 4, 380, 500, 40, (0, 0, 0, 0))}.items():
+        cfg = ioc.IOInstanceSegmentorConfig(input_resolutions=[res], output_resolutions=[res, res, res],
+                                            patch_input_shape=[256, 256], patch_output_shape=[164, 164],
+                                            stride_shape=[164, 164], margin=margin, tile_shape=[tile, tile])
+        npm, hv, tp = oh.synth_maps(1, rh, rw, seed=seed, n_blobs=nb)
+        heads = [npm[0], hv[0], tp[0]]
+        wsi_shape = (rw + pad[0] + pad[2], rh + pad[1] + pad[3])
+        fake = SimpleNamespace(_ioconfig=cfg, mask_padding=pad,
+                               dataloader=SimpleNamespace(dataset=SimpleNamespace(mask_reader=None)))
+        sets = mts.MultiTaskSegmentor._get_tile_info(fake, image_shape=(rw, rh), wsi_proc_shape=wsi_shape)
+        meta = mts._build_tile_tasks(tile_info_sets=sets, verbose=False)
+        base = cfg.to_baseline()
+        model_self = SimpleNamespace(tasks=["nuclei_segmentation"])
+        wsi_info, max_inst = None, None
+        for bounds, flag, mode in meta:
+            crop = [p[bounds[1]:bounds[3], bounds[0]:bounds[2], :] for p in heads]
+            post = hov.HoVerNet.postproc(model_self, crop)
+            if wsi_info is None:
+                wsi_info = ({"task_type": post[0]["task_type"], "info_dict": {},
+                             "predictions": np.zeros(wsi_shape[::-1], dtype=post[0]["predictions"].dtype)},)
+            wsi_info, max_inst = mts._update_tile_based_predictions_array(
+                post_process_output=post, wsi_info_dict=wsi_info, bounds=bounds, offset=(pad[0], pad[1]),
+                max_inst_value=max_inst)
+            tl, br = bounds[:2], bounds[2:]
+            for k, inst_dict in enumerate(mts._get_inst_info_dicts(post_process_output=post)):
+                fresh, stale = mts._compute_info_dict_for_merge(
+                    inst_dict=inst_dict, tile_mode=mode, ref_inst_info_dict=wsi_info[k]["info_dict"], ioconfig=base,
+                    tile_shape=br - tl, tile_tl=tl, tile_flag=flag)
+                wsi_info[k]["info_dict"].update(fresh)
+                for key in stale:
+                    wsi_info[k]["info_dict"].pop(key, None)
+        recs = list(wsi_info[0]["info_dict"].values())
+        cols = {key: mts.apply_coordinate_offset(
+            data_array=np.array([r[key] for r in recs] + [None], dtype=object)[:-1], offset=np.array(pad[:2]), key=key,
+            verbose=False) for key in ("box", "centroid", "contours")}
+        out[f"{tag}_cfg"] = np.array([rh, rw, seed, nb, tile, margin, *pad])
+        for si, (b, f) in enumerate(sets):
+            out[f"{tag}_set{si}_bounds"], out[f"{tag}_set{si}_flags"] = np.asarray(b), np.asarray(f)
+        out[f"{tag}_box"] = np.array([c for c in cols["box"]]).reshape(-1, 4)
+        out[f"{tag}_centroid"] = np.array([c for c in cols["centroid"]]).reshape(-1, 2)
+        out[f"{tag}_polylen"] = np.array([len(c) for c in cols["contours"]])
+        out[f"{tag}_poly"] = np.concatenate(list(cols["contours"])).astype(np.int32)
+        out[f"{tag}_type"] = np.array([r["type"] for r in recs])
+        out[f"{tag}_prob"] = np.array([r["prob"] for r in recs])
+        out[f"{tag}_pred"] = wsi_info[0]["predictions"]
+        print(tag, "tiles per set", [len(b) for b, _ in sets], "instances", len(recs), "max id", int(wsi_info[0]["predictions"].max()))
+    # region bookkeeping of infer_wsi
+    rng = np.random.default_rng(0)
+    for k in range(4):
+        h, w = int(rng.integers(700, 1500)), int(rng.integers(700, 1500))
+        xs, ys = np.arange(0, w, 164), np.arange(0, h, 164)
+        locs = np.array([[x, y, x + 164, y + 164] for y in ys for x in xs])
+        keep = rng.random(len(locs)) < 0.3
+        kept = locs[keep]
+        mb = (kept[:, 0].min(), kept[:, 1].min(), kept[:, 2].max(), kept[:, 3].max())
+        inside, padding, shape = sem.get_full_output_locs_inside_mask(full_output_locs=locs.copy(), mask_bounds=mb,
+                                                                      output_shape=(h, w))
+        out[f"region{k}_in"] = np.array([h, w, *mb])
+        out[f"region{k}_locs"], out[f"region{k}_inside"] = locs, inside
+        out[f"region{k}_padding"], out[f"region{k}_shape"] = np.array(padding), np.array(shape)
+    np.savez_compressed(HERE / "tile_golden.npz", **out)
+    print("wrote tile_golden.npz")
+
+
 def grid_goldens() -> None:
     """PatchExtractor.get_coordinates / filter_coordinates and merge_batch_to_canvas of the real reference."""
     pe = _ref_import("tiatoolbox.tools.patchextraction")
@@ -204,13 +285,15 @@ def reinhard_goldens() -> None:
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stain", "mask", "hover", "grid", "reinhard"]
+    which = sys.argv[1:] or ["stain", "mask", "hover", "grid", "reinhard", "tile"]
     if "reinhard" in which:
         reinhard_goldens()
     if "grid" in which:
         grid_goldens()
     if "hover" in which:
         hover_goldens()
+    if "tile" in which:
+        tile_goldens()
     if "stain" in which:
         stain_goldens()
     if "mask" in which:

@@ -1,0 +1,131 @@
+"""WSI tile mode of MultiTaskSegmentor: tile sets, margin rules, id stitching and offsets against goldens produced
+by the REAL reference's functions (``tests/golden/make_golden.py tile``; shapely replaced by the axis-aligned
+stand-ins of ``oracle/geomref.py``).  CPU tests drive the product's merge with the oracle's per-tile
+post-processing; the GPU test drives it with the HIP post-processing pipeline."""
+
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hovernet as oh
+from tiatoolbox_amd.models.engine import multi_task_segmentor as mts
+from tiatoolbox_amd.models.engine.io_config import IOInstanceSegmentorConfig
+
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD / "tile_golden.npz")
+
+
+def _engine(gold, tag, model):
+    rh, rw, seed, nb, tile, margin, *pad = (int(v) for v in gold[f"{tag}_cfg"])
+    res = {"units": "mpp", "resolution": 0.25}
+    eng = mts.MultiTaskSegmentor.__new__(mts.MultiTaskSegmentor)
+    eng.model = model
+    eng.verbose = False
+    eng._ioconfig = IOInstanceSegmentorConfig(  # noqa: SLF001
+        input_resolutions=[res], output_resolutions=[res, res, res], patch_input_shape=[256, 256],
+        patch_output_shape=[164, 164], stride_shape=[164, 164], margin=margin, tile_shape=[tile, tile])
+    eng.mask_padding = tuple(pad)
+    npm, hv, tp = oh.synth_maps(1, rh, rw, seed=seed, n_blobs=nb)
+    wsi_shape = (rw + pad[0] + pad[2], rh + pad[1] + pad[3])
+    return eng, [npm[0], hv[0], tp[0]], (rw, rh), wsi_shape
+
+
+class _OracleHoVerNet:
+    """Per-tile post-processing through the CPU oracle, packed by the product's own ``HoVerNet._pack``."""
+
+    tasks = ("nuclei_segmentation",)
+
+    def postproc_batch(self, np_map, hv_map, tp_map):
+        from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
+
+        outs = []
+        for i in range(np_map.shape[0]):
+            inst = oh.proc_np_hv(np_map[i].numpy(), hv_map[i].numpy())
+            info = oh.get_instance_info(inst, np.around(tp_map[i].numpy()).astype("uint8")[..., 0])
+            outs.append(HoVerNet._pack(self, inst, info))  # noqa: SLF001
+        return outs
+
+
+def _check_table(task: dict, gold, tag: str) -> None:
+    cols = task["info_dict"]
+    assert np.array_equal(np.array(list(cols["box"])).reshape(-1, 4), gold[f"{tag}_box"])
+    np.testing.assert_array_equal(np.array(list(cols["centroid"])).reshape(-1, 2), gold[f"{tag}_centroid"])
+    assert np.array_equal(np.array([len(c) for c in cols["contours"]]), gold[f"{tag}_polylen"])
+    assert np.array_equal(np.concatenate(list(cols["contours"])), gold[f"{tag}_poly"])
+    assert np.array_equal(np.array(list(cols["type"])), gold[f"{tag}_type"])
+    np.testing.assert_array_equal(np.array(list(cols["prob"]), dtype=np.float64), gold[f"{tag}_prob"])
+    assert np.array_equal(task["predictions"], gold[f"{tag}_pred"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_tile_sets_match_reference(gold, tag):
+    eng, _, region, wsi_shape = _engine(gold, tag, None)
+    sets = eng._get_tile_info(region, wsi_shape)  # noqa: SLF001
+    assert len(sets) == 4
+    for si, (bounds, flags) in enumerate(sets):
+        assert np.array_equal(bounds, gold[f"{tag}_set{si}_bounds"]), si
+        assert np.array_equal(flags, gold[f"{tag}_set{si}_flags"]), si
+    # a region that fits one tile: a single set without removal flags (ref. :1424-1427)
+    small = eng._get_tile_info((200, 150), (200, 150))  # noqa: SLF001
+    assert len(small) == 1 and not small[0][1].any()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_tile_merge_matches_reference_with_oracle_postproc(gold, tag):
+    eng, heads, _, wsi_shape = _engine(gold, tag, _OracleHoVerNet())
+    out = eng._process_tile_mode([torch.from_numpy(h) for h in heads], wsi_shape, None, return_predictions=(True,))  # noqa: SLF001
+    _check_table(out[0], gold, tag)
+
+
+def test_region_bookkeeping_matches_reference(gold):
+    for k in range(4):
+        h, w, *mb = (int(v) for v in gold[f"region{k}_in"])
+        inside, padding, shape = mts.get_full_output_locs_inside_mask(gold[f"region{k}_locs"], mb, (h, w))
+        assert np.array_equal(inside, gold[f"region{k}_inside"])
+        assert tuple(padding) == tuple(gold[f"region{k}_padding"]) and tuple(shape) == tuple(gold[f"region{k}_shape"])
+
+
+def test_margin_rules_small_cases():
+    cfg = IOInstanceSegmentorConfig(input_resolutions=[{"units": "baseline", "resolution": 1.0}], patch_input_shape=[8, 8],
+                                    patch_output_shape=[8, 8], margin=4, tile_shape=[32, 32])
+    inst = {1: {"box": np.array([0, 0, 3, 3])},        # wholly inside the top and left bands
+            2: {"box": np.array([10, 2, 14, 6])},      # crosses the top band's inner line
+            3: {"box": np.array([10, 10, 14, 14])},    # interior
+            4: {"box": np.array([29, 10, 32, 14])}}    # wholly inside the right band
+    picked, lines = mts._get_sel_indices_margin_lines(cfg, (32, 32), (1, 0, 0, 1), 0, np.array([100, 200]), inst)  # noqa: SLF001
+    assert sorted(set(picked)) == [0, 3]               # top + right flagged; instance 1 is in the top band
+    assert lines[0] == (104, 204, 128, 204) and lines[3] == (128, 204, 128, 228)
+    picked, _ = mts._get_sel_indices_margin_lines(cfg, (32, 32), (1, 1, 0, 0), 1, np.array([0, 0]), inst)  # noqa: SLF001
+    assert sorted(set(picked)) == [0, 1, 3]            # strips: anything meeting a flagged band or an unflagged edge
+    with pytest.raises(ValueError, match="Unknown tile mode"):
+        mts._get_sel_indices_margin_lines(cfg, (32, 32), (0, 0, 0, 0), 7, np.array([0, 0]), inst)  # noqa: SLF001
+    assert mts._compute_info_dict_for_merge({}, 0, {}, cfg, (32, 32), np.array([0, 0]), (0, 0, 0, 0)) == ({}, [])  # noqa: SLF001
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_tile_mode_on_device_matches_reference(gold, tag):
+    """The same merge driven by the HIP post-processing (tiles of one shape batched on the device)."""
+    from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
+
+    model = HoVerNet(num_types=6, mode="fast")
+    eng, heads, _, wsi_shape = _engine(gold, tag, model)
+    maps = [torch.from_numpy(h).cuda() for h in heads]
+    out = eng._process_tile_mode(maps, wsi_shape, None, return_predictions=(True,))  # noqa: SLF001
+    _check_table(out[0], gold, tag)
+    # full-region mode: one postproc over the whole map == the oracle on the whole map, shifted by the padding
+    full = eng._process_full_wsi(maps, return_predictions=(True,))  # noqa: SLF001
+    inst = oh.proc_np_hv(heads[0], heads[1])
+    info = oh.get_instance_info(inst, np.around(heads[2]).astype("uint8")[..., 0], offset=eng.mask_padding[:2])
+    assert np.array_equal(np.array([v["box"] for v in info.values()]), np.array(list(full[0]["info_dict"]["box"])))
+    pl, pt, pr, pb = eng.mask_padding
+    assert np.array_equal(full[0]["predictions"], np.pad(inst, ((pt, pb), (pl, pr))))

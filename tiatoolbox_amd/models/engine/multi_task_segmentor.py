@@ -3,18 +3,198 @@
 
 ``infer_patches`` keeps every head's output resident on the GPU; ``post_process_patches`` runs the
 model's *batched* device post-processing (HoVer-Net: Sobel/energy/CCL/watershed kernels over all
-patches of a chunk at once) instead of a Python loop over patches.  Tile-mode WSI stitching
-(reference :836-1554) is outside this round's scope.
+patches of a chunk at once) instead of a Python loop over patches.
+
+WSI mode (reference :477-731, 836-1554, 2833-3297): every head is stitched into one device-resident map of
+the tissue region; maps no larger than ``ioconfig.tile_shape`` are post-processed in one go, larger ones tile
+by tile (tiles of equal shape batched through the device pipeline) and merged across the seams with the
+reference's four tile sets / margin rules.  Results are plain NumPy containers (no dask / zarr).
 """
 
 from __future__ import annotations
 
+import uuid
 import warnings
 
 import numpy as np
 import torch
 
 from tiatoolbox_amd.models.engine.engine_abc import EngineABC
+from tiatoolbox_amd.tools.patchextraction import PatchExtractor
+from tiatoolbox_amd.wsicore import ArrayWSIReader
+
+
+# ===================================================================================== WSI mode
+# Tile-mode merging of instance predictions (reference :1078-1287, 1362-1554, 2833-3297).  The reference
+# expresses every test with shapely boxes and an STRtree; all of them are axis-aligned rectangle
+# predicates, evaluated here directly on NumPy box arrays:
+#   STRtree.query(box)     -> rectangles whose closed extents meet (touching counts)
+#   box.contains(instance) -> the instance rectangle lies inside a non-degenerate box
+def _boxes_meeting(boxes: np.ndarray, q) -> np.ndarray:
+    b = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+    return np.flatnonzero((b[:, 0] <= q[2]) & (b[:, 2] >= q[0]) & (b[:, 1] <= q[3]) & (b[:, 3] >= q[1]))
+
+
+def _box_holds(q, box) -> bool:
+    return bool(q[2] > q[0] and q[3] > q[1] and q[0] <= box[0] and q[1] <= box[1] and q[2] >= box[2] and q[3] >= box[3])
+
+
+def get_full_output_locs_inside_mask(full_output_locs: np.ndarray, mask_bounds, output_shape):
+    """Output locations that meet the tissue bounding box, re-based to its top-left patch; the padding that
+    puts the region back into the slide; the region's (height, width) (ref. ``semantic_segmentor.py:1757-1802``)."""
+    locs = np.asarray(full_output_locs)
+    mx0, my0, mx1, my1 = mask_bounds
+    meets = ~((locs[:, 2] < mx0) | (locs[:, 0] > mx1) | (locs[:, 3] < my0) | (locs[:, 1] > my1))
+    inside = locs[meets].copy()
+    min_x, min_y = int(inside[:, 0].min()), int(inside[:, 1].min())
+    max_x, max_y = int(inside[:, 2].max()), int(inside[:, 3].max())
+    pad_bottom, pad_right = max(int(output_shape[0]) - max_y, 0), max(int(output_shape[1]) - max_x, 0)
+    inside -= np.array([min_x, min_y, min_x, min_y])
+    region = (int(output_shape[0]) - min_y - pad_bottom, int(output_shape[1]) - min_x - pad_right)
+    return inside, (min_x, min_y, pad_right, pad_bottom), region
+
+
+def apply_coordinate_offset(data_array: np.ndarray, offset, key, keys_to_shift=("centroid", "box", "contours")):
+    """Shift boxes (4-vectors) by (dx, dy, dx, dy) and points / polygons by (dx, dy) (ref. :3760-3829)."""
+    dx, dy = offset
+    if key not in keys_to_shift or (dx == 0 and dy == 0):
+        return data_array
+    out = np.empty(len(data_array), dtype=object)
+    for i, item in enumerate(data_array):
+        is_box = item.ndim == 1 and item.size == 4  # noqa: PLR2004
+        out[i] = (item + (np.array([dx, dy, dx, dy]) if is_box else np.array([dx, dy]))).astype(item.dtype)
+    return out
+
+
+def _tile_frames(width: int, height: int, margin: int):
+    """Per side (top, bottom, left, right): the margin band and the one-pixel boundary band of a tile."""
+    bands = [(0, 0, width, margin), (0, height - margin, width, height), (0, 0, margin, height),
+             (width - margin, 0, width, height)]
+    edges = [(0, 0, width, 1), (0, height - 1, width, height), (0, 0, 1, height), (width - 1, 0, width, height)]
+    return bands, edges
+
+
+def _get_margin_lines(margin: int, height: int, width: int, tile_tl) -> list:
+    """The four inner margin lines of a tile in slide coordinates, as degenerate rectangles (ref. :3023-3038)."""
+    tx, ty = int(tile_tl[0]), int(tile_tl[1])
+    lines = [(margin, margin, width - margin, margin), (margin, height - margin, width - margin, height - margin),
+             (margin, margin, margin, height - margin), (width - margin, margin, width - margin, height - margin)]
+    return [(a + tx, b + ty, c + tx, d + ty) for a, b, c, d in lines]
+
+
+def _get_sel_indices_margin_lines(ioconfig, tile_shape, tile_flag, tile_mode: int, tile_tl, inst_dict: dict):
+    """Indices of the tile's instances to discard, and the tile's margin lines (ref. :2944-3020).
+
+    Grid tiles (mode 0) and cross tiles (mode 3) drop instances that lie wholly inside a flagged margin band
+    (every band for mode 3); strip tiles (modes 1, 2) drop everything that meets the flagged sides' margin
+    band, or the boundary band of the unflagged sides.
+    """
+    if tile_mode not in (0, 1, 2, 3):
+        msg = f"Unknown tile mode {tile_mode}."
+        raise ValueError(msg)
+    margin = 0 if ioconfig.margin is None else int(ioconfig.margin)
+    width, height = (int(v) for v in tile_shape)
+    boxes = np.array([v["box"] for v in inst_dict.values()])
+    bands, edges = _tile_frames(width, height, margin)
+    lines = _get_margin_lines(margin, height, width, tile_tl)
+    picked: list[int] = []
+    if tile_mode in (0, 3):
+        for side, band in enumerate(bands):
+            if tile_flag[side] or tile_mode == 3:  # noqa: PLR2004
+                picked += [int(i) for i in _boxes_meeting(boxes, band) if _box_holds(band, boxes[i])]
+        return picked, lines
+    for side, flagged in enumerate(tile_flag):
+        picked += [int(i) for i in _boxes_meeting(boxes, bands[side] if flagged else edges[side])]
+    return picked, lines
+
+
+def retrieve_sel_uids(sel_indices: list, inst_dict: dict) -> list:
+    keys = list(inst_dict.keys()) if len(sel_indices) else []
+    return [keys[i] for i in sel_indices]
+
+
+def _move_tile_space_to_wsi_space(inst_dict: dict, tile_tl, remove_insts_in_tile: list) -> dict:
+    """Surviving instances, shifted to slide coordinates, under fresh unique keys (ref. :3041-3058)."""
+    dropped = set(remove_insts_in_tile)
+    shift = np.asarray(tile_tl)
+    moved = {}
+    for key, info in inst_dict.items():
+        if key in dropped:
+            continue
+        info["box"] = info["box"] + np.concatenate([shift, shift])
+        if "centroid" in info:
+            info["centroid"] = info["centroid"] + shift
+        info["contours"] = info["contours"] + shift.astype(info["contours"].dtype)
+        moved[uuid.uuid4().hex] = info
+    return moved
+
+
+def _compute_info_dict_for_merge(inst_dict: dict, tile_mode: int, ref_inst_info_dict: dict, ioconfig, tile_shape,
+                                 tile_tl, tile_flag):
+    """``(new instances in slide space, keys of accumulated instances to delete)`` for one tile (ref. :2833-2933,
+    3269-3296): cross tiles (mode 3) replace whatever already sits across their margin lines."""
+    if len(inst_dict) == 0:
+        return {}, []
+    picked, lines = _get_sel_indices_margin_lines(ioconfig, tile_shape, tile_flag, tile_mode, tile_tl, inst_dict)
+    moved = _move_tile_space_to_wsi_space(inst_dict, tile_tl, retrieve_sel_uids(picked, inst_dict))
+    if tile_mode != 3 or not ref_inst_info_dict:  # noqa: PLR2004
+        return moved, []
+    ref_boxes = np.array([v["box"] for v in ref_inst_info_dict.values()])
+    crossing = [int(i) for line in lines for i in _boxes_meeting(ref_boxes, line)]
+    return moved, retrieve_sel_uids(crossing, ref_inst_info_dict)
+
+
+def _get_inst_info_dicts(post_process_output) -> list:
+    """Column-wise ``info_dict`` of every task -> ``{1-based id: {key: value}}`` (ref. :3061-3083)."""
+    dicts = []
+    for out in post_process_output:
+        cols = out["info_dict"]
+        first = next(iter(cols))
+        dicts.append({i + 1: {k: v[i] for k, v in cols.items()} for i in range(len(cols[first]))})
+    return dicts
+
+
+def _update_tile_based_predictions_array(post_process_output, wsi_info_dict, bounds, offset, max_inst_value=None):
+    """Paste a tile's prediction map into the slide map; instance ids are shifted by the running maximum and
+    instances overlapping something already present are left out (ref. :3160-3212)."""
+    b = np.array(bounds)
+    b[:2] += np.asarray(offset)
+    b[2:] += np.asarray(offset)
+    x0, y0, x1, y1 = (int(v) for v in b)
+    for idx, out in enumerate(post_process_output):
+        full = wsi_info_dict[idx]["predictions"]
+        if full is None:
+            continue
+        x1, y1 = min(x1, full.shape[1]), min(y1, full.shape[0])
+        new = out["predictions"][0:y1 - y0, 0:x1 - x0]
+        if out["seg_type"] == "instance":
+            old = full[y0:y1, x0:x1]
+            clash = (new > 0) & (old > 0)
+            max_inst_value = 0 if max_inst_value is None else max_inst_value
+            keep = new > 0
+            if clash.any():
+                bad = np.unique(new[clash])
+                keep &= ~np.isin(new, bad[bad > 0])
+            merged = old.copy()
+            merged[keep] = new[keep] + max_inst_value
+            if keep.any():
+                max_inst_value = merged.max() + max_inst_value
+            new = merged
+        full[y0:y1, x0:x1] = new
+    return wsi_info_dict, max_inst_value
+
+
+def _build_tile_tasks(tile_info_sets: list) -> list:
+    return [(bounds, flags[i], mode) for mode, (all_bounds, flags) in enumerate(tile_info_sets)
+            for i, bounds in enumerate(all_bounds)]
+
+
+def _sides_on_region_border(boxes: np.ndarray, flags: np.ndarray, w: int, h: int) -> np.ndarray:
+    """Clear the flag of every tile side that lies on the border of the processed region."""
+    borders = [(0, 0, w, 0), (0, h, w, h), (0, 0, 0, h), (w, 0, w, h)]
+    for side, line in enumerate(borders):
+        flags[_boxes_meeting(boxes, line), side] = 0
+    return flags
 
 
 class MultiTaskSegmentor(EngineABC):
@@ -25,6 +205,8 @@ class MultiTaskSegmentor(EngineABC):
         super().__init__(model=model, batch_size=batch_size, num_workers=num_workers, weights=weights, device=device,
                          verbose=verbose)
         self.return_probabilities = False
+        self.mask_bounds = None
+        self.mask_padding = (0, 0, 0, 0)
         self.fold_batchnorm = False  # HoVer-Net's pre-activation BN->ReLU->conv order cannot be folded forwards
         self.tasks = set(getattr(self.model, "tasks", []))
 
@@ -61,6 +243,248 @@ class MultiTaskSegmentor(EngineABC):
         if self.return_probabilities:
             out["probabilities"] = [h.cpu().numpy() if isinstance(h, torch.Tensor) else h for h in heads]
         return out
+
+    # ------------------------------------------------------------------------------ WSI mode
+    def _get_tile_info(self, image_shape, wsi_proc_shape, mask_reader=None) -> list:
+        """Four tile sets with their removal flags (ref. :1362-1554): the regular grid, vertical seam strips,
+        horizontal seam strips and seam crossings.  ``image_shape`` = (width, height) of the processed region."""
+        cfg = self._ioconfig
+        margin = 0 if cfg.margin is None else int(cfg.margin)
+        out_shape = np.asarray(cfg.patch_output_shape)
+        tile_shape = (np.floor(np.asarray(cfg.tile_shape) / out_shape) * out_shape).astype(np.int32)
+        image_shape = np.asarray(image_shape)
+        boxes = PatchExtractor.get_coordinates(image_shape=image_shape, patch_input_shape=tile_shape,
+                                               patch_output_shape=tile_shape, stride_shape=tile_shape)[1]
+        shift = np.array([*self.mask_padding[:2], *self.mask_padding[:2]])
+        if mask_reader is not None:
+            boxes = boxes[PatchExtractor.filter_coordinates(mask_reader, boxes + shift, wsi_shape=wsi_proc_shape,
+                                                            min_mask_ratio=0)]
+        if np.all(image_shape <= tile_shape):
+            return [[boxes, np.zeros((len(boxes), 4), dtype=np.int32)]]
+        w, h = (int(v) for v in image_shape)
+        flag = _sides_on_region_border(boxes, np.ones((len(boxes), 4), dtype=np.int32), w, h)
+        sets = [[boxes, flag]]
+        bottom_right, top_right, bottom_left = boxes[:, 2:], boxes[:, [2, 1]], boxes[:, [0, 3]]
+        # vertical strips over the right seams
+        pick = np.flatnonzero(flag[:, 3])
+        strips = np.concatenate([top_right[pick] - [margin, 0], bottom_right[pick] + [margin, 0]], axis=-1)
+        sflag = np.zeros((len(strips), 4), dtype=np.int32)
+        sflag[:, [0, 1]] = 1
+        sets.append([strips, _sides_on_region_border(strips, sflag, w, h)])
+        # horizontal strips over the bottom seams
+        pick = np.flatnonzero(flag[:, 1])
+        strips = np.concatenate([bottom_left[pick] - [0, margin], bottom_right[pick] + [0, margin]], axis=-1)
+        sflag = np.zeros((len(strips), 4), dtype=np.int32)
+        sflag[:, [2, 3]] = 1
+        sets.append([strips, _sides_on_region_border(strips, sflag, w, h)])
+        # squares over the seam crossings
+        pick = np.flatnonzero(flag[:, 1] * flag[:, 3])
+        squares = np.concatenate([bottom_right[pick] - 2 * margin, bottom_right[pick] + 2 * margin], axis=-1)
+        sets.append([squares, np.ones((len(squares), 4), dtype=np.int32)])
+        return sets
+
+    def infer_wsi(self, reader: ArrayWSIReader, mask_reader: ArrayWSIReader | None = None) -> dict:
+        """Patch inference over the tissue region of one slide, every head stitched into one device map
+        (ref. :477-731).  Sets ``mask_bounds`` / ``mask_padding`` like the reference."""
+        from tiatoolbox_amd import _lib
+        from tiatoolbox_amd.models.engine.engine_abc import _DTYPES
+        from tiatoolbox_amd.models.engine.semantic_segmentor import _finalize, _row_merge
+
+        dev = torch.device(self.device)
+        if dev.type != "cuda":
+            msg = "WSI-mode stitching runs on the GPU (device='cuda'); there is no CPU fallback."
+            raise _lib.HipLibraryError(msg)
+        cfg = self._ioconfig
+        w, h = reader.slide_dimensions
+        in_b, out_b = PatchExtractor.get_coordinates(
+            patch_output_shape=tuple(cfg.patch_output_shape[::-1]), image_shape=(w, h),
+            patch_input_shape=tuple(cfg.patch_input_shape[::-1]), stride_shape=tuple(cfg.stride_shape[::-1]))
+        keep = np.ones(len(in_b), dtype=bool)
+        if mask_reader is not None:
+            keep = PatchExtractor.filter_coordinates(mask_reader, out_b, (w, h), min_mask_ratio=0)
+        if not keep.any():
+            self.mask_bounds, self.mask_padding = None, (0, 0, 0, 0)
+            return {"probabilities": None, "coordinates": out_b[keep]}
+        kept = out_b[keep]
+        self.mask_bounds = (kept[:, 0].min(), kept[:, 1].min(), kept[:, 2].max(), kept[:, 3].max())
+        inside, self.mask_padding, (rh, rw) = get_full_output_locs_inside_mask(out_b, self.mask_bounds, (h, w))
+        min_x, min_y = self.mask_padding[:2]
+        dtype = _DTYPES[str(self.compute_dtype).replace("torch.", "")]
+        model = self._inference_model(dtype)
+        infer_batch = self._get_model_attr("infer_batch")
+        oh = int(cfg.patch_output_shape[0])
+        heads: list[torch.Tensor] | None = None
+        prev: list | None = None   # per head (row, cnt, ys)
+        dummy = torch.zeros((rh, rw), dtype=torch.uint8, device=dev)
+        row_ys = np.unique(inside[:, 1])
+
+        for ri, ys in enumerate(row_ys.tolist()):
+            sel = np.flatnonzero(keep & (out_b[:, 1] - min_y == ys))
+            rows = None
+            if len(sel):
+                outs = [infer_batch(model, reader.read_bounds_batch(in_b[sel[s:s + self.batch_size]]), device=self.device)
+                        for s in range(0, len(sel), self.batch_size)]
+                blocks = [torch.cat([o[k] for o in outs]).float().contiguous() for k in range(len(outs[0]))]
+                if heads is None:
+                    heads = [torch.zeros((rh, rw, b.shape[-1]), dtype=torch.float32, device=dev) for b in blocks]
+                rows = [(*_row_merge(b, out_b[sel, 0] - min_x, rw), ys) for b in blocks]
+            if heads is None:
+                continue  # nothing inferred yet: the maps start as zeros
+            if rows is None:
+                rows = [(torch.zeros((oh, rw, hd.shape[-1]), dtype=torch.float32, device=dev),
+                         torch.zeros((oh, rw), dtype=torch.uint8, device=dev), ys) for hd in heads]
+            # the band [ys, next row): this row plus whatever the previous row still covers
+            y1 = min(int(row_ys[ri + 1]) if ri + 1 < len(row_ys) else ys + oh, rh)
+            for k, head in enumerate(heads):
+                cur = rows[k]
+                if prev is None:
+                    _finalize(cur[0], cur[1], cur[2], None, None, 0, ys, y1, head, dummy)
+                else:
+                    _finalize(prev[k][0], prev[k][1], prev[k][2], cur[0], cur[1], cur[2], ys, y1, head, dummy)
+            prev = rows
+        return {"probabilities": heads, "coordinates": kept}
+
+    def _postproc_maps(self, maps: list[torch.Tensor], offset=(0, 0)) -> tuple[dict, ...]:
+        """The model's ``postproc`` on device-resident head maps; ``predictions`` come back as NumPy."""
+        model = self.model.module if hasattr(self.model, "module") else self.model
+        out = model.postproc(list(maps), offset=offset)
+        for task in out:
+            if isinstance(task.get("predictions"), torch.Tensor):
+                task["predictions"] = task["predictions"].cpu().numpy()
+        return out
+
+    def _process_full_wsi(self, probabilities, *, return_predictions=None):
+        """One ``postproc`` over the whole processed region (ref. :999-1076)."""
+        outs = self._postproc_maps(probabilities, offset=tuple(int(v) for v in self.mask_padding[:2]))
+        flags = [False] * len(outs) if return_predictions is None else list(return_predictions)
+        pad_left, pad_top, pad_right, pad_bottom = (int(v) for v in self.mask_padding)
+        for task, wanted in zip(outs, flags):
+            if not wanted:
+                del task["predictions"]
+            else:
+                task["predictions"] = np.pad(task["predictions"], ((pad_top, pad_bottom), (pad_left, pad_right)))
+        return outs
+
+    def _process_tile_mode(self, probabilities, wsi_proc_shape, mask_reader=None, *, return_predictions=None):
+        """Post-process tile by tile and merge across the seams (ref. :1078-1287)."""
+        rh, rw = probabilities[0].shape[:2]
+        tile_sets = self._get_tile_info((rw, rh), wsi_proc_shape, mask_reader)
+        tasks = _build_tile_tasks(tile_sets)
+        ioconfig = self._ioconfig.to_baseline()
+        model = self.model.module if hasattr(self.model, "module") else self.model
+        # every tile's post-processing first: tiles of one shape go through the batched device pipeline together
+        results: list = [None] * len(tasks)
+        by_shape: dict[tuple[int, int], list[int]] = {}
+        clipped = []
+        for i, (b, _, _) in enumerate(tasks):
+            # slicing past the region's end truncates the tile, exactly like the reference's array slicing (:1344-1350)
+            x0, y0, x1, y1 = max(int(b[0]), 0), max(int(b[1]), 0), min(int(b[2]), rw), min(int(b[3]), rh)
+            clipped.append((x0, y0, x1, y1))
+            by_shape.setdefault((y1 - y0, x1 - x0), []).append(i)
+        chunk = max(1, int(getattr(self, "tile_batch", 8)))
+        for members in by_shape.values():
+            for s in range(0, len(members), chunk):
+                part = members[s:s + chunk]
+                crops = [torch.stack([p[clipped[i][1]:clipped[i][3], clipped[i][0]:clipped[i][2]] for i in part])
+                         for p in probabilities]
+                if hasattr(model, "postproc_batch"):
+                    outs = model.postproc_batch(crops[0], crops[1], crops[2] if len(crops) > 2 else None)  # noqa: PLR2004
+                    for j, i in enumerate(part):
+                        results[i] = (outs[j],)
+                else:
+                    for j, i in enumerate(part):
+                        results[i] = self._postproc_maps([c[j] for c in crops])
+        # then the merge, in the reference's tile order
+        wsi_info, max_inst = None, None
+        for (bounds, flag, mode), out in zip(tasks, results):
+            if wsi_info is None:
+                flags = [False] * len(out) if return_predictions is None else list(return_predictions)
+                wsi_info = tuple({"task_type": t["task_type"],
+                                  "predictions": np.zeros(tuple(wsi_proc_shape[::-1]), dtype=t["predictions"].dtype)
+                                  if flags[k] else None, "info_dict": {}} for k, t in enumerate(out))
+            wsi_info, max_inst = _update_tile_based_predictions_array(out, wsi_info, bounds, self.mask_padding[:2], max_inst)
+            tl, br = np.asarray(bounds[:2]), np.asarray(bounds[2:])
+            for k, inst_dict in enumerate(_get_inst_info_dicts(out)):
+                fresh, stale = _compute_info_dict_for_merge(inst_dict, mode, wsi_info[k]["info_dict"], ioconfig, br - tl, tl, flag)
+                wsi_info[k]["info_dict"].update(fresh)
+                for key in stale:
+                    wsi_info[k]["info_dict"].pop(key, None)
+        return self._inst_dict_for_dask_processing(wsi_info)
+
+    def _inst_dict_for_dask_processing(self, wsi_info_dict, keys_to_shift=("centroid", "box", "contours")):
+        """Row-wise instance records -> one object array per key, shifted back into slide coordinates
+        (ref. :1289-1329; NumPy arrays instead of dask arrays)."""
+        offset = np.array(self.mask_padding[:2])
+        for task in wsi_info_dict or ():
+            records = list(task["info_dict"].values())
+            cols = {}
+            for key in (records[0] if records else {}):
+                col = np.empty(len(records), dtype=object)
+                for i, rec in enumerate(records):
+                    col[i] = rec[key]
+                cols[key] = apply_coordinate_offset(col, offset, key, keys_to_shift)
+            task["info_dict"] = cols
+        return wsi_info_dict
+
+    def post_process_wsi(self, raw_predictions: dict, wsi_proc_shape, mask_reader=None, *, return_predictions=None) -> dict:
+        """Full-region or tile-mode post-processing, organised per task (ref. :836-997)."""
+        probabilities = raw_predictions["probabilities"]
+        tile_h, tile_w = self._ioconfig.tile_shape
+        if any(p.shape[0] > tile_h or p.shape[1] > tile_w for p in probabilities):
+            outs = self._process_tile_mode(probabilities, wsi_proc_shape, mask_reader, return_predictions=return_predictions)
+        else:
+            outs = self._process_full_wsi(probabilities, return_predictions=return_predictions)
+        self.tasks = set()
+        for task in outs or ():
+            name = task["task_type"]
+            self.tasks.add(name)
+            raw_predictions[name] = {}
+            for key, value in task.items():
+                if key == "task_type":
+                    continue
+                if isinstance(value, np.ndarray):
+                    raw_predictions[name][key] = value
+                elif isinstance(value, dict):
+                    raw_predictions[name].update(value)
+        return raw_predictions
+
+    def run(self, images, *, masks=None, patch_mode: bool = True, ioconfig=None, return_predictions=None, **kwargs):
+        """Patch mode: ``EngineABC.run``.  WSI mode: ``images`` = list of ``ArrayWSIReader`` / HxWx3 arrays; one dict per
+        slide with the task's instance table (``box`` / ``centroid`` / ``contours`` / ``prob`` / ``type``), the
+        patch ``coordinates`` and, on request, ``predictions`` / ``probabilities``."""
+        if patch_mode:
+            return super().run(images, masks=masks, patch_mode=True, ioconfig=ioconfig, **kwargs)
+        self._update_run_params(images, **{k: v for k, v in kwargs.items() if k in ("return_labels", "return_probabilities")})
+        if not isinstance(images, (list, tuple)):
+            msg = "Input must be a list of file paths or a numpy array."
+            raise TypeError(msg)
+        self._validate_input_numbers(images=images, masks=masks)
+        self._ioconfig = self._load_ioconfig(ioconfig=ioconfig)
+        self.model = self.model.to(device=self.device)
+        results = []
+        for i, image in enumerate(images):
+            reader = image if isinstance(image, ArrayWSIReader) else ArrayWSIReader(image)
+            mask_reader = None
+            if masks is not None:
+                m = masks[i]
+                mask_reader = m if isinstance(m, ArrayWSIReader) else ArrayWSIReader(m, mode="bool")
+            elif kwargs.get("auto_get_mask", True):
+                mask_reader = reader.tissue_mask(resolution=1.25, units="power")
+            raw = self.infer_wsi(reader, mask_reader)
+            if raw["probabilities"] is None:
+                results.append({"coordinates": raw["coordinates"]})
+                continue
+            out = self.post_process_wsi(raw, reader.slide_dimensions, mask_reader, return_predictions=return_predictions)
+            heads = out.pop("probabilities")
+            if self.return_probabilities:
+                pad_left, pad_top, pad_right, pad_bottom = (int(v) for v in self.mask_padding)
+                out["probabilities"] = [np.pad(p.cpu().numpy(), ((pad_top, pad_bottom), (pad_left, pad_right), (0, 0)))
+                                        for p in heads]
+            if len(self.tasks) == 1:  # single task: its table moves to the top level (ref. :1695-1704)
+                out.update(out.pop(next(iter(self.tasks))))
+                out.pop("seg_type", None)
+            results.append(out)
+        return results
 
     def save_predictions(self, processed_predictions: dict, output_type: str, **_):
         """Single task: the task dict is flattened into the top level, ``seg_type`` dropped (ref. :1695-1704)."""
