@@ -129,3 +129,61 @@ def test_tile_mode_on_device_matches_reference(gold, tag):
     assert np.array_equal(np.array([v["box"] for v in info.values()]), np.array(list(full[0]["info_dict"]["box"])))
     pl, pt, pr, pb = eng.mask_padding
     assert np.array_equal(full[0]["predictions"], np.pad(inst, ((pt, pb), (pl, pr))))
+
+
+@pytest.mark.gpu
+def test_wsi_mode_end_to_end():
+    """run(patch_mode=False): tissue-masked patch grid -> stitched head maps -> post-processing.  The stitched
+    maps equal the engine's own patch outputs placed at their output locations (stride == output shape for
+    HoVer-Net, so no averaging), and the instance table equals the oracle's on those maps (full-region mode)
+    or the tile merge with oracle tiles (tile mode)."""
+    from tiatoolbox_amd.models.engine.multi_task_segmentor import MultiTaskSegmentor
+    from tiatoolbox_amd.tools.patchextraction import PatchExtractor
+    from tiatoolbox_amd.utils import synth
+    from tiatoolbox_amd.wsicore import ArrayWSIReader
+
+    slide = np.full((900, 1150, 3), 244, np.uint8)
+    tissue = synth.g_he(12, 256, 256, seed=23)
+    for k, (y, x) in enumerate([(100, 150), (100, 406), (356, 150), (356, 406), (356, 662), (560, 800)]):
+        slide[y:y + 256, x:x + 256] = tissue[k]
+    eng = MultiTaskSegmentor("hovernet_fast-pannuke", batch_size=4, device="cuda")
+    reader = ArrayWSIReader(slide)
+    out = eng.run([reader], patch_mode=False, return_probabilities=True, return_predictions=(True,))[0]
+    assert {"box", "centroid", "contours", "prob", "type", "predictions", "probabilities", "coordinates"} <= set(out)
+    assert out["predictions"].shape == (900, 1150)
+    npm, hv, tp = out["probabilities"]
+    assert npm.shape == (900, 1150, 1) and hv.shape == (900, 1150, 2) and tp.shape == (900, 1150, 1)
+    # placement check against the engine's own per-patch inference
+    mask_reader = reader.tissue_mask(resolution=1.25, units="power")
+    cfg = eng._ioconfig  # noqa: SLF001
+    in_b, out_b = PatchExtractor.get_coordinates(patch_output_shape=tuple(cfg.patch_output_shape[::-1]),
+                                                 image_shape=reader.slide_dimensions,
+                                                 patch_input_shape=tuple(cfg.patch_input_shape[::-1]),
+                                                 stride_shape=tuple(cfg.stride_shape[::-1]))
+    keep = PatchExtractor.filter_coordinates(mask_reader, out_b, reader.slide_dimensions, min_mask_ratio=0)
+    assert 0 < keep.sum() < len(keep)
+    assert np.array_equal(out["coordinates"], out_b[keep])
+    patches = reader.read_bounds_batch(in_b[keep]).cpu().numpy()
+    per_patch = eng.run(patches, patch_mode=True, return_probabilities=True)["probabilities"]
+    pl, pt = eng.mask_padding[:2]
+    for j, (x0, y0, x1, y1) in enumerate(out_b[keep]):
+        ye, xe = min(y1, 900), min(x1, 1150)
+        np.testing.assert_allclose(npm[y0:ye, x0:xe], per_patch[0][j][:ye - y0, :xe - x0], atol=2e-3)
+        np.testing.assert_allclose(hv[y0:ye, x0:xe], per_patch[1][j][:ye - y0, :xe - x0], atol=2e-2, rtol=1e-2)
+    assert not npm[:pt].any() and not npm[:, :pl].any()
+    # post-processing == oracle on the region the engine processed (900 x 1150 exceeds no 1024 tile? width does)
+    region = [p[pt:900 - eng.mask_padding[3], pl:1150 - eng.mask_padding[2]] for p in (npm, hv, tp)]
+    rh, rw = region[0].shape[:2]
+    if rh <= 1024 and rw <= 1024:
+        inst = oh.proc_np_hv(region[0], region[1])
+        info = oh.get_instance_info(inst, np.around(region[2]).astype("uint8")[..., 0], offset=(pl, pt))
+        assert np.array_equal(np.array(list(out["box"])).reshape(-1, 4), np.array([v["box"] for v in info.values()]).reshape(-1, 4))
+    else:
+        ref_eng = MultiTaskSegmentor.__new__(MultiTaskSegmentor)
+        ref_eng.model, ref_eng._ioconfig, ref_eng.mask_padding, ref_eng.verbose = _OracleHoVerNet(), cfg, eng.mask_padding, False  # noqa: SLF001
+        exp = ref_eng._process_tile_mode([torch.from_numpy(np.ascontiguousarray(r)) for r in region],  # noqa: SLF001
+                                         reader.slide_dimensions, mask_reader, return_predictions=(True,))
+        assert np.array_equal(np.array(list(out["box"])).reshape(-1, 4),
+                              np.array(list(exp[0]["info_dict"]["box"])).reshape(-1, 4))
+        assert np.array_equal(out["predictions"], exp[0]["predictions"])
+    assert len(out["box"]) == len(out["contours"]) == len(out["type"]) == len(out["prob"])

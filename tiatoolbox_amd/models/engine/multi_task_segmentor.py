@@ -454,7 +454,11 @@ class MultiTaskSegmentor(EngineABC):
         patch ``coordinates`` and, on request, ``predictions`` / ``probabilities``."""
         if patch_mode:
             return super().run(images, masks=masks, patch_mode=True, ioconfig=ioconfig, **kwargs)
-        self._update_run_params(images, **{k: v for k, v in kwargs.items() if k in ("return_labels", "return_probabilities")})
+        if kwargs.get("return_labels"):
+            msg = "`return_labels` is not supported for MultiTaskSegmentor."
+            raise ValueError(msg)  # ref. :2149-2156
+        for key, val in kwargs.items():
+            setattr(self, key, val)
         if not isinstance(images, (list, tuple)):
             msg = "Input must be a list of file paths or a numpy array."
             raise TypeError(msg)
