@@ -131,59 +131,74 @@ def test_tile_mode_on_device_matches_reference(gold, tag):
     assert np.array_equal(full[0]["predictions"], np.pad(inst, ((pt, pb), (pl, pr))))
 
 
+def _stub_hovernet():
+    """HoVer-Net whose heads are a deterministic function of the input pixels (random weights give no nuclei):
+    np = darkness of the centre crop, hv = patch-local ramps modulated by darkness, tp = 1 + (darkness > 0.8)."""
+    from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
+
+    class _Stub(HoVerNet):
+        @staticmethod
+        def infer_batch(model, batch_data, *, device):  # noqa: ARG004
+            x = torch.as_tensor(batch_data).to(device).float()
+            dark = (1.0 - x.mean(-1) / 255.0)[:, 46:210, 46:210]
+            ramp = torch.linspace(-1, 1, 164, device=dark.device)
+            hv = torch.stack([ramp[None, None, :] * dark, ramp[None, :, None] * dark], dim=-1)
+            return dark[..., None].contiguous(), hv.contiguous(), (1.0 + (dark > 0.8).float())[..., None].contiguous()
+
+    return _Stub(num_types=6, mode="fast")
+
+
 @pytest.mark.gpu
 def test_wsi_mode_end_to_end():
     """run(patch_mode=False): tissue-masked patch grid -> stitched head maps -> post-processing.  The stitched
-    maps equal the engine's own patch outputs placed at their output locations (stride == output shape for
-    HoVer-Net, so no averaging), and the instance table equals the oracle's on those maps (full-region mode)
-    or the tile merge with oracle tiles (tile mode)."""
+    maps equal the per-patch outputs placed at their output locations (stride == output shape for HoVer-Net, so
+    no averaging), and the instance table equals the merge driven by the oracle's post-processing of the same
+    maps (tile mode: the region is wider than one 1024 tile)."""
+    from tiatoolbox_amd.models.architecture import get_pretrained_model
     from tiatoolbox_amd.models.engine.multi_task_segmentor import MultiTaskSegmentor
     from tiatoolbox_amd.tools.patchextraction import PatchExtractor
     from tiatoolbox_amd.utils import synth
     from tiatoolbox_amd.wsicore import ArrayWSIReader
 
-    slide = np.full((900, 1150, 3), 244, np.uint8)
+    rng = np.random.default_rng(5)
+    slide = np.full((900, 1300, 3), 244, np.uint8)
     tissue = synth.g_he(12, 256, 256, seed=23)
-    for k, (y, x) in enumerate([(100, 150), (100, 406), (356, 150), (356, 406), (356, 662), (560, 800)]):
+    yy, xx = np.mgrid[0:900, 0:1300]
+    for k, (y, x) in enumerate([(100, 30), (100, 286), (356, 30), (356, 286), (356, 542), (560, 1000), (300, 1000)]):
         slide[y:y + 256, x:x + 256] = tissue[k]
-    eng = MultiTaskSegmentor("hovernet_fast-pannuke", batch_size=4, device="cuda")
+        for _ in range(14):
+            cy, cx, r = rng.integers(y + 8, y + 248), rng.integers(x + 8, x + 248), rng.integers(5, 10)
+            slide[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 25
+    cfg = get_pretrained_model("hovernet_fast-pannuke")[1]
+    eng = MultiTaskSegmentor(_stub_hovernet(), batch_size=4, device="cuda")
     reader = ArrayWSIReader(slide)
-    out = eng.run([reader], patch_mode=False, return_probabilities=True, return_predictions=(True,))[0]
+    out = eng.run([reader], patch_mode=False, ioconfig=cfg, return_probabilities=True, return_predictions=(True,))[0]
     assert {"box", "centroid", "contours", "prob", "type", "predictions", "probabilities", "coordinates"} <= set(out)
-    assert out["predictions"].shape == (900, 1150)
+    assert out["predictions"].shape == (900, 1300) and len(out["box"]) > 30
     npm, hv, tp = out["probabilities"]
-    assert npm.shape == (900, 1150, 1) and hv.shape == (900, 1150, 2) and tp.shape == (900, 1150, 1)
-    # placement check against the engine's own per-patch inference
+    assert npm.shape == (900, 1300, 1) and hv.shape == (900, 1300, 2) and tp.shape == (900, 1300, 1)
     mask_reader = reader.tissue_mask(resolution=1.25, units="power")
-    cfg = eng._ioconfig  # noqa: SLF001
-    in_b, out_b = PatchExtractor.get_coordinates(patch_output_shape=tuple(cfg.patch_output_shape[::-1]),
-                                                 image_shape=reader.slide_dimensions,
-                                                 patch_input_shape=tuple(cfg.patch_input_shape[::-1]),
-                                                 stride_shape=tuple(cfg.stride_shape[::-1]))
+    in_b, out_b = PatchExtractor.get_coordinates(patch_output_shape=(164, 164), image_shape=reader.slide_dimensions,
+                                                 patch_input_shape=(256, 256), stride_shape=(164, 164))
     keep = PatchExtractor.filter_coordinates(mask_reader, out_b, reader.slide_dimensions, min_mask_ratio=0)
     assert 0 < keep.sum() < len(keep)
     assert np.array_equal(out["coordinates"], out_b[keep])
-    patches = reader.read_bounds_batch(in_b[keep]).cpu().numpy()
-    per_patch = eng.run(patches, patch_mode=True, return_probabilities=True)["probabilities"]
-    pl, pt = eng.mask_padding[:2]
+    heads = eng.model.infer_batch(eng.model, reader.read_bounds_batch(in_b[keep]), device="cuda")
     for j, (x0, y0, x1, y1) in enumerate(out_b[keep]):
-        ye, xe = min(y1, 900), min(x1, 1150)
-        np.testing.assert_allclose(npm[y0:ye, x0:xe], per_patch[0][j][:ye - y0, :xe - x0], atol=2e-3)
-        np.testing.assert_allclose(hv[y0:ye, x0:xe], per_patch[1][j][:ye - y0, :xe - x0], atol=2e-2, rtol=1e-2)
+        ye, xe = min(y1, 900), min(x1, 1300)
+        for got, ref in zip((npm, hv, tp), heads):
+            assert np.array_equal(got[y0:ye, x0:xe], ref[j].cpu().numpy()[:ye - y0, :xe - x0])
+    pl, pt, pr, pb = eng.mask_padding
     assert not npm[:pt].any() and not npm[:, :pl].any()
-    # post-processing == oracle on the region the engine processed (900 x 1150 exceeds no 1024 tile? width does)
-    region = [p[pt:900 - eng.mask_padding[3], pl:1150 - eng.mask_padding[2]] for p in (npm, hv, tp)]
-    rh, rw = region[0].shape[:2]
-    if rh <= 1024 and rw <= 1024:
-        inst = oh.proc_np_hv(region[0], region[1])
-        info = oh.get_instance_info(inst, np.around(region[2]).astype("uint8")[..., 0], offset=(pl, pt))
-        assert np.array_equal(np.array(list(out["box"])).reshape(-1, 4), np.array([v["box"] for v in info.values()]).reshape(-1, 4))
-    else:
-        ref_eng = MultiTaskSegmentor.__new__(MultiTaskSegmentor)
-        ref_eng.model, ref_eng._ioconfig, ref_eng.mask_padding, ref_eng.verbose = _OracleHoVerNet(), cfg, eng.mask_padding, False  # noqa: SLF001
-        exp = ref_eng._process_tile_mode([torch.from_numpy(np.ascontiguousarray(r)) for r in region],  # noqa: SLF001
-                                         reader.slide_dimensions, mask_reader, return_predictions=(True,))
-        assert np.array_equal(np.array(list(out["box"])).reshape(-1, 4),
-                              np.array(list(exp[0]["info_dict"]["box"])).reshape(-1, 4))
-        assert np.array_equal(out["predictions"], exp[0]["predictions"])
-    assert len(out["box"]) == len(out["contours"]) == len(out["type"]) == len(out["prob"])
+    region = [np.ascontiguousarray(p[pt:900 - pb, pl:1300 - pr]) for p in (npm, hv, tp)]
+    assert region[0].shape[1] > 1024  # tile mode
+    ref_eng = MultiTaskSegmentor.__new__(MultiTaskSegmentor)
+    ref_eng.model, ref_eng._ioconfig, ref_eng.mask_padding, ref_eng.verbose = _OracleHoVerNet(), cfg, eng.mask_padding, False  # noqa: SLF001
+    exp = ref_eng._process_tile_mode([torch.from_numpy(r) for r in region], reader.slide_dimensions, mask_reader,  # noqa: SLF001
+                                     return_predictions=(True,))[0]
+    assert np.array_equal(np.array(list(out["box"])).reshape(-1, 4), np.array(list(exp["info_dict"]["box"])).reshape(-1, 4))
+    assert np.array_equal(np.concatenate(list(out["contours"])), np.concatenate(list(exp["info_dict"]["contours"])))
+    assert [int(t) for t in out["type"]] == [int(t) for t in exp["info_dict"]["type"]]
+    assert np.array_equal(out["predictions"], exp["predictions"])
+    with pytest.raises(ValueError, match="return_labels"):
+        eng.run([reader], patch_mode=False, ioconfig=cfg, return_labels=True)
