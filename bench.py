@@ -109,6 +109,29 @@ def cpu_baseline(target, patches, model_cpu, sample: int) -> dict:
     }
 
 
+def pmc_traffic(kernel_substr: str) -> dict | None:
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this round
+    (``scripts/final_profile.sh``: FETCH_SIZE and WRITE_SIZE in separate runs, same 4096 x 224^2 workload).
+    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the bytes actually read -- calibrated here
+    on the apply kernels, whose reads are known: 2 x 301.6 MB = the 616.6 MB input -- WRITE_SIZE is taken as is."""
+    import re
+
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = sorted((ROOT / "profiles").glob(f"*_stain_pmc_{counter}.txt"))
+        if not files:
+            return None
+        for line in files[-1].read_text().splitlines():
+            m = re.search(rf"{counter} mean=\s*([0-9.]+) n=\s*\d+\s+(.*)", line)
+            if m and kernel_substr in m.group(2):
+                vals[counter] = float(m.group(1)) * 1024.0
+                vals["file_" + counter] = files[-1].name
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return {"bytes": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
+            "source": f"profiles/{vals['file_FETCH_SIZE']} (x2, gfx950) + profiles/{vals['file_WRITE_SIZE']}"}
+
+
 def main() -> None:
     args = parse()
     import numpy as np
@@ -236,7 +259,7 @@ def main() -> None:
     roofline = {
         "kernel": dominant, "bound": "hbm", "achieved": round(dk["achieved_GBs"], 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(dk["frac"], 5), "traffic": None,
-        "launch_ms": round(dk["seconds"] * 1e3, 4),
+        "algorithmic_bytes": dk["alg_bytes"], "launch_ms": round(dk["seconds"] * 1e3, 4),
         "other_kernels": {
             name: {"bound": "hbm", "achieved": round(k["achieved_GBs"], 2), "unit": "GB/s",
                    "frac": round(k["frac"], 5), "launch_ms": round(k["seconds"] * 1e3, 4)}
@@ -246,6 +269,10 @@ def main() -> None:
                      "unit": "TFLOP/s", "frac": round(flops / t_cnn / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5),
                      "ms": round(t_cnn * 1e3, 3)},
     }
+    pmc = pmc_traffic(dominant.split("(")[0]) if (n, hw) == (4096, 224) else None
+    if pmc is not None:  # PMC passes cannot run inside the timed process; they are this round's committed profile
+        roofline["traffic"] = round(pmc["bytes"])
+        roofline["traffic_source"] = pmc["source"]
     total = n * world_size * args.steps
     line = {
         "metric": "patches/s, Macenko stain-norm + resnet18 PatchPredictor (synthetic patch batches)",

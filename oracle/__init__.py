@@ -25,7 +25,13 @@ Pinning status
 * pinned to the reference's *Python-level* logic by executing the real reference
   modules from ``/root/reference`` with only the absent third-party primitives
   shimmed (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``).
-* the OpenCV / scikit-image primitives themselves (``cv2.cvtColor`` RGB<->LAB 8-bit,
-  ``cv2.Sobel`` ...) are **parity unpinned** against the real libraries: they are not
+  Fixtures: stain (Macenko / Vahadane / Ruifrok / Custom / augment), maskers, HoVer-Net
+  ``_proc_np_hv`` + ``get_instance_info`` (incl. contour polygons), patch grids + canvas merges,
+  Reinhard, and the WSI tile-mode merge of instance predictions (tile sets, margin rules, id
+  stitching: the reference's own functions driven like ``_process_tile_mode`` drives them).
+* the OpenCV / scikit-image / shapely primitives themselves (``cv2.cvtColor`` RGB<->LAB 8-bit,
+  ``cv2.Sobel``, ``cv2.findContours`` [``cvref.first_contour``: Suzuki-Abe border following with
+  structural known answers], ``skimage.segmentation.watershed``, shapely ``box`` / ``STRtree``
+  [``geomref.py``] ...) are **parity unpinned** against the real libraries: they are not
   installable here.  Every constant in ``cvref.py`` says where it comes from.
 """

@@ -326,12 +326,73 @@ __global__ __launch_bounds__(BT) void area_filter_kernel(int* __restrict__ label
 }
 
 // ---- binary morphology -------------------------------------------------------------------------------------
+// Small structuring elements (every |dx| <= 4, at most 16 rows): the element is folded into one bit mask per
+// row; a lane produces 4 adjacent output pixels from 3 aligned dword loads per element row (12 input bytes
+// compressed to 12 window bits) instead of one byte load per element entry and pixel.  Anything else takes the
+// generic per-entry loop.  Outside the image: dilate sees 0, erode sees 1 (OpenCV's default border).
 __global__ __launch_bounds__(BT) void morph_kernel(const uint8_t* __restrict__ src, int h, int w,
-                                                    const int* __restrict__ offs, int n_off, int op,
+                                                    const int* __restrict__ offs, int n_off, int op, int vec_ok,
                                                     uint8_t* __restrict__ dst) {
+    __shared__ int s_dy[16];
+    __shared__ unsigned s_mask[16];  // bit (dx + 4) set <=> (dy, dx) belongs to the element
+    __shared__ int s_rows, s_fast;
+    if (threadIdx.x == 0) {
+        int rows = 0, fast = vec_ok;
+        for (int k = 0; k < n_off && fast; ++k) {
+            const int dy = offs[2 * k], dx = offs[2 * k + 1];
+            if (dx < -4 || dx > 4) { fast = 0; break; }
+            int r = 0;
+            while (r < rows && s_dy[r] != dy) ++r;
+            if (r == rows) {
+                if (rows == 16) { fast = 0; break; }
+                s_dy[rows] = dy;
+                s_mask[rows] = 0u;
+                ++rows;
+            }
+            s_mask[r] |= 1u << (dx + 4);
+        }
+        s_rows = rows;
+        s_fast = fast;
+    }
+    __syncthreads();
     const long hw = (long)h * w;
     const uint8_t* s = src + (size_t)blockIdx.y * hw;
     uint8_t* d = dst + (size_t)blockIdx.y * hw;
+    if (s_fast) {
+        const int wq = w >> 2, rows = s_rows;
+        const long nq = (long)h * wq;
+        const uint32_t* sq = reinterpret_cast<const uint32_t*>(s);
+        uint32_t* dq = reinterpret_cast<uint32_t*>(d);
+        for (long q = (long)blockIdx.x * BT + threadIdx.x; q < nq; q += (long)gridDim.x * BT) {
+            const int y = (int)(q / wq), xq = (int)(q - (long)y * wq);
+            unsigned any4 = 0u, all4 = 0xfu;
+            for (int r = 0; r < rows; ++r) {
+                const int yy = y + s_dy[r];
+                if (yy < 0 || yy >= h) continue;
+                const uint32_t* row = sq + (long)yy * wq;
+                unsigned win = 0u, valid = 0u;  // bit i <-> column 4*xq - 4 + i
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int c = xq - 1 + k;
+                    if (c < 0 || c >= wq) continue;
+                    const uint32_t v = row[c];
+                    const uint32_t t = ((((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) >> 7) & 0x01010101u;  // byte != 0
+                    win |= ((t * 0x01020408u) >> 24) << (4 * k);
+                    valid |= 0xfu << (4 * k);
+                }
+                const unsigned m = s_mask[r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned sel = m << j;  // element bits aligned to the window for output pixel j
+                    if (win & sel) any4 |= 1u << j;
+                    if ((~win & valid) & sel) all4 &= ~(1u << j);
+                }
+            }
+            const unsigned res = op == 0 ? any4 : all4;
+            dq[q] = (res & 1u) | ((res & 2u) << 7) | ((res & 4u) << 14) | ((res & 8u) << 21);
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * BT + threadIdx.x; i < hw; i += (long)gridDim.x * BT) {
         const int y = (int)(i / w), x = (int)(i - (long)y * w);
         bool any = false, all = true;
@@ -431,8 +492,9 @@ extern "C" int tia_binary_morph_u8(const uint8_t* d_src, int64_t n, int64_t h, i
     if (!d_src || !d_dst || !d_offsets || n_off <= 0 || (op != 0 && op != 1)) return TIA_EINVAL;
     if (bad3(n, h, w)) return TIA_ESIZE;
     dim3 grid(nblocks((long)h * w, BT, 4096), (unsigned)n);
+    const int vec_ok = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_dst)) & 3) == 0;
     hipLaunchKernelGGL(morph_kernel, grid, dim3(BT), 0, (hipStream_t)stream, d_src, (int)h, (int)w, d_offsets, n_off,
-                       op, d_dst);
+                       op, vec_ok, d_dst);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
