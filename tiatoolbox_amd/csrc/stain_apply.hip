@@ -506,6 +506,22 @@ __global__ __launch_bounds__(AT) void stain_augment_kernel(const uint8_t* __rest
     }
     __syncthreads();
     const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
+    if constexpr (MASK_ONLY) {
+        // 4 pixels per lane: three dword loads in, one dword of mask bytes out
+        if ((hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(src);
+            uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)patch * (size_t)hw);
+            auto tis = [&](uint32_t r, uint32_t g, uint32_t b) -> uint32_t {
+                return (((ty[0][r] + ty[1][g] + ty[2][b] + (1 << 11)) >> 12) < y_thr) ? 1u : 0u;
+            };
+            for (long g4 = (long)blockIdx.x * AT + threadIdx.x; g4 < (hw >> 2); g4 += (long)gridDim.x * AT) {
+                const uint32_t a = q[g4 * 3], b = q[g4 * 3 + 1], c = q[g4 * 3 + 2];
+                o[g4] = tis(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u) | (tis(a >> 24, b & 255u, (b >> 8) & 255u) << 8) |
+                        (tis((b >> 16) & 255u, b >> 24, c & 255u) << 16) | (tis((c >> 8) & 255u, (c >> 16) & 255u, c >> 24) << 24);
+            }
+            return;
+        }
+    }
     for (long i = (long)blockIdx.x * AT + threadIdx.x; i < hw; i += (long)gridDim.x * AT) {
         const uint32_t r = src[3 * i], g = src[3 * i + 1], b = src[3 * i + 2];
         const int t = ty[0][r] + ty[1][g] + ty[2][b];

@@ -197,9 +197,10 @@ class EngineABC:
             m = m.to(dtype=dtype) if dtype != torch.float32 else m
             if torch.device(self.device).type == "cuda":
                 m = m.to(memory_format=torch.channels_last)
-                # fixed patch shape and batch size: let MIOpen search its solvers once per convolution shape
-                # (resnet18 fp16, 1024 x 224^2: 43 -> 36 ms per pass on MI355X)
-                torch.backends.cudnn.benchmark = bool(getattr(self, "miopen_find", True))
+                # `miopen_find=True` (run kwarg / attribute): let MIOpen search its solvers once per convolution
+                # shape -- worth it for long runs at one batch shape (resnet18 fp16, 1024 x 224^2: 43 -> 36 ms per
+                # pass on MI355X), costly when batch sizes vary (every new shape is searched again), so off by default
+                torch.backends.cudnn.benchmark = bool(getattr(self, "miopen_find", False))
             m.eval()
             self._fast_model, self._fast_key = m, key
         return self._fast_model
