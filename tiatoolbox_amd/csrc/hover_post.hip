@@ -404,6 +404,182 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
     }  // labels of this lane
 }
 
+// ---- watershed, one WAVE per blob ----------------------------------------------------------------------------------
+// Same priority flood, but a whole wave owns one blob: lane 0 runs the (inherently sequential) algorithm and does
+// every global access -- so ordering is plain single-thread program order -- while the 64 lanes together are the
+// register file of the heap's top six levels (node i lives in lane i; v_readlane / a one-lane write instead of a
+// memory round trip per sift step).  Control flow is wave-uniform: everything lane 0 loads is broadcast with
+// v_readfirstlane.  Nodes >= 64 spill to the blob's global segment.  Many more waves are resident than with one
+// lane per blob, which is what hides the remaining neighbour-load latency.
+__device__ __forceinline__ int bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double bcast0(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ int lane_get(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double lane_get(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+__global__ __launch_bounds__(64) void ws_flood_wave_kernel(const int* __restrict__ blob, const double* __restrict__ dist,
+                                                            const int* __restrict__ areas, const int* __restrict__ offs,
+                                                            const int* __restrict__ count, const int* __restrict__ bbox, int h,
+                                                            int w, int min_keep, HeapItem* __restrict__ heaps,
+                                                            int* __restrict__ inst) {
+    const long hw = (long)h * w;
+    const int plane = blockIdx.x;  // plane fastest: consecutive workgroups (= consecutive XCDs) take different planes
+    const int lane = threadIdx.x;
+    const int n_labels = count[plane];
+    for (int label = blockIdx.y + 1; label <= n_labels; label += gridDim.y) {
+        const int area = areas[(size_t)plane * (hw + 1) + label];
+        if (area < min_keep) continue;
+        const size_t off = (size_t)plane * hw;
+        const int* bl = blob + off;
+        const double* ds = dist + off;
+        int* out = inst + off;
+        HeapItem* glob = heaps + off + offs[(size_t)plane * (hw + 1) + label];
+        double hv = 0.0;  // this lane's heap node
+        int ha = 0, hx = 0;
+        auto hget = [&](int i) -> HeapItem {
+            HeapItem e;
+            if (i < 64) {
+                e.value = lane_get(hv, i);
+                e.age = lane_get(ha, i);
+                e.index = lane_get(hx, i);
+            } else {
+                double v = 0.0;
+                int a = 0, x = 0;
+                if (lane == 0) {
+                    const HeapItem g = glob[i];
+                    v = g.value;
+                    a = g.age;
+                    x = g.index;
+                }
+                e.value = bcast0(v);
+                e.age = bcast0(a);
+                e.index = bcast0(x);
+            }
+            return e;
+        };
+        auto hput = [&](int i, const HeapItem& e) {
+            if (i < 64) {
+                if (lane == i) {
+                    hv = e.value;
+                    ha = e.age;
+                    hx = e.index;
+                }
+            } else if (lane == 0) {
+                glob[i] = e;
+            }
+        };
+        auto heap_push = [&](int& items, const HeapItem& e) {  // skimage heap_general.pxi: append + sift up
+            int pos = items++;
+            while (pos > 0) {
+                const int parent = (pos - 1) >> 1;
+                const HeapItem p = hget(parent);
+                if (!heap_smaller(e, p)) break;
+                hput(pos, p);
+                pos = parent;
+            }
+            hput(pos, e);
+        };
+        auto heap_pop = [&](int& items) {  // root out, last item to the root, smaller child up to a leaf, sift back
+            const HeapItem top = hget(0);
+            --items;
+            if (items == 0) return top;
+            const HeapItem last = hget(items);
+            int pos = 0, child = 1;
+            while (child < items) {
+                const int right = child + 1;
+                HeapItem c = hget(child);
+                if (right < items) {
+                    const HeapItem r = hget(right);
+                    if (!heap_smaller(c, r)) {
+                        child = right;
+                        c = r;
+                    }
+                }
+                hput(pos, c);
+                pos = child;
+                child = 2 * pos + 1;
+            }
+            while (pos > 0) {
+                const int parent = (pos - 1) >> 1;
+                const HeapItem p = hget(parent);
+                if (!heap_smaller(last, p)) break;
+                hput(pos, p);
+                pos = parent;
+            }
+            hput(pos, last);
+            return top;
+        };
+        const int* bb = bbox + ((size_t)plane * (hw + 1) + label) * 4;
+        const int y0 = bb[0], y1 = bb[1], x0 = bb[2], x1 = bb[3];
+        int items = 0, age = 0;
+        // initial queue: marker pixels of the blob in raster order, age 0.  64 pixels of a row are examined at once;
+        // the hits are pushed in lane (= raster) order.
+        for (int y = y0; y <= y1; ++y) {
+            for (int xb = x0; xb <= x1; xb += 64) {
+                const int x = xb + lane;
+                const long i = (long)y * w + x;
+                const bool hit = x <= x1 && bl[i] == label && out[i] > 0;
+                const double val = hit ? ds[i] : 0.0;
+                unsigned long long m = __ballot(hit);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    HeapItem e;
+                    e.value = lane_get(val, src);
+                    e.age = 0;
+                    e.index = (int)((long)y * w + xb + src);
+                    heap_push(items, e);
+                }
+            }
+        }
+        if (items == 0) {  // a blob without markers stays background
+            for (int y = y0; y <= y1; ++y)
+                for (int x = x0 + lane; x <= x1; x += 64) {
+                    const long i = (long)y * w + x;
+                    if (bl[i] == label) out[i] = 0;
+                }
+            continue;
+        }
+        while (items > 0) {
+            const HeapItem e = heap_pop(items);
+            const int y = e.index / w, x = e.index - y * w;
+            int lab = 0, st[4] = {0, 0, 0, 0};
+            double dv[4] = {0.0, 0.0, 0.0, 0.0};
+            long ni[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // up, left, right, down (skimage's raveled offsets)
+                const int yy = y + (j == 0 ? -1 : (j == 3 ? 1 : 0));
+                const int xx = x + (j == 1 ? -1 : (j == 2 ? 1 : 0));
+                const bool inb = yy >= 0 && yy < h && xx >= 0 && xx < w;
+                ni[j] = inb ? (long)yy * w + xx : (long)e.index;
+            }
+            if (lane == 0) {  // all nine loads in flight together
+                lab = out[e.index];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    st[j] = ni[j] != (long)e.index ? out[ni[j]] : 0;
+                    dv[j] = ds[ni[j]];
+                }
+            }
+            lab = bcast0(lab);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (bcast0(st[j]) != -1) continue;  // outside the mask, or labelled already
+                ++age;
+                if (lane == 0) out[ni[j]] = lab;
+                HeapItem ne;
+                ne.value = bcast0(dv[j]);
+                ne.age = age;
+                ne.index = (int)ni[j];
+                heap_push(items, ne);
+            }
+        }
+    }
+}
+
 // ---- instance statistics ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HT) void inst_stats_init_kernel(long long* __restrict__ stats, long n_entries) {
     for (long i = (long)blockIdx.x * HT + threadIdx.x; i < n_entries; i += (long)gridDim.x * HT) {
@@ -605,8 +781,19 @@ extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, in
     const long max_labels = hw / 2 + 2;
     long fx = (max_labels + 63) / 64, fcap = 65536 / n > 4 ? 65536 / n : 4;  // lanes stride over labels beyond the cap
     dim3 fgrid((unsigned)n, (unsigned)(fx < fcap ? fx : fcap));
-    hipLaunchKernelGGL(ws_flood_kernel, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w, 10,
-                       heaps, d_inst);
+    static const int wave_per_blob = [] {
+        const char* e = getenv("TIA_FLOOD_WAVE");  // developer switch: 0 = one lane per blob
+        return e ? atoi(e) : 1;
+    }();
+    if (wave_per_blob) {
+        long wy = max_labels < 4096 ? max_labels : 4096, wcap = 262144 / n > 16 ? 262144 / n : 16;
+        dim3 wgrid((unsigned)n, (unsigned)(wy < wcap ? wy : wcap));
+        hipLaunchKernelGGL(ws_flood_wave_kernel, wgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h,
+                           (int)w, 10, heaps, d_inst);
+    } else {
+        hipLaunchKernelGGL(ws_flood_kernel, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w,
+                           10, heaps, d_inst);
+    }
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
