@@ -276,3 +276,46 @@ def test_nucleus_instance_segmentor_patch_mode():
             assert [int(t) for t in out["type"][i]] == [v["type"] for v in info.values()]
     with pytest.raises(ValueError, match="return_labels"):
         eng.run(patches, patch_mode=True, return_labels=True)
+
+
+def test_columnar_instance_table_equals_per_instance_assembly():
+    """Host assembly used by the batched engine path (NumPy columns) == the per-instance restatement of
+    hovernet.py:670-748, including type ties, the background runner-up rule and the <3-vertex drop rule."""
+    from tiatoolbox_amd.models.architecture import _hover_device as hd
+
+    rng = np.random.default_rng(11)
+    m, t = 200, 6
+    stats = np.zeros((m + 1, 8), np.int64)
+    types = np.zeros((m + 1, t), np.int32)
+    meta = np.zeros((m + 1, 4), np.int32)
+    chunks, first = [], 0
+    for i in range(1, m + 1):
+        if rng.random() < 0.1:
+            continue  # absent id
+        x0, y0 = rng.integers(0, 500, 2)
+        bw, bh = rng.integers(1, 40, 2)
+        area = int(rng.integers(1, bw * bh + 1))
+        stats[i, :7] = [area, x0, y0, x0 + bw - 1, y0 + bh - 1, area * x0 + rng.integers(0, area * bw), area * y0 + rng.integers(0, area * bh)]
+        votes = rng.multinomial(area, rng.dirichlet(np.ones(t) * 0.4))
+        if rng.random() < 0.3:   # force ties / background wins
+            votes[:] = 0
+            votes[0] = area // 2
+            votes[rng.integers(1, t)] = area - area // 2
+        types[i] = votes
+        npts = int(rng.integers(1, 12))
+        meta[i] = [x0, y0, npts, first]
+        chunks.append(rng.integers(0, 600, (npts, 2)).astype(np.int32))
+        first += npts
+    points = np.concatenate(chunks)
+    for offset in ((0, 0), (17, 400)):
+        for use_types in (True, False):
+            ty = types if use_types else None
+            info = hd.info_from_stats(stats, ty, offset, meta=meta, points=points)
+            table = hd.table_from_stats(stats, ty, offset, meta=meta, points=points)
+            assert list(info) == table["ids"].tolist() and len(info) > 50
+            assert np.array_equal(table["box"], np.array([v["box"] for v in info.values()]))
+            np.testing.assert_array_equal(table["centroid"], np.array([v["centroid"] for v in info.values()]))
+            for j, v in enumerate(info.values()):
+                assert np.array_equal(table["contours"][j], v["contours"]) and table["contours"][j].dtype == np.int32
+                assert table["type"][j] == v["type"] and table["prob"][j] == v["prob"]
+    assert hd.table_from_stats(np.zeros((3, 8), np.int64), None) is None

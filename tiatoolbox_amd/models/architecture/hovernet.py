@@ -327,6 +327,14 @@ class HoVerNet(ModelABC):
         stats_h = stats.cpu().numpy()
         types_h = types.cpu().numpy() if types is not None else None
         inst_h = inst.cpu().numpy()
-        return [self._pack(inst_h[i], hd.info_from_stats(stats_h[i], types_h[i] if types_h is not None else None,
-                                                         meta=meta[i], points=points))
-                for i in range(inst.shape[0])]
+        outs = []
+        for i in range(inst.shape[0]):  # column-wise assembly: no per-instance Python arithmetic
+            table = hd.table_from_stats(stats_h[i], types_h[i] if types_h is not None else None, meta=meta[i], points=points)
+            outs.append(self._pack_table(inst_h[i], table))
+        return outs
+
+    def _pack_table(self, pred_inst, table: dict | None) -> dict:
+        if table is None:
+            return self._pack(pred_inst, {})
+        cols = {k: table[k] for k in ("box", "centroid", "contours", "prob", "type")}
+        return {"task_type": self.tasks[0], "predictions": pred_inst, "info_dict": cols, "seg_type": "instance"}

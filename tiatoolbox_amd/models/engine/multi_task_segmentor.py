@@ -490,6 +490,8 @@ class MultiTaskSegmentor(EngineABC):
             results.append(out)
         return results
 
+    predict = run  # tiatoolbox 1.x name
+
     def save_predictions(self, processed_predictions: dict, output_type: str, **_):
         """Single task: the task dict is flattened into the top level, ``seg_type`` dropped (ref. :1695-1704)."""
         return {k: v for k, v in processed_predictions.items() if k not in self.drop_keys}
