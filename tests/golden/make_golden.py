@@ -218,6 +218,25 @@ def tile_goldens() -> None:
         out[f"{tag}_prob"] = np.array([r["prob"] for r in recs])
         out[f"{tag}_pred"] = wsi_info[0]["predictions"]
         print(tag, "tiles per set", [len(b) for b, _ in sets], "instances", len(recs), "max id", int(wsi_info[0]["predictions"].max()))
+    # tile sets under a tissue mask (tiles whose box holds no mask pixel are dropped before the seam sets are built)
+    wsr = _ref_import("tiatoolbox.wsicore.wsireader")
+    rng = np.random.default_rng(9)
+    for k, (rw, rh, tile, margin, pad) in enumerate([(2600, 2100, 700, 64, (120, 60, 0, 0)), (1900, 3000, 1024, 128, (0, 0, 0, 0))]):
+        cfg = ioc.IOInstanceSegmentorConfig(input_resolutions=[res], output_resolutions=[res, res, res],
+                                            patch_input_shape=[256, 256], patch_output_shape=[164, 164],
+                                            stride_shape=[164, 164], margin=margin, tile_shape=[tile, tile])
+        wsi_shape = (rw + pad[0], rh + pad[1])
+        mask = (rng.random((wsi_shape[1] // 32, wsi_shape[0] // 32)) < 0.012).astype(np.uint8)
+        reader = object.__new__(wsr.VirtualWSIReader)
+        reader.img = mask
+        fake = SimpleNamespace(_ioconfig=cfg, mask_padding=pad,
+                               dataloader=SimpleNamespace(dataset=SimpleNamespace(mask_reader=reader)))
+        sets = mts.MultiTaskSegmentor._get_tile_info(fake, image_shape=(rw, rh), wsi_proc_shape=wsi_shape)
+        out[f"masked{k}_cfg"] = np.array([rw, rh, tile, margin, *pad])
+        out[f"masked{k}_mask"] = mask
+        for si, (b, f) in enumerate(sets):
+            out[f"masked{k}_set{si}_bounds"], out[f"masked{k}_set{si}_flags"] = np.asarray(b).reshape(-1, 4), np.asarray(f).reshape(-1, 4)
+        print("masked", k, "tiles per set", [len(b) for b, _ in sets])
     # region bookkeeping of infer_wsi
     rng = np.random.default_rng(0)
     for k in range(4):

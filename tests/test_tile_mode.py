@@ -202,3 +202,26 @@ def test_wsi_mode_end_to_end():
     assert np.array_equal(out["predictions"], exp["predictions"])
     with pytest.raises(ValueError, match="return_labels"):
         eng.run([reader], patch_mode=False, ioconfig=cfg, return_labels=True)
+
+
+def test_tile_sets_under_a_tissue_mask_match_reference(gold):
+    """``_get_tile_info`` with a mask reader: grid tiles without tissue are dropped (in slide coordinates, i.e. after
+    the padding offset) before the seam strips / crossings are derived from the survivors."""
+    class _Mask:
+        def __init__(self, img):
+            self.img = img
+
+    for k in range(2):
+        rw, rh, tile, margin, *pad = (int(v) for v in gold[f"masked{k}_cfg"])
+        res = {"units": "mpp", "resolution": 0.25}
+        eng = mts.MultiTaskSegmentor.__new__(mts.MultiTaskSegmentor)
+        eng._ioconfig = IOInstanceSegmentorConfig(  # noqa: SLF001
+            input_resolutions=[res], output_resolutions=[res, res, res], patch_input_shape=[256, 256],
+            patch_output_shape=[164, 164], stride_shape=[164, 164], margin=margin, tile_shape=[tile, tile])
+        eng.mask_padding = tuple(pad)
+        sets = eng._get_tile_info((rw, rh), (rw + pad[0], rh + pad[1]), _Mask(gold[f"masked{k}_mask"]))  # noqa: SLF001
+        assert len(sets) == 4
+        for si, (bounds, flags) in enumerate(sets):
+            assert np.array_equal(np.asarray(bounds).reshape(-1, 4), gold[f"masked{k}_set{si}_bounds"]), (k, si)
+            assert np.array_equal(np.asarray(flags).reshape(-1, 4), gold[f"masked{k}_set{si}_flags"]), (k, si)
+        assert len(sets[0][0]) < len(eng._get_tile_info((rw, rh), (rw + pad[0], rh + pad[1]))[0][0])  # noqa: SLF001
