@@ -198,7 +198,7 @@ def _sides_on_region_border(boxes: np.ndarray, flags: np.ndarray, w: int, h: int
 
 
 class MultiTaskSegmentor(EngineABC):
-    """Multi-task (here: nuclei instance) segmentation, patch mode (ref. :229-3829)."""
+    """Multi-task (here: nuclei instance) segmentation in patch and WSI mode (ref. :229-3829)."""
 
     def __init__(self, model, batch_size: int = 8, num_workers: int = 0, weights=None, *, device: str = "cpu",
                  verbose: bool = True) -> None:
