@@ -53,3 +53,99 @@ def test_all_gather_and_engine_world2(tmp_path, n):
     single = PatchPredictor("resnet18-kather100k", batch_size=5).run(
         synth.g_he(5, 64, 64, seed=4), patch_mode=True, return_probabilities=True, patch_input_shape=(64, 64))
     np.testing.assert_allclose(p0, single["probabilities"], atol=1e-6)
+
+
+# ------------------------------------------------------------------ instance tables across ranks
+class _CpuInstanceNet(torch.nn.Module):
+    """Deterministic two-head 'network' + oracle post-processing: lets the patch-sharded instance engine run on CPU
+    (the real post-processing needs the GPU) so that the ragged all-gather of instance tables can be checked."""
+
+    tasks = ("nuclei_segmentation",)
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+        self.preproc_func = lambda img: img
+        self.postproc_func = self.postproc
+
+    @staticmethod
+    def infer_batch(model, batch_data, *, device):  # noqa: ARG004
+        x = torch.as_tensor(batch_data).float()
+        dark = (1.0 - x.mean(-1) / 255.0)[:, 8:56, 8:56]
+        ramp = torch.linspace(-1, 1, 48)
+        hv = torch.stack([ramp[None, None, :] * dark, ramp[None, :, None] * dark], dim=-1)
+        return dark[..., None].contiguous(), hv.contiguous(), (1.0 + (dark > 0.8).float())[..., None].contiguous()
+
+    def postproc(self, raw_maps, offset=(0, 0)):
+        from oracle import hovernet as oh
+        from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
+
+        npm, hv, tp = (np.asarray(m) for m in raw_maps)
+        inst = oh.proc_np_hv(npm, hv)
+        info = oh.get_instance_info(inst, np.around(tp).astype("uint8")[..., 0], offset)
+        return (HoVerNet._pack(self, inst, info),)  # noqa: SLF001
+
+
+def _instance_patches() -> np.ndarray:
+    rng = np.random.default_rng(17)
+    patches = np.full((5, 64, 64, 3), 235, np.uint8)
+    yy, xx = np.mgrid[0:64, 0:64]
+    for k in range(5):
+        for _ in range(k):  # patch 0 stays empty: an empty table must survive the gather
+            cy, cx, r = rng.integers(14, 50), rng.integers(14, 50), rng.integers(4, 8)
+            patches[k][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 20
+    return patches
+
+
+def _run_instance_engine():
+    from tiatoolbox_amd.models.engine.io_config import IOInstanceSegmentorConfig
+    from tiatoolbox_amd.models.engine.multi_task_segmentor import MultiTaskSegmentor
+
+    res = {"units": "baseline", "resolution": 1.0}
+    cfg = IOInstanceSegmentorConfig(input_resolutions=[res], output_resolutions=[res, res, res], patch_input_shape=[64, 64],
+                                    patch_output_shape=[48, 48], stride_shape=[48, 48], margin=8, tile_shape=[96, 96])
+    eng = MultiTaskSegmentor(_CpuInstanceNet(), batch_size=2, device="cpu")
+    return eng.run(_instance_patches(), patch_mode=True, ioconfig=cfg, return_probabilities=True)
+
+
+def _inst_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import pickle
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    tdist.init_from_env("gloo")
+    out = _run_instance_engine()
+    with open(os.path.join(out_dir, f"inst{rank}.pkl"), "wb") as fh:
+        pickle.dump(out, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _same_tables(a: dict, b: dict) -> None:
+    assert set(a) == set(b)
+    assert np.array_equal(a["predictions"], b["predictions"])
+    for k in range(len(a["box"])):
+        assert len(a["box"][k]) == len(b["box"][k])
+        if len(a["box"][k]) == 0:
+            continue
+        assert np.array_equal(np.asarray(a["box"][k], dtype=np.int64), np.asarray(b["box"][k], dtype=np.int64))
+        np.testing.assert_array_equal(np.asarray(a["centroid"][k], dtype=np.float64), np.asarray(b["centroid"][k], dtype=np.float64))
+        assert [int(t) for t in a["type"][k]] == [int(t) for t in b["type"][k]]
+        assert [float(p) for p in a["prob"][k]] == [float(p) for p in b["prob"][k]]
+        for ca, cb in zip(a["contours"][k], b["contours"][k]):
+            assert np.array_equal(ca, cb) and ca.dtype == np.int32
+    for ha, hb in zip(a["probabilities"], b["probabilities"]):
+        assert np.array_equal(ha, hb)
+
+
+def test_instance_tables_gathered_across_ranks(tmp_path):
+    """MultiTaskSegmentor patch mode, world_size 2 (gloo): every rank post-processes its own shard; label maps and the
+    ragged instance tables (incl. an empty one and polygons of different lengths) are all-gathered in input order."""
+    import pickle
+
+    port = 29900 + (os.getpid() % 150)
+    mp.spawn(_inst_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    single = _run_instance_engine()
+    assert sum(len(b) for b in single["box"]) >= 5 and len(single["box"][0]) == 0
+    for rank in range(2):
+        with open(tmp_path / f"inst{rank}.pkl", "rb") as fh:
+            _same_tables(pickle.load(fh), single)  # noqa: S301

@@ -68,3 +68,81 @@ def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     out = torch.empty((world_size * per, *local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, pad.contiguous())
     return out[:n_total]
+
+
+def all_gather_ragged(local: torch.Tensor) -> tuple[torch.Tensor, list[int]]:
+    """Concatenate per-rank tensors of different length along dim 0, in rank order.
+
+    One fixed-size ``all_gather`` of the lengths, then one ``all_gather_into_tensor`` of the payload padded to the
+    longest shard.  Returns ``(concatenated, lengths per rank)``; ``(local, [len])`` when not distributed.
+    """
+    if not is_distributed():
+        return local, [int(local.shape[0])]
+    _, world_size = world()
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    lens = torch.empty(world_size, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(lens, n_local)
+    lens_h = [int(v) for v in lens.cpu().tolist()]
+    per = max(max(lens_h), 1)
+    pad = torch.zeros((per, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world_size * per, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    parts = [out[r * per: r * per + lens_h[r]] for r in range(world_size)]
+    return torch.cat(parts), lens_h
+
+
+_TABLE_KEYS = ("box", "centroid", "contours", "prob", "type")
+
+
+def gather_instance_tables(tables: list[dict], device: torch.device) -> list[dict]:
+    """All-gather per-patch instance tables (``box`` / ``centroid`` / ``contours`` / ``prob`` / ``type`` columns)
+    of patch-sharded post-processing, SURVEY section 8(e): counts first, then the flat payloads -- instance counts per
+    patch, boxes, centroids, types, probabilities, polygon lengths and one packed vertex list.  Every rank gets the
+    tables of all patches in input order (shards are contiguous and gathered in rank order)."""
+    import numpy as np
+
+    if not is_distributed():
+        return tables
+    n_inst = [len(t["box"]) for t in tables]
+    k = sum(n_inst)
+
+    def col(key, shape, dtype, conv=None):
+        rows = [np.asarray(conv(t[key]) if conv else t[key]).reshape(-1, *shape) for t, c in zip(tables, n_inst) if c]
+        return np.concatenate(rows).astype(dtype) if rows else np.zeros((0, *shape), dtype)
+
+    none_to = lambda fill: (lambda c: [fill if v is None else v for v in c])  # noqa: E731
+    polys = [p for t, c in zip(tables, n_inst) if c for p in t["contours"]]
+    payload = {
+        "count": np.asarray(n_inst, np.int64).reshape(-1),
+        "box": col("box", (4,), np.int64),
+        "centroid": col("centroid", (2,), np.float64),
+        "type": col("type", (), np.int64, none_to(-1)),
+        "prob": col("prob", (), np.float64, none_to(float("nan"))),
+        "polylen": np.asarray([len(p) for p in polys], np.int64).reshape(-1),
+        "poly": np.concatenate(polys).astype(np.int32) if polys else np.zeros((0, 2), np.int32),
+    }
+    assert payload["box"].shape[0] == k
+    got = {name: all_gather_ragged(torch.from_numpy(np.ascontiguousarray(arr)).to(device))[0].cpu().numpy()
+           for name, arr in payload.items()}
+    out, i0, p0 = [], 0, 0
+    for c in got["count"].tolist():
+        if c == 0:
+            empty = np.empty(shape=0)
+            out.append({key: empty for key in _TABLE_KEYS})
+            continue
+        lens = got["polylen"][i0:i0 + c]
+        contours = np.empty(c, dtype=object)
+        for j, m in enumerate(lens.tolist()):
+            contours[j] = got["poly"][p0:p0 + m]
+            p0 += m
+        types = np.empty(c, dtype=object)
+        probs = np.empty(c, dtype=object)
+        for j in range(c):
+            tv, pv = int(got["type"][i0 + j]), float(got["prob"][i0 + j])
+            types[j] = None if tv < 0 else tv
+            probs[j] = None if pv != pv else pv
+        out.append({"box": got["box"][i0:i0 + c], "centroid": got["centroid"][i0:i0 + c], "contours": contours,
+                    "prob": probs, "type": types})
+        i0 += c
+    return out

@@ -316,16 +316,20 @@ class EngineABC:
         multi_head = isinstance(outs[0], tuple)
         heads = list(zip(*outs)) if multi_head else [outs]
         gathered = []
+        # engines that post-process their own shard (instance segmentation) gather results, not raw head maps
+        gather_now = world_size > 1 and getattr(self, "gather_raw_predictions", True)
         for chunks in heads:
             chunks = [c if isinstance(c, torch.Tensor) else torch.from_numpy(np.asarray(c)) for c in chunks]
             local = torch.cat(chunks)
-            if world_size > 1:
+            if gather_now:
                 if torch.device(self.device).type == "cuda":
                     local = local.to(self.device)
                 local = tdist.all_gather_rows(local, n)
             gathered.append(local)
         local = tuple(gathered) if multi_head else gathered[0]
         raw_predictions = {"probabilities": local}
+        if world_size > 1 and not gather_now:
+            raw_predictions["shard"] = (lo, hi, n)
         if self.return_labels and dataloader.labels is not None:
             raw_predictions["labels"] = np.asarray(dataloader.labels).reshape(-1)
         if return_coordinates:

@@ -208,6 +208,9 @@ class MultiTaskSegmentor(EngineABC):
         self.mask_bounds = None
         self.mask_padding = (0, 0, 0, 0)
         self.fold_batchnorm = False  # HoVer-Net's pre-activation BN->ReLU->conv order cannot be folded forwards
+        # multi-process runs: every rank post-processes its own patch shard and the instance tables are gathered
+        #  instead of gathering the raw head maps and post-processing everything everywhere
+        self.gather_raw_predictions = False
         self.tasks = set(getattr(self.model, "tasks", []))
 
     def _update_run_params(self, images, **kwargs):
@@ -236,10 +239,23 @@ class MultiTaskSegmentor(EngineABC):
         out: dict = {}
         task = results[0]["task_type"] if results else "nuclei_segmentation"
         self.tasks = {task}
-        out["predictions"] = (np.stack([r["predictions"] for r in results]) if results
-                              else np.empty((0,), dtype=np.int32))
+        preds = (np.stack([r["predictions"] for r in results]) if results else np.empty((0,), dtype=np.int32))
+        tables = [r["info_dict"] for r in results]
+        if "shard" in raw_predictions:  # patch-sharded run: gather label maps and instance tables in input order
+            from tiatoolbox_amd import distributed as tdist
+
+            dev = heads[0].device if isinstance(heads[0], torch.Tensor) else torch.device("cpu")
+            _, _, n_total = raw_predictions["shard"]
+            side = tuple(heads[0].shape[1:3])
+            local = torch.from_numpy(np.ascontiguousarray(preds.reshape(-1, *side).astype(np.int32))).to(dev)
+            preds = tdist.all_gather_rows(local, n_total).cpu().numpy()
+            tables = tdist.gather_instance_tables(tables, dev)
+            if self.return_probabilities:
+                heads = [tdist.all_gather_rows(h if isinstance(h, torch.Tensor) else torch.from_numpy(np.asarray(h)), n_total)
+                         for h in heads]
+        out["predictions"] = preds
         for key in ("box", "centroid", "contours", "prob", "type"):
-            out[key] = [r["info_dict"][key] for r in results]
+            out[key] = [t[key] for t in tables]
         if self.return_probabilities:
             out["probabilities"] = [h.cpu().numpy() if isinstance(h, torch.Tensor) else h for h in heads]
         return out
