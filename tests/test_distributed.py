@@ -149,3 +149,35 @@ def test_instance_tables_gathered_across_ranks(tmp_path):
     for rank in range(2):
         with open(tmp_path / f"inst{rank}.pkl", "rb") as fh:
             _same_tables(pickle.load(fh), single)  # noqa: S301
+
+
+def _tile_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import pickle
+
+    import test_tile_mode as ttm
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    tdist.init_from_env("gloo")
+    gold = np.load(ttm.GOLD / "tile_golden.npz")
+    eng, heads, _, wsi_shape = ttm._engine(gold, "a", ttm._OracleHoVerNet())  # noqa: SLF001
+    eng.distributed = True
+    out = eng._process_tile_mode([torch.from_numpy(h) for h in heads], wsi_shape, None, return_predictions=(True,))  # noqa: SLF001
+    with open(os.path.join(out_dir, f"tile{rank}.pkl"), "wb") as fh:
+        pickle.dump(out[0], fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_mode_sharded_across_ranks_matches_reference(tmp_path):
+    """WSI tile mode, world_size 2 (gloo): the 25 tiles are post-processed half per rank, tables and tile label maps
+    are gathered, and both ranks end with the table the REAL reference produces (tile_golden 'a')."""
+    import pickle
+
+    import test_tile_mode as ttm
+
+    port = 30100 + (os.getpid() % 150)
+    mp.spawn(_tile_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    gold = np.load(ttm.GOLD / "tile_golden.npz")
+    for rank in range(2):
+        with open(tmp_path / f"tile{rank}.pkl", "rb") as fh:
+            ttm._check_table(pickle.load(fh), gold, "a")  # noqa: S301, SLF001

@@ -398,7 +398,17 @@ class MultiTaskSegmentor(EngineABC):
             clipped.append((x0, y0, x1, y1))
             by_shape.setdefault((y1 - y0, x1 - x0), []).append(i)
         chunk = max(1, int(getattr(self, "tile_batch", 8)))
+        # multi-process runs shard the tiles (round-robin inside every shape group); the merge below is sequential and
+        # cheap, so every rank repeats it on the gathered tile results and ends with the same tables
+        from tiatoolbox_amd import distributed as tdist
+
+        rank, world = tdist.world() if getattr(self, "distributed", True) else (0, 1)
+        owned: list[list[int]] = [[] for _ in range(world)]
         for members in by_shape.values():
+            for j, i in enumerate(members):
+                owned[j % world].append(i)
+        for members in by_shape.values():
+            members = [i for j, i in enumerate(members) if j % world == rank]
             for s in range(0, len(members), chunk):
                 part = members[s:s + chunk]
                 crops = [torch.stack([p[clipped[i][1]:clipped[i][3], clipped[i][0]:clipped[i][2]] for i in part])
@@ -410,6 +420,9 @@ class MultiTaskSegmentor(EngineABC):
                 else:
                     for j, i in enumerate(part):
                         results[i] = self._postproc_maps([c[j] for c in crops])
+        if world > 1:
+            results = self._gather_tile_results(results, [sorted(o) for o in owned], rank, clipped, probabilities[0].device,
+                                                want_predictions=bool(return_predictions) and any(return_predictions))
         # then the merge, in the reference's tile order
         wsi_info, max_inst = None, None
         for (bounds, flag, mode), out in zip(tasks, results):
@@ -426,6 +439,37 @@ class MultiTaskSegmentor(EngineABC):
                 for key in stale:
                     wsi_info[k]["info_dict"].pop(key, None)
         return self._inst_dict_for_dask_processing(wsi_info)
+
+    def _gather_tile_results(self, results, owned, rank, clipped, device, *, want_predictions: bool):
+        """Exchange per-tile post-processing results between ranks (single-task models): instance tables through the
+        ragged gather of ``distributed.gather_instance_tables``, tile label maps (only when a slide-sized prediction
+        map is requested) as one flat int32 payload split by the tile shapes every rank knows."""
+        from tiatoolbox_amd import distributed as tdist
+
+        model = self.model.module if hasattr(self.model, "module") else self.model
+        task_type = model.tasks[0]
+        mine = owned[rank]
+        if any(len(results[i]) != 1 for i in mine):
+            msg = "Tile sharding across processes supports single-task models."
+            raise NotImplementedError(msg)
+        tables = tdist.gather_instance_tables([results[i][0]["info_dict"] for i in mine], device)
+        order = [i for tiles in owned for i in tiles]
+        preds: dict[int, np.ndarray] = {}
+        if want_predictions:
+            flat = (np.concatenate([np.asarray(results[i][0]["predictions"], dtype=np.int32).ravel() for i in mine])
+                    if mine else np.zeros(0, np.int32))
+            full = tdist.all_gather_ragged(torch.from_numpy(np.ascontiguousarray(flat)).to(device))[0].cpu().numpy()
+            pos = 0
+            for i in order:
+                x0, y0, x1, y1 = clipped[i]
+                size = (y1 - y0) * (x1 - x0)
+                preds[i] = full[pos:pos + size].reshape(y1 - y0, x1 - x0)
+                pos += size
+        out: list = [None] * len(results)
+        for k, i in enumerate(order):
+            out[i] = ({"task_type": task_type, "predictions": preds.get(i, np.zeros((0, 0), np.int32)),
+                       "info_dict": tables[k], "seg_type": "instance"},)
+        return out
 
     def _inst_dict_for_dask_processing(self, wsi_info_dict, keys_to_shift=("centroid", "box", "contours")):
         """Row-wise instance records -> one object array per key, shifted back into slide coordinates
