@@ -65,3 +65,33 @@ def test_no_cpu_fallback_without_gpu():
     norm = get_normalizer("macenko")
     with pytest.raises(_lib.HipLibraryError):
         norm.fit(np.zeros((8, 8, 3), np.uint8))
+
+
+def test_package_level_names_of_the_reference_layout():
+    """``s/tiatoolbox/tiatoolbox_amd/`` in a pipeline's imports must resolve for the covered path
+    (reference ``tiatoolbox/__init__.py``, ``models/__init__.py``, ``tools/__init__.py``, ``utils/__init__.py``)."""
+    import importlib
+    import sys
+
+    import tiatoolbox_amd
+
+    assert tiatoolbox_amd.logger.name == "tiatoolbox_amd" and tiatoolbox_amd.__version__
+    from tiatoolbox_amd import models, tools, utils
+    from tiatoolbox_amd.models import (HoVerNet, IOInstanceSegmentorConfig, IOPatchPredictorConfig, IOSegmentorConfig,  # noqa: F401
+                                       ModelIOConfigABC, MultiTaskSegmentor, NucleusInstanceSegmentor, PatchDataset,
+                                       PatchPredictor, SemanticSegmentor)
+    from tiatoolbox_amd.models.dataset import predefined_preproc_func  # noqa: F401
+    from tiatoolbox_amd.models.engine.nucleus_instance_segmentor import NucleusInstanceSegmentor as Moved
+
+    assert Moved is NucleusInstanceSegmentor
+    assert models.engine.patch_predictor.PatchPredictor is PatchPredictor
+    assert tools.stainnorm.get_normalizer and tools.tissuemask.OtsuTissueMasker and tools.stainaugment.StainAugmentor
+    assert utils.misc.get_luminosity_tissue_mask and utils.transforms.rgb2od and utils.exceptions.MethodNotSupportedError
+    for pkg in ("tiatoolbox_amd", "tiatoolbox_amd.models", "tiatoolbox_amd.tools", "tiatoolbox_amd.utils"):
+        mod = sys.modules[pkg]
+        for name in mod.__all__:
+            assert getattr(mod, name) is not None, (pkg, name)
+    import pytest
+
+    with pytest.raises(AttributeError):
+        importlib.import_module("tiatoolbox_amd.models").DeepFeatureExtractor  # noqa: B018  (out of scope)
