@@ -8,6 +8,7 @@ streams.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 from . import build as _build
@@ -85,7 +86,10 @@ _SIGNATURES = {
 
 
 def lib_path() -> Path:
-    return _build.LIB_PATH
+    """The product library, or -- developer switch -- the variant named by ``TIA_LIB_PATH`` (built with
+    ``build.build(defines=..., out=...)``; it must export the same C ABI)."""
+    override = os.environ.get("TIA_LIB_PATH")
+    return Path(override) if override else _build.LIB_PATH
 
 
 def load() -> C.CDLL:

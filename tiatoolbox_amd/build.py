@@ -35,18 +35,24 @@ def needs_build() -> bool:
     return any(p.stat().st_mtime > t for p in deps)
 
 
-def build(*, force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP source into one shared library (cross-compiles without a GPU)."""
-    if not force and not needs_build():
+def build(*, force: bool = False, verbose: bool = False, defines: tuple[str, ...] = (), out: Path | None = None) -> Path:
+    """Compile every HIP source into one shared library (cross-compiles without a GPU).
+
+    ``defines`` / ``out`` build an experimental variant next to the product library (e.g.
+    ``build(defines=("TIA_F32_BINS=1",), out=LIB_DIR / "libtiatoolbox_amd_f32bins.so")``); select it at run time with
+    the environment variable ``TIA_LIB_PATH`` (see ``_lib.lib_path``).
+    """
+    target = Path(out) if out is not None else LIB_PATH
+    if out is None and not defines and not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     LIB_DIR.mkdir(parents=True, exist_ok=True)
-    cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", f"-I{CSRC}",
-           *[str(s) for s in sources()], "-o", str(LIB_PATH)]
+    cmd = [hipcc, *HIPCC_FLAGS, *[f"-D{d}" for d in defines], f"-I{ROOT / 'include'}", f"-I{CSRC}",
+           *[str(s) for s in sources()], "-o", str(target)]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return target
 
 
 if __name__ == "__main__":
