@@ -72,3 +72,47 @@ def test_exact_order_statistics_from_approximate_bins():
             accepted += 1
             assert res[0] == srt[r] and res[1] == srt[min(r + 1, n - 1)]
     assert accepted > 10 * fallbacks
+
+
+def test_float32_pseudo_angle_error_model():
+    """The per-pixel error bound the experimental kernel relies on: float32 projections (fma chain on the float32 OD
+    table), reciprocal pessimised by one ulp, quadrant arithmetic in float32 -- against the float64 key.  Bound:
+    ``4.8e-7 * (od_r+od_g+od_b) / (|p0|+|p1|) + 5e-7``; pixels with ``200 (|p0|+|p1|) <= l1`` would take the float64 key.
+    On stained-tissue data the bound holds everywhere, stays below 1 % of a bin, and no pixel is 'uncertain'."""
+    from pathlib import Path
+
+    from oracle import stain as ostain
+    from tiatoolbox_amd.utils import cvtables, synth
+
+    f32 = np.float32
+
+    def fma32(a, b, c):
+        return (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(f32)
+
+    od64 = cvtables.od_lut()
+    od32 = od64.astype(f32)
+    delta = 4.001953125 / 4096
+    target = np.load(Path(__file__).parent / "golden" / "target_crop_256.npy")
+    for patch in [*synth.g_he(3, 224, 224, seed=1), target]:
+        mask = ostain.get_luminosity_tissue_mask(patch.copy(), threshold=0.8).reshape(-1)
+        px = patch.reshape(-1, 3)[mask]
+        o64, o32 = od64[px], od32[px]
+        _, vec = np.linalg.eigh(np.cov(o64, rowvar=False))
+        e1, e2 = vec[:, 2] * np.sign(vec[0, 2] or 1), vec[:, 1] * np.sign(vec[0, 1] or 1)
+        p0, p1 = o64 @ e1, o64 @ e2
+        d = np.abs(p0) + np.abs(p1)
+        r = p1 / d
+        k64 = np.where(p0 >= 0, r, np.where(p1 >= 0, 2 - r, -2 - r))
+        q = []
+        for e in (e1.astype(f32), e2.astype(f32)):
+            q.append(fma32(o32[:, 2], e[2], fma32(o32[:, 1], e[1], (o32[:, 0] * e[0]).astype(f32))))
+        ds = (np.abs(q[0]) + np.abs(q[1])).astype(f32)
+        rcp = np.nextafter((f32(1) / ds).astype(f32), f32(np.inf))
+        rq = (q[1] * rcp).astype(f32)
+        k32 = np.where(q[0] >= 0, rq, np.where(q[1] >= 0, (f32(2) - rq).astype(f32), (f32(-2) - rq).astype(f32)))
+        l1 = o32.sum(1)
+        certain = 200.0 * ds > l1
+        err = np.abs(k32.astype(np.float64) - k64)
+        bound = 4.8e-7 * l1 / d + 5e-7
+        assert certain.all()
+        assert (err <= bound).all() and bound.max() < 0.01 * delta
