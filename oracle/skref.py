@@ -7,8 +7,6 @@ not installable here; these follow its published algorithms.
 
 from __future__ import annotations
 
-import heapq
-
 import numpy as np
 
 
@@ -67,43 +65,83 @@ def remove_small_objects_labels(lab: np.ndarray, max_size: int) -> np.ndarray:
     return out
 
 
-class _HeapItem:
-    """skimage's heap orders items by (value, age) only (``heap_general.pxi``: ``smaller``)."""
+class _Heap:
+    """skimage's ``heap_general.pxi`` binary min-heap, ordered by ``(value, age)`` only.
 
-    __slots__ = ("value", "age", "index")
+    ``push``: append, then swap with the parent while *smaller* than it.  ``pop``: the last item replaces the root, then
+    sifts down -- at every node the smallest of (node, left child, right child) moves up, stopping as soon as the node
+    itself is the smallest.  (Not CPython's ``heapq`` procedure, which first bubbles the smaller child up to a leaf; the
+    two only differ in the order in which entries that TIE on ``(value, age)`` leave the queue -- e.g. the initial
+    markers of a plateau, which all carry age 0.)  Restated from memory of scikit-image 0.2x; parity unpinned.
+    """
 
-    def __init__(self, value: float, age: int, index: int) -> None:
-        self.value, self.age, self.index = value, age, index
+    __slots__ = ("items",)
 
-    def __lt__(self, other: "_HeapItem") -> bool:
-        if self.value != other.value:
-            return self.value < other.value
-        return self.age < other.age
+    def __init__(self) -> None:
+        self.items: list[tuple[float, int, int]] = []
+
+    @staticmethod
+    def _smaller(a: tuple, b: tuple) -> bool:
+        if a[0] != b[0]:
+            return a[0] < b[0]
+        return a[1] < b[1]
+
+    def push(self, item: tuple[float, int, int]) -> None:
+        a = self.items
+        a.append(item)
+        child = len(a) - 1
+        while child > 0:
+            parent = (child + 1) // 2 - 1
+            if not self._smaller(a[child], a[parent]):
+                break
+            a[child], a[parent] = a[parent], a[child]
+            child = parent
+
+    def pop(self) -> tuple[float, int, int]:
+        a = self.items
+        top = a[0]
+        last = a.pop()
+        if not a:
+            return top
+        a[0] = last
+        i, n = 0, len(a)
+        while True:
+            left, right, smallest = 2 * i + 1, 2 * i + 2, i
+            if left >= n:
+                break
+            if self._smaller(a[left], a[i]):
+                smallest = left
+            if right < n and self._smaller(a[right], a[smallest]):
+                smallest = right
+            if smallest == i:
+                break
+            a[i], a[smallest] = a[smallest], a[i]
+            i = smallest
+        return top
 
 
 def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.ndarray:
     """``skimage.segmentation.watershed(image, markers, mask=mask)`` (connectivity 1).
 
-    Priority flood (``_watershed_cy.watershed_raveled``): a binary heap (same sift procedures as
-    CPython's ``heapq``) ordered by ``(value, age)``; every marker pixel (raster order) is pushed
-    with its own value and age 0; a popped pixel visits its neighbours in raveled offset order
-    (up, left, right, down); each unlabelled in-mask neighbour takes the popped pixel's label and
-    is pushed with its own image value and the next age.  Call site:
+    Priority flood (``_watershed_cy.watershed_raveled``): a binary heap (:class:`_Heap`) ordered by ``(value, age)``;
+    every marker pixel (raster order) is pushed with its own value and age 0; a popped pixel visits its neighbours in
+    raveled offset order (up, left, right, down); each unlabelled in-mask neighbour takes the popped pixel's label and is
+    pushed with its own image value and the next age.  Call site:
     ``tiatoolbox/models/architecture/hovernet.py:616``.
     """
     image = np.asarray(image, dtype=np.float64)
     h, w = image.shape
     out = np.where(mask, markers, 0).astype(np.int32)
     maskb = np.asarray(mask, dtype=bool)
-    heap: list = []
+    heap = _Heap()
     age = 0
     flat_out = out.ravel()
     flat_img = image.ravel()
     flat_mask = maskb.ravel()
     for idx in np.flatnonzero(flat_out):
-        heapq.heappush(heap, _HeapItem(flat_img[idx], 0, int(idx)))
-    while heap:
-        idx = heapq.heappop(heap).index
+        heap.push((float(flat_img[idx]), 0, int(idx)))
+    while heap.items:
+        idx = heap.pop()[2]
         r, c = divmod(idx, w)
         lab = flat_out[idx]
         for dr, dc in ((-1, 0), (0, -1), (0, 1), (1, 0)):
@@ -115,5 +153,5 @@ def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.nd
                 continue
             age += 1
             flat_out[n] = lab
-            heapq.heappush(heap, _HeapItem(flat_img[n], age, n))
+            heap.push((float(flat_img[n]), age, n))
     return out

@@ -319,3 +319,88 @@ def test_columnar_instance_table_equals_per_instance_assembly():
                 assert np.array_equal(table["contours"][j], v["contours"]) and table["contours"][j].dtype == np.int32
                 assert table["type"][j] == v["type"] and table["prob"][j] == v["prob"]
     assert hd.table_from_stats(np.zeros((3, 8), np.int64), None) is None
+
+
+def _pop_hole_classic(a: list, smaller) -> tuple:
+    """Line-by-line Python mirror of the ``TIA_HEAP_CLASSIC`` pop in ``hover_post.hip`` (hole formulation)."""
+    top = a[0]
+    items = len(a) - 1
+    if items == 0:
+        a.pop()
+        return top
+    last = a[items]
+    del a[items]
+    at = 0
+    while 2 * at + 1 < items:
+        left, right = 2 * at + 1, 2 * at + 2
+        best, best_i = last, at
+        if smaller(a[left], best):
+            best, best_i = a[left], left
+        if right < items and smaller(a[right], best):
+            best, best_i = a[right], right
+        if best_i == at:
+            break
+        a[at] = best
+        at = best_i
+    a[at] = last
+    return top
+
+
+def test_classic_heap_pop_formulations_agree_on_ties():
+    """The kernel's optional skimage-style pop (items shifted through a hole) == the oracle's swap-based restatement
+    of ``heap_general.pxi``, pop by pop, on sequences full of (value, age) ties; and the watershed oracle differs from
+    a ``heapq``-procedure flood only when such ties exist."""
+    import heapq
+
+    from oracle import skref
+
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        ref, hole = skref._Heap(), []  # noqa: SLF001
+        for step in range(int(rng.integers(5, 120))):
+            if hole and rng.random() < 0.4:
+                assert ref.pop() == _pop_hole_classic(hole, skref._Heap._smaller)  # noqa: SLF001
+            else:
+                item = (float(rng.integers(0, 4)), int(rng.integers(0, 3)), step)
+                ref.push(item)
+                hole.append(item)   # push = append + move up while smaller than the parent (same in both forms)
+                c = len(hole) - 1
+                while c > 0 and skref._Heap._smaller(hole[c], hole[(c + 1) // 2 - 1]):  # noqa: SLF001
+                    p = (c + 1) // 2 - 1
+                    hole[c], hole[p] = hole[p], hole[c]
+                    c = p
+            assert ref.items == hole
+        while hole:
+            assert ref.pop() == _pop_hole_classic(hole, skref._Heap._smaller)  # noqa: SLF001
+
+    class _Item:  # heapq procedure with the same (value, age) ordering
+        def __init__(self, t):
+            self.t = t
+
+        def __lt__(self, other):
+            return skref._Heap._smaller(self.t, other.t)  # noqa: SLF001
+
+    def flood_heapq(image, markers, mask):
+        h, w = image.shape
+        out = np.where(mask, markers, 0).astype(np.int32).ravel()
+        img, msk, heap, age = image.ravel(), mask.ravel(), [], 0
+        for idx in np.flatnonzero(out):
+            heapq.heappush(heap, _Item((img[idx], 0, int(idx))))
+        while heap:
+            idx = heapq.heappop(heap).t[2]
+            r, c = divmod(idx, w)
+            for dr, dc in ((-1, 0), (0, -1), (0, 1), (1, 0)):
+                rr, cc = r + dr, c + dc
+                if 0 <= rr < h and 0 <= cc < w and out[rr * w + cc] == 0 and msk[rr * w + cc]:
+                    age += 1
+                    out[rr * w + cc] = out[idx]
+                    heapq.heappush(heap, _Item((img[rr * w + cc], age, rr * w + cc)))
+        return out.reshape(h, w)
+
+    img = rng.random((40, 50))
+    mask = rng.random((40, 50)) < 0.85
+    markers = np.zeros((40, 50), int)
+    for k in range(1, 6):
+        y, x = rng.integers(0, 36), rng.integers(0, 46)
+        markers[y:y + 3, x:x + 3] = k
+    assert np.array_equal(skref.watershed(img, markers, mask), flood_heapq(img, markers, mask))  # no ties: identical

@@ -223,6 +223,15 @@ __device__ __forceinline__ bool heap_smaller(const HeapItem& a, const HeapItem& 
     if (a.value != b.value) return a.value < b.value;
     return a.age < b.age;
 }
+// Heap procedures.  push = append + move up while smaller than the parent (what skimage does).  pop exists in two
+// forms: the default bubbles the smaller child up to a leaf and sifts the displaced last item back (CPython heapq
+// style); -DTIA_HEAP_CLASSIC=1 selects skimage's own procedure (heap_general.pxi: at every node the smallest of
+// node / left / right moves up, stop when the node is the smallest).  Both are valid priority queues and pop in
+// the same order unless two entries tie on (value, age) -- only possible among the initial markers (all age 0) of
+// an exactly flat plateau; the classic form is not yet validated on hardware, hence not the default.
+#ifndef TIA_HEAP_CLASSIC
+#define TIA_HEAP_CLASSIC 0
+#endif
 // One lane owns one heap, kept in the lane's global-memory segment.  (Keeping the top levels of every
 // heap in LDS was measured and lost: 5.6 ms -> 8.0 ms per 256 x 164^2 batch; the extra branches and the 63 KB
 // LDS footprint cost more than the L2 round trips they save.)
@@ -321,6 +330,33 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
         --items;
         if (items == 0) return top;
         const HeapItem last = glob[items];
+#if TIA_HEAP_CLASSIC
+        {
+            int at = 0;
+            while (2 * at + 1 < items) {
+                const int left = 2 * at + 1, right = left + 1;
+                const HeapItem lc = glob[left];
+                int best_i = at;
+                HeapItem best = last;  // the item conceptually sitting at `at`
+                if (heap_smaller(lc, best)) {
+                    best = lc;
+                    best_i = left;
+                }
+                if (right < items) {
+                    const HeapItem rc = glob[right];
+                    if (heap_smaller(rc, best)) {
+                        best = rc;
+                        best_i = right;
+                    }
+                }
+                if (best_i == at) break;
+                glob[at] = best;
+                at = best_i;
+            }
+            glob[at] = last;
+            return top;
+        }
+#endif
         int pos = 0, child = 1;
         while (child < items) {
             const int right = child + 1;
@@ -487,6 +523,33 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(const int* __restrict
             --items;
             if (items == 0) return top;
             const HeapItem last = hget(items);
+#if TIA_HEAP_CLASSIC
+            {
+                int at = 0;
+                while (2 * at + 1 < items) {
+                    const int left = 2 * at + 1, right = left + 1;
+                    const HeapItem lc = hget(left);
+                    int best_i = at;
+                    HeapItem best = last;  // the item conceptually sitting at `at`
+                    if (heap_smaller(lc, best)) {
+                        best = lc;
+                        best_i = left;
+                    }
+                    if (right < items) {
+                        const HeapItem rc = hget(right);
+                        if (heap_smaller(rc, best)) {
+                            best = rc;
+                            best_i = right;
+                        }
+                    }
+                    if (best_i == at) break;
+                    hput(at, best);
+                    at = best_i;
+                }
+                hput(at, last);
+                return top;
+            }
+#endif
             int pos = 0, child = 1;
             while (child < items) {
                 const int right = child + 1;
