@@ -1274,6 +1274,7 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
         if (!finite) flags |= TIA_FLAG_DEGENERATE;
         if (prm.has_target) {
             const double sc0 = prm.target_maxc[0] / maxc[0], sc1 = prm.target_maxc[1] / maxc[1];
+            if (!(isfinite(sc0) && isfinite(sc1))) flags |= TIA_FLAG_DEGENERATE;  // zero 99th-percentile concentration
             out[TIA_ST_SCALE + 0] = sc0;
             out[TIA_ST_SCALE + 1] = sc1;
             for (int j = 0; j < 3; ++j)

@@ -28,6 +28,12 @@ def load_img(path: str | Path) -> np.ndarray:
     return np.asarray(Image.open(path).convert("RGB"))
 
 
+def _is_tensor(obj) -> bool:
+    import torch
+
+    return isinstance(obj, torch.Tensor)
+
+
 class PatchDataset:
     """In-memory (NHWC array / list of arrays) or on-disk (list of paths) patches.
 
@@ -64,6 +70,12 @@ class PatchDataset:
 
     def _check_input_integrity(self) -> None:
         msg = "Input must be either a list/array of images or a list of valid image paths."
+        if _is_tensor(self.inputs):  # MI355X overload: NHWC batch resident in HBM
+            if self.inputs.dim() != 4:  # noqa: PLR2004
+                msg = "Each sample must be an array of the form HWC."
+                raise ValueError(msg)
+            self.data_is_npy_alike = True
+            return
         if all(isinstance(v, (Path, str)) for v in self.inputs):
             if any(not Path(v).exists() for v in self.inputs):
                 raise ValueError(msg)
@@ -92,6 +104,8 @@ class PatchDataset:
 
     def raw(self, idx: int) -> np.ndarray:
         patch = self.inputs[idx]
+        if _is_tensor(patch):
+            patch = patch.cpu().numpy()
         if not self.data_is_npy_alike:
             patch = load_img(patch)
         self.check_shape(patch.shape)

@@ -10,9 +10,9 @@ across ranks and the per-patch outputs are all-gathered (RCCL).
 
 from __future__ import annotations
 
-import os
-
+import contextlib
 import logging
+import os
 from pathlib import Path
 
 import numpy as np
@@ -30,6 +30,15 @@ _DTYPES = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch
            "fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
 
 
+def _clear_last_hip_error() -> None:
+    import ctypes
+
+    try:
+        ctypes.CDLL("libamdhip64.so").hipGetLastError()
+    except OSError:  # pragma: no cover  (no HIP runtime: nothing to clear)
+        pass
+
+
 class _HostFeed:
     """Asynchronous host -> device feed of uint8 patch batches.
 
@@ -43,12 +52,17 @@ class _HostFeed:
         self.stream = torch.cuda.Stream(device)
         self.registered = False
         self._pending: dict[tuple[int, int], tuple[torch.Tensor, torch.cuda.Event]] = {}
-        if os.environ.get("TIA_HOST_REGISTER", "1") == "1" and array.flags.c_contiguous and array.nbytes >= (1 << 22):
+        if (os.environ.get("TIA_HOST_REGISTER", "1") == "1" and array.flags.c_contiguous and array.flags.writeable
+                and array.nbytes >= (1 << 22)):
             try:
                 rc = torch.cuda.cudart().cudaHostRegister(array.ctypes.data, array.nbytes, 0)
                 self.registered = int(getattr(rc, "value", rc)) == 0
             except Exception:  # noqa: BLE001  (any runtime refusal: keep the synchronous path)
                 self.registered = False
+            if not self.registered:
+                # a refused registration (mmap'd / already registered memory) leaves the runtime's sticky last-error
+                # set; clear it so the next launch check (tia_* entry points return hipGetLastError()) is not blamed
+                _clear_last_hip_error()
 
     def prefetch(self, lo: int, hi: int) -> None:
         if not self.registered or (lo, hi) in self._pending or lo >= hi:
@@ -75,6 +89,12 @@ class _HostFeed:
             torch.cuda.synchronize(self.device)
             torch.cuda.cudart().cudaHostUnregister(self.array.ctypes.data)
             self.registered = False
+
+
+def _weights_version(model: torch.nn.Module) -> tuple:
+    """Changes whenever a parameter/buffer is rewritten in place (``load_state_dict`` bumps ``Tensor._version``) or
+    replaced (``data_ptr``): the derived inference copy (BN folded, cast) must then be rebuilt."""
+    return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))  # noqa: SLF001
 
 
 class EngineABC:
@@ -157,6 +177,12 @@ class EngineABC:
     @staticmethod
     def _validate_images_masks(images):
         """ref. :1121-1159"""
+        if isinstance(images, torch.Tensor):  # MI355X overload: an NHWC batch already resident in HBM
+            if images.dim() != 4:  # noqa: PLR2004
+                msg = ("The input numpy array should be four dimensional."
+                       "The shape of the numpy array should be NHWC.")
+                raise ValueError(msg)
+            return images
         if not isinstance(images, (list, np.ndarray)):
             msg = "Input must be a list of file paths or a numpy array."
             raise TypeError(msg)
@@ -205,8 +231,13 @@ class EngineABC:
             msg = f"Please provide save_dir for output_type={output_type}"
             raise ValueError(msg)
         if self.output_type.lower() != "dict":
-            msg = (f"output_type={self.output_type!r} needs zarr / the annotation store, which are outside "
-                   "the accelerated hot path; use output_type='dict'.")
+            if save_dir is not None and output_type.lower() == "dict":
+                msg = ("`save_dir` turns dict output into a zarr store in the reference (engine_abc.py:1330-1332); "
+                       "zarr / annotation-store writers are outside the accelerated hot path: call run() without "
+                       "`save_dir` and save the returned dict yourself.")
+            else:
+                msg = (f"output_type={self.output_type!r} needs zarr / the annotation store, which are outside "
+                       "the accelerated hot path; use output_type='dict' without `save_dir`.")
             raise NotImplementedError(msg)
         if not patch_mode and save_dir is None:
             msg = "Input WSIs detected but no save directory provided. Please provide a 'save_dir'."
@@ -232,7 +263,8 @@ class EngineABC:
         """The module used for the forward pass: parameters in ``dtype``, channels-last (MIOpen NHWC)."""
         if dtype == torch.float32 and torch.device(self.device).type != "cuda":
             return self.model
-        key = (dtype, str(self.device), id(self.model), self.fold_batchnorm)
+        miopen_find = bool(getattr(self, "miopen_find", False))
+        key = (dtype, str(self.device), id(self.model), self.fold_batchnorm, miopen_find, _weights_version(self.model))
         if self._fast_key != key:
             import copy
 
@@ -249,15 +281,45 @@ class EngineABC:
                 # `miopen_find=True` (run kwarg / attribute): let MIOpen search its solvers once per convolution
                 # shape -- worth it for long runs at one batch shape (resnet18 fp16, 1024 x 224^2: 43 -> 36 ms per
                 # pass on MI355X), costly when batch sizes vary (every new shape is searched again), so off by default
-                torch.backends.cudnn.benchmark = bool(getattr(self, "miopen_find", False))
             m.eval()
             self._fast_model, self._fast_key = m, key
         return self._fast_model
+
+    @contextlib.contextmanager
+    def _miopen_scope(self):
+        """``miopen_find=True`` (run kwarg / attribute) lets MIOpen search its solvers once per convolution shape --
+        worth it for long runs at one batch shape (resnet18 fp16, 1024 x 224^2: 43 -> 36 ms per pass on MI355X), costly
+        when batch sizes vary.  The switch is process-global in torch, so it is set for the run and restored after."""
+        prev = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = bool(getattr(self, "miopen_find", False))
+        try:
+            yield
+        finally:
+            torch.backends.cudnn.benchmark = prev
+
+    def invalidate_inference_cache(self) -> None:
+        """Drop the derived (BN-folded / cast) inference copy; it is rebuilt on the next run."""
+        self._fast_model, self._fast_key = None, None
 
     def _preprocess_batch(self, dataset: PatchDataset, lo: int, hi: int, dtype: torch.dtype) -> torch.Tensor:
         """Raw patches [lo,hi) -> model-ready NHWC tensor on ``self.device``."""
         dev = torch.device(self.device)
         hook = dataset.preproc_func
+        if isinstance(dataset.inputs, torch.Tensor):  # device-resident batch: no host round trip at all
+            dataset.check_shape(dataset.inputs.shape[1:])
+            t = dataset.inputs[lo:hi]
+            if t.device != dev:
+                t = t.to(dev)
+            device_batch = getattr(hook, "device_batch", None)
+            if device_batch is not None:
+                return device_batch(t, dtype)
+            bound_norm = getattr(hook, "__self__", None)
+            from tiatoolbox_amd.tools.stainnorm import StainNormalizer as _SN
+
+            if isinstance(bound_norm, _SN):
+                return bound_norm.transform(t).to(dtype)
+            items = [torch.as_tensor(np.asarray(hook(p))) for p in t.cpu().numpy()]
+            return torch.stack(items).to(dev)
         if isinstance(dataset.inputs, np.ndarray):
             dataset.check_shape(dataset.inputs.shape[1:])
             raw = np.ascontiguousarray(dataset.inputs[lo:hi])
@@ -299,13 +361,14 @@ class EngineABC:
         if dev.type == "cuda" and isinstance(dataloader.inputs, np.ndarray) and dataloader.inputs.dtype == np.uint8:
             self._feed = _HostFeed(dataloader.inputs, dev)
         try:
-            for s in range(lo, hi, self.batch_size):
-                e = min(s + self.batch_size, hi)
-                if self._feed is not None:  # batch k+1 crosses PCIe while batch k computes
-                    self._feed.prefetch(s, e)
-                    self._feed.prefetch(e, min(e + self.batch_size, hi))
-                batch = self._preprocess_batch(dataloader, s, e, dtype)
-                outs.append(infer_batch(model, batch, device=self.device))
+            with self._miopen_scope():
+                for s in range(lo, hi, self.batch_size):
+                    e = min(s + self.batch_size, hi)
+                    if self._feed is not None:  # batch k+1 crosses PCIe while batch k computes
+                        self._feed.prefetch(s, e)
+                        self._feed.prefetch(e, min(e + self.batch_size, hi))
+                    batch = self._preprocess_batch(dataloader, s, e, dtype)
+                    outs.append(infer_batch(model, batch, device=self.device))
         finally:
             if self._feed is not None:
                 self._feed.close()

@@ -32,11 +32,14 @@ class PatchPredictor(EngineABC):
             self.drop_keys.append("probabilities")
         elif "probabilities" in self.drop_keys:
             self.drop_keys = [k for k in self.drop_keys if k != "probabilities"]
-        if self.stain_normalizer is not None:
-            from tiatoolbox_amd.models.dataset.classification import StainNormPreproc
+        from tiatoolbox_amd.models.dataset.classification import StainNormPreproc
 
-            model = self.model.module if hasattr(self.model, "module") else self.model
+        model = self.model.module if hasattr(self.model, "module") else self.model
+        if self.stain_normalizer is not None:
             model.preproc_func = StainNormPreproc(self.stain_normalizer, self._default_preproc)
+        elif isinstance(model.preproc_func, StainNormPreproc) and getattr(self, "_installed_norm", False):
+            model.preproc_func = self._default_preproc  # a later run(stain_normalizer=None) undoes the shorthand
+        self._installed_norm = self.stain_normalizer is not None
         return out
 
     def post_process_patches(self, raw_predictions: dict, **_) -> dict:

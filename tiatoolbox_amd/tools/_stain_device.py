@@ -186,3 +186,12 @@ def raise_on_flags(stats: torch.Tensor) -> None:
         if stats.shape[0] > 1:
             msg += f" (patch indices {empty.tolist()[:16]})"
         raise ValueError(msg)  # utils/misc.py:286-288
+    degenerate = torch.nonzero(flags & _lib.FLAG_DEGENERATE).flatten()
+    if degenerate.numel():
+        # fewer than two tissue pixels (np.cov with ddof=1 is NaN and np.linalg.eigh does not converge in the
+        # reference, stainextract.py:202-205) or non-finite statistics (e.g. a zero 99th-percentile concentration,
+        # stainnorm.py:103-104): never let them flow silently into the apply kernel
+        msg = "Degenerate stain statistics (fewer than two tissue pixels, or non-finite stain matrix / maxC)."
+        if stats.shape[0] > 1:
+            msg += f" (patch indices {degenerate.tolist()[:16]})"
+        raise np.linalg.LinAlgError(msg)

@@ -146,8 +146,18 @@ class ReinhardNormalizer(StainNormalizer):
     def fit(self, target) -> None:
         self.target_means, self.target_stds = self.get_mean_std(target)
 
-    def transform(self, img):
-        """Histogram -> per-image LUTs -> fused RGB->Lab->LUT->RGB apply: three launches, no host round trip."""
+    def transform(self, img, *, out: str = "uint8"):
+        """Histogram -> per-image LUTs -> fused RGB->Lab->LUT->RGB apply: three launches, no host round trip.
+
+        ``out``: ``"uint8"`` (reference behaviour, :342-367) or ``"unit_float16|bfloat16|float32"`` = ``ToTensor()`` of
+        the uint8 result (what the engines feed the CNN; same keyword as :meth:`StainNormalizer.transform`).
+        """
+        unit = {"uint8": None, "unit_float16": torch.float16, "unit_bfloat16": torch.bfloat16,
+                "unit_float32": torch.float32}
+        if out not in unit:
+            msg = f"ReinhardNormalizer.transform: unsupported out={out!r} (the Lab round trip is 8-bit)."
+            raise ValueError(msg)
+        unit_dtype = unit[out]
         batch, kind = _tensors.to_device_batch(img)
         n, h, w, _ = batch.shape
         dev = batch.device
@@ -175,4 +185,6 @@ class ReinhardNormalizer(StainNormalizer):
         if bool(flags.any()):
             msg = "float division by zero"  # the reference divides Python floats (stainnorm.py:281-290)
             raise ZeroDivisionError(msg)
+        if unit_dtype is not None:
+            out = out.to(torch.float32).div(255).to(unit_dtype)
         return _tensors.from_device(out, kind)

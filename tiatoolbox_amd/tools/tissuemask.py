@@ -119,28 +119,34 @@ class MorphologicalMasker(OtsuTissueMasker):
     """Otsu + small-region removal (8-connected) + elliptical dilation (ref. :167-306)."""
 
     def __init__(self, *, mpp=None, power=None, kernel_size=None, min_region_size=None) -> None:
+        """Exactly one of ``mpp`` / ``power`` / ``kernel_size`` (or none: a 1x1 element) sizes the ellipse.
+
+        Contract of the reference constructor (``tissuemask.py:229-272``): ``power`` is mapped to microns per pixel,
+        an mpp of ``m`` gives an element of ``max(32 / m, 1)`` pixels per axis (the code's 32, not the docstring's
+        64), scalars are broadcast to both axes, sizes are rounded half-to-even, and ``min_region_size`` defaults to
+        the number of set pixels of the element.
+        """
         super().__init__()
-        self.min_region_size = min_region_size
         self.threshold = None
-        if sum(arg is not None for arg in [mpp, power, kernel_size]) > 1:
+        given = {name: val for name, val in (("mpp", mpp), ("power", power), ("kernel_size", kernel_size))
+                 if val is not None}
+        if len(given) > 1:
             msg = "Only one of mpp, power, kernel_size can be given."
             raise ValueError(msg)
-        if all(arg is None for arg in [mpp, power, kernel_size]):
-            kernel_size = np.array([1, 1])
-        if power is not None:
-            mpp = objective_power2mpp(power)
-        if mpp is not None:
-            mpp_array = np.array(mpp)
-            if mpp_array.size != 2:  # noqa: PLR2004
-                mpp_array = mpp_array.repeat(2)
-            kernel_size = np.max([32 / mpp_array, np.array([1, 1])], axis=0)
-        kernel_size_array = np.array(kernel_size)
-        if kernel_size_array.size != 2:  # noqa: PLR2004
-            kernel_size_array = kernel_size_array.repeat(2)
-        self.kernel_size = tuple(np.round(kernel_size_array).astype(int))
+
+        def pair(value) -> np.ndarray:
+            arr = np.asarray(value, dtype=np.float64).reshape(-1)
+            return np.repeat(arr, 2) if arr.size == 1 else arr
+
+        if "power" in given:
+            given = {"mpp": objective_power2mpp(power)}
+        if "mpp" in given:
+            size = np.maximum(32 / pair(given["mpp"]), 1.0)
+        else:
+            size = pair(given.get("kernel_size", 1))
+        self.kernel_size = tuple(np.round(size).astype(int))
         self.kernel = img.get_structuring_element_ellipse(self.kernel_size)
-        if self.min_region_size is None:
-            self.min_region_size = int(np.sum(self.kernel))
+        self.min_region_size = int(self.kernel.sum()) if min_region_size is None else min_region_size
 
     def transform(self, images):
         if not self.fitted:
