@@ -208,6 +208,33 @@ int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, int64_t n, in
                              void* d_ws, size_t ws_bytes, void* stream);
 
 /*
+ * Same pipeline with optional copies of its intermediate planes (any of the five may be NULL), so each stage can be
+ * compared with the reference's corresponding local (hovernet.py:547-614) instead of only the final label map:
+ *   d_sobel_h / d_sobel_v [n,h,w] f64 = cv2.Sobel(normalised h|v, CV_64F, ksize) before the second normalisation (:554-555)
+ *   d_dist [n,h,w] f64 = -cv2.GaussianBlur((1 - overall) * blb, (3,3), 0)                                      (:599-600)
+ *   d_markers [n,h,w] i32 = labelled, size-filtered markers fed to the watershed                             (:607-614)
+ *   d_blobs [n,h,w] i32 = blb (0/1) after remove_small_objects                                               (:543-545)
+ */
+int tia_hover_proc_np_hv_stages_f32(const float* d_np, const float* d_hv, int64_t n, int64_t h, int64_t w,
+                                    int32_t ksize, int32_t obj_size, int32_t* d_inst, int32_t* d_ninst,
+                                    double* d_sobel_h, double* d_sobel_v, double* d_dist, int32_t* d_markers,
+                                    int32_t* d_blobs, void* d_ws, size_t ws_bytes, void* stream);
+
+/* Bytes of scratch tia_watershed_blobs_f64 needs for n planes of h x w. */
+size_t tia_watershed_workspace_bytes(int64_t n, int64_t h, int64_t w);
+
+/*
+ * skimage.segmentation.watershed(image, markers, mask=mask) with connectivity 1, no compactness, no watershed line
+ * (the call at hovernet.py:616), for n planes: priority flood ordered by (value, insertion age) with skimage's own
+ * binary-heap procedures (heap_general.pxi), neighbours visited up / left / right / down, a pixel labelled when it is
+ * pushed.  Floods of different 4-connected mask components are independent and run concurrently, one wave each.
+ *   d_image [n,h,w] f64   d_markers [n,h,w] i32 (>= 0; 0 = no marker)   d_mask [n,h,w] u8 (non-zero = flood here)
+ *   d_out [n,h,w] i32: label of the marker whose flood reached the pixel; 0 outside the mask and in unreached blobs
+ */
+int tia_watershed_blobs_f64(const double* d_image, const int32_t* d_markers, const uint8_t* d_mask, int64_t n,
+                            int64_t h, int64_t w, int32_t* d_out, void* d_ws, size_t ws_bytes, void* stream);
+
+/*
  * Per-instance statistics for HoVerNet.get_instance_info (hovernet.py:670-748): for every id in
  * 1..max_inst of every plane: pixel count, bounding box (x_min,y_min,x_max,y_max inclusive),
  * sum of x, sum of y, and the histogram of d_type (uint8, may be NULL) over its pixels.

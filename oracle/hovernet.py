@@ -34,6 +34,8 @@ def proc_np_hv(np_map: np.ndarray, hv_map: np.ndarray, scale_factor: float = 1, 
 
     sobel_h = cvref.sobel_f64(h_dir, 1, 0, ksize)
     sobel_v = cvref.sobel_f64(v_dir, 0, 1, ksize)
+    if debug is not None:
+        debug.update(sobel_h_raw=sobel_h, sobel_v_raw=sobel_v)
     sobel_h = 1 - cvref.normalize_minmax_to_f32(sobel_h)
     sobel_v = 1 - cvref.normalize_minmax_to_f32(sobel_v)
 

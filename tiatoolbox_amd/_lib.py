@@ -71,6 +71,10 @@ _SIGNATURES = {
     "tia_fill_holes_u8": ([_P, _I64, _I64, _I64, _P, _P, _P], C.c_int),
     "tia_hover_workspace_bytes": ([_I64, _I64, _I64], C.c_size_t),
     "tia_hover_proc_np_hv_f32": ([_P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P, C.c_size_t, _P], C.c_int),
+    "tia_hover_proc_np_hv_stages_f32": ([_P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
+                                        C.c_int),
+    "tia_watershed_workspace_bytes": ([_I64, _I64, _I64], C.c_size_t),
+    "tia_watershed_blobs_f64": ([_P, _P, _P, _I64, _I64, _I64, _P, _P, C.c_size_t, _P], C.c_int),
     "tia_canvas_row_merge_f32": ([_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
     "tia_canvas_finalize_f32": ([_P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P], C.c_int),
     "tia_lab_hist_u8": ([_P, _I64, _I64, _I64, _P, _P, _P], C.c_int),

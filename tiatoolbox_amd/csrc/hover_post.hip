@@ -31,6 +31,10 @@ __global__ __launch_bounds__(256) void np_threshold_kernel(const float* __restri
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) mask[i] = np_map[i] >= 0.5f ? 1 : 0;
 }
 
+__global__ __launch_bounds__(256) void blob_indicator_kernel(const int* __restrict__ lab, long n, int32_t* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = lab[i] > 0 ? 1 : 0;
+}
+
 // ---- per-plane min / max ---------------------------------------------------------------------------------
 // out[plane*2] = min, out[plane*2+1] = max (as f64) of two maps per launch.  One workgroup per plane,
 // coalesced sweeps with four loads in flight; NaNs are never selected (v < mn / v > mx comparisons).
@@ -230,7 +234,7 @@ __device__ __forceinline__ bool heap_smaller(const HeapItem& a, const HeapItem& 
 // the same order unless two entries tie on (value, age) -- only possible among the initial markers (all age 0) of
 // an exactly flat plateau; the classic form is not yet validated on hardware, hence not the default.
 #ifndef TIA_HEAP_CLASSIC
-#define TIA_HEAP_CLASSIC 0
+#define TIA_HEAP_CLASSIC 1
 #endif
 // One lane owns one heap, kept in the lane's global-memory segment.  (Keeping the top levels of every
 // heap in LDS was measured and lost: 5.6 ms -> 8.0 ms per 256 x 164^2 batch; the extra branches and the 63 KB
@@ -758,9 +762,46 @@ extern "C" size_t tia_hover_workspace_bytes(int64_t n, int64_t h, int64_t w) {
     return hover_layout((long)n, (long)h * w).total;
 }
 
-extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, int64_t n, int64_t h, int64_t w,
-                                         int32_t ksize, int32_t obj_size, int32_t* d_inst, int32_t* d_ninst, void* d_ws,
-                                         size_t ws_bytes, void* stream) {
+// watershed(image, markers, mask = blob labels > 0): ws_init + one priority flood per blob.  `areas` = per-label pixel
+// counts of blob_lab ([n][hw+1]), `offs` = their exclusive scan (heap segment offsets), min_keep = smallest blob kept.
+static int launch_watershed(const int* blob_lab, const int* mark_lab, const double* dist, const int* areas, const int* offs,
+                            const int* cnt_blob, int* bbox, HeapItem* heaps, int* d_inst, long n, int h, int w, int min_keep,
+                            hipStream_t st) {
+    const long hw = (long)h * w;
+    dim3 grid(hblocks(hw), (unsigned)n);
+    hipLaunchKernelGGL(ws_init_kernel, grid, dim3(HT), 0, st, blob_lab, mark_lab, h, w, d_inst, bbox);
+    const long max_labels = hw / 2 + 2;
+    long fx = (max_labels + 63) / 64, fcap = 65536 / n > 4 ? 65536 / n : 4;  // lanes stride over labels beyond the cap
+    dim3 fgrid((unsigned)n, (unsigned)(fx < fcap ? fx : fcap));
+    static const int wave_per_blob = [] {
+        const char* e = getenv("TIA_FLOOD_WAVE");  // developer switch: 0 = one lane per blob
+        return e ? atoi(e) : 1;
+    }();
+    if (wave_per_blob) {
+        long wy = max_labels < 4096 ? max_labels : 4096, wcap = 262144 / n > 16 ? 262144 / n : 16;
+        dim3 wgrid((unsigned)n, (unsigned)(wy < wcap ? wy : wcap));
+        hipLaunchKernelGGL(ws_flood_wave_kernel, wgrid, dim3(64), 0, st, blob_lab, dist, areas, offs, cnt_blob, bbox, h, w,
+                           min_keep, heaps, d_inst);
+    } else {
+        hipLaunchKernelGGL(ws_flood_kernel, fgrid, dim3(64), 0, st, blob_lab, dist, areas, offs, cnt_blob, bbox, h, w,
+                           min_keep, heaps, d_inst);
+    }
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+// Optional copies of the pipeline's intermediate planes (any pointer may be null): what the parity tests compare with
+// the oracle stage by stage, so that a compensating error cannot hide behind an identical final label map.
+struct HoverTaps {
+    double* sobel_h;   // cv2.Sobel(normalised h, CV_64F, 1, 0, ksize)   [n,h,w]
+    double* sobel_v;   // cv2.Sobel(normalised v, CV_64F, 0, 1, ksize)   [n,h,w]
+    double* dist;      // -GaussianBlur((1 - overall) * blb)            [n,h,w]
+    int32_t* markers;  // labelled, size-filtered markers                [n,h,w]
+    int32_t* blobs;    // 1 where blb (after the size filter), else 0    [n,h,w]
+};
+
+static int hover_proc_impl(const float* d_np, const float* d_hv, int64_t n, int64_t h, int64_t w, int32_t ksize,
+                           int32_t obj_size, int32_t* d_inst, int32_t* d_ninst, void* d_ws, size_t ws_bytes, void* stream,
+                           const HoverTaps& taps) {
     if (!d_np || !d_hv || !d_inst || !d_ninst || !d_ws) return TIA_EINVAL;
     if (n <= 0 || h <= 0 || w <= 0 || n > 65535 || ksize < 5 || ksize > 31 || (ksize & 1) == 0) return TIA_EINVAL;
     const long hw = (long)h * w;
@@ -787,6 +828,10 @@ extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, in
     double* mm = (double*)(base + L.mm);  // [4][n][2]: h raw, v raw, sobel h, sobel v
     int* se_offs = (int*)(base + L.se_offs);
     int* areas = ws_int;  // tia_label_area_filter_i32 leaves the per-label areas here
+    const size_t plane_f64 = (size_t)n * hw * sizeof(double), plane_i32 = (size_t)n * hw * sizeof(int32_t);
+    auto tap = [&](void* dst, const void* src, size_t bytes) {
+        return !dst || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    };
 
     dim3 grid(hblocks(hw), (unsigned)n);
     int rc;
@@ -814,6 +859,7 @@ extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, in
     hipLaunchKernelGGL(sobel_row_kernel, grid, dim3(HT), 0, st, d_hv, 1, (int)h, (int)w, mm + 2 * n, ks, ksize, rowbuf);
     hipLaunchKernelGGL(sobel_col_kernel, grid, dim3(HT), 0, st, rowbuf, (int)h, (int)w, kd, ksize, 0, sob_v);
     hipLaunchKernelGGL(minmax_pair_kernel, dim3((unsigned)n), dim3(1024), 0, st, sob_h, sob_v, hw, mm + 4 * n, mm + 6 * n);
+    if (!tap(taps.sobel_h, sob_h, plane_f64) || !tap(taps.sobel_v, sob_v, plane_f64)) return TIA_ELAUNCH;
 
     // 3. energy, marker seed
     hipLaunchKernelGGL(energy_kernel, grid, dim3(HT), 0, st, sob_h, sob_v, mm + 4 * n, mm + 6 * n, blob_lab, hw, dist0, tmp_a);
@@ -835,29 +881,85 @@ extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, in
     if (rc != TIA_OK) return rc;
     rc = tia_label_area_filter_i32(mark_lab, n, h, w, obj_size, ws_int, st);
     if (rc != TIA_OK) return rc;
+    if (!tap(taps.markers, mark_lab, plane_i32)) return TIA_ELAUNCH;
 
     // 5. watershed(dist, markers, mask = blb)
     // areas_keep lives in `dist`: move it to ws_int (free again) before dist is written
     if (hipMemcpyAsync(ws_int, areas_keep, (size_t)n * (hw + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return TIA_ELAUNCH;
     hipLaunchKernelGGL(gauss3_neg_kernel, grid, dim3(HT), 0, st, dist0, (int)h, (int)w, dist);
-    hipLaunchKernelGGL(ws_init_kernel, grid, dim3(HT), 0, st, blob_lab, mark_lab, (int)h, (int)w, d_inst, bbox);
-    const long max_labels = hw / 2 + 2;
-    long fx = (max_labels + 63) / 64, fcap = 65536 / n > 4 ? 65536 / n : 4;  // lanes stride over labels beyond the cap
-    dim3 fgrid((unsigned)n, (unsigned)(fx < fcap ? fx : fcap));
-    static const int wave_per_blob = [] {
-        const char* e = getenv("TIA_FLOOD_WAVE");  // developer switch: 0 = one lane per blob
-        return e ? atoi(e) : 1;
-    }();
-    if (wave_per_blob) {
-        long wy = max_labels < 4096 ? max_labels : 4096, wcap = 262144 / n > 16 ? 262144 / n : 16;
-        dim3 wgrid((unsigned)n, (unsigned)(wy < wcap ? wy : wcap));
-        hipLaunchKernelGGL(ws_flood_wave_kernel, wgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h,
-                           (int)w, 10, heaps, d_inst);
-    } else {
-        hipLaunchKernelGGL(ws_flood_kernel, fgrid, dim3(64), 0, st, blob_lab, dist, ws_int, offs, cnt_blob, bbox, (int)h, (int)w,
-                           10, heaps, d_inst);
-    }
-    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+    if (!tap(taps.dist, dist, plane_f64)) return TIA_ELAUNCH;
+    if (taps.blobs)
+        hipLaunchKernelGGL(blob_indicator_kernel, dim3(hblocks((long)n * hw, HT, 65535)), dim3(HT), 0, st, blob_lab, (long)n * hw,
+                           taps.blobs);
+    return launch_watershed(blob_lab, mark_lab, dist, ws_int, offs, cnt_blob, bbox, heaps, d_inst, (long)n, (int)h, (int)w, 10,
+                            st);
+}
+
+extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, int64_t n, int64_t h, int64_t w,
+                                         int32_t ksize, int32_t obj_size, int32_t* d_inst, int32_t* d_ninst, void* d_ws,
+                                         size_t ws_bytes, void* stream) {
+    return hover_proc_impl(d_np, d_hv, n, h, w, ksize, obj_size, d_inst, d_ninst, d_ws, ws_bytes, stream, HoverTaps{});
+}
+
+extern "C" int tia_hover_proc_np_hv_stages_f32(const float* d_np, const float* d_hv, int64_t n, int64_t h, int64_t w,
+                                                int32_t ksize, int32_t obj_size, int32_t* d_inst, int32_t* d_ninst,
+                                                double* d_sobel_h, double* d_sobel_v, double* d_dist, int32_t* d_markers,
+                                                int32_t* d_blobs, void* d_ws, size_t ws_bytes, void* stream) {
+    HoverTaps taps{d_sobel_h, d_sobel_v, d_dist, d_markers, d_blobs};
+    return hover_proc_impl(d_np, d_hv, n, h, w, ksize, obj_size, d_inst, d_ninst, d_ws, ws_bytes, stream, taps);
+}
+
+// ---- stand-alone marker-controlled watershed ---------------------------------------------------------------------------
+struct WatershedWs {
+    size_t total, blob_lab, ws_int, bbox, offs, cnt, heaps;
+};
+static WatershedWs watershed_layout(long n, long hw) {
+    WatershedWs L{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = o;
+        o = align256(o + bytes);
+        return at;
+    };
+    L.blob_lab = take((size_t)n * hw * 4);
+    L.ws_int = take(((size_t)2 * n * hw + 2 * n + (size_t)n * (hw + 1)) * 4);
+    L.bbox = take((size_t)n * (hw + 1) * 16);
+    L.offs = take((size_t)n * (hw + 1) * 4);
+    L.cnt = take((size_t)n * 4 * 2);
+    L.heaps = take((size_t)n * hw * sizeof(HeapItem));
+    L.total = o;
+    return L;
+}
+
+extern "C" size_t tia_watershed_workspace_bytes(int64_t n, int64_t h, int64_t w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    return watershed_layout((long)n, (long)h * w).total;
+}
+
+extern "C" int tia_watershed_blobs_f64(const double* d_image, const int32_t* d_markers, const uint8_t* d_mask, int64_t n,
+                                        int64_t h, int64_t w, int32_t* d_out, void* d_ws, size_t ws_bytes, void* stream) {
+    if (!d_image || !d_markers || !d_mask || !d_out || !d_ws) return TIA_EINVAL;
+    if (n <= 0 || h <= 0 || w <= 0 || n > 65535) return TIA_EINVAL;
+    const long hw = (long)h * w;
+    if (hw > 0x3fffffffL) return TIA_ESIZE;
+    const WatershedWs L = watershed_layout((long)n, hw);
+    if (ws_bytes < L.total) return TIA_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)d_ws;
+    int* blob_lab = (int*)(base + L.blob_lab);
+    int* ws_int = (int*)(base + L.ws_int);
+    int* bbox = (int*)(base + L.bbox);
+    int* offs = (int*)(base + L.offs);
+    int* cnt = (int*)(base + L.cnt);
+    HeapItem* heaps = (HeapItem*)(base + L.heaps);
+    // connectivity-1 floods never cross between 4-connected components of the mask: one private queue per component
+    int rc = tia_ccl_label_i32(d_mask, n, h, w, 4, blob_lab, cnt, ws_int, st);
+    if (rc != TIA_OK) return rc;
+    rc = tia_label_area_filter_i32(blob_lab, n, h, w, 1, ws_int, st);  // keeps every blob; leaves the areas in ws_int
+    if (rc != TIA_OK) return rc;
+    hipLaunchKernelGGL(bbox_reset_kernel, dim3(hblocks((long)n * (hw + 1), HT, 65535)), dim3(HT), 0, st, bbox, (long)n * (hw + 1));
+    hipLaunchKernelGGL(ws_offsets_kernel, dim3((unsigned)n), dim3(1024), 0, st, ws_int, cnt, hw, 1, offs);
+    return launch_watershed(blob_lab, d_markers, d_image, ws_int, offs, cnt, bbox, heaps, d_out, (long)n, (int)h, (int)w, 1, st);
 }
 
 extern "C" int tia_hover_instance_stats(const int32_t* d_inst, const uint8_t* d_type, int64_t n, int64_t h, int64_t w,

@@ -38,6 +38,58 @@ def proc_np_hv(np_map: torch.Tensor, hv_map: torch.Tensor, *, ksize: int = 21, o
     return inst, ninst
 
 
+def proc_np_hv_stages(np_map: torch.Tensor, hv_map: torch.Tensor, *, ksize: int = 21, obj_size: int = 10) -> dict:
+    """``_proc_np_hv`` with its intermediate planes (``tia_hover_proc_np_hv_stages_f32``): ``inst``, ``n_markers``,
+    ``sobel_h``/``sobel_v`` (raw CV_64F Sobel), ``dist``, ``marker`` (labelled), ``blb`` (0/1) -- device tensors."""
+    _lib.require_cuda(np_map, "np_map")
+    _lib.require_cuda(hv_map, "hv_map")
+    if np_map.dim() == 4:
+        np_map = np_map[..., 0]
+    np_map = np_map.to(torch.float32).contiguous()
+    hv_map = hv_map.to(torch.float32).contiguous()
+    n, h, w = np_map.shape
+    dev = np_map.device
+    out = {"inst": torch.empty((n, h, w), dtype=torch.int32, device=dev),
+           "n_markers": torch.empty(n, dtype=torch.int32, device=dev),
+           "sobel_h": torch.empty((n, h, w), dtype=torch.float64, device=dev),
+           "sobel_v": torch.empty((n, h, w), dtype=torch.float64, device=dev),
+           "dist": torch.empty((n, h, w), dtype=torch.float64, device=dev),
+           "marker": torch.empty((n, h, w), dtype=torch.int32, device=dev),
+           "blb": torch.empty((n, h, w), dtype=torch.int32, device=dev)}
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        nbytes = lib.tia_hover_workspace_bytes(n, h, w)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = lib.tia_hover_proc_np_hv_stages_f32(
+            np_map.data_ptr(), hv_map.data_ptr(), n, h, w, ksize, obj_size, out["inst"].data_ptr(),
+            out["n_markers"].data_ptr(), out["sobel_h"].data_ptr(), out["sobel_v"].data_ptr(), out["dist"].data_ptr(),
+            out["marker"].data_ptr(), out["blb"].data_ptr(), ws.data_ptr(), nbytes, _lib.current_stream())
+    _lib.check(rc, "tia_hover_proc_np_hv_stages_f32")
+    return out
+
+
+def watershed(image: torch.Tensor, markers: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """``skimage.segmentation.watershed(image, markers, mask=mask)`` (connectivity 1) for ``[N,H,W]`` (or ``[H,W]``)
+    CUDA tensors; image float64, markers int32, mask anything truthy.  Returns int32 labels."""
+    _lib.require_cuda(image, "image")
+    single = image.dim() == 2  # noqa: PLR2004
+    if single:
+        image, markers, mask = image[None], markers[None], mask[None]
+    image = image.to(torch.float64).contiguous()
+    markers = markers.to(device=image.device, dtype=torch.int32).contiguous()
+    mask = (mask.to(image.device) != 0).to(torch.uint8).contiguous()
+    n, h, w = image.shape
+    out = torch.empty((n, h, w), dtype=torch.int32, device=image.device)
+    lib = _lib.load()
+    with torch.cuda.device(image.device):
+        nbytes = lib.tia_watershed_workspace_bytes(n, h, w)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=image.device)
+        rc = lib.tia_watershed_blobs_f64(image.data_ptr(), markers.data_ptr(), mask.data_ptr(), n, h, w, out.data_ptr(),
+                                         ws.data_ptr(), nbytes, _lib.current_stream())
+    _lib.check(rc, "tia_watershed_blobs_f64")
+    return out[0] if single else out
+
+
 def instance_stats(inst: torch.Tensor, type_map: torch.Tensor | None, max_inst: int, num_types: int = 0):
     """Per-instance area / bbox / coordinate sums (int64 ``[N, max_inst+1, 8]``) and type histograms."""
     _lib.require_cuda(inst, "inst")
