@@ -239,8 +239,10 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
 
     def run(images, dtype: str = args.dtype):
         # miopen_find: MIOpen searches its solvers once per convolution shape (first warm-up step); engine option
+        size = tuple(int(v) for v in images.shape[1:3])
         return engine.run(images, patch_mode=True, return_probabilities=True, stain_normalizer=norm,
-                          compute_dtype=dtype, miopen_find=os.environ.get("TIA_MIOPEN_FIND", "1") == "1")
+                          patch_input_shape=size, compute_dtype=dtype,
+                          miopen_find=os.environ.get("TIA_MIOPEN_FIND", "1") == "1")
 
     def barrier() -> None:
         if world_size > 1:

@@ -473,7 +473,7 @@ def test_columnar_instance_table_equals_per_instance_assembly():
 
 
 def _pop_hole_classic(a: list, smaller) -> tuple:
-    """Line-by-line Python mirror of the ``TIA_HEAP_CLASSIC`` pop in ``hover_post.hip`` (hole formulation)."""
+    """Line-by-line Python mirror of the (skimage-style) pop in ``hover_post.hip`` (hole formulation)."""
     top = a[0]
     items = len(a) - 1
     if items == 0:

@@ -227,15 +227,12 @@ __device__ __forceinline__ bool heap_smaller(const HeapItem& a, const HeapItem& 
     if (a.value != b.value) return a.value < b.value;
     return a.age < b.age;
 }
-// Heap procedures.  push = append + move up while smaller than the parent (what skimage does).  pop exists in two
-// forms: the default bubbles the smaller child up to a leaf and sifts the displaced last item back (CPython heapq
-// style); -DTIA_HEAP_CLASSIC=1 selects skimage's own procedure (heap_general.pxi: at every node the smallest of
-// node / left / right moves up, stop when the node is the smallest).  Both are valid priority queues and pop in
-// the same order unless two entries tie on (value, age) -- only possible among the initial markers (all age 0) of
-// an exactly flat plateau; the classic form is not yet validated on hardware, hence not the default.
-#ifndef TIA_HEAP_CLASSIC
-#define TIA_HEAP_CLASSIC 1
-#endif
+// Heap procedures = skimage's heap_general.pxi, because entries that tie on (value, age) -- the initial markers of a
+// flat plateau all carry age 0 -- leave the queue in an order that depends on the heap's internal arrangement:
+// push = append + move up while smaller than the parent; pop = the last item replaces the root, then at every node
+// the smallest of node / left / right moves up until the node itself is the smallest (not CPython heapq's
+// bubble-to-a-leaf-and-sift-back, which pops such ties in a different order: 4.62 vs 4.84 ms per 256 x 164^2 batch,
+// profiles/r02a_hover_*.jsonl; tests/test_hovernet_post.py forces the ties).
 // One lane owns one heap, kept in the lane's global-memory segment.  (Keeping the top levels of every
 // heap in LDS was measured and lost: 5.6 ms -> 8.0 ms per 256 x 164^2 batch; the extra branches and the 63 KB
 // LDS footprint cost more than the L2 round trips they save.)
@@ -328,13 +325,12 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
         }
         glob[pos] = e;
     };
-    // pop = take root, move the last item to the root, bubble the smaller child up to a leaf, sift back
+    // pop (heap_general.pxi): root out, last item to the root, sift down
     auto heap_pop = [&](int& items) {
         const HeapItem top = glob[0];
         --items;
         if (items == 0) return top;
         const HeapItem last = glob[items];
-#if TIA_HEAP_CLASSIC
         {
             int at = 0;
             while (2 * at + 1 < items) {
@@ -360,31 +356,6 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(const int* __restrict__ bl
             glob[at] = last;
             return top;
         }
-#endif
-        int pos = 0, child = 1;
-        while (child < items) {
-            const int right = child + 1;
-            HeapItem c = glob[child];
-            if (right < items) {
-                const HeapItem r = glob[right];
-                if (!heap_smaller(c, r)) {
-                    child = right;
-                    c = r;
-                }
-            }
-            glob[pos] = c;
-            pos = child;
-            child = 2 * pos + 1;
-        }
-        while (pos > 0) {
-            const int parent = (pos - 1) >> 1;
-            const HeapItem p = glob[parent];
-            if (!heap_smaller(last, p)) break;
-            glob[pos] = p;
-            pos = parent;
-        }
-        glob[pos] = last;
-        return top;
     };
     const int* bb = bbox + ((size_t)plane * (hw + 1) + label) * 4;
     const int y0 = bb[0], y1 = bb[1], x0 = bb[2], x1 = bb[3];
@@ -522,12 +493,11 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(const int* __restrict
             }
             hput(pos, e);
         };
-        auto heap_pop = [&](int& items) {  // root out, last item to the root, smaller child up to a leaf, sift back
+        auto heap_pop = [&](int& items) {  // heap_general.pxi: root out, last item to the root, sift down
             const HeapItem top = hget(0);
             --items;
             if (items == 0) return top;
             const HeapItem last = hget(items);
-#if TIA_HEAP_CLASSIC
             {
                 int at = 0;
                 while (2 * at + 1 < items) {
@@ -553,31 +523,6 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(const int* __restrict
                 hput(at, last);
                 return top;
             }
-#endif
-            int pos = 0, child = 1;
-            while (child < items) {
-                const int right = child + 1;
-                HeapItem c = hget(child);
-                if (right < items) {
-                    const HeapItem r = hget(right);
-                    if (!heap_smaller(c, r)) {
-                        child = right;
-                        c = r;
-                    }
-                }
-                hput(pos, c);
-                pos = child;
-                child = 2 * pos + 1;
-            }
-            while (pos > 0) {
-                const int parent = (pos - 1) >> 1;
-                const HeapItem p = hget(parent);
-                if (!heap_smaller(last, p)) break;
-                hput(pos, p);
-                pos = parent;
-            }
-            hput(pos, last);
-            return top;
         };
         const int* bb = bbox + ((size_t)plane * (hw + 1) + label) * 4;
         const int y0 = bb[0], y1 = bb[1], x0 = bb[2], x1 = bb[3];

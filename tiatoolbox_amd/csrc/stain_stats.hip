@@ -29,18 +29,6 @@ constexpr int BPT = NB / NT;     // bins per thread in the scan
 #endif
 constexpr int MASK_WORDS = TIA_MASKBITS ? 2048 : 1;  // up to 65536 pixels (256x256)
 
-// EXPERIMENT (off by default, not yet validated on hardware): level-0 histograms on float32 keys.  The sweeps that
-// build the selection histograms are f64-VALU bound; binning needs far less precision than the result.  With
-// |approx key - exact key| <= eps < bin width / 4 for every pixel, the exact order statistics are still obtained:
-// if b is the bin holding rank r of the APPROXIMATE keys, every pixel in bins <= b-2 is exactly smaller and every pixel
-// in bins >= b+2 exactly larger than the r-th exact value, so sorting the EXACT keys of bins b-1..b+1 (plus the first
-// non-empty bin beyond and its successor, where the (r+1)-th value may live) and indexing with r - count(bins <= b-2)
-// is exact.  Any violated precondition (edge bins, too many candidates, bin width too small for the error bound)
-// falls back to the all-f64 path.  Model and proof check: DESIGN.md 4.1 (Python model, 12k random/adversarial cases).
-#ifndef TIA_F32_BINS
-#define TIA_F32_BINS 0
-#endif
-
 struct SelState {
     double lo[2][MAXLEVEL + 1];
     double scale[2][MAXLEVEL + 1];
@@ -56,11 +44,6 @@ struct SelState {
     int sel_hi[2];     // last bin collected on the fast path (next non-empty bin when k+1 leaves the bin)
     unsigned long long above_key[2];
     unsigned long long member_key[2];
-#if TIA_F32_BINS
-    int approx;        // caller: the level-0 pass supplied by `hist0` bins approximate keys
-    int approx_fail;   // select2: preconditions violated, rerun with exact keys
-    int lo2[2], hi2[2];  // second candidate bin range (first non-empty bin beyond b+1 and its successor)
-#endif
 };
 
 #ifndef TIA_OD_REP
@@ -70,9 +53,6 @@ constexpr int ODR = TIA_OD_REP;  // copies of the f64 OD table: lane l reads cop
                                  // data-dependent look-ups over the LDS banks (the kernel is LDS-bound)
 
 struct Smem {
-#if TIA_F32_BINS
-    float odf[256];
-#endif
     double od[256 * ODR];
     int ty[3][256];
     unsigned hist[256];
@@ -313,48 +293,6 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
         // fast path: exactly one histogram level for every target that needed one -> the cached bins are
         // exactly the membership test.  If rank k is the last member of its bin, the bin holding k+1 (the
         // next non-empty one) is collected too, so no separate "minimum above" search is needed.
-#if TIA_F32_BINS
-        if (write_cache && nh0 && nh1 && st.approx) {
-            // approximate bins: candidates = bins b-1..b+1 and [b2, b2+1], b2 = first non-empty bin >= b+2
-            if (threadIdx.x < 2) st.sel_hi[threadIdx.x] = NB;
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const unsigned* hb = (shared && t == 1) ? s.bins[0] : s.bins[t];
-                const int sel = st.sel[t][0];
-                int first = NB;
-                for (int i = threadIdx.x * BPT; i < threadIdx.x * BPT + BPT; ++i)
-                    if (i > sel + 1 && hb[i] != 0 && i < first) first = i;
-                if (first < NB) atomicMin(&st.sel_hi[t], first);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int ok = 1;
-                for (int t = 0; t < 2; ++t) {
-                    const unsigned* hb = (shared && t == 1) ? s.bins[0] : s.bins[t];
-                    const int b = st.sel[t][0], b2 = st.sel_hi[t];
-                    if (st.level[t] != 1 || b - 1 < 1 || b + 1 > NB - 2) { ok = 0; break; }
-                    unsigned long long c = (unsigned long long)hb[b - 1] + hb[b] + hb[b + 1];
-                    if (b2 < NB) {
-                        if (b2 + 1 > NB - 2) { ok = 0; break; }
-                        c += (unsigned long long)hb[b2] + hb[b2 + 1];
-                        st.lo2[t] = b2;
-                        st.hi2[t] = b2 + 1;
-                    } else {
-                        st.lo2[t] = NB;      // empty range
-                        st.hi2[t] = NB - 1;
-                    }
-                    if (c > (unsigned long long)CAP) { ok = 0; break; }
-                    st.r[t] += hb[b - 1];   // rank inside the candidate set: everything in bins <= b-2 is exactly smaller
-                    st.cnt[t] = c;
-                }
-                st.fast = ok;
-                st.approx_fail = ok ? 0 : 1;
-            }
-            __syncthreads();
-            if (st.approx_fail) return;  // uniform: the caller reruns with exact keys
-        } else
-#endif
         if (write_cache && nh0 && nh1) {
             if (threadIdx.x < 2) st.sel_hi[threadIdx.x] = NB;
             __syncthreads();
@@ -407,14 +345,7 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
     __syncthreads();
     if (st.fast) {
         // group-level sweep over the cached bins only: pixel bytes are fetched for the (rare) members
-#if TIA_F32_BINS
-        const bool apx = st.approx != 0;
-        const int slo[2] = {st.sel[0][0] - (apx ? 1 : 0), st.sel[1][0] - (apx ? 1 : 0)};
-        const int shi[2] = {apx ? st.sel[0][0] + 1 : st.sel_hi[0], apx ? st.sel[1][0] + 1 : st.sel_hi[1]};
-        const int slo2[2] = {apx ? st.lo2[0] : NB, apx ? st.lo2[1] : NB}, shi2[2] = {apx ? st.hi2[0] : -1, apx ? st.hi2[1] : -1};
-#else
         const int slo[2] = {st.sel[0][0], st.sel[1][0]}, shi[2] = {st.sel_hi[0], st.sel_hi[1]};
-#endif
         const unsigned long long* c0p = reinterpret_cast<const unsigned long long*>(bincache);
         const unsigned long long* c1p = shared_values ? c0p : reinterpret_cast<const unsigned long long*>(bincache + (size_t)hw);
         const long ng = hw >> 2;
@@ -434,13 +365,8 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int a0 = (int)((q0[u] >> (16 * i)) & 0xffffu), a1 = (int)((q1[u] >> (16 * i)) & 0xffffu);
-#if TIA_F32_BINS
-                    hit |= ((a0 >= slo[0] && a0 <= shi[0]) || (a0 >= slo2[0] && a0 <= shi2[0])) ? (1u << i) : 0u;
-                    hit |= ((a1 >= slo[1] && a1 <= shi[1]) || (a1 >= slo2[1] && a1 <= shi2[1])) ? (16u << i) : 0u;
-#else
                     hit |= (a0 >= slo[0] && a0 <= shi[0]) ? (1u << i) : 0u;
                     hit |= (a1 >= slo[1] && a1 <= shi[1]) ? (16u << i) : 0u;
-#endif
                 }
                 if (hit) {
                     for (int i = 0; i < 4; ++i) {
@@ -550,11 +476,6 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
         const unsigned long long r = st.r[t], c = st.cnt[t];
         const bool has_next = (k[t] + 1 < n[t]);
         const double above = key_f64(st.above_key[t]);
-#if TIA_F32_BINS
-        if (st.approx && (r >= c || (has_next && r + 1 >= c))) {
-            if (threadIdx.x == 0) st.approx_fail = 1;  // cannot happen if the preconditions held; never trust it silently
-        }
-#endif
         if (c <= (unsigned long long)CAP) {
             vprev[t] = s.cand[t][r];
             vnext[t] = !has_next ? vprev[t] : ((r + 1 < c) ? s.cand[t][r + 1] : above);
@@ -649,9 +570,6 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
 
     if (tid < TIA_STATS_STRIDE) out[tid] = 0.0;
     for (int i = tid; i < 256 * ODR; i += NT) s.od[i] = tab->od_lut[i / ODR];
-#if TIA_F32_BINS
-    for (int i = tid; i < 256; i += NT) s.odf[i] = tab->od_lut_f32[i];
-#endif
     const int odl = tid & (ODR - 1);
 #define OD(v) s.od[(v) * ODR + odl]
     if (tid == 0) {
@@ -911,17 +829,6 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
         np_index(n_tissue, prm.q_phi_hi, kp[1], kn[1], gm[1]);
         const double lo0[2] = {-2.0009765625, -2.0009765625}, hi0[2] = {2.0009765625, 2.0009765625};
         double vp[2], vn[2];
-#if TIA_F32_BINS
-        const float e1xf = (float)e1x, e1yf = (float)e1y, e1zf = (float)e1z, e2xf = (float)e2x, e2yf = (float)e2y, e2zf = (float)e2z;
-        bool phi_approx = true;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-        phi_approx = attempt == 0;
-        if (tid == 0) {
-            s.st.approx = phi_approx ? 1 : 0;
-            s.st.approx_fail = 0;
-        }
-        __syncthreads();
-#endif
         select2(p, hw,
                 [&](long idx, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
                     if (!is_tissue_cached(idx, r, g, b)) return 0u;
@@ -935,55 +842,6 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
                     if (!grp || use_bits) return false;
                     const double lo = s.st.lo[0][0], sc = s.st.scale[0][0];
                     unsigned bl = 0, ab = 0;
-#if TIA_F32_BINS
-                    if (phi_approx) {
-                        // float32 keys; error model: |p~ - p| <= 4 ulp(f32) * (od_r + od_g + od_b), so the pseudo-angle is
-                        // off by <= 4.8e-7 * l1 / d + 5e-7.  Pixels with l1 > 200 d (OD almost orthogonal to the stain
-                        // plane) take the f64 key; for everyone else the error stays below 1/8 of the 9.8e-4 bin width.
-                        const float lof = (float)lo, scf = (float)sc;
-                        for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup& wg) {
-                            uint32_t rr[4], gg[4], bb[4];
-                            unpack_group(a, b, c, rr, gg, bb);
-                            float fx[4], fy[4], fz[4];
-                            int lum[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                fx[i] = s.odf[rr[i]];
-                                fy[i] = s.odf[gg[i]];
-                                fz[i] = s.odf[bb[i]];
-                                lum[i] = s.ty[0][rr[i]] + s.ty[1][gg[i]] + s.ty[2][bb[i]];
-                            }
-                            unsigned long long codes = 0ull;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const bool tissue = ((lum[i] + (1 << 11)) >> 12) < y_thr;
-                                const float q0 = __builtin_fmaf(fz[i], e1zf, __builtin_fmaf(fy[i], e1yf, fx[i] * e1xf));
-                                const float q1 = __builtin_fmaf(fz[i], e2zf, __builtin_fmaf(fy[i], e2yf, fx[i] * e2xf));
-                                const float dsum = fabsf(q0) + fabsf(q1);
-                                float df;
-                                if (200.0f * dsum > fx[i] + fy[i] + fz[i]) {
-                                    const float rq = q1 * __builtin_amdgcn_rcpf(dsum);
-                                    const float key = q0 >= 0.0f ? rq : (q1 >= 0.0f ? 2.0f - rq : -2.0f - rq);
-                                    df = (key - lof) * scf;
-                                } else {  // rare: exact key
-                                    const double p0 = dot3(OD(rr[i]), OD(gg[i]), OD(bb[i]), e1x, e1y, e1z);
-                                    const double p1 = dot3(OD(rr[i]), OD(gg[i]), OD(bb[i]), e2x, e2y, e2z);
-                                    df = (float)((pseudo_angle(p1, p0) - lo) * sc);
-                                }
-                                const bool low = !(df >= 0.0f), high = df >= (float)NB;
-                                const int bin = low ? 0 : (high ? NB - 1 : (int)df);
-                                bl += (tissue && low) ? 1u : 0u;
-                                ab += (tissue && high) ? 1u : 0u;
-                                hist_add(s.bins[0], bin, tissue && !low && !high, wg);
-                                codes |= (unsigned long long)(tissue ? (unsigned)bin : 0xffffu) << (16 * i);
-                            }
-                            *reinterpret_cast<unsigned long long*>(bincache + g * 4) = codes;
-                        });
-                        below[0] = bl;
-                        above[0] = ab;
-                        return true;
-                    }
-#endif
                     for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup& wg) {
                         uint32_t rr[4], gg[4], bb[4];
                         unpack_group(a, b, c, rr, gg, bb);
@@ -1017,13 +875,6 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
                     return true;
                 },
                 s, kp, nn, lo0, hi0, lo0, hi0, true, bincache, vp, vn);
-#if TIA_F32_BINS
-        __syncthreads();
-        const int failed = s.st.approx_fail;
-        __syncthreads();
-        if (!failed) break;
-        }  // attempt
-#endif
         if (tid == 0) {
             s.tm[TM_PHI_TOTAL] = clock64() - t_begin;
             s.tm[15] = s.st.level[0] * 1000000 + s.st.level[1] * 100000 + (long long)s.st.cnt[0] + (long long)s.st.cnt[1] * 0;
@@ -1133,26 +984,6 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
             hi0[t] = whi;
         }
         double vp[2], vn[2];
-#if TIA_F32_BINS
-        // float32 concentrations for binning: |c~ - c| <= 4 ulp(f32) * od_max * (|P0|+|P1|+|P2|) plus 2.4e-4 of a bin
-        // from the float32 bin arithmetic; usable when that stays below 1/8 of the bin width for both channels
-        const float Pf[6] = {(float)P[0], (float)P[1], (float)P[2], (float)P[3], (float)P[4], (float)P[5]};
-        bool conc_can = true;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const double width = (hi0[t] - lo0[t]) / (double)NB;
-            const double err = 2.4e-7 * ob * (fabs(P[0 + t]) + fabs(P[2 + t]) + fabs(P[4 + t])) + 2.4e-4 * width;
-            conc_can = conc_can && width > 0.0 && err < 0.125 * width;
-        }
-        bool conc_approx = true;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-        conc_approx = attempt == 0 && conc_can;
-        if (tid == 0) {
-            s.st.approx = conc_approx ? 1 : 0;
-            s.st.approx_fail = 0;
-        }
-        __syncthreads();
-#endif
         select2(p, hw,
                 [&](long, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
                     const double ox = OD(r), oy = OD(g), oz = OD(b);
@@ -1164,48 +995,6 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
                     if (!grp) return false;
                     const double l0 = s.st.lo[0][0], s0 = s.st.scale[0][0], l1 = s.st.lo[1][0], s1 = s.st.scale[1][0];
                     unsigned bl0 = 0, ab0 = 0, bl1 = 0, ab1 = 0;
-#if TIA_F32_BINS
-                    if (conc_approx) {
-                        const float l0f = (float)l0, s0f = (float)s0, l1f = (float)l1, s1f = (float)s1;
-                        for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup& wg) {
-                            uint32_t rr[4], gg[4], bb[4];
-                            unpack_group(a, b, c, rr, gg, bb);
-                            float fx[4], fy[4], fz[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                fx[i] = s.odf[rr[i]];
-                                fy[i] = s.odf[gg[i]];
-                                fz[i] = s.odf[bb[i]];
-                            }
-                            unsigned long long code0 = 0ull, code1 = 0ull;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float c0 = __builtin_fmaf(fz[i], Pf[4], __builtin_fmaf(fy[i], Pf[2], fx[i] * Pf[0]));
-                                const float c1 = __builtin_fmaf(fz[i], Pf[5], __builtin_fmaf(fy[i], Pf[3], fx[i] * Pf[1]));
-                                const float d0 = (c0 - l0f) * s0f, d1 = (c1 - l1f) * s1f;
-                                const bool low0 = !(d0 >= 0.0f), high0 = d0 >= (float)NB;
-                                const bool low1 = !(d1 >= 0.0f), high1 = d1 >= (float)NB;
-                                const int b0 = low0 ? 0 : (high0 ? NB - 1 : (int)d0);
-                                const int b1 = low1 ? 0 : (high1 ? NB - 1 : (int)d1);
-                                bl0 += low0 ? 1u : 0u;
-                                ab0 += high0 ? 1u : 0u;
-                                bl1 += low1 ? 1u : 0u;
-                                ab1 += high1 ? 1u : 0u;
-                                hist_add(s.bins[0], b0, !low0 && !high0, wg);
-                                hist_add(s.bins[1], b1, !low1 && !high1, wg);
-                                code0 |= (unsigned long long)(unsigned)b0 << (16 * i);
-                                code1 |= (unsigned long long)(unsigned)b1 << (16 * i);
-                            }
-                            *reinterpret_cast<unsigned long long*>(bincache + g * 4) = code0;
-                            *reinterpret_cast<unsigned long long*>(bincache + (size_t)hw + g * 4) = code1;
-                        });
-                        below[0] = bl0;
-                        above[0] = ab0;
-                        below[1] = bl1;
-                        above[1] = ab1;
-                        return true;
-                    }
-#endif
                     for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup& wg) {
                         uint32_t rr[4], gg[4], bb[4];
                         unpack_group(a, b, c, rr, gg, bb);
@@ -1244,13 +1033,6 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
                     return true;
                 },
                 s, kp, nn, lo0, hi0, olo0, ohi0, false, bincache, vp, vn);
-#if TIA_F32_BINS
-        __syncthreads();
-        const int failed = s.st.approx_fail;
-        __syncthreads();
-        if (!failed) break;
-        }  // attempt
-#endif
         if (tid == 0) {
             s.tm[11] = s.st.level[0];
             s.tm[12] = s.st.level[1];
