@@ -24,7 +24,7 @@ extern "C" {
 #define TIA_ELAUNCH (-2)  /* hipLaunch / runtime failure (hipGetLastError() != success)  */
 #define TIA_ESIZE (-3)    /* size outside what the kernel supports                        */
 
-#define TIA_ABI_VERSION 1
+#define TIA_ABI_VERSION 2
 int tia_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -60,7 +60,14 @@ typedef struct tia_stain_tables {
 #define TIA_FLAG_DEGENERATE 2
 
 #define TIA_MODE_MACENKO 0 /* estimate the stain matrix per patch (MacenkoExtractor)       */
-#define TIA_MODE_FIXED 1   /* stain matrix given (Custom / Ruifrok / Vahadane-apply)        */
+#define TIA_MODE_FIXED 1   /* stain matrix given (Custom / Ruifrok)                         */
+#define TIA_MODE_GIVEN 3   /* as TIA_MODE_FIXED, but every patch brings its own stain matrix: d_stats[i][TIA_ST_STAIN..+5]
+                              is read on entry (StainAugmentor.fit on a batch, stainaugment.py:141-175) */
+#define TIA_MODE_VAHADANE 2 /* per-patch dictionary learning (VahadaneExtractor, stainextract.py:281-322): X = tissue
+                              OD transposed (3 x N), sklearn DictionaryLearning(n_components=2, alpha, fit_algorithm="lars",
+                              positive_dict=True, max_iter) restated -- SVD initialisation, two-atom lasso codes, in-place
+                              dictionary update with the 1e-6 unused-atom rule, cost-based stopping; the stain matrix is
+                              the code transposed, H row first, unit rows */
 
 typedef struct tia_stain_params {
     double q_img_lo;        /* contrast_enhancer low percentile / 100   (0.02) */
@@ -76,6 +83,10 @@ typedef struct tia_stain_params {
     int32_t has_target;     /* 1: also emit TIA_ST_M / TIA_ST_SCALE                          */
     int32_t zero_to_one;    /* 1: treat byte 0 as 1 in the mask path (rgb2od's in-place edit
                                seen by StainAugmentor.fit, stainaugment.py:163-175)          */
+    double dl_alpha;        /* TIA_MODE_VAHADANE: regularizer (alpha = transform_alpha, 0.1; stainextract.py:307-308) */
+    double dl_tol;          /* DictionaryLearning.tol (1e-8)                                  */
+    int32_t dl_max_iter;    /* DictionaryLearning.max_iter (3; stainextract.py:313)           */
+    int32_t dl_seed;        /* stream of the unused-atom re-draw (the reference is unseeded)  */
 } tia_stain_params;
 
 /*
@@ -88,8 +99,11 @@ typedef struct tia_stain_params {
  *   d_ws     optional scratch of tia_stain_stats_workspace_bytes(n,h,w) bytes (8-byte aligned): a
  *            per-pixel histogram-bin cache that lets the selection's collect passes skip the value
  *            computation; with NULL / too little space the kernel recomputes (same results).
+ *            TIA_MODE_VAHADANE needs tia_stain_stats_workspace_bytes_mode(n,h,w,mode) bytes, 16-byte aligned
+ *            (bin cache + the 2 x N float64 dictionary of every patch); too little -> TIA_ESIZE.
  */
 size_t tia_stain_stats_workspace_bytes(int64_t n, int64_t h, int64_t w);
+size_t tia_stain_stats_workspace_bytes_mode(int64_t n, int64_t h, int64_t w, int32_t mode);
 int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
                        const tia_stain_tables* d_tables, const tia_stain_params* params,
                        double* d_stats, void* d_ws, size_t ws_bytes, void* stream);

@@ -18,7 +18,7 @@ ST_CYCLES = 48
 ST_STAIN, ST_MAXC, ST_NTISSUE, ST_PLOW, ST_PHIGH = 0, 6, 8, 9, 10
 ST_MINPHI, ST_MAXPHI, ST_COV, ST_EVEC, ST_FLAGS, ST_PINV, ST_M, ST_SCALE = 11, 12, 13, 19, 25, 26, 32, 41
 FLAG_EMPTY_MASK, FLAG_DEGENERATE = 1, 2
-MODE_MACENKO, MODE_FIXED = 0, 1
+MODE_MACENKO, MODE_FIXED, MODE_VAHADANE, MODE_GIVEN = 0, 1, 2, 3
 OUT_U8, OUT_F32, OUT_F64, OUT_UNIT_F16, OUT_UNIT_BF16, OUT_UNIT_F32 = 0, 1, 2, 3, 4, 5
 MATH_F64, MATH_F32 = 0, 1
 
@@ -37,6 +37,7 @@ class StainParams(C.Structure):
         ("q_phi_hi", C.c_double), ("q_conc", C.c_double), ("stain_fixed", C.c_double * 6),
         ("target_stain", C.c_double * 6), ("target_maxc", C.c_double * 2), ("y_thr", C.c_int32),
         ("mode", C.c_int32), ("has_target", C.c_int32), ("zero_to_one", C.c_int32),
+        ("dl_alpha", C.c_double), ("dl_tol", C.c_double), ("dl_max_iter", C.c_int32), ("dl_seed", C.c_int32),
     ]
 
 
@@ -57,6 +58,7 @@ _I64, _I32, _P = C.c_int64, C.c_int32, C.c_void_p
 _SIGNATURES = {
     "tia_abi_version": ([], C.c_int),
     "tia_stain_stats_workspace_bytes": ([_I64, _I64, _I64], C.c_size_t),
+    "tia_stain_stats_workspace_bytes_mode": ([_I64, _I64, _I64, _I32], C.c_size_t),
     "tia_stain_stats_u8": ([_P, _I64, _I64, _I64, _P, C.POINTER(StainParams), _P, _P, C.c_size_t, _P], C.c_int),
     "tia_stain_apply_u8": ([_P, _I64, _I64, _I64, _P, _P, C.POINTER(C.c_double), _P, _I32, _I32, _P], C.c_int),
     "tia_stain_concentrations_f64": ([_P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),

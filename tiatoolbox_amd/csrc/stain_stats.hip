@@ -8,6 +8,8 @@
 //   P5/P6 exact 99th percentile of both stain concentrations
 // Reference: tools/stainextract.py:177-227, tools/stainnorm.py:49-66,81-85,103,
 //            utils/misc.py:261-290,405-444, utils/transforms.py:209-231.
+#include <type_traits>
+
 #include "common.hpp"
 
 // numpy evaluates these expressions without fused multiply-add; keep the per-patch
@@ -553,14 +555,71 @@ __device__ void jacobi3(const double (&a6)[6], double (&w)[3], double (&v)[3][3]
     w[2] = a[2][2];
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Vahadane: sklearn.decomposition.DictionaryLearning restated (stainextract.py:305-316)
+// ---------------------------------------------------------------------------------------
+// One target of LassoLars(alpha/N, fit_intercept=False, precompute=gram).fit(D^T, x, Xy=cov) with two atoms, i.e. the
+// minimiser of 0.5 w'Gw - c'w + alpha |w|_1 (sklearn scales the squared error by 1/(2N), alpha by 1/N: same problem).
+// The lasso path ends at the unique minimiser; with two variables it is one of nine orthant-face minimisers, and the
+// global one is the face minimiser that lies in its own (closed) orthant with the smallest objective.
+__device__ void lasso2(double g00, double g01, double g11, double c0, double c1, double alpha, double (&w)[2]) {
+    auto obj = [&](double a, double b) {
+        return 0.5 * (g00 * a * a + 2.0 * g01 * a * b + g11 * b * b) - (c0 * a + c1 * b) + alpha * (fabs(a) + fabs(b));
+    };
+    double best = 0.0;  // w = 0
+    w[0] = 0.0;
+    w[1] = 0.0;
+    if (fabs(c0) > alpha && g00 > 0.0) {
+        const double a = (c0 - (c0 > 0.0 ? alpha : -alpha)) / g00;
+        const double f = obj(a, 0.0);
+        if (f < best) { best = f; w[0] = a; w[1] = 0.0; }
+    }
+    if (fabs(c1) > alpha && g11 > 0.0) {
+        const double b = (c1 - (c1 > 0.0 ? alpha : -alpha)) / g11;
+        const double f = obj(0.0, b);
+        if (f < best) { best = f; w[0] = 0.0; w[1] = b; }
+    }
+    const double det = g00 * g11 - g01 * g01;
+    if (det > 0.0) {
+        for (int k = 0; k < 4; ++k) {
+            const double s0 = (k & 1) ? -1.0 : 1.0, s1 = (k & 2) ? -1.0 : 1.0;
+            const double r0 = c0 - alpha * s0, r1 = c1 - alpha * s1;
+            const double a = (g11 * r0 - g01 * r1) / det, b = (g00 * r1 - g01 * r0) / det;
+            if (a * s0 > 0.0 && b * s1 > 0.0) {
+                const double f = obj(a, b);
+                if (f < best) { best = f; w[0] = a; w[1] = b; }
+            }
+        }
+    }
+}
+// counter-based generator for the (rare) "atom never used" branch of _update_dict (:527-536).  The reference leaves
+// DictionaryLearning unseeded, so no particular random stream is the right one; this one is a function of
+// (seed, patch, iteration, atom, pixel) only, hence deterministic and independent of scheduling.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double unit_open(unsigned long long z) { return ((double)(z >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+__device__ __noinline__ double normal_of(unsigned long long key) {
+    const double u1 = unit_open(mix64(key)), u2 = unit_open(mix64(key ^ 0xd1b54a32d192ed03ull));
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
 // ---------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __restrict__ img, long hw,
+// DL = true: the TIA_MODE_VAHADANE instantiation (dictionary learning instead of the Macenko branch); kept apart so that
+// its extra live state does not cost the Macenko / fixed-matrix kernel registers.
+template <bool DL>
+__global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8_t* __restrict__ img, long hw,
                                                           const tia_stain_tables* __restrict__ tab,
                                                           tia_stain_params prm,
                                                           double* __restrict__ stats,
-                                                          uint16_t* __restrict__ binws) {
+                                                          uint16_t* __restrict__ binws,
+                                                          double2* __restrict__ dictws) {
     __shared__ Smem s;
     const uint8_t* p = img + (size_t)blockIdx.x * (size_t)hw * 3u;
     double* out = stats + (size_t)blockIdx.x * TIA_STATS_STRIDE;
@@ -568,6 +627,13 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
     const int tid = threadIdx.x;
     const bool z1 = prm.zero_to_one != 0;
 
+    // TIA_MODE_GIVEN: the caller's per-patch stain matrix arrives in the statistics record itself
+    double s_given[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (!DL && prm.mode == TIA_MODE_GIVEN) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s_given[i] = out[TIA_ST_STAIN + i];
+        __syncthreads();
+    }
     if (tid < TIA_STATS_STRIDE) out[tid] = 0.0;
     for (int i = tid; i < 256 * ODR; i += NT) s.od[i] = tab->od_lut[i / ODR];
     const int odl = tid & (ODR - 1);
@@ -716,7 +782,7 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
     double S[6];  // source stain matrix rows H,E
     unsigned flags = 0;
 
-    if (prm.mode == TIA_MODE_MACENKO) {
+    if (!DL && prm.mode == TIA_MODE_MACENKO) {
         // ---- P2: tissue mask + OD moments -----------------------------------------------------
         double acc[13];
 #pragma unroll
@@ -900,9 +966,241 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 6; ++i) S[i] = s.bc[8 + i];
+    } else if (DL) {
+        // ---- Vahadane: X = OD[tissue].T (3 samples x N pixel features); code, dictionary = dict_learning(X, 2 atoms,
+        //      alpha, max_iter, tol, method="lasso_lars", positive_dict=True); the stain matrix is the CODE (3 x 2)
+        //      transposed (stainextract.py:316).  The dictionary (2 x N, f64) lives in the per-patch scratch `dict`,
+        //      everything else is a handful of whole-patch reductions between sweeps.
+        double2* __restrict__ dict = dictws + (size_t)blockIdx.x * (size_t)hw;
+        const double alpha = prm.dl_alpha;
+        // S0: uncentred second moments of the tissue OD (X X^T), tissue sums, all-pixel cross moments
+        double acc[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) acc[i] = 0.0;
+        for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
+            const double x = OD(r), y = OD(g), z = OD(b);
+            acc[10] = __builtin_fma(x, y, acc[10]);
+            acc[11] = __builtin_fma(x, z, acc[11]);
+            acc[12] = __builtin_fma(y, z, acc[12]);
+            if (is_tissue(r, g, b)) {
+                acc[0] += 1.0;
+                acc[1] += x;
+                acc[2] += y;
+                acc[3] += z;
+                acc[4] = __builtin_fma(x, x, acc[4]);
+                acc[5] = __builtin_fma(x, y, acc[5]);
+                acc[6] = __builtin_fma(x, z, acc[6]);
+                acc[7] = __builtin_fma(y, y, acc[7]);
+                acc[8] = __builtin_fma(y, z, acc[8]);
+                acc[9] = __builtin_fma(z, z, acc[9]);
+            }
+        });
+        block_sum(acc, s);
+        if (tid < 3) s.chx[tid] = acc[10 + tid];
+        if (tid < 10) s.bc[24 + tid] = acc[tid];  // tissue count, sums and second moments (unused-atom re-draw)
+        stamp(s, TM_P2);
+        const double nt = acc[0];
+        if (nt == 0.0) {
+            if (tid == 0) {
+                out[TIA_ST_NTISSUE] = 0.0;
+                out[TIA_ST_FLAGS] = (double)TIA_FLAG_EMPTY_MASK;
+            }
+            return;  // uniform across the block
+        }
+        // SVD of X through the eigen-decomposition of X X^T: U = eigenvectors (descending), s_k = sqrt(w_k),
+        // s_k * Vt_k = u_k^T X; svd_flip makes the largest-magnitude entry of every u_k positive (_dict_learning :592-596)
+        if (tid == 0) {
+            const double g6[6] = {acc[4], acc[5], acc[6], acc[7], acc[8], acc[9]};
+            double w[3], v[3][3];
+            jacobi3(g6, w, v);
+            int i0 = 0, i1 = 1, i2 = 2;
+            if (w[i0] < w[i1]) { int t = i0; i0 = i1; i1 = t; }
+            if (w[i0] < w[i2]) { int t = i0; i0 = i2; i2 = t; }
+            if (w[i1] < w[i2]) { int t = i1; i1 = i2; i2 = t; }
+            const int order[2] = {i0, i1};
+            for (int k = 0; k < 2; ++k) {
+                double u[3] = {v[0][order[k]], v[1][order[k]], v[2][order[k]]};
+                int m = 0;
+                if (fabs(u[1]) > fabs(u[m])) m = 1;
+                if (fabs(u[2]) > fabs(u[m])) m = 2;
+                const double sg = u[m] < 0.0 ? -1.0 : 1.0;
+                for (int c = 0; c < 3; ++c) s.bc[16 + c * 2 + k] = u[c] * sg;  // code[c][k]
+            }
+            out[TIA_ST_NTISSUE] = nt;
+        }
+        __syncthreads();
+        stamp(s, TM_EIG);
+        double code[3][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            code[c][0] = s.bc[16 + c * 2];
+            code[c][1] = s.bc[16 + c * 2 + 1];
+        }
+        // S1: dictionary_k = u_k^T X, with the Gram matrix and covariance the first sparse coding needs
+        double gc[9];  // g00 g01 g11 | cov[k][c] = d_k . x_c
+        auto gram_cov_reset = [&]() {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) gc[i] = 0.0;
+        };
+        auto gram_cov_add = [&](double d0, double d1, double x, double y, double z) {
+            gc[0] = __builtin_fma(d0, d0, gc[0]);
+            gc[1] = __builtin_fma(d0, d1, gc[1]);
+            gc[2] = __builtin_fma(d1, d1, gc[2]);
+            gc[3] = __builtin_fma(d0, x, gc[3]);
+            gc[4] = __builtin_fma(d0, y, gc[4]);
+            gc[5] = __builtin_fma(d0, z, gc[5]);
+            gc[6] = __builtin_fma(d1, x, gc[6]);
+            gc[7] = __builtin_fma(d1, y, gc[7]);
+            gc[8] = __builtin_fma(d1, z, gc[8]);
+        };
+        gram_cov_reset();
+        for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+            if (!is_tissue(r, g, b)) return;
+            const double x = OD(r), y = OD(g), z = OD(b);
+            const double d0 = dot3(x, y, z, code[0][0], code[1][0], code[2][0]);
+            const double d1 = dot3(x, y, z, code[0][1], code[1][1], code[2][1]);
+            dict[idx] = make_double2(d0, d1);
+            gram_cov_add(d0, d1, x, y, z);
+        });
+        block_sum(gc, s);
+        double cost_prev = 0.0;
+        int n_iter = 0;
+        for (int it = 0; it < prm.dl_max_iter; ++it) {
+            n_iter = it + 1;
+            // sparse coding of the three samples (R, G, B rows of X) against the two atoms
+            // (one lane per sample; the codes travel through LDS so the solver is not inlined three times per lane)
+            __syncthreads();
+            if (tid < 3) {
+                double wv[2];
+                lasso2(gc[0], gc[1], gc[2], gc[3 + tid], gc[6 + tid], alpha, wv);
+                s.bc[16 + tid * 2] = wv[0];
+                s.bc[16 + tid * 2 + 1] = wv[1];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                code[c][0] = s.bc[16 + c * 2];
+                code[c][1] = s.bc[16 + c * 2 + 1];
+            }
+            // _update_dict (:519-545): A = code^T code, B = X^T code; atoms updated one after the other
+            double A[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                A[0][0] += code[c][0] * code[c][0];
+                A[0][1] += code[c][0] * code[c][1];
+                A[1][1] += code[c][1] * code[c][1];
+            }
+            A[1][0] = A[0][1];
+            const bool last = it + 1 == prm.dl_max_iter;
+            if (last) {  // the returned code only sees _update_dict through the zeroing of unused atoms
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (!(A[k][k] > 1e-6))
+                        for (int c = 0; c < 3; ++c) code[c][k] = 0.0;
+                break;
+            }
+            double nrm0 = 1.0, nrm1 = 1.0;
+            auto update_atom = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const bool used = A[k][k] > 1e-6;
+                int pick = 0;
+                double level = 0.0;
+                if (!used) {  // atom (almost) never used: re-draw it from the data plus a little noise
+                    const unsigned long long key = mix64((unsigned long long)prm.dl_seed * 0x100000001b3ull ^
+                                                         ((unsigned long long)blockIdx.x << 20) ^ (unsigned long long)(it * 2 + k));
+                    pick = (int)(key % 3ull);
+                    const double m1 = s.bc[24 + 1 + pick] / nt, m2 = s.bc[24 + (pick == 0 ? 4 : (pick == 1 ? 7 : 9))] / nt;
+                    double var = m2 - m1 * m1;
+                    var = var > 0.0 ? var : 0.0;
+                    const double sd = sqrt(var);
+                    level = 0.01 * (sd != 0.0 ? sd : 1.0);
+                    for (int c = 0; c < 3; ++c) code[c][k] = 0.0;
+                }
+                const double akk = A[k][k], ak0 = A[k][0], ak1 = A[k][1];
+                const double ck0 = code[0][k], ck1 = code[1][k], ck2 = code[2][k];
+                const double n0 = nrm0;  // atom 0 is divided by its norm lazily, while atom 1 is updated
+                double nn2[1] = {0.0};
+                const unsigned long long nkey = mix64((unsigned long long)prm.dl_seed ^ ((unsigned long long)blockIdx.x << 32) ^
+                                                      (unsigned long long)(it * 2 + k + 1));
+                if (used) {
+                    for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+                        if (!is_tissue(r, g, b)) return;
+                        const double x = OD(r), y = OD(g), z = OD(b);
+                        double2 d = dict[idx];
+                        if (k == 1) d.x = d.x / n0;  // dictionary[0] /= max(norm, 1)
+                        const double bk = x * ck0 + y * ck1 + z * ck2;           // B[:, k]
+                        const double ad = ak0 * d.x + ak1 * d.y;                 // A[k] @ dictionary
+                        double v = (k == 0 ? d.x : d.y) + (bk - ad) / akk;
+                        v = v < 0.0 ? 0.0 : v;  // positive_dict
+                        if (k == 0) d.x = v; else d.y = v;
+                        dict[idx] = d;
+                        nn2[0] = __builtin_fma(v, v, nn2[0]);
+                    });
+                } else {  // rare: plain loop, keeps the transcendental code out of the unrolled sweep
+                    for (long idx = tid; idx < hw; idx += NT) {
+                        const uint32_t r = p[3 * idx], g = p[3 * idx + 1], b = p[3 * idx + 2];
+                        if (!is_tissue(r, g, b)) continue;
+                        double2 d = dict[idx];
+                        if (k == 1) d.x = d.x / n0;
+                        const double base = pick == 0 ? OD(r) : (pick == 1 ? OD(g) : OD(b));
+                        double v = base + level * normal_of(nkey + (unsigned long long)idx * 0x9e3779b97f4a7c15ull);
+                        v = v < 0.0 ? 0.0 : v;
+                        if (k == 0) d.x = v; else d.y = v;
+                        dict[idx] = d;
+                        nn2[0] = __builtin_fma(v, v, nn2[0]);
+                    }
+                }
+                block_sum(nn2, s);
+                const double nv = sqrt(nn2[0]);
+                (k == 0 ? nrm0 : nrm1) = nv > 1.0 ? nv : 1.0;
+            };
+            update_atom(std::integral_constant<int, 0>{});
+            update_atom(std::integral_constant<int, 1>{});
+            // atom 1's normalisation is applied in the sweep that evaluates the cost and prepares the next coding
+            const double n1 = nrm1;
+            double cst[1] = {0.0};
+            gram_cov_reset();
+            for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+                if (!is_tissue(r, g, b)) return;
+                const double x = OD(r), y = OD(g), z = OD(b);
+                double2 d = dict[idx];
+                d.y = d.y / n1;
+                dict[idx] = d;
+                const double ex = x - (code[0][0] * d.x + code[0][1] * d.y);
+                const double ey = y - (code[1][0] * d.x + code[1][1] * d.y);
+                const double ez = z - (code[2][0] * d.x + code[2][1] * d.y);
+                cst[0] += ex * ex + ey * ey + ez * ez;
+                gram_cov_add(d.x, d.y, x, y, z);
+            });
+            block_sum(cst, s);
+            block_sum(gc, s);
+            double l1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) l1 += fabs(code[c][0]) + fabs(code[c][1]);
+            const double cost = 0.5 * cst[0] + alpha * l1;
+            if (it > 0 && (cost_prev - cost) < prm.dl_tol * cost) break;  // :657-665
+            cost_prev = cost;
+        }
+        // dictionary = code.T; H first (dl_output_for_h_and_e, :53-68); unit rows (:322)
+        {
+            double h[3] = {code[0][0], code[1][0], code[2][0]}, e[3] = {code[0][1], code[1][1], code[2][1]};
+            const bool swap = h[0] < e[0];
+            const double nh = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+            const double ne = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double hv = h[i] / nh, ev = e[i] / ne;
+                S[i] = swap ? ev : hv;
+                S[3 + i] = swap ? hv : ev;
+            }
+        }
+        if (tid == 0) {
+            out[TIA_ST_MINPHI] = (double)n_iter;  // Vahadane: number of dictionary-learning iterations run
+            s.tm[TM_PHI_TOTAL] = clock64() - t_begin;
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) S[i] = prm.stain_fixed[i];
+        for (int i = 0; i < 6; ++i) S[i] = prm.mode == TIA_MODE_GIVEN ? s_given[i] : prm.stain_fixed[i];
         double acc[3] = {0.0, 0.0, 0.0};
         for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
             const double x = OD(r), y = OD(g), z = OD(b);
@@ -1073,9 +1371,18 @@ __global__ __launch_bounds__(NT, 4) void stain_stats_kernel(const uint8_t* __res
 
 }  // namespace tia
 
+static size_t align256s(size_t x) { return (x + 255) & ~(size_t)255; }
+
 extern "C" size_t tia_stain_stats_workspace_bytes(int64_t n, int64_t h, int64_t w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
     return (size_t)n * (size_t)h * (size_t)w * 2u * sizeof(uint16_t);
+}
+
+extern "C" size_t tia_stain_stats_workspace_bytes_mode(int64_t n, int64_t h, int64_t w, int32_t mode) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    const size_t bins = align256s(tia_stain_stats_workspace_bytes(n, h, w));
+    if (mode != TIA_MODE_VAHADANE) return bins;
+    return bins + (size_t)n * (size_t)h * (size_t)w * sizeof(double2);  // the 2 x N dictionary of every patch
 }
 
 extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
@@ -1083,16 +1390,24 @@ extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, in
                                    double* d_stats, void* d_ws, size_t ws_bytes, void* stream) {
     if (!d_img || !d_tables || !params || !d_stats) return TIA_EINVAL;
     if (n <= 0 || h <= 0 || w <= 0) return TIA_EINVAL;
-    if (params->mode != TIA_MODE_MACENKO && params->mode != TIA_MODE_FIXED) return TIA_EINVAL;
+    if (params->mode < TIA_MODE_MACENKO || params->mode > TIA_MODE_GIVEN) return TIA_EINVAL;
     const long hw = (long)h * (long)w;
     if ((unsigned long long)hw * 3ull >= 0xffffffffull) return TIA_ESIZE;  // 32-bit histogram counts
     if (n > 0x7fffffffll) return TIA_ESIZE;
+    const bool aligned = d_ws && (reinterpret_cast<uintptr_t>(d_ws) & 15) == 0;
     // the per-pixel bin cache is optional: without (enough) workspace the kernel recomputes values
-    uint16_t* binws = (d_ws && ws_bytes >= tia_stain_stats_workspace_bytes(n, h, w) &&
-                       (reinterpret_cast<uintptr_t>(d_ws) & 7) == 0)
-                          ? (uint16_t*)d_ws
-                          : nullptr;
-    hipLaunchKernelGGL(tia::stain_stats_kernel, dim3((unsigned)n), dim3(tia::NT), 0,
-                       (hipStream_t)stream, d_img, hw, d_tables, *params, d_stats, binws);
+    uint16_t* binws = (aligned && ws_bytes >= tia_stain_stats_workspace_bytes(n, h, w)) ? (uint16_t*)d_ws : nullptr;
+    double2* dictws = nullptr;
+    if (params->mode == TIA_MODE_VAHADANE) {  // the dictionary scratch is not optional
+        if (!aligned || ws_bytes < tia_stain_stats_workspace_bytes_mode(n, h, w, TIA_MODE_VAHADANE)) return TIA_ESIZE;
+        if (params->dl_max_iter < 1 || !(params->dl_alpha >= 0.0)) return TIA_EINVAL;
+        dictws = (double2*)((char*)d_ws + align256s(tia_stain_stats_workspace_bytes(n, h, w)));
+    }
+    if (params->mode == TIA_MODE_VAHADANE)
+        hipLaunchKernelGGL(tia::stain_stats_kernel<true>, dim3((unsigned)n), dim3(tia::NT), 0, (hipStream_t)stream, d_img, hw,
+                           d_tables, *params, d_stats, binws, dictws);
+    else
+        hipLaunchKernelGGL(tia::stain_stats_kernel<false>, dim3((unsigned)n), dim3(tia::NT), 0, (hipStream_t)stream, d_img, hw,
+                           d_tables, *params, d_stats, binws, dictws);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

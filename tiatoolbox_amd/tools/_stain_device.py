@@ -59,8 +59,10 @@ def as_batch(img: torch.Tensor) -> torch.Tensor:
 
 def make_params(*, mode: int, luminosity_threshold: float = 0.8, angular_percentile: float = 99,
                 stain_fixed: np.ndarray | None = None, target_stain: np.ndarray | None = None,
-                target_maxc: np.ndarray | None = None, zero_to_one: bool = False) -> _lib.StainParams:
+                target_maxc: np.ndarray | None = None, zero_to_one: bool = False, dl_alpha: float = 0.1,
+                dl_tol: float = 1e-8, dl_max_iter: int = 3, dl_seed: int = 0) -> _lib.StainParams:
     p = _lib.StainParams()
+    p.dl_alpha, p.dl_tol, p.dl_max_iter, p.dl_seed = float(dl_alpha), float(dl_tol), int(dl_max_iter), int(dl_seed)
     # np.percentile divides q by 100 in float64 (numpy/lib/_function_base_impl.py: percentile)
     p.q_img_lo = float(np.true_divide(2, 100))
     p.q_img_hi = float(np.true_divide(98, 100))
@@ -83,19 +85,33 @@ def make_params(*, mode: int, luminosity_threshold: float = 0.8, angular_percent
     return p
 
 
-def stain_stats(img: torch.Tensor, params: _lib.StainParams) -> torch.Tensor:
-    """Per-patch statistics ``[N, 48]`` float64 (see ``include/tiatoolbox_amd.h``)."""
+_VAHADANE_CHUNK_BYTES = 8 << 30  # dictionary scratch per launch (16 B per pixel per patch): bigger batches go in chunks
+
+
+def stain_stats(img: torch.Tensor, params: _lib.StainParams, stain_given: torch.Tensor | None = None) -> torch.Tensor:
+    """Per-patch statistics ``[N, 64]`` float64 (see ``include/tiatoolbox_amd.h``).  ``MODE_GIVEN``: ``stain_given``
+    ``[N, 2, 3]`` float64 = each patch's own stain matrix."""
     img = as_batch(img)
     n, h, w, _ = img.shape
     stats = torch.empty((n, _lib.TIA_STATS_STRIDE), dtype=torch.float64, device=img.device)
+    if params.mode == _lib.MODE_GIVEN:
+        if stain_given is None or tuple(stain_given.shape) != (n, 2, 3):
+            msg = "MODE_GIVEN needs an [N, 2, 3] stain matrix tensor."
+            raise ValueError(msg)
+        stats[:, _lib.ST_STAIN:_lib.ST_STAIN + 6] = stain_given.to(device=img.device, dtype=torch.float64).reshape(n, 6)
     tab = tables(img.device)
     lib = _lib.load()
-    ws_bytes = lib.tia_stain_stats_workspace_bytes(n, h, w)
+    chunk = n
+    if params.mode == _lib.MODE_VAHADANE:
+        chunk = max(1, min(n, _VAHADANE_CHUNK_BYTES // (h * w * 20)))
+    ws_bytes = lib.tia_stain_stats_workspace_bytes_mode(chunk, h, w, params.mode)
     ws = _workspace(img.device, ws_bytes)
     with torch.cuda.device(img.device):
-        rc = lib.tia_stain_stats_u8(img.data_ptr(), n, h, w, tab.data_ptr(), C.byref(params), stats.data_ptr(),
-                                    ws.data_ptr(), ws_bytes, _lib.current_stream())
-    _lib.check(rc, "tia_stain_stats_u8")
+        for s in range(0, n, chunk):
+            m = min(chunk, n - s)
+            rc = lib.tia_stain_stats_u8(img[s:s + m].data_ptr(), m, h, w, tab.data_ptr(), C.byref(params),
+                                        stats[s:s + m].data_ptr(), ws.data_ptr(), ws_bytes, _lib.current_stream())
+            _lib.check(rc, "tia_stain_stats_u8")
     return stats
 
 

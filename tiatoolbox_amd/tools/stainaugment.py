@@ -62,6 +62,7 @@ class StainAugmentor(ImageOnlyTransform):
         self.img_shape: tuple[int, ...]
         self.n_stains: int = 2
         self._batch = None
+        self._own_matrix = False
         self._stats = None
         self._y_thr = 0
         self._kind = "np3"
@@ -73,16 +74,19 @@ class StainAugmentor(ImageOnlyTransform):
         in place (:163-175); ``zero_to_one`` reproduces that.
         """
         batch, kind = _tensors.to_device_batch(img)
-        if batch.shape[0] != 1:
-            msg = "StainAugmentor.fit expects a single HxWx3 image."
-            raise ValueError(msg)
-        if self.stain_matrix is None:
-            sm = self.stain_normalizer.extractor.get_stain_matrix(batch[0])
-            self.stain_matrix = sm.cpu().numpy() if isinstance(sm, torch.Tensor) else np.asarray(sm)
-        sm = self.stain_matrix
-        params = dev.make_params(mode=_lib.MODE_FIXED, luminosity_threshold=threshold,
-                                 stain_fixed=np.asarray(sm, dtype=np.float64).reshape(2, 3), zero_to_one=True)
-        self._stats = dev.stain_stats(batch, params)
+        n = batch.shape[0]
+        if self.stain_matrix is None or self._own_matrix:
+            # reference behaviour for one image (:153-161); for an NHWC batch every patch gets its own matrix, which is
+            # then not kept as `stain_matrix` (a later fit() on other images estimates afresh)
+            sm = self.stain_normalizer.extractor.get_stain_matrix(batch)
+            sm = sm if isinstance(sm, torch.Tensor) else torch.from_numpy(np.asarray(sm))
+            sm = sm.reshape(-1, 2, 3)
+            self.stain_matrix = sm[0].cpu().numpy() if n == 1 else sm.cpu().numpy()
+            self._own_matrix = n != 1
+        else:
+            sm = torch.from_numpy(np.asarray(self.stain_matrix, dtype=np.float64).reshape(1, 2, 3)).expand(n, 2, 3)
+        params = dev.make_params(mode=_lib.MODE_GIVEN, luminosity_threshold=threshold, zero_to_one=True)
+        self._stats = dev.stain_stats(batch, params, stain_given=sm.contiguous())
         self._y_thr = params.y_thr
         self._batch, self._kind = batch, kind
         self.n_stains = 2

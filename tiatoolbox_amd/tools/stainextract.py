@@ -1,9 +1,9 @@
 """Stain-matrix extraction (API of reference ``tiatoolbox/tools/stainextract.py``).
 
 ``MacenkoExtractor`` runs entirely on the GPU (``tia_stain_stats_u8``: tissue mask, OD
-covariance, eigen-decomposition, exact angular percentiles).  ``VahadaneExtractor`` uses
-the GPU for the tissue mask / OD conversion and scikit-learn's ``DictionaryLearning`` for
-the (tiny, sequential, 3-sample) dictionary solve, exactly as the reference does.
+covariance, eigen-decomposition, exact angular percentiles), and so does ``VahadaneExtractor``
+(``TIA_MODE_VAHADANE``: the reference's scikit-learn ``DictionaryLearning`` configuration restated
+for the 3-sample problem, one workgroup per patch).
 """
 
 from __future__ import annotations
@@ -90,7 +90,14 @@ class MacenkoExtractor:
 
 
 class VahadaneExtractor:
-    """Vahadane stain extractor (ref. :230-322)."""
+    """Vahadane stain extractor (ref. :230-322), computed per patch on the GPU.
+
+    ``tia_stain_stats_u8`` in ``TIA_MODE_VAHADANE`` restates scikit-learn's ``DictionaryLearning`` as the reference
+    configures it (:305-316: 2 atoms, ``alpha = transform_alpha = regularizer``, LARS coding, ``positive_dict``,
+    ``max_iter=3``) for the 3 x N problem at hand -- X = tissue OD transposed, so the *code* (3 x 2) is the stain
+    matrix -- one workgroup per patch.  ``random_state`` only seeds the re-draw of a never-used atom
+    (``_update_dict``), which the reference leaves to an unseeded generator.
+    """
 
     def __init__(self, luminosity_threshold: float = 0.8, regularizer: float = 0.1) -> None:
         logger.warning(
@@ -103,21 +110,17 @@ class VahadaneExtractor:
         self.__luminosity_threshold = luminosity_threshold
         self.__regularizer = regularizer
         self.random_state = None  # reference leaves DictionaryLearning unseeded (:305-315)
+        self.max_iter = 3         # :313
 
-    def get_stain_matrix(self, img: np.ndarray) -> np.ndarray:
-        from sklearn.decomposition import DictionaryLearning
+    def stats_params(self, **kw) -> _lib.StainParams:
+        seed = 0 if self.random_state is None else int(self.random_state) & 0x7fffffff
+        return dev.make_params(mode=_lib.MODE_VAHADANE, luminosity_threshold=self.__luminosity_threshold,
+                               dl_alpha=self.__regularizer, dl_max_iter=self.max_iter, dl_seed=seed, **kw)
 
-        from tiatoolbox_amd.utils.misc import get_luminosity_tissue_mask
-        from tiatoolbox_amd.utils.transforms import rgb2od
-
-        batch, _ = _tensors.to_device_batch(img)
-        mask = get_luminosity_tissue_mask(batch, threshold=self.__luminosity_threshold)[0].reshape(-1)
-        img_od = rgb2od(batch)[0].reshape(-1, 3)[mask].cpu().numpy()
-        dl = DictionaryLearning(
-            n_components=2, alpha=self.__regularizer, transform_alpha=self.__regularizer,
-            fit_algorithm="lars", transform_algorithm="lasso_lars", positive_dict=True, verbose=False,
-            max_iter=3, transform_max_iter=1000, random_state=self.random_state,
-        )
-        dictionary = dl.fit_transform(X=img_od.T).T
-        dictionary = dl_output_for_h_and_e(dictionary)
-        return dictionary / np.linalg.norm(dictionary, axis=1)[:, None]
+    def get_stain_matrix(self, img):
+        """(2,3) stain matrix of an HWC image; (N,2,3) for an NHWC batch."""
+        batch, kind = _tensors.to_device_batch(img)
+        stats = dev.stain_stats(batch, self.stats_params())
+        dev.raise_on_flags(stats)
+        sm = stats[:, _lib.ST_STAIN:_lib.ST_STAIN + 6].reshape(-1, 2, 3)
+        return _tensors.from_device(sm, kind)
