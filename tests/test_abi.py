@@ -46,11 +46,34 @@ def test_python_binding_covers_header():
     assert sorted(_lib._SIGNATURES) == _declared_symbols()
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """ctypes mirrors == what a C compiler makes of ``include/tiatoolbox_amd.h`` (sizes and every field offset)."""
+    import shutil
+    import subprocess
+
     from tiatoolbox_amd import _lib
 
     assert ctypes.sizeof(_lib.StainTables) == 256 * 8 + 256 * 4 + 3 * 256 * 4
-    assert ctypes.sizeof(_lib.StainParams) == 8 * (5 + 6 + 6 + 2) + 4 * 4
+    assert ctypes.sizeof(_lib.StainParams) == 8 * (5 + 6 + 6 + 2) + 4 * 4 + 8 * 2 + 4 * 2
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    fields = [name for name, _ in _lib.StainParams._fields_]  # noqa: SLF001
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tiatoolbox_amd.h"', "int main(void) {",
+             '  printf("%zu %zu\\n", sizeof(tia_stain_params), sizeof(tia_stain_tables));']
+    lines += [f'  printf("{f} %zu\\n", offsetof(tia_stain_params, {f}));' for f in fields]
+    lines += ["  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    sizes = [int(v) for v in out[0].split()]
+    assert sizes == [ctypes.sizeof(_lib.StainParams), ctypes.sizeof(_lib.StainTables)]
+    for line in out[1:]:
+        if line.strip():
+            name, off = line.split()
+            assert getattr(_lib.StainParams, name).offset == int(off), name
 
 
 def test_no_cpu_fallback_without_gpu():
