@@ -364,6 +364,26 @@ int tia_bias_act_nhwc(void* d_x, const void* d_bias, const void* d_residual, int
 int tia_bias_relu_maxpool_nhwc(const void* d_x, const void* d_bias, int64_t n, int64_t h, int64_t w,
                                int64_t c, int32_t dtype, void* d_out, void* stream);
 
+/* =======================================================================================
+ * All borders of binary planes: cv2.findContours(layer, RETR_TREE, CHAIN_APPROX_NONE | _SIMPLE)
+ * (models/architecture/hovernetplus.py:222-226, HoVerNetPlus._get_layer_info)
+ * ===================================================================================== */
+
+/* Raster-first pixel (flat index, 0x7f7f7f7f if absent) and frame contact of every label 1..kmax of every plane:
+ * with tia_ccl_label_i32 (8-connected foreground, 4-connected background) this yields the start pixel of every outer
+ * border (a component's first pixel) and of every hole border (left of an enclosed background component's first pixel).
+ *   d_labels [n,h,w] i32   d_first, d_edge [n, kmax+1] i32 */
+int tia_label_first_pixel_i32(const int32_t* d_labels, int64_t n, int64_t h, int64_t w, int32_t kmax,
+                              int32_t* d_first, int32_t* d_edge, void* stream);
+
+/* Border following (Suzuki & Abe 1985, step 3 = OpenCV icvFetchContour), one lane per border.
+ *   d_starts [nb,4] i32 = plane, x0, y0, is_hole.  d_points == NULL: count pass, d_counts[nb] = points per border.
+ *   Otherwise border e writes its (x, y) pairs at d_points + 2*d_offsets[e] (capacity = total pairs allocated).
+ *   simple != 0: CHAIN_APPROX_SIMPLE (direction changes only); 0: CHAIN_APPROX_NONE (every border pixel). */
+int tia_border_trace_u8(const uint8_t* d_mask, int64_t n, int64_t h, int64_t w, const int32_t* d_starts, int64_t nb,
+                        int32_t simple, int32_t* d_counts, const int64_t* d_offsets, int64_t capacity,
+                        int32_t* d_points, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

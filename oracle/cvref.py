@@ -218,6 +218,8 @@ def morphology_ex(mask: np.ndarray, op: str, kernel: np.ndarray) -> np.ndarray:
         return _morph(mask, kernel, erode=True)
     if op == "OPEN":
         return _morph(_morph(mask, kernel, erode=True), kernel, erode=False)
+    if op == "CLOSE":
+        return _morph(_morph(mask, kernel, erode=False), kernel, erode=True)
     raise NotImplementedError(op)
 
 
@@ -483,7 +485,7 @@ def _follow_border(f: np.ndarray, x0: int, y0: int, nbd: int, *, is_hole: bool, 
     return pts
 
 
-def find_contours_tree(mask: np.ndarray) -> list[dict]:
+def find_contours_tree(mask: np.ndarray, *, simple: bool = True) -> list[dict]:
     """All borders of a binary image with their topology, in raster order of discovery.
 
     ``cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE)`` restated from Suzuki & Abe's
@@ -514,13 +516,33 @@ def find_contours_tree(mask: np.ndarray) -> list[dict]:
                 lnbd_parent = -1 if lnbd == 1 else borders[lnbd - 2]["parent"]
                 parent = lnbd_parent if lnbd_hole == is_hole else lnbd - 2
                 nbd = len(borders) + 2
-                pts = _follow_border(f, start[0], start[1], nbd, is_hole=is_hole)
+                pts = _follow_border(f, start[0], start[1], nbd, is_hole=is_hole, simple=simple)
                 borders.append({"points": np.array(pts, dtype=np.int32).reshape(-1, 2) - 1,
                                 "is_hole": is_hole, "parent": parent})
                 p = f[y, x]
             if p not in (0, 1):
                 lnbd = abs(int(p))
     return borders
+
+
+def find_contours(mask: np.ndarray, *, simple: bool = True) -> list[np.ndarray]:
+    """``cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE | CHAIN_APPROX_NONE)[0]`` as a list of (k, 2) arrays.
+
+    Order = OpenCV's: every new border is linked at the *front* of its parent's child list and the tree is enumerated
+    in pre-order (node, its children, next sibling), so siblings come out in reverse order of discovery.  Call site
+    needing the whole list: ``hovernetplus.py:222-226`` (``_get_layer_info``).  Parity unpinned (no cv2 here).
+    """
+    tree = find_contours_tree(mask, simple=simple)
+    children: dict[int, list[int]] = {}
+    for i, b in enumerate(tree):
+        children.setdefault(b["parent"], []).append(i)
+    out: list[np.ndarray] = []
+    stack = list(children.get(-1, []))  # popping from the end = last discovered first
+    while stack:
+        i = stack.pop()
+        out.append(tree[i]["points"])
+        stack.extend(children.get(i, []))  # its children come next, again last discovered first
+    return out
 
 
 def first_contour(mask: np.ndarray) -> np.ndarray:

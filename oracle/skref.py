@@ -65,6 +65,20 @@ def remove_small_objects_labels(lab: np.ndarray, max_size: int) -> np.ndarray:
     return out
 
 
+def remove_small_objects(ar: np.ndarray, max_size: int) -> np.ndarray:
+    """``skimage.morphology.remove_small_objects(ar, max_size=s)`` for both input kinds: a boolean image is first
+    labelled with connectivity 1 (``ndimage.label`` with its default cross) and returned boolean; an integer image
+    is taken as labels.  Objects with ``area <= max_size`` go.  Call sites: ``hovernet.py:544,614`` (labels),
+    ``hovernetplus.py:162-165`` (boolean)."""
+    ar = np.asarray(ar)
+    if ar.dtype == bool:
+        from scipy import ndimage
+
+        lab = ndimage.label(ar)[0]
+        return remove_small_objects_labels(lab, max_size) > 0
+    return remove_small_objects_labels(ar, max_size)
+
+
 class _Heap:
     """skimage's ``heap_general.pxi`` binary min-heap, ordered by ``(value, age)`` only.
 

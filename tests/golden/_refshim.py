@@ -97,6 +97,7 @@ def install() -> None:
     cv2.MORPH_ELLIPSE = "ELLIPSE"
     cv2.MORPH_DILATE = "DILATE"
     cv2.MORPH_OPEN = "OPEN"
+    cv2.MORPH_CLOSE = "CLOSE"
     cv2.NORM_MINMAX = "MINMAX"
     cv2.CV_32F = "32F"
     cv2.CV_64F = "64F"
@@ -126,14 +127,15 @@ def install() -> None:
 
     cv2.RETR_TREE = "TREE"
     cv2.CHAIN_APPROX_SIMPLE = "SIMPLE"
+    cv2.CHAIN_APPROX_NONE = "NONE"
 
     def moments(img):
         ys, xs = np.nonzero(img)
         return {"m00": float(len(xs)), "m10": float(xs.sum()), "m01": float(ys.sum())}
 
     def find_contours(img, mode, method):  # noqa: ARG001
-        """``(contours, hierarchy)``; only element 0 is populated faithfully (all the reference reads)."""
-        return [cvref.first_contour(img)[:, None, :]], None
+        """``(contours, hierarchy)``: every border, in OpenCV's RETR_TREE order (hierarchy itself is never read)."""
+        return [c[:, None, :] for c in cvref.find_contours(img, simple=method == "SIMPLE")], None
 
     cv2.moments = moments
     cv2.findContours = find_contours
@@ -155,6 +157,5 @@ def install() -> None:
 
     skimage.exposure.rescale_intensity = skref.rescale_intensity
     skimage.filters.threshold_otsu = skref.threshold_otsu_u8
-    skimage.morphology.remove_small_objects = (
-        lambda lab, max_size=None, **_: skref.remove_small_objects_labels(lab, max_size))
+    skimage.morphology.remove_small_objects = lambda ar, max_size=None, **_: skref.remove_small_objects(ar, max_size)
     skimage.segmentation.watershed = lambda image, markers=None, mask=None: skref.watershed(image, markers, mask)

@@ -155,6 +155,60 @@ def hover_goldens() -> None:
           [int(out[f"{t}_inst"].max()) for t in "ab"])
 
 
+def hoverplus_goldens() -> None:
+    """HoVerNet+ (hovernetplus.py): ``_proc_ls`` / ``_get_layer_info`` / ``_proc_np_hv(scale_factor=0.5)`` of the real
+    reference on synthetic head outputs, and forward passes of the reference's own ``HoVerNet`` / ``HoVerNetPlus``
+    modules carrying THIS repo's seeded weights (strict ``load_state_dict``), sub-sampled."""
+    import torch
+
+    from oracle import hovernet as oh
+    from oracle import hovernetplus as ohp
+
+    hp = _ref_import("tiatoolbox.models.architecture.hovernetplus")
+    hov = _ref_import("tiatoolbox.models.architecture.hovernet")
+    out = {}
+    for tag, (h, w, seed) in {"a": (300, 340, 1), "b": (256, 256, 2)}.items():
+        ls = ohp.synth_layer_map(h, w, seed=seed)
+        layer = hp.HoVerNetPlus._proc_ls(ls)
+        out[f"ls_{tag}_shape"] = np.array([h, w, seed])
+        out[f"ls_{tag}_map"] = layer
+        info = hp.HoVerNetPlus._get_layer_info(layer, (7, 3))
+        out[f"ls_{tag}_type"] = np.array([int(v["type"]) for v in info.values()])
+        out[f"ls_{tag}_box"] = np.array([v["box"] for v in info.values()])
+        out[f"ls_{tag}_polylen"] = np.array([len(v["contours"]) for v in info.values()])
+        out[f"ls_{tag}_poly"] = np.concatenate([v["contours"] for v in info.values()]).astype(np.int32)
+    for tag, (h, w, seed, nb) in {"a": (164, 164, 41, 40), "b": (128, 150, 42, 25)}.items():
+        npm, hv, _ = oh.synth_maps(2, h, w, seed=seed, n_blobs=nb)
+        out[f"nuc_{tag}_shape"] = np.array([h, w, seed, nb])
+        out[f"nuc_{tag}_inst"] = np.stack([hp.HoVerNetPlus._proc_np_hv(npm[i], hv[i], scale_factor=0.5) for i in range(2)])
+    # forward parity: the reference modules with this repo's parameters
+    from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
+    from tiatoolbox_amd.models.architecture.hovernetplus import HoVerNetPlus
+
+    x = torch.from_numpy(synth.g_he(1, 256, 256, seed=77)).float().permute(0, 3, 1, 2)
+    torch.manual_seed(5)
+    mine = HoVerNet(num_types=6, mode="fast").eval()
+    ref = hov.HoVerNet(num_types=6, mode="fast").eval()
+    ref.load_state_dict(mine.state_dict(), strict=True)
+    with torch.no_grad():
+        o = ref(x)
+    for k, v in o.items():
+        out[f"fwd_hovernet_{k}"] = v[0, :, ::6, ::6].numpy()
+    torch.manual_seed(6)
+    mine = HoVerNetPlus(num_types=3, num_layers=5).eval()
+    ref = hp.HoVerNetPlus(num_types=3, num_layers=5).eval()
+    ref.load_state_dict(mine.state_dict(), strict=True)
+    with torch.no_grad():
+        o = ref(x)
+    for k, v in o.items():
+        out[f"fwd_hovernetplus_{k}"] = v[0, :, ::6, ::6].numpy()
+    heads = hp.HoVerNetPlus.infer_batch(ref, x.permute(0, 2, 3, 1), device="cpu")
+    out["fwd_hovernetplus_infer_tp"] = heads[2][0, ::4, ::4, 0]
+    out["fwd_hovernetplus_infer_ls"] = heads[3][0, ::4, ::4, 0]
+    np.savez_compressed(HERE / "hoverplus_golden.npz", **out)
+    print("wrote hoverplus_golden.npz:", {k: v.shape for k, v in out.items() if "map" in k or "inst" in k or "fwd" in k})
+
+
 def tile_goldens() -> None:
     """WSI tile-mode merge of instance predictions: the real reference's tile sets, margin rules, id stitching and
     offset handling (``multi_task_segmentor.py:1078-1287,1362-1554,2833-3297``) driven exactly like
@@ -304,7 +358,9 @@ def reinhard_goldens() -> None:
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["stain", "mask", "hover", "grid", "reinhard", "tile"]
+    which = sys.argv[1:] or ["stain", "mask", "hover", "hoverplus", "grid", "reinhard", "tile"]
+    if "hoverplus" in which:
+        hoverplus_goldens()
     if "reinhard" in which:
         reinhard_goldens()
     if "grid" in which:

@@ -1,0 +1,219 @@
+"""HoVerNet+ (hovernetplus.py): oracle vs the real reference (CPU goldens), forward parity of the model classes against
+the reference's own modules (goldens made by loading this repo's weights into them), HIP vs oracle (GPU, bit-exact)."""
+
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import hovernet as oh
+from oracle import hovernetplus as ohp
+
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD / "hoverplus_golden.npz")
+
+
+def _layer_info_equal(info: dict, gold, tag: str) -> None:
+    assert np.array_equal(np.array([int(v["type"]) for v in info.values()]), gold[f"ls_{tag}_type"])
+    assert np.array_equal(np.array([v["box"] for v in info.values()]), gold[f"ls_{tag}_box"])
+    assert np.array_equal(np.array([len(v["contours"]) for v in info.values()]), gold[f"ls_{tag}_polylen"])
+    assert np.array_equal(np.concatenate([v["contours"] for v in info.values()]), gold[f"ls_{tag}_poly"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_matches_real_reference(gold, tag):
+    h, w, seed = (int(v) for v in gold[f"ls_{tag}_shape"])
+    layer = ohp.proc_ls(ohp.synth_layer_map(h, w, seed=seed))
+    assert layer.dtype == np.uint8 and np.array_equal(layer, gold[f"ls_{tag}_map"])
+    _layer_info_equal(ohp.get_layer_info(layer, (7, 3)), gold, tag)
+    h, w, seed, nb = (int(v) for v in gold[f"nuc_{tag}_shape"])
+    npm, hv, _ = oh.synth_maps(2, h, w, seed=seed, n_blobs=nb)
+    for i in range(2):
+        assert np.array_equal(oh.proc_np_hv(npm[i], hv[i], scale_factor=0.5), gold[f"nuc_{tag}_inst"][i])
+
+
+def test_find_contours_order_and_approx_none_known_answers():
+    """Structure of ``cv2.findContours(RETR_TREE, CHAIN_APPROX_NONE)`` as restated (cv2 is absent: parity unpinned):
+    pre-order, last-discovered sibling first; a hole follows its outer border; every border pixel is listed once per
+    visit; a filled w x h rectangle has 2(w+h)-4 border pixels starting at its top-left corner going DOWN first."""
+    from oracle import cvref
+
+    m = np.zeros((12, 20), np.uint8)
+    m[1:6, 1:8] = 1
+    m[2:5, 3:6] = 0          # hole
+    m[3, 4] = 1              # island inside the hole
+    m[7:11, 10:18] = 1       # second top-level component, discovered later
+    cs = cvref.find_contours(m, simple=False)
+    assert [len(c) for c in cs] == [2 * (8 + 4) - 4, 2 * (7 + 5) - 4, 12, 1]
+    assert cs[0][:3].tolist() == [[10, 7], [10, 8], [10, 9]]
+    assert cs[1][0].tolist() == [1, 1] and cs[3].tolist() == [[4, 3]]
+    simple = cvref.find_contours(m, simple=True)
+    assert simple[0].tolist() == [[10, 7], [10, 10], [17, 10], [17, 7]]
+    assert [len(c) for c in simple] == [4, 4, 8, 1]
+
+
+def test_forward_parity_with_the_reference_modules(gold):
+    """The reference's own ``HoVerNet`` / ``HoVerNetPlus`` modules, loaded (strictly) with this repo's seeded
+    parameters, produced the goldens (``make_golden.py hoverplus``); this repo's modules must reproduce them."""
+    import torch
+
+    from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
+    from tiatoolbox_amd.models.architecture.hovernetplus import HoVerNetPlus
+    from tiatoolbox_amd.utils import synth
+
+    x = torch.from_numpy(synth.g_he(1, 256, 256, seed=77)).float().permute(0, 3, 1, 2)
+    torch.manual_seed(5)
+    m = HoVerNet(num_types=6, mode="fast").eval()
+    with torch.no_grad():
+        o = m(x)
+    for k, v in o.items():
+        np.testing.assert_allclose(v[0, :, ::6, ::6].numpy(), gold[f"fwd_hovernet_{k}"], atol=1e-5, rtol=1e-5)
+    torch.manual_seed(6)
+    mp = HoVerNetPlus(num_types=3, num_layers=5).eval()
+    assert set(mp.decoder) == {"tp", "np", "hv", "ls"} and mp.tasks == ["nuclei_segmentation", "layer_segmentation"]
+    with torch.no_grad():
+        o = mp(x)
+    assert {k: tuple(v.shape) for k, v in o.items()} == {"tp": (1, 3, 164, 164), "np": (1, 2, 164, 164),
+                                                          "hv": (1, 2, 164, 164), "ls": (1, 5, 164, 164)}
+    for k, v in o.items():
+        np.testing.assert_allclose(v[0, :, ::6, ::6].numpy(), gold[f"fwd_hovernetplus_{k}"], atol=1e-5, rtol=1e-5)
+    heads = HoVerNetPlus.infer_batch(mp, x.permute(0, 2, 3, 1).numpy(), device="cpu")
+    assert [h.shape for h in heads] == [(1, 164, 164, 1), (1, 164, 164, 2), (1, 164, 164, 1), (1, 164, 164, 1)]
+    assert np.array_equal(heads[2][0, ::4, ::4, 0], gold["fwd_hovernetplus_infer_tp"])
+    assert np.array_equal(heads[3][0, ::4, ::4, 0], gold["fwd_hovernetplus_infer_ls"])
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_proc_ls_and_layer_info_bit_exact(gold, tag):
+    import torch
+
+    from tiatoolbox_amd.models.architecture.hovernetplus import HoVerNetPlus
+
+    h, w, seed = (int(v) for v in gold[f"ls_{tag}_shape"])
+    ls = ohp.synth_layer_map(h, w, seed=seed)
+    layer = HoVerNetPlus._proc_ls(ls)
+    assert layer.dtype == np.uint8 and np.array_equal(layer, gold[f"ls_{tag}_map"])
+    dev_layer = HoVerNetPlus._proc_ls(torch.from_numpy(ls).cuda())
+    assert dev_layer.is_cuda and np.array_equal(dev_layer.cpu().numpy(), layer)
+    _layer_info_equal(HoVerNetPlus._get_layer_info(layer, (7, 3)), gold, tag)
+
+
+@pytest.mark.gpu
+def test_hip_proc_ls_vs_oracle_more_inputs():
+    import torch
+
+    from tiatoolbox_amd.models.architecture.hovernetplus import HoVerNetPlus
+
+    for (h, w, seed) in ((260, 300, 11), (200, 411, 12), (333, 257, 13)):
+        ls = ohp.synth_layer_map(h, w, seed=seed)
+        assert np.array_equal(HoVerNetPlus._proc_ls(ls), ohp.proc_ls(ls)), (h, w)
+    batch = np.stack([ohp.synth_layer_map(256, 256, seed=s) for s in (21, 22, 23)])
+    got = HoVerNetPlus._proc_ls(torch.from_numpy(batch).cuda()).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], ohp.proc_ls(batch[i]))
+    rng = np.random.default_rng(0)   # speckle only: nothing survives the 20 000 px filter, the mask closes to a slab
+    noise = rng.integers(0, 5, (150, 160)).astype(np.float32)
+    assert np.array_equal(HoVerNetPlus._proc_ls(noise), ohp.proc_ls(noise))
+    assert not HoVerNetPlus._proc_ls(np.zeros((64, 64, 1), np.float32)).any()
+
+
+@pytest.mark.gpu
+def test_hip_all_borders_match_suzuki_abe_oracle():
+    """Every border of a binary image (outer and hole, nested), in OpenCV's order, for both approximation modes:
+    component-based parallel discovery + one lane per border == the sequential raster scan of ``cvref``."""
+    import torch
+
+    from oracle import cvref
+    from tiatoolbox_amd.models.architecture import _hover_device as hd
+
+    rng = np.random.default_rng(5)
+    cases = [(rng.random((40, 52)) < p).astype(np.uint8) for p in (0.3, 0.5, 0.62, 0.8)]
+    cases.append(np.kron((rng.random((12, 15)) < 0.55).astype(np.uint8), np.ones((3, 4), np.uint8)))
+    rings = np.zeros((41, 41), np.uint8)
+    for k, r in enumerate(range(20, 0, -3)):
+        rings[20 - r:21 + r, 20 - r:21 + r] = 1 - k % 2
+    cases.append(rings)
+    full = np.ones((9, 11), np.uint8)
+    cases += [full, np.zeros((9, 11), np.uint8), np.pad(full, 1), np.eye(13, dtype=np.uint8)]
+    thin = np.zeros((10, 12), np.uint8)
+    thin[2:8, 2] = thin[2:8, 9] = thin[2, 2:10] = thin[7, 2:10] = 1   # one-pixel-thick ring: outer and hole share pixels
+    cases.append(thin)
+    for simple in (False, True):
+        for m in cases:
+            exp = cvref.find_contours(m, simple=simple)
+            got = hd.all_borders(torch.from_numpy(m[None]).cuda(), simple=simple)[0]
+            assert len(got) == len(exp), (m.shape, len(got), len(exp))
+            for a, b in zip(got, exp):
+                assert a.dtype == np.int32 and np.array_equal(a, b)
+    # batched planes of one shape
+    stack = np.stack(cases[:4])
+    got = hd.all_borders(torch.from_numpy(stack).cuda())
+    for i in range(4):
+        exp = cvref.find_contours(stack[i], simple=False)
+        assert len(got[i]) == len(exp) and all(np.array_equal(a, b) for a, b in zip(got[i], exp))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_nuclei_at_half_scale_bit_exact(gold, tag):
+    """``_proc_np_hv(scale_factor=0.5)``: Sobel-11, markers >= 3 px (hovernetplus.py:358)."""
+    import torch
+
+    from tiatoolbox_amd.models.architecture.hovernetplus import HoVerNetPlus
+
+    h, w, seed, nb = (int(v) for v in gold[f"nuc_{tag}_shape"])
+    npm, hv, _ = oh.synth_maps(2, h, w, seed=seed, n_blobs=nb)
+    got = HoVerNetPlus._proc_np_hv(torch.from_numpy(npm).cuda(), torch.from_numpy(hv).cuda(), scale_factor=0.5)
+    assert np.array_equal(got.cpu().numpy(), gold[f"nuc_{tag}_inst"])
+
+
+@pytest.mark.gpu
+def test_hip_postproc_end_to_end():
+    import torch
+
+    from tiatoolbox_amd.models.architecture.hovernetplus import HoVerNetPlus
+
+    npm, hv, tp = oh.synth_maps(1, 256, 256, seed=51, n_blobs=70, num_types=3)
+    ls = ohp.synth_layer_map(256, 256, seed=52)
+    model = HoVerNetPlus(num_types=3, num_layers=5)
+    nuclei, layers = model.postproc([npm[0], hv[0], tp[0], ls], offset=(5, 9))
+    exp_inst = oh.proc_np_hv(npm[0], hv[0], scale_factor=0.5)
+    assert nuclei["task_type"] == "nuclei_segmentation" and nuclei["seg_type"] == "instance"
+    assert np.array_equal(nuclei["predictions"], exp_inst)
+    info = oh.get_instance_info(exp_inst, np.around(tp[0]).astype("uint8")[..., 0], (5, 9))
+    assert np.array_equal(nuclei["info_dict"]["box"], np.array([v["box"] for v in info.values()]))
+    exp_layer = ohp.proc_ls(ls)
+    assert layers["task_type"] == "layer_segmentation" and layers["seg_type"] == "semantic"
+    assert np.array_equal(layers["predictions"], exp_layer)
+    exp_info = ohp.get_layer_info(exp_layer, (5, 9))
+    assert np.array_equal(layers["info_dict"]["type"], np.array([v["type"] for v in exp_info.values()]))
+    assert np.array_equal(layers["info_dict"]["box"], np.array([v["box"] for v in exp_info.values()]))
+    for a, b in zip(layers["info_dict"]["contours"], [v["contours"] for v in exp_info.values()]):
+        assert np.array_equal(a, b)
+    del torch
+
+
+@pytest.mark.gpu
+def test_multi_task_segmentor_runs_hovernetplus_patches():
+    """Engine end to end: two tasks per patch, each with its own sub-dict (multi_task_segmentor.py:1706-1730)."""
+    from tiatoolbox_amd.models.engine.multi_task_segmentor import MultiTaskSegmentor
+    from tiatoolbox_amd.utils import synth
+
+    patches = synth.g_he(2, 256, 256, seed=61)
+    eng = MultiTaskSegmentor("hovernetplus-oed", batch_size=2, device="cuda")
+    out = eng.run(patches, patch_mode=True, return_probabilities=True)
+    assert {"nuclei_segmentation", "layer_segmentation", "probabilities"} <= set(out)
+    npm, hv, tp, ls = out["probabilities"]
+    assert ls.shape == (2, 164, 164, 1)
+    for i in range(2):
+        assert np.array_equal(out["nuclei_segmentation"]["predictions"][i], oh.proc_np_hv(npm[i], hv[i], scale_factor=0.5))
+        assert np.array_equal(out["layer_segmentation"]["predictions"][i], ohp.proc_ls(ls[i]))
+    assert len(out["layer_segmentation"]["contours"]) == 2 and len(out["nuclei_segmentation"]["box"]) == 2

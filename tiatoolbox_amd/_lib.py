@@ -87,6 +87,8 @@ _SIGNATURES = {
     "tia_bias_relu_maxpool_nhwc": ([_P, _P, _I64, _I64, _I64, _I64, _I32, _P, _P], C.c_int),
     "tia_hover_instance_stats": ([_P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P], C.c_int),
     "tia_hover_contour_scan": ([_P, _I64, _I64, _I64, _I32, _P, _P, _P, _P, _P], C.c_int),
+    "tia_label_first_pixel_i32": ([_P, _I64, _I64, _I64, _I32, _P, _P, _P], C.c_int),
+    "tia_border_trace_u8": ([_P, _I64, _I64, _I64, _P, _I64, _I32, _P, _P, _I64, _P, _P], C.c_int),
     "tia_hover_contour_write": ([_P, _I64, _I64, _I64, _I32, _P, _P, _I64, _P, _P], C.c_int),
 }
 

@@ -40,8 +40,8 @@ struct Plane {
 
 // Follows one border from (x0, y0).  MARK: leave +-cls on the visited pixels.  Returns the number of
 // CHAIN_APPROX_SIMPLE points; writes them to `out` (x, y pairs) when it is not null.
-template <bool MARK>
-__device__ int follow_border(const Plane& f, int x0, int y0, bool is_hole, int cls, long limit, int* out) {
+template <bool MARK, bool SIMPLE = true, class P = Plane>
+__device__ int follow_border(const P& f, int x0, int y0, bool is_hole, int cls, long limit, int* out) {
     int s_end = is_hole ? 0 : 4, s = s_end;
     int x1, y1, v1;
     do {
@@ -69,7 +69,7 @@ __device__ int follow_border(const Plane& f, int x0, int y0, bool is_hole, int c
             if (passed_east) f.set(x3, y3, -cls);
             else if (f.get(x3, y3) == 1) f.set(x3, y3, cls);
         }
-        if (s != prev_s) {
+        if (!SIMPLE || s != prev_s) {  // CHAIN_APPROX_NONE keeps every border pixel visited
             if (out) { out[2 * npts] = x3; out[2 * npts + 1] = y3; }
             ++npts;
             prev_s = s;
@@ -161,6 +161,59 @@ __global__ __launch_bounds__(CT) void contour_write_kernel(const int* __restrict
     follow_border<false>(f, m[0], m[1], false, 2, 8 * stats[e * 8] + 16, points + 2 * (long)m[3]);
 }
 
+
+// ---- all borders of binary planes: cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_SIMPLE | CHAIN_APPROX_NONE) ------------
+// (reference hovernetplus.py:222-226).  A border's trace does not depend on the marks other borders leave, and the set of
+// borders Suzuki-Abe's raster scan discovers is: the outer border of every 8-connected foreground component, started at
+// the component's raster-first pixel, and the hole border of every 4-connected background component that does not reach
+// the image frame, started at the pixel left of its raster-first pixel.  So the components come from the labelling
+// kernels, the starts from one atomicMin pass, and every border is followed by its own lane.
+struct MaskPlane {
+    const uint8_t* m;
+    int h, w;
+    __device__ int get(int x, int y) const {
+        if ((unsigned)x >= (unsigned)w || (unsigned)y >= (unsigned)h) return 0;
+        return m[(long)y * w + x] != 0 ? 1 : 0;
+    }
+    __device__ void set(int, int, int) const {}
+};
+
+// first[plane][label] = smallest raster index of the label; edge[plane][label] = 1 if it touches the image frame
+__global__ __launch_bounds__(256) void label_first_pixel_kernel(const int* __restrict__ lab, int h, int w, int kmax,
+                                                                int* __restrict__ first, int* __restrict__ edge) {
+    const long hw = (long)h * w;
+    const int* l = lab + (size_t)blockIdx.y * hw;
+    int* fp = first + (size_t)blockIdx.y * (kmax + 1);
+    int* ep = edge + (size_t)blockIdx.y * (kmax + 1);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+        const int v = l[i];
+        if (v <= 0 || v > kmax) continue;
+        const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        // only a run's first pixel can be the component's first pixel
+        if (x == 0 || l[i - 1] != v) atomicMin(&fp[v], (int)i);
+        if (x == 0 || y == 0 || x == w - 1 || y == h - 1) ep[v] = 1;
+    }
+}
+
+__global__ __launch_bounds__(CT) void border_trace_kernel(const uint8_t* __restrict__ mask, int h, int w,
+                                                          const int* __restrict__ starts, long nb, int simple,
+                                                          int* __restrict__ counts, const long long* __restrict__ offsets,
+                                                          long long capacity, int* __restrict__ points) {
+    const long e = (long)blockIdx.x * CT + threadIdx.x;
+    if (e >= nb) return;
+    const int* st = starts + e * 4;
+    MaskPlane f{mask + (size_t)st[0] * h * w, h, w};
+    const long limit = 8L * h * w + 16;
+    int* out = nullptr;
+    if (points) {
+        if (offsets[e] + counts[e] > capacity) return;
+        out = points + 2 * offsets[e];
+    }
+    const int n = simple ? follow_border<false, true>(f, st[1], st[2], st[3] != 0, 2, limit, out)
+                         : follow_border<false, false>(f, st[1], st[2], st[3] != 0, 2, limit, out);
+    if (!points) counts[e] = n;
+}
+
 }  // namespace
 
 extern "C" int tia_hover_contour_scan(const int32_t* d_inst, int64_t n, int64_t h, int64_t w, int32_t max_inst,
@@ -187,6 +240,33 @@ extern "C" int tia_hover_contour_write(const int32_t* d_inst, int64_t n, int64_t
     const long entries = (long)n * (max_inst + 1);
     hipLaunchKernelGGL(contour_write_kernel, dim3((unsigned)((entries + CT - 1) / CT)), dim3(CT), 0, (hipStream_t)stream,
                        d_inst, (const long long*)d_stats, (int)h, (int)w, max_inst, entries, d_meta, (long long)capacity,
+                       d_points);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_label_first_pixel_i32(const int32_t* d_labels, int64_t n, int64_t h, int64_t w, int32_t kmax,
+                                         int32_t* d_first, int32_t* d_edge, void* stream) {
+    if (!d_labels || !d_first || !d_edge || n <= 0 || h <= 0 || w <= 0 || kmax < 0 || n > 65535) return TIA_EINVAL;
+    if ((long)h * w > 0x7fffffffL) return TIA_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cells = (size_t)n * (kmax + 1);
+    if (hipMemsetAsync(d_first, 0x7f, cells * 4, st) != hipSuccess) return TIA_ELAUNCH;  // 0x7f7f7f7f: "no pixel"
+    if (hipMemsetAsync(d_edge, 0, cells * 4, st) != hipSuccess) return TIA_ELAUNCH;
+    long blocks = ((long)h * w + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(label_first_pixel_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, st, d_labels, (int)h, (int)w,
+                       kmax, d_first, d_edge);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_border_trace_u8(const uint8_t* d_mask, int64_t n, int64_t h, int64_t w, const int32_t* d_starts,
+                                   int64_t nb, int32_t simple, int32_t* d_counts, const int64_t* d_offsets,
+                                   int64_t capacity, int32_t* d_points, void* stream) {
+    if (!d_mask || !d_starts || !d_counts || n <= 0 || h <= 0 || w <= 0 || nb < 0) return TIA_EINVAL;
+    if (d_points && (!d_offsets || capacity < 0)) return TIA_EINVAL;
+    if (nb == 0) return TIA_OK;
+    hipLaunchKernelGGL(border_trace_kernel, dim3((unsigned)((nb + CT - 1) / CT)), dim3(CT), 0, (hipStream_t)stream, d_mask,
+                       (int)h, (int)w, d_starts, (long)nb, simple, d_counts, (const long long*)d_offsets, (long long)capacity,
                        d_points);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

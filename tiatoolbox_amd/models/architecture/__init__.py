@@ -66,6 +66,19 @@ PRETRAINED_INFO = {
             "patch_output_shape": [164, 164], "stride_shape": [164, 164],
             "save_resolution": {"units": "mpp", "resolution": 0.25}, "ignore_index": 0}),
     },
+    "hovernetplus-oed": {  # pretrained_model.yaml:758-793
+        "architecture": ("hovernetplus.HoVerNetPlus", {
+            "num_types": 3, "num_layers": 5,
+            "nuc_type_dict": {0: "Background", 1: "Other", 2: "Epithelial"},
+            "layer_type_dict": {0: "Background", 1: "Other Tissue", 2: "Basal Epithelium", 3: "(Core) Epithelium",
+                                4: "Keratin"}}),
+        "ioconfig": (IOInstanceSegmentorConfig, {
+            "input_resolutions": [{"units": "mpp", "resolution": 0.50}],
+            "output_resolutions": [{"units": "mpp", "resolution": 0.50}] * 4,
+            "margin": 128, "tile_shape": [2048, 2048], "patch_input_shape": [256, 256],
+            "patch_output_shape": [164, 164], "stride_shape": [164, 164],
+            "save_resolution": {"units": "mpp", "resolution": 0.50}, "ignore_index": 0}),
+    },
 }
 
 

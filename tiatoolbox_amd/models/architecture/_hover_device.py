@@ -90,6 +90,93 @@ def watershed(image: torch.Tensor, markers: torch.Tensor, mask: torch.Tensor) ->
     return out[0] if single else out
 
 
+def all_borders(masks: torch.Tensor, *, simple: bool = False) -> list[list[np.ndarray]]:
+    """``cv2.findContours(mask, RETR_TREE, CHAIN_APPROX_NONE | CHAIN_APPROX_SIMPLE)[0]`` for every plane of a binary
+    ``[N,H,W]`` CUDA tensor: per plane the list of ``(k, 2)`` int32 ``(x, y)`` arrays in OpenCV's order.
+
+    Components come from the labelling kernels (8-connected foreground, 4-connected background), border starts from
+    ``tia_label_first_pixel_i32``, every border is followed by its own lane (``tia_border_trace_u8``: count pass,
+    prefix sum, write pass); the host only builds the (small) border tree that fixes the output order: a new border is
+    linked at the front of its parent's child list and the tree is enumerated in pre-order (hovernetplus.py:222-226).
+    """
+    from tiatoolbox_amd.tools import _img_device as img
+
+    _lib.require_cuda(masks, "masks")
+    m = (masks != 0).to(torch.uint8).contiguous()
+    n, h, w = m.shape
+    dev = m.device
+    lib = _lib.load()
+    fg_lab, kf = img.ccl_label(m, connectivity=8)
+    bg_lab, kb = img.ccl_label(1 - m, connectivity=4)
+    kf_h, kb_h = kf.cpu().numpy(), kb.cpu().numpy()
+
+    def first_pixels(lab: torch.Tensor, kmax: int):
+        first = torch.empty((n, kmax + 1), dtype=torch.int32, device=dev)
+        edge = torch.empty((n, kmax + 1), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.tia_label_first_pixel_i32(lab.data_ptr(), n, h, w, kmax, first.data_ptr(), edge.data_ptr(),
+                                               _lib.current_stream())
+        _lib.check(rc, "tia_label_first_pixel_i32")
+        return first.cpu().numpy(), edge.cpu().numpy()
+
+    first_f, _ = first_pixels(fg_lab, int(kf_h.max(initial=0)))
+    first_b, edge_b = first_pixels(bg_lab, int(kb_h.max(initial=0)))
+    # border table: plane, x0, y0, is_hole, trigger (raster position where the scan discovers it), own label
+    rows = []
+    for i in range(n):
+        for k in range(1, int(kf_h[i]) + 1):
+            idx = int(first_f[i, k])
+            rows.append((i, idx % w, idx // w, 0, idx, k))
+        for b in range(1, int(kb_h[i]) + 1):
+            if not edge_b[i, b]:
+                idx = int(first_b[i, b])
+                rows.append((i, idx % w - 1, idx // w, 1, idx, b))
+    if not rows:
+        return [[] for _ in range(n)]
+    table = np.asarray(rows, dtype=np.int64)
+    # label on the other side of each start: background left of an outer start, foreground left of a hole's first pixel
+    left = np.where(table[:, 3] == 1, table[:, 4] - 1, np.where(table[:, 1] > 0, table[:, 4] - 1, -1))
+    flat = torch.from_numpy(table[:, 0] * (h * w) + np.maximum(left, 0)).to(dev)
+    other_bg = bg_lab.reshape(-1)[flat].cpu().numpy()
+    other_fg = fg_lab.reshape(-1)[flat].cpu().numpy()
+    starts = torch.from_numpy(np.ascontiguousarray(table[:, :4].astype(np.int32))).to(dev)
+    nb = len(table)
+    counts = torch.zeros(nb, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.tia_border_trace_u8(m.data_ptr(), n, h, w, starts.data_ptr(), nb, int(simple), counts.data_ptr(), 0, 0, 0,
+                                     _lib.current_stream())
+        _lib.check(rc, "tia_border_trace_u8")
+        offsets = torch.cumsum(counts.to(torch.int64), 0) - counts
+        total = int(counts.sum())
+        points = torch.empty((max(total, 1), 2), dtype=torch.int32, device=dev)
+        rc = lib.tia_border_trace_u8(m.data_ptr(), n, h, w, starts.data_ptr(), nb, int(simple), counts.data_ptr(),
+                                     offsets.data_ptr(), total, points.data_ptr(), _lib.current_stream())
+        _lib.check(rc, "tia_border_trace_u8")
+    pts, cnt, off = points.cpu().numpy(), counts.cpu().numpy(), offsets.cpu().numpy()
+    out: list[list[np.ndarray]] = []
+    for i in range(n):
+        sel = np.flatnonzero(table[:, 0] == i)
+        sel = sel[np.argsort(table[sel, 4], kind="stable")]  # discovery order
+        outer_of = {int(table[r, 5]): r for r in sel if table[r, 3] == 0}
+        hole_of = {int(table[r, 5]): r for r in sel if table[r, 3] == 1}
+        children: dict[int, list[int]] = {}
+        for r in sel:
+            if table[r, 3] == 1:
+                parent = outer_of[int(other_fg[r])]
+            else:
+                b = int(other_bg[r]) if left[r] >= 0 else 0
+                parent = hole_of.get(b, -1) if b > 0 else -1
+            children.setdefault(parent, []).append(int(r))
+        ordered: list[np.ndarray] = []
+        stack = list(children.get(-1, []))
+        while stack:
+            r = stack.pop()
+            ordered.append(pts[off[r]:off[r] + cnt[r]].copy())
+            stack.extend(children.get(r, []))
+        out.append(ordered)
+    return out
+
+
 def instance_stats(inst: torch.Tensor, type_map: torch.Tensor | None, max_inst: int, num_types: int = 0):
     """Per-instance area / bbox / coordinate sums (int64 ``[N, max_inst+1, 8]``) and type histograms."""
     _lib.require_cuda(inst, "inst")

@@ -224,6 +224,8 @@ class MultiTaskSegmentor(EngineABC):
         """Per-patch ``postproc`` for every patch, batched on the device (ref. :733-834, :1556-1685)."""
         heads = raw_predictions["probabilities"]
         model = self.model.module if hasattr(self.model, "module") else self.model
+        if len(getattr(model, "tasks", ())) > 1:
+            return self._post_process_patches_multi_task(raw_predictions, model)
         results: list[dict] = []
         n = heads[0].shape[0]
         on_gpu = heads[0].is_cuda
@@ -469,6 +471,31 @@ class MultiTaskSegmentor(EngineABC):
         for k, i in enumerate(order):
             out[i] = ({"task_type": task_type, "predictions": preds.get(i, np.zeros((0, 0), np.int32)),
                        "info_dict": tables[k], "seg_type": "instance"},)
+        return out
+
+    def _post_process_patches_multi_task(self, raw_predictions: dict, model) -> dict:
+        """Several tasks per patch (HoVerNet+: nuclei + layers): the model's ``postproc`` per patch on device-resident
+        heads; every task gets its own sub-dict ``{predictions, <info columns>}`` (ref. :1556-1685, :1706-1730)."""
+        heads = raw_predictions["probabilities"]
+        if "shard" in raw_predictions:
+            msg = "patch-sharded runs of multi-task models are not supported; run one process."
+            raise NotImplementedError(msg)
+        n = heads[0].shape[0]
+        per_task: dict[str, list[dict]] = {}
+        for i in range(n):
+            for task in model.postproc([h[i] for h in heads], offset=(0, 0)):
+                per_task.setdefault(task["task_type"], []).append(task)
+        self.tasks = set(per_task) or set(model.tasks)
+        out: dict = {}
+        for name, items in per_task.items():
+            preds = [t["predictions"] for t in items]
+            preds = [p.cpu().numpy() if isinstance(p, torch.Tensor) else np.asarray(p) for p in preds]
+            sub = {"predictions": np.stack(preds), "seg_type": items[0]["seg_type"]}
+            for key in items[0]["info_dict"]:
+                sub[key] = [t["info_dict"][key] for t in items]
+            out[name] = sub
+        if self.return_probabilities:
+            out["probabilities"] = [h.cpu().numpy() if isinstance(h, torch.Tensor) else h for h in heads]
         return out
 
     def _inst_dict_for_dask_processing(self, wsi_info_dict, keys_to_shift=("centroid", "box", "contours")):
