@@ -364,6 +364,13 @@ int tia_bias_act_nhwc(void* d_x, const void* d_bias, const void* d_residual, int
 int tia_bias_relu_maxpool_nhwc(const void* d_x, const void* d_bias, int64_t n, int64_t h, int64_t w,
                                int64_t c, int32_t dtype, void* d_out, void* stream);
 
+/* Patch reads from an in-memory slide level (WSIPatchDataset.__getitem__, models/dataset/dataset_abc.py:418-448;
+ * tools/patchextraction.py:356-461 supplies the bounds): out[i] = slide[y0:y0+ph, x0:x0+pw] for d_bounds[i] =
+ * (x0, y0, x1, y1) in baseline pixels, with `pad` (255) wherever the region leaves the slide.
+ *   d_slide [sh,sw,c] u8   d_bounds [m,4] i32   d_out [m,ph,pw,c] u8 (ph*pw*c % 4 == 0, m <= 65535) */
+int tia_gather_patches_u8(const uint8_t* d_slide, int64_t sh, int64_t sw, int64_t c, const int32_t* d_bounds,
+                          int64_t m, int64_t ph, int64_t pw, int32_t pad, uint8_t* d_out, void* stream);
+
 /* =======================================================================================
  * All borders of binary planes: cv2.findContours(layer, RETR_TREE, CHAIN_APPROX_NONE | _SIMPLE)
  * (models/architecture/hovernetplus.py:222-226, HoVerNetPlus._get_layer_info)

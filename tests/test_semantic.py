@@ -166,3 +166,44 @@ def test_semantic_segmentor_wsi_mode_matches_oracle_composition():
     patches = synth.g_he(3, 128, 128, seed=4)
     out = eng.run(patches, patch_mode=True, ioconfig=cfg, return_probabilities=True)
     assert out["probabilities"].shape == (3, 64, 64, 3) and out["predictions"].shape == (3, 64, 64)
+
+
+@pytest.mark.gpu
+def test_hip_gather_patches_matches_padded_slicing():
+    """``tia_gather_patches_u8`` (ArrayWSIReader.read_bounds_batch) == NumPy slicing of a 255-padded slide: regions
+    hanging over every edge and corner, fully outside, byte-unaligned x offsets, 1-channel (mask) slides, and the
+    odd-size fallback (``WSIPatchDataset.__getitem__`` pads with 255, dataset_abc.py:430-436)."""
+    from tiatoolbox_amd.wsicore import ArrayWSIReader
+
+    rng = np.random.default_rng(4)
+    slide = rng.integers(0, 255, (157, 203, 3), dtype=np.uint8)
+    reader = ArrayWSIReader(slide)
+
+    def expect(arr, bounds, pad_value=255):
+        p = 300
+        padded = np.pad(arr, ((p, p), (p, p)) + ((0, 0),) * (arr.ndim - 2), constant_values=pad_value)
+        return np.stack([padded[y0 + p:y1 + p, x0 + p:x1 + p] for x0, y0, x1, y1 in bounds])
+
+    for pw, ph in ((64, 48), (32, 32), (20, 7), (203, 157), (256, 256)):
+        tl = np.array([[0, 0], [-17, -5], [203 - pw + 9, 3], [5, 157 - ph + 11], [-pw + 1, -ph + 1], [203 - 1, 157 - 1],
+                       [-pw - 3, 10], [1, 2], [2, 3], [3, 1], [50, 60], [-1, 155]])
+        bounds = np.concatenate([tl, tl + np.array([pw, ph])], axis=1)
+        got = reader.read_bounds_batch(bounds).cpu().numpy()
+        assert got.shape == (len(bounds), ph, pw, 3)
+        assert np.array_equal(got, expect(slide, bounds)), (pw, ph)
+    odd = np.array([[3, 4, 3 + 5, 4 + 5], [-2, -2, 3, 3]])  # 5*5*3 bytes: not a dword multiple
+    assert np.array_equal(reader.read_bounds_batch(odd).cpu().numpy(), expect(slide, odd))
+    assert np.array_equal(reader.read_bounds(odd[0]), expect(slide, odd[:1])[0])
+    mask = rng.integers(0, 2, (64, 72), dtype=np.uint8)
+    mreader = ArrayWSIReader(mask, mpp=None, power=1.25, mode="bool")
+    mb = np.array([[-4, -4, 12, 12], [60, 50, 76, 66]])
+    assert np.array_equal(mreader.read_bounds_batch(mb, pad_value=0).cpu().numpy(), expect(mask, mb, 0))
+    with pytest.raises(ValueError, match="one size"):
+        reader.read_bounds_batch(np.array([[0, 0, 4, 4], [0, 0, 8, 8]]))
+    # thumbnail: exact box mean, rounded half to even (cv2.INTER_AREA at an integer factor)
+    big = rng.integers(0, 255, (64, 96, 3), dtype=np.uint8)
+    thumb = ArrayWSIReader(big, power=40.0).slide_thumbnail(5.0, "power").cpu().numpy()
+    exp = np.rint(big.reshape(8, 8, 12, 8, 3).astype(np.float64).mean(axis=(1, 3))).astype(np.uint8)
+    assert np.array_equal(thumb, exp)
+    with pytest.raises(ValueError, match="integer down-sampling"):
+        ArrayWSIReader(big, power=40.0).slide_thumbnail(3.0, "power")

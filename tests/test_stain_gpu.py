@@ -273,21 +273,7 @@ def test_stain_augmentor_f32_fast_path(gold, he_patches):
     del torch
 
 
-def test_vahadane_pipeline_runs_and_matches_oracle_given_same_dictionary(he_patches):
-    """Vahadane: the dictionary solve is scikit-learn's (as in the reference); everything around it is
-    HIP.  With a fixed random_state both sides use the same solver, tolerance 1e-1 mean-abs like the
-    reference's own test (tests/test_stainnorm.py:151-165)."""
-    from tiatoolbox_amd.tools.stainnorm import get_normalizer
-
-    norm = get_normalizer("vahadane")
-    norm.extractor.random_state = 0
-    norm.fit(he_patches[0][:96, :96])
-    out = norm.transform(he_patches[1][:96, :96])
-    ref = ostain.get_normalizer("vahadane")
-    ref.fit(he_patches[0][:96, :96].copy())
-    exp = ref.transform(he_patches[1][:96, :96].copy())
-    assert out.shape == exp.shape and out.dtype == np.uint8
-    assert np.mean(np.abs(out.astype(float) - exp.astype(float))) / 255 < 1e-1@pytest.mark.gpu
+@pytest.mark.gpu
 def test_vahadane_dictionary_learning_on_device_matches_sklearn(he_patches, target_image):
     """``TIA_MODE_VAHADANE`` (dictionary learning restated in the HIP kernel) against scikit-learn's
     ``DictionaryLearning`` driven exactly as the reference drives it (stainextract.py:305-316; the oracle's

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "tia_watershed_blobs_f64": ([_P, _P, _P, _I64, _I64, _I64, _P, _P, C.c_size_t, _P], C.c_int),
     "tia_canvas_row_merge_f32": ([_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
     "tia_canvas_finalize_f32": ([_P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P], C.c_int),
+    "tia_gather_patches_u8": ([_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I32, _P, _P], C.c_int),
     "tia_lab_hist_u8": ([_P, _I64, _I64, _I64, _P, _P, _P], C.c_int),
     "tia_reinhard_apply_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
     "tia_reinhard_luts": ([_P, _I64, _P, _P, _P, _P, _P, _P, _P], C.c_int),

@@ -72,6 +72,73 @@ __global__ __launch_bounds__(CT) void finalize_kernel(const float* __restrict__ 
     }
 }
 
+
+// ---- patch reads from an in-memory slide level ---------------------------------------------------------------------
+// WSIPatchDataset.__getitem__ / read_bounds(..., pad_constant_values=255) (models/dataset/dataset_abc.py:418-448) for a
+// whole batch of equally sized bounds at once: out[m, y, x, :] = slide[y0+y, x0+x, :] or `pad` outside the slide.
+// One thread produces 4 consecutive output bytes (one dword store; rows of ph*pw*c bytes are dword multiples, checked
+// by the launcher), reading the source with one dword load when the source run is in bounds and aligned.
+__global__ __launch_bounds__(CT) void gather_patches_kernel(const uint8_t* __restrict__ slide, int sh, int sw, int c,
+                                                             const int* __restrict__ bounds, int ph, int pw, int pad,
+                                                             uint8_t* __restrict__ out) {
+    const long row_bytes = (long)pw * c;
+    const long patch_bytes = (long)ph * row_bytes;
+    const int m = blockIdx.y;
+    const int x0 = bounds[m * 4 + 0], y0 = bounds[m * 4 + 1];
+    uint8_t* dst = out + (size_t)m * patch_bytes;
+    const uint32_t pad4 = 0x01010101u * (uint32_t)(pad & 255);
+    for (long i = ((long)blockIdx.x * CT + threadIdx.x) * 4; i < patch_bytes; i += (long)gridDim.x * CT * 4) {
+        const int y = (int)(i / row_bytes);
+        const long xb = i - (long)y * row_bytes;       // byte offset inside the patch row
+        const int sy = y0 + y;
+        uint32_t v = pad4;
+        if (sy >= 0 && sy < sh) {
+            const long sb = (long)x0 * c + xb;         // byte offset inside the slide row (may be negative)
+            const uint8_t* srow = slide + (size_t)sy * sw * c;
+            const long lim = (long)sw * c;
+            if (sb >= 0 && sb + 4 <= lim && xb + 4 <= row_bytes) {
+                const uint8_t* sp = srow + sb;
+                if ((reinterpret_cast<uintptr_t>(sp) & 3) == 0) {
+                    v = *reinterpret_cast<const uint32_t*>(sp);
+                } else {
+                    v = (uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
+                }
+            } else {  // the dword straddles the slide edge or the end of the patch row: byte by byte
+                v = 0;
+                for (int k = 0; k < 4; ++k) {
+                    long xk = xb + k;
+                    int yk = y;
+                    if (xk >= row_bytes) {  // next patch row
+                        xk -= row_bytes;
+                        ++yk;
+                    }
+                    const int syk = y0 + yk;
+                    const long sbk = (long)x0 * c + xk;
+                    uint32_t b = (uint32_t)(pad & 255);
+                    if (yk < ph && syk >= 0 && syk < sh && sbk >= 0 && sbk < lim) b = slide[(size_t)syk * sw * c + sbk];
+                    v |= b << (8 * k);
+                }
+            }
+        } else if (xb + 4 > row_bytes) {  // padded row whose dword runs into the next (possibly valid) row
+            v = 0;
+            for (int k = 0; k < 4; ++k) {
+                long xk = xb + k;
+                int yk = y;
+                if (xk >= row_bytes) {
+                    xk -= row_bytes;
+                    ++yk;
+                }
+                const int syk = y0 + yk;
+                const long sbk = (long)x0 * c + xk;
+                uint32_t b = (uint32_t)(pad & 255);
+                if (yk < ph && syk >= 0 && syk < sh && sbk >= 0 && sbk < (long)sw * c) b = slide[(size_t)syk * sw * c + sbk];
+                v |= b << (8 * k);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(dst + i) = v;
+    }
+}
+
 }  // namespace tia
 
 using namespace tia;
@@ -103,5 +170,19 @@ extern "C" int tia_canvas_finalize_f32(const float* d_row_a, const uint8_t* d_cn
     if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nb), dim3(CT), 0, (hipStream_t)stream, d_row_a, d_cnt_a, (long)ys_a, d_row_b,
                        d_cnt_b, (long)ys_b, (int)oh, (int)width, (int)c, (long)y_begin, (long)y_end, d_probs, d_pred);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_gather_patches_u8(const uint8_t* d_slide, int64_t sh, int64_t sw, int64_t c, const int32_t* d_bounds,
+                                     int64_t m, int64_t ph, int64_t pw, int32_t pad, uint8_t* d_out, void* stream) {
+    if (!d_slide || !d_bounds || !d_out || sh <= 0 || sw <= 0 || c <= 0 || m < 0 || ph <= 0 || pw <= 0) return TIA_EINVAL;
+    if (m == 0) return TIA_OK;
+    const long patch_bytes = (long)ph * pw * c;
+    if ((patch_bytes & 3) != 0 || m > 65535 || sh > 0x7fffffffL || sw * c > 0x7fffffffL) return TIA_ESIZE;
+    if ((reinterpret_cast<uintptr_t>(d_out) & 3) != 0) return TIA_EINVAL;
+    long blocks = (patch_bytes / 4 + tia::CT - 1) / tia::CT;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(tia::gather_patches_kernel, dim3((unsigned)blocks, (unsigned)m), dim3(tia::CT), 0, (hipStream_t)stream,
+                       d_slide, (int)sh, (int)sw, (int)c, d_bounds, (int)ph, (int)pw, pad, d_out);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

@@ -3,9 +3,9 @@ need: ``VirtualWSIReader`` :3121-3694, ``slide_thumbnail``, ``tissue_mask`` :173
 
 File-format readers (OpenSlide, TIFF, DICOM, ...) are out of scope: a slide is an
 ``H x W x 3`` uint8 array (NumPy or CUDA tensor) with an objective power / mpp.  Reads happen on the
-GPU: the level-0 image lives in HBM (a 20k x 20k slide is 1.2 GB of the 288 GB) and patches are
-gathered from a 255-padded copy, so out-of-bounds regions are white exactly as
-``WSIPatchDataset.__getitem__`` pads them (``dataset_abc.py:430-436``).
+GPU: the level-0 image lives in HBM (a 20k x 20k slide is 1.2 GB of the 288 GB) and a batch of patches is
+gathered by one kernel launch (``tia_gather_patches_u8``) that writes 255 wherever a region leaves the slide, exactly
+as ``WSIPatchDataset.__getitem__`` pads (``dataset_abc.py:430-436``).
 """
 
 from __future__ import annotations
@@ -27,8 +27,6 @@ class ArrayWSIReader:
         self.mode = mode
         self.mpp = mpp
         self.power = power
-        self._padded = None
-        self._pad = (0, 0, 0, 0)
 
     @property
     def img(self) -> np.ndarray:
@@ -43,41 +41,60 @@ class ArrayWSIReader:
         return int(self._dev.shape[1]), int(self._dev.shape[0])  # (width, height)
 
     # ------------------------------------------------------------------------------- reads
-    def prepare_padding(self, left: int, top: int, right: int, bottom: int, value: int = 255) -> None:
-        """Build the padded device copy that makes every later bounded read a plain slice."""
-        if self._padded is not None and self._pad == (left, top, right, bottom):
-            return
-        h, w = self._dev.shape[:2]
-        rest = self._dev.shape[2:]
-        padded = torch.full((h + top + bottom, w + left + right, *rest), value, dtype=self._dev.dtype,
-                            device=self._dev.device)
-        padded[top:top + h, left:left + w] = self._dev
-        self._padded, self._pad = padded, (left, top, right, bottom)
+    def read_bounds_batch(self, bounds: np.ndarray, pad_value: int = 255) -> torch.Tensor:
+        """Stack of equally-sized regions ``[x0, y0, x1, y1]`` (baseline pixels), ``pad_value`` outside the slide:
+        one gather launch (``tia_gather_patches_u8``) writes the whole ``[M, ph, pw, C]`` batch."""
+        from tiatoolbox_amd import _lib
 
-    def read_bounds_batch(self, bounds: np.ndarray) -> torch.Tensor:
-        """Stack of equally-sized regions ``[x0, y0, x1, y1]`` (baseline pixels), padded with 255."""
-        bounds = np.asarray(bounds)
-        left = max(0, int(-bounds[:, 0].min()))
-        top = max(0, int(-bounds[:, 1].min()))
-        w, h = self.slide_dimensions
-        right = max(0, int(bounds[:, 2].max()) - w)
-        bottom = max(0, int(bounds[:, 3].max()) - h)
-        pl, pt, pr, pb = self._pad
-        if self._padded is None or left > pl or top > pt or right > pr or bottom > pb:
-            self.prepare_padding(max(left, pl), max(top, pt), max(right, pr), max(bottom, pb))
-        pl, pt, _, _ = self._pad
-        return torch.stack([self._padded[y0 + pt:y1 + pt, x0 + pl:x1 + pl] for x0, y0, x1, y1 in bounds.tolist()])
+        bounds = np.ascontiguousarray(np.asarray(bounds).reshape(-1, 4), dtype=np.int32)
+        sizes = np.unique(np.stack([bounds[:, 2] - bounds[:, 0], bounds[:, 3] - bounds[:, 1]], axis=1), axis=0)
+        if len(sizes) != 1:
+            msg = "read_bounds_batch expects regions of one size."
+            raise ValueError(msg)
+        pw, ph = int(sizes[0, 0]), int(sizes[0, 1])
+        src = self._dev if self._dev.dim() == 3 else self._dev[..., None]  # noqa: PLR2004
+        src = src.contiguous()
+        if src.dtype == torch.bool:
+            src = src.to(torch.uint8)
+        if src.dtype != torch.uint8:
+            msg = "device patch reads need a uint8 slide."
+            raise TypeError(msg)
+        sh, sw, c = src.shape
+        m = len(bounds)
+        out = torch.empty((m, ph, pw, c), dtype=torch.uint8, device=src.device)
+        if (ph * pw * c) % 4 != 0:  # odd-sized patches: plain slicing of a padded copy (rare; keeps the contract)
+            pad = max(0, -int(bounds[:, :2].min()), int(bounds[:, 2].max()) - sw, int(bounds[:, 3].max()) - sh)
+            padded = torch.nn.functional.pad(src.permute(2, 0, 1), (pad, pad, pad, pad), value=pad_value).permute(1, 2, 0)
+            for i, (x0, y0, x1, y1) in enumerate(bounds.tolist()):
+                out[i] = padded[y0 + pad:y1 + pad, x0 + pad:x1 + pad]
+        else:
+            bt = torch.from_numpy(bounds).to(src.device)
+            lib = _lib.load()
+            with torch.cuda.device(src.device):
+                for s in range(0, m, 65535):
+                    k = min(65535, m - s)
+                    rc = lib.tia_gather_patches_u8(src.data_ptr(), sh, sw, c, bt[s:s + k].data_ptr(), k, ph, pw, int(pad_value),
+                                                   out[s:s + k].data_ptr(), _lib.current_stream())
+                    _lib.check(rc, "tia_gather_patches_u8")
+        return out if self._dev.dim() == 3 else out[..., 0]  # noqa: PLR2004
 
     def read_bounds(self, bounds) -> np.ndarray:
         return self.read_bounds_batch(np.asarray(bounds)[None])[0].cpu().numpy()
 
     # ---------------------------------------------------------------------- thumbnail / mask
     def slide_thumbnail(self, resolution: float = 1.25, units: str = "power") -> torch.Tensor:
-        """Area-averaged down-sample to the requested objective power (integer factor), uint8."""
+        """Thumbnail at the requested objective power, uint8.  The reference reads it through ``imresize`` whose
+        down-sampling interpolation is ``cv2.INTER_AREA`` (``utils/transforms.py:imresize``, ``wsireader.py:1735-1786``);
+        for an integer factor that is the exact box mean rounded half-to-even (``cvRound``), which is what this does."""
         if units != "power" or self.power is None:
             msg = "ArrayWSIReader thumbnails are requested by objective power."
             raise ValueError(msg)
-        factor = max(1, int(round(self.power / resolution)))
+        ratio = self.power / resolution
+        factor = max(1, int(round(ratio)))
+        if abs(ratio - factor) > 1e-9:  # noqa: PLR2004
+            msg = (f"ArrayWSIReader holds one (baseline) level: thumbnails need an integer down-sampling factor, got "
+                   f"{self.power}/{resolution}.")
+            raise ValueError(msg)
         h, w = self._dev.shape[:2]
         th, tw = h // factor, w // factor
         x = self._dev[:th * factor, :tw * factor].reshape(th, factor, tw, factor, -1).to(torch.float32)
