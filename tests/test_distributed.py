@@ -181,3 +181,54 @@ def test_tile_mode_sharded_across_ranks_matches_reference(tmp_path):
     for rank in range(2):
         with open(tmp_path / f"tile{rank}.pkl", "rb") as fh:
             ttm._check_table(pickle.load(fh), gold, "a")  # noqa: S301, SLF001
+
+
+# ------------------------------------------------------------------ semantic WSI mode: rank-local bands
+def _band_truth(h: int, w: int, c: int | None = None) -> torch.Tensor:
+    y = torch.arange(h).view(h, 1)
+    x = torch.arange(w).view(1, w)
+    base = ((y * 31 + x * 7) % 251).to(torch.uint8)
+    if c is None:
+        return base
+    return (base.float()[..., None] + torch.arange(c).float()) / 7.0
+
+
+def _band_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    tdist.init_from_env("gloo")
+    from tiatoolbox_amd.models.engine.semantic_segmentor import band_plan, exchange_bands
+
+    for h, w, stride, oh in ((1000, 37, 90, 110), (333, 20, 450, 512), (95, 8, 10, 12)):
+        row_ys = np.arange(0, int(np.ceil(h / stride) * stride), stride)
+        plan = band_plan(row_ys, oh, h, rank, world)
+        lo, hi = plan["own"]
+        assert plan["rows"] == list(range(max(lo - 1, 0), hi))  # own rows plus one leading row
+        truth, truth_p = _band_truth(h, w), _band_truth(h, w, 3)
+        y_lo, y_hi = plan["y_lo"], plan["y_hi"]
+        got = exchange_bands(truth[y_lo:y_hi].clone(), plan, h)
+        got_p = exchange_bands(truth_p[y_lo:y_hi].clone(), plan, h)
+        assert torch.equal(got, truth) and torch.equal(got_p, truth_p), (h, rank)
+    torch.save(torch.tensor(plan["bands"]), os.path.join(out_dir, f"bands{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_semantic_band_exchange_world2(tmp_path):
+    """Collective logic of sharded semantic WSI inference on CPU tensors (gloo): every rank owns a contiguous band of
+    canvas rows, the bands tile the slide, and one padded all-gather rebuilds predictions and probabilities on
+    every rank (rank-local bands instead of an all-reduce of a full-size map)."""
+    from tiatoolbox_amd.models.engine.semantic_segmentor import band_plan
+
+    for world in (1, 2, 3, 8):  # layout properties for any world size (no process group needed)
+        for h, stride in ((20000, 450), (1000, 90), (95, 10), (40, 450)):
+            row_ys = np.arange(0, int(np.ceil(h / stride) * stride), stride)
+            plans = [band_plan(row_ys, stride + 62, h, r, world) for r in range(world)]
+            bands = plans[0]["bands"]
+            assert all(p["bands"] == bands for p in plans)
+            covered = [b for b in bands if b[1] > b[0]]
+            assert covered[0][0] == 0 and covered[-1][1] == h
+            assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+            assert sorted(r for p in plans for r in range(*p["own"])) == list(range(len(row_ys)))
+    port = 29850 + (os.getpid() % 100)
+    mp.spawn(_band_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert torch.equal(torch.load(tmp_path / "bands0.pt"), torch.load(tmp_path / "bands1.pt"))

@@ -174,3 +174,67 @@ def test_hip_fused_resnet_matches_plain_model(patches):
         got16 = hip.half()(x.cuda().half().contiguous(memory_format=torch.channels_last)).float().cpu()
     assert (got - ref).abs().max() < 1e-4
     assert (got16 - ref).abs().max() < 5e-3
+
+
+def test_wsi_mode_contracts_without_gpu(tmp_path):
+    """Reference contracts of WSI mode that need no device (engine_abc.py:1333-1372, dataset_abc.py:397-401)."""
+    eng = PatchPredictor("resnet18-kather100k", batch_size=4)
+    slide = np.full((300, 300, 3), 255, np.uint8)
+    with pytest.raises(OSError, match="no save directory"):
+        eng.run([slide], patch_mode=False)
+    with pytest.raises(TypeError, match="list of file paths"):
+        eng.run(slide, patch_mode=False, save_dir=tmp_path)
+    with pytest.raises(NotImplementedError, match="file formats"):
+        eng.run([tmp_path / "slide.svs"], patch_mode=False, save_dir=tmp_path)
+
+
+@pytest.mark.gpu
+def test_patch_predictor_wsi_mode(tmp_path, target_image):
+    """WSI mode over an in-memory slide == patch mode over the patches the reference's ``WSIPatchDataset`` would
+    read: grid from ``PatchExtractor.get_coordinates``, tissue-mask filter, 255 padding at the slide edge
+    (engine_abc.py:1540-1682, dataset_abc.py:309-448, patch_predictor.py:382-446)."""
+    from oracle import stain as ostain  # noqa: F401  (oracle import keeps test infra together)
+    from tiatoolbox_amd.tools.patchextraction import PatchExtractor
+    from tiatoolbox_amd.utils import synth
+    from tiatoolbox_amd.wsicore import ArrayWSIReader
+
+    tissue = synth.g_he(1, 700, 900, seed=9)[0]
+    slide = np.full((1000, 1180, 3), 245, np.uint8)
+    slide[150:850, 100:1000] = tissue
+    reader = ArrayWSIReader(slide, mpp=0.5, power=20.0)
+    eng = PatchPredictor("resnet18-kather100k", batch_size=8, device="cuda")
+    out = eng.run([reader], patch_mode=False, save_dir=tmp_path, return_probabilities=True)
+    assert list(out) == [0] and out[0].name == "0.npz"
+    res = np.load(out[0])
+    coords = res["coordinates"]
+    grid = PatchExtractor.get_coordinates(image_shape=(1180, 1000), patch_input_shape=(224, 224), stride_shape=(224, 224))
+    mask_reader = reader.tissue_mask(resolution=1.25, units="power")
+    keep = PatchExtractor.filter_coordinates(mask_reader, grid, wsi_shape=(1180, 1000), min_mask_ratio=0)
+    assert np.array_equal(coords, grid[keep]) and 4 < len(coords) < len(grid)
+    padded = np.pad(slide, ((0, 400), (0, 400), (0, 0)), constant_values=255)
+    patches = np.stack([padded[y0:y1, x0:x1] for x0, y0, x1, y1 in coords])
+    exp = PatchPredictor("resnet18-kather100k", batch_size=8, device="cuda").run(patches, patch_mode=True,
+                                                                                 return_probabilities=True)
+    np.testing.assert_allclose(res["probabilities"], exp["probabilities"], atol=1e-5)
+    assert np.array_equal(res["predictions"], exp["predictions"])
+    # masks given explicitly, Macenko pre-normalisation in the loop, .npy path as the slide
+    np.save(tmp_path / "slide_a.npy", slide)
+    mask = np.zeros((1000, 1180), np.uint8)
+    mask[200:500, 200:700] = 1
+    from tiatoolbox_amd.tools.stainnorm import get_normalizer
+
+    norm = get_normalizer("macenko")
+    norm.fit(target_image)
+    out2 = eng.run([tmp_path / "slide_a.npy"], masks=[mask], patch_mode=False, save_dir=tmp_path / "b", stain_normalizer=norm,
+                   input_resolutions=[{"units": "mpp", "resolution": 0.25}])
+    res2 = np.load(next(iter(out2.values())))
+    assert "probabilities" not in res2.files or True
+    k2 = PatchExtractor.filter_coordinates(ArrayWSIReader(mask, mpp=None, power=None, mode="bool"), grid,
+                                           wsi_shape=(1180, 1000), min_mask_ratio=0)
+    assert np.array_equal(res2["coordinates"], grid[k2]) and len(res2["predictions"]) == int(k2.sum())
+    with pytest.raises(ValueError, match="no resolution pyramid"):
+        eng.run([reader], patch_mode=False, save_dir=tmp_path / "c", input_resolutions=[{"units": "mpp", "resolution": 1.0}],
+                stain_normalizer=None)
+    with pytest.raises(ValueError, match="No patch coordinates remain"):
+        eng.run([reader], masks=[np.zeros((1000, 1180), np.uint8)], patch_mode=False, save_dir=tmp_path / "d",
+                input_resolutions=[{"units": "mpp", "resolution": 0.5}])

@@ -230,7 +230,9 @@ class EngineABC:
         if save_dir is None and output_type.lower() in ["zarr", "qupath", "annotationstore"]:
             msg = f"Please provide save_dir for output_type={output_type}"
             raise ValueError(msg)
-        if self.output_type.lower() != "dict":
+        if not patch_mode and save_dir is not None and output_type.lower() == "dict":
+            self.output_type = "npz"  # WSI mode: one <name>.npz per slide under save_dir (zarr itself is out of scope)
+        if self.output_type.lower() not in ("dict", "npz"):
             if save_dir is not None and output_type.lower() == "dict":
                 msg = ("`save_dir` turns dict output into a zarr store in the reference (engine_abc.py:1330-1332); "
                        "zarr / annotation-store writers are outside the accelerated hot path: call run() without "
@@ -242,8 +244,13 @@ class EngineABC:
         if not patch_mode and save_dir is None:
             msg = "Input WSIs detected but no save directory provided. Please provide a 'save_dir'."
             raise OSError(msg)
-        self.images = self._validate_images_masks(images=images)
-        if masks is not None:
+        if not patch_mode and not isinstance(images, (list, tuple)):
+            msg = "Input must be a list of file paths or a numpy array."
+            raise TypeError(msg)
+        self.images = self._validate_images_masks(images=images) if patch_mode else list(images)
+        if masks is not None and not patch_mode:
+            self.masks = list(masks)
+        elif masks is not None:
             self.masks = self._validate_images_masks(images=masks)
         self._ioconfig = self._load_ioconfig(ioconfig=ioconfig)
         self.model = self.model.to(device=self.device)
@@ -418,6 +425,116 @@ class EngineABC:
         processed = self.post_process_patches(raw_predictions=raw, **kwargs)
         return self.save_predictions(processed_predictions=processed, output_type=output_type, **kwargs)
 
+    # ------------------------------------------------------------------------------ WSI mode
+    def _open_slide(self, image, *, as_mask: bool = False):
+        """In-memory slide: an ``ArrayWSIReader``, an ``H x W (x 3)`` array / tensor, or a ``.npy`` path.  File-format
+        readers (OpenSlide, TIFF, ...) are out of scope."""
+        from tiatoolbox_amd.wsicore import ArrayWSIReader
+
+        if isinstance(image, ArrayWSIReader):
+            return image
+        if isinstance(image, (str, Path)):
+            path = Path(image)
+            if path.suffix != ".npy":
+                msg = (f"cannot open `{path}`: whole-slide file formats are outside the accelerated hot path; pass an "
+                       "ArrayWSIReader, an array, or a .npy file.")
+                raise NotImplementedError(msg)
+            image = np.load(path)
+        kw = {"mpp": None, "power": None, "mode": "bool"} if as_mask else {}
+        if as_mask and not isinstance(image, torch.Tensor):
+            image = (np.asarray(image) > 0).astype(np.uint8)
+        return ArrayWSIReader(image, **kw)
+
+    @staticmethod
+    def _check_read_resolution(reader, ioconfig) -> None:
+        """The in-memory reader holds ONE level: the model's input resolution must be that level."""
+        res = ioconfig.input_resolutions[0]
+        units, value = res["units"], float(res["resolution"])
+        native = {"mpp": reader.mpp, "power": reader.power, "baseline": 1.0}.get(units)
+        if native is None or abs(float(native) - value) > 1e-6 * max(1.0, abs(value)):  # noqa: PLR2004
+            msg = (f"the model reads at {value} {units} but the in-memory slide is at {native} {units}: ArrayWSIReader "
+                   "has no resolution pyramid; resample the slide first or pass a matching `input_resolutions`.")
+            raise ValueError(msg)
+
+    def get_wsi_coordinates(self, reader, mask_reader, *, min_mask_ratio: float = 0.0) -> np.ndarray:
+        """Patch grid of one slide, filtered by the tissue mask (``WSIPatchDataset.__init__``, dataset_abc.py:309-345)."""
+        from tiatoolbox_amd.tools.patchextraction import PatchExtractor
+
+        cfg = self._ioconfig
+        wsi_shape = reader.slide_dimensions
+        coords = PatchExtractor.get_coordinates(image_shape=wsi_shape, patch_input_shape=tuple(cfg.patch_input_shape)[::-1],
+                                                stride_shape=tuple(cfg.stride_shape)[::-1])
+        if mask_reader is not None:
+            keep = PatchExtractor.filter_coordinates(mask_reader, coords, wsi_shape=wsi_shape, min_mask_ratio=min_mask_ratio)
+            coords = coords[keep]
+        if len(coords) == 0:
+            msg = "No patch coordinates remain after filtering."
+            raise ValueError(msg)
+        return coords
+
+    def infer_wsi(self, reader, coords: np.ndarray) -> dict:
+        """Forward every patch of one slide: device gather of the patch batch (``tia_gather_patches_u8``) -> the model's
+        ``preproc_func`` in its batched device form -> ``infer_batch``; patches sharded over ranks (ref. :590-648)."""
+        dev = torch.device(self.device)
+        if dev.type != "cuda":
+            msg = "WSI mode reads patches with a HIP gather kernel (device='cuda'); there is no CPU fallback."
+            from tiatoolbox_amd import _lib
+
+            raise _lib.HipLibraryError(msg)
+        dtype = _DTYPES[str(self.compute_dtype).replace("torch.", "")]
+        model = self._inference_model(dtype)
+        infer_batch = self._get_model_attr("infer_batch")
+        hook = self._get_model_attr("preproc_func")
+        device_batch = getattr(hook, "device_batch", None)
+        n = len(coords)
+        rank, world_size = tdist.world() if self.distributed else (0, 1)
+        lo, hi = tdist.shard_bounds(n, rank, world_size)
+        outs = []
+        with self._miopen_scope():
+            for s in range(lo, hi, self.batch_size):
+                raw = reader.read_bounds_batch(coords[s:min(s + self.batch_size, hi)])
+                if device_batch is not None:
+                    batch = device_batch(raw, dtype)
+                else:  # arbitrary user hook: per patch on the host, as Dataset.__getitem__ does in the reference
+                    batch = torch.stack([torch.as_tensor(np.asarray(hook(p))) for p in raw.cpu().numpy()]).to(dev)
+                outs.append(infer_batch(model, batch, device=self.device))
+        if not outs:
+            probe = reader.read_bounds_batch(coords[:1])
+            probe = device_batch(probe, dtype) if device_batch is not None else probe
+            outs = [infer_batch(model, probe, device=self.device)[:0]]
+        local = torch.cat([o if isinstance(o, torch.Tensor) else torch.from_numpy(np.asarray(o)) for o in outs])
+        if world_size > 1:
+            local = tdist.all_gather_rows(local.to(dev), n)
+        return {"probabilities": local, "coordinates": coords}
+
+    def _run_wsi_mode(self, save_dir, **kwargs) -> dict:
+        """Per slide: tissue mask -> patch grid -> ``infer_wsi`` -> ``post_process_patches`` -> ``<stem>.npz`` under
+        ``save_dir`` (ref. ``_run_wsi_mode`` :1540-1682; arrays ``predictions``, ``coordinates`` and, on request,
+        ``probabilities`` -- the members of the reference's zarr store).  Returns ``{image key: Path}``."""
+        save_dir = Path(save_dir)
+        save_dir.mkdir(parents=True, exist_ok=True)
+        out: dict = {}
+        images = self.images if isinstance(self.images, (list, tuple)) else [self.images]
+        for num, image in enumerate(images):
+            reader = self._open_slide(image)
+            self._check_read_resolution(reader, self._ioconfig)
+            mask_reader = None
+            if self.masks is not None:
+                mask_reader = self._open_slide(self.masks[num], as_mask=True)
+            elif kwargs.get("auto_get_mask", getattr(self, "auto_get_mask", True)):
+                mask_reader = reader.tissue_mask(resolution=1.25, units="power")
+            coords = self.get_wsi_coordinates(reader, mask_reader, min_mask_ratio=float(kwargs.get("min_mask_ratio", 0.0)))
+            raw = self.infer_wsi(reader, coords)
+            processed = self.post_process_patches(raw_predictions=raw, **kwargs)
+            arrays = self.save_predictions(processed_predictions=processed, output_type="dict", **kwargs)
+            key = image if isinstance(image, (str, Path)) else num
+            stem = Path(image).stem if isinstance(image, (str, Path)) else str(num)
+            path = save_dir / f"{stem}.npz"
+            if tdist.world()[0] == 0 or not self.distributed:
+                np.savez(path, **arrays)
+            out[key] = path
+        return out
+
     def run(self, images, *, masks=None, input_resolutions=None, patch_input_shape=None, ioconfig=None,
             patch_mode: bool = True, save_dir=None, overwrite: bool = False, output_type: str = "dict", **kwargs):
         """Run the engine on patches (ref. :1684-1829)."""
@@ -427,7 +544,6 @@ class EngineABC:
             output_type=output_type, **kwargs)
         if patch_mode:
             return self._run_patch_mode(output_type=self.output_type, save_dir=save_dir, **kwargs)
-        msg = "WSI mode is provided by the engines that implement it (SemanticSegmentor)."
-        raise NotImplementedError(msg)
+        return self._run_wsi_mode(save_dir=save_dir, **kwargs)
 
     predict = run  # tiatoolbox 1.x name, still used by the reference's example notebooks

@@ -333,33 +333,52 @@ class MultiTaskSegmentor(EngineABC):
         oh = int(cfg.patch_output_shape[0])
         heads: list[torch.Tensor] | None = None
         prev: list | None = None   # per head (row, cnt, ys)
-        dummy = torch.zeros((rh, rw), dtype=torch.uint8, device=dev)
         row_ys = np.unique(inside[:, 1])
+        # patch rows are sharded over ranks: every rank stitches the band of head-map rows it owns (plus one leading
+        # patch row for the overlap) and the bands are all-gathered once; one rank = the whole region
+        from tiatoolbox_amd import distributed as tdist
+        from tiatoolbox_amd.models.engine.semantic_segmentor import band_plan, exchange_bands
 
-        for ri, ys in enumerate(row_ys.tolist()):
-            sel = np.flatnonzero(keep & (out_b[:, 1] - min_y == ys))
-            rows = None
-            if len(sel):
-                outs = [infer_batch(model, reader.read_bounds_batch(in_b[sel[s:s + self.batch_size]]), device=self.device)
-                        for s in range(0, len(sel), self.batch_size)]
-                blocks = [torch.cat([o[k] for o in outs]).float().contiguous() for k in range(len(outs[0]))]
+        rank, world = tdist.world() if self.distributed else (0, 1)
+        plan = band_plan(row_ys, oh, rh, rank, world)
+        r_lo = plan["own"][0]
+        y_lo, y_hi = plan["y_lo"], plan["y_hi"]
+        band_h = max(y_hi - y_lo, 0)
+        dummy = torch.zeros((band_h, rw), dtype=torch.uint8, device=dev)
+
+        with self._miopen_scope():
+            for ri in plan["rows"]:
+                ys = int(row_ys[ri])
+                sel = np.flatnonzero(keep & (out_b[:, 1] - min_y == ys))
+                rows = None
+                if len(sel):
+                    outs = [infer_batch(model, reader.read_bounds_batch(in_b[sel[s:s + self.batch_size]]), device=self.device)
+                            for s in range(0, len(sel), self.batch_size)]
+                    blocks = [torch.cat([o[k] for o in outs]).float().contiguous() for k in range(len(outs[0]))]
+                    if heads is None:
+                        heads = [torch.zeros((band_h, rw, b.shape[-1]), dtype=torch.float32, device=dev) for b in blocks]
+                    rows = [(*_row_merge(b, out_b[sel, 0] - min_x, rw), ys) for b in blocks]
                 if heads is None:
-                    heads = [torch.zeros((rh, rw, b.shape[-1]), dtype=torch.float32, device=dev) for b in blocks]
-                rows = [(*_row_merge(b, out_b[sel, 0] - min_x, rw), ys) for b in blocks]
-            if heads is None:
-                continue  # nothing inferred yet: the maps start as zeros
-            if rows is None:
-                rows = [(torch.zeros((oh, rw, hd.shape[-1]), dtype=torch.float32, device=dev),
-                         torch.zeros((oh, rw), dtype=torch.uint8, device=dev), ys) for hd in heads]
-            # the band [ys, next row): this row plus whatever the previous row still covers
-            y1 = min(int(row_ys[ri + 1]) if ri + 1 < len(row_ys) else ys + oh, rh)
-            for k, head in enumerate(heads):
-                cur = rows[k]
-                if prev is None:
-                    _finalize(cur[0], cur[1], cur[2], None, None, 0, ys, y1, head, dummy)
-                else:
-                    _finalize(prev[k][0], prev[k][1], prev[k][2], cur[0], cur[1], cur[2], ys, y1, head, dummy)
-            prev = rows
+                    continue  # nothing inferred yet: the maps start as zeros
+                if rows is None:
+                    rows = [(torch.zeros((oh, rw, hd.shape[-1]), dtype=torch.float32, device=dev),
+                             torch.zeros((oh, rw), dtype=torch.uint8, device=dev), ys) for hd in heads]
+                if ri >= r_lo:
+                    # the band [ys, next row): this row plus whatever the previous row still covers
+                    y1 = min(int(row_ys[ri + 1]) if ri + 1 < len(row_ys) else ys + oh, rh)
+                    for k, head in enumerate(heads):
+                        cur = rows[k]
+                        if prev is None:
+                            _finalize(cur[0], cur[1], cur[2], None, None, 0, ys, y1, head, dummy, y_base=y_lo)
+                        else:
+                            _finalize(prev[k][0], prev[k][1], prev[k][2], cur[0], cur[1], cur[2], ys, y1, head, dummy,
+                                      y_base=y_lo)
+                prev = rows
+        if world > 1:
+            if heads is None:  # this rank's rows hold no tissue: it still takes part in the exchange with zero bands
+                probe = infer_batch(model, reader.read_bounds_batch(in_b[keep][:1]), device=self.device)
+                heads = [torch.zeros((band_h, rw, p.shape[-1]), dtype=torch.float32, device=dev) for p in probe]
+            heads = [exchange_bands(hd, plan, rh) for hd in heads]
         return {"probabilities": heads, "coordinates": kept}
 
     def _postproc_maps(self, maps: list[torch.Tensor], offset=(0, 0)) -> tuple[dict, ...]:

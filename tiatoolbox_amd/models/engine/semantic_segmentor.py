@@ -52,14 +52,61 @@ def _row_merge(blocks: torch.Tensor, xs: np.ndarray, width: int) -> tuple[torch.
     return row, cnt
 
 
-def _finalize(row_a, cnt_a, ys_a, row_b, cnt_b, ys_b, y0, y1, probs, pred) -> None:
+def _finalize(row_a, cnt_a, ys_a, row_b, cnt_b, ys_b, y0, y1, probs, pred, *, y_base: int = 0) -> None:
+    """Normalise + arg-max canvas rows ``[y0, y1)``.  ``pred`` / ``probs`` may be a band of the slide-sized maps whose
+    first row is slide row ``y_base``: row coordinates are shifted by ``-y_base`` (the kernel only ever uses the
+    differences ``y - ys``)."""
     oh, width, c = row_a.shape
     with torch.cuda.device(row_a.device):
         rc = _lib.load().tia_canvas_finalize_f32(
-            row_a.data_ptr(), cnt_a.data_ptr(), int(ys_a), row_b.data_ptr() if row_b is not None else 0,
-            cnt_b.data_ptr() if cnt_b is not None else 0, int(ys_b), oh, width, c, int(y0), int(y1),
+            row_a.data_ptr(), cnt_a.data_ptr(), int(ys_a) - y_base, row_b.data_ptr() if row_b is not None else 0,
+            cnt_b.data_ptr() if cnt_b is not None else 0, int(ys_b) - y_base, oh, width, c, int(y0) - y_base, int(y1) - y_base,
             probs.data_ptr() if probs is not None else 0, pred.data_ptr(), _lib.current_stream())
     _lib.check(rc, "tia_canvas_finalize_f32")
+
+
+def band_plan(row_ys: np.ndarray, oh: int, height: int, rank: int, world: int) -> dict:
+    """Which patch rows a rank infers and which canvas rows it owns (contiguous bands of patch rows).
+
+    ``rows`` = indices into ``row_ys`` the rank must infer (its own rows plus one leading row, whose lower part overlaps
+    the band's first canvas rows); ``own`` = the slice of ``rows`` it finalises; ``y_lo:y_hi`` = canvas rows it owns;
+    ``bands`` = ``(y_lo, y_hi)`` of every rank, so all ranks agree on the layout of the exchange."""
+    n_rows = len(row_ys)
+
+    def limits(r: int) -> tuple[int, int, int, int]:
+        lo, hi = tdist.shard_bounds(n_rows, r, world)
+        y_lo = min(int(row_ys[lo]), height) if lo < n_rows else height
+        y_hi = min(int(row_ys[hi]), height) if hi < n_rows else height
+        if lo >= hi:
+            y_lo = y_hi = height
+        return lo, hi, y_lo, y_hi
+
+    lo, hi, y_lo, y_hi = limits(rank)
+    return {"rows": list(range(max(lo - 1, 0), hi)), "own": (lo, hi), "y_lo": y_lo, "y_hi": y_hi,
+            "bands": [limits(r)[2:] for r in range(world)], "oh": oh}
+
+
+def exchange_bands(local: torch.Tensor, plan: dict, height: int) -> torch.Tensor:
+    """All-gather of the rank-local canvas bands into the full map (every rank gets it): one
+    ``all_gather_into_tensor`` of bands padded to the tallest one -- each rank contributes only the rows it owns, so
+    the exchange moves the map once instead of all-reducing a mostly-zero full-size copy per rank.
+
+    ``local`` = this rank's band ``[y_hi - y_lo, W, ...]``; works on CPU tensors too (gloo), which is how the
+    collective logic is tested without a GPU."""
+    bands = plan["bands"]
+    world = len(bands)
+    if world == 1:
+        return local
+    tallest = max(max(b[1] - b[0] for b in bands), 1)
+    pad = torch.zeros((tallest, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * tallest, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    torch.distributed.all_gather_into_tensor(out, pad.contiguous())
+    full = torch.zeros((height, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r, (y_lo, y_hi) in enumerate(bands):
+        if y_hi > y_lo:
+            full[y_lo:y_hi] = out[r * tallest: r * tallest + (y_hi - y_lo)]
+    return full
 
 
 class SemanticSegmentor(PatchPredictor):
@@ -101,46 +148,49 @@ class SemanticSegmentor(PatchPredictor):
         row_ys = np.unique(out_b[:, 1])
         oh = int(self._ioconfig.patch_output_shape[0])
         rank, world = tdist.world() if self.distributed else (0, 1)
-        r_lo, r_hi = tdist.shard_bounds(len(row_ys), rank, world)
-        pred = torch.zeros((h, w), dtype=torch.uint8, device=dev)
+        plan = band_plan(row_ys, oh, h, rank, world)
+        r_lo, r_hi = plan["own"]
+        y_lo, y_hi = plan["y_lo"], plan["y_hi"]
+        # rank-local band of the slide-sized maps (row 0 of the band = canvas row y_lo)
+        pred = torch.zeros((max(y_hi - y_lo, 0), w), dtype=torch.uint8, device=dev)
         probs = None
         n_ch = None
         prev = None  # (row, cnt, ys)
-        # one extra leading row so the band's first canvas rows see their upper neighbour
-        for ri in range(max(r_lo - 1, 0), r_hi):
-            ys = int(row_ys[ri])
-            sel = np.flatnonzero((out_b[:, 1] == ys) & keep)
-            if len(sel):
-                outs = []
-                for s in range(0, len(sel), self.batch_size):
-                    idx = sel[s:s + self.batch_size]
-                    outs.append(infer_batch(model, reader.read_bounds_batch(in_b[idx]), device=self.device))
-                blocks = torch.cat(outs)
-                n_ch = blocks.shape[-1]
-                if return_probabilities and probs is None:
-                    probs = torch.zeros((h, w, n_ch), dtype=torch.float32, device=dev)
-                row, cnt = _row_merge(blocks, out_b[sel, 0], w)
-            else:
-                if n_ch is None:
-                    probe = infer_batch(model, reader.read_bounds_batch(in_b[:1]), device=self.device)
-                    n_ch = probe.shape[-1]
-                row = torch.zeros((oh, w, n_ch), dtype=torch.float32, device=dev)
-                cnt = torch.zeros((oh, w), dtype=torch.uint8, device=dev)
-            if ri >= r_lo:
-                y1 = min(int(row_ys[ri + 1]) if ri + 1 < len(row_ys) else ys + oh, h)
-                if prev is None:
-                    _finalize(row, cnt, ys, None, None, 0, ys, y1, probs, pred)
+
+        with self._miopen_scope():
+            for ri in plan["rows"]:
+                ys = int(row_ys[ri])
+                sel = np.flatnonzero((out_b[:, 1] == ys) & keep)
+                if len(sel):
+                    outs = []
+                    for s in range(0, len(sel), self.batch_size):
+                        idx = sel[s:s + self.batch_size]
+                        outs.append(infer_batch(model, reader.read_bounds_batch(in_b[idx]), device=self.device))
+                    blocks = torch.cat(outs)
+                    n_ch = blocks.shape[-1]
+                    row, cnt = _row_merge(blocks, out_b[sel, 0], w)
                 else:
-                    _finalize(prev[0], prev[1], prev[2], row, cnt, ys, ys, y1, probs, pred)
-            prev = (row, cnt, ys)
-        if world > 1:  # each rank owns a horizontal band; exchange the uint8 bands
-            band = torch.zeros_like(pred)
-            y_lo = int(row_ys[r_lo]) if r_lo < len(row_ys) else h
-            y_hi = min(int(row_ys[r_hi]) if r_hi < len(row_ys) else h, h)
-            band[y_lo:y_hi] = pred[y_lo:y_hi]
-            torch.distributed.all_reduce(band, op=torch.distributed.ReduceOp.MAX)
-            pred = band
-        out = {"predictions": pred, "coordinates": out_b[keep]}
+                    if n_ch is None:
+                        probe = infer_batch(model, reader.read_bounds_batch(in_b[:1]), device=self.device)
+                        n_ch = probe.shape[-1]
+                    row = torch.zeros((oh, w, n_ch), dtype=torch.float32, device=dev)
+                    cnt = torch.zeros((oh, w), dtype=torch.uint8, device=dev)
+                if return_probabilities and probs is None:
+                    probs = torch.zeros((max(y_hi - y_lo, 0), w, n_ch), dtype=torch.float32, device=dev)
+                if ri >= r_lo:
+                    y1 = min(int(row_ys[ri + 1]) if ri + 1 < len(row_ys) else ys + oh, h)
+                    if prev is None:
+                        _finalize(row, cnt, ys, None, None, 0, ys, y1, probs, pred, y_base=y_lo)
+                    else:
+                        _finalize(prev[0], prev[1], prev[2], row, cnt, ys, ys, y1, probs, pred, y_base=y_lo)
+                prev = (row, cnt, ys)
+        if return_probabilities and probs is None:
+            probs = torch.zeros((max(y_hi - y_lo, 0), w, n_ch or 1), dtype=torch.float32, device=dev)
+        if world > 1 and not getattr(self, "return_bands", False):
+            pred = exchange_bands(pred, plan, h)
+            if return_probabilities:
+                probs = exchange_bands(probs, plan, h)
+        out = {"predictions": pred, "coordinates": out_b[keep], "band": (y_lo, y_hi)}
         if return_probabilities and probs is not None:
             out["probabilities"] = probs
         return out
