@@ -1,0 +1,368 @@
+"""``bench.py --config semantic | hovernet | vahadane``: BASELINE.json configs[2], configs[3], configs[4].
+
+Same contract as the headline bench (one JSON line on rank 0, W untimed warm-up steps, K timed steps between
+barrier + synchronize, max over ranks, ``roofline`` from HIP events on the launch stream, ``cpu_baseline`` = the oracle
+on a bounded sample on rank 0 at N=1).  A *step* is one pass of the config's whole job over the rank's share:
+
+* ``semantic`` -- ``SemanticSegmentor("fcn_resnet50_unet-bcss").run([slide], patch_mode=False)`` over ONE synthetic
+  ``--slide`` x ``--slide`` (default 20 000) in-memory WSI: Otsu tissue mask of the thumbnail, patch grid + mask filter,
+  device patch gather, UNet-R50 fp32, device stitching; patch rows sharded over ranks, bands all-gathered (strong scaling:
+  the slide is the job).  Unit: 1024x1024 input patches/s.
+* ``hovernet`` -- ``NucleusInstanceSegmentor("hovernet_fast-pannuke").run(patches, patch_mode=True)`` on 256x256 tiles:
+  HoVer-Net fast fp32 + the HIP post-processing (Sobel-21 ... watershed, instance statistics, contours).  Unit: tiles/s.
+  The post-processing is also timed alone on synthetic head outputs with ~60 nuclei per tile.
+* ``vahadane`` -- ``VahadaneNormalizer.transform`` (dictionary learning on the device + normalise) followed by
+  ``StainAugmentor(method="vahadane").fit + augment`` over 256x256 patches (8192 per GPU = 65 536 over 8).  Unit: patches/s.
+"""
+
+from __future__ import annotations
+
+import os
+import statistics
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+HBM_PEAK_GBS = 8000.0
+MFMA_PEAK_F32 = 157.3
+
+
+def _setup(args):
+    import logging
+
+    import torch
+
+    from tiatoolbox_amd import distributed as tdist
+
+    rank, world_size, local_rank = tdist.init_from_env()
+    torch.cuda.set_device(local_rank)
+    logging.getLogger("tiatoolbox_amd").setLevel(logging.ERROR)
+    return rank, world_size, torch.device("cuda", local_rank)
+
+
+def _timed(step, args, world_size: int, device) -> float:
+    import torch
+
+    def barrier() -> None:
+        if world_size > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    if world_size > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _ev(fn, reps: int = 5) -> float:
+    import torch
+
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def _median_time(fn, reps: int = 3) -> float:
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts)
+
+
+def _flops_of(model, x) -> float:
+    import torch
+    from torch.utils.flop_counter import FlopCounterMode
+
+    with torch.inference_mode(), FlopCounterMode(display=False) as fc:
+        model(x)
+    return float(fc.get_total_flops())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def bench_semantic(args) -> dict | None:
+    import numpy as np
+    import torch
+
+    from tiatoolbox_amd.models.engine.semantic_segmentor import SemanticSegmentor, _finalize, _row_merge
+    from tiatoolbox_amd.utils import synth
+    from tiatoolbox_amd.wsicore import ArrayWSIReader
+
+    rank, world_size, device = _setup(args)
+    side = int(args.slide)
+    # synthetic slide: a G-he tile mosaic on a bright background (20 % margin + gutters, so the Otsu mask drops tiles)
+    tile = torch.from_numpy(synth.g_he(1, 2048, 2048, seed=3)[0]).to(device)
+    slide = torch.full((side, side, 3), 243, dtype=torch.uint8, device=device)
+    lo, hi = side // 10, side - side // 10
+    for y in range(lo, hi, 2048 + 256):
+        for x in range(lo, hi, 2048 + 256):
+            h, w = min(2048, hi - y), min(2048, hi - x)
+            slide[y:y + h, x:x + w] = tile[:h, :w]
+    reader = ArrayWSIReader(slide, mpp=0.25, power=40.0)
+    eng = SemanticSegmentor("fcn_resnet50_unet-bcss", batch_size=int(os.environ.get("TIA_SEM_BATCH", "8")),
+                            device=str(device), verbose=False)
+    result = {}
+
+    def step():
+        result["out"] = eng.run([reader], patch_mode=False, miopen_find=True)
+
+    step()  # MIOpen solver search, lazy loads
+    cfg = eng._ioconfig  # noqa: SLF001
+    mask_reader = reader.tissue_mask(resolution=1.25, units="power")
+    in_b, out_b, keep = eng.get_coordinates(reader, mask_reader)
+    n_patches, n_grid = int(keep.sum()), len(keep)
+    elapsed = _timed(step, args, world_size, device)
+    pred = result["out"]["predictions"][0]
+    assert pred.shape == (side, side) and pred.dtype == np.uint8
+    if rank != 0:
+        return None
+    total = n_patches * args.steps
+    ph = int(cfg.patch_input_shape[0])
+    oh = int(cfg.patch_output_shape[0])
+    # dominant hand-written kernels: one patch row through the canvas kernels (HIP events)
+    per_row = int(np.sum((out_b[:, 1] == out_b[0, 1])))
+    blocks = torch.rand((per_row, oh, oh, 5), device=device)
+    xs = out_b[out_b[:, 1] == out_b[0, 1]][:, 0]
+    t_merge = _ev(lambda: _row_merge(blocks, xs, side))
+    row, cnt = _row_merge(blocks, xs, side)
+    band = torch.zeros((oh, side), dtype=torch.uint8, device=device)
+    t_fin = _ev(lambda: _finalize(row, cnt, 0, row, cnt, 450, 450, 450 + 450, None, band, y_base=450))
+    merge_bytes = blocks.numel() * 4 + row.numel() * 4 + cnt.numel()
+    fin_bytes = 2 * 450 * side * 5 * 4 + 2 * 450 * side + 450 * side
+    t_gather = _ev(lambda: reader.read_bounds_batch(in_b[keep][:8]))
+    gather_bytes = 2 * 8 * ph * ph * 3
+    model = eng._inference_model(torch.float32)  # noqa: SLF001
+    x = reader.read_bounds_batch(in_b[keep][:1]).float().permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    flops = _flops_of(model, x)
+    t_fwd = _ev(lambda: eng.model.infer_batch(model, reader.read_bounds_batch(in_b[keep][:8]), device=str(device)), reps=3) / 8
+    line = {
+        "metric": "patches/s (1024x1024x3 in, 512x512x5 out), SemanticSegmentor(fcn_resnet50_unet-bcss) WSI mode",
+        "value": round(total / elapsed, 3), "unit": "patches/s", "n_gpus": world_size, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "float32", "data": "synthetic",
+        "config": {"workload": (f"BASELINE configs[2]: SemanticSegmentor(fcn_resnet50_unet-bcss, seeded random weights).run("
+                                f"[one synthetic {side}x{side} in-memory WSI], patch_mode=False), Otsu tissue mask: "
+                                f"{n_patches} of {n_grid} grid patches kept"),
+                   "slide": side, "patches_per_slide": n_patches, "megapixels_per_s": round(side * side * args.steps / elapsed / 1e6, 1),
+                   "parallelism": f"patch rows sharded over {world_size} rank(s), rank-local bands, one all-gather of the uint8 map"},
+        "roofline": {
+            "kernel": "row_merge_kernel", "bound": "hbm", "achieved": round(merge_bytes / t_merge / 1e9, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(merge_bytes / t_merge / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes": merge_bytes, "launch_ms": round(t_merge * 1e3, 4),
+            "other_kernels": {
+                "finalize_kernel": {"bound": "hbm", "achieved": round(fin_bytes / t_fin / 1e9, 1), "unit": "GB/s",
+                                    "frac": round(fin_bytes / t_fin / 1e9 / HBM_PEAK_GBS, 4), "launch_ms": round(t_fin * 1e3, 4)},
+                "gather_patches_kernel": {"bound": "hbm", "achieved": round(gather_bytes / t_gather / 1e9, 1), "unit": "GB/s",
+                                          "frac": round(gather_bytes / t_gather / 1e9 / HBM_PEAK_GBS, 4),
+                                          "launch_ms": round(t_gather * 1e3, 4)}},
+            "backbone": {"bound": "mfma", "what": "UNet-R50 forward per 1024^2 patch (MIOpen), batch 8",
+                         "gflop_per_patch": round(flops / 1e9, 1), "achieved": round(flops / t_fwd / 1e12, 2),
+                         "peak": MFMA_PEAK_F32, "unit": "TFLOP/s", "frac": round(flops / t_fwd / 1e12 / MFMA_PEAK_F32, 4),
+                         "ms_per_patch": round(t_fwd * 1e3, 3)}},
+    }
+    if not args.no_cpu_baseline and world_size == 1:
+        from oracle import semantic as osem
+        from tiatoolbox_amd.models.architecture import get_pretrained_model
+
+        cpu_model, _ = get_pretrained_model("fcn_resnet50_unet-bcss")
+        cpu_model.eval()
+        xc = torch.rand(1, 3, ph, ph) * 255
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        with torch.inference_mode():
+            cpu_model(xc)
+            t_cnn = _median_time(lambda: cpu_model(xc))
+        sample = np.random.default_rng(0).random((4, oh, oh, 5), dtype=np.float32)
+        locs = np.array([[0, 0, oh, oh], [450, 0, 450 + oh, oh], [0, 450, oh, 450 + oh], [450, 450, 450 + oh, 450 + oh]])
+        t_merge_cpu = _median_time(lambda: osem.merge_wsi(sample, locs, (450 + oh, 450 + oh))) / 4
+        line["cpu_baseline"] = {
+            "value": round(1.0 / (t_cnn + t_merge_cpu), 4), "unit": "patches/s", "cores": min(os.cpu_count() or 1, 64),
+            "kind": "port", "repeats": 3, "statistic": "median",
+            "sample": (f"1 patch: torch-CPU fp32 UNet-R50 forward ({t_cnn:.2f} s) + oracle overlap-average merge "
+                       f"({t_merge_cpu * 1e3:.1f} ms per patch over a 2x2 patch neighbourhood)")}
+    return line
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def bench_hovernet(args) -> dict | None:
+    import warnings
+
+    import numpy as np
+    import torch
+
+    from oracle import hovernet as oh
+    from tiatoolbox_amd.models.architecture import _hover_device as hd
+    from tiatoolbox_amd.models.engine.multi_task_segmentor import NucleusInstanceSegmentor
+    from tiatoolbox_amd.utils import synth
+
+    rank, world_size, device = _setup(args)
+    n = args.patches if args.patches != 4096 else 256  # tiles per GPU per step
+    host = synth.g_he(min(n, 64), 256, 256, seed=5)
+    tiles = np.ascontiguousarray(np.tile(host, ((n * world_size + len(host) - 1) // len(host), 1, 1, 1))[:n * world_size])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        eng = NucleusInstanceSegmentor("hovernet_fast-pannuke", batch_size=int(os.environ.get("TIA_HOVER_BATCH", "32")),
+                                       device=str(device), verbose=False)
+    result = {}
+
+    def step():
+        result["out"] = eng.run(tiles, patch_mode=True, miopen_find=True)
+
+    step()
+    elapsed = _timed(step, args, world_size, device)
+    out = result["out"]
+    assert out["predictions"].shape == (n * world_size, 164, 164)
+    if rank != 0:
+        return None
+    # post-processing alone, on synthetic head outputs with ~60 nuclei per 164^2 tile (HIP events)
+    npm, hv, tp = oh.synth_maps(8, 164, 164, seed=1, n_blobs=60)
+    reps = max(1, n // 8)
+    npm_d = torch.from_numpy(npm).to(device).repeat(reps, 1, 1, 1)
+    hv_d = torch.from_numpy(hv).to(device).repeat(reps, 1, 1, 1)
+    tp_d = torch.from_numpy(tp).to(device).repeat(reps, 1, 1, 1)
+    m = npm_d.shape[0]
+    t_proc = _ev(lambda: hd.proc_np_hv(npm_d, hv_d), reps=5)
+    model = eng.model.module if hasattr(eng.model, "module") else eng.model
+    t_post = _ev(lambda: model.postproc_batch(npm_d, hv_d, tp_d), reps=3)
+    inst, _ = hd.proc_np_hv(npm_d[:8], hv_d[:8])
+    n_inst = int(sum(len(np.unique(inst[i].cpu().numpy())) - 1 for i in range(8))) / 8
+    alg = m * 164 * 164 * 20
+    fmodel = eng._inference_model(torch.float32)  # noqa: SLF001
+    x = torch.from_numpy(tiles[:8]).to(device).float().permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    flops = _flops_of(fmodel, x) / 8
+    xb = torch.from_numpy(tiles[:32]).to(device)
+    t_fwd = _ev(lambda: model.infer_batch(fmodel, xb, device=str(device)), reps=3) / 32
+    line = {
+        "metric": "tiles/s (256x256x3 in, 164x164 out), NucleusInstanceSegmentor(hovernet_fast-pannuke) incl. HIP post-processing",
+        "value": round(n * world_size * args.steps / elapsed, 2), "unit": "tiles/s", "n_gpus": world_size, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "float32", "data": "synthetic",
+        "config": {"workload": (f"BASELINE configs[3]: NucleusInstanceSegmentor(hovernet_fast-pannuke, seeded random weights)"
+                                f".run({n} synthetic 256x256x3 tiles per GPU, patch_mode=True): HoVer-Net fast fp32 + "
+                                "Sobel-21/energy/markers/watershed + instance tables and contours on the device"),
+                   "tiles_per_gpu": n,
+                   "parallelism": f"dp{world_size} (tile-sharded; label maps and ragged instance tables all-gathered)"},
+        "roofline": {
+            "kernel": "hover _proc_np_hv (14 kernels; flood dominates)", "bound": "hbm",
+            "achieved": round(alg / t_proc / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg / t_proc / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": alg,
+            "launch_ms": round(t_proc * 1e3, 3),
+            "workload": f"{m} synthetic head maps of 164x164 with ~{n_inst:.0f} nuclei each, 20 B/px (SURVEY 8(d))",
+            "postproc_incl_tables_ms": round(t_post * 1e3, 3), "postproc_tiles_per_s": round(m / t_post, 1),
+            "backbone": {"bound": "mfma", "what": "HoVer-Net fast forward per 256^2 tile (MIOpen), batch 32",
+                         "gflop_per_tile": round(flops / 1e9, 1), "achieved": round(flops / t_fwd / 1e12, 2),
+                         "peak": MFMA_PEAK_F32, "unit": "TFLOP/s", "frac": round(flops / t_fwd / 1e12 / MFMA_PEAK_F32, 4),
+                         "ms_per_tile": round(t_fwd * 1e3, 3)}},
+    }
+    if not args.no_cpu_baseline and world_size == 1:
+        from tiatoolbox_amd.models.architecture import get_pretrained_model
+
+        def cpu_post():
+            for i in range(4):
+                inst_i = oh.proc_np_hv(npm[i], hv[i])
+                oh.get_instance_info(inst_i, np.around(tp[i]).astype("uint8")[..., 0])
+
+        t_post_cpu = _median_time(cpu_post) / 4
+        cpu_model, _ = get_pretrained_model("hovernet_fast-pannuke")
+        cpu_model.eval()
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        xc = torch.from_numpy(tiles[:4]).float().permute(0, 3, 1, 2)
+        with torch.inference_mode():
+            cpu_model(xc)
+            t_cnn = _median_time(lambda: cpu_model(xc)) / 4
+        line["cpu_baseline"] = {
+            "value": round(1.0 / (t_cnn + t_post_cpu), 4), "unit": "tiles/s", "cores": min(os.cpu_count() or 1, 64),
+            "kind": "port", "repeats": 3, "statistic": "median",
+            "sample": (f"4 tiles: torch-CPU fp32 HoVer-Net fast ({t_cnn * 1e3:.0f} ms/tile, threaded) + oracle "
+                       f"_proc_np_hv + get_instance_info on one core ({t_post_cpu * 1e3:.0f} ms/tile, ~60 nuclei)")}
+    return line
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def bench_vahadane(args) -> dict | None:
+    import numpy as np
+    import torch
+
+    from tiatoolbox_amd.tools import _stain_device as dev
+    from tiatoolbox_amd.tools.stainaugment import StainAugmentor
+    from tiatoolbox_amd.tools.stainnorm import get_normalizer
+    from tiatoolbox_amd.utils import synth
+
+    rank, world_size, device = _setup(args)
+    n = args.patches if args.patches != 4096 else 8192  # per GPU: 65 536 over 8
+    hw = 256
+    host = synth.g_he(256, hw, hw, seed=11 + rank)
+    x = torch.from_numpy(host).to(device).repeat((n + 255) // 256, 1, 1, 1)[:n].contiguous()
+    target = np.load(ROOT / "tests" / "golden" / "target_crop_256.npy")
+    norm = get_normalizer("vahadane")
+    norm.precision = args.precision
+    norm.fit(target)
+    aug = StainAugmentor(method="vahadane", sigma1=0.4, sigma2=0.2, augment_background=False,
+                         precision="f32" if args.precision == "f32" else "f64")
+    rng = np.random.default_rng(0)
+    ab = np.concatenate([rng.uniform(0.6, 1.4, (n, 2)), rng.uniform(-0.2, 0.2, (n, 2))], axis=1)
+    result = {}
+
+    def step():
+        normed = norm.transform(x)                 # per-patch dictionary learning + normalisation, uint8 out
+        aug.fit(normed, threshold=0.85)            # per-patch dictionary learning of the normalised patch + statistics
+        result["out"] = aug.augment(alpha_beta=ab)
+
+    step()
+    elapsed = _timed(step, args, world_size, device)
+    out = result["out"]
+    assert out.shape == x.shape and out.dtype == torch.uint8
+    if rank != 0:
+        return None
+    params = norm.extractor.stats_params(target_stain=norm.stain_matrix_target, target_maxc=norm.maxC_target)
+    t_stats = _ev(lambda: dev.stain_stats(x, params), reps=3)
+    px = n * hw * hw
+    line = {
+        "metric": "patches/s (256x256x3), VahadaneNormalizer.transform + StainAugmentor(vahadane).fit/augment",
+        "value": round(n * world_size * args.steps / elapsed, 2), "unit": "patches/s", "n_gpus": world_size,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"BASELINE configs[4]: VahadaneNormalizer (dictionary learning on the device, sklearn "
+                                f"DictionaryLearning restated) + StainAugmentor over {n} synthetic 256x256x3 patches per GPU "
+                                f"(65 536 over 8 GPUs); statistics and dictionary f64, per-pixel {args.precision}"),
+                   "patches_per_gpu": n, "parallelism": f"dp{world_size} (patch-sharded, no collective)"},
+        "roofline": {"kernel": "stain_stats_kernel<DL> (Vahadane)", "bound": "hbm",
+                     "achieved": round(px * 3 / t_stats / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(px * 3 / t_stats / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": px * 3,
+                     "launch_ms": round(t_stats * 1e3, 3),
+                     "note": "8 sweeps over the tissue pixels with a 16 B/px float64 dictionary read and written in each"},
+    }
+    if not args.no_cpu_baseline and world_size == 1:
+        from oracle import stain as ostain
+
+        ref = ostain.get_normalizer("vahadane")
+        ref.fit(target.copy())
+
+        vex = ostain.VahadaneExtractor(random_state=0)
+
+        def cpu_step():
+            for p in host[:2]:
+                nrm = ref.transform(p.copy())
+                sm = vex.get_stain_matrix(nrm.copy())  # StainAugmentor.fit: stain matrix of the image to augment
+                ostain.stain_augment(nrm, sm, np.array([1.1, 0.9]), np.array([0.05, -0.05]), threshold=0.85)
+
+        cpu_step()
+        t_cpu = _median_time(cpu_step) / 2
+        line["cpu_baseline"] = {"value": round(1.0 / t_cpu, 4), "unit": "patches/s", "cores": 1, "kind": "port",
+                                "repeats": 3, "statistic": "median",
+                                "sample": "2 patches on one core: oracle Vahadane transform (scikit-learn "
+                                          "DictionaryLearning, as the reference) + oracle StainAugmentor fit/augment"}
+    return line
