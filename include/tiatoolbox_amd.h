@@ -87,6 +87,9 @@ typedef struct tia_stain_params {
     double dl_tol;          /* DictionaryLearning.tol (1e-8)                                  */
     int32_t dl_max_iter;    /* DictionaryLearning.max_iter (3; stainextract.py:313)           */
     int32_t dl_seed;        /* stream of the unused-atom re-draw (the reference is unseeded)  */
+    int32_t select_mode;    /* order statistics: 0 = sample-placed windows (one float32 sweep + exact candidates) with the
+                               histogram path as fall-back; 1 = histogram path only (same results; parity audit)       */
+    int32_t reserved;
 } tia_stain_params;
 
 /*

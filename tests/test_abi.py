@@ -54,7 +54,7 @@ def test_struct_layouts_match_header(tmp_path):
     from tiatoolbox_amd import _lib
 
     assert ctypes.sizeof(_lib.StainTables) == 256 * 8 + 256 * 4 + 3 * 256 * 4
-    assert ctypes.sizeof(_lib.StainParams) == 8 * (5 + 6 + 6 + 2) + 4 * 4 + 8 * 2 + 4 * 2
+    assert ctypes.sizeof(_lib.StainParams) == 8 * (5 + 6 + 6 + 2) + 4 * 4 + 8 * 2 + 4 * 4
     gcc = shutil.which("gcc")
     if gcc is None:
         pytest.skip("no C compiler")

@@ -315,3 +315,43 @@ def test_vahadane_dictionary_learning_on_device_matches_sklearn(he_patches, targ
     white = np.full((1, 32, 32, 3), 255, np.uint8)
     with pytest.raises(ValueError, match="Empty tissue mask"):
         ex.get_stain_matrix(white)
+
+
+@pytest.mark.gpu
+def test_window_selection_equals_histogram_selection(he_patches, target_image):
+    """The order statistics (angular percentiles, 99th-percentile concentrations) come from sample-placed windows swept
+    in float32 with exact float64 candidates; the multi-level histogram selection is the fall-back.  Both are exact
+    selections of the same float64 keys, so every statistic must be BIT-identical between ``select_mode`` 0 and 1 --
+    on realistic patches, uniform noise (flat key distributions), tiny / odd-sized patches (sample too small, per-pixel
+    path), saturated patches (massive ties), a large image (no mask-bit cache) and every extractor mode."""
+    import torch
+
+    from tiatoolbox_amd import _lib
+    from tiatoolbox_amd.tools import _stain_device as dev
+    from tiatoolbox_amd.utils import synth
+
+    rng = np.random.default_rng(8)
+    flat = np.full((2, 64, 64, 3), 120, np.uint8)
+    flat[:, ::2, ::3] = 60
+    flat[1, :32] = rng.integers(0, 256, (32, 64, 3))
+    steps = (np.clip(synth.g_he(3, 128, 128, seed=31).astype(int) // 32 * 32 + 16, 0, 255)).astype(np.uint8)  # heavy ties
+    big = np.ascontiguousarray(np.tile(target_image, (3, 3, 1))[:700, :650])
+    batches = [he_patches, synth.g_he(48, 224, 224, seed=30), synth.g_uniform(8, 256, 256, seed=2), steps, flat,
+               synth.g_he(3, 37, 41, seed=32), synth.g_he(2, 16, 16, seed=33), big[None],
+               np.ascontiguousarray(synth.g_he(1, 1000, 1000, seed=34))]
+    target = np.array([[0.55, 0.76, 0.35], [0.1, 0.96, 0.27]])
+    modes = {"macenko": {"mode": _lib.MODE_MACENKO}, "fixed": {"mode": _lib.MODE_FIXED, "stain_fixed": target},
+             "vahadane": {"mode": _lib.MODE_VAHADANE}}
+    checked = 0
+    for batch in batches:
+        x = torch.from_numpy(batch).cuda()
+        for name, kw in modes.items():
+            if name == "vahadane" and batch.shape[1] > 300:
+                continue
+            a = dev.stain_stats(x, dev.make_params(select_mode=0, target_stain=target, target_maxc=np.array([[1.9, 1.0]]), **kw))
+            b = dev.stain_stats(x, dev.make_params(select_mode=1, target_stain=target, target_maxc=np.array([[1.9, 1.0]]), **kw))
+            a, b = a.cpu().numpy()[:, :_lib.ST_CYCLES], b.cpu().numpy()[:, :_lib.ST_CYCLES]
+            same = (a == b) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), (name, batch.shape, np.argwhere(~same)[:5], a[~same][:5], b[~same][:5])
+            checked += a.shape[0]
+    assert checked > 150

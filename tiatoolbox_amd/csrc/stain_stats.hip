@@ -24,12 +24,11 @@ constexpr int NB = 4096;         // histogram bins per selection target per leve
 constexpr int CAP = 1024;        // candidates sorted in LDS
 constexpr int MAXLEVEL = 7;      // 4096^6 > 2^64: deeper levels cannot split an f64 range further
 constexpr int BPT = NB / NT;     // bins per thread in the scan
-// Optional LDS tissue-mask bit cache (P2 writes, P3/P4 read).  Measured neutral on MI355X (the
-// three int table look-ups it saves are not the bottleneck), so it is off by default.
-#ifndef TIA_MASKBITS
-#define TIA_MASKBITS 0
-#endif
-constexpr int MASK_WORDS = TIA_MASKBITS ? 2048 : 1;  // up to 65536 pixels (256x256)
+// P2 records the tissue mask as bits in LDS (8 lanes x 4 pixels = one word); the window sweeps of the angular
+// selection test a bit instead of repeating three table look-ups per pixel.
+constexpr int MASK_WORDS = 2048;  // tissue-mask bits of patches up to 65536 pixels (256x256); larger ones recompute
+constexpr int SNB = 1024;         // bins of the sample histograms that place the selection windows
+constexpr int SAMPLE_TARGET = 4096;  // pixels sampled to place a window
 
 struct SelState {
     double lo[2][MAXLEVEL + 1];
@@ -71,6 +70,12 @@ struct Smem {
     unsigned long long ubc[8];
     int ibc[8];
     unsigned mbits[MASK_WORDS];  // tissue mask bits of the patch (when it fits)
+    unsigned sbins[2][SNB];      // sample histograms (window placement)
+    double wlo[2], whi[2];       // selection windows: candidates have wlo <= key <= whi
+    double smin[2], sscale[2];   // sample histogram binning
+    unsigned long long wbelow[2];
+    unsigned wn[2];
+    int wok;
     long long tm[16];   // per-phase cycle accumulators (thread 0)
     long long tlast;
 };
@@ -491,6 +496,233 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
     stamp(s, TM_SEL_SORT);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Window selection: the same exact order statistics as select2 from ONE sweep over the pixels.
+//   1. a ~4096-pixel sample (exact keys) places, per target, a key window [wlo, whi] that holds ranks k and k+1 with
+//      overwhelming probability (3.5 sigma of the sample-rank distribution, widened to sample-histogram bin edges);
+//   2. `sweep` classifies EVERY pixel against the windows with float32 arithmetic on the VALU only (no table
+//      look-ups): definitely below -> counted, definitely above -> ignored, anything within the float32 error bound of
+//      the window -> its pixel index is appended to an LDS list;
+//   3. the listed pixels (a few per cent) get their exact float64 key and are classified exactly: below / above /
+//      candidate;
+//   4. if ranks k, k+1 fall inside the candidate set (checked from the exact counts), sort it and pick; otherwise the
+//      caller falls back to select2.  The result never depends on the sample or on float32 rounding -- only the cost does.
+// sample(idx, x) -> validity bits and exact values of pixel idx;  sweep(list, cap, n_list) = the float32 sweep;
+// exact(idx, x) as sample (used for the listed pixels).
+template <class SAMPLE, class SWEEP>
+__device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, long hw, SAMPLE&& sample, SWEEP&& sweep, Smem& s,
+                                               const unsigned long long (&k)[2], const unsigned long long (&n)[2],
+                                               double (&vprev)[2], double (&vnext)[2]) {
+    const int tid = threadIdx.x;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    if (n[0] == 0 || n[1] == 0) return false;
+    const long stride = hw / SAMPLE_TARGET > 1 ? hw / SAMPLE_TARGET : 1;
+    const long ns_all = (hw + stride - 1) / stride;
+    // ---- sample: range and count -------------------------------------------------------------------------------------
+    if (tid < 2) {
+        s.st.above_key[tid] = 0ull;     // running max (as key)
+        s.st.member_key[tid] = ~0ull;   // running min (as key)
+        s.wn[tid] = 0u;
+        s.wbelow[tid] = 0ull;
+    }
+    for (int i = tid; i < 2 * SNB; i += NT) (&s.sbins[0][0])[i] = 0u;
+    __syncthreads();
+    {
+        unsigned long long mn[2] = {~0ull, ~0ull}, mx[2] = {0ull, 0ull};
+        unsigned cnt[2] = {0u, 0u};
+        for (long j = tid; j < ns_all; j += NT) {
+            const long idx = j * stride;
+            double x[2];
+            const unsigned vm = sample(idx, x);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (!((vm >> t) & 1u)) continue;
+                const unsigned long long key = f64_key(x[t]);
+                mn[t] = key < mn[t] ? key : mn[t];
+                mx[t] = key > mx[t] ? key : mx[t];
+                ++cnt[t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned long long a = wave_min_u64(mn[t]);
+            const unsigned long long b = ~wave_min_u64(~mx[t]);
+            unsigned c = cnt[t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+            if (lane_id() == 0) {
+                atomicMin(&s.st.member_key[t], a);
+                atomicMax(&s.st.above_key[t], b);
+                atomicAdd(&s.wn[t], c);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned ns[2] = {s.wn[0], s.wn[1]};
+    if (ns[0] < 64u || ns[1] < 64u) return false;  // too small to place a window: the histogram path handles it
+    if (tid < 2) {
+        const double lo = key_f64(s.st.member_key[tid]), hi = key_f64(s.st.above_key[tid]);
+        const double sc = (double)SNB / (hi - lo);
+        s.smin[tid] = lo;
+        s.sscale[tid] = (hi > lo && sc > 0.0 && sc < 1.0e300) ? sc : 0.0;
+    }
+    __syncthreads();
+    // ---- sample histogram ---------------------------------------------------------------------------------------------
+    for (long j = tid; j < ns_all; j += NT) {
+        const long idx = j * stride;
+        double x[2];
+        const unsigned vm = sample(idx, x);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!((vm >> t) & 1u)) continue;
+            const double d = (x[t] - s.smin[t]) * s.sscale[t];
+            const int b = !(d >= 0.0) ? 0 : (d >= (double)SNB ? SNB - 1 : (int)d);
+            atomicAdd(&s.sbins[t][b], 1u);
+        }
+    }
+    __syncthreads();
+    // ---- windows: wave t places the window of target t ------------------------------------------------------------------
+    if (wave_id() < 2) {
+        const int t = wave_id();
+        const int lane = lane_id();
+        constexpr int PER = SNB / 64;
+        unsigned local[PER], sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            local[i] = s.sbins[t][lane * PER + i];
+            sum += local[i];
+        }
+        const unsigned incl = wave_incl_scan_u32(sum);
+        const double q = ((double)k[t] + 0.5) / (double)n[t];
+        const double centre = q * (double)ns[t];
+        const double sigma = sqrt((double)ns[t] * q * (1.0 - q));
+        const double rlo = floor(centre - 3.5 * sigma - 2.0), rhi = ceil(centre + 3.5 * sigma + 2.0);
+        // bin holding sample rank r (0-based): first bin whose inclusive count exceeds r
+        auto bin_of_rank = [&](double r) -> int {
+            unsigned before = incl - sum;
+            int found = SNB;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const unsigned after = before + local[i];
+                if (found == SNB && (double)after > r && local[i] != 0u) found = lane * PER + i;
+                before = after;
+            }
+            // smallest candidate over the wave
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int other = __shfl_xor(found, o, 64);
+                found = other < found ? other : found;
+            }
+            return found;
+        };
+        const int blo = rlo < 0.0 ? -1 : bin_of_rank(rlo);
+        const int bhi = rhi >= (double)ns[t] ? SNB : bin_of_rank(rhi);
+        if (lane == 0) {
+            const double sc = s.sscale[t];
+            const bool flat = !(sc > 0.0);
+            // one extra bin of slack on either side; the outermost bins are open-ended
+            s.wlo[t] = (flat || blo <= 1) ? -inf : s.smin[t] + (double)(blo - 1) / sc;
+            s.whi[t] = (flat || bhi >= SNB - 2) ? inf : s.smin[t] + (double)(bhi + 2) / sc;
+        }
+    }
+    if (tid == 0) s.wok = 1;
+    if (tid < 2) s.wn[tid] = 0u;
+    __syncthreads();
+    stamp(s, TM_SEL_FIND);
+    // ---- the float32 sweep: counts "definitely below", lists everything within the error bound of a window -------------
+    unsigned* list = &s.bins[0][0];
+    constexpr unsigned LIST_CAP = 2u * NB;
+    unsigned* n_list = &s.st.ncand[0];
+    if (tid < 2) {
+        s.st.ncand[tid] = 0u;
+    }
+    __syncthreads();
+    sweep(list, LIST_CAP, n_list);
+    __syncthreads();
+    stamp(s, TM_SEL_HIST);
+    const unsigned nl = *n_list;
+    if (nl > LIST_CAP) return false;  // uniform
+    // ---- exact classification of the listed pixels ----------------------------------------------------------------------
+    {
+        unsigned bl[2] = {0u, 0u};
+        for (unsigned i = tid; i < nl; i += NT) {
+            const unsigned e = list[i];
+            const long idx = (long)(e & 0x3fffffffu);
+            double x[2];
+            const unsigned vm = sample(idx, x);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (!((e >> (30 + t)) & 1u) || !((vm >> t) & 1u)) continue;
+                if (x[t] < s.wlo[t]) {
+                    ++bl[t];
+                } else if (!(x[t] > s.whi[t])) {
+                    const unsigned pos = atomicAdd(&s.wn[t], 1u);
+                    if (pos < (unsigned)CAP) s.cand[t][pos] = x[t];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            unsigned c = bl[t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+            if (lane_id() == 0 && c) atomicAdd(&s.wbelow[t], (unsigned long long)c);
+        }
+    }
+    __syncthreads();
+    stamp(s, TM_SEL_COLLECT);
+    if (tid == 0) {
+        int ok = 1;
+        for (int t = 0; t < 2; ++t) {
+            const unsigned long long below = s.wbelow[t], nc = s.wn[t];
+            const bool has_next = k[t] + 1 < n[t];
+            if (nc > (unsigned long long)CAP || k[t] < below || k[t] + (has_next ? 1 : 0) >= below + nc) ok = 0;
+        }
+        s.wok = ok;
+    }
+    __syncthreads();
+    if (!s.wok) return false;
+    // ---- sort the candidates (both targets at once) and pick -------------------------------------------------------------
+    unsigned pmax = 2;
+    for (int t = 0; t < 2; ++t) {
+        unsigned pp = 2;
+        while (pp < s.wn[t]) pp <<= 1;
+        pmax = pp > pmax ? pp : pmax;
+    }
+    for (int t = 0; t < 2; ++t)
+        for (unsigned i = s.wn[t] + tid; i < pmax; i += NT) s.cand[t][i] = inf;
+    __syncthreads();
+    for (unsigned kk = 2; kk <= pmax; kk <<= 1) {
+        for (unsigned j = kk >> 1; j > 0; j >>= 1) {
+            for (unsigned i = tid; i < pmax; i += NT) {
+                const unsigned partner = i ^ j;
+                if (partner > i) {
+                    const bool asc = (i & kk) == 0;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const double a = s.cand[t][i], b = s.cand[t][partner];
+                        if ((a > b) == asc) {
+                            s.cand[t][i] = b;
+                            s.cand[t][partner] = a;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const unsigned long long r = k[t] - s.wbelow[t];
+        vprev[t] = s.cand[t][r];
+        vnext[t] = (k[t] + 1 < n[t]) ? s.cand[t][r + 1] : vprev[t];
+    }
+    __syncthreads();
+    stamp(s, TM_SEL_SORT);
+    return true;
+}
+
 // Monotone pseudo-angle: strictly increasing in atan2(y, x) over (-pi, pi], range [-2, 2].
 //   x >= 0:  r            (phi in [-pi/2, pi/2]),   r = y / (|x| + |y|)
 //   x <  0:  2 - r (y>=0) or -2 - r (y<0)
@@ -769,14 +1001,33 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         return ((t + (1 << 11)) >> 12) < y_thr;
     };
     // P2 records the mask as bits in LDS; later passes test a bit instead of three table look-ups
-    const bool use_bits = TIA_MASKBITS && hw <= (long)MASK_WORDS * 32;
-    if (use_bits && prm.mode == TIA_MODE_MACENKO) {
+    const bool use_bits = hw <= (long)MASK_WORDS * 32;
+    if (use_bits && !grp && !DL && prm.mode == TIA_MODE_MACENKO) {  // the per-pixel path ORs single bits
         for (int i = tid; i < MASK_WORDS; i += NT) s.mbits[i] = 0;
         __syncthreads();
     }
     auto is_tissue_cached = [&](long idx, uint32_t r, uint32_t g, uint32_t b) -> bool {
         if (use_bits) return (s.mbits[idx >> 5] >> (idx & 31)) & 1u;
         return is_tissue(r, g, b);
+    };
+    // float32 optical density on the VALU (no table): -ln(max(v,1)/255) clamped at 1e-6 like rgb2od; |error| < 5e-7
+    // (v_log_f32 is accurate to 1 ulp).  Only ever used to CLASSIFY pixels against selection windows, with that error
+    // bound (and a wide margin) built into the comparison; every value that enters a result is float64 from the table.
+    auto od32 = [](uint32_t v) -> float {
+        const float f = (float)(v ? v : 1u) * (1.0f / 255.0f);
+        const float o = -0.69314718f * __log2f(f);
+        return o > 1e-6f ? o : 1e-6f;
+    };
+    // wave-aggregated append of a pixel index (+ which targets need the exact key) to the LDS list of a window sweep
+    auto list_push = [&](bool need, unsigned entry, unsigned* list, unsigned cap, unsigned* n_list) {
+        const unsigned long long m = __ballot(need);
+        if (m == 0ull) return;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane_id() == leader) base = atomicAdd(n_list, (unsigned)__popcll(m));
+        base = __shfl(base, leader, 64);
+        const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane_id()) - 1ull));
+        if (need && pos < cap) list[pos] = entry;
     };
 
     double S[6];  // source stain matrix rows H,E
@@ -787,12 +1038,13 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         double acc[13];
 #pragma unroll
         for (int i = 0; i < 13; ++i) acc[i] = 0.0;
-        if (grp && !use_bits) {
-            for_each_group<NT>(p, hw, [&](long, uint32_t a, uint32_t b, uint32_t c, const WaveGroup&) {
+        if (grp) {
+            for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup&) {
                 uint32_t rr[4], gg[4], bb[4];
                 unpack_group(a, b, c, rr, gg, bb);
                 double x[4], y[4], z[4];
                 int lum[4];
+                unsigned nib = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {  // every look-up of the group is in flight before the first use
                     x[i] = OD(rr[i]);
@@ -806,6 +1058,7 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                     acc[11] = __builtin_fma(x[i], z[i], acc[11]);
                     acc[12] = __builtin_fma(y[i], z[i], acc[12]);
                     if (((lum[i] + (1 << 11)) >> 12) < y_thr) {
+                        nib |= 1u << i;
                         acc[0] += 1.0;
                         acc[1] += x[i];
                         acc[2] += y[i];
@@ -817,6 +1070,13 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                         acc[8] = __builtin_fma(y[i], z[i], acc[8]);
                         acc[9] = __builtin_fma(z[i], z[i], acc[9]);
                     }
+                }
+                if (use_bits) {  // 8 consecutive lanes hold 32 consecutive pixels: one mask word
+                    unsigned word = nib << (4 * (lane_id() & 7));
+                    word |= __shfl_xor(word, 1, 64);
+                    word |= __shfl_xor(word, 2, 64);
+                    word |= __shfl_xor(word, 4, 64);
+                    if ((lane_id() & 7) == 0) s.mbits[g >> 3] = word;
                 }
             });
         } else
@@ -895,6 +1155,56 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         np_index(n_tissue, prm.q_phi_hi, kp[1], kn[1], gm[1]);
         const double lo0[2] = {-2.0009765625, -2.0009765625}, hi0[2] = {2.0009765625, 2.0009765625};
         double vp[2], vn[2];
+        bool phi_done = false;
+        if (hw < (1L << 30) && prm.select_mode == 0) {
+            const float e1xf = (float)e1x, e1yf = (float)e1y, e1zf = (float)e1z;
+            const float e2xf = (float)e2x, e2yf = (float)e2y, e2zf = (float)e2z;
+            phi_done = window_select2(
+                p, hw,
+                [&](long idx, double (&x)[2]) -> unsigned {
+                    const uint32_t r = p[3 * idx], g = p[3 * idx + 1], b = p[3 * idx + 2];
+                    if (!is_tissue_cached(idx, r, g, b)) return 0u;
+                    const double ox = OD(r), oy = OD(g), oz = OD(b);
+                    const double p0 = dot3(ox, oy, oz, e1x, e1y, e1z);
+                    const double p1 = dot3(ox, oy, oz, e2x, e2y, e2z);
+                    x[0] = x[1] = pseudo_angle(p1, p0);
+                    return 3u;
+                },
+                [&](unsigned* list, unsigned cap, unsigned* n_list) {
+                    const float lo0 = (float)s.wlo[0], hi0 = (float)s.whi[0], lo1 = (float)s.wlo[1], hi1 = (float)s.whi[1];
+                    unsigned bl0 = 0, bl1 = 0;
+                    for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+                        const bool tissue = is_tissue_cached(idx, r, g, b);
+                        const float fr = od32(r), fg = od32(g), fb = od32(b);
+                        const float x = fmaf(fb, e1zf, fmaf(fg, e1yf, fr * e1xf));
+                        const float y = fmaf(fb, e2zf, fmaf(fg, e2yf, fr * e2xf));
+                        const float d = fabsf(x) + fabsf(y);
+                        const float rd = __builtin_amdgcn_rcpf(d);
+                        const float q = y * rd;
+                        const float key = x >= 0.0f ? q : (y >= 0.0f ? 2.0f - q : -2.0f - q);
+                        // |key32 - key| <= (|dy| + |key| |dd|) / d with |dx|, |dy| <= 2.6e-6 (od32 error x |e|_1 + rounding):
+                        // <= 1.1e-5 / d; four-fold margin, plus the float rounding of the bounds themselves
+                        const float tol = 4.0e-5f * rd + 2.0e-6f;
+                        const bool below0 = key + tol < lo0, above0 = key - tol > hi0;
+                        const bool below1 = key + tol < lo1, above1 = key - tol > hi1;
+                        bl0 += (tissue && below0) ? 1u : 0u;
+                        bl1 += (tissue && below1) ? 1u : 0u;
+                        const bool need0 = tissue && !below0 && !above0, need1 = tissue && !below1 && !above1;
+                        list_push(need0 || need1, (unsigned)idx | (need0 ? 1u << 30 : 0u) | (need1 ? 1u << 31 : 0u), list, cap, n_list);
+                    });
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        bl0 += __shfl_down(bl0, o, 64);
+                        bl1 += __shfl_down(bl1, o, 64);
+                    }
+                    if (lane_id() == 0) {
+                        if (bl0) atomicAdd(&s.wbelow[0], (unsigned long long)bl0);
+                        if (bl1) atomicAdd(&s.wbelow[1], (unsigned long long)bl1);
+                    }
+                },
+                s, kp, nn, vp, vn);
+        }
+        if (!phi_done)
         select2(p, hw,
                 [&](long idx, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
                     if (!is_tissue_cached(idx, r, g, b)) return 0u;
@@ -905,7 +1215,7 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                     return 3u;
                 },
                 [&](unsigned (&below)[2], unsigned (&above)[2]) -> bool {
-                    if (!grp || use_bits) return false;
+                    if (!grp) return false;
                     const double lo = s.st.lo[0][0], sc = s.st.scale[0][0];
                     unsigned bl = 0, ab = 0;
                     for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup& wg) {
@@ -1282,6 +1592,52 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
             hi0[t] = whi;
         }
         double vp[2], vn[2];
+        bool conc_done = false;
+        if (hw < (1L << 30) && prm.select_mode == 0) {
+            const float p00 = (float)P[0], p10 = (float)P[2], p20 = (float)P[4];
+            const float p01 = (float)P[1], p11 = (float)P[3], p21 = (float)P[5];
+            // |C32 - C| <= od32 error (5e-7) x |P column|_1 + three roundings of products <= 5.6 |P| (1e-6 |P column|_1):
+            // eight-fold margin, plus the float rounding of the bounds
+            const float tol0 = 1.2e-5f * (fabsf(p00) + fabsf(p10) + fabsf(p20)) + 1e-7f;
+            const float tol1 = 1.2e-5f * (fabsf(p01) + fabsf(p11) + fabsf(p21)) + 1e-7f;
+            conc_done = window_select2(
+                p, hw,
+                [&](long idx, double (&x)[2]) -> unsigned {
+                    const uint32_t r = p[3 * idx], g = p[3 * idx + 1], b = p[3 * idx + 2];
+                    const double ox = OD(r), oy = OD(g), oz = OD(b);
+                    x[0] = dot3(ox, oy, oz, P[0], P[2], P[4]);
+                    x[1] = dot3(ox, oy, oz, P[1], P[3], P[5]);
+                    return 3u;
+                },
+                [&](unsigned* list, unsigned cap, unsigned* n_list) {
+                    const float lo0 = (float)s.wlo[0], hi0 = (float)s.whi[0], lo1 = (float)s.wlo[1], hi1 = (float)s.whi[1];
+                    const float t0 = tol0 + 2.4e-7f * (fabsf(lo0) < 3e38f ? fabsf(lo0) : 0.0f) + 2.4e-7f * (fabsf(hi0) < 3e38f ? fabsf(hi0) : 0.0f);
+                    const float t1 = tol1 + 2.4e-7f * (fabsf(lo1) < 3e38f ? fabsf(lo1) : 0.0f) + 2.4e-7f * (fabsf(hi1) < 3e38f ? fabsf(hi1) : 0.0f);
+                    unsigned bl0 = 0, bl1 = 0;
+                    for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+                        const float fr = od32(r), fg = od32(g), fb = od32(b);
+                        const float c0 = fmaf(fb, p20, fmaf(fg, p10, fr * p00));
+                        const float c1 = fmaf(fb, p21, fmaf(fg, p11, fr * p01));
+                        const bool below0 = c0 + t0 < lo0, above0 = c0 - t0 > hi0;
+                        const bool below1 = c1 + t1 < lo1, above1 = c1 - t1 > hi1;
+                        bl0 += below0 ? 1u : 0u;
+                        bl1 += below1 ? 1u : 0u;
+                        const bool need0 = !below0 && !above0, need1 = !below1 && !above1;
+                        list_push(need0 || need1, (unsigned)idx | (need0 ? 1u << 30 : 0u) | (need1 ? 1u << 31 : 0u), list, cap, n_list);
+                    });
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        bl0 += __shfl_down(bl0, o, 64);
+                        bl1 += __shfl_down(bl1, o, 64);
+                    }
+                    if (lane_id() == 0) {
+                        if (bl0) atomicAdd(&s.wbelow[0], (unsigned long long)bl0);
+                        if (bl1) atomicAdd(&s.wbelow[1], (unsigned long long)bl1);
+                    }
+                },
+                s, kp, nn, vp, vn);
+        }
+        if (!conc_done)
         select2(p, hw,
                 [&](long, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
                     const double ox = OD(r), oy = OD(g), oz = OD(b);
