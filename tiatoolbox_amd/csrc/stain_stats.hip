@@ -64,9 +64,8 @@ struct Smem {
     double red[NW][16];
     unsigned wtot[NW];
     SelState st;
-    double bc[40];
+    double bc[48];
     double chm[6];      // per-channel sum(od), sum(od^2) over all pixels
-    double chx[3];      // cross sums sum(od_r od_g), sum(od_r od_b), sum(od_g od_b) over all pixels
     unsigned long long ubc[8];
     int ibc[8];
     unsigned mbits[MASK_WORDS];  // tissue mask bits of the patch (when it fits)
@@ -499,27 +498,29 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Window selection: the same exact order statistics as select2 from ONE sweep over the pixels.
-//   1. a ~4096-pixel sample (exact keys) places, per target, a key window [wlo, whi] that holds ranks k and k+1 with
-//      overwhelming probability (3.5 sigma of the sample-rank distribution, widened to sample-histogram bin edges);
-//   2. `sweep` classifies EVERY pixel against the windows with float32 arithmetic on the VALU only (no table
-//      look-ups): definitely below -> counted, definitely above -> ignored, anything within the float32 error bound of
-//      the window -> its pixel index is appended to an LDS list;
-//   3. the listed pixels (a few per cent) get their exact float64 key and are classified exactly: below / above /
-//      candidate;
-//   4. if ranks k, k+1 fall inside the candidate set (checked from the exact counts), sort it and pick; otherwise the
-//      caller falls back to select2.  The result never depends on the sample or on float32 rounding -- only the cost does.
-// sample(idx, x) -> validity bits and exact values of pixel idx;  sweep(list, cap, n_list) = the float32 sweep;
-// exact(idx, x) as sample (used for the listed pixels).
-template <class SAMPLE, class SWEEP>
-__device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, long hw, SAMPLE&& sample, SWEEP&& sweep, Smem& s,
-                                               const unsigned long long (&k)[2], const unsigned long long (&n)[2],
-                                               double (&vprev)[2], double (&vnext)[2]) {
+//   1. a <= 4096-pixel sample, evaluated in float32 on the VALU, places per target a key window [wlo, whi] that holds
+//      ranks k and k+1 with overwhelming probability (3.5 sigma of the sample-rank distribution, widened to the edges of
+//      a 1024-bin sample histogram plus one bin of slack);
+//   2. `sweep` classifies EVERY pixel against the windows with float32 arithmetic on the VALU only (no table look-ups):
+//      definitely below -> counted, definitely above -> ignored, anything within the float32 error bound of a window
+//      edge or inside the window -> its pixel index goes to an LDS list;
+//   3. the listed pixels (a few per cent) get their exact float64 key (`exact`) and are classified exactly: below /
+//      above / candidate;
+//   4. ranks k, k+1 must fall inside the candidate set (checked from the exact counts); a 1024-bin histogram of the
+//      candidates then isolates the one or two bins holding them and a single wave orders those few values.
+// Whenever a precondition fails (sample too small, list or candidate overflow, ranks outside the window, a crowded bin)
+// the function returns false and the caller runs select2.  Results never depend on the sample or on float32 rounding --
+// only the cost does (tests: bitwise audit of both paths).
+template <class SAMPLE32, class EXACT, class SWEEP>
+__device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, long hw, SAMPLE32&& sample32, EXACT&& exact,
+                                               SWEEP&& sweep, Smem& s, const unsigned long long (&k)[2],
+                                               const unsigned long long (&n)[2], double (&vprev)[2], double (&vnext)[2]) {
     const int tid = threadIdx.x;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    const float finf = __int_as_float(0x7f800000);
     if (n[0] == 0 || n[1] == 0) return false;
-    const long stride = hw / SAMPLE_TARGET > 1 ? hw / SAMPLE_TARGET : 1;
-    const long ns_all = (hw + stride - 1) / stride;
-    // ---- sample: range and count -------------------------------------------------------------------------------------
+    constexpr int SPT = SAMPLE_TARGET / NT;  // samples per thread
+    const long stride = (hw + SAMPLE_TARGET - 1) / SAMPLE_TARGET;
     if (tid < 2) {
         s.st.above_key[tid] = 0ull;     // running max (as key)
         s.st.member_key[tid] = ~0ull;   // running min (as key)
@@ -527,66 +528,108 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
         s.wbelow[tid] = 0ull;
     }
     for (int i = tid; i < 2 * SNB; i += NT) (&s.sbins[0][0])[i] = 0u;
-    __syncthreads();
+    // ---- sample (float32, registers): all byte loads in flight together -------------------------------------------------
+    float sv[2][SPT];
+    unsigned svalid[SPT];
     {
-        unsigned long long mn[2] = {~0ull, ~0ull}, mx[2] = {0ull, 0ull};
-        unsigned cnt[2] = {0u, 0u};
-        for (long j = tid; j < ns_all; j += NT) {
-            const long idx = j * stride;
-            double x[2];
-            const unsigned vm = sample(idx, x);
+        uint32_t rgb[SPT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (!((vm >> t) & 1u)) continue;
-                const unsigned long long key = f64_key(x[t]);
-                mn[t] = key < mn[t] ? key : mn[t];
-                mx[t] = key > mx[t] ? key : mx[t];
-                ++cnt[t];
-            }
+        for (int j = 0; j < SPT; ++j) {
+            const long idx = ((long)j * NT + tid) * stride;
+            rgb[j] = idx < hw ? ((uint32_t)p[3 * idx] | ((uint32_t)p[3 * idx + 1] << 8) | ((uint32_t)p[3 * idx + 2] << 16)) : 0u;
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const unsigned long long a = wave_min_u64(mn[t]);
-            const unsigned long long b = ~wave_min_u64(~mx[t]);
-            unsigned c = cnt[t];
+        for (int j = 0; j < SPT; ++j) {
+            const long idx = ((long)j * NT + tid) * stride;
+            float v[2] = {0.0f, 0.0f};
+            svalid[j] = idx < hw ? sample32(idx, rgb[j] & 255u, (rgb[j] >> 8) & 255u, (rgb[j] >> 16) & 255u, v) : 0u;
+            sv[0][j] = v[0];
+            sv[1][j] = v[1];
+        }
+    }
+    {
+        float mn[2] = {finf, finf}, mx[2] = {-finf, -finf};
+        unsigned cnt[2] = {0u, 0u};
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-            if (lane_id() == 0) {
-                atomicMin(&s.st.member_key[t], a);
-                atomicMax(&s.st.above_key[t], b);
-                atomicAdd(&s.wn[t], c);
+        for (int j = 0; j < SPT; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if ((svalid[j] >> t) & 1u) {
+                    mn[t] = fminf(mn[t], sv[t][j]);
+                    mx[t] = fmaxf(mx[t], sv[t][j]);
+                    ++cnt[t];
+                }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mn[t] = fminf(mn[t], __shfl_down(mn[t], o, 64));
+                mx[t] = fmaxf(mx[t], __shfl_down(mx[t], o, 64));
+                cnt[t] += __shfl_down(cnt[t], o, 64);
+            }
+        }
+        __syncthreads();  // zeroing above done
+        if (lane_id() == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                atomicMin(&s.st.member_key[t], f64_key((double)mn[t]));
+                atomicMax(&s.st.above_key[t], f64_key((double)mx[t]));
+                atomicAdd(&s.wn[t], cnt[t]);
             }
         }
     }
     __syncthreads();
     const unsigned ns[2] = {s.wn[0], s.wn[1]};
     if (ns[0] < 64u || ns[1] < 64u) return false;  // too small to place a window: the histogram path handles it
-    if (tid < 2) {
-        const double lo = key_f64(s.st.member_key[tid]), hi = key_f64(s.st.above_key[tid]);
-        const double sc = (double)SNB / (hi - lo);
-        s.smin[tid] = lo;
-        s.sscale[tid] = (hi > lo && sc > 0.0 && sc < 1.0e300) ? sc : 0.0;
-    }
-    __syncthreads();
-    // ---- sample histogram ---------------------------------------------------------------------------------------------
-    for (long j = tid; j < ns_all; j += NT) {
-        const long idx = j * stride;
-        double x[2];
-        const unsigned vm = sample(idx, x);
+    float smin[2], sscale[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (!((vm >> t) & 1u)) continue;
-            const double d = (x[t] - s.smin[t]) * s.sscale[t];
-            const int b = !(d >= 0.0) ? 0 : (d >= (double)SNB ? SNB - 1 : (int)d);
-            atomicAdd(&s.sbins[t][b], 1u);
-        }
+    for (int t = 0; t < 2; ++t) {
+        const double lo = key_f64(s.st.member_key[t]), hi = key_f64(s.st.above_key[t]);
+        const double sc = (double)SNB / (hi - lo);
+        smin[t] = (float)lo;
+        sscale[t] = (hi > lo && sc > 0.0 && sc < 1.0e30) ? (float)sc : 0.0f;
     }
+#pragma unroll
+    for (int j = 0; j < SPT; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if ((svalid[j] >> t) & 1u) {
+                const float d = (sv[t][j] - smin[t]) * sscale[t];
+                const int b = !(d >= 0.0f) ? 0 : (d >= (float)SNB ? SNB - 1 : (int)d);
+                atomicAdd(&s.sbins[t][b], 1u);
+            }
     __syncthreads();
     // ---- windows: wave t places the window of target t ------------------------------------------------------------------
+    constexpr int PER = SNB / 64;
+    // bin holding rank r (0-based) of a 1024-bin histogram held 16 bins per lane: first bin whose inclusive count exceeds r
+    auto bin_of_rank = [&](const unsigned (&local)[PER], unsigned incl, unsigned sum, double r, unsigned& before_bin) -> int {
+        unsigned before = incl - sum;
+        int found = SNB;
+        unsigned fb = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const unsigned after = before + local[i];
+            if (found == SNB && (double)after > r && local[i] != 0u) {
+                found = lane_id() * PER + i;
+                fb = before;
+            }
+            before = after;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int other = __shfl_xor(found, o, 64);
+            const unsigned ob = __shfl_xor(fb, o, 64);
+            if (other < found) {
+                found = other;
+                fb = ob;
+            }
+        }
+        before_bin = fb;
+        return found;
+    };
     if (wave_id() < 2) {
         const int t = wave_id();
         const int lane = lane_id();
-        constexpr int PER = SNB / 64;
         unsigned local[PER], sum = 0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -598,46 +641,31 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
         const double centre = q * (double)ns[t];
         const double sigma = sqrt((double)ns[t] * q * (1.0 - q));
         const double rlo = floor(centre - 3.5 * sigma - 2.0), rhi = ceil(centre + 3.5 * sigma + 2.0);
-        // bin holding sample rank r (0-based): first bin whose inclusive count exceeds r
-        auto bin_of_rank = [&](double r) -> int {
-            unsigned before = incl - sum;
-            int found = SNB;
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const unsigned after = before + local[i];
-                if (found == SNB && (double)after > r && local[i] != 0u) found = lane * PER + i;
-                before = after;
-            }
-            // smallest candidate over the wave
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int other = __shfl_xor(found, o, 64);
-                found = other < found ? other : found;
-            }
-            return found;
-        };
-        const int blo = rlo < 0.0 ? -1 : bin_of_rank(rlo);
-        const int bhi = rhi >= (double)ns[t] ? SNB : bin_of_rank(rhi);
+        unsigned dummy;
+        const int blo = rlo < 0.0 ? -1 : bin_of_rank(local, incl, sum, rlo, dummy);
+        const int bhi = rhi >= (double)ns[t] ? SNB : bin_of_rank(local, incl, sum, rhi, dummy);
         if (lane == 0) {
-            const double sc = s.sscale[t];
+            const double sc = (double)sscale[t];
             const bool flat = !(sc > 0.0);
             // one extra bin of slack on either side; the outermost bins are open-ended
-            s.wlo[t] = (flat || blo <= 1) ? -inf : s.smin[t] + (double)(blo - 1) / sc;
-            s.whi[t] = (flat || bhi >= SNB - 2) ? inf : s.smin[t] + (double)(bhi + 2) / sc;
+            s.wlo[t] = (flat || blo <= 1) ? -inf : (double)smin[t] + (double)(blo - 1) / sc;
+            s.whi[t] = (flat || bhi >= SNB - 2) ? inf : (double)smin[t] + (double)(bhi + 2) / sc;
         }
     }
-    if (tid == 0) s.wok = 1;
-    if (tid < 2) s.wn[tid] = 0u;
+    __syncthreads();
+    if (tid < 2) {
+        s.wn[tid] = 0u;
+        s.st.ncand[tid] = 0u;
+        s.st.above_key[tid] = 0ull;
+        s.st.member_key[tid] = ~0ull;
+    }
+    for (int i = tid; i < 2 * SNB; i += NT) (&s.sbins[0][0])[i] = 0u;
     __syncthreads();
     stamp(s, TM_SEL_FIND);
     // ---- the float32 sweep: counts "definitely below", lists everything within the error bound of a window -------------
     unsigned* list = &s.bins[0][0];
     constexpr unsigned LIST_CAP = 2u * NB;
     unsigned* n_list = &s.st.ncand[0];
-    if (tid < 2) {
-        s.st.ncand[tid] = 0u;
-    }
-    __syncthreads();
     sweep(list, LIST_CAP, n_list);
     __syncthreads();
     stamp(s, TM_SEL_HIST);
@@ -646,11 +674,12 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
     // ---- exact classification of the listed pixels ----------------------------------------------------------------------
     {
         unsigned bl[2] = {0u, 0u};
+        unsigned long long mn[2] = {~0ull, ~0ull}, mx[2] = {0ull, 0ull};
         for (unsigned i = tid; i < nl; i += NT) {
             const unsigned e = list[i];
             const long idx = (long)(e & 0x3fffffffu);
             double x[2];
-            const unsigned vm = sample(idx, x);
+            const unsigned vm = exact(idx, x);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 if (!((e >> (30 + t)) & 1u) || !((vm >> t) & 1u)) continue;
@@ -659,6 +688,9 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
                 } else if (!(x[t] > s.whi[t])) {
                     const unsigned pos = atomicAdd(&s.wn[t], 1u);
                     if (pos < (unsigned)CAP) s.cand[t][pos] = x[t];
+                    const unsigned long long key = f64_key(x[t]);
+                    mn[t] = key < mn[t] ? key : mn[t];
+                    mx[t] = key > mx[t] ? key : mx[t];
                 }
             }
         }
@@ -667,7 +699,13 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
             unsigned c = bl[t];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-            if (lane_id() == 0 && c) atomicAdd(&s.wbelow[t], (unsigned long long)c);
+            const unsigned long long a = wave_min_u64(mn[t]);
+            const unsigned long long b = ~wave_min_u64(~mx[t]);
+            if (lane_id() == 0) {
+                if (c) atomicAdd(&s.wbelow[t], (unsigned long long)c);
+                atomicMin(&s.st.member_key[t], a);
+                atomicMax(&s.st.above_key[t], b);
+            }
         }
     }
     __syncthreads();
@@ -683,40 +721,121 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
     }
     __syncthreads();
     if (!s.wok) return false;
-    // ---- sort the candidates (both targets at once) and pick -------------------------------------------------------------
-    unsigned pmax = 2;
-    for (int t = 0; t < 2; ++t) {
-        unsigned pp = 2;
-        while (pp < s.wn[t]) pp <<= 1;
-        pmax = pp > pmax ? pp : pmax;
-    }
-    for (int t = 0; t < 2; ++t)
-        for (unsigned i = s.wn[t] + tid; i < pmax; i += NT) s.cand[t][i] = inf;
-    __syncthreads();
-    for (unsigned kk = 2; kk <= pmax; kk <<= 1) {
-        for (unsigned j = kk >> 1; j > 0; j >>= 1) {
-            for (unsigned i = tid; i < pmax; i += NT) {
-                const unsigned partner = i ^ j;
-                if (partner > i) {
-                    const bool asc = (i & kk) == 0;
+    // ---- refine inside the candidate set: histogram -> the bin(s) of local ranks r, r+1 -> one wave orders them ----------
+    const unsigned nc[2] = {s.wn[0], s.wn[1]};
+    double clo[2], csc[2];
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const double a = s.cand[t][i], b = s.cand[t][partner];
-                        if ((a > b) == asc) {
-                            s.cand[t][i] = b;
-                            s.cand[t][partner] = a;
+    for (int t = 0; t < 2; ++t) {
+        const double lo = key_f64(s.st.member_key[t]), hi = key_f64(s.st.above_key[t]);
+        const double sc = (double)SNB / (hi - lo);
+        clo[t] = lo;
+        csc[t] = (hi > lo && sc > 0.0 && sc < 1.0e300) ? sc : 0.0;
+    }
+    auto cbin = [&](int t, double x) -> int {
+        const double d = (x - clo[t]) * csc[t];
+        return !(d >= 0.0) ? 0 : (d >= (double)SNB ? SNB - 1 : (int)d);
+    };
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        for (unsigned i = tid; i < nc[t]; i += NT) atomicAdd(&s.sbins[t][cbin(t, s.cand[t][i])], 1u);
+    if (tid < 2) s.st.ncand[tid] = 0u;
+    __syncthreads();
+    if (wave_id() < 2) {
+        const int t = wave_id();
+        const int lane = lane_id();
+        unsigned local[PER], sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            local[i] = s.sbins[t][lane * PER + i];
+            sum += local[i];
+        }
+        const unsigned incl = wave_incl_scan_u32(sum);
+        const unsigned long long r = k[t] - s.wbelow[t];
+        const bool has_next = k[t] + 1 < n[t];
+        unsigned before_a = 0, before_b = 0;
+        const int ba = bin_of_rank(local, incl, sum, (double)r, before_a);
+        const int bb = has_next ? bin_of_rank(local, incl, sum, (double)(r + 1), before_b) : ba;
+        if (lane == 0) {
+            s.st.sel[t][0] = ba;
+            s.st.sel_hi[t] = bb;
+            s.st.r[t] = r - before_a;  // rank inside the picked set (bins ba and, if different, bb; nothing in between)
+        }
+    }
+    __syncthreads();
+    // gather the members of the picked bins (a few values) behind the candidates' own storage: s.red / s.bc are too small,
+    // the sample histogram of the OTHER kind is free: reuse s.bins (the list is consumed)
+    double* small = reinterpret_cast<double*>(&s.bins[0][0]);  // [2][64]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ba = s.st.sel[t][0], bb = s.st.sel_hi[t];
+        for (unsigned i = tid; i < nc[t]; i += NT) {
+            const double x = s.cand[t][i];
+            const int b = cbin(t, x);
+            if (b == ba || b == bb) {
+                const unsigned pos = atomicAdd(&s.st.ncand[t], 1u);
+                if (pos < 64u) small[t * 64 + pos] = x;
+            }
+        }
+    }
+    __syncthreads();
+    if (s.st.ncand[0] > 64u || s.st.ncand[1] > 64u) {  // a crowded bin (massive ties): order the whole candidate set instead
+        unsigned pmax = 2;
+        for (int t = 0; t < 2; ++t) {
+            unsigned pp = 2;
+            while (pp < nc[t]) pp <<= 1;
+            pmax = pp > pmax ? pp : pmax;
+        }
+        for (int t = 0; t < 2; ++t)
+            for (unsigned i = nc[t] + tid; i < pmax; i += NT) s.cand[t][i] = inf;
+        __syncthreads();
+        for (unsigned kk = 2; kk <= pmax; kk <<= 1) {
+            for (unsigned j = kk >> 1; j > 0; j >>= 1) {
+                for (unsigned i = tid; i < pmax; i += NT) {
+                    const unsigned partner = i ^ j;
+                    if (partner > i) {
+                        const bool asc = (i & kk) == 0;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const double a = s.cand[t][i], b = s.cand[t][partner];
+                            if ((a > b) == asc) {
+                                s.cand[t][i] = b;
+                                s.cand[t][partner] = a;
+                            }
                         }
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned long long r = k[t] - s.wbelow[t];
+            vprev[t] = s.cand[t][r];
+            vnext[t] = (k[t] + 1 < n[t]) ? s.cand[t][r + 1] : vprev[t];
+        }
+        __syncthreads();
+        stamp(s, TM_SEL_SORT);
+        return true;
     }
+    if (wave_id() < 2) {  // rank by counting inside one wave: value of lane i, number of values ordered before it
+        const int t = wave_id();
+        const int lane = lane_id();
+        const unsigned m = s.st.ncand[t];
+        const double x = (unsigned)lane < m ? small[t * 64 + lane] : inf;
+        unsigned rank = 0;
+        for (unsigned j = 0; j < m; ++j) {
+            const double y = small[t * 64 + j];
+            rank += (y < x || (y == x && j < (unsigned)lane)) ? 1u : 0u;
+        }
+        const unsigned long long r = s.st.r[t];
+        if ((unsigned)lane < m && rank == (unsigned)r) s.bc[40 + 2 * t] = x;
+        if ((unsigned)lane < m && rank == (unsigned)r + 1u) s.bc[41 + 2 * t] = x;
+    }
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const unsigned long long r = k[t] - s.wbelow[t];
-        vprev[t] = s.cand[t][r];
-        vnext[t] = (k[t] + 1 < n[t]) ? s.cand[t][r + 1] : vprev[t];
+        vprev[t] = s.bc[40 + 2 * t];
+        vnext[t] = (k[t] + 1 < n[t]) ? s.bc[41 + 2 * t] : vprev[t];
     }
     __syncthreads();
     stamp(s, TM_SEL_SORT);
@@ -1035,9 +1154,9 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
 
     if (!DL && prm.mode == TIA_MODE_MACENKO) {
         // ---- P2: tissue mask + OD moments -----------------------------------------------------
-        double acc[13];
+        double acc[10];
 #pragma unroll
-        for (int i = 0; i < 13; ++i) acc[i] = 0.0;
+        for (int i = 0; i < 10; ++i) acc[i] = 0.0;
         if (grp) {
             for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup&) {
                 uint32_t rr[4], gg[4], bb[4];
@@ -1054,9 +1173,6 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc[10] = __builtin_fma(x[i], y[i], acc[10]);
-                    acc[11] = __builtin_fma(x[i], z[i], acc[11]);
-                    acc[12] = __builtin_fma(y[i], z[i], acc[12]);
                     if (((lum[i] + (1 << 11)) >> 12) < y_thr) {
                         nib |= 1u << i;
                         acc[0] += 1.0;
@@ -1082,9 +1198,6 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         } else
         for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
             const double x = OD(r), y = OD(g), z = OD(b);
-            acc[10] = __builtin_fma(x, y, acc[10]);  // all-pixel cross moments: exact variance of the concentrations
-            acc[11] = __builtin_fma(x, z, acc[11]);
-            acc[12] = __builtin_fma(y, z, acc[12]);
             if (is_tissue(r, g, b)) {
                 if (use_bits) atomicOr(&s.mbits[idx >> 5], 1u << (idx & 31));
                 acc[0] += 1.0;
@@ -1100,7 +1213,6 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
             }
         });
         block_sum(acc, s);
-        if (tid < 3) s.chx[tid] = acc[10 + tid];
         stamp(s, TM_P2);
         const double nt = acc[0];
         const unsigned long long n_tissue = (unsigned long long)nt;
@@ -1157,10 +1269,32 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         double vp[2], vn[2];
         bool phi_done = false;
         if (hw < (1L << 30) && prm.select_mode == 0) {
-            const float e1xf = (float)e1x, e1yf = (float)e1y, e1zf = (float)e1z;
-            const float e2xf = (float)e2x, e2yf = (float)e2y, e2zf = (float)e2z;
+            // float32 classification: with L_c = log2(max(v_c, 1)) the projections are x = Kx - sum_c ex_c L_c (ex = ln2 e1,
+            // Kx = log2(255) sum_c ex_c), likewise y; for window edges kb in [-1, 1] and x > 0, key < kb <=> y - kb (|x|+|y|) < 0.
+            // Error budget of s = y - kb d: |dL| <= 1 ulp(8) = 9.6e-7, constants rounded to float32 (6e-8 x 8), three FMA
+            // roundings (6e-8 x 10 each), the 1e-6 clamp of od(255): |dx|, |dy| <= 7e-6, |ds| <= 3 x 7e-6; four-fold margin.
+            const float ln2 = 0.6931471805599453f, l255 = 7.994353436858858f;
+            const float ex0 = ln2 * (float)e1x, ex1 = ln2 * (float)e1y, ex2 = ln2 * (float)e1z;
+            const float ey0 = ln2 * (float)e2x, ey1 = ln2 * (float)e2y, ey2 = ln2 * (float)e2z;
+            const float kx = l255 * (ex0 + ex1 + ex2), ky = l255 * (ey0 + ey1 + ey2);
+            const float tol = 8.0e-5f;
+            auto proj = [&](uint32_t r, uint32_t g, uint32_t b, float& x, float& y) {
+                const float lr = __log2f(fmaxf((float)r, 1.0f)), lg = __log2f(fmaxf((float)g, 1.0f)),
+                            lb = __log2f(fmaxf((float)b, 1.0f));
+                x = fmaf(-ex2, lb, fmaf(-ex1, lg, fmaf(-ex0, lr, kx)));
+                y = fmaf(-ey2, lb, fmaf(-ey1, lg, fmaf(-ey0, lr, ky)));
+            };
             phi_done = window_select2(
                 p, hw,
+                [&](long idx, uint32_t r, uint32_t g, uint32_t b, float (&v)[2]) -> unsigned {
+                    if (!is_tissue_cached(idx, r, g, b)) return 0u;
+                    float x, y;
+                    proj(r, g, b, x, y);
+                    const float d = fabsf(x) + fabsf(y);
+                    const float q = d > 0.0f ? y / d : 0.0f;
+                    v[0] = v[1] = x >= 0.0f ? q : (y >= 0.0f ? 2.0f - q : -2.0f - q);
+                    return 3u;
+                },
                 [&](long idx, double (&x)[2]) -> unsigned {
                     const uint32_t r = p[3 * idx], g = p[3 * idx + 1], b = p[3 * idx + 2];
                     if (!is_tissue_cached(idx, r, g, b)) return 0u;
@@ -1171,32 +1305,27 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                     return 3u;
                 },
                 [&](unsigned* list, unsigned cap, unsigned* n_list) {
-                    const float lo0 = (float)s.wlo[0], hi0 = (float)s.whi[0], lo1 = (float)s.wlo[1], hi1 = (float)s.whi[1];
-                    unsigned bl0 = 0, bl1 = 0;
+                    // window edges outside [-1, 1] (keys of the x < 0 half plane) are not handled by the cross-product
+                    // test: make every tissue pixel a candidate of that target, the overflow check then falls back
+                    const double w[4] = {s.wlo[0], s.whi[0], s.wlo[1], s.whi[1]};
+                    bool edges_ok = true;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) edges_ok = edges_ok && (!(fabs(w[i]) < 1e300) || fabs(w[i]) <= 1.0);
+                    const float lo0 = (float)w[0], hi0 = (float)w[1], lo1 = (float)w[2], hi1 = (float)w[3];
+                    unsigned bl0 = 0, bl1 = 0;  // wave-uniform: scalar population counts of the comparison masks
                     for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
                         const bool tissue = is_tissue_cached(idx, r, g, b);
-                        const float fr = od32(r), fg = od32(g), fb = od32(b);
-                        const float x = fmaf(fb, e1zf, fmaf(fg, e1yf, fr * e1xf));
-                        const float y = fmaf(fb, e2zf, fmaf(fg, e2yf, fr * e2xf));
+                        float x, y;
+                        proj(r, g, b, x, y);
                         const float d = fabsf(x) + fabsf(y);
-                        const float rd = __builtin_amdgcn_rcpf(d);
-                        const float q = y * rd;
-                        const float key = x >= 0.0f ? q : (y >= 0.0f ? 2.0f - q : -2.0f - q);
-                        // |key32 - key| <= (|dy| + |key| |dd|) / d with |dx|, |dy| <= 2.6e-6 (od32 error x |e|_1 + rounding):
-                        // <= 1.1e-5 / d; four-fold margin, plus the float rounding of the bounds themselves
-                        const float tol = 4.0e-5f * rd + 2.0e-6f;
-                        const bool below0 = key + tol < lo0, above0 = key - tol > hi0;
-                        const bool below1 = key + tol < lo1, above1 = key - tol > hi1;
-                        bl0 += (tissue && below0) ? 1u : 0u;
-                        bl1 += (tissue && below1) ? 1u : 0u;
+                        const bool plain = edges_ok && x > tol;  // otherwise: exact classification
+                        const bool below0 = plain && fmaf(-lo0, d, y) < -tol, above0 = plain && fmaf(-hi0, d, y) > tol;
+                        const bool below1 = plain && fmaf(-lo1, d, y) < -tol, above1 = plain && fmaf(-hi1, d, y) > tol;
+                        bl0 += (unsigned)__popcll(__ballot(tissue && below0));
+                        bl1 += (unsigned)__popcll(__ballot(tissue && below1));
                         const bool need0 = tissue && !below0 && !above0, need1 = tissue && !below1 && !above1;
                         list_push(need0 || need1, (unsigned)idx | (need0 ? 1u << 30 : 0u) | (need1 ? 1u << 31 : 0u), list, cap, n_list);
                     });
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        bl0 += __shfl_down(bl0, o, 64);
-                        bl1 += __shfl_down(bl1, o, 64);
-                    }
                     if (lane_id() == 0) {
                         if (bl0) atomicAdd(&s.wbelow[0], (unsigned long long)bl0);
                         if (bl1) atomicAdd(&s.wbelow[1], (unsigned long long)bl1);
@@ -1284,15 +1413,12 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         double2* __restrict__ dict = dictws + (size_t)blockIdx.x * (size_t)hw;
         const double alpha = prm.dl_alpha;
         // S0: uncentred second moments of the tissue OD (X X^T), tissue sums, all-pixel cross moments
-        double acc[13];
+        double acc[10];
 #pragma unroll
-        for (int i = 0; i < 13; ++i) acc[i] = 0.0;
+        for (int i = 0; i < 10; ++i) acc[i] = 0.0;
         for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
-            const double x = OD(r), y = OD(g), z = OD(b);
-            acc[10] = __builtin_fma(x, y, acc[10]);
-            acc[11] = __builtin_fma(x, z, acc[11]);
-            acc[12] = __builtin_fma(y, z, acc[12]);
             if (is_tissue(r, g, b)) {
+                const double x = OD(r), y = OD(g), z = OD(b);
                 acc[0] += 1.0;
                 acc[1] += x;
                 acc[2] += y;
@@ -1306,7 +1432,6 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
             }
         });
         block_sum(acc, s);
-        if (tid < 3) s.chx[tid] = acc[10 + tid];
         if (tid < 10) s.bc[24 + tid] = acc[tid];  // tissue count, sums and second moments (unused-atom re-draw)
         stamp(s, TM_P2);
         const double nt = acc[0];
@@ -1511,16 +1636,6 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
     } else {
 #pragma unroll
         for (int i = 0; i < 6; ++i) S[i] = prm.mode == TIA_MODE_GIVEN ? s_given[i] : prm.stain_fixed[i];
-        double acc[3] = {0.0, 0.0, 0.0};
-        for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
-            const double x = OD(r), y = OD(g), z = OD(b);
-            acc[0] = __builtin_fma(x, y, acc[0]);
-            acc[1] = __builtin_fma(x, z, acc[1]);
-            acc[2] = __builtin_fma(y, z, acc[2]);
-        });
-        block_sum(acc, s);
-        if (tid < 3) s.chx[tid] = acc[tid];
-        __syncthreads();
         stamp(s, TM_P2);
     }
 
@@ -1566,16 +1681,12 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                 mj[j] = s.chm[j] * inv_n;
                 mu += c * mj[j];
             }
-            // exact variance of C_t over all pixels: P^T Cov P (diagonal terms from the per-channel
-            // histograms, cross terms from the moment pass)
+            // sigma(C_t) <= sum_c |P[c][t]| sigma(od_c) (per-channel moments come from the byte histograms of P1)
             const double cxx = s.chm[3] * inv_n - mj[0] * mj[0], cyy = s.chm[4] * inv_n - mj[1] * mj[1];
             const double czz = s.chm[5] * inv_n - mj[2] * mj[2];
-            const double cxy = s.chx[0] * inv_n - mj[0] * mj[1], cxz = s.chx[1] * inv_n - mj[0] * mj[2];
-            const double cyz = s.chx[2] * inv_n - mj[1] * mj[2];
-            const double p0 = P[0 + t], p1 = P[2 + t], p2 = P[4 + t];
-            double var = p0 * p0 * cxx + p1 * p1 * cyy + p2 * p2 * czz +
-                         2.0 * (p0 * p1 * cxy + p0 * p2 * cxz + p1 * p2 * cyz);
-            var = var > 0.0 ? var : 0.0;
+            const double sdev = fabs(P[0 + t]) * sqrt(cxx > 0.0 ? cxx : 0.0) + fabs(P[2 + t]) * sqrt(cyy > 0.0 ? cyy : 0.0) +
+                                fabs(P[4 + t]) * sqrt(czz > 0.0 ? czz : 0.0);
+            const double var = sdev * sdev;
             const double sg = sqrt(var) * 1.000001 + 1e-12 * (fabs(mu) + 1.0);
             const double pad = 1e-9 * (fabs(lo) + fabs(hi)) + 1e-12;
             olo0[t] = lo - pad;
@@ -1594,14 +1705,26 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         double vp[2], vn[2];
         bool conc_done = false;
         if (hw < (1L << 30) && prm.select_mode == 0) {
-            const float p00 = (float)P[0], p10 = (float)P[2], p20 = (float)P[4];
-            const float p01 = (float)P[1], p11 = (float)P[3], p21 = (float)P[5];
-            // |C32 - C| <= od32 error (5e-7) x |P column|_1 + three roundings of products <= 5.6 |P| (1e-6 |P column|_1):
-            // eight-fold margin, plus the float rounding of the bounds
-            const float tol0 = 1.2e-5f * (fabsf(p00) + fabsf(p10) + fabsf(p20)) + 1e-7f;
-            const float tol1 = 1.2e-5f * (fabsf(p01) + fabsf(p11) + fabsf(p21)) + 1e-7f;
+            // C_t = sum_c P[c][t] od_c = K_t - sum_c pt_c L_c with pt = ln2 P (see the angular sweep for the error budget):
+            // |dC_t| <= (9.6e-7 + 5e-7 + 1e-6 / ln2) |pt|_1 + 4 roundings of |C| <= ~4e-6 |P column|_1; eight-fold margin.
+            const float ln2 = 0.6931471805599453f, l255 = 7.994353436858858f;
+            const float a0 = ln2 * (float)P[0], a1 = ln2 * (float)P[2], a2 = ln2 * (float)P[4];
+            const float b0 = ln2 * (float)P[1], b1 = ln2 * (float)P[3], b2 = ln2 * (float)P[5];
+            const float ka = l255 * (a0 + a1 + a2), kb = l255 * (b0 + b1 + b2);
+            const float tol0 = 3.2e-5f * (fabsf((float)P[0]) + fabsf((float)P[2]) + fabsf((float)P[4])) + 1e-7f;
+            const float tol1 = 3.2e-5f * (fabsf((float)P[1]) + fabsf((float)P[3]) + fabsf((float)P[5])) + 1e-7f;
+            auto conc32 = [&](uint32_t r, uint32_t g, uint32_t b, float& c0, float& c1) {
+                const float lr = __log2f(fmaxf((float)r, 1.0f)), lg = __log2f(fmaxf((float)g, 1.0f)),
+                            lb = __log2f(fmaxf((float)b, 1.0f));
+                c0 = fmaf(-a2, lb, fmaf(-a1, lg, fmaf(-a0, lr, ka)));
+                c1 = fmaf(-b2, lb, fmaf(-b1, lg, fmaf(-b0, lr, kb)));
+            };
             conc_done = window_select2(
                 p, hw,
+                [&](long, uint32_t r, uint32_t g, uint32_t b, float (&v)[2]) -> unsigned {
+                    conc32(r, g, b, v[0], v[1]);
+                    return 3u;
+                },
                 [&](long idx, double (&x)[2]) -> unsigned {
                     const uint32_t r = p[3 * idx], g = p[3 * idx + 1], b = p[3 * idx + 2];
                     const double ox = OD(r), oy = OD(g), oz = OD(b);
@@ -1611,25 +1734,20 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                 },
                 [&](unsigned* list, unsigned cap, unsigned* n_list) {
                     const float lo0 = (float)s.wlo[0], hi0 = (float)s.whi[0], lo1 = (float)s.wlo[1], hi1 = (float)s.whi[1];
-                    const float t0 = tol0 + 2.4e-7f * (fabsf(lo0) < 3e38f ? fabsf(lo0) : 0.0f) + 2.4e-7f * (fabsf(hi0) < 3e38f ? fabsf(hi0) : 0.0f);
-                    const float t1 = tol1 + 2.4e-7f * (fabsf(lo1) < 3e38f ? fabsf(lo1) : 0.0f) + 2.4e-7f * (fabsf(hi1) < 3e38f ? fabsf(hi1) : 0.0f);
+                    // the float32 images of the window edges are themselves rounded: 1.2e-7 relative
+                    auto slack = [](float v) { return fabsf(v) < 3e38f ? 2.4e-7f * fabsf(v) : 0.0f; };
+                    const float t0 = tol0 + slack(lo0) + slack(hi0), t1 = tol1 + slack(lo1) + slack(hi1);
                     unsigned bl0 = 0, bl1 = 0;
                     for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
-                        const float fr = od32(r), fg = od32(g), fb = od32(b);
-                        const float c0 = fmaf(fb, p20, fmaf(fg, p10, fr * p00));
-                        const float c1 = fmaf(fb, p21, fmaf(fg, p11, fr * p01));
+                        float c0, c1;
+                        conc32(r, g, b, c0, c1);
                         const bool below0 = c0 + t0 < lo0, above0 = c0 - t0 > hi0;
                         const bool below1 = c1 + t1 < lo1, above1 = c1 - t1 > hi1;
-                        bl0 += below0 ? 1u : 0u;
-                        bl1 += below1 ? 1u : 0u;
+                        bl0 += (unsigned)__popcll(__ballot(below0));
+                        bl1 += (unsigned)__popcll(__ballot(below1));
                         const bool need0 = !below0 && !above0, need1 = !below1 && !above1;
                         list_push(need0 || need1, (unsigned)idx | (need0 ? 1u << 30 : 0u) | (need1 ? 1u << 31 : 0u), list, cap, n_list);
                     });
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        bl0 += __shfl_down(bl0, o, 64);
-                        bl1 += __shfl_down(bl1, o, 64);
-                    }
                     if (lane_id() == 0) {
                         if (bl0) atomicAdd(&s.wbelow[0], (unsigned long long)bl0);
                         if (bl1) atomicAdd(&s.wbelow[1], (unsigned long long)bl1);

@@ -288,9 +288,10 @@ def table_from_stats(stats: np.ndarray, types: np.ndarray | None, offset=(0, 0),
     contours = np.empty(ids.size, dtype=object)
     if meta is not None:
         first, npts = meta[ids, 3].astype(np.int64), meta[ids, 2].astype(np.int64)
-        shifted = (points + offset[None]).astype(np.int32)
+        lo, hi = int(first.min()), int((first + npts).max())   # this plane's slice of the batch-wide vertex buffer
+        shifted = (points[lo:hi] + offset[None]).astype(np.int32)
         for j in range(ids.size):
-            contours[j] = shifted[first[j]:first[j] + npts[j]]
+            contours[j] = shifted[first[j] - lo:first[j] - lo + npts[j]]
     prob = np.empty(ids.size, dtype=object)
     kind = np.empty(ids.size, dtype=object)
     if types is not None:
