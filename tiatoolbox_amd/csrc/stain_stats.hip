@@ -75,6 +75,7 @@ struct Smem {
     unsigned long long wbelow[2];
     unsigned wn[2];
     int wok;
+    unsigned wcnt[NW];           // entries in each wave's private segment of the sweep list
     long long tm[16];   // per-phase cycle accumulators (thread 0)
     long long tlast;
 };
@@ -518,7 +519,7 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
     const int tid = threadIdx.x;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     const float finf = __int_as_float(0x7f800000);
-    if (n[0] == 0 || n[1] == 0) return false;
+    if (n[0] == 0 || n[1] == 0 || !groups_ok(p, hw) || hw >= (1L << 24)) return false;  // the sweep works on 4-pixel groups
     constexpr int SPT = SAMPLE_TARGET / NT;  // samples per thread
     const long stride = (hw + SAMPLE_TARGET - 1) / SAMPLE_TARGET;
     if (tid < 2) {
@@ -528,9 +529,9 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
         s.wbelow[tid] = 0ull;
     }
     for (int i = tid; i < 2 * SNB; i += NT) (&s.sbins[0][0])[i] = 0u;
-    // ---- sample (float32, registers): all byte loads in flight together -------------------------------------------------
-    float sv[2][SPT];
-    unsigned svalid[SPT];
+    // ---- sample (float32): all byte loads in flight together; the values wait in the (still unused) histogram area --------
+    float* sbuf = reinterpret_cast<float*>(&s.bins[0][0]);  // [2][SAMPLE_TARGET]; NaN = not a member
+    const float fnan = __int_as_float(0x7fc00000);
     {
         uint32_t rgb[SPT];
 #pragma unroll
@@ -538,27 +539,22 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
             const long idx = ((long)j * NT + tid) * stride;
             rgb[j] = idx < hw ? ((uint32_t)p[3 * idx] | ((uint32_t)p[3 * idx + 1] << 8) | ((uint32_t)p[3 * idx + 2] << 16)) : 0u;
         }
+        float mn[2] = {finf, finf}, mx[2] = {-finf, -finf};
+        unsigned cnt[2] = {0u, 0u};
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const long idx = ((long)j * NT + tid) * stride;
             float v[2] = {0.0f, 0.0f};
-            svalid[j] = idx < hw ? sample32(idx, rgb[j] & 255u, (rgb[j] >> 8) & 255u, (rgb[j] >> 16) & 255u, v) : 0u;
-            sv[0][j] = v[0];
-            sv[1][j] = v[1];
+            const unsigned valid = idx < hw ? sample32(idx, rgb[j] & 255u, (rgb[j] >> 8) & 255u, (rgb[j] >> 16) & 255u, v) : 0u;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bool ok = (valid >> t) & 1u;
+                sbuf[t * SAMPLE_TARGET + j * NT + tid] = ok ? v[t] : fnan;
+                mn[t] = ok ? fminf(mn[t], v[t]) : mn[t];
+                mx[t] = ok ? fmaxf(mx[t], v[t]) : mx[t];
+                cnt[t] += ok ? 1u : 0u;
+            }
         }
-    }
-    {
-        float mn[2] = {finf, finf}, mx[2] = {-finf, -finf};
-        unsigned cnt[2] = {0u, 0u};
-#pragma unroll
-        for (int j = 0; j < SPT; ++j)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                if ((svalid[j] >> t) & 1u) {
-                    mn[t] = fminf(mn[t], sv[t][j]);
-                    mx[t] = fmaxf(mx[t], sv[t][j]);
-                    ++cnt[t];
-                }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -590,14 +586,15 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
         sscale[t] = (hi > lo && sc > 0.0 && sc < 1.0e30) ? (float)sc : 0.0f;
     }
 #pragma unroll
-    for (int j = 0; j < SPT; ++j)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-            if ((svalid[j] >> t) & 1u) {
-                const float d = (sv[t][j] - smin[t]) * sscale[t];
+    for (int t = 0; t < 2; ++t)
+        for (int i = tid; i < SAMPLE_TARGET; i += NT) {
+            const float v = sbuf[t * SAMPLE_TARGET + i];
+            if (v == v) {
+                const float d = (v - smin[t]) * sscale[t];
                 const int b = !(d >= 0.0f) ? 0 : (d >= (float)SNB ? SNB - 1 : (int)d);
                 atomicAdd(&s.sbins[t][b], 1u);
             }
+        }
     __syncthreads();
     // ---- windows: wave t places the window of target t ------------------------------------------------------------------
     constexpr int PER = SNB / 64;
@@ -663,34 +660,59 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
     __syncthreads();
     stamp(s, TM_SEL_FIND);
     // ---- the float32 sweep: counts "definitely below", lists everything within the error bound of a window -------------
+    // The list lives in the histogram area; every wave appends to its own segment with a register-resident count (no
+    // atomics, nothing to wait for in the hot loop).  Entry = pixel-group index | 8 need-bits << 22 (target t of pixel i
+    // of the group: bit 2i+t).
     unsigned* list = &s.bins[0][0];
-    constexpr unsigned LIST_CAP = 2u * NB;
-    unsigned* n_list = &s.st.ncand[0];
-    sweep(list, LIST_CAP, n_list);
+    constexpr unsigned SEG = 2u * NB / NW;
+    sweep(list, SEG);
     __syncthreads();
     stamp(s, TM_SEL_HIST);
-    const unsigned nl = *n_list;
-    if (nl > LIST_CAP) return false;  // uniform
+    {
+        bool over = false;
+        for (int w = 0; w < NW; ++w) over = over || s.wcnt[w] > SEG;
+        if (over) return false;  // uniform
+    }
     // ---- exact classification of the listed pixels ----------------------------------------------------------------------
     {
         unsigned bl[2] = {0u, 0u};
         unsigned long long mn[2] = {~0ull, ~0ull}, mx[2] = {0ull, 0ull};
-        for (unsigned i = tid; i < nl; i += NT) {
-            const unsigned e = list[i];
-            const long idx = (long)(e & 0x3fffffffu);
-            double x[2];
-            const unsigned vm = exact(idx, x);
+        unsigned pre[NW + 1];
+        pre[0] = 0;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (!((e >> (30 + t)) & 1u) || !((vm >> t) & 1u)) continue;
-                if (x[t] < s.wlo[t]) {
-                    ++bl[t];
-                } else if (!(x[t] > s.whi[t])) {
-                    const unsigned pos = atomicAdd(&s.wn[t], 1u);
-                    if (pos < (unsigned)CAP) s.cand[t][pos] = x[t];
-                    const unsigned long long key = f64_key(x[t]);
-                    mn[t] = key < mn[t] ? key : mn[t];
-                    mx[t] = key > mx[t] ? key : mx[t];
+        for (int w = 0; w < NW; ++w) pre[w + 1] = pre[w] + s.wcnt[w];
+        const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
+        for (unsigned i = tid; i < pre[NW]; i += NT) {
+            int w = 0;
+            unsigned base = 0;
+#pragma unroll
+            for (int v = 1; v < NW; ++v)
+                if (i >= pre[v]) {
+                    w = v;
+                    base = pre[v];
+                }
+            const unsigned e = list[w * SEG + (i - base)];
+            const long g = (long)(e & 0x3fffffu);
+            uint32_t rr[4], gg[4], bb[4];
+            unpack_group(q[g * 3], q[g * 3 + 1], q[g * 3 + 2], rr, gg, bb);
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const unsigned need = (e >> (22 + 2 * px)) & 3u;
+                if (!need) continue;
+                double x[2];
+                const unsigned vm = exact(g * 4 + px, rr[px], gg[px], bb[px], x);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (!((need >> t) & 1u) || !((vm >> t) & 1u)) continue;
+                    if (x[t] < s.wlo[t]) {
+                        ++bl[t];
+                    } else if (!(x[t] > s.whi[t])) {
+                        const unsigned pos = atomicAdd(&s.wn[t], 1u);
+                        if (pos < (unsigned)CAP) s.cand[t][pos] = x[t];
+                        const unsigned long long key = f64_key(x[t]);
+                        mn[t] = key < mn[t] ? key : mn[t];
+                        mx[t] = key > mx[t] ? key : mx[t];
+                    }
                 }
             }
         }
@@ -699,12 +721,12 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
             unsigned c = bl[t];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-            const unsigned long long a = wave_min_u64(mn[t]);
-            const unsigned long long b = ~wave_min_u64(~mx[t]);
+            const unsigned long long a2 = wave_min_u64(mn[t]);
+            const unsigned long long b2 = ~wave_min_u64(~mx[t]);
             if (lane_id() == 0) {
                 if (c) atomicAdd(&s.wbelow[t], (unsigned long long)c);
-                atomicMin(&s.st.member_key[t], a);
-                atomicMax(&s.st.above_key[t], b);
+                atomicMin(&s.st.member_key[t], a2);
+                atomicMax(&s.st.above_key[t], b2);
             }
         }
     }
@@ -1137,16 +1159,14 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         const float o = -0.69314718f * __log2f(f);
         return o > 1e-6f ? o : 1e-6f;
     };
-    // wave-aggregated append of a pixel index (+ which targets need the exact key) to the LDS list of a window sweep
-    auto list_push = [&](bool need, unsigned entry, unsigned* list, unsigned cap, unsigned* n_list) {
+    // append one entry per lane that needs it to this wave's private list segment: position = wave count (uniform, in a
+    // register) + number of needing lanes below this one (v_mbcnt); no atomics, no cross-lane traffic
+    auto seg_push = [&](bool need, unsigned entry, unsigned* seg, unsigned cap, unsigned& count) {
         const unsigned long long m = __ballot(need);
-        if (m == 0ull) return;
-        const int leader = __ffsll((long long)m) - 1;
-        unsigned base = 0;
-        if (lane_id() == leader) base = atomicAdd(n_list, (unsigned)__popcll(m));
-        base = __shfl(base, leader, 64);
-        const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane_id()) - 1ull));
-        if (need && pos < cap) list[pos] = entry;
+        const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const unsigned pos = count + before;
+        if (need && pos < cap) seg[pos] = entry;
+        count += (unsigned)__popcll(m);
     };
 
     double S[6];  // source stain matrix rows H,E
@@ -1188,11 +1208,12 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                     }
                 }
                 if (use_bits) {  // 8 consecutive lanes hold 32 consecutive pixels: one mask word
-                    unsigned word = nib << (4 * (lane_id() & 7));
-                    word |= __shfl_xor(word, 1, 64);
-                    word |= __shfl_xor(word, 2, 64);
-                    word |= __shfl_xor(word, 4, 64);
-                    if ((lane_id() & 7) == 0) s.mbits[g >> 3] = word;
+                    // OR over the octet with DPP row shifts (lane i receives lane i+n; VALU only, no LDS crossbar traffic)
+                    int word = (int)(nib << (4 * (lane_id() & 7)));
+                    word |= __builtin_amdgcn_update_dpp(0, word, 0x101, 0xf, 0xf, true);  // row_shl:1
+                    word |= __builtin_amdgcn_update_dpp(0, word, 0x102, 0xf, 0xf, true);  // row_shl:2
+                    word |= __builtin_amdgcn_update_dpp(0, word, 0x104, 0xf, 0xf, true);  // row_shl:4
+                    if ((lane_id() & 7) == 0) s.mbits[g >> 3] = (unsigned)word;
                 }
             });
         } else
@@ -1268,7 +1289,7 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         const double lo0[2] = {-2.0009765625, -2.0009765625}, hi0[2] = {2.0009765625, 2.0009765625};
         double vp[2], vn[2];
         bool phi_done = false;
-        if (hw < (1L << 30) && prm.select_mode == 0) {
+        if (prm.select_mode == 0) {
             // float32 classification: with L_c = log2(max(v_c, 1)) the projections are x = Kx - sum_c ex_c L_c (ex = ln2 e1,
             // Kx = log2(255) sum_c ex_c), likewise y; for window edges kb in [-1, 1] and x > 0, key < kb <=> y - kb (|x|+|y|) < 0.
             // Error budget of s = y - kb d: |dL| <= 1 ulp(8) = 9.6e-7, constants rounded to float32 (6e-8 x 8), three FMA
@@ -1295,8 +1316,7 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                     v[0] = v[1] = x >= 0.0f ? q : (y >= 0.0f ? 2.0f - q : -2.0f - q);
                     return 3u;
                 },
-                [&](long idx, double (&x)[2]) -> unsigned {
-                    const uint32_t r = p[3 * idx], g = p[3 * idx + 1], b = p[3 * idx + 2];
+                [&](long idx, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
                     if (!is_tissue_cached(idx, r, g, b)) return 0u;
                     const double ox = OD(r), oy = OD(g), oz = OD(b);
                     const double p0 = dot3(ox, oy, oz, e1x, e1y, e1z);
@@ -1304,29 +1324,46 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                     x[0] = x[1] = pseudo_angle(p1, p0);
                     return 3u;
                 },
-                [&](unsigned* list, unsigned cap, unsigned* n_list) {
+                [&](unsigned* list, unsigned seg_cap) {
                     // window edges outside [-1, 1] (keys of the x < 0 half plane) are not handled by the cross-product
-                    // test: make every tissue pixel a candidate of that target, the overflow check then falls back
+                    // test: every tissue pixel then becomes a candidate, the overflow check falls back to select2
                     const double w[4] = {s.wlo[0], s.whi[0], s.wlo[1], s.whi[1]};
                     bool edges_ok = true;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) edges_ok = edges_ok && (!(fabs(w[i]) < 1e300) || fabs(w[i]) <= 1.0);
                     const float lo0 = (float)w[0], hi0 = (float)w[1], lo1 = (float)w[2], hi1 = (float)w[3];
-                    unsigned bl0 = 0, bl1 = 0;  // wave-uniform: scalar population counts of the comparison masks
-                    for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
-                        const bool tissue = is_tissue_cached(idx, r, g, b);
-                        float x, y;
-                        proj(r, g, b, x, y);
-                        const float d = fabsf(x) + fabsf(y);
-                        const bool plain = edges_ok && x > tol;  // otherwise: exact classification
-                        const bool below0 = plain && fmaf(-lo0, d, y) < -tol, above0 = plain && fmaf(-hi0, d, y) > tol;
-                        const bool below1 = plain && fmaf(-lo1, d, y) < -tol, above1 = plain && fmaf(-hi1, d, y) > tol;
-                        bl0 += (unsigned)__popcll(__ballot(tissue && below0));
-                        bl1 += (unsigned)__popcll(__ballot(tissue && below1));
-                        const bool need0 = tissue && !below0 && !above0, need1 = tissue && !below1 && !above1;
-                        list_push(need0 || need1, (unsigned)idx | (need0 ? 1u << 30 : 0u) | (need1 ? 1u << 31 : 0u), list, cap, n_list);
+                    unsigned bl0 = 0, bl1 = 0, count = 0;  // wave-uniform (scalar population counts of the masks)
+                    unsigned* seg = list + wave_id() * seg_cap;
+                    for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup&) {
+                        uint32_t rr[4], gg[4], bb[4];
+                        unpack_group(a, b, c, rr, gg, bb);
+                        unsigned nib;
+                        if (use_bits) {
+                            nib = (s.mbits[g >> 3] >> (4 * (int)(g & 7))) & 15u;
+                        } else {
+                            nib = 0;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) nib |= is_tissue(rr[i], gg[i], bb[i]) ? 1u << i : 0u;
+                        }
+                        unsigned flags = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool tissue = (nib >> i) & 1u;
+                            float x, y;
+                            proj(rr[i], gg[i], bb[i], x, y);
+                            const float d = fabsf(x) + fabsf(y);
+                            const bool plain = edges_ok && x > tol;  // otherwise: exact classification
+                            const bool below0 = plain && fmaf(-lo0, d, y) < -tol, above0 = plain && fmaf(-hi0, d, y) > tol;
+                            const bool below1 = plain && fmaf(-lo1, d, y) < -tol, above1 = plain && fmaf(-hi1, d, y) > tol;
+                            bl0 += (unsigned)__popcll(__ballot(tissue && below0));
+                            bl1 += (unsigned)__popcll(__ballot(tissue && below1));
+                            const unsigned need = (tissue && !below0 && !above0 ? 1u : 0u) | (tissue && !below1 && !above1 ? 2u : 0u);
+                            flags |= need << (2 * i);
+                        }
+                        seg_push(flags != 0u, (unsigned)g | (flags << 22), seg, seg_cap, count);
                     });
                     if (lane_id() == 0) {
+                        s.wcnt[wave_id()] = count;
                         if (bl0) atomicAdd(&s.wbelow[0], (unsigned long long)bl0);
                         if (bl1) atomicAdd(&s.wbelow[1], (unsigned long long)bl1);
                     }
@@ -1704,7 +1741,7 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         }
         double vp[2], vn[2];
         bool conc_done = false;
-        if (hw < (1L << 30) && prm.select_mode == 0) {
+        if (prm.select_mode == 0) {
             // C_t = sum_c P[c][t] od_c = K_t - sum_c pt_c L_c with pt = ln2 P (see the angular sweep for the error budget):
             // |dC_t| <= (9.6e-7 + 5e-7 + 1e-6 / ln2) |pt|_1 + 4 roundings of |C| <= ~4e-6 |P column|_1; eight-fold margin.
             const float ln2 = 0.6931471805599453f, l255 = 7.994353436858858f;
@@ -1725,30 +1762,37 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                     conc32(r, g, b, v[0], v[1]);
                     return 3u;
                 },
-                [&](long idx, double (&x)[2]) -> unsigned {
-                    const uint32_t r = p[3 * idx], g = p[3 * idx + 1], b = p[3 * idx + 2];
+                [&](long, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
                     const double ox = OD(r), oy = OD(g), oz = OD(b);
                     x[0] = dot3(ox, oy, oz, P[0], P[2], P[4]);
                     x[1] = dot3(ox, oy, oz, P[1], P[3], P[5]);
                     return 3u;
                 },
-                [&](unsigned* list, unsigned cap, unsigned* n_list) {
+                [&](unsigned* list, unsigned seg_cap) {
                     const float lo0 = (float)s.wlo[0], hi0 = (float)s.whi[0], lo1 = (float)s.wlo[1], hi1 = (float)s.whi[1];
                     // the float32 images of the window edges are themselves rounded: 1.2e-7 relative
                     auto slack = [](float v) { return fabsf(v) < 3e38f ? 2.4e-7f * fabsf(v) : 0.0f; };
                     const float t0 = tol0 + slack(lo0) + slack(hi0), t1 = tol1 + slack(lo1) + slack(hi1);
-                    unsigned bl0 = 0, bl1 = 0;
-                    for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
-                        float c0, c1;
-                        conc32(r, g, b, c0, c1);
-                        const bool below0 = c0 + t0 < lo0, above0 = c0 - t0 > hi0;
-                        const bool below1 = c1 + t1 < lo1, above1 = c1 - t1 > hi1;
-                        bl0 += (unsigned)__popcll(__ballot(below0));
-                        bl1 += (unsigned)__popcll(__ballot(below1));
-                        const bool need0 = !below0 && !above0, need1 = !below1 && !above1;
-                        list_push(need0 || need1, (unsigned)idx | (need0 ? 1u << 30 : 0u) | (need1 ? 1u << 31 : 0u), list, cap, n_list);
+                    unsigned bl0 = 0, bl1 = 0, count = 0;
+                    unsigned* seg = list + wave_id() * seg_cap;
+                    for_each_group<NT>(p, hw, [&](long g, uint32_t a, uint32_t b, uint32_t c, const WaveGroup&) {
+                        uint32_t rr[4], gg[4], bb[4];
+                        unpack_group(a, b, c, rr, gg, bb);
+                        unsigned flags = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float c0, c1;
+                            conc32(rr[i], gg[i], bb[i], c0, c1);
+                            const bool below0 = c0 + t0 < lo0, above0 = c0 - t0 > hi0;
+                            const bool below1 = c1 + t1 < lo1, above1 = c1 - t1 > hi1;
+                            bl0 += (unsigned)__popcll(__ballot(below0));
+                            bl1 += (unsigned)__popcll(__ballot(below1));
+                            flags |= ((!below0 && !above0 ? 1u : 0u) | (!below1 && !above1 ? 2u : 0u)) << (2 * i);
+                        }
+                        seg_push(flags != 0u, (unsigned)g | (flags << 22), seg, seg_cap, count);
                     });
                     if (lane_id() == 0) {
+                        s.wcnt[wave_id()] = count;
                         if (bl0) atomicAdd(&s.wbelow[0], (unsigned long long)bl0);
                         if (bl1) atomicAdd(&s.wbelow[1], (unsigned long long)bl1);
                     }
