@@ -375,6 +375,22 @@ int tia_gather_patches_u8(const uint8_t* d_slide, int64_t sh, int64_t sw, int64_
                           int64_t m, int64_t ph, int64_t pw, int32_t pad, uint8_t* d_out, void* stream);
 
 /* =======================================================================================
+ * ResNet convolutions on the matrix cores (models/architecture/vanilla.py:300-316 -> torchvision BasicBlock)
+ * ===================================================================================== */
+
+/* OIHW float32 weights -> the implicit GEMM's B matrix [kh][kw][cin][cout] (done once per model). */
+int tia_conv_pack_weights_f32(const float* d_w_oihw, int64_t cout, int64_t cin, int64_t kh, int64_t kw,
+                              float* d_packed, void* stream);
+
+/* y = act(conv2d(x, w) + bias [+ residual]) for NHWC float32 tensors: implicit GEMM on v_mfma_f32_32x32x2_f32 (f32 in,
+ * f32 accumulate: the reference's float32 arithmetic, vanilla.py:242), BatchNorm already folded into w / bias.
+ *   d_x [n,h,w,cin]   d_w_packed [kh,kw,cin,cout]   d_bias [cout] or NULL   d_residual [n,ho,wo,cout] or NULL
+ *   d_y [n,ho,wo,cout], ho = (h + 2 pad - kh) / stride + 1.   cin % 32 == 0, cout % 64 == 0, 16-byte aligned x / w. */
+int tia_conv2d_nhwc_f32(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                        float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
+                        int64_t kw, int64_t stride, int64_t pad, int32_t relu, void* stream);
+
+/* =======================================================================================
  * All borders of binary planes: cv2.findContours(layer, RETR_TREE, CHAIN_APPROX_NONE | _SIMPLE)
  * (models/architecture/hovernetplus.py:222-226, HoVerNetPlus._get_layer_info)
  * ===================================================================================== */

@@ -238,3 +238,65 @@ def test_patch_predictor_wsi_mode(tmp_path, target_image):
     with pytest.raises(ValueError, match="No patch coordinates remain"):
         eng.run([reader], masks=[np.zeros((1000, 1180), np.uint8)], patch_mode=False, save_dir=tmp_path / "d",
                 input_resolutions=[{"units": "mpp", "resolution": 0.5}])
+
+
+@pytest.mark.gpu
+def test_hip_mfma_conv_matches_torch_cpu_fp32():
+    """``tia_conv2d_nhwc_f32`` (implicit GEMM on v_mfma_f32_32x32x2_f32, fused bias / residual / ReLU) against
+    ``torch.nn.functional.conv2d`` on the CPU in float32, for every BasicBlock convolution shape of resnet18 (3x3 stride
+    1 / 2, 1x1 stride 2 down-sampling), ragged pixel counts (M not a tile multiple) and all epilogue variants: <= 1e-4."""
+    import torch.nn.functional as F  # noqa: N812
+
+    from tiatoolbox_amd.models.architecture.fused import hip_conv2d, pack_conv_weights
+
+    g = torch.Generator().manual_seed(0)
+    cases = [(3, 64, 64, 56, 3, 1), (2, 64, 128, 56, 3, 2), (2, 64, 128, 56, 1, 2), (3, 128, 128, 28, 3, 1),
+             (2, 128, 256, 28, 3, 2), (5, 256, 256, 14, 3, 1), (2, 256, 512, 14, 3, 2), (7, 512, 512, 7, 3, 1),
+             (1, 32, 64, 9, 3, 1), (2, 64, 64, 13, 3, 2)]
+    for n, cin, cout, hw, k, stride in cases:
+        pad = 1 if k == 3 else 0
+        conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=True)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+            conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        x = torch.randn((n, cin, hw, hw), generator=g)
+        ref_lin = F.conv2d(x, conv.weight, conv.bias, stride=stride, padding=pad)
+        res = torch.randn(ref_lin.shape, generator=g)
+        dev_conv = conv.cuda()
+        wp = pack_conv_weights(dev_conv)
+        assert wp.shape == (k, k, cin, cout)
+        assert torch.equal(wp.cpu(), conv.weight.detach().cpu().permute(2, 3, 1, 0).contiguous())
+        xd = x.cuda().contiguous(memory_format=torch.channels_last)
+        rd = res.cuda().contiguous(memory_format=torch.channels_last)
+        for use_res, relu in ((False, False), (False, True), (True, True)):
+            exp = ref_lin + (res if use_res else 0)
+            exp = torch.relu(exp) if relu else exp
+            got = hip_conv2d(xd, wp, dev_conv.bias, rd if use_res else None, kernel=k, stride=stride, padding=pad, relu=relu)
+            assert got.shape == exp.shape and got.is_contiguous(memory_format=torch.channels_last)
+            err = (got.cpu() - exp).abs().max().item()
+            assert err <= 1e-4, (n, cin, cout, hw, k, stride, use_res, relu, err)
+
+
+@pytest.mark.gpu
+def test_mfma_resnet_matches_plain_model(patches):
+    """resnet18 with every block convolution on the hand-written MFMA kernel == the plain torch module on the CPU."""
+    from tiatoolbox_amd.models.architecture import get_pretrained_model
+    from tiatoolbox_amd.models.architecture.fused import fuse_cnn_model
+
+    model, _ = get_pretrained_model("resnet18-kather100k")
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.1)
+    x = (torch.from_numpy(patches).float() / 255).permute(0, 3, 1, 2)
+    with torch.inference_mode():
+        ref = model.eval()(x)
+        mfma = fuse_cnn_model(model, epilogue_fusion="mfma").cuda().to(memory_format=torch.channels_last)
+        got = mfma(x.cuda().contiguous(memory_format=torch.channels_last)).cpu()
+    assert (got - ref).abs().max() < 1e-4
+    eng = PatchPredictor("resnet18-kather100k", batch_size=4, device="cuda")
+    a = eng.run(patches, patch_mode=True, return_probabilities=True, conv_backend="mfma")
+    b = PatchPredictor("resnet18-kather100k", batch_size=4).run(patches, patch_mode=True, return_probabilities=True)
+    np.testing.assert_allclose(a["probabilities"], b["probabilities"], atol=1e-4)

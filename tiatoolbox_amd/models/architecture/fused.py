@@ -204,6 +204,93 @@ class HipFusedResNet(nn.Module):
         return self.blocks(x)
 
 
+# ------------------------------------------------------------------------------------------------
+# Hand-written MFMA convolutions (conv_mfma.hip): float32 implicit GEMM with the epilogue fused in
+# ------------------------------------------------------------------------------------------------
+def hip_conv2d(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor | None, residual: torch.Tensor | None, *,
+               kernel: int, stride: int, padding: int, relu: bool) -> torch.Tensor:
+    """``relu(conv2d(x, w) + bias + residual)`` on a float32 channels-last CUDA tensor (``tia_conv2d_nhwc_f32``)."""
+    from tiatoolbox_amd import _lib
+
+    if not (_nhwc_ptr_ok(x) and x.dtype == torch.float32):
+        msg = "hip_conv2d expects a float32 channels-last CUDA tensor."
+        raise ValueError(msg)
+    n, cin, h, w = x.shape
+    cout = w_packed.shape[-1]
+    ho = (h + 2 * padding - kernel) // stride + 1
+    wo = (w + 2 * padding - kernel) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_conv2d_nhwc_f32(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                                             residual.data_ptr() if residual is not None else 0, y.data_ptr(), n, h, w, cin,
+                                             cout, kernel, kernel, stride, padding, int(relu), _lib.current_stream())
+    _lib.check(rc, "tia_conv2d_nhwc_f32")
+    return y
+
+
+def pack_conv_weights(conv: nn.Conv2d) -> torch.Tensor:
+    """OIHW -> ``[kh, kw, cin, cout]`` float32 on the convolution's device (``tia_conv_pack_weights_f32``)."""
+    from tiatoolbox_amd import _lib
+
+    w = conv.weight.detach().to(torch.float32).contiguous()
+    cout, cin, kh, kw = w.shape
+    out = torch.empty((kh, kw, cin, cout), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().tia_conv_pack_weights_f32(w.data_ptr(), cout, cin, kh, kw, out.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "tia_conv_pack_weights_f32")
+    return out
+
+
+class _MfmaBasic(nn.Module):
+    """BasicBlock as three launches: (downsample) / conv1+bias+ReLU / conv2+bias+residual+ReLU."""
+
+    def __init__(self, blk: BasicBlock) -> None:
+        super().__init__()
+        self.conv1, self.conv2 = blk.conv1, blk.conv2
+        self.down = blk.downsample[0] if blk.downsample is not None else None
+        self._packed: dict[str, torch.Tensor] = {}
+
+    def _w(self, name: str) -> torch.Tensor:
+        conv = getattr(self, name)
+        cached = self._packed.get(name)
+        if cached is None or cached.device != conv.weight.device:
+            cached = self._packed[name] = pack_conv_weights(conv)
+        return cached
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        s = self.conv1.stride[0]
+        identity = x
+        if self.down is not None:
+            identity = hip_conv2d(x, self._w("down"), self.down.bias, None, kernel=1, stride=self.down.stride[0], padding=0,
+                                  relu=False)
+        out = hip_conv2d(x, self._w("conv1"), self.conv1.bias, None, kernel=3, stride=s, padding=1, relu=True)
+        return hip_conv2d(out, self._w("conv2"), self.conv2.bias, identity, kernel=3, stride=1, padding=1, relu=True)
+
+
+class MfmaResNet(nn.Module):
+    """ResNet-18/34 trunk in float32: stem = MIOpen 7x7 (3 input channels) + the fused bias/ReLU/max-pool kernel, every
+    BasicBlock convolution = the hand-written MFMA implicit GEMM with its epilogue fused (BN folded, channels-last)."""
+
+    def __init__(self, trunk: nn.Sequential) -> None:
+        super().__init__()
+        folded = fold_conv_bn(trunk)
+        self.stem = folded[0]
+        blocks = []
+        for layer in list(folded)[4:]:
+            for blk in layer:
+                if not isinstance(blk, BasicBlock):
+                    msg = "MfmaResNet covers BasicBlock trunks (resnet18 / resnet34)."
+                    raise TypeError(msg)
+                blocks.append(_MfmaBasic(blk))
+        self.blocks = nn.Sequential(*blocks)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        x = hip_bias_relu_maxpool(_conv_nobias(x, self.stem), self.stem.bias)
+        return self.blocks(x)
+
+
 def fuse_cnn_model(model: nn.Module, *, epilogue_fusion: bool | str = False) -> nn.Module:
     """Derived inference copy of a ``CNNModel``/``CNNBackbone`` with BN folded into the convolutions.
 
@@ -213,11 +300,15 @@ def fuse_cnn_model(model: nn.Module, *, epilogue_fusion: bool | str = False) -> 
     default is off; BN folding alone gives 70.8 -> 54.5 ms.  ``epilogue_fusion="hip"`` keeps MIOpen for
     the convolutions (without bias) and runs bias (+ residual) + ReLU (and the stem's max-pool) as the
     hand-written single-pass kernels of ``csrc/cnn_epilogue.hip`` (CUDA/HIP tensors only).
+    ``epilogue_fusion="mfma"`` (float32, BasicBlock trunks): every block convolution is the hand-written MFMA implicit
+    GEMM of ``csrc/conv_mfma.hip`` with bias / residual / ReLU in its epilogue; only the 3-channel stem stays on MIOpen.
     """
     fused = copy.deepcopy(model).eval()
     trunk = fused.feat_extract
     if isinstance(trunk, nn.Sequential) and len(trunk) == 8 and isinstance(trunk[0], nn.Conv2d):
-        if epilogue_fusion == "hip":
+        if epilogue_fusion == "mfma":
+            fused.feat_extract = MfmaResNet(trunk)
+        elif epilogue_fusion == "hip":
             fused.feat_extract = HipFusedResNet(trunk)
         else:
             fused.feat_extract = FusedResNet(trunk) if epilogue_fusion else fold_conv_bn(trunk)

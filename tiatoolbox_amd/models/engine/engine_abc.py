@@ -271,7 +271,8 @@ class EngineABC:
         if dtype == torch.float32 and torch.device(self.device).type != "cuda":
             return self.model
         miopen_find = bool(getattr(self, "miopen_find", False))
-        key = (dtype, str(self.device), id(self.model), self.fold_batchnorm, miopen_find, _weights_version(self.model))
+        key = (dtype, str(self.device), id(self.model), self.fold_batchnorm, miopen_find, _weights_version(self.model),
+               str(getattr(self, "conv_backend", "miopen")))
         if self._fast_key != key:
             import copy
 
@@ -280,7 +281,11 @@ class EngineABC:
                 from tiatoolbox_amd.models.architecture.fused import fuse_cnn_model
 
                 on_gpu = torch.device(self.device).type == "cuda"
-                m = fuse_cnn_model(m, epilogue_fusion="hip" if on_gpu else False)
+                # `conv_backend` (run kwarg / attribute): "miopen" = library convolutions + hand-written epilogues (default);
+                # "mfma" = the hand-written float32 MFMA implicit GEMM with its epilogue fused (BasicBlock trunks, fp32)
+                backend = str(getattr(self, "conv_backend", "miopen"))
+                use_mfma = on_gpu and backend == "mfma" and dtype == torch.float32
+                m = fuse_cnn_model(m, epilogue_fusion=("mfma" if use_mfma else "hip") if on_gpu else False)
             m = m.to(device=self.device)
             m = m.to(dtype=dtype) if dtype != torch.float32 else m
             if torch.device(self.device).type == "cuda":
