@@ -54,6 +54,8 @@ def parse() -> argparse.Namespace:
                     choices=["float32", "float16", "bfloat16"], help="CNN arithmetic (reference: float32)")
     ap.add_argument("--precision", default="f64", choices=["f32", "f64"],
                     help="per-pixel arithmetic of the stain apply kernel (reference: f64; statistics are always f64)")
+    ap.add_argument("--conv-backend", default=os.environ.get("TIA_CONV_BACKEND", "mfma"), choices=["miopen", "mfma"],
+                    help="resnet block convolutions: MIOpen + HIP epilogues, or the hand-written MFMA implicit GEMM (fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip host-inclusive / fp16 / 256^2 extra measurements")
     ap.add_argument("--cpu-sample", type=int, default=64)
@@ -241,7 +243,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
         # miopen_find: MIOpen searches its solvers once per convolution shape (first warm-up step); engine option
         size = tuple(int(v) for v in images.shape[1:3])
         return engine.run(images, patch_mode=True, return_probabilities=True, stain_normalizer=norm,
-                          patch_input_shape=size, compute_dtype=dtype,
+                          patch_input_shape=size, compute_dtype=dtype, conv_backend=args.conv_backend,
                           miopen_find=os.environ.get("TIA_MIOPEN_FIND", "1") == "1")
 
     def barrier() -> None:
@@ -284,6 +286,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                                 f"string quotes 256x256x3: see extras.patch_256"),
                    "api": "PatchPredictor.run(images, patch_mode=True, return_probabilities=True, stain_normalizer=...)",
                    "patches_per_gpu": n, "patch_size": hw, "engine_batch_size": args.micro_batch,
+                   "conv_backend": args.conv_backend,
                    "parallelism": f"dp{world_size} (patch-sharded, all_gather of probabilities)"},
     }
 
@@ -335,7 +338,9 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
             name: {"bound": "hbm", "achieved": round(k["achieved_GBs"], 2), "unit": "GB/s",
                    "frac": round(k["frac"], 5), "launch_ms": round(k["seconds"] * 1e3, 4)}
             for name, k in kernels.items() if name != dominant},
-        "backbone": {"bound": "mfma", "what": "resnet18 forward: MIOpen convolutions + hand-written HIP epilogues",
+        "backbone": {"bound": "mfma", "what": ("resnet18 forward: hand-written MFMA implicit-GEMM convolutions with fused "
+                                               "epilogues (stem: MIOpen)" if args.conv_backend == "mfma" and args.dtype == "float32"
+                                               else "resnet18 forward: MIOpen convolutions + hand-written HIP epilogues"),
                      "achieved": round(flops / t_cnn / 1e12, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype],
                      "unit": "TFLOP/s", "frac": round(flops / t_cnn / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5),
                      "ms": round(t_cnn * 1e3, 3)},
@@ -367,6 +372,19 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                 "max_abs_dprob_vs_float32": dp, "tolerance": 1e-3, "within_tolerance": bool(dp <= 1e-3),
                 "argmax_agreement": float((out16["predictions"] == out["predictions"][:n]).mean()),
                 "note": "extra only: fp16 MFMA backbone (fp32 accumulate), same batch; not the reported value"}
+        if args.dtype == "float32":
+            other = "miopen" if args.conv_backend == "mfma" else "mfma"
+            this = args.conv_backend
+            args.conv_backend = other
+            run(xs)
+            el_o, out_o = timed(xs, k_extra, 1)
+            args.conv_backend = this
+            run(xs)
+            extras[f"conv_backend_{other}"] = {
+                "value": round(n * k_extra / el_o, 2), "unit": "patches/s", "ms_per_step": round(el_o / k_extra * 1e3, 3),
+                "max_abs_dprob_vs_reported": float(np.abs(out_o["probabilities"].astype(np.float64) - probs[:n]).max()),
+                "note": ("same call with the block convolutions on MIOpen + separate HIP epilogues" if other == "miopen"
+                         else "same call with the hand-written MFMA implicit-GEMM convolutions")}
         if hw != 256:
             _, x256 = workload(256, n)
             run(x256)

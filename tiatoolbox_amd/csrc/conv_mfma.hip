@@ -32,7 +32,7 @@ struct ConvDims {
 };
 
 template <int BN>
-__global__ __launch_bounds__(NTH) void conv_mfma_f32_kernel(const float* __restrict__ x, const float* __restrict__ wk,
+__global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                             const float* __restrict__ bias, const float* __restrict__ res,
                                                             float* __restrict__ y, ConvDims d, int relu, int m_tiles) {
     constexpr int NTILE = BN / 64;       // 32-wide MFMA tiles per wave along N
@@ -52,61 +52,77 @@ __global__ __launch_bounds__(NTH) void conv_mfma_f32_kernel(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- A staging: thread -> 4 (pixel, channel-quad) slots ------------------------------------------------------------
+    // ---- A staging: thread -> 4 (pixel, channel-quad) slots; everything per slot lives in named scalars (arrays indexed
+    //      through lambdas ended up in scratch memory, whose accesses share the vmcnt counter with the global loads) ----
     const int quad = tid & 7;
-    int iy0[4], ix0[4];
-    long pbase[4];
-    bool pvalid[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const long m = m0 + (tid >> 3) + 32 * r;
-        pvalid[r] = m < m_total;
-        const long mm = pvalid[r] ? m : 0;
-        const int b = (int)(mm / ((long)d.ho * d.wo));
-        const int rem = (int)(mm - (long)b * d.ho * d.wo);
-        const int oy = rem / d.wo, ox = rem - oy * d.wo;
-        iy0[r] = oy * d.stride - d.pad;
-        ix0[r] = ox * d.stride - d.pad;
-        pbase[r] = (long)b * d.h * d.w;
-    }
     const int slices_per_tap = d.cin / BK;
     const int n_slices = d.kh * d.kw * slices_per_tap;
-
-    float4 ra[4], rb[B_PER_THREAD];
-    auto load_slice = [&](int sidx) {
-        const int tap = sidx / slices_per_tap;
-        const int c0 = (sidx - tap * slices_per_tap) * BK;
-        const int kh = tap / d.kw, kw = tap - kh * d.kw;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int iy = iy0[r] + kh, ix = ix0[r] + kw;
-            const bool inb = pvalid[r] && (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
-            ra[r] = inb ? *reinterpret_cast<const float4*>(x + ((pbase[r] + (long)iy * d.w + ix) * d.cin + c0 + 4 * quad))
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const float* wrow = wk + ((long)tap * d.cin + c0) * d.cout + n0;
-#pragma unroll
-        for (int r = 0; r < B_PER_THREAD; ++r) {
-            const int s = tid + NTH * r;
-            const int row = s / BQ, c4 = s - row * BQ;
-            rb[r] = *reinterpret_cast<const float4*>(wrow + (long)row * d.cout + 4 * c4);
-        }
-    };
-    auto store_slice = [&]() {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float* dst = As + ((tid >> 3) + 32 * r) * LDA + 4 * quad;
-            dst[0] = ra[r].x;
-            dst[1] = ra[r].y;
-            dst[2] = ra[r].z;
-            dst[3] = ra[r].w;
-        }
-#pragma unroll
-        for (int r = 0; r < B_PER_THREAD; ++r) {
-            const int s = tid + NTH * r;
-            *reinterpret_cast<float4*>(Bs + 4 * s) = rb[r];  // row * BN + 4 * c4 == 4 * s
-        }
-    };
+#define TIA_SLOT_INIT(R)                                                                       \
+    int iy0_##R, ix0_##R;                                                                      \
+    long pbase_##R;                                                                            \
+    bool pvalid_##R;                                                                           \
+    {                                                                                          \
+        const long m = m0 + (tid >> 3) + 32 * R;                                               \
+        pvalid_##R = m < m_total;                                                              \
+        const long mm = pvalid_##R ? m : 0;                                                    \
+        const int b = (int)(mm / ((long)d.ho * d.wo));                                         \
+        const int rem = (int)(mm - (long)b * d.ho * d.wo);                                     \
+        const int oy = rem / d.wo, ox = rem - oy * d.wo;                                       \
+        iy0_##R = oy * d.stride - d.pad;                                                       \
+        ix0_##R = ox * d.stride - d.pad;                                                       \
+        pbase_##R = (long)b * d.h * d.w;                                                       \
+    }
+    TIA_SLOT_INIT(0)
+    TIA_SLOT_INIT(1)
+    TIA_SLOT_INIT(2)
+    TIA_SLOT_INIT(3)
+#undef TIA_SLOT_INIT
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    bool ok0, ok1, ok2, ok3;
+    rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // branch-free A load: padding taps read a valid dummy address and are zeroed when the slice is written to LDS -- a
+    // conditional load would make the compiler wait for it right here, in front of the MFMA loop
+#define TIA_LOAD_A(R)                                                                                         \
+    {                                                                                                         \
+        const int iy = iy0_##R + kh, ix = ix0_##R + kw;                                                       \
+        ok##R = pvalid_##R && (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;                   \
+        const long pix = ok##R ? pbase_##R + (long)iy * d.w + ix : 0;                                         \
+        ra##R = *reinterpret_cast<const float4*>(x + (pix * d.cin + c0 + 4 * quad));                          \
+    }
+#define TIA_LOAD_B(R)                                                                                         \
+    {                                                                                                         \
+        const int s = tid + NTH * R;                                                                          \
+        const int row = s / BQ, c4 = s - row * BQ;                                                            \
+        rb##R = *reinterpret_cast<const float4*>(wrow + (long)row * d.cout + 4 * c4);                         \
+    }
+#define TIA_LOAD_SLICE(SIDX)                                                       \
+    {                                                                              \
+        const int tap = (SIDX) / slices_per_tap;                                   \
+        const int c0 = ((SIDX)-tap * slices_per_tap) * BK;                         \
+        const int kh = tap / d.kw, kw = tap - kh * d.kw;                           \
+        TIA_LOAD_A(0) TIA_LOAD_A(1) TIA_LOAD_A(2) TIA_LOAD_A(3)                    \
+        const float* wrow = wk + ((long)tap * d.cin + c0) * d.cout + n0;           \
+        TIA_LOAD_B(0) TIA_LOAD_B(1)                                                \
+        if (B_PER_THREAD == 4) { TIA_LOAD_B(2) TIA_LOAD_B(3) }                     \
+    }
+#define TIA_STORE_A(R)                                                             \
+    {                                                                              \
+        float* dst = As + ((tid >> 3) + 32 * R) * LDA + 4 * quad;                  \
+        dst[0] = ok##R ? ra##R.x : 0.0f;                                           \
+        dst[1] = ok##R ? ra##R.y : 0.0f;                                           \
+        dst[2] = ok##R ? ra##R.z : 0.0f;                                           \
+        dst[3] = ok##R ? ra##R.w : 0.0f;                                           \
+    }
+#define TIA_STORE_SLICE()                                                                       \
+    {                                                                                           \
+        TIA_STORE_A(0) TIA_STORE_A(1) TIA_STORE_A(2) TIA_STORE_A(3)                             \
+        *reinterpret_cast<float4*>(Bs + 4 * (tid + NTH * 0)) = rb0;                             \
+        *reinterpret_cast<float4*>(Bs + 4 * (tid + NTH * 1)) = rb1;                             \
+        if (B_PER_THREAD == 4) {                                                                \
+            *reinterpret_cast<float4*>(Bs + 4 * (tid + NTH * 2)) = rb2;                         \
+            *reinterpret_cast<float4*>(Bs + 4 * (tid + NTH * 3)) = rb3;                         \
+        }                                                                                       \
+    }
 
     f32x16 acc[2][NTILE];
 #pragma unroll
@@ -119,12 +135,15 @@ __global__ __launch_bounds__(NTH) void conv_mfma_f32_kernel(const float* __restr
     const float* a_ptr = As + (wm * 64 + (lane & 31)) * LDA + (lane >> 5);
     const float* b_ptr = Bs + (lane >> 5) * BN + wn * (BN / 2) + (lane & 31);
 
-    load_slice(0);
-    store_slice();
+    TIA_LOAD_SLICE(0)
+    TIA_STORE_SLICE()
     __syncthreads();
     for (int sidx = 0; sidx < n_slices; ++sidx) {
-        const bool more = sidx + 1 < n_slices;
-        if (more) load_slice(sidx + 1);  // in flight while the matrix cores work on the current slice
+        // always stage a "next" slice (the last iteration re-reads the final one): no control flow around the staging
+        // registers, and their loads stay in flight while the matrix cores work
+        const int nxt = sidx + 1 < n_slices ? sidx + 1 : sidx;
+        TIA_LOAD_SLICE(nxt)
+        __builtin_amdgcn_sched_barrier(0);  // the loads are issued HERE, not sunk below the MFMAs by the scheduler
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[2], b[NTILE];
@@ -137,29 +156,45 @@ __global__ __launch_bounds__(NTH) void conv_mfma_f32_kernel(const float* __restr
 #pragma unroll
                 for (int j = 0; j < NTILE; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // pin the first use of the staged registers BEHIND the MFMA loop: otherwise the compiler hoists the padding selects
+        // (and with them the wait for the global loads) in front of the loop
+        asm volatile("" : "+v"(ra0.x), "+v"(ra0.y), "+v"(ra0.z), "+v"(ra0.w), "+v"(ra1.x), "+v"(ra1.y), "+v"(ra1.z), "+v"(ra1.w));
+        asm volatile("" : "+v"(ra2.x), "+v"(ra2.y), "+v"(ra2.z), "+v"(ra2.w), "+v"(ra3.x), "+v"(ra3.y), "+v"(ra3.z), "+v"(ra3.w));
         __syncthreads();
-        if (more) {
-            store_slice();
-            __syncthreads();
-        }
+        TIA_STORE_SLICE()
+        __syncthreads();
     }
+#undef TIA_LOAD_A
+#undef TIA_LOAD_B
+#undef TIA_LOAD_SLICE
+#undef TIA_STORE_A
+#undef TIA_STORE_SLICE
 
     // ---- epilogue: bias (+ residual) (+ ReLU); C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    // Per 32x32 tile all 16 residual loads are issued together (rows beyond the end are clamped, their results unused):
+    // one memory latency per tile instead of one per element.
 #pragma unroll
     for (int j = 0; j < NTILE; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
         const float bv = bias ? bias[n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            const long mrow = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            float rv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const long m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (m < m_total) {
-                    float v = acc[i][j][e] + bv;
-                    if (res) v = v + res[m * d.cout + n];
-                    if (relu) v = v > 0.0f ? v : 0.0f;
-                    y[m * d.cout + n] = v;
-                }
+                long m = mrow + (e & 3) + 8 * (e >> 2);
+                m = m < m_total ? m : m_total - 1;
+                rv[e] = res ? res[m * d.cout + n] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long m = mrow + (e & 3) + 8 * (e >> 2);
+                float v = acc[i][j][e] + bv;
+                v = v + rv[e];
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                if (m < m_total) y[m * d.cout + n] = v;
             }
         }
     }

@@ -124,6 +124,7 @@ class EngineABC:
         self.compute_dtype = "float32"    # arithmetic type of the CNN forward
         self.distributed = True           # shard over ranks when torch.distributed is initialised
         self.fold_batchnorm = True        # inference copy with BN folded into the convolutions
+        self.conv_backend = "mfma"        # float32 BasicBlock trunks: hand-written MFMA convolutions ("miopen": library)
         self._fast_model = None
         self._fast_key = None
 
@@ -272,7 +273,7 @@ class EngineABC:
             return self.model
         miopen_find = bool(getattr(self, "miopen_find", False))
         key = (dtype, str(self.device), id(self.model), self.fold_batchnorm, miopen_find, _weights_version(self.model),
-               str(getattr(self, "conv_backend", "miopen")))
+               str(getattr(self, "conv_backend", "mfma")))
         if self._fast_key != key:
             import copy
 
@@ -281,10 +282,14 @@ class EngineABC:
                 from tiatoolbox_amd.models.architecture.fused import fuse_cnn_model
 
                 on_gpu = torch.device(self.device).type == "cuda"
-                # `conv_backend` (run kwarg / attribute): "miopen" = library convolutions + hand-written epilogues (default);
-                # "mfma" = the hand-written float32 MFMA implicit GEMM with its epilogue fused (BasicBlock trunks, fp32)
-                backend = str(getattr(self, "conv_backend", "miopen"))
-                use_mfma = on_gpu and backend == "mfma" and dtype == torch.float32
+                # `conv_backend` (run kwarg / attribute): "mfma" (default) = the hand-written float32 MFMA implicit GEMM with
+                # its epilogue fused, for float32 runs of BasicBlock trunks (resnet18/34); "miopen" = library convolutions
+                # + hand-written epilogues (always used for fp16 / bf16 and Bottleneck trunks)
+                backend = str(getattr(self, "conv_backend", "mfma"))
+                from tiatoolbox_amd.models.architecture.resnet import BasicBlock
+
+                basic = any(isinstance(mod, BasicBlock) for mod in m.modules())
+                use_mfma = on_gpu and backend == "mfma" and dtype == torch.float32 and basic
                 m = fuse_cnn_model(m, epilogue_fusion=("mfma" if use_mfma else "hip") if on_gpu else False)
             m = m.to(device=self.device)
             m = m.to(dtype=dtype) if dtype != torch.float32 else m
