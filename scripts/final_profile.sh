@@ -1,32 +1,36 @@
 #!/bin/bash
-# Round-end measurement pass on the GPU box: smoke, bench (+cpu_baseline), rocprofv3 kernel trace of the bench,
-# separate --pmc passes for HBM traffic of the stain kernels, and the stage-level measurements of the other
-# kernel families with their kernel traces.  Everything lands in gpurun_out/ (copied to profiles/ afterwards).
+# Round-end measurement pass on the GPU box (everything lands in gpurun_out/, copied to profiles/ afterwards):
+# full GPU test suite, smoke, the default bench (+cpu_baseline), rocprofv3 kernel trace of the bench, separate --pmc
+# passes (HBM traffic of the stain kernels; MFMA-busy of the convolution kernel), the other kernel families.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-TAG=${1:-r01c}
+TAG=${1:-r02f}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/${TAG}_pytest_gpu.log; cat $OUT/${TAG}_pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"
-timeout 600 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"; cut -c1-600 $OUT/${TAG}_bench.json
 cd /tmp
 rm -rf /tmp/rp_bench; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_bench -- \
-    python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
-python $R/scripts/prof_summarize.py /tmp/rp_bench $OUT/${TAG}_bench_rocprofv3_summary.txt > /dev/null
+    python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
+python $R/scripts/prof_summarize.py /tmp/rp_bench $OUT/${TAG}_bench_rocprofv3_summary.txt > /dev/null; head -14 $OUT/${TAG}_bench_rocprofv3_summary.txt | cut -c1-150
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/rp_$c; timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/rp_$c -- \
       python $R/scripts/perf_stain.py 4096 > /dev/null 2>&1
   python $R/scripts/prof_summarize.py /tmp/rp_$c $OUT/${TAG}_stain_pmc_${c}.txt > /dev/null
 done
+rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u > $OUT/${TAG}_mfma_counter_names.txt; cat $OUT/${TAG}_mfma_counter_names.txt | tr '\n' ' '; echo
+for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES; do
+  rm -rf /tmp/rp_$c; timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/rp_$c -- \
+      python $R/scripts/perf_conv.py 1024 > /dev/null 2>&1
+  python $R/scripts/prof_summarize.py /tmp/rp_$c $OUT/${TAG}_conv_pmc_${c}.txt > /dev/null 2>&1; grep -h conv_mfma $OUT/${TAG}_conv_pmc_${c}.txt | cut -c1-120
+done
 cd $R
 timeout 400 python scripts/perf_stain.py 4096 2>&1 | grep -v amdgpu > $OUT/${TAG}_perf_stain.txt
+timeout 300 python scripts/perf_conv.py 1024 2>&1 | grep -v amdgpu > $OUT/${TAG}_perf_conv.txt; tail -1 $OUT/${TAG}_perf_conv.txt
 timeout 400 python scripts/perf_kernels.py 2>&1 | grep stage > $OUT/${TAG}_perf_kernels.jsonl
-cd /tmp
-for s in reinhard mask hover; do
-  rm -rf /tmp/rp_$s; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$s -- \
-      python $R/scripts/perf_kernels.py $s > /dev/null 2>&1
-  python $R/scripts/prof_summarize.py /tmp/rp_$s $OUT/${TAG}_perf_${s}_rocprofv3_summary.txt > /dev/null
-done
-ls -la $OUT | tail -20
+timeout 600 python bench.py --config hovernet --steps 5 --warmup 2 > $OUT/${TAG}_bench_hovernet.json 2> /dev/null; cut -c1-300 $OUT/${TAG}_bench_hovernet.json
+timeout 300 python bench.py --config vahadane --steps 5 --warmup 2 > $OUT/${TAG}_bench_vahadane.json 2> /dev/null; cut -c1-200 $OUT/${TAG}_bench_vahadane.json
+ls $OUT | grep $TAG | wc -l
