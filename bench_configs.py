@@ -139,8 +139,9 @@ def bench_semantic(args) -> dict | None:
     xs = out_b[out_b[:, 1] == out_b[0, 1]][:, 0]
     t_merge = _ev(lambda: _row_merge(blocks, xs, side))
     row, cnt = _row_merge(blocks, xs, side)
+    row2, cnt2 = row.clone(), cnt.clone()  # distinct buffers: the two patch rows of a real stitch
     band = torch.zeros((oh, side), dtype=torch.uint8, device=device)
-    t_fin = _ev(lambda: _finalize(row, cnt, 0, row, cnt, 450, 450, 450 + 450, None, band, y_base=450))
+    t_fin = _ev(lambda: _finalize(row, cnt, 0, row2, cnt2, 450, 450, 450 + 450, None, band, y_base=450))
     merge_bytes = blocks.numel() * 4 + row.numel() * 4 + cnt.numel()
     fin_bytes = 2 * 450 * side * 5 * 4 + 2 * 450 * side + 450 * side
     t_gather = _ev(lambda: reader.read_bounds_batch(in_b[keep][:8]))
