@@ -536,8 +536,10 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
         uint32_t rgb[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
+            // branch-free (clamped index): a conditional load would be waited for on its own, one memory latency per sample
             const long idx = ((long)j * NT + tid) * stride;
-            rgb[j] = idx < hw ? ((uint32_t)p[3 * idx] | ((uint32_t)p[3 * idx + 1] << 8) | ((uint32_t)p[3 * idx + 2] << 16)) : 0u;
+            const long ic = idx < hw ? idx : hw - 1;
+            rgb[j] = (uint32_t)p[3 * ic] | ((uint32_t)p[3 * ic + 1] << 8) | ((uint32_t)p[3 * ic + 2] << 16);
         }
         float mn[2] = {finf, finf}, mx[2] = {-finf, -finf};
         unsigned cnt[2] = {0u, 0u};
@@ -599,14 +601,14 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
     // ---- windows: wave t places the window of target t ------------------------------------------------------------------
     constexpr int PER = SNB / 64;
     // bin holding rank r (0-based) of a 1024-bin histogram held 16 bins per lane: first bin whose inclusive count exceeds r
-    auto bin_of_rank = [&](const unsigned (&local)[PER], unsigned incl, unsigned sum, double r, unsigned& before_bin) -> int {
+    auto bin_of_rank = [&](const unsigned (&local)[PER], unsigned incl, unsigned sum, unsigned r, unsigned& before_bin) -> int {
         unsigned before = incl - sum;
         int found = SNB;
         unsigned fb = 0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const unsigned after = before + local[i];
-            if (found == SNB && (double)after > r && local[i] != 0u) {
+            if (found == SNB && after > r) {  // after > r >= before implies local[i] != 0
                 found = lane_id() * PER + i;
                 fb = before;
             }
@@ -639,8 +641,8 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
         const double sigma = sqrt((double)ns[t] * q * (1.0 - q));
         const double rlo = floor(centre - 3.5 * sigma - 2.0), rhi = ceil(centre + 3.5 * sigma + 2.0);
         unsigned dummy;
-        const int blo = rlo < 0.0 ? -1 : bin_of_rank(local, incl, sum, rlo, dummy);
-        const int bhi = rhi >= (double)ns[t] ? SNB : bin_of_rank(local, incl, sum, rhi, dummy);
+        const int blo = rlo < 0.0 ? -1 : bin_of_rank(local, incl, sum, (unsigned)rlo, dummy);
+        const int bhi = rhi >= (double)ns[t] ? SNB : bin_of_rank(local, incl, sum, (unsigned)rhi, dummy);
         if (lane == 0) {
             const double sc = (double)sscale[t];
             const bool flat = !(sc > 0.0);
@@ -682,36 +684,56 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
 #pragma unroll
         for (int w = 0; w < NW; ++w) pre[w + 1] = pre[w] + s.wcnt[w];
         const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
-        for (unsigned i = tid; i < pre[NW]; i += NT) {
-            int w = 0;
-            unsigned base = 0;
+        const unsigned total = pre[NW];
+        constexpr int EU = 4;  // listed groups per thread whose pixel words are fetched together (one latency, not four)
+        for (unsigned i0 = tid; i0 < total; i0 += NT * EU) {
+            unsigned ent[EU];
+            uint32_t wa[EU], wb[EU], wc[EU];
 #pragma unroll
-            for (int v = 1; v < NW; ++v)
-                if (i >= pre[v]) {
-                    w = v;
-                    base = pre[v];
-                }
-            const unsigned e = list[w * SEG + (i - base)];
-            const long g = (long)(e & 0x3fffffu);
-            uint32_t rr[4], gg[4], bb[4];
-            unpack_group(q[g * 3], q[g * 3 + 1], q[g * 3 + 2], rr, gg, bb);
+            for (int u = 0; u < EU; ++u) {
+                const unsigned i = i0 + (unsigned)u * NT;
+                const unsigned ic = i < total ? i : total - 1;
+                int w = 0;
+                unsigned base = 0;
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const unsigned need = (e >> (22 + 2 * px)) & 3u;
-                if (!need) continue;
-                double x[2];
-                const unsigned vm = exact(g * 4 + px, rr[px], gg[px], bb[px], x);
+                for (int v = 1; v < NW; ++v)
+                    if (ic >= pre[v]) {
+                        w = v;
+                        base = pre[v];
+                    }
+                ent[u] = i < total ? list[w * SEG + (ic - base)] : 0u;  // 0: no need-bits
+            }
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    if (!((need >> t) & 1u) || !((vm >> t) & 1u)) continue;
-                    if (x[t] < s.wlo[t]) {
-                        ++bl[t];
-                    } else if (!(x[t] > s.whi[t])) {
-                        const unsigned pos = atomicAdd(&s.wn[t], 1u);
-                        if (pos < (unsigned)CAP) s.cand[t][pos] = x[t];
-                        const unsigned long long key = f64_key(x[t]);
-                        mn[t] = key < mn[t] ? key : mn[t];
-                        mx[t] = key > mx[t] ? key : mx[t];
+            for (int u = 0; u < EU; ++u) {
+                const long g = (long)(ent[u] & 0x3fffffu);
+                wa[u] = q[g * 3];
+                wb[u] = q[g * 3 + 1];
+                wc[u] = q[g * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < EU; ++u) {
+                const unsigned e = ent[u];
+                const long g = (long)(e & 0x3fffffu);
+                uint32_t rr[4], gg[4], bb[4];
+                unpack_group(wa[u], wb[u], wc[u], rr, gg, bb);
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    const unsigned need = (e >> (22 + 2 * px)) & 3u;
+                    if (!need) continue;
+                    double x[2];
+                    const unsigned vm = exact(g * 4 + px, rr[px], gg[px], bb[px], x);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        if (!((need >> t) & 1u) || !((vm >> t) & 1u)) continue;
+                        if (x[t] < s.wlo[t]) {
+                            ++bl[t];
+                        } else if (!(x[t] > s.whi[t])) {
+                            const unsigned pos = atomicAdd(&s.wn[t], 1u);
+                            if (pos < (unsigned)CAP) s.cand[t][pos] = x[t];
+                            const unsigned long long key = f64_key(x[t]);
+                            mn[t] = key < mn[t] ? key : mn[t];
+                            mx[t] = key > mx[t] ? key : mx[t];
+                        }
                     }
                 }
             }
@@ -775,8 +797,8 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
         const unsigned long long r = k[t] - s.wbelow[t];
         const bool has_next = k[t] + 1 < n[t];
         unsigned before_a = 0, before_b = 0;
-        const int ba = bin_of_rank(local, incl, sum, (double)r, before_a);
-        const int bb = has_next ? bin_of_rank(local, incl, sum, (double)(r + 1), before_b) : ba;
+        const int ba = bin_of_rank(local, incl, sum, (unsigned)r, before_a);
+        const int bb = has_next ? bin_of_rank(local, incl, sum, (unsigned)r + 1u, before_b) : ba;
         if (lane == 0) {
             s.st.sel[t][0] = ba;
             s.st.sel_hi[t] = bb;
