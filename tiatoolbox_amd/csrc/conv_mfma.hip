@@ -29,7 +29,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 struct ConvDims {
     int n, h, w, cin, cout, ho, wo, kh, kw, stride, pad;
+    unsigned x_bytes, w_bytes;  // buffer extents of this launch (both < 2^31: the host splits the batch)
 };
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+constexpr int OOB = (int)0x80000000;  // voffset beyond every buffer extent: the load returns zeros (padding taps)
 
 template <int BN>
 __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __restrict__ x, const float* __restrict__ wk,
@@ -52,75 +56,89 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- A staging: thread -> 4 (pixel, channel-quad) slots; everything per slot lives in named scalars (arrays indexed
-    //      through lambdas ended up in scratch memory, whose accesses share the vmcnt counter with the global loads) ----
+    // Both operands come through buffer descriptors (built from kernel arguments only, so they live in SGPRs): a 32-bit
+    // per-lane byte offset is all the address arithmetic a load needs, and an out-of-range offset reads as zero -- which
+    // is exactly what a padding tap must contribute, without a select after the load.
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)d.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)d.w_bytes, 0x00020000);
+
+    // ---- A staging: thread -> 4 (pixel, channel-quad) slots.  Per slot: the byte offset of tap (0, 0) of its pixel
+    //      (may lie before the buffer: only used when the tap is inside the image) and one bit per kernel row / column
+    //      saying whether that row / column of taps falls inside the image.  A slice then costs an AND, a compare, an
+    //      add and a select per slot; everything else about the slice is wave-uniform (scalar unit). ----
     const int quad = tid & 7;
-    const int slices_per_tap = d.cin / BK;
-    const int n_slices = d.kh * d.kw * slices_per_tap;
 #define TIA_SLOT_INIT(R)                                                                       \
-    int iy0_##R, ix0_##R;                                                                      \
-    long pbase_##R;                                                                            \
-    bool pvalid_##R;                                                                           \
+    int cen_##R;                                                                               \
+    unsigned msk_##R;                                                                          \
     {                                                                                          \
         const long m = m0 + (tid >> 3) + 32 * R;                                               \
-        pvalid_##R = m < m_total;                                                              \
-        const long mm = pvalid_##R ? m : 0;                                                    \
-        const int b = (int)(mm / ((long)d.ho * d.wo));                                         \
-        const int rem = (int)(mm - (long)b * d.ho * d.wo);                                     \
+        const bool pvalid = m < m_total;                                                       \
+        const int mm = pvalid ? (int)m : 0;                                                    \
+        const int b = mm / (d.ho * d.wo);                                                      \
+        const int rem = mm - b * d.ho * d.wo;                                                  \
         const int oy = rem / d.wo, ox = rem - oy * d.wo;                                       \
-        iy0_##R = oy * d.stride - d.pad;                                                       \
-        ix0_##R = ox * d.stride - d.pad;                                                       \
-        pbase_##R = (long)b * d.h * d.w;                                                       \
+        const int iy0 = oy * d.stride - d.pad, ix0 = ox * d.stride - d.pad;                    \
+        cen_##R = (((b * d.h + iy0) * d.w + ix0) * d.cin + 4 * quad) * 4;                      \
+        unsigned rows = 0, cols = 0;                                                           \
+        for (int t = 0; t < d.kh; ++t) rows |= (unsigned)((unsigned)(iy0 + t) < (unsigned)d.h) << t;        \
+        for (int t = 0; t < d.kw; ++t) cols |= (unsigned)((unsigned)(ix0 + t) < (unsigned)d.w) << (16 + t); \
+        msk_##R = pvalid ? (rows | cols) : 0u;                                                 \
     }
     TIA_SLOT_INIT(0)
     TIA_SLOT_INIT(1)
     TIA_SLOT_INIT(2)
     TIA_SLOT_INIT(3)
 #undef TIA_SLOT_INIT
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    bool ok0, ok1, ok2, ok3;
-    rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // branch-free A load: padding taps read a valid dummy address and are zeroed when the slice is written to LDS -- a
-    // conditional load would make the compiler wait for it right here, in front of the MFMA loop
+    const int bvoff = ((tid / BQ) * d.cout + 4 * (tid % BQ)) * 4;  // B: row tid / BQ (+ NTH / BQ per further slot), one float4
+    const int brow_step = (NTH / BQ) * d.cout * 4;
+
+    // slice cursor (scalar): tap (kh, kw) and first channel c0 of the slice that is staged next
+    int s_kh = 0, s_kw = 0, s_c0 = 0;
+    u32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    rb2 = rb3 = u32x4{0u, 0u, 0u, 0u};
 #define TIA_LOAD_A(R)                                                                                         \
     {                                                                                                         \
-        const int iy = iy0_##R + kh, ix = ix0_##R + kw;                                                       \
-        ok##R = pvalid_##R && (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;                   \
-        const long pix = ok##R ? pbase_##R + (long)iy * d.w + ix : 0;                                         \
-        ra##R = *reinterpret_cast<const float4*>(x + (pix * d.cin + c0 + 4 * quad));                          \
+        const bool ok = (msk_##R & sel) == sel;                                                               \
+        ra##R = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? cen_##R + sdelta : OOB, 0, 0);                 \
     }
-#define TIA_LOAD_B(R)                                                                                         \
+#define TIA_LOAD_SLICE()                                                                                      \
     {                                                                                                         \
-        const int s = tid + NTH * R;                                                                          \
-        const int row = s / BQ, c4 = s - row * BQ;                                                            \
-        rb##R = *reinterpret_cast<const float4*>(wrow + (long)row * d.cout + 4 * c4);                         \
+        const int sdelta = ((s_kh * d.w + s_kw) * d.cin + s_c0) * 4;                                          \
+        const unsigned sel = (1u << s_kh) | (1u << (16 + s_kw));                                              \
+        const int swrow = (((s_kh * d.kw + s_kw) * d.cin + s_c0) * d.cout + n0) * 4;                          \
+        TIA_LOAD_A(0) TIA_LOAD_A(1) TIA_LOAD_A(2) TIA_LOAD_A(3)                                               \
+        rb0 = __builtin_amdgcn_raw_buffer_load_b128(rw, bvoff, swrow, 0);                                     \
+        rb1 = __builtin_amdgcn_raw_buffer_load_b128(rw, bvoff, swrow + brow_step, 0);                         \
+        if (B_PER_THREAD == 4) {                                                                              \
+            rb2 = __builtin_amdgcn_raw_buffer_load_b128(rw, bvoff, swrow + 2 * brow_step, 0);                 \
+            rb3 = __builtin_amdgcn_raw_buffer_load_b128(rw, bvoff, swrow + 3 * brow_step, 0);                 \
+        }                                                                                                     \
     }
-#define TIA_LOAD_SLICE(SIDX)                                                       \
-    {                                                                              \
-        const int tap = (SIDX) / slices_per_tap;                                   \
-        const int c0 = ((SIDX)-tap * slices_per_tap) * BK;                         \
-        const int kh = tap / d.kw, kw = tap - kh * d.kw;                           \
-        TIA_LOAD_A(0) TIA_LOAD_A(1) TIA_LOAD_A(2) TIA_LOAD_A(3)                    \
-        const float* wrow = wk + ((long)tap * d.cin + c0) * d.cout + n0;           \
-        TIA_LOAD_B(0) TIA_LOAD_B(1)                                                \
-        if (B_PER_THREAD == 4) { TIA_LOAD_B(2) TIA_LOAD_B(3) }                     \
+    // advance the cursor; past the last slice it stays there (the final iteration re-stages the last slice, so the loop
+    // body has no control flow around its loads)
+#define TIA_NEXT_SLICE()                                                                                      \
+    {                                                                                                         \
+        int c0 = s_c0 + BK, kw = s_kw, kh = s_kh;                                                             \
+        if (c0 == d.cin) { c0 = 0; ++kw; }                                                                    \
+        if (kw == d.kw) { kw = 0; ++kh; }                                                                     \
+        if (kh < d.kh) { s_c0 = c0; s_kw = kw; s_kh = kh; }                                                   \
     }
 #define TIA_STORE_A(R)                                                             \
     {                                                                              \
         float* dst = As + ((tid >> 3) + 32 * R) * LDA + 4 * quad;                  \
-        dst[0] = ok##R ? ra##R.x : 0.0f;                                           \
-        dst[1] = ok##R ? ra##R.y : 0.0f;                                           \
-        dst[2] = ok##R ? ra##R.z : 0.0f;                                           \
-        dst[3] = ok##R ? ra##R.w : 0.0f;                                           \
+        dst[0] = __uint_as_float(ra##R.x);                                         \
+        dst[1] = __uint_as_float(ra##R.y);                                         \
+        dst[2] = __uint_as_float(ra##R.z);                                         \
+        dst[3] = __uint_as_float(ra##R.w);                                         \
     }
 #define TIA_STORE_SLICE()                                                                       \
     {                                                                                           \
         TIA_STORE_A(0) TIA_STORE_A(1) TIA_STORE_A(2) TIA_STORE_A(3)                             \
-        *reinterpret_cast<float4*>(Bs + 4 * (tid + NTH * 0)) = rb0;                             \
-        *reinterpret_cast<float4*>(Bs + 4 * (tid + NTH * 1)) = rb1;                             \
+        *reinterpret_cast<u32x4*>(Bs + 4 * (tid + NTH * 0)) = rb0;                              \
+        *reinterpret_cast<u32x4*>(Bs + 4 * (tid + NTH * 1)) = rb1;                              \
         if (B_PER_THREAD == 4) {                                                                \
-            *reinterpret_cast<float4*>(Bs + 4 * (tid + NTH * 2)) = rb2;                         \
-            *reinterpret_cast<float4*>(Bs + 4 * (tid + NTH * 3)) = rb3;                         \
+            *reinterpret_cast<u32x4*>(Bs + 4 * (tid + NTH * 2)) = rb2;                          \
+            *reinterpret_cast<u32x4*>(Bs + 4 * (tid + NTH * 3)) = rb3;                          \
         }                                                                                       \
     }
 
@@ -134,40 +152,44 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
 
     const float* a_ptr = As + (wm * 64 + (lane & 31)) * LDA + (lane >> 5);
     const float* b_ptr = Bs + (lane >> 5) * BN + wn * (BN / 2) + (lane & 31);
+    const int n_slices = d.kh * d.kw * (d.cin / BK);
 
-    TIA_LOAD_SLICE(0)
+    TIA_LOAD_SLICE()
     TIA_STORE_SLICE()
     __syncthreads();
     for (int sidx = 0; sidx < n_slices; ++sidx) {
-        // always stage a "next" slice (the last iteration re-reads the final one): no control flow around the staging
-        // registers, and their loads stay in flight while the matrix cores work
-        const int nxt = sidx + 1 < n_slices ? sidx + 1 : sidx;
-        TIA_LOAD_SLICE(nxt)
+        TIA_NEXT_SLICE()
+        TIA_LOAD_SLICE()
         __builtin_amdgcn_sched_barrier(0);  // the loads are issued HERE, not sunk below the MFMAs by the scheduler
+        // fragments of k-step kk + 2 are fetched from LDS before the MFMAs of k-step kk are issued
+        float a[2][2], b[2][NTILE];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[2], b[NTILE];
+        for (int i = 0; i < 2; ++i) a[0][i] = a_ptr[i * 32 * LDA];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = a_ptr[i * 32 * LDA + kk];
+        for (int j = 0; j < NTILE; ++j) b[0][j] = b_ptr[j * 32];
 #pragma unroll
-            for (int j = 0; j < NTILE; ++j) b[j] = b_ptr[kk * BN + j * 32];
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int cur = ks & 1, nx = cur ^ 1;
+            if (ks + 1 < BK / 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[nx][i] = a_ptr[i * 32 * LDA + 2 * (ks + 1)];
+#pragma unroll
+                for (int j = 0; j < NTILE; ++j) b[nx][j] = b_ptr[2 * (ks + 1) * BN + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NTILE; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NTILE; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // pin the first use of the staged registers BEHIND the MFMA loop: otherwise the compiler hoists the padding selects
-        // (and with them the wait for the global loads) in front of the loop
-        asm volatile("" : "+v"(ra0.x), "+v"(ra0.y), "+v"(ra0.z), "+v"(ra0.w), "+v"(ra1.x), "+v"(ra1.y), "+v"(ra1.z), "+v"(ra1.w));
-        asm volatile("" : "+v"(ra2.x), "+v"(ra2.y), "+v"(ra2.z), "+v"(ra2.w), "+v"(ra3.x), "+v"(ra3.y), "+v"(ra3.z), "+v"(ra3.w));
         __syncthreads();
         TIA_STORE_SLICE()
         __syncthreads();
     }
 #undef TIA_LOAD_A
-#undef TIA_LOAD_B
 #undef TIA_LOAD_SLICE
+#undef TIA_NEXT_SLICE
 #undef TIA_STORE_A
 #undef TIA_STORE_SLICE
 
@@ -234,18 +256,30 @@ extern "C" int tia_conv2d_nhwc_f32(const float* d_x, const float* d_w_packed, co
     if (cin % BK != 0 || cout % 64 != 0) return TIA_ESIZE;
     if (((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_w_packed)) & 15) != 0) return TIA_EINVAL;
     const long ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
-    if (ho <= 0 || wo <= 0) return TIA_EINVAL;
-    const long m_total = n * ho * wo;
-    const long m_tiles = (m_total + BM - 1) / BM;
-    if (m_tiles > 0x7ffffff0L / 8 || n * h * w * cin > 0x7fffffffffffL) return TIA_ESIZE;
-    ConvDims d{(int)n, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)kh, (int)kw, (int)stride, (int)pad};
-    const long grid_x = ((m_tiles + 7) / 8) * 8;  // whole rounds over the 8 XCDs (surplus workgroups exit at once)
+    if (ho <= 0 || wo <= 0 || kh > 16 || kw > 16) return TIA_EINVAL;
+    // the kernel addresses its input with 32-bit byte offsets: images go in groups of < 2 GiB
+    const long image_bytes = h * w * cin * 4, w_bytes = kh * kw * cin * cout * 4;
+    if (image_bytes > 0x7fffffffL || w_bytes > 0x7fffffffL || ho * wo > 0x7fffffffL / 4) return TIA_ESIZE;
+    long group = 0x7fffffffL / image_bytes;
+    if (group * ho * wo > 0x7fffffffL / 2) group = 0x7fffffffL / 2 / (ho * wo);
+    if (group < 1) return TIA_ESIZE;
     hipStream_t st = (hipStream_t)stream;
-    if (cout % 128 == 0)
-        hipLaunchKernelGGL(conv_mfma_f32_kernel<128>, dim3((unsigned)grid_x, (unsigned)(cout / 128)), dim3(NTH), 0, st, d_x, d_w_packed,
-                           d_bias, d_residual, d_y, d, relu, (int)m_tiles);
-    else
-        hipLaunchKernelGGL(conv_mfma_f32_kernel<64>, dim3((unsigned)grid_x, (unsigned)(cout / 64)), dim3(NTH), 0, st, d_x, d_w_packed,
-                           d_bias, d_residual, d_y, d, relu, (int)m_tiles);
+    for (long first = 0; first < n; first += group) {
+        const long nb = n - first < group ? n - first : group;
+        const long m_total = nb * ho * wo;
+        const long m_tiles = (m_total + BM - 1) / BM;
+        ConvDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)kh, (int)kw, (int)stride, (int)pad,
+                   (unsigned)(nb * image_bytes), (unsigned)w_bytes};
+        const float* xg = d_x + first * h * w * cin;
+        const float* rg = d_residual ? d_residual + first * ho * wo * cout : nullptr;
+        float* yg = d_y + first * ho * wo * cout;
+        const long grid_x = ((m_tiles + 7) / 8) * 8;  // whole rounds over the 8 XCDs (surplus workgroups exit at once)
+        if (cout % 128 == 0)
+            hipLaunchKernelGGL(conv_mfma_f32_kernel<128>, dim3((unsigned)grid_x, (unsigned)(cout / 128)), dim3(NTH), 0, st, xg,
+                               d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles);
+        else
+            hipLaunchKernelGGL(conv_mfma_f32_kernel<64>, dim3((unsigned)grid_x, (unsigned)(cout / 64)), dim3(NTH), 0, st, xg,
+                               d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles);
+    }
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
