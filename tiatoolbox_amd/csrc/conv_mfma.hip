@@ -10,7 +10,12 @@
 //   * A slice (128 x 32) staged in LDS row-major with 33-dword rows: MFMA lane i reads row i, bank (33 i + k) % 32 --
 //     conflict-free without transposing the NHWC run; B slice (32 x BN, weights pre-packed [tap][cin][cout]) is read
 //     along cout, contiguous per lane
-//   * the next slice's global loads are issued before the MFMA loop of the current one (register staging)
+//   * the next slice's global loads are issued before the MFMA loop of the current one (register staging), through buffer
+//     descriptors: per slice a slot costs an AND, a compare, an add and a select (the per-pixel part is computed once),
+//     and the bounds check zero-fills padding taps
+//   * measured and rejected on MI355X (profiles/r02h_perf_conv_v*.txt): double-buffered LDS with the staging write in the
+//     middle of the MFMA loop and one barrier per slice (2 workgroups / CU instead of 3: -5 %), s_setprio around the MFMA
+//     phase (-4 %), 256 x 64 tiles for cout = 64 (-3 %), forcing 4 / 6 waves per SIMD by register cap (spills: -1 / -13 %)
 //   * blockIdx is remapped so that each XCD (its own L2) walks a contiguous range of pixel tiles: neighbouring tiles
 //     share their input halo rows
 #include <hip/hip_runtime.h>
