@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(const int* __restrict
                                                             const int* __restrict__ areas, const int* __restrict__ offs,
                                                             const int* __restrict__ count, const int* __restrict__ bbox, int h,
                                                             int w, int min_keep, HeapItem* __restrict__ heaps,
-                                                            int* __restrict__ inst) {
+                                                            const int* __restrict__ done, int* __restrict__ inst) {
     const long hw = (long)h * w;
     const int plane = blockIdx.x;  // plane fastest: consecutive workgroups (= consecutive XCDs) take different planes
     const int lane = threadIdx.x;
@@ -443,6 +443,7 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(const int* __restrict
     for (int label = blockIdx.y + 1; label <= n_labels; label += gridDim.y) {
         const int area = areas[(size_t)plane * (hw + 1) + label];
         if (area < min_keep) continue;
+        if (done && done[(size_t)plane * (hw + 1) + label]) continue;  // settled by ws_relax_wave_kernel
         const size_t off = (size_t)plane * hw;
         const int* bl = blob + off;
         const double* ds = dist + off;
@@ -592,6 +593,176 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(const int* __restrict
     }
 }
 
+// ---- watershed by minimax relaxation, one wave per blob, all lanes working ---------------------------------------------
+// The priority flood labels an unlabelled pixel n at the pop of its FIRST-popped neighbour, and pops follow (value, age).
+// Let L(p) = the highest value on p's claim chain back to its marker pixel (L = own value for marker pixels); it equals
+// the minimax path value from the markers, so it does not depend on how ties are broken.  A neighbour with strictly
+// smaller L pops strictly earlier (everything on its chain lies below the other chain's highest pixel, which therefore
+// cannot reach the front of the queue first), hence n's claimer is one of its minimum-L neighbours.  So: relax
+// (L, D, label) over the unlabelled pixels until nothing changes -- each takes its neighbour with the smallest (L, D),
+// L(n) = max(value(n), L), D = hops since the chain's highest pixel (strictly growing along a chain, which keeps the
+// parent pointers acyclic inside equal-L regions) -- and then CHECK every unlabelled pixel: if all its minimum-L
+// neighbours carry its own label, induction over the true pop order shows the flood produces exactly this labelling,
+// whatever the tie-breaks.  If some pixel has two minimum-L neighbours with different labels (an exact tie that the
+// heap's age / arrangement would decide), the blob is left untouched and flagged for the sequential heap flood below.
+// tests/test_flood_relaxation_model.py checks the argument on a NumPy model against the oracle; on HoVer-Net maps no blob
+// needs the fallback.  State lives in two plane-sized arrays (L as f64 bits; D and label packed), read and written with
+// agent-scope relaxed atomics so that a lane sees what another lane of its wave stored in an earlier pass.
+__device__ __forceinline__ unsigned long long relax_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void relax_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct RelaxNb {
+    double l;
+    int d, lab;
+};
+// state of neighbour q of a pixel as the relaxation sees it: marker pixels are sources (L = own value, D = 0)
+__device__ __forceinline__ RelaxNb relax_neighbour(bool inb, long q, const int* __restrict__ out, const double* __restrict__ ds,
+                                                   const unsigned long long* stl, const unsigned long long* stdl) {
+    const int o = out[q];
+    const double dq = ds[q];
+    const unsigned long long lq = relax_load(stl + q), dlq = relax_load(stdl + q);
+    RelaxNb r;
+    const bool marker = inb && o > 0, open = inb && o < 0;
+    r.l = marker ? dq : (open ? __longlong_as_double((long long)lq) : __builtin_huge_val());
+    r.d = marker ? 0 : (int)(unsigned)(dlq >> 32);
+    r.lab = marker ? o : (int)(unsigned)dlq;
+    return r;
+}
+__global__ __launch_bounds__(64) void ws_relax_wave_kernel(const int* __restrict__ blob, const double* __restrict__ dist,
+                                                            const int* __restrict__ areas, const int* __restrict__ offs,
+                                                            const int* __restrict__ count, const int* __restrict__ bbox, int h,
+                                                            int w, int min_keep, HeapItem* __restrict__ heaps,
+                                                            unsigned long long* __restrict__ st_l,
+                                                            unsigned long long* __restrict__ st_dl, int* __restrict__ done,
+                                                            int* __restrict__ inst) {
+    const long hw = (long)h * w;
+    const int plane = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n_labels = count[plane];
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long inf_bits = (unsigned long long)__double_as_longlong(__builtin_huge_val());
+    for (int label = blockIdx.y + 1; label <= n_labels; label += gridDim.y) {
+        const size_t slot = (size_t)plane * (hw + 1) + label;
+        if (areas[slot] < min_keep) continue;
+        const size_t off = (size_t)plane * hw;
+        const int* bl = blob + off;
+        const double* ds = dist + off;
+        int* out = inst + off;
+        unsigned long long* stl = st_l + off;
+        unsigned long long* stdl = st_dl + off;
+        int* list = reinterpret_cast<int*>(heaps + off + offs[slot]);  // the blob's heap segment holds the pixel list meanwhile
+        const int* bb = bbox + slot * 4;
+        const int y0 = bb[0], y1 = bb[1], x0 = bb[2], x1 = bb[3];
+        // 1. the blob's unlabelled pixels in raster order; are there markers at all?
+        int n_open = 0;
+        bool any_marker = false;
+        for (int y = y0; y <= y1; ++y) {
+            for (int xb = x0; xb <= x1; xb += 64) {
+                const int x = xb + lane;
+                const long i = (long)y * w + x;
+                const bool mine = x <= x1 && bl[i] == label;
+                const int o = mine ? out[i] : 0;
+                any_marker = any_marker || __ballot(o > 0) != 0ull;
+                const bool open = o < 0;
+                const unsigned long long m = __ballot(open);
+                if (open) {
+                    __hip_atomic_store(list + n_open + __builtin_popcountll(m & lt_mask), (int)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    relax_store(stl + i, inf_bits);
+                    relax_store(stdl + i, 0ull);
+                }
+                n_open += __builtin_popcountll(m);
+            }
+        }
+        if (!any_marker) {  // a blob without markers stays background
+            for (int k = lane; k < n_open; k += 64) out[__hip_atomic_load(list + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = 0;
+            if (lane == 0) done[slot] = 1;
+            continue;
+        }
+        if (n_open == 0) {
+            if (lane == 0) done[slot] = 1;
+            continue;
+        }
+        // 2. relax until a whole sweep changes nothing (raster order inside a sweep: Gauss-Seidel between passes)
+        bool failed = false;
+        for (int sweep = 0;; ++sweep) {
+            bool changed = false;
+            for (int base = 0; base < n_open; base += 64) {
+                const int k = base + lane;
+                const bool active = k < n_open;
+                const long p = __hip_atomic_load(list + (active ? k : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int y = (int)(p / w), x = (int)(p - (long)y * w);
+                const double v = ds[p];
+                const unsigned long long cur_l = relax_load(stl + p), cur_dl = relax_load(stdl + p);
+                double best_l = __builtin_huge_val();
+                int best_d = 0, best_lab = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // up, left, right, down
+                    const int yy = y + (j == 0 ? -1 : (j == 3 ? 1 : 0));
+                    const int xx = x + (j == 1 ? -1 : (j == 2 ? 1 : 0));
+                    const bool inb = yy >= 0 && yy < h && xx >= 0 && xx < w;
+                    const RelaxNb nb = relax_neighbour(inb, inb ? (long)yy * w + xx : p, out, ds, stl, stdl);
+                    const bool better = nb.l < best_l || (nb.l == best_l && nb.l < __builtin_huge_val() && nb.d < best_d);
+                    best_l = better ? nb.l : best_l;
+                    best_d = better ? nb.d : best_d;
+                    best_lab = better ? nb.lab : best_lab;
+                }
+                const bool up = v > best_l;
+                const double new_l = up ? v : best_l;
+                const int new_d = up ? 0 : best_d + 1;
+                const unsigned long long new_lb = (unsigned long long)__double_as_longlong(new_l);
+                const unsigned long long new_dl = ((unsigned long long)(unsigned)new_d << 32) | (unsigned)best_lab;
+                const bool ch = active && best_l < __builtin_huge_val() && (new_lb != cur_l || new_dl != cur_dl);
+                if (ch) {
+                    relax_store(stl + p, new_lb);
+                    relax_store(stdl + p, new_dl);
+                }
+                changed = changed || __ballot(ch) != 0ull;
+            }
+            if (!changed) break;
+            if (sweep > n_open + 8) {  // cannot happen (Bellman-Ford bound); leave the blob to the heap flood
+                failed = true;
+                break;
+            }
+        }
+        // 3. every unlabelled pixel: reached, and all its minimum-L neighbours carry its label?
+        for (int base = 0; base < n_open && !failed; base += 64) {
+            const int k = base + lane;
+            const bool active = k < n_open;
+            const long p = __hip_atomic_load(list + (active ? k : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int y = (int)(p / w), x = (int)(p - (long)y * w);
+            const unsigned long long cur_l = relax_load(stl + p), cur_dl = relax_load(stdl + p);
+            const int my_lab = (int)(unsigned)cur_dl;
+            RelaxNb nb[4];
+            double min_l = __builtin_huge_val();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yy = y + (j == 0 ? -1 : (j == 3 ? 1 : 0));
+                const int xx = x + (j == 1 ? -1 : (j == 2 ? 1 : 0));
+                const bool inb = yy >= 0 && yy < h && xx >= 0 && xx < w;
+                nb[j] = relax_neighbour(inb, inb ? (long)yy * w + xx : p, out, ds, stl, stdl);
+                min_l = nb[j].l < min_l ? nb[j].l : min_l;
+            }
+            bool bad = cur_l == inf_bits || my_lab <= 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bad = bad || (nb[j].l == min_l && nb[j].lab != my_lab);
+            failed = __ballot(active && bad) != 0ull;
+        }
+        if (failed) {
+            if (lane == 0) done[slot] = 0;
+            continue;
+        }
+        // 4. commit
+        for (int k = lane; k < n_open; k += 64) {
+            const int p = __hip_atomic_load(list + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[p] = (int)(unsigned)relax_load(stdl + p);
+        }
+        if (lane == 0) done[slot] = 1;
+    }
+}
+
 // ---- instance statistics ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HT) void inst_stats_init_kernel(long long* __restrict__ stats, long n_entries) {
     for (long i = (long)blockIdx.x * HT + threadIdx.x; i < n_entries; i += (long)gridDim.x * HT) {
@@ -709,8 +880,10 @@ extern "C" size_t tia_hover_workspace_bytes(int64_t n, int64_t h, int64_t w) {
 
 // watershed(image, markers, mask = blob labels > 0): ws_init + one priority flood per blob.  `areas` = per-label pixel
 // counts of blob_lab ([n][hw+1]), `offs` = their exclusive scan (heap segment offsets), min_keep = smallest blob kept.
+// `relax_l` / `relax_dl` ([n][hw] 64-bit words each) and `done` ([n][hw+1] ints) serve the relaxation pass.
 static int launch_watershed(const int* blob_lab, const int* mark_lab, const double* dist, const int* areas, const int* offs,
-                            const int* cnt_blob, int* bbox, HeapItem* heaps, int* d_inst, long n, int h, int w, int min_keep,
+                            const int* cnt_blob, int* bbox, HeapItem* heaps, unsigned long long* relax_l,
+                            unsigned long long* relax_dl, int* done, int* d_inst, long n, int h, int w, int min_keep,
                             hipStream_t st) {
     const long hw = (long)h * w;
     dim3 grid(hblocks(hw), (unsigned)n);
@@ -722,11 +895,19 @@ static int launch_watershed(const int* blob_lab, const int* mark_lab, const doub
         const char* e = getenv("TIA_FLOOD_WAVE");  // developer switch: 0 = one lane per blob
         return e ? atoi(e) : 1;
     }();
+    static const int relax = [] {
+        const char* e = getenv("TIA_FLOOD_RELAX");  // developer switch: 0 = sequential heap flood for every blob
+        return e ? atoi(e) : 1;
+    }();
     if (wave_per_blob) {
         long wy = max_labels < 4096 ? max_labels : 4096, wcap = 262144 / n > 16 ? 262144 / n : 16;
         dim3 wgrid((unsigned)n, (unsigned)(wy < wcap ? wy : wcap));
+        // all blobs by parallel relaxation; the (rare) blobs whose labelling hinges on an exact tie are left to the heap
+        if (relax)
+            hipLaunchKernelGGL(ws_relax_wave_kernel, wgrid, dim3(64), 0, st, blob_lab, dist, areas, offs, cnt_blob, bbox, h, w,
+                               min_keep, heaps, relax_l, relax_dl, done, d_inst);
         hipLaunchKernelGGL(ws_flood_wave_kernel, wgrid, dim3(64), 0, st, blob_lab, dist, areas, offs, cnt_blob, bbox, h, w,
-                           min_keep, heaps, d_inst);
+                           min_keep, heaps, relax ? done : nullptr, d_inst);
     } else {
         hipLaunchKernelGGL(ws_flood_kernel, fgrid, dim3(64), 0, st, blob_lab, dist, areas, offs, cnt_blob, bbox, h, w,
                            min_keep, heaps, d_inst);
@@ -836,8 +1017,9 @@ static int hover_proc_impl(const float* d_np, const float* d_hv, int64_t n, int6
     if (taps.blobs)
         hipLaunchKernelGGL(blob_indicator_kernel, dim3(hblocks((long)n * hw, HT, 65535)), dim3(HT), 0, st, blob_lab, (long)n * hw,
                            taps.blobs);
-    return launch_watershed(blob_lab, mark_lab, dist, ws_int, offs, cnt_blob, bbox, heaps, d_inst, (long)n, (int)h, (int)w, 10,
-                            st);
+    // the Sobel planes and the row buffer are free by now: relaxation state and per-blob flags
+    return launch_watershed(blob_lab, mark_lab, dist, ws_int, offs, cnt_blob, bbox, heaps, (unsigned long long*)sob_h,
+                            (unsigned long long*)sob_v, (int*)rowbuf, d_inst, (long)n, (int)h, (int)w, 10, st);
 }
 
 extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, int64_t n, int64_t h, int64_t w,
@@ -856,7 +1038,7 @@ extern "C" int tia_hover_proc_np_hv_stages_f32(const float* d_np, const float* d
 
 // ---- stand-alone marker-controlled watershed ---------------------------------------------------------------------------
 struct WatershedWs {
-    size_t total, blob_lab, ws_int, bbox, offs, cnt, heaps;
+    size_t total, blob_lab, ws_int, bbox, offs, cnt, heaps, relax_l, relax_dl, done;
 };
 static WatershedWs watershed_layout(long n, long hw) {
     WatershedWs L{};
@@ -872,6 +1054,9 @@ static WatershedWs watershed_layout(long n, long hw) {
     L.offs = take((size_t)n * (hw + 1) * 4);
     L.cnt = take((size_t)n * 4 * 2);
     L.heaps = take((size_t)n * hw * sizeof(HeapItem));
+    L.relax_l = take((size_t)n * hw * 8);
+    L.relax_dl = take((size_t)n * hw * 8);
+    L.done = take((size_t)n * (hw + 1) * 4);
     L.total = o;
     return L;
 }
@@ -904,7 +1089,8 @@ extern "C" int tia_watershed_blobs_f64(const double* d_image, const int32_t* d_m
     if (rc != TIA_OK) return rc;
     hipLaunchKernelGGL(bbox_reset_kernel, dim3(hblocks((long)n * (hw + 1), HT, 65535)), dim3(HT), 0, st, bbox, (long)n * (hw + 1));
     hipLaunchKernelGGL(ws_offsets_kernel, dim3((unsigned)n), dim3(1024), 0, st, ws_int, cnt, hw, 1, offs);
-    return launch_watershed(blob_lab, d_markers, d_image, ws_int, offs, cnt, bbox, heaps, d_out, (long)n, (int)h, (int)w, 1, st);
+    return launch_watershed(blob_lab, d_markers, d_image, ws_int, offs, cnt, bbox, heaps, (unsigned long long*)(base + L.relax_l),
+                            (unsigned long long*)(base + L.relax_dl), (int*)(base + L.done), d_out, (long)n, (int)h, (int)w, 1, st);
 }
 
 extern "C" int tia_hover_instance_stats(const int32_t* d_inst, const uint8_t* d_type, int64_t n, int64_t h, int64_t w,
