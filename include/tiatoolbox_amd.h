@@ -2,6 +2,11 @@
  * tiatoolbox_amd -- C ABI of the MI355X (gfx950) hot-path library  (libtiatoolbox_amd.so)
  *
  * Every entry point takes raw DEVICE pointers + sizes + a hipStream_t (passed as void*).
+ * Naming convention: `d_*` arguments are device pointers (data planes, workspaces, outputs);
+ * small parameter blocks that are read on the host while the call is being enqueued are
+ * passed by `const` pointer WITHOUT the prefix (`params`, `h_target_stain`, `target_means`,
+ * `target_stds`; each is marked "host" where it is declared) -- they play the role of
+ * by-value arguments and are copied at launch.
  * No allocation, no synchronisation, no exceptions cross this boundary; each call
  * enqueues kernels on `stream` and returns 0 (TIA_OK) or a negative TIA_E* code.
  *
@@ -129,7 +134,7 @@ int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
  */
 int tia_stain_apply_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
                        const tia_stain_tables* d_tables, const double* d_stats,
-                       const double* target_stain /* host, [6] */, void* d_out, int32_t out_kind,
+                       const double* h_target_stain /* host parameter block, double[6] */, void* d_out, int32_t out_kind,
                        int32_t math, void* stream);
 
 /*

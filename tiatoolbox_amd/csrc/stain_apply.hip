@@ -618,14 +618,14 @@ extern "C" int tia_abi_version(void) { return TIA_ABI_VERSION; }
 
 extern "C" int tia_stain_apply_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
                                    const tia_stain_tables* d_tables, const double* d_stats,
-                                   const double* target_stain, void* d_out, int32_t out_kind,
+                                   const double* h_target_stain, void* d_out, int32_t out_kind,
                                    int32_t math, void* stream) {
     if (!d_img || !d_tables || !d_stats || !d_out) return TIA_EINVAL;
     if (bad_dims(n, h, w)) return n > 65535 ? TIA_ESIZE : TIA_EINVAL;
     tia::StainT tgt{};
     if (math == TIA_MATH_F64) {
-        if (!target_stain) return TIA_EINVAL;
-        for (int i = 0; i < 6; ++i) tgt.s[i] = target_stain[i];
+        if (!h_target_stain) return TIA_EINVAL;
+        for (int i = 0; i < 6; ++i) tgt.s[i] = h_target_stain[i];
         return tia::launch_apply<TIA_MATH_F64>(d_img, n, (long)h * w, d_tables, d_stats, tgt, d_out,
                                                out_kind, (hipStream_t)stream);
     }
