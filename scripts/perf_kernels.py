@@ -108,6 +108,18 @@ def sec_hover():
     i1, n1 = hd.proc_np_hv(a, b)
     report("hover proc_np_hv, one 1000^2 tile", timeit(lambda: hd.proc_np_hv(a, b), reps=5, warm=1), 20 * 1000 * 1000,
            instances=int(n1.sum()))
+    # head maps that look like noise (what a random-weight network emits): a few huge blobs per tile
+    from scipy import ndimage
+
+    rng = np.random.default_rng(0)
+    npn = np.stack([ndimage.gaussian_filter(rng.standard_normal((h, w)), 5.0) for _ in range(8)])
+    npn = (npn / np.abs(npn).max() * 0.5 + 0.55).astype(np.float32)[..., None]
+    hvn = np.stack([ndimage.gaussian_filter(rng.standard_normal((h, w, 2)), (3.0, 3.0, 0)) for _ in range(8)])
+    hvn = (hvn / np.abs(hvn).max()).astype(np.float32)
+    an, bn = torch.from_numpy(npn).cuda().repeat(rep, 1, 1, 1), torch.from_numpy(hvn).cuda().repeat(rep, 1, 1, 1)
+    i2, n2 = hd.proc_np_hv(an, bn)
+    report("hover proc_np_hv, 256x164^2 noise-like maps (huge blobs)", timeit(lambda: hd.proc_np_hv(an, bn), reps=3, warm=1),
+           20 * px, instances=int(n2.sum()))
 
 
 def sec_canvas():

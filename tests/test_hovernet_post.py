@@ -270,6 +270,63 @@ def test_hip_watershed_forced_ties_match_skimage_heap():
 
 
 @pytest.mark.gpu
+def test_hip_watershed_relaxation_paths_match_the_priority_flood():
+    """The three routes of the device watershed against ``oracle.skref.watershed``: blobs of more than 4096 pixels (one
+    1024-thread workgroup relaxes them), a long one-pixel-wide serpentine corridor (the relaxation runs out of its pass budget and the
+    blob goes to the heap flood), and a quantised plateau field in one large blob (exact ties -> flagged -> heap)."""
+    import torch
+    from scipy import ndimage
+
+    from oracle import skref
+    from tiatoolbox_amd.models.architecture import _hover_device as hd
+
+    def run(img, mk, mask):
+        got = hd.watershed(torch.from_numpy(img).cuda(), torch.from_numpy(mk).cuda(), torch.from_numpy(mask).cuda())
+        return got.cpu().numpy()
+
+    rng = np.random.default_rng(11)
+    # (a) one big blob (~14k px) plus small ones, smooth tie-free values, 25 markers
+    h, w = 128, 144
+    img = ndimage.gaussian_filter(rng.standard_normal((h, w)), 3.0)
+    mask = np.zeros((h, w), bool)
+    mask[4:110, 6:140] = True
+    mask[60:64, :] = True
+    mask[116:126, 10:30] = True
+    mask[116:126, 40:45] = True
+    seeds = np.zeros((h, w), bool)
+    seeds.ravel()[rng.choice(h * w, 40, replace=False)] = True
+    mk = ndimage.label(ndimage.binary_dilation(seeds, iterations=1) & mask)[0].astype(np.int32)
+    assert (ndimage.label(mask)[0] == ndimage.label(mask)[0][50, 50]).sum() > 4096
+    assert np.array_equal(run(img, mk, mask), skref.watershed(img, mk, mask))
+    # (b) serpentine corridor, one pixel wide, two markers at its ends: chain length ~ area
+    n = 41
+    mask = np.zeros((n, n), bool)
+    mask[0::2, :] = True
+    for r in range(1, n, 2):
+        mask[r, n - 1 if (r // 2) % 2 == 0 else 0] = True
+    assert ndimage.label(mask)[1] == 1
+    img = rng.random((n, n))
+    mk = np.zeros((n, n), np.int32)
+    mk[0, 0] = 1
+    mk[n - 1, n - 1 if ((n - 1) // 2) % 2 == 0 else 0] = 2
+    assert np.array_equal(run(img, mk, mask), skref.watershed(img, mk, mask))
+    # (c) plateaus: exact ties inside one large blob
+    h, w = 96, 96
+    img = np.round(ndimage.gaussian_filter(rng.standard_normal((h, w)), 2.0) * 6) / 6
+    mask = np.ones((h, w), bool)
+    mk = np.zeros((h, w), np.int32)
+    mk.ravel()[rng.choice(h * w, 9, replace=False)] = np.arange(1, 10)
+    assert np.array_equal(run(img, mk, mask), skref.watershed(img, mk, mask))
+    # (d) a batch mixing the cases' plane shapes is covered by the forced-tie test; here: big blob + ties in one batch
+    imgs = np.stack([img, ndimage.gaussian_filter(rng.standard_normal((h, w)), 2.0)])
+    mks = np.stack([mk, mk])
+    masks = np.stack([mask, mask])
+    got = run(imgs, mks, masks)
+    for i in range(2):
+        assert np.array_equal(got[i], skref.watershed(imgs[i], mks[i], masks[i])), i
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize(("ksize", "scale"), [(21, 1), (11, 0.5)])
 def test_hip_stage_planes_vs_oracle(ksize, scale):
     """Intermediate planes of ``_proc_np_hv`` (raw Sobel, distance map, labelled markers, blb) against the oracle's

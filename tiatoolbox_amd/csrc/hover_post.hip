@@ -631,22 +631,35 @@ __device__ __forceinline__ RelaxNb relax_neighbour(bool inb, long q, const int* 
     r.lab = marker ? o : (int)(unsigned)dlq;
     return r;
 }
-__global__ __launch_bounds__(64) void ws_relax_wave_kernel(const int* __restrict__ blob, const double* __restrict__ dist,
-                                                            const int* __restrict__ areas, const int* __restrict__ offs,
-                                                            const int* __restrict__ count, const int* __restrict__ bbox, int h,
-                                                            int w, int min_keep, HeapItem* __restrict__ heaps,
-                                                            unsigned long long* __restrict__ st_l,
-                                                            unsigned long long* __restrict__ st_dl, int* __restrict__ done,
-                                                            int* __restrict__ inst) {
+// NT = 64: one wave per blob (blobs of up to RELAX_BIG pixels); NT = 1024: one workgroup per bigger blob.  Sweeps
+// alternate between raster and reverse raster order; a blob whose relaxation has cost more passes than the heap flood
+// would have (long thin chains) is abandoned to the heap as well.
+constexpr int RELAX_BIG = 4096;
+template <int NT>
+__global__ __launch_bounds__(NT) void ws_relax_kernel(const int* __restrict__ blob, const double* __restrict__ dist,
+                                                       const int* __restrict__ areas, const int* __restrict__ offs,
+                                                       const int* __restrict__ count, const int* __restrict__ bbox, int h, int w,
+                                                       int min_keep, HeapItem* __restrict__ heaps,
+                                                       unsigned long long* __restrict__ st_l,
+                                                       unsigned long long* __restrict__ st_dl, int* __restrict__ done,
+                                                       int* __restrict__ inst) {
+    constexpr bool BLOCK = NT > 64;
+    __shared__ int sh_count, sh_marker;
     const long hw = (long)h * w;
     const int plane = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int n_labels = count[plane];
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const unsigned long long inf_bits = (unsigned long long)__double_as_longlong(__builtin_huge_val());
+    // "does any thread of the group say yes" -- a ballot for one wave, a barrier reduction for a workgroup
+    auto any_of = [&](bool v) -> bool {
+        if constexpr (BLOCK) return __syncthreads_or(v ? 1 : 0) != 0;
+        else return __ballot(v) != 0ull;
+    };
     for (int label = blockIdx.y + 1; label <= n_labels; label += gridDim.y) {
         const size_t slot = (size_t)plane * (hw + 1) + label;
-        if (areas[slot] < min_keep) continue;
+        const int area = areas[slot];
+        if (area < min_keep || (area > RELAX_BIG) != BLOCK) continue;
         const size_t off = (size_t)plane * hw;
         const int* bl = blob + off;
         const double* ds = dist + off;
@@ -656,43 +669,77 @@ __global__ __launch_bounds__(64) void ws_relax_wave_kernel(const int* __restrict
         int* list = reinterpret_cast<int*>(heaps + off + offs[slot]);  // the blob's heap segment holds the pixel list meanwhile
         const int* bb = bbox + slot * 4;
         const int y0 = bb[0], y1 = bb[1], x0 = bb[2], x1 = bb[3];
-        // 1. the blob's unlabelled pixels in raster order; are there markers at all?
+        // 1. the blob's unlabelled pixels (raster order for one wave; any order for a workgroup); are there markers at all?
         int n_open = 0;
         bool any_marker = false;
-        for (int y = y0; y <= y1; ++y) {
-            for (int xb = x0; xb <= x1; xb += 64) {
-                const int x = xb + lane;
-                const long i = (long)y * w + x;
-                const bool mine = x <= x1 && bl[i] == label;
+        if constexpr (BLOCK) {
+            if (tid == 0) sh_count = 0, sh_marker = 0;
+            __syncthreads();
+            const int bw = x1 - x0 + 1;
+            const long box = (long)(y1 - y0 + 1) * bw;
+            for (long base = 0; base < box; base += NT) {  // uniform trip count
+                const long t = base + tid;
+                const int yy = (int)(t / bw), xx = (int)(t - (long)yy * bw);
+                const long i = (long)(y0 + yy) * w + x0 + xx;
+                const bool mine = t < box && bl[i] == label;
                 const int o = mine ? out[i] : 0;
-                any_marker = any_marker || __ballot(o > 0) != 0ull;
                 const bool open = o < 0;
                 const unsigned long long m = __ballot(open);
+                int wbase = 0;
+                if (lane == 0 && m) wbase = atomicAdd(&sh_count, __builtin_popcountll(m));
+                wbase = __shfl(wbase, 0);
                 if (open) {
-                    __hip_atomic_store(list + n_open + __builtin_popcountll(m & lt_mask), (int)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(list + wbase + __builtin_popcountll(m & lt_mask), (int)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     relax_store(stl + i, inf_bits);
                     relax_store(stdl + i, 0ull);
                 }
-                n_open += __builtin_popcountll(m);
+                const unsigned long long mk = __ballot(o > 0);
+                if (lane == 0 && mk) sh_marker = 1;
+            }
+            __syncthreads();
+            n_open = sh_count;
+            any_marker = sh_marker != 0;
+            __syncthreads();  // sh_* are reset by the next big blob
+        } else {
+            for (int y = y0; y <= y1; ++y) {
+                for (int xb = x0; xb <= x1; xb += 64) {
+                    const int x = xb + lane;
+                    const long i = (long)y * w + x;
+                    const bool mine = x <= x1 && bl[i] == label;
+                    const int o = mine ? out[i] : 0;
+                    any_marker = any_marker || __ballot(o > 0) != 0ull;
+                    const bool open = o < 0;
+                    const unsigned long long m = __ballot(open);
+                    if (open) {
+                        __hip_atomic_store(list + n_open + __builtin_popcountll(m & lt_mask), (int)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        relax_store(stl + i, inf_bits);
+                        relax_store(stdl + i, 0ull);
+                    }
+                    n_open += __builtin_popcountll(m);
+                }
             }
         }
         if (!any_marker) {  // a blob without markers stays background
-            for (int k = lane; k < n_open; k += 64) out[__hip_atomic_load(list + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = 0;
-            if (lane == 0) done[slot] = 1;
+            for (int k = tid; k < n_open; k += NT) out[__hip_atomic_load(list + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = 0;
+            if (tid == 0) done[slot] = 1;
             continue;
         }
         if (n_open == 0) {
-            if (lane == 0) done[slot] = 1;
+            if (tid == 0) done[slot] = 1;
             continue;
         }
-        // 2. relax until a whole sweep changes nothing (raster order inside a sweep: Gauss-Seidel between passes)
+        // 2. relax until a whole sweep changes nothing
         bool failed = false;
+        // a pass costs about one memory round trip, like a pop of the heap flood: past 2 x area passes the heap is cheaper
+        const long budget = 2L * area + 64;
+        long passes = 0;
         for (int sweep = 0;; ++sweep) {
             bool changed = false;
-            for (int base = 0; base < n_open; base += 64) {
-                const int k = base + lane;
-                const bool active = k < n_open;
-                const long p = __hip_atomic_load(list + (active ? k : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int base = 0; base < n_open; base += NT) {
+                const int k0 = base + tid;
+                const bool active = k0 < n_open;
+                const int k = !active ? 0 : ((sweep & 1) ? n_open - 1 - k0 : k0);
+                const long p = __hip_atomic_load(list + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int y = (int)(p / w), x = (int)(p - (long)y * w);
                 const double v = ds[p];
                 const unsigned long long cur_l = relax_load(stl + p), cur_dl = relax_load(stdl + p);
@@ -719,17 +766,19 @@ __global__ __launch_bounds__(64) void ws_relax_wave_kernel(const int* __restrict
                     relax_store(stl + p, new_lb);
                     relax_store(stdl + p, new_dl);
                 }
-                changed = changed || __ballot(ch) != 0ull;
+                changed = changed || ch;
             }
-            if (!changed) break;
-            if (sweep > n_open + 8) {  // cannot happen (Bellman-Ford bound); leave the blob to the heap flood
+            passes += (n_open + NT - 1) / NT;
+            if (!any_of(changed)) break;  // (a workgroup's barrier also orders this sweep's stores before the next sweep's loads)
+            if (passes > budget) {
                 failed = true;
                 break;
             }
         }
         // 3. every unlabelled pixel: reached, and all its minimum-L neighbours carry its label?
-        for (int base = 0; base < n_open && !failed; base += 64) {
-            const int k = base + lane;
+        bool bad_any = false;
+        for (int base = 0; base < n_open && !failed; base += NT) {
+            const int k = base + tid;
             const bool active = k < n_open;
             const long p = __hip_atomic_load(list + (active ? k : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int y = (int)(p / w), x = (int)(p - (long)y * w);
@@ -748,18 +797,19 @@ __global__ __launch_bounds__(64) void ws_relax_wave_kernel(const int* __restrict
             bool bad = cur_l == inf_bits || my_lab <= 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) bad = bad || (nb[j].l == min_l && nb[j].lab != my_lab);
-            failed = __ballot(active && bad) != 0ull;
+            bad_any = bad_any || (active && bad);
         }
+        if (!failed) failed = any_of(bad_any);
         if (failed) {
-            if (lane == 0) done[slot] = 0;
+            if (tid == 0) done[slot] = 0;
             continue;
         }
         // 4. commit
-        for (int k = lane; k < n_open; k += 64) {
+        for (int k = tid; k < n_open; k += NT) {
             const int p = __hip_atomic_load(list + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out[p] = (int)(unsigned)relax_load(stdl + p);
         }
-        if (lane == 0) done[slot] = 1;
+        if (tid == 0) done[slot] = 1;
     }
 }
 
@@ -903,9 +953,15 @@ static int launch_watershed(const int* blob_lab, const int* mark_lab, const doub
         long wy = max_labels < 4096 ? max_labels : 4096, wcap = 262144 / n > 16 ? 262144 / n : 16;
         dim3 wgrid((unsigned)n, (unsigned)(wy < wcap ? wy : wcap));
         // all blobs by parallel relaxation; the (rare) blobs whose labelling hinges on an exact tie are left to the heap
-        if (relax)
-            hipLaunchKernelGGL(ws_relax_wave_kernel, wgrid, dim3(64), 0, st, blob_lab, dist, areas, offs, cnt_blob, bbox, h, w,
+        if (relax) {
+            hipLaunchKernelGGL(ws_relax_kernel<64>, wgrid, dim3(64), 0, st, blob_lab, dist, areas, offs, cnt_blob, bbox, h, w,
                                min_keep, heaps, relax_l, relax_dl, done, d_inst);
+            if (hw > RELAX_BIG) {  // blobs of more than RELAX_BIG pixels: one 1024-thread workgroup each
+                const long by = hw / RELAX_BIG < 64 ? hw / RELAX_BIG : 64;
+                hipLaunchKernelGGL(ws_relax_kernel<1024>, dim3((unsigned)n, (unsigned)(by < 1 ? 1 : by)), dim3(1024), 0, st, blob_lab,
+                                   dist, areas, offs, cnt_blob, bbox, h, w, min_keep, heaps, relax_l, relax_dl, done, d_inst);
+            }
+        }
         hipLaunchKernelGGL(ws_flood_wave_kernel, wgrid, dim3(64), 0, st, blob_lab, dist, areas, offs, cnt_blob, bbox, h, w,
                            min_keep, heaps, relax ? done : nullptr, d_inst);
     } else {
