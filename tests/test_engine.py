@@ -300,3 +300,64 @@ def test_mfma_resnet_matches_plain_model(patches):
     a = eng.run(patches, patch_mode=True, return_probabilities=True, conv_backend="mfma")
     b = PatchPredictor("resnet18-kather100k", batch_size=4).run(patches, patch_mode=True, return_probabilities=True)
     np.testing.assert_allclose(a["probabilities"], b["probabilities"], atol=1e-4)
+
+
+def test_deep_feature_extractor_contract_cpu(patches):
+    """``DeepFeatureExtractor("resnet18")`` (reference ``engine/deep_feature_extractor.py:70-290``): a bare backbone name
+    builds ``CNNBackbone`` without ioconfig; ``run`` returns the pooled features under ``"probabilities"`` and no
+    ``"predictions"``; they equal the module's own forward pass."""
+    from tiatoolbox_amd.models import DeepFeatureExtractor
+    from tiatoolbox_amd.models.architecture.vanilla import CNNBackbone
+
+    eng = DeepFeatureExtractor("resnet18", batch_size=4)
+    assert isinstance(eng.model, CNNBackbone) and eng.ioconfig is None
+    with pytest.raises(ValueError, match="ModelIOConfigABC"):
+        eng.run(patches, patch_mode=True)  # no default ioconfig: one must be passed (reference engine_abc.py:1009-1040)
+    from tiatoolbox_amd.models import IOPatchPredictorConfig
+
+    cfg = IOPatchPredictorConfig(input_resolutions=[{"units": "baseline", "resolution": 1.0}], patch_input_shape=(224, 224),
+                                 stride_shape=(224, 224))
+    out = eng.run(patches, patch_mode=True, ioconfig=cfg)
+    assert set(out) == {"probabilities"} and out["probabilities"].shape == (len(patches), 512)
+    with torch.inference_mode():
+        ref = eng.model.eval()(torch.from_numpy(patches).float().permute(0, 3, 1, 2)).numpy()
+    np.testing.assert_allclose(out["probabilities"], ref, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_deep_feature_extractor_gpu_matches_cpu(patches):
+    """Same features from the device path (BN-folded trunk, hand-written MFMA convolutions) within 1e-4 of torch-CPU
+    float32; a CUDA uint8 batch is accepted like in ``PatchPredictor``."""
+    from tiatoolbox_amd.models import DeepFeatureExtractor
+
+    from tiatoolbox_amd.models import IOPatchPredictorConfig
+
+    kw = {"patch_mode": True,
+          "ioconfig": IOPatchPredictorConfig(input_resolutions=[{"units": "baseline", "resolution": 1.0}],
+                                             patch_input_shape=(224, 224), stride_shape=(224, 224))}
+    cpu = DeepFeatureExtractor("resnet18", batch_size=4).run(patches, **kw)["probabilities"]
+    eng = DeepFeatureExtractor("resnet18", batch_size=4, device="cuda")
+    gpu = eng.run(patches, **kw)
+    assert "predictions" not in gpu
+    scale = np.abs(cpu).max()
+    assert np.abs(gpu["probabilities"] - cpu).max() <= 1e-4 * max(scale, 1.0)
+    gpu2 = eng.run(torch.from_numpy(patches).cuda(), **kw)
+    np.testing.assert_array_equal(gpu2["probabilities"], gpu["probabilities"])
+    # WSI mode: features + coordinates per slide (reference infer_wsi :142-260)
+    from tiatoolbox_amd.utils import synth
+    from tiatoolbox_amd.wsicore import ArrayWSIReader
+
+    slide = np.full((700, 900, 3), 245, np.uint8)
+    slide[100:600, 100:800] = synth.g_he(1, 500, 700, seed=3)[0]
+    import tempfile
+    from pathlib import Path
+
+    with tempfile.TemporaryDirectory() as tmp:
+        res = np.load(eng.run([ArrayWSIReader(slide, mpp=0.5, power=20.0)], patch_mode=False, save_dir=Path(tmp),
+                              ioconfig=kw["ioconfig"])[0])
+        assert "predictions" not in res.files
+        coords, feats = res["coordinates"], res["probabilities"]
+        assert feats.shape == (len(coords), 512) and len(coords) > 2
+        padded = np.pad(slide, ((0, 300), (0, 300), (0, 0)), constant_values=255)
+        again = eng.run(np.stack([padded[y0:y1, x0:x1] for x0, y0, x1, y1 in coords]), **kw)["probabilities"]
+        np.testing.assert_allclose(feats, again, atol=1e-5)

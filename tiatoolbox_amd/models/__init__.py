@@ -14,6 +14,7 @@ _EXPORTS = {
     "MultiTaskSegmentor": "engine.multi_task_segmentor",
     "NucleusInstanceSegmentor": "engine.multi_task_segmentor",
     "PatchPredictor": "engine.patch_predictor",
+    "DeepFeatureExtractor": "engine.deep_feature_extractor",
     "SemanticSegmentor": "engine.semantic_segmentor",
 }
 _SUBMODULES = ("architecture", "dataset", "engine", "models_abc")
