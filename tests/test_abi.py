@@ -116,5 +116,6 @@ def test_package_level_names_of_the_reference_layout():
             assert getattr(mod, name) is not None, (pkg, name)
     import pytest
 
+    assert importlib.import_module("tiatoolbox_amd.models").DeepFeatureExtractor.__name__ == "DeepFeatureExtractor"
     with pytest.raises(AttributeError):
-        importlib.import_module("tiatoolbox_amd.models").DeepFeatureExtractor  # noqa: B018  (out of scope)
+        importlib.import_module("tiatoolbox_amd.models").NucleusDetector  # noqa: B018  (out of scope)
