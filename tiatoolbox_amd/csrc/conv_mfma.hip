@@ -166,26 +166,33 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
         TIA_NEXT_SLICE()
         TIA_LOAD_SLICE()
         __builtin_amdgcn_sched_barrier(0);  // the loads are issued HERE, not sunk below the MFMAs by the scheduler
-        // fragments of k-step kk + 2 are fetched from LDS before the MFMAs of k-step kk are issued
-        float a[2][2], b[2][NTILE];
+        // software pipeline over PAIRS of k-steps: the fragments of pair kp + 1 (2 + 2 * NTILE LDS reads: both k-steps of
+        // an A row come from one ds_read2) are requested before the 4 * NTILE MFMAs of pair kp are issued, and
+        // sched_group_barrier keeps that order -- an LDS round trip then hides behind >= 256 cycles of matrix work
+        float a[2][2][2], b[2][2][NTILE];  // [buffer][k-step of the pair][tile]
+        auto frags = [&](int buf, int kp) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[0][i] = a_ptr[i * 32 * LDA];
+            for (int q = 0; q < 2; ++q) {
 #pragma unroll
-        for (int j = 0; j < NTILE; ++j) b[0][j] = b_ptr[j * 32];
+                for (int i = 0; i < 2; ++i) a[buf][q][i] = a_ptr[i * 32 * LDA + 4 * kp + 2 * q];
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const int cur = ks & 1, nx = cur ^ 1;
-            if (ks + 1 < BK / 2) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[nx][i] = a_ptr[i * 32 * LDA + 2 * (ks + 1)];
-#pragma unroll
-                for (int j = 0; j < NTILE; ++j) b[nx][j] = b_ptr[2 * (ks + 1) * BN + j * 32];
+                for (int j = 0; j < NTILE; ++j) b[buf][q][j] = b_ptr[(4 * kp + 2 * q) * BN + j * 32];
             }
+        };
+        frags(0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int kp = 0; kp < BK / 4; ++kp) {
+            const int cur = kp & 1;
+            if (kp + 1 < BK / 4) frags(cur ^ 1, kp + 1);
 #pragma unroll
-                for (int j = 0; j < NTILE; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTILE; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q][i], b[cur][q][j], acc[i][j], 0, 0, 0);
+            if (kp + 1 < BK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NTILE, 0);  // DS reads of the next pair
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NTILE, 0);                             // then this pair's MFMAs
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
