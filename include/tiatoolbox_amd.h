@@ -395,6 +395,22 @@ int tia_conv2d_nhwc_f32(const float* d_x, const float* d_w_packed, const float* 
                         float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
                         int64_t kw, int64_t stride, int64_t pad, int32_t relu, void* stream);
 
+/* The same convolution with the zero border given explicitly: `pad_top` / `pad_left` rows / columns of zeros in front,
+ * and as many behind as the requested output size [ho, wo] reaches (taps outside the image read as zeros).  This is how
+ * TensorFlow-style "same" padding of a strided convolution (0 in front, 1 behind: HoVer-Net's TFSamepaddingLayer,
+ * models/architecture/hovernet.py:30-69) and "valid" convolutions (pad 0, ho = (h - kh) / stride + 1) are expressed.
+ * Requires pad_top < kh, pad_left < kw and (ho - 1) * stride - pad_top < h (likewise for columns). */
+int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                           float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
+                           int64_t kw, int64_t stride, int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo,
+                           int32_t relu, void* stream);
+
+/* y = act(x * scale[c] + shift[c]) on NHWC float32 ([rows, c], c % 4 == 0; y may alias x): an inference-mode
+ * BatchNorm (+ ReLU) that sits in FRONT of a convolution and therefore cannot be folded into one -- the pre-activation
+ * units of HoVer-Net (models/architecture/hovernet.py:72-261: "preact_bna" / "blk_bna"). */
+int tia_scale_shift_act_nhwc_f32(const float* d_x, const float* d_scale, const float* d_shift, float* d_y, int64_t rows,
+                                 int64_t c, int32_t relu, void* stream);
+
 /* =======================================================================================
  * All borders of binary planes: cv2.findContours(layer, RETR_TREE, CHAIN_APPROX_NONE | _SIMPLE)
  * (models/architecture/hovernetplus.py:222-226, HoVerNetPlus._get_layer_info)

@@ -612,3 +612,59 @@ def test_classic_heap_pop_formulations_agree_on_ties():
         y, x = rng.integers(0, 36), rng.integers(0, 46)
         markers[y:y + 3, x:x + 3] = k
     assert np.array_equal(skref.watershed(img, markers, mask), flood_heapq(img, markers, mask))  # no ties: identical
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("plus", [False, True])
+def test_fused_hovernet_forward_matches_plain_module(plus):
+    """``FusedHoVerNet`` (104 of 144 convolutions on ``tia_conv2d_nhwc_f32_ex`` with folded BN / fused ReLU / residual
+    epilogues, ``tia_scale_shift_act_nhwc_f32`` for the pre-activations, TF "same" padding through the explicit front
+    padding) against the plain torch module on the CPU in float32, with randomised BN statistics: every head within
+    2e-4 of its range.  Also the two new entry points on their own against torch."""
+    import copy
+
+    import torch
+    import torch.nn.functional as F  # noqa: N812
+
+    from tiatoolbox_amd.models.architecture.fused import hip_conv2d_ex, hip_scale_shift_act, pack_conv_weights
+    from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
+    from tiatoolbox_amd.models.architecture.hovernet_fused import FusedHoVerNet
+    from tiatoolbox_amd.models.architecture.hovernetplus import HoVerNetPlus
+
+    g = torch.Generator().manual_seed(5)
+    if not plus:
+        # asymmetric padding: 3x3 stride 2 with 0 rows in front / 1 behind == F.pad + valid convolution; valid 3x3; 1x1 + residual
+        for (cin, cout, hw, k, s, lo, hi) in [(64, 128, 20, 3, 2, 0, 1), (32, 64, 17, 3, 1, 0, 0), (96, 64, 9, 1, 1, 0, 0),
+                                              (64, 64, 12, 3, 1, 1, 1), (32, 64, 11, 3, 2, 1, 1)]:
+            conv = torch.nn.Conv2d(cin, cout, k, stride=s, bias=True)
+            x = torch.randn((3, cin, hw, hw), generator=g)
+            ref = conv(F.pad(x, (lo, hi, lo, hi))).detach()
+            res = torch.randn(ref.shape, generator=g)
+            dev = copy.deepcopy(conv).cuda()
+            got = hip_conv2d_ex(x.cuda().contiguous(memory_format=torch.channels_last), pack_conv_weights(dev), dev.bias,
+                                res.cuda().contiguous(memory_format=torch.channels_last), kernel=k, stride=s, pad_lo=lo, pad_hi=hi,
+                                relu=True)
+            assert (got.cpu() - torch.relu(ref + res)).abs().max() <= 1e-4, (cin, cout, hw, k, s, lo, hi)
+        x = torch.randn((2, 96, 7, 5), generator=g)
+        sc, sh = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g)
+        got = hip_scale_shift_act(x.cuda().contiguous(memory_format=torch.channels_last), sc.cuda(), sh.cuda())
+        assert torch.equal(got.cpu(), torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]))
+
+    torch.manual_seed(3)
+    model = (HoVerNetPlus(num_types=3, num_layers=5) if plus else HoVerNet(num_types=6, mode="fast")).eval()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.05, generator=g)
+            mod.running_var.uniform_(0.8, 1.2, generator=g)
+            mod.weight.data.uniform_(0.8, 1.2, generator=g)
+            mod.bias.data.normal_(0, 0.05, generator=g)
+    x = torch.randint(0, 256, (1 if plus else 2, 3, 256, 256), generator=g).float()
+    with torch.inference_mode():
+        ref = model(x)
+        fused = FusedHoVerNet(copy.deepcopy(model).cuda()).cuda()
+        got = fused(x.cuda().contiguous(memory_format=torch.channels_last))
+    assert list(got) == list(ref)
+    for name in ref:
+        r, o = ref[name], got[name].cpu()
+        assert o.shape == r.shape == (x.shape[0], r.shape[1], 164, 164)
+        assert (o - r).abs().max() <= 2e-4 * max(float(r.abs().max()), 1.0), name

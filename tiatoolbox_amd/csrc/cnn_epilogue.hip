@@ -180,6 +180,29 @@ static int launch_stem(const void* x, const void* bias, long n, long h, long w, 
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
+
+// y = relu(x * scale[c] + shift[c])  -- an inference BatchNorm (+ ReLU) that cannot be folded into a convolution (the
+// pre-activation units of HoVer-Net: BN -> ReLU -> conv).  float32, 16 bytes per lane, y may alias x.  The product and
+// the sum are rounded separately (contract off above), like torch's eval-mode batch_norm followed by relu.
+__global__ __launch_bounds__(ET) void scale_shift_act_kernel(const u4* __restrict__ x, const u4* __restrict__ scale,
+                                                              const u4* __restrict__ shift, long total_v, int cv, int relu,
+                                                              u4* __restrict__ y) {
+    for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total_v; i += (long)gridDim.x * ET) {
+        const int c = (int)(i % cv);
+        float f[8], sc[8], sh[8];
+        Vec<float>::unpack(x[i], f);
+        Vec<float>::unpack(scale[c], sc);
+        Vec<float>::unpack(shift[c], sh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = f[k] * sc[k];
+            v = v + sh[k];
+            f[k] = relu ? (v > 0.0f ? v : 0.0f) : v;
+        }
+        y[i] = Vec<float>::pack(f);
+    }
+}
+
 }  // namespace tia
 
 using namespace tia;
@@ -210,4 +233,18 @@ extern "C" int tia_bias_relu_maxpool_nhwc(const void* d_x, const void* d_bias, i
         case TIA_DT_BF16: return launch_stem<__hip_bfloat16>(d_x, d_bias, n, h, w, c, d_out, st);
         default: return TIA_EINVAL;
     }
+}
+
+extern "C" int tia_scale_shift_act_nhwc_f32(const float* d_x, const float* d_scale, const float* d_shift, float* d_y, int64_t rows,
+                                             int64_t c, int32_t relu, void* stream) {
+    if (!d_x || !d_scale || !d_shift || !d_y || rows <= 0 || c <= 0 || (c & 3) != 0) return TIA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_scale) | reinterpret_cast<uintptr_t>(d_shift) |
+         reinterpret_cast<uintptr_t>(d_y)) & 15)
+        return TIA_EINVAL;
+    const long total_v = rows * (c / 4);
+    long blocks = (total_v + ET - 1) / ET;
+    if (blocks > 256L * 64) blocks = 256L * 64;
+    hipLaunchKernelGGL(scale_shift_act_kernel, dim3((unsigned)blocks), dim3(ET), 0, (hipStream_t)stream, (const u4*)d_x,
+                       (const u4*)d_scale, (const u4*)d_shift, total_v, (int)(c / 4), relu, (u4*)d_y);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

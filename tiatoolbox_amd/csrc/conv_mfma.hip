@@ -33,7 +33,7 @@ constexpr int LDA = BK + 1;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 struct ConvDims {
-    int n, h, w, cin, cout, ho, wo, kh, kw, stride, pad;
+    int n, h, w, cin, cout, ho, wo, kh, kw, stride, pad_y, pad_x;  // pad_* = zero rows / columns in front (top, left)
     unsigned x_bytes, w_bytes;  // buffer extents of this launch (both < 2^31: the host splits the batch)
 };
 
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
         const int b = mm / (d.ho * d.wo);                                                      \
         const int rem = mm - b * d.ho * d.wo;                                                  \
         const int oy = rem / d.wo, ox = rem - oy * d.wo;                                       \
-        const int iy0 = oy * d.stride - d.pad, ix0 = ox * d.stride - d.pad;                    \
+        const int iy0 = oy * d.stride - d.pad_y, ix0 = ox * d.stride - d.pad_x;                    \
         cen_##R = (((b * d.h + iy0) * d.w + ix0) * d.cin + 4 * quad) * 4;                      \
         unsigned rows = 0, cols = 0;                                                           \
         for (int t = 0; t < d.kh; ++t) rows |= (unsigned)((unsigned)(iy0 + t) < (unsigned)d.h) << t;        \
@@ -261,14 +261,18 @@ extern "C" int tia_conv_pack_weights_f32(const float* d_w_oihw, int64_t cout, in
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
-extern "C" int tia_conv2d_nhwc_f32(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,
-                                   float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
-                                   int64_t kw, int64_t stride, int64_t pad, int32_t relu, void* stream) {
-    if (!d_x || !d_w_packed || !d_y || n <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return TIA_EINVAL;
+extern "C" int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                                      float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
+                                      int64_t kw, int64_t stride, int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo,
+                                      int32_t relu, void* stream) {
+    if (!d_x || !d_w_packed || !d_y || n <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0)
+        return TIA_EINVAL;
     if (cin % BK != 0 || cout % 64 != 0) return TIA_ESIZE;
     if (((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_w_packed)) & 15) != 0) return TIA_EINVAL;
-    const long ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
-    if (ho <= 0 || wo <= 0 || kh > 16 || kw > 16) return TIA_EINVAL;
+    // every output pixel must see at least its first tap row / column start inside [-(k-1), h): rows and columns beyond the
+    // image on either side read as zeros (that is how asymmetric "same" padding is expressed: pad_top / pad_left + ho / wo)
+    if (ho <= 0 || wo <= 0 || kh > 16 || kw > 16 || pad_top >= kh || pad_left >= kw) return TIA_EINVAL;
+    if ((ho - 1) * stride - pad_top >= h || (wo - 1) * stride - pad_left >= w) return TIA_EINVAL;
     // the kernel addresses its input with 32-bit byte offsets: images go in groups of < 2 GiB
     const long image_bytes = h * w * cin * 4, w_bytes = kh * kw * cin * cout * 4;
     if (image_bytes > 0x7fffffffL || w_bytes > 0x7fffffffL || ho * wo > 0x7fffffffL / 4) return TIA_ESIZE;
@@ -280,8 +284,8 @@ extern "C" int tia_conv2d_nhwc_f32(const float* d_x, const float* d_w_packed, co
         const long nb = n - first < group ? n - first : group;
         const long m_total = nb * ho * wo;
         const long m_tiles = (m_total + BM - 1) / BM;
-        ConvDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)kh, (int)kw, (int)stride, (int)pad,
-                   (unsigned)(nb * image_bytes), (unsigned)w_bytes};
+        ConvDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)kh, (int)kw, (int)stride, (int)pad_top,
+                   (int)pad_left, (unsigned)(nb * image_bytes), (unsigned)w_bytes};
         const float* xg = d_x + first * h * w * cin;
         const float* rg = d_residual ? d_residual + first * ho * wo * cout : nullptr;
         float* yg = d_y + first * ho * wo * cout;
@@ -294,4 +298,13 @@ extern "C" int tia_conv2d_nhwc_f32(const float* d_x, const float* d_w_packed, co
                                d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles);
     }
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_conv2d_nhwc_f32(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                                   float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
+                                   int64_t kw, int64_t stride, int64_t pad, int32_t relu, void* stream) {
+    if (h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return TIA_EINVAL;
+    const long ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+    return tia_conv2d_nhwc_f32_ex(d_x, d_w_packed, d_bias, d_residual, d_y, n, h, w, cin, cout, kh, kw, stride, pad, pad, ho, wo, relu,
+                                  stream);
 }

@@ -228,6 +228,52 @@ def hip_conv2d(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor | Non
     return y
 
 
+def hip_conv2d_ex(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor | None, residual: torch.Tensor | None, *,
+                  kernel: int, stride: int, pad_lo: int, pad_hi: int, relu: bool) -> torch.Tensor:
+    """Like :func:`hip_conv2d` with ``pad_lo`` zero rows / columns in front and ``pad_hi`` behind (``tia_conv2d_nhwc_f32_ex``):
+    TensorFlow-style "same" padding of strided convolutions, and valid convolutions (0 / 0)."""
+    from tiatoolbox_amd import _lib
+
+    if not (_nhwc_ptr_ok(x) and x.dtype == torch.float32):
+        msg = "hip_conv2d_ex expects a float32 channels-last CUDA tensor."
+        raise ValueError(msg)
+    if residual is not None and not (_nhwc_ptr_ok(residual) and residual.dtype == torch.float32):
+        msg = "hip_conv2d_ex expects a float32 channels-last CUDA residual."
+        raise ValueError(msg)
+    n, cin, h, w = x.shape
+    cout = w_packed.shape[-1]
+    ho = (h + pad_lo + pad_hi - kernel) // stride + 1
+    wo = (w + pad_lo + pad_hi - kernel) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if residual is not None and residual.shape != y.shape:
+        msg = f"residual shape {tuple(residual.shape)} != output shape {tuple(y.shape)}"
+        raise ValueError(msg)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_conv2d_nhwc_f32_ex(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                                                residual.data_ptr() if residual is not None else 0, y.data_ptr(), n, h, w, cin,
+                                                cout, kernel, kernel, stride, pad_lo, pad_lo, ho, wo, int(relu),
+                                                _lib.current_stream())
+    _lib.check(rc, "tia_conv2d_nhwc_f32_ex")
+    return y
+
+
+def hip_scale_shift_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, *, relu: bool = True,
+                        inplace: bool = False) -> torch.Tensor:
+    """``relu(x * scale[c] + shift[c])`` on a float32 channels-last CUDA tensor (``tia_scale_shift_act_nhwc_f32``)."""
+    from tiatoolbox_amd import _lib
+
+    if not (_nhwc_ptr_ok(x) and x.dtype == torch.float32):
+        msg = "hip_scale_shift_act expects a float32 channels-last CUDA tensor."
+        raise ValueError(msg)
+    n, c, h, w = x.shape
+    y = x if inplace else torch.empty_like(x, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_scale_shift_act_nhwc_f32(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), n * h * w, c,
+                                                      int(relu), _lib.current_stream())
+    _lib.check(rc, "tia_scale_shift_act_nhwc_f32")
+    return y
+
+
 def pack_conv_weights(conv: nn.Conv2d) -> torch.Tensor:
     """OIHW -> ``[kh, kw, cin, cout]`` float32 on the convolution's device (``tia_conv_pack_weights_f32``)."""
     from tiatoolbox_amd import _lib

@@ -1,0 +1,192 @@
+"""Inference copy of :class:`HoVerNet` / :class:`HoVerNetPlus` on the hand-written float32 MFMA convolutions.
+
+Same arithmetic graph as ``HoVerNet.forward`` (reference ``models/architecture/hovernet.py:405-454``), re-expressed so
+that every convolution with ``cin % 32 == 0`` and ``cout % 64 == 0`` -- all 1x1 / 3x3 convolutions of the
+pre-activation ResNet-50 encoder, the decoders' ``conva`` / ``convf`` and the dense units' 1x1 -- runs on
+``tia_conv2d_nhwc_f32_ex`` with its epilogue fused:
+
+* ``conv -> BN -> ReLU`` (``conv1`` / ``conv2`` of every unit, the stem): BN folded into the weights, bias + ReLU in the
+  convolution's epilogue;
+* ``conv3 + shortcut``: the residual add rides in the epilogue of ``conv3``;
+* ``BN -> ReLU -> conv`` (pre-activations, ``blk_bna``): one ``tia_scale_shift_act_nhwc_f32`` pass instead of two;
+* TensorFlow "same" padding of the strided 3x3: expressed by the convolution's explicit front padding / output size.
+
+The 3-channel stem, the grouped convolutions of the dense units (32 -> 8 channels per group) and the final
+``64 -> n_out`` 1x1 stay on MIOpen.  Built from a loaded model (reference parameter names), never the object that loads
+weights; float32, CUDA, channels-last only.
+"""
+
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F  # noqa: N812
+from torch import nn
+
+from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv2d_ex, hip_scale_shift_act,
+                                                      pack_conv_weights)
+from tiatoolbox_amd.models.architecture.hovernet import centre_crop_to_shape
+from tiatoolbox_amd.models.architecture.utils import centre_crop
+
+
+def _cl(x: torch.Tensor) -> torch.Tensor:
+    return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+
+
+def _bn_affine(bn: nn.BatchNorm2d) -> tuple[torch.Tensor, torch.Tensor]:
+    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float().contiguous()
+    shift = (bn.bias - bn.running_mean * scale).detach().float().contiguous()
+    return scale, shift
+
+
+def _same_pads(size: int, ksize: int, stride: int) -> tuple[int, int]:
+    """``TFSamepaddingLayer`` (ref. :30-69): total pad from the HEIGHT's remainder, smaller half in front."""
+    rem = size % stride
+    pad = max(ksize - (stride if rem == 0 else rem), 0)
+    return pad // 2, pad - pad // 2
+
+
+class _Conv(nn.Module):
+    """One convolution of the graph: weights (optionally with a following BN folded in) packed for the MFMA kernel."""
+
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d | None = None) -> None:
+        super().__init__()
+        w = conv.weight.detach().float()
+        bias = conv.bias.detach().float() if conv.bias is not None else None
+        if bn is not None:
+            scale, shift = _bn_affine(bn)
+            w = w * scale[:, None, None, None]
+            bias = shift if bias is None else bias * scale + shift
+        self.kernel, self.stride = conv.kernel_size[0], conv.stride[0]
+        self.mfma_ok = conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
+        self.groups = conv.groups
+        self.weight = nn.Parameter(w.contiguous(), requires_grad=False)
+        self.bias = nn.Parameter(bias.contiguous(), requires_grad=False) if bias is not None else None
+        self._packed: torch.Tensor | None = None
+
+    def forward(self, x: torch.Tensor, *, pads: tuple[int, int] = (0, 0), relu: bool = False,
+                residual: torch.Tensor | None = None) -> torch.Tensor:
+        if self.mfma_ok:
+            if self._packed is None or self._packed.device != self.weight.device:
+                self._packed = pack_conv_weights(self)  # reads `.weight` (OIHW)
+            return hip_conv2d_ex(_cl(x), self._packed, self.bias, residual, kernel=self.kernel, stride=self.stride,
+                                 pad_lo=pads[0], pad_hi=pads[1], relu=relu)
+        if pads != (0, 0):
+            x = F.pad(x, (pads[0], pads[1], pads[0], pads[1]))
+        y = _cl(F.conv2d(x, self.weight, None, self.stride, 0, 1, self.groups))
+        if self.bias is not None or relu or residual is not None:
+            bias = self.bias if self.bias is not None else torch.zeros(y.shape[1], device=y.device)
+            if y.shape[1] % 4 == 0:
+                return hip_bias_act_(y, bias, residual, relu=relu)
+            y = y + bias[None, :, None, None]
+            y = y + residual if residual is not None else y
+            return F.relu(y) if relu else y
+        return y
+
+
+class _BnAct(nn.Module):
+    def __init__(self, bn: nn.BatchNorm2d) -> None:
+        super().__init__()
+        scale, shift = _bn_affine(bn)
+        self.register_buffer("scale", scale)
+        self.register_buffer("shift", shift)
+
+    def forward(self, x: torch.Tensor, *, inplace: bool = False) -> torch.Tensor:
+        return hip_scale_shift_act(_cl(x), self.scale, self.shift, relu=True, inplace=inplace)
+
+
+class _FusedResidualBlock(nn.Module):
+    def __init__(self, blk: nn.Module) -> None:
+        super().__init__()
+        self.pre = nn.ModuleList()
+        self.c1, self.c2, self.c3 = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for unit in blk.units:
+            mods = dict(unit.named_children())
+            self.pre.append(_BnAct(mods["preact/bn"]) if "preact/bn" in mods else nn.Identity())
+            self.c1.append(_Conv(mods["conv1"], mods["conv1/bn"]))
+            self.c2.append(_Conv(mods["conv2"], mods["conv2/bn"]))
+            self.c3.append(_Conv(mods["conv3"]))
+        self.shortcut = _Conv(blk.shortcut) if blk.shortcut is not None else None
+        self.out = _BnAct(blk.blk_bna.bn)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        shortcut = x if self.shortcut is None else self.shortcut(x)
+        for pre, c1, c2, c3 in zip(self.pre, self.c1, self.c2, self.c3):
+            a = x if isinstance(pre, nn.Identity) else pre(x)
+            a = c1(a, relu=True)
+            a = c2(a, pads=_same_pads(a.shape[2], c2.kernel, c2.stride), relu=True)
+            x = c3(a, residual=_cl(shortcut))
+            shortcut = x
+        return self.out(x)
+
+
+class _FusedDenseBlock(nn.Module):
+    def __init__(self, blk: nn.Module) -> None:
+        super().__init__()
+        self.pre, self.c1, self.c2 = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for unit in blk.units:
+            mods = dict(unit.named_children())
+            self.pre.append(_BnAct(mods["preact_bna/bn"]))
+            self.c1.append(_Conv(mods["conv1"], mods["conv1/bn"]))
+            self.c2.append(_Conv(mods["conv2"]))
+        self.out = _BnAct(blk.blk_bna.bn)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        for pre, c1, c2 in zip(self.pre, self.c1, self.c2):
+            new = c2(c1(pre(x), relu=True))
+            x = torch.cat([centre_crop_to_shape(x, new), new], dim=1)
+        return self.out(x, inplace=True)
+
+
+class _FusedBranch(nn.Module):
+    def __init__(self, branch: nn.Sequential) -> None:
+        super().__init__()
+        u3, u2, u1, u0 = branch[0], branch[1], branch[2], branch[3]
+        self.u3a, self.u3d, self.u3f = _Conv(u3.conva), _FusedDenseBlock(u3.dense), _Conv(u3.convf)
+        self.u2a, self.u2d, self.u2f = _Conv(u2.conva), _FusedDenseBlock(u2.dense), _Conv(u2.convf)
+        self.u1a = _Conv(u1.conva)
+        self.u1_ksize = u1.conva.kernel_size[0]
+        self.u0bn = _BnAct(u0.bn)
+        self.u0 = _Conv(u0.conv)
+
+
+class FusedHoVerNet(nn.Module):
+    """``forward(x)`` == ``HoVerNet.forward(x)`` (``{branch: logits}``), float32 on a CUDA device."""
+
+    def __init__(self, model: nn.Module) -> None:
+        super().__init__()
+        model = model.eval()
+        self.mode = model.mode
+        stem = dict(model.conv0.named_children())
+        self.stem = _Conv(stem["/"], stem["bn"])
+        self.stem_pad = "pad" in stem
+        self.d0, self.d1 = _FusedResidualBlock(model.d0), _FusedResidualBlock(model.d1)
+        self.d2, self.d3 = _FusedResidualBlock(model.d2), _FusedResidualBlock(model.d3)
+        self.conv_bot = _Conv(model.conv_bot)
+        self.decoder = nn.ModuleDict(OrderedDict((name, _FusedBranch(branch)) for name, branch in model.decoder.items()))
+
+    @staticmethod
+    def _up2(x: torch.Tensor) -> torch.Tensor:
+        return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+
+    def forward(self, input_tensor: torch.Tensor) -> dict:
+        x = _cl(input_tensor / 255.0)
+        pads = _same_pads(x.shape[2], self.stem.kernel, 1) if self.stem_pad else (0, 0)
+        d0 = self.d0(self.stem(x, pads=pads, relu=True))
+        d1 = self.d1(d0)
+        d2 = self.d2(d1)
+        d3 = self.conv_bot(self.d3(d2))
+        if self.mode == "original":
+            d0, d1 = centre_crop(d0, [184, 184]), centre_crop(d1, [72, 72])
+        else:
+            d0, d1 = centre_crop(d0, [92, 92]), centre_crop(d1, [36, 36])
+        up3 = self._up2(d3) + d2  # shared by the branches
+        out = OrderedDict()
+        for name, br in self.decoder.items():
+            u3 = br.u3f(br.u3d(br.u3a(up3)))
+            u2 = br.u2f(br.u2d(br.u2a(self._up2(u3) + d1)))
+            u1_in = self._up2(u2) + d0
+            u1 = br.u1a(u1_in, pads=_same_pads(u1_in.shape[2], br.u1_ksize, 1))
+            out[name] = br.u0(br.u0bn(u1, inplace=True))
+        return out
