@@ -411,6 +411,13 @@ int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed, const floa
 int tia_scale_shift_act_nhwc_f32(const float* d_x, const float* d_scale, const float* d_shift, float* d_y, int64_t rows,
                                  int64_t c, int32_t relu, void* stream);
 
+/* out[b, Y, X, :] = x[b, Y/2, X/2, :] + y[b, Y, X, :] on NHWC float32: nearest x2 upsampling fused with the decoder's
+ * skip-connection add (models/architecture/hovernet.py:447-449, utils.py:202-243).  x [n,h,w,c]; y a (possibly
+ * centre-cropped) view of an NHWC tensor with contiguous channels: d_y points at its first element,
+ * y_image_stride / y_row_stride in elements (multiples of 4, 16-byte aligned base); out [n,2h,2w,c]; c % 4 == 0. */
+int tia_upsample2x_add_nhwc_f32(const float* d_x, const float* d_y, int64_t y_image_stride, int64_t y_row_stride,
+                                float* d_out, int64_t n, int64_t h, int64_t w, int64_t c, void* stream);
+
 /* =======================================================================================
  * All borders of binary planes: cv2.findContours(layer, RETR_TREE, CHAIN_APPROX_NONE | _SIMPLE)
  * (models/architecture/hovernetplus.py:222-226, HoVerNetPlus._get_layer_info)

@@ -649,6 +649,12 @@ def test_fused_hovernet_forward_matches_plain_module(plus):
         sc, sh = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g)
         got = hip_scale_shift_act(x.cuda().contiguous(memory_format=torch.channels_last), sc.cuda(), sh.cuda())
         assert torch.equal(got.cpu(), torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]))
+        from tiatoolbox_amd.models.architecture.fused import hip_upsample2x_add
+
+        lo = torch.randn((2, 32, 5, 7), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        skip = torch.randn((2, 32, 16, 20), generator=g).cuda().contiguous(memory_format=torch.channels_last)[:, :, 3:13, 3:17]
+        assert not skip.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(hip_upsample2x_add(lo, skip), lo.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + skip)
 
     torch.manual_seed(3)
     model = (HoVerNetPlus(num_types=3, num_layers=5) if plus else HoVerNet(num_types=6, mode="fast")).eval()

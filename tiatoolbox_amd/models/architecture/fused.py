@@ -274,6 +274,24 @@ def hip_scale_shift_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tenso
     return y
 
 
+def hip_upsample2x_add(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """``x.repeat_interleave(2, 2).repeat_interleave(2, 3) + y`` in one pass (``tia_upsample2x_add_nhwc_f32``); ``y`` may be a
+    centre-cropped view of a channels-last tensor."""
+    from tiatoolbox_amd import _lib
+
+    n, c, h, w = x.shape
+    ok_y = (y.is_cuda and y.dtype == torch.float32 and y.shape == (n, c, 2 * h, 2 * w) and y.stride(1) == 1 and y.stride(3) == c
+            and y.stride(2) % 4 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0)
+    if not (_nhwc_ptr_ok(x) and x.dtype == torch.float32 and ok_y and c % 4 == 0):
+        return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + y
+    out = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_upsample2x_add_nhwc_f32(x.data_ptr(), y.data_ptr(), y.stride(0), y.stride(2), out.data_ptr(), n, h, w, c,
+                                                     _lib.current_stream())
+    _lib.check(rc, "tia_upsample2x_add_nhwc_f32")
+    return out
+
+
 def pack_conv_weights(conv: nn.Conv2d) -> torch.Tensor:
     """OIHW -> ``[kh, kw, cin, cout]`` float32 on the convolution's device (``tia_conv_pack_weights_f32``)."""
     from tiatoolbox_amd import _lib

@@ -25,7 +25,7 @@ import torch.nn.functional as F  # noqa: N812
 from torch import nn
 
 from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv2d_ex, hip_scale_shift_act,
-                                                      pack_conv_weights)
+                                                      hip_upsample2x_add, pack_conv_weights)
 from tiatoolbox_amd.models.architecture.hovernet import centre_crop_to_shape
 from tiatoolbox_amd.models.architecture.utils import centre_crop
 
@@ -166,10 +166,6 @@ class FusedHoVerNet(nn.Module):
         self.conv_bot = _Conv(model.conv_bot)
         self.decoder = nn.ModuleDict(OrderedDict((name, _FusedBranch(branch)) for name, branch in model.decoder.items()))
 
-    @staticmethod
-    def _up2(x: torch.Tensor) -> torch.Tensor:
-        return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
-
     def forward(self, input_tensor: torch.Tensor) -> dict:
         x = _cl(input_tensor / 255.0)
         pads = _same_pads(x.shape[2], self.stem.kernel, 1) if self.stem_pad else (0, 0)
@@ -181,12 +177,12 @@ class FusedHoVerNet(nn.Module):
             d0, d1 = centre_crop(d0, [184, 184]), centre_crop(d1, [72, 72])
         else:
             d0, d1 = centre_crop(d0, [92, 92]), centre_crop(d1, [36, 36])
-        up3 = self._up2(d3) + d2  # shared by the branches
+        up3 = hip_upsample2x_add(_cl(d3), d2)  # shared by the branches
         out = OrderedDict()
         for name, br in self.decoder.items():
             u3 = br.u3f(br.u3d(br.u3a(up3)))
-            u2 = br.u2f(br.u2d(br.u2a(self._up2(u3) + d1)))
-            u1_in = self._up2(u2) + d0
+            u2 = br.u2f(br.u2d(br.u2a(hip_upsample2x_add(_cl(u3), d1))))
+            u1_in = hip_upsample2x_add(_cl(u2), d0)
             u1 = br.u1a(u1_in, pads=_same_pads(u1_in.shape[2], br.u1_ksize, 1))
             out[name] = br.u0(br.u0bn(u1, inplace=True))
         return out
