@@ -118,7 +118,7 @@ def bench_semantic(args) -> dict | None:
     result = {}
 
     def step():
-        result["out"] = eng.run([reader], patch_mode=False, miopen_find=True)
+        result["out"] = eng.run([reader], patch_mode=False, miopen_find=True, conv_backend=args.conv_backend)
 
     step()  # MIOpen solver search, lazy loads
     cfg = eng._ioconfig  # noqa: SLF001
@@ -148,7 +148,8 @@ def bench_semantic(args) -> dict | None:
     gather_bytes = 2 * 8 * ph * ph * 3
     model = eng._inference_model(torch.float32)  # noqa: SLF001
     x = reader.read_bounds_batch(in_b[keep][:1]).float().permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
-    flops = _flops_of(model, x)
+    plain = eng.model.module if hasattr(eng.model, "module") else eng.model
+    flops = _flops_of(plain, x)  # counted on the plain torch module (the fused copy launches its own kernels)
     t_fwd = _ev(lambda: eng.model.infer_batch(model, reader.read_bounds_batch(in_b[keep][:8]), device=str(device)), reps=3) / 8
     line = {
         "metric": "patches/s (1024x1024x3 in, 512x512x5 out), SemanticSegmentor(fcn_resnet50_unet-bcss) WSI mode",
@@ -170,7 +171,9 @@ def bench_semantic(args) -> dict | None:
                 "gather_patches_kernel": {"bound": "hbm", "achieved": round(gather_bytes / t_gather / 1e9, 1), "unit": "GB/s",
                                           "frac": round(gather_bytes / t_gather / 1e9 / HBM_PEAK_GBS, 4),
                                           "launch_ms": round(t_gather * 1e3, 4)}},
-            "backbone": {"bound": "mfma", "what": "UNet-R50 forward per 1024^2 patch (MIOpen), batch 8",
+            "backbone": {"bound": "mfma", "what": ("UNet-R50 forward per 1024^2 patch, batch 8: " + type(model).__name__
+                                                   + (" (61 of 63 convolutions on the hand-written MFMA kernel, BN / ReLU / "
+                                                      "residual fused)" if type(model).__name__ == "FusedUNet" else " (MIOpen)")),
                          "gflop_per_patch": round(flops / 1e9, 1), "achieved": round(flops / t_fwd / 1e12, 2),
                          "peak": MFMA_PEAK_F32, "unit": "TFLOP/s", "frac": round(flops / t_fwd / 1e12 / MFMA_PEAK_F32, 4),
                          "ms_per_patch": round(t_fwd * 1e3, 3)}},

@@ -207,3 +207,38 @@ def test_hip_gather_patches_matches_padded_slicing():
     assert np.array_equal(thumb, exp)
     with pytest.raises(ValueError, match="integer down-sampling"):
         ArrayWSIReader(big, power=40.0).slide_thumbnail(3.0, "power")
+
+
+@pytest.mark.gpu
+def test_fused_unet_forward_matches_plain_module():
+    """``FusedUNet`` (61 of 63 convolutions on the MFMA kernel: Bottlenecks as conv+BN+ReLU / conv+BN+identity+ReLU
+    launches, up-sampling fused with the skip add, decoder pre-activations in one pass) against the plain torch module
+    on the CPU in float32 with randomised BN statistics: logits within 2e-4 of their range; and it is what the engine
+    runs for float32 on the GPU."""
+    import copy
+
+    import torch
+
+    from tiatoolbox_amd.models.architecture.unet import UNetModel
+    from tiatoolbox_amd.models.architecture.unet_fused import FusedUNet
+    from tiatoolbox_amd.models.engine.semantic_segmentor import SemanticSegmentor
+
+    torch.manual_seed(1)
+    g = torch.Generator().manual_seed(5)
+    model = UNetModel(3, 5, "resnet50", decoder_block=[3, 3]).eval()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.05, generator=g)
+            mod.running_var.uniform_(0.8, 1.2, generator=g)
+            mod.weight.data.uniform_(0.8, 1.2, generator=g)
+            mod.bias.data.normal_(0, 0.05, generator=g)
+    x = torch.randint(0, 256, (2, 3, 256, 320), generator=g).float()
+    with torch.inference_mode():
+        ref = model(x)
+        got = FusedUNet(copy.deepcopy(model).cuda()).cuda()(x.cuda().contiguous(memory_format=torch.channels_last)).cpu()
+    assert got.shape == ref.shape == (2, 5, 128, 160)
+    assert (got - ref).abs().max() <= 2e-4 * max(float(ref.abs().max()), 1.0)
+    eng = SemanticSegmentor(model, batch_size=2, device="cuda")
+    assert type(eng._inference_model(torch.float32)).__name__ == "FusedUNet"
+    eng.conv_backend = "miopen"
+    assert type(eng._inference_model(torch.float32)).__name__ != "FusedUNet"

@@ -1,0 +1,89 @@
+"""Inference copy of :class:`UNetModel` (ResNet-50 encoder) on the hand-written float32 MFMA convolutions.
+
+Same arithmetic graph as ``UNetModel.forward`` (reference ``models/architecture/unet.py:356-417``):
+
+* encoder = torchvision-layout ResNet-50: every Bottleneck as three launches -- ``conv1 + BN + ReLU``, ``conv2 + BN +
+  ReLU`` and ``conv3 + BN + identity + ReLU`` -- with the BNs folded into the weights and the residual add / ReLU in the
+  convolution epilogues (the down-sampling 1x1 likewise, without ReLU);
+* decoder (pre-activation blocks ``BN -> ReLU -> conv -> BN -> ReLU -> conv`` after ``upsample2x(x) + skip``): the
+  up-sampling and the skip add in one pass, the first BN + ReLU in one pass, the second BN folded into the first
+  convolution;
+* the 3-channel 7x7 stem and the final ``64 -> n_classes`` 1x1 stay on MIOpen; the max-pool is torch's.
+
+Built from a loaded model (reference parameter names); float32, CUDA, channels-last only.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F  # noqa: N812
+from torch import nn
+
+from tiatoolbox_amd.models.architecture.fused import hip_upsample2x_add
+from tiatoolbox_amd.models.architecture.hovernet_fused import _BnAct, _cl, _Conv
+from tiatoolbox_amd.models.architecture.resnet import Bottleneck
+
+
+class _FusedBottleneckMfma(nn.Module):
+    def __init__(self, blk: Bottleneck) -> None:
+        super().__init__()
+        self.c1, self.c2, self.c3 = _Conv(blk.conv1, blk.bn1), _Conv(blk.conv2, blk.bn2), _Conv(blk.conv3, blk.bn3)
+        self.pad = blk.conv2.padding[0]
+        self.down = _Conv(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        identity = x if self.down is None else self.down(x)
+        out = self.c1(x, relu=True)
+        out = self.c2(out, pads=(self.pad, self.pad), relu=True)
+        return self.c3(out, relu=True, residual=_cl(identity))
+
+
+class FusedUNet(nn.Module):
+    """``forward(x)`` == ``UNetModel.forward(x)`` (class logits), float32 on a CUDA device; ResNet-50 encoder, pre-activation
+    decoder, ``skip_type="add"`` (the layout of ``fcn-tissue_mask`` / ``fcn_resnet50_unet-bcss``)."""
+
+    def __init__(self, model: nn.Module) -> None:
+        super().__init__()
+        model = model.eval()
+        bb = model.backbone
+        if not hasattr(bb, "layer1") or model.skip_type != "add":
+            msg = "FusedUNet covers the ResNet-50 encoder with additive skip connections."
+            raise TypeError(msg)
+        self.stem = _Conv(bb.conv1, bb.bn1)
+        self.stem_pad = bb.conv1.padding[0]
+        self.maxpool = bb.maxpool
+        self.layers = nn.ModuleList(nn.Sequential(*[_FusedBottleneckMfma(b) for b in layer])
+                                    for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4))
+        self.conv1x1 = _Conv(model.conv1x1)
+        self.up = nn.ModuleList()
+        for block in model.uplist:
+            mods = list(block)
+            # [BN_a, ReLU, conv_a, BN_b, ReLU, conv_b, ...]: BN_a stays a pass of its own, every later BN folds backwards
+            if not (isinstance(mods[0], nn.BatchNorm2d) and len(mods) % 3 == 0):
+                msg = "FusedUNet expects pre-activation decoder blocks."
+                raise TypeError(msg)
+            convs = [mods[i] for i in range(2, len(mods), 3)]
+            bns = [mods[i] for i in range(3, len(mods), 3)]
+            stage = nn.ModuleList([_BnAct(mods[0])])
+            for i, conv in enumerate(convs):
+                stage.append(_Conv(conv, bns[i] if i < len(bns) else None))
+            self.up.append(stage)
+        self.clf = _Conv(model.clf)
+
+    def forward(self, imgs: torch.Tensor, *args, **kwargs) -> torch.Tensor:  # noqa: ARG002
+        x = _cl(imgs / 255.0)
+        feats = [self.stem(x, pads=(self.stem_pad, self.stem_pad), relu=True)]
+        x = self.maxpool(feats[0])
+        for layer in self.layers:
+            x = layer(x)
+            feats.append(x)
+        x = self.conv1x1(feats[-1])
+        skips = feats[:-1]
+        for idx, stage in enumerate(self.up, start=1):
+            x = hip_upsample2x_add(_cl(x), _cl(skips[-idx]))
+            x = stage[0](x, inplace=True)
+            for j, conv in enumerate(list(stage)[1:]):
+                last = j == len(stage) - 2
+                p = (conv.kernel - 1) // 2
+                x = conv(x, pads=(p, p), relu=not last)
+        return self.clf(x)
