@@ -411,6 +411,13 @@ int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed, const floa
 int tia_scale_shift_act_nhwc_f32(const float* d_x, const float* d_scale, const float* d_shift, float* d_y, int64_t rows,
                                  int64_t c, int32_t relu, void* stream);
 
+/* The same on a view: d_x points at element [0,0,0,0] of a window of a wider NHWC buffer (a channel prefix and a spatial
+ * crop), strides in elements (multiples of 4, 16-byte aligned base, x_pixel_stride >= c); y [n,h,w,c] dense.  Lets the
+ * dense units of HoVer-Net (hovernet.py:72-98) grow their feature stack in place instead of re-concatenating it. */
+int tia_scale_shift_act_view_nhwc_f32(const float* d_x, int64_t x_image_stride, int64_t x_row_stride, int64_t x_pixel_stride,
+                                      const float* d_scale, const float* d_shift, float* d_y, int64_t n, int64_t h,
+                                      int64_t w, int64_t c, int32_t relu, void* stream);
+
 /* out[b, Y, X, :] = x[b, Y/2, X/2, :] + y[b, Y, X, :] on NHWC float32: nearest x2 upsampling fused with the decoder's
  * skip-connection add (models/architecture/hovernet.py:447-449, utils.py:202-243).  x [n,h,w,c]; y a (possibly
  * centre-cropped) view of an NHWC tensor with contiguous channels: d_y points at its first element,

@@ -649,7 +649,13 @@ def test_fused_hovernet_forward_matches_plain_module(plus):
         sc, sh = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g)
         got = hip_scale_shift_act(x.cuda().contiguous(memory_format=torch.channels_last), sc.cuda(), sh.cuda())
         assert torch.equal(got.cpu(), torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]))
-        from tiatoolbox_amd.models.architecture.fused import hip_upsample2x_add
+        from tiatoolbox_amd.models.architecture.fused import hip_scale_shift_act_view, hip_upsample2x_add
+
+        wide = torch.randn((2, 160, 9, 11), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        win = wide[:, :96, 2:7, 1:10]
+        exp = torch.relu(win * sc.cuda()[None, :, None, None] + sh.cuda()[None, :, None, None])
+        got = hip_scale_shift_act_view(win, sc.cuda(), sh.cuda())
+        assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, exp)
 
         lo = torch.randn((2, 32, 5, 7), generator=g).cuda().contiguous(memory_format=torch.channels_last)
         skip = torch.randn((2, 32, 16, 20), generator=g).cuda().contiguous(memory_format=torch.channels_last)[:, :, 3:13, 3:17]

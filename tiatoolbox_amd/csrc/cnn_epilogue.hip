@@ -225,6 +225,34 @@ __global__ __launch_bounds__(ET) void upsample2x_add_kernel(const u4* __restrict
     }
 }
 
+
+// The same on a VIEW of an NHWC tensor (a channel prefix and a spatial window of a wider buffer: image / row / pixel
+// strides in elements), written densely: what lets the dense units of HoVer-Net grow their feature stack in place
+// instead of re-concatenating it (hovernet.py:93-98).
+__global__ __launch_bounds__(ET) void scale_shift_act_view_kernel(const float* __restrict__ x, long sb, long sy, long sp,
+                                                                   const u4* __restrict__ scale, const u4* __restrict__ shift, int n,
+                                                                   int h, int w, int cv, int relu, u4* __restrict__ y) {
+    const long total = (long)n * h * w * cv;
+    for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
+        const int c = (int)(i % cv);
+        long t = i / cv;
+        const int px = (int)(t % w);
+        t /= w;
+        const int py = (int)(t % h), b = (int)(t / h);
+        float f[8], sc[8], sh[8];
+        Vec<float>::unpack(*reinterpret_cast<const u4*>(x + (long)b * sb + (long)py * sy + (long)px * sp + 4 * c), f);
+        Vec<float>::unpack(scale[c], sc);
+        Vec<float>::unpack(shift[c], sh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = f[k] * sc[k];
+            v = v + sh[k];
+            f[k] = relu ? (v > 0.0f ? v : 0.0f) : v;
+        }
+        y[i] = Vec<float>::pack(f);
+    }
+}
+
 }  // namespace tia
 
 using namespace tia;
@@ -281,5 +309,22 @@ extern "C" int tia_upsample2x_add_nhwc_f32(const float* d_x, const float* d_y, i
     if (blocks > 256L * 64) blocks = 256L * 64;
     hipLaunchKernelGGL(upsample2x_add_kernel, dim3((unsigned)blocks), dim3(ET), 0, (hipStream_t)stream, (const u4*)d_x, d_y,
                        (long)y_image_stride, (long)y_row_stride, (int)n, (int)h, (int)w, (int)(c / 4), (u4*)d_out);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_scale_shift_act_view_nhwc_f32(const float* d_x, int64_t x_image_stride, int64_t x_row_stride, int64_t x_pixel_stride,
+                                                  const float* d_scale, const float* d_shift, float* d_y, int64_t n, int64_t h,
+                                                  int64_t w, int64_t c, int32_t relu, void* stream) {
+    if (!d_x || !d_scale || !d_shift || !d_y || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) != 0) return TIA_EINVAL;
+    if (((x_image_stride | x_row_stride | x_pixel_stride) & 3) != 0 || x_pixel_stride < c) return TIA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_scale) | reinterpret_cast<uintptr_t>(d_shift) |
+         reinterpret_cast<uintptr_t>(d_y)) & 15)
+        return TIA_EINVAL;
+    const long total = n * h * w * (c / 4);
+    long blocks = (total + ET - 1) / ET;
+    if (blocks > 256L * 64) blocks = 256L * 64;
+    hipLaunchKernelGGL(scale_shift_act_view_kernel, dim3((unsigned)blocks), dim3(ET), 0, (hipStream_t)stream, d_x, (long)x_image_stride,
+                       (long)x_row_stride, (long)x_pixel_stride, (const u4*)d_scale, (const u4*)d_shift, (int)n, (int)h, (int)w,
+                       (int)(c / 4), relu, (u4*)d_y);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

@@ -274,6 +274,26 @@ def hip_scale_shift_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tenso
     return y
 
 
+def hip_scale_shift_act_view(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, *, relu: bool = True) -> torch.Tensor:
+    """``relu(x * scale[c] + shift[c])`` of a channel-prefix / spatial-window VIEW of a channels-last float32 CUDA tensor,
+    written to a dense channels-last tensor (``tia_scale_shift_act_view_nhwc_f32``)."""
+    from tiatoolbox_amd import _lib
+
+    n, c, h, w = x.shape
+    ok = (x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and c % 4 == 0 and x.data_ptr() % 16 == 0
+          and all(x.stride(d) % 4 == 0 for d in (0, 2, 3)) and x.stride(3) >= c)
+    if not ok:
+        y = x * scale[None, :, None, None] + shift[None, :, None, None]
+        return (F.relu(y) if relu else y).contiguous(memory_format=torch.channels_last)
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_scale_shift_act_view_nhwc_f32(x.data_ptr(), x.stride(0), x.stride(2), x.stride(3), scale.data_ptr(),
+                                                           shift.data_ptr(), y.data_ptr(), n, h, w, c, int(relu),
+                                                           _lib.current_stream())
+    _lib.check(rc, "tia_scale_shift_act_view_nhwc_f32")
+    return y
+
+
 def hip_upsample2x_add(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """``x.repeat_interleave(2, 2).repeat_interleave(2, 3) + y`` in one pass (``tia_upsample2x_add_nhwc_f32``); ``y`` may be a
     centre-cropped view of a channels-last tensor."""

@@ -25,7 +25,7 @@ import torch.nn.functional as F  # noqa: N812
 from torch import nn
 
 from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv2d_ex, hip_scale_shift_act,
-                                                      hip_upsample2x_add, pack_conv_weights)
+                                                      hip_scale_shift_act_view, hip_upsample2x_add, pack_conv_weights)
 from tiatoolbox_amd.models.architecture.hovernet import centre_crop_to_shape
 from tiatoolbox_amd.models.architecture.utils import centre_crop
 
@@ -95,6 +95,10 @@ class _BnAct(nn.Module):
     def forward(self, x: torch.Tensor, *, inplace: bool = False) -> torch.Tensor:
         return hip_scale_shift_act(_cl(x), self.scale, self.shift, relu=True, inplace=inplace)
 
+    def view(self, x: torch.Tensor) -> torch.Tensor:
+        """The same for a channel-prefix / window view of a wider channels-last buffer; dense result."""
+        return hip_scale_shift_act_view(x, self.scale, self.shift, relu=True)
+
 
 class _FusedResidualBlock(nn.Module):
     def __init__(self, blk: nn.Module) -> None:
@@ -133,10 +137,22 @@ class _FusedDenseBlock(nn.Module):
         self.out = _BnAct(blk.blk_bna.bn)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        for pre, c1, c2 in zip(self.pre, self.c1, self.c2):
-            new = c2(c1(pre(x), relu=True))
-            x = torch.cat([centre_crop_to_shape(x, new), new], dim=1)
-        return self.out(x, inplace=True)
+        # x_{i+1} = cat(centre_crop(x_i), new_i): instead of re-concatenating the growing stack, one buffer holds all
+        # channels at the input size; unit i reads the channel prefix / shrinking window it owns and writes its 32 new
+        # channels into the next slice (valid k x k convolutions crop (k - 1) / 2 pixels per side and unit)
+        n, c0, h0, w0 = x.shape
+        units = len(self.c1)
+        grow = self.c2[0].weight.shape[0]
+        r = (self.c2[0].kernel - 1) // 2
+        buf = torch.empty((n, c0 + grow * units, h0, w0), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        buf[:, :c0] = x
+        c = c0
+        for i, (pre, c1, c2) in enumerate(zip(self.pre, self.c1, self.c2)):
+            view = buf[:, :c, i * r:h0 - i * r, i * r:w0 - i * r]
+            new = c2(c1(pre.view(view), relu=True))
+            buf[:, c:c + grow, (i + 1) * r:h0 - (i + 1) * r, (i + 1) * r:w0 - (i + 1) * r] = new
+            c += grow
+        return self.out.view(buf[:, :, units * r:h0 - units * r, units * r:w0 - units * r])
 
 
 class _FusedBranch(nn.Module):
