@@ -418,6 +418,16 @@ int tia_scale_shift_act_view_nhwc_f32(const float* d_x, int64_t x_image_stride, 
                                       const float* d_scale, const float* d_shift, float* d_y, int64_t n, int64_t h,
                                       int64_t w, int64_t c, int32_t relu, void* stream);
 
+/* Grouped "valid" k x k convolution, stride 1, 32 input and 8 output channels per group (the second convolution of
+ * HoVer-Net's dense units, hovernet.py:86-88: Conv2d(128, 32, k, groups=4)); float32 NHWC.
+ *   d_x [n,h,w,groups*32] dense;  d_w_packed [groups][k][k][32][8] (from OIHW [groups*8, 32, k, k]);
+ *   y: element [b, oy, ox, c] at d_y + b*y_image_stride + oy*y_row_stride + ox*y_pixel_stride + c (strides in
+ *   elements, multiples of 4), ho = h - k + 1 -- so the result can land in a channel slice of a wider buffer.
+ * Other channel counts -> TIA_ESIZE. */
+int tia_grouped_conv_valid_nhwc_f32(const float* d_x, const float* d_w_packed, float* d_y, int64_t y_image_stride,
+                                    int64_t y_row_stride, int64_t y_pixel_stride, int64_t n, int64_t h, int64_t w,
+                                    int64_t groups, int64_t cin_per_group, int64_t cout_per_group, int64_t k, void* stream);
+
 /* out[b, Y, X, :] = x[b, Y/2, X/2, :] + y[b, Y, X, :] on NHWC float32: nearest x2 upsampling fused with the decoder's
  * skip-connection add (models/architecture/hovernet.py:447-449, utils.py:202-243).  x [n,h,w,c]; y a (possibly
  * centre-cropped) view of an NHWC tensor with contiguous channels: d_y points at its first element,

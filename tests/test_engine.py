@@ -278,12 +278,14 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
 
 
 @pytest.mark.gpu
-def test_mfma_resnet_matches_plain_model(patches):
-    """resnet18 with every block convolution on the hand-written MFMA kernel == the plain torch module on the CPU."""
+@pytest.mark.parametrize("name", ["resnet18-kather100k", "resnet50-kather100k"])
+def test_mfma_resnet_matches_plain_model(patches, name):
+    """resnet18 (BasicBlock) / resnet50 (Bottleneck) with every block convolution on the hand-written MFMA kernel == the
+    plain torch module on the CPU."""
     from tiatoolbox_amd.models.architecture import get_pretrained_model
     from tiatoolbox_amd.models.architecture.fused import fuse_cnn_model
 
-    model, _ = get_pretrained_model("resnet18-kather100k")
+    model, _ = get_pretrained_model(name)
     for mod in model.modules():
         if isinstance(mod, torch.nn.BatchNorm2d):
             mod.running_mean.normal_(0, 0.1)
@@ -296,9 +298,10 @@ def test_mfma_resnet_matches_plain_model(patches):
         mfma = fuse_cnn_model(model, epilogue_fusion="mfma").cuda().to(memory_format=torch.channels_last)
         got = mfma(x.cuda().contiguous(memory_format=torch.channels_last)).cpu()
     assert (got - ref).abs().max() < 1e-4
-    eng = PatchPredictor("resnet18-kather100k", batch_size=4, device="cuda")
+    eng = PatchPredictor(name, batch_size=4, device="cuda")
     a = eng.run(patches, patch_mode=True, return_probabilities=True, conv_backend="mfma")
-    b = PatchPredictor("resnet18-kather100k", batch_size=4).run(patches, patch_mode=True, return_probabilities=True)
+    assert any(type(m).__name__ == "MfmaResNet" for m in eng._inference_model(torch.float32).modules())
+    b = PatchPredictor(name, batch_size=4).run(patches, patch_mode=True, return_probabilities=True)
     np.testing.assert_allclose(a["probabilities"], b["probabilities"], atol=1e-4)
 
 

@@ -651,6 +651,20 @@ def test_fused_hovernet_forward_matches_plain_module(plus):
         assert torch.equal(got.cpu(), torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]))
         from tiatoolbox_amd.models.architecture.fused import hip_scale_shift_act_view, hip_upsample2x_add
 
+        from tiatoolbox_amd.models.architecture.fused import hip_grouped_conv_valid
+
+        for k in (3, 5):  # the dense units' grouped convolution (fast: 3x3, original: 5x5), also into a slice of a wider buffer
+            conv = torch.nn.Conv2d(128, 32, k, groups=4, bias=False)
+            xg = torch.randn((3, 128, 13, 17), generator=g)
+            ref = conv(xg).detach()
+            wp = conv.weight.detach().view(4, 8, 32, k, k).permute(0, 3, 4, 2, 1).contiguous().cuda()
+            xd = xg.cuda().contiguous(memory_format=torch.channels_last)
+            got = hip_grouped_conv_valid(xd, wp, groups=4, kernel=k)
+            assert got.shape == ref.shape and (got.cpu() - ref).abs().max() <= 1e-5
+            big = torch.zeros((3, 96, 13, 17), device="cuda").contiguous(memory_format=torch.channels_last)
+            r = (k - 1) // 2
+            hip_grouped_conv_valid(xd, wp, groups=4, kernel=k, out=big[:, 64:96, r:13 - r, r:17 - r])
+            assert torch.equal(big[:, 64:96, r:13 - r, r:17 - r], got) and float(big[:, :64].abs().max()) == 0.0
         wide = torch.randn((2, 160, 9, 11), generator=g).cuda().contiguous(memory_format=torch.channels_last)
         win = wide[:, :96, 2:7, 1:10]
         exp = torch.relu(win * sc.cuda()[None, :, None, None] + sh.cuda()[None, :, None, None])

@@ -253,6 +253,53 @@ __global__ __launch_bounds__(ET) void scale_shift_act_view_kernel(const float* _
     }
 }
 
+
+// Grouped "valid" k x k convolution with few channels per group (HoVer-Net's dense units: 128 -> 32 channels in 4 groups of
+// 32 -> 8, hovernet.py:86-88), float32 NHWC.  Too narrow for the 32-wide MFMA tile (a block-diagonal dense formulation
+// wastes three quarters of the matrix work), so: one thread per output pixel and group, 8 accumulators, the pixel's 32
+// input channels as eight 16-byte loads per tap, the group's weights wave-uniform (scalar loads), fmaf chain in
+// (tap, channel) order.  The result may go into a channel slice / spatial window of a wider buffer (strides in elements).
+template <int CPG, int OPG>
+__global__ __launch_bounds__(ET) void grouped_conv_valid_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                                 float* __restrict__ y, int n, int h, int w, int groups, int k,
+                                                                 long y_sb, long y_sy, long y_sp) {
+    const int g = blockIdx.y;
+    const int ho = h - k + 1, wo = w - k + 1;
+    const long m_total = (long)n * ho * wo;
+    const long m = (long)blockIdx.x * ET + threadIdx.x;
+    const bool valid = m < m_total;
+    const long mm = valid ? m : 0;
+    const int b = (int)(mm / ((long)ho * wo));
+    const int rem = (int)(mm - (long)b * ho * wo);
+    const int oy = rem / wo, ox = rem - oy * wo;
+    const int cin = groups * CPG;
+    const float* xp = x + (((long)b * h + oy) * w + ox) * cin + g * CPG;
+    const float* wg = wpk + (long)g * k * k * CPG * OPG;
+    float acc[OPG];
+#pragma unroll
+    for (int j = 0; j < OPG; ++j) acc[j] = 0.0f;
+    for (int ky = 0; ky < k; ++ky) {
+        for (int kx = 0; kx < k; ++kx) {
+            const float4* xr = reinterpret_cast<const float4*>(xp + ((long)ky * w + kx) * cin);
+            const float* wr = wg + (long)(ky * k + kx) * CPG * OPG;
+#pragma unroll
+            for (int c4 = 0; c4 < CPG / 4; ++c4) {
+                const float4 v = xr[c4];
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < OPG; ++j) acc[j] = fmaf(e[q], wr[(4 * c4 + q) * OPG + j], acc[j]);
+            }
+        }
+    }
+    if (valid) {
+        float* yp = y + (long)b * y_sb + (long)oy * y_sy + (long)ox * y_sp + g * OPG;
+#pragma unroll
+        for (int j = 0; j < OPG; j += 4) *reinterpret_cast<float4*>(yp + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+    }
+}
+
 }  // namespace tia
 
 using namespace tia;
@@ -326,5 +373,22 @@ extern "C" int tia_scale_shift_act_view_nhwc_f32(const float* d_x, int64_t x_ima
     hipLaunchKernelGGL(scale_shift_act_view_kernel, dim3((unsigned)blocks), dim3(ET), 0, (hipStream_t)stream, d_x, (long)x_image_stride,
                        (long)x_row_stride, (long)x_pixel_stride, (const u4*)d_scale, (const u4*)d_shift, (int)n, (int)h, (int)w,
                        (int)(c / 4), relu, (u4*)d_y);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_grouped_conv_valid_nhwc_f32(const float* d_x, const float* d_w_packed, float* d_y, int64_t y_image_stride,
+                                                int64_t y_row_stride, int64_t y_pixel_stride, int64_t n, int64_t h, int64_t w,
+                                                int64_t groups, int64_t cin_per_group, int64_t cout_per_group, int64_t k,
+                                                void* stream) {
+    if (!d_x || !d_w_packed || !d_y || n <= 0 || groups <= 0 || groups > 65535 || k <= 0 || h < k || w < k) return TIA_EINVAL;
+    if (cin_per_group != 32 || cout_per_group != 8) return TIA_ESIZE;
+    if (((y_image_stride | y_row_stride | y_pixel_stride) & 3) != 0 || y_pixel_stride < groups * cout_per_group) return TIA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_w_packed) | reinterpret_cast<uintptr_t>(d_y)) & 15) return TIA_EINVAL;
+    const long m_total = n * (h - k + 1) * (w - k + 1);
+    const long blocks = (m_total + ET - 1) / ET;
+    if (blocks > 0x7fffffffL) return TIA_ESIZE;
+    hipLaunchKernelGGL((grouped_conv_valid_kernel<32, 8>), dim3((unsigned)blocks, (unsigned)groups), dim3(ET), 0, (hipStream_t)stream, d_x,
+                       d_w_packed, d_y, (int)n, (int)h, (int)w, (int)groups, (int)k, (long)y_image_stride, (long)y_row_stride,
+                       (long)y_pixel_stride);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

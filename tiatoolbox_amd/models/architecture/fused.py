@@ -294,6 +294,31 @@ def hip_scale_shift_act_view(x: torch.Tensor, scale: torch.Tensor, shift: torch.
     return y
 
 
+def hip_grouped_conv_valid(x: torch.Tensor, w_packed: torch.Tensor, *, groups: int, kernel: int,
+                           out: torch.Tensor | None = None) -> torch.Tensor:
+    """Grouped valid ``kernel x kernel`` convolution, 32 -> 8 channels per group (``tia_grouped_conv_valid_nhwc_f32``); ``out``
+    may be a channel slice / window view of a wider channels-last buffer.  ``w_packed``: ``[groups, k, k, 32, 8]``."""
+    from tiatoolbox_amd import _lib
+
+    if not (_nhwc_ptr_ok(x) and x.dtype == torch.float32):
+        msg = "hip_grouped_conv_valid expects a float32 channels-last CUDA tensor."
+        raise ValueError(msg)
+    n, cin, h, w = x.shape
+    ho, wo = h - kernel + 1, w - kernel + 1
+    if out is None:
+        out = torch.empty((n, groups * 8, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if (out.shape != (n, groups * 8, ho, wo) or out.stride(1) != 1 or out.dtype != torch.float32 or out.data_ptr() % 16
+            or any(out.stride(d) % 4 for d in (0, 2, 3))):
+        msg = "hip_grouped_conv_valid: `out` must be a float32 channels-last (view of a) tensor of the output shape."
+        raise ValueError(msg)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_grouped_conv_valid_nhwc_f32(x.data_ptr(), w_packed.data_ptr(), out.data_ptr(), out.stride(0),
+                                                         out.stride(2), out.stride(3), n, h, w, groups, cin // groups, 8, kernel,
+                                                         _lib.current_stream())
+    _lib.check(rc, "tia_grouped_conv_valid_nhwc_f32")
+    return out
+
+
 def hip_upsample2x_add(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """``x.repeat_interleave(2, 2).repeat_interleave(2, 3) + y`` in one pass (``tia_upsample2x_add_nhwc_f32``); ``y`` may be a
     centre-cropped view of a channels-last tensor."""
@@ -351,9 +376,36 @@ class _MfmaBasic(nn.Module):
         return hip_conv2d(out, self._w("conv2"), self.conv2.bias, identity, kernel=3, stride=1, padding=1, relu=True)
 
 
+class _MfmaBottleneck(nn.Module):
+    """Bottleneck as (downsample) / 1x1+bias+ReLU / 3x3+bias+ReLU / 1x1+bias+residual+ReLU launches."""
+
+    def __init__(self, blk: Bottleneck) -> None:
+        super().__init__()
+        self.conv1, self.conv2, self.conv3 = blk.conv1, blk.conv2, blk.conv3
+        self.down = blk.downsample[0] if blk.downsample is not None else None
+        self._packed: dict[str, torch.Tensor] = {}
+
+    def _w(self, name: str) -> torch.Tensor:
+        conv = getattr(self, name)
+        cached = self._packed.get(name)
+        if cached is None or cached.device != conv.weight.device:
+            cached = self._packed[name] = pack_conv_weights(conv)
+        return cached
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        identity = x
+        if self.down is not None:
+            identity = hip_conv2d(x, self._w("down"), self.down.bias, None, kernel=1, stride=self.down.stride[0], padding=0,
+                                  relu=False)
+        out = hip_conv2d(x, self._w("conv1"), self.conv1.bias, None, kernel=1, stride=self.conv1.stride[0], padding=0, relu=True)
+        out = hip_conv2d(out, self._w("conv2"), self.conv2.bias, None, kernel=3, stride=self.conv2.stride[0], padding=1, relu=True)
+        return hip_conv2d(out, self._w("conv3"), self.conv3.bias, identity, kernel=1, stride=1, padding=0, relu=True)
+
+
 class MfmaResNet(nn.Module):
-    """ResNet-18/34 trunk in float32: stem = MIOpen 7x7 (3 input channels) + the fused bias/ReLU/max-pool kernel, every
-    BasicBlock convolution = the hand-written MFMA implicit GEMM with its epilogue fused (BN folded, channels-last)."""
+    """ResNet trunk in float32: stem = MIOpen 7x7 (3 input channels) + the fused bias/ReLU/max-pool kernel, every block
+    convolution (BasicBlock: resnet18/34; Bottleneck: resnet50/101) = the hand-written MFMA implicit GEMM with its epilogue
+    fused (BN folded, channels-last)."""
 
     def __init__(self, trunk: nn.Sequential) -> None:
         super().__init__()
@@ -362,10 +414,10 @@ class MfmaResNet(nn.Module):
         blocks = []
         for layer in list(folded)[4:]:
             for blk in layer:
-                if not isinstance(blk, BasicBlock):
-                    msg = "MfmaResNet covers BasicBlock trunks (resnet18 / resnet34)."
+                if not isinstance(blk, (BasicBlock, Bottleneck)):
+                    msg = "MfmaResNet covers BasicBlock / Bottleneck trunks."
                     raise TypeError(msg)
-                blocks.append(_MfmaBasic(blk))
+                blocks.append(_MfmaBasic(blk) if isinstance(blk, BasicBlock) else _MfmaBottleneck(blk))
         self.blocks = nn.Sequential(*blocks)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -24,8 +24,9 @@ import torch
 import torch.nn.functional as F  # noqa: N812
 from torch import nn
 
-from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv2d_ex, hip_scale_shift_act,
-                                                      hip_scale_shift_act_view, hip_upsample2x_add, pack_conv_weights)
+from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv2d_ex, hip_grouped_conv_valid,
+                                                      hip_scale_shift_act, hip_scale_shift_act_view, hip_upsample2x_add,
+                                                      pack_conv_weights)
 from tiatoolbox_amd.models.architecture.hovernet import centre_crop_to_shape
 from tiatoolbox_amd.models.architecture.utils import centre_crop
 
@@ -61,12 +62,20 @@ class _Conv(nn.Module):
         self.kernel, self.stride = conv.kernel_size[0], conv.stride[0]
         self.mfma_ok = conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
         self.groups = conv.groups
+        # the dense units' grouped convolution: 32 -> 8 channels per group, stride 1, no bias
+        self.grouped_ok = (conv.groups > 1 and conv.in_channels // conv.groups == 32 and conv.out_channels // conv.groups == 8
+                           and conv.stride[0] == 1 and bias is None)
         self.weight = nn.Parameter(w.contiguous(), requires_grad=False)
         self.bias = nn.Parameter(bias.contiguous(), requires_grad=False) if bias is not None else None
         self._packed: torch.Tensor | None = None
 
     def forward(self, x: torch.Tensor, *, pads: tuple[int, int] = (0, 0), relu: bool = False,
-                residual: torch.Tensor | None = None) -> torch.Tensor:
+                residual: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+        if self.grouped_ok and pads == (0, 0) and not relu and residual is None:
+            if self._packed is None or self._packed.device != self.weight.device:
+                g, k = self.groups, self.kernel
+                self._packed = self.weight.view(g, 8, 32, k, k).permute(0, 3, 4, 2, 1).contiguous()  # [g][ky][kx][c][j]
+            return hip_grouped_conv_valid(_cl(x), self._packed, groups=self.groups, kernel=self.kernel, out=out)
         if self.mfma_ok:
             if self._packed is None or self._packed.device != self.weight.device:
                 self._packed = pack_conv_weights(self)  # reads `.weight` (OIHW)
@@ -149,8 +158,11 @@ class _FusedDenseBlock(nn.Module):
         c = c0
         for i, (pre, c1, c2) in enumerate(zip(self.pre, self.c1, self.c2)):
             view = buf[:, :c, i * r:h0 - i * r, i * r:w0 - i * r]
-            new = c2(c1(pre.view(view), relu=True))
-            buf[:, c:c + grow, (i + 1) * r:h0 - (i + 1) * r, (i + 1) * r:w0 - (i + 1) * r] = new
+            dst = buf[:, c:c + grow, (i + 1) * r:h0 - (i + 1) * r, (i + 1) * r:w0 - (i + 1) * r]
+            if c2.grouped_ok:
+                c2(c1(pre.view(view), relu=True), out=dst)  # written straight into its slice
+            else:
+                dst.copy_(c2(c1(pre.view(view), relu=True)))
             c += grow
         return self.out.view(buf[:, :, units * r:h0 - units * r, units * r:w0 - units * r])
 

@@ -283,13 +283,13 @@ class EngineABC:
 
                 on_gpu = torch.device(self.device).type == "cuda"
                 # `conv_backend` (run kwarg / attribute): "mfma" (default) = the hand-written float32 MFMA implicit GEMM with
-                # its epilogue fused, for float32 runs of BasicBlock trunks (resnet18/34); "miopen" = library convolutions
-                # + hand-written epilogues (always used for fp16 / bf16 and Bottleneck trunks)
+                # its epilogue fused, for float32 runs of ResNet trunks (BasicBlock and Bottleneck); "miopen" = library
+                # convolutions + hand-written epilogues (always used for fp16 / bf16)
                 backend = str(getattr(self, "conv_backend", "mfma"))
-                from tiatoolbox_amd.models.architecture.resnet import BasicBlock
+                from tiatoolbox_amd.models.architecture.resnet import BasicBlock, Bottleneck
 
-                basic = any(isinstance(mod, BasicBlock) for mod in m.modules())
-                use_mfma = on_gpu and backend == "mfma" and dtype == torch.float32 and basic
+                resnet = any(isinstance(mod, (BasicBlock, Bottleneck)) for mod in m.modules())
+                use_mfma = on_gpu and backend == "mfma" and dtype == torch.float32 and resnet
                 m = fuse_cnn_model(m, epilogue_fusion=("mfma" if use_mfma else "hip") if on_gpu else False)
             else:
                 from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
