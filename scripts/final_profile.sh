@@ -1,11 +1,12 @@
 #!/bin/bash
 # Round-end measurement pass on the GPU box (everything lands in gpurun_out/, copied to profiles/ afterwards):
 # full GPU test suite, smoke, the default bench (+cpu_baseline), rocprofv3 kernel trace of the bench, separate --pmc
-# passes (HBM traffic of the stain kernels; MFMA-busy of the convolution kernel), the other kernel families.
+# passes (HBM traffic of the stain kernels; the convolution kernel's counters are scripts/r02_call9.sh), the other kernel
+# families, the other bench configurations.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-TAG=${1:-r02f}
+TAG=${1:-r02p}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
@@ -21,16 +22,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
       python $R/scripts/perf_stain.py 4096 > /dev/null 2>&1
   python $R/scripts/prof_summarize.py /tmp/rp_$c $OUT/${TAG}_stain_pmc_${c}.txt > /dev/null
 done
-rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u > $OUT/${TAG}_mfma_counter_names.txt; cat $OUT/${TAG}_mfma_counter_names.txt | tr '\n' ' '; echo
-for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES; do
-  rm -rf /tmp/rp_$c; timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/rp_$c -- \
-      python $R/scripts/perf_conv.py 1024 > /dev/null 2>&1
-  python $R/scripts/prof_summarize.py /tmp/rp_$c $OUT/${TAG}_conv_pmc_${c}.txt > /dev/null 2>&1; grep -h conv_mfma $OUT/${TAG}_conv_pmc_${c}.txt | cut -c1-120
-done
 cd $R
 timeout 400 python scripts/perf_stain.py 4096 2>&1 | grep -v amdgpu > $OUT/${TAG}_perf_stain.txt
 timeout 300 python scripts/perf_conv.py 1024 2>&1 | grep -v amdgpu > $OUT/${TAG}_perf_conv.txt; tail -1 $OUT/${TAG}_perf_conv.txt
 timeout 400 python scripts/perf_kernels.py 2>&1 | grep stage > $OUT/${TAG}_perf_kernels.jsonl
 timeout 600 python bench.py --config hovernet --steps 5 --warmup 2 > $OUT/${TAG}_bench_hovernet.json 2> /dev/null; cut -c1-300 $OUT/${TAG}_bench_hovernet.json
 timeout 300 python bench.py --config vahadane --steps 5 --warmup 2 > $OUT/${TAG}_bench_vahadane.json 2> /dev/null; cut -c1-200 $OUT/${TAG}_bench_vahadane.json
+timeout 600 python bench.py --config semantic --steps 1 --warmup 1 > $OUT/${TAG}_bench_semantic.json 2> /dev/null; cut -c1-300 $OUT/${TAG}_bench_semantic.json
 ls $OUT | grep $TAG | wc -l
