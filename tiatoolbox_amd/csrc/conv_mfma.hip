@@ -15,11 +15,14 @@
 //     and the bounds check zero-fills padding taps
 //   * measured and rejected on MI355X (profiles/r02h_perf_conv_v*.txt): double-buffered LDS with the staging write in the
 //     middle of the MFMA loop and one barrier per slice (2 workgroups / CU instead of 3: -5 %), s_setprio around the MFMA
-//     phase (-4 %), 256 x 64 tiles for cout = 64 (-3 %), forcing 4 / 6 waves per SIMD by register cap (spills: -1 / -13 %)
+//     phase (-4 %), 256 x 64 tiles for cout = 64 (-3 %), forcing 4 / 6 waves per SIMD by register cap (spills: -1 / -13 %);
+//     128 x 64 tiles everywhere (TIA_CONV_BN64=1): +15-20 % on the three 1x1 down-sampling convolutions, +3 % on the last 3x3
+//     layer, -3 % on the 28^2 / 14^2 layers -- the trunk total is unchanged (profiles/r02q_perf_conv_bn64.txt)
 //   * blockIdx is remapped so that each XCD (its own L2) walks a contiguous range of pixel tiles: neighbouring tiles
 //     share their input halo rows
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/tiatoolbox_amd.h"
 
@@ -290,7 +293,8 @@ extern "C" int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed,
         const float* rg = d_residual ? d_residual + first * ho * wo * cout : nullptr;
         float* yg = d_y + first * ho * wo * cout;
         const long grid_x = ((m_tiles + 7) / 8) * 8;  // whole rounds over the 8 XCDs (surplus workgroups exit at once)
-        if (cout % 128 == 0)
+        static const bool force64 = getenv("TIA_CONV_BN64") != nullptr;  // developer switch (tile-shape experiments)
+        if (cout % 128 == 0 && !force64)
             hipLaunchKernelGGL(conv_mfma_f32_kernel<128>, dim3((unsigned)grid_x, (unsigned)(cout / 128)), dim3(NTH), 0, st, xg,
                                d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles);
         else
