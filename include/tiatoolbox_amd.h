@@ -405,6 +405,17 @@ int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed, const floa
                            int64_t kw, int64_t stride, int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo,
                            int32_t relu, void* stream);
 
+/* tia_conv2d_nhwc_f32_ex with a second, post-activated output produced in the same epilogue:
+ *   v  = act(conv(x, w) + bias [+ residual])      -> d_y   (may be NULL when only d_y2 is wanted)
+ *   y2 = relu(v * post_scale[c] + post_shift[c])   -> d_y2  (required)
+ * i.e. the BatchNorm + ReLU that follows a residual sum in a pre-activation network (HoVer-Net's next-unit "preact" /
+ * "blk_bna", models/architecture/hovernet.py:100-147), applied while the sum is still in registers. */
+int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                             float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
+                             int64_t kw, int64_t stride, int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo,
+                             int32_t relu, const float* d_post_scale, const float* d_post_shift, float* d_y2,
+                             void* stream);
+
 /* y = act(x * scale[c] + shift[c]) on NHWC float32 ([rows, c], c % 4 == 0; y may alias x): an inference-mode
  * BatchNorm (+ ReLU) that sits in FRONT of a convolution and therefore cannot be folded into one -- the pre-activation
  * units of HoVer-Net (models/architecture/hovernet.py:72-261: "preact_bna" / "blk_bna"). */

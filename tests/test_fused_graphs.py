@@ -22,6 +22,11 @@ def _conv_ex(x, wp, bias, res, *, kernel, stride, pad_lo, pad_hi, relu):  # noqa
     return F.relu(y) if relu else y
 
 
+def _conv_post(x, wp, bias, res, *, kernel, stride, pad_lo, pad_hi, relu, post_scale, post_shift, want_raw=True):
+    v = _conv_ex(x, wp, bias, res, kernel=kernel, stride=stride, pad_lo=pad_lo, pad_hi=pad_hi, relu=relu)
+    return (v if want_raw else None), F.relu(v * post_scale[None, :, None, None] + post_shift[None, :, None, None])
+
+
 def _scale_shift(x, sc, sh, *, relu=True, inplace=False):  # noqa: ARG001
     y = x * sc[None, :, None, None] + sh[None, :, None, None]
     return F.relu(y) if relu else y
@@ -47,6 +52,7 @@ def torch_kernels(monkeypatch):
     import tiatoolbox_amd.models.architecture.unet_fused as uf
 
     monkeypatch.setattr(hf, "hip_conv2d_ex", _conv_ex)
+    monkeypatch.setattr(hf, "hip_conv2d_post", _conv_post)
     monkeypatch.setattr(hf, "pack_conv_weights", lambda conv: conv.weight.detach().permute(2, 3, 1, 0).contiguous())
     monkeypatch.setattr(hf, "hip_scale_shift_act", _scale_shift)
     monkeypatch.setattr(hf, "hip_scale_shift_act_view", lambda x, sc, sh, relu=True: _scale_shift(x, sc, sh, relu=relu))

@@ -645,6 +645,26 @@ def test_fused_hovernet_forward_matches_plain_module(plus):
                                 res.cuda().contiguous(memory_format=torch.channels_last), kernel=k, stride=s, pad_lo=lo, pad_hi=hi,
                                 relu=True)
             assert (got.cpu() - torch.relu(ref + res)).abs().max() <= 1e-4, (cin, cout, hw, k, s, lo, hi)
+        from tiatoolbox_amd.models.architecture.fused import hip_conv2d_post
+
+        for cout in (64, 256):  # second output of the epilogue: relu(bn(conv + residual)), with and without the raw sum
+            conv = torch.nn.Conv2d(96, cout, 1, bias=False)
+            x = torch.randn((2, 96, 9, 6), generator=g)
+            res = torch.randn((2, cout, 9, 6), generator=g)
+            ps, pt = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+            raw_ref = conv(x).detach() + res
+            act_ref = torch.relu(raw_ref * ps[None, :, None, None] + pt[None, :, None, None])
+            dev = copy.deepcopy(conv).cuda()
+            for want_raw in (True, False):
+                raw, act = hip_conv2d_post(x.cuda().contiguous(memory_format=torch.channels_last), pack_conv_weights(dev), None,
+                                           res.cuda().contiguous(memory_format=torch.channels_last), kernel=1, stride=1, pad_lo=0,
+                                           pad_hi=0, relu=False, post_scale=ps.cuda(), post_shift=pt.cuda(), want_raw=want_raw)
+                assert (raw is None) == (not want_raw)
+                assert (act.cpu() - act_ref).abs().max() <= 1e-4
+                if raw is not None:
+                    assert (raw.cpu() - raw_ref).abs().max() <= 1e-4
+                    again = torch.relu(raw * ps.cuda()[None, :, None, None] + pt.cuda()[None, :, None, None])
+                    assert (act - again).abs().max() <= 1e-6  # the two outputs are consistent with each other
         x = torch.randn((2, 96, 7, 5), generator=g)
         sc, sh = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g)
         got = hip_scale_shift_act(x.cuda().contiguous(memory_format=torch.channels_last), sc.cuda(), sh.cuda())

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "tia_conv2d_nhwc_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     "tia_conv2d_nhwc_f32_ex": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P],
                                C.c_int),
+    "tia_conv2d_post_nhwc_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32,
+                                  _P, _P, _P, _P], C.c_int),
     "tia_scale_shift_act_nhwc_f32": ([_P, _P, _P, _P, _I64, _I64, _I32, _P], C.c_int),
     "tia_scale_shift_act_view_nhwc_f32": ([_P, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     "tia_grouped_conv_valid_nhwc_f32": ([_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P], C.c_int),

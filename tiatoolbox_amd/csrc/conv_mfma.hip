@@ -43,10 +43,20 @@ struct ConvDims {
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 constexpr int OOB = (int)0x80000000;  // voffset beyond every buffer extent: the load returns zeros (padding taps)
 
-template <int BN>
+// second, "post-activated" output of the epilogue: y2 = relu(v * scale[c] + shift[c]) of the value v that goes to y -- the
+// BatchNorm + ReLU that FOLLOWS a residual sum in a pre-activation network (HoVer-Net: the next unit's "preact" or the
+// block's "blk_bna"), produced while the sum is still in registers.  y itself may then be null (only y2 wanted).
+struct ConvPost {
+    const float* scale;
+    const float* shift;
+    float* y2;
+};
+
+template <int BN, bool POST = false>
 __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                             const float* __restrict__ bias, const float* __restrict__ res,
-                                                            float* __restrict__ y, ConvDims d, int relu, int m_tiles) {
+                                                            float* __restrict__ y, ConvDims d, int relu, int m_tiles,
+                                                            ConvPost post = ConvPost{nullptr, nullptr, nullptr}) {
     constexpr int NTILE = BN / 64;       // 32-wide MFMA tiles per wave along N
     constexpr int BQ = BN / 4;           // float4 per B row
     constexpr int B_PER_THREAD = BK * BQ / NTH;
@@ -215,6 +225,11 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
     for (int j = 0; j < NTILE; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
         const float bv = bias ? bias[n] : 0.0f;
+        float ps = 1.0f, pt = 0.0f;
+        if constexpr (POST) {
+            ps = post.scale[n];
+            pt = post.shift[n];
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const long mrow = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
@@ -231,7 +246,16 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
                 float v = acc[i][j][e] + bv;
                 v = v + rv[e];
                 if (relu) v = v > 0.0f ? v : 0.0f;
-                if (m < m_total) y[m * d.cout + n] = v;
+                if constexpr (POST) {
+                    if (m < m_total) {
+                        if (y) y[m * d.cout + n] = v;
+                        float a = __fmul_rn(v, ps);  // product and sum rounded separately, like batch_norm + relu
+                        a = __fadd_rn(a, pt);
+                        post.y2[m * d.cout + n] = a > 0.0f ? a : 0.0f;
+                    }
+                } else {
+                    if (m < m_total) y[m * d.cout + n] = v;
+                }
             }
         }
     }
@@ -264,11 +288,13 @@ extern "C" int tia_conv_pack_weights_f32(const float* d_w_oihw, int64_t cout, in
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
-extern "C" int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,
-                                      float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
-                                      int64_t kw, int64_t stride, int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo,
-                                      int32_t relu, void* stream) {
-    if (!d_x || !d_w_packed || !d_y || n <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0)
+static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y, int64_t n,
+                       int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t stride, int64_t pad_top,
+                       int64_t pad_left, int64_t ho, int64_t wo, int32_t relu, const float* d_post_scale, const float* d_post_shift,
+                       float* d_y2, void* stream) {
+    const bool with_post = d_y2 != nullptr;
+    if (with_post && (!d_post_scale || !d_post_shift)) return TIA_EINVAL;
+    if (!d_x || !d_w_packed || (!d_y && !with_post) || n <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0)
         return TIA_EINVAL;
     if (cin % BK != 0 || cout % 64 != 0) return TIA_ESIZE;
     if (((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_w_packed)) & 15) != 0) return TIA_EINVAL;
@@ -291,21 +317,51 @@ extern "C" int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed,
                    (int)pad_left, (unsigned)(nb * image_bytes), (unsigned)w_bytes};
         const float* xg = d_x + first * h * w * cin;
         const float* rg = d_residual ? d_residual + first * ho * wo * cout : nullptr;
-        float* yg = d_y + first * ho * wo * cout;
+        float* yg = d_y ? d_y + first * ho * wo * cout : nullptr;
+        const ConvPost post{d_post_scale, d_post_shift, with_post ? d_y2 + first * ho * wo * cout : nullptr};
         const long grid_x = ((m_tiles + 7) / 8) * 8;  // whole rounds over the 8 XCDs (surplus workgroups exit at once)
         static const bool force64 = getenv("TIA_CONV_BN64") != nullptr;  // developer switches (tile-shape experiments)
         static const bool no_rule = getenv("TIA_CONV_NO_1X1_RULE") != nullptr;
         // 1x1 convolutions with few input channels have only cin / 32 slices per tile: the narrower tile (more workgroups,
         // 5 instead of 3 per CU) hides their prologue / epilogue better (+15-20 % on resnet18's down-sampling convolutions)
         const bool narrow = force64 || (!no_rule && kh == 1 && kw == 1 && cin <= 256);
-        if (cout % 128 == 0 && !narrow)
-            hipLaunchKernelGGL(conv_mfma_f32_kernel<128>, dim3((unsigned)grid_x, (unsigned)(cout / 128)), dim3(NTH), 0, st, xg,
-                               d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles);
-        else
-            hipLaunchKernelGGL(conv_mfma_f32_kernel<64>, dim3((unsigned)grid_x, (unsigned)(cout / 64)), dim3(NTH), 0, st, xg,
-                               d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles);
+        const ConvPost none{nullptr, nullptr, nullptr};
+        if (cout % 128 == 0 && !narrow) {
+            if (with_post)
+                hipLaunchKernelGGL((conv_mfma_f32_kernel<128, true>), dim3((unsigned)grid_x, (unsigned)(cout / 128)), dim3(NTH), 0, st, xg,
+                                   d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles, post);
+            else
+                hipLaunchKernelGGL((conv_mfma_f32_kernel<128, false>), dim3((unsigned)grid_x, (unsigned)(cout / 128)), dim3(NTH), 0, st,
+                                   xg, d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles, none);
+        } else {
+            if (with_post)
+                hipLaunchKernelGGL((conv_mfma_f32_kernel<64, true>), dim3((unsigned)grid_x, (unsigned)(cout / 64)), dim3(NTH), 0, st, xg,
+                                   d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles, post);
+            else
+                hipLaunchKernelGGL((conv_mfma_f32_kernel<64, false>), dim3((unsigned)grid_x, (unsigned)(cout / 64)), dim3(NTH), 0, st, xg,
+                                   d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles, none);
+        }
     }
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                                      float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
+                                      int64_t kw, int64_t stride, int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo,
+                                      int32_t relu, void* stream) {
+    if (!d_y) return TIA_EINVAL;
+    return conv2d_impl(d_x, d_w_packed, d_bias, d_residual, d_y, n, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo, relu,
+                       nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,
+                                        float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
+                                        int64_t kw, int64_t stride, int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo,
+                                        int32_t relu, const float* d_post_scale, const float* d_post_shift, float* d_y2,
+                                        void* stream) {
+    if (!d_y2) return TIA_EINVAL;
+    return conv2d_impl(d_x, d_w_packed, d_bias, d_residual, d_y, n, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo, relu,
+                       d_post_scale, d_post_shift, d_y2, stream);
 }
 
 extern "C" int tia_conv2d_nhwc_f32(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,

@@ -257,6 +257,36 @@ def hip_conv2d_ex(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor | 
     return y
 
 
+def hip_conv2d_post(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor | None, residual: torch.Tensor | None, *,
+                    kernel: int, stride: int, pad_lo: int, pad_hi: int, relu: bool, post_scale: torch.Tensor,
+                    post_shift: torch.Tensor, want_raw: bool = True) -> tuple[torch.Tensor | None, torch.Tensor]:
+    """:func:`hip_conv2d_ex` plus ``relu(v * post_scale[c] + post_shift[c])`` of its result ``v`` from the same epilogue
+    (``tia_conv2d_post_nhwc_f32``); returns ``(v or None, activated)``."""
+    from tiatoolbox_amd import _lib
+
+    if not (_nhwc_ptr_ok(x) and x.dtype == torch.float32):
+        msg = "hip_conv2d_post expects a float32 channels-last CUDA tensor."
+        raise ValueError(msg)
+    n, cin, h, w = x.shape
+    cout = w_packed.shape[-1]
+    ho = (h + pad_lo + pad_hi - kernel) // stride + 1
+    wo = (w + pad_lo + pad_hi - kernel) // stride + 1
+    shape = (n, cout, ho, wo)
+    if residual is not None and not (_nhwc_ptr_ok(residual) and residual.dtype == torch.float32 and residual.shape == shape):
+        msg = "hip_conv2d_post: residual must be a float32 channels-last CUDA tensor of the output shape."
+        raise ValueError(msg)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last) if want_raw else None
+    y2 = torch.empty(shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_conv2d_post_nhwc_f32(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                                                  residual.data_ptr() if residual is not None else 0,
+                                                  y.data_ptr() if y is not None else 0, n, h, w, cin, cout, kernel, kernel, stride,
+                                                  pad_lo, pad_lo, ho, wo, int(relu), post_scale.data_ptr(), post_shift.data_ptr(),
+                                                  y2.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "tia_conv2d_post_nhwc_f32")
+    return y, y2
+
+
 def hip_scale_shift_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, *, relu: bool = True,
                         inplace: bool = False) -> torch.Tensor:
     """``relu(x * scale[c] + shift[c])`` on a float32 channels-last CUDA tensor (``tia_scale_shift_act_nhwc_f32``)."""

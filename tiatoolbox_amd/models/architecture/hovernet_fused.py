@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F  # noqa: N812
 from torch import nn
 
-from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv2d_ex, hip_grouped_conv_valid,
+from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv2d_ex, hip_conv2d_post, hip_grouped_conv_valid,
                                                       hip_scale_shift_act, hip_scale_shift_act_view, hip_upsample2x_add,
                                                       pack_conv_weights)
 from tiatoolbox_amd.models.architecture.hovernet import centre_crop_to_shape
@@ -94,6 +94,14 @@ class _Conv(nn.Module):
         return y
 
 
+def _conv_with_post(conv: "_Conv", x: torch.Tensor, residual: torch.Tensor, bn: "_BnAct", *, want_raw: bool):
+    """``v = conv(x) + residual`` and ``relu(bn(v))`` from one launch (1x1 MFMA convolution); ``(v or None, activated)``."""
+    if conv._packed is None or conv._packed.device != conv.weight.device:  # noqa: SLF001
+        conv._packed = pack_conv_weights(conv)  # noqa: SLF001
+    return hip_conv2d_post(_cl(x), conv._packed, conv.bias, residual, kernel=conv.kernel, stride=conv.stride, pad_lo=0,  # noqa: SLF001
+                           pad_hi=0, relu=False, post_scale=bn.scale, post_shift=bn.shift, want_raw=want_raw)
+
+
 class _BnAct(nn.Module):
     def __init__(self, bn: nn.BatchNorm2d) -> None:
         super().__init__()
@@ -125,13 +133,21 @@ class _FusedResidualBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         shortcut = x if self.shortcut is None else self.shortcut(x)
-        for pre, c1, c2, c3 in zip(self.pre, self.c1, self.c2, self.c3):
-            a = x if isinstance(pre, nn.Identity) else pre(x)
+        units = len(self.c1)
+        a = x  # the first unit has no pre-activation
+        for i, (c1, c2, c3) in enumerate(zip(self.c1, self.c2, self.c3)):
             a = c1(a, relu=True)
             a = c2(a, pads=_same_pads(a.shape[2], c2.kernel, c2.stride), relu=True)
-            x = c3(a, residual=_cl(shortcut))
-            shortcut = x
-        return self.out(x)
+            last = i + 1 == units
+            nxt = self.out if last else self.pre[i + 1]
+            if c3.mfma_ok:
+                # conv3 + shortcut, and the BN + ReLU that follows the sum (next unit's pre-activation, or the block's
+                # blk_bna), from one epilogue; the raw sum is only kept while a later unit needs it as its shortcut
+                shortcut, a = _conv_with_post(c3, a, _cl(shortcut), nxt, want_raw=not last)
+            else:
+                shortcut = c3(a, residual=_cl(shortcut))
+                a = nxt(shortcut)
+        return a
 
 
 class _FusedDenseBlock(nn.Module):
