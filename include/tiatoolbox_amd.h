@@ -445,6 +445,11 @@ int tia_grouped_conv_valid_nhwc_f32(const float* d_x, const float* d_w_packed, f
  * y_image_stride / y_row_stride in elements (multiples of 4, 16-byte aligned base); out [n,2h,2w,c]; c % 4 == 0. */
 int tia_upsample2x_add_nhwc_f32(const float* d_x, const float* d_y, int64_t y_image_stride, int64_t y_row_stride,
                                 float* d_out, int64_t n, int64_t h, int64_t w, int64_t c, void* stream);
+/* The same followed by relu(. * scale[c] + shift[c]) (both NULL: plain sum): up-sampling, skip add and the pre-activation of
+ * a UNet decoder block (models/architecture/unet.py:193-240, 356-417) in one pass. */
+int tia_upsample2x_add_act_nhwc_f32(const float* d_x, const float* d_y, int64_t y_image_stride, int64_t y_row_stride,
+                                    const float* d_scale, const float* d_shift, float* d_out, int64_t n, int64_t h,
+                                    int64_t w, int64_t c, void* stream);
 
 /* =======================================================================================
  * All borders of binary planes: cv2.findContours(layer, RETR_TREE, CHAIN_APPROX_NONE | _SIMPLE)

@@ -58,7 +58,10 @@ def torch_kernels(monkeypatch):
     monkeypatch.setattr(hf, "hip_scale_shift_act_view", lambda x, sc, sh, relu=True: _scale_shift(x, sc, sh, relu=relu))
     monkeypatch.setattr(hf, "hip_bias_act_", _bias_act)
     monkeypatch.setattr(hf, "hip_grouped_conv_valid", _grouped)
-    up = lambda x, y: x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + y  # noqa: E731
+    def up(x, y, scale=None, shift=None):
+        out = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + y
+        return out if scale is None else F.relu(out * scale[None, :, None, None] + shift[None, :, None, None])
+
     monkeypatch.setattr(hf, "hip_upsample2x_add", up)
     monkeypatch.setattr(uf, "hip_upsample2x_add", up)
     return hf, uf

@@ -695,6 +695,10 @@ def test_fused_hovernet_forward_matches_plain_module(plus):
         skip = torch.randn((2, 32, 16, 20), generator=g).cuda().contiguous(memory_format=torch.channels_last)[:, :, 3:13, 3:17]
         assert not skip.is_contiguous(memory_format=torch.channels_last)
         assert torch.equal(hip_upsample2x_add(lo, skip), lo.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + skip)
+        s32, t32 = (torch.rand(32, generator=g) + 0.5).cuda(), torch.randn(32, generator=g).cuda()
+        both = torch.relu((lo.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + skip) * s32[None, :, None, None]
+                          + t32[None, :, None, None])
+        assert (hip_upsample2x_add(lo, skip, s32, t32) - both).abs().max() <= 1e-6
 
     torch.manual_seed(3)
     model = (HoVerNetPlus(num_types=3, num_layers=5) if plus else HoVerNet(num_types=6, mode="fast")).eval()

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "tia_scale_shift_act_view_nhwc_f32": ([_P, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     "tia_grouped_conv_valid_nhwc_f32": ([_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P], C.c_int),
     "tia_upsample2x_add_nhwc_f32": ([_P, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P], C.c_int),
+    "tia_upsample2x_add_act_nhwc_f32": ([_P, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _P], C.c_int),
     "tia_bias_act_nhwc": ([_P, _P, _P, _I64, _I64, _I32, _I32, _P], C.c_int),
     "tia_bias_relu_maxpool_nhwc": ([_P, _P, _I64, _I64, _I64, _I64, _I32, _P, _P], C.c_int),
     "tia_hover_instance_stats": ([_P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P], C.c_int),

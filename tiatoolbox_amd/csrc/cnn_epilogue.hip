@@ -207,8 +207,10 @@ __global__ __launch_bounds__(ET) void scale_shift_act_kernel(const u4* __restric
 // out[b, Y, X, :] = x[b, Y / 2, X / 2, :] + y[b, Y, X, :]  -- nearest-neighbour x2 upsampling fused with the skip-connection
 // add of the HoVer-Net decoders (hovernet.py:447-449: `upsample2x(d3) + d2`); y may be a centre-cropped VIEW (row and image
 // strides given in elements, channels contiguous).  float32, 16 bytes per lane.
+// (optionally followed by relu(. * scale[c] + shift[c]): the pre-activation of the UNet decoder blocks, unet.py:193-240)
 __global__ __launch_bounds__(ET) void upsample2x_add_kernel(const u4* __restrict__ x, const float* __restrict__ y, long y_sb, long y_sy,
-                                                             int n, int h, int w, int cv, u4* __restrict__ out) {
+                                                             int n, int h, int w, int cv, const u4* __restrict__ scale,
+                                                             const u4* __restrict__ shift, u4* __restrict__ out) {
     const long total = (long)n * (2 * h) * (2 * w) * cv;
     for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
         const int c = (int)(i % cv);
@@ -221,6 +223,17 @@ __global__ __launch_bounds__(ET) void upsample2x_add_kernel(const u4* __restrict
         Vec<float>::unpack(*reinterpret_cast<const u4*>(y + (long)b * y_sb + (long)Y * y_sy + ((long)X * cv + c) * 4), r);
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = a[k] + r[k];
+        if (scale) {
+            float sc[8], sh[8];
+            Vec<float>::unpack(scale[c], sc);
+            Vec<float>::unpack(shift[c], sh);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = a[k] * sc[k];
+                v = v + sh[k];
+                a[k] = v > 0.0f ? v : 0.0f;
+            }
+        }
         out[i] = Vec<float>::pack(a);
     }
 }
@@ -346,17 +359,26 @@ extern "C" int tia_scale_shift_act_nhwc_f32(const float* d_x, const float* d_sca
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
-extern "C" int tia_upsample2x_add_nhwc_f32(const float* d_x, const float* d_y, int64_t y_image_stride, int64_t y_row_stride,
-                                            float* d_out, int64_t n, int64_t h, int64_t w, int64_t c, void* stream) {
+extern "C" int tia_upsample2x_add_act_nhwc_f32(const float* d_x, const float* d_y, int64_t y_image_stride, int64_t y_row_stride,
+                                                const float* d_scale, const float* d_shift, float* d_out, int64_t n, int64_t h,
+                                                int64_t w, int64_t c, void* stream) {
     if (!d_x || !d_y || !d_out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) != 0) return TIA_EINVAL;
+    if ((d_scale == nullptr) != (d_shift == nullptr)) return TIA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_scale) | reinterpret_cast<uintptr_t>(d_shift)) & 15) return TIA_EINVAL;
     if ((y_image_stride & 3) != 0 || (y_row_stride & 3) != 0 || y_row_stride < 2 * w * c) return TIA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_y) | reinterpret_cast<uintptr_t>(d_out)) & 15) return TIA_EINVAL;
     const long total = n * 4 * h * w * (c / 4);
     long blocks = (total + ET - 1) / ET;
     if (blocks > 256L * 64) blocks = 256L * 64;
     hipLaunchKernelGGL(upsample2x_add_kernel, dim3((unsigned)blocks), dim3(ET), 0, (hipStream_t)stream, (const u4*)d_x, d_y,
-                       (long)y_image_stride, (long)y_row_stride, (int)n, (int)h, (int)w, (int)(c / 4), (u4*)d_out);
+                       (long)y_image_stride, (long)y_row_stride, (int)n, (int)h, (int)w, (int)(c / 4), (const u4*)d_scale,
+                       (const u4*)d_shift, (u4*)d_out);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_upsample2x_add_nhwc_f32(const float* d_x, const float* d_y, int64_t y_image_stride, int64_t y_row_stride,
+                                            float* d_out, int64_t n, int64_t h, int64_t w, int64_t c, void* stream) {
+    return tia_upsample2x_add_act_nhwc_f32(d_x, d_y, y_image_stride, y_row_stride, nullptr, nullptr, d_out, n, h, w, c, stream);
 }
 
 extern "C" int tia_scale_shift_act_view_nhwc_f32(const float* d_x, int64_t x_image_stride, int64_t x_row_stride, int64_t x_pixel_stride,

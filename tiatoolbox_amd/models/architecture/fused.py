@@ -349,21 +349,25 @@ def hip_grouped_conv_valid(x: torch.Tensor, w_packed: torch.Tensor, *, groups: i
     return out
 
 
-def hip_upsample2x_add(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-    """``x.repeat_interleave(2, 2).repeat_interleave(2, 3) + y`` in one pass (``tia_upsample2x_add_nhwc_f32``); ``y`` may be a
-    centre-cropped view of a channels-last tensor."""
+def hip_upsample2x_add(x: torch.Tensor, y: torch.Tensor, scale: torch.Tensor | None = None,
+                       shift: torch.Tensor | None = None) -> torch.Tensor:
+    """``x.repeat_interleave(2, 2).repeat_interleave(2, 3) + y`` in one pass (``tia_upsample2x_add_act_nhwc_f32``); ``y`` may be
+    a centre-cropped view of a channels-last tensor.  With ``scale`` / ``shift``: followed by ``relu(. * scale + shift)``."""
     from tiatoolbox_amd import _lib
 
     n, c, h, w = x.shape
     ok_y = (y.is_cuda and y.dtype == torch.float32 and y.shape == (n, c, 2 * h, 2 * w) and y.stride(1) == 1 and y.stride(3) == c
             and y.stride(2) % 4 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0)
     if not (_nhwc_ptr_ok(x) and x.dtype == torch.float32 and ok_y and c % 4 == 0):
-        return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + y
+        out = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + y
+        return out if scale is None else F.relu(out * scale[None, :, None, None] + shift[None, :, None, None])
     out = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        rc = _lib.load().tia_upsample2x_add_nhwc_f32(x.data_ptr(), y.data_ptr(), y.stride(0), y.stride(2), out.data_ptr(), n, h, w, c,
-                                                     _lib.current_stream())
-    _lib.check(rc, "tia_upsample2x_add_nhwc_f32")
+        rc = _lib.load().tia_upsample2x_add_act_nhwc_f32(x.data_ptr(), y.data_ptr(), y.stride(0), y.stride(2),
+                                                         scale.data_ptr() if scale is not None else 0,
+                                                         shift.data_ptr() if shift is not None else 0, out.data_ptr(), n, h, w, c,
+                                                         _lib.current_stream())
+    _lib.check(rc, "tia_upsample2x_add_act_nhwc_f32")
     return out
 
 

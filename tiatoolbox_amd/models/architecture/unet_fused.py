@@ -6,7 +6,7 @@ Same arithmetic graph as ``UNetModel.forward`` (reference ``models/architecture/
   ReLU`` and ``conv3 + BN + identity + ReLU`` -- with the BNs folded into the weights and the residual add / ReLU in the
   convolution epilogues (the down-sampling 1x1 likewise, without ReLU);
 * decoder (pre-activation blocks ``BN -> ReLU -> conv -> BN -> ReLU -> conv`` after ``upsample2x(x) + skip``): the
-  up-sampling and the skip add in one pass, the first BN + ReLU in one pass, the second BN folded into the first
+  up-sampling, the skip add and the first BN + ReLU in one pass, the second BN folded into the first
   convolution;
 * the 3-channel 7x7 stem and the final ``64 -> n_classes`` 1x1 stay on MIOpen; the max-pool is torch's.
 
@@ -80,8 +80,7 @@ class FusedUNet(nn.Module):
         x = self.conv1x1(feats[-1])
         skips = feats[:-1]
         for idx, stage in enumerate(self.up, start=1):
-            x = hip_upsample2x_add(_cl(x), _cl(skips[-idx]))
-            x = stage[0](x, inplace=True)
+            x = hip_upsample2x_add(_cl(x), _cl(skips[-idx]), stage[0].scale, stage[0].shift)  # + the block's pre-activation
             for j, conv in enumerate(list(stage)[1:]):
                 last = j == len(stage) - 2
                 p = (conv.kernel - 1) // 2
