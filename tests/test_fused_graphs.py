@@ -138,3 +138,21 @@ def test_same_padding_arithmetic_matches_the_layer():
             assert padded.shape[2] == size + lo + hi
             probe = TFSamepaddingLayer(k, s)(torch.ones(1, 1, size, size))[0, 0]
             assert probe[:lo].sum() == 0 and probe[lo].sum() > 0  # exactly `lo` zero rows in front
+
+
+def test_hip_wrappers_refuse_host_tensors():
+    """The convolution / epilogue wrappers are device-only: a CPU tensor is an error, never a silent torch fallback."""
+    from tiatoolbox_amd.models.architecture import fused
+
+    x = torch.zeros((1, 32, 4, 4)).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros((1, 1, 32, 64))
+    with pytest.raises(ValueError, match="channels-last CUDA"):
+        fused.hip_conv2d_ex(x, w, None, None, kernel=1, stride=1, pad_lo=0, pad_hi=0, relu=False)
+    with pytest.raises(ValueError, match="channels-last CUDA"):
+        fused.hip_conv2d_post(x, w, None, None, kernel=1, stride=1, pad_lo=0, pad_hi=0, relu=False,
+                              post_scale=torch.ones(64), post_shift=torch.zeros(64))
+    with pytest.raises(ValueError, match="channels-last CUDA"):
+        fused.hip_scale_shift_act(x, torch.ones(32), torch.zeros(32))
+    with pytest.raises(ValueError, match="channels-last CUDA"):
+        fused.hip_grouped_conv_valid(torch.zeros((1, 128, 5, 5)).contiguous(memory_format=torch.channels_last),
+                                     torch.zeros((4, 3, 3, 32, 8)), groups=4, kernel=3)
