@@ -153,6 +153,10 @@ def test_hip_wrappers_refuse_host_tensors():
                               post_scale=torch.ones(64), post_shift=torch.zeros(64))
     with pytest.raises(ValueError, match="channels-last CUDA"):
         fused.hip_scale_shift_act(x, torch.ones(32), torch.zeros(32))
+    with pytest.raises(ValueError, match="CUDA"):
+        fused.hip_upsample2x_add(x, torch.zeros((1, 32, 8, 8)))
+    with pytest.raises(ValueError, match="CUDA"):
+        fused.hip_scale_shift_act_view(x, torch.ones(32), torch.zeros(32))
     with pytest.raises(ValueError, match="channels-last CUDA"):
         fused.hip_grouped_conv_valid(torch.zeros((1, 128, 5, 5)).contiguous(memory_format=torch.channels_last),
                                      torch.zeros((4, 3, 3, 32, 8)), groups=4, kernel=3)

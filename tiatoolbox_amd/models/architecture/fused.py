@@ -309,6 +309,9 @@ def hip_scale_shift_act_view(x: torch.Tensor, scale: torch.Tensor, shift: torch.
     written to a dense channels-last tensor (``tia_scale_shift_act_view_nhwc_f32``)."""
     from tiatoolbox_amd import _lib
 
+    if not x.is_cuda:
+        msg = "hip_scale_shift_act_view expects a CUDA tensor."
+        raise ValueError(msg)
     n, c, h, w = x.shape
     ok = (x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and c % 4 == 0 and x.data_ptr() % 16 == 0
           and all(x.stride(d) % 4 == 0 for d in (0, 2, 3)) and x.stride(3) >= c)
@@ -355,6 +358,9 @@ def hip_upsample2x_add(x: torch.Tensor, y: torch.Tensor, scale: torch.Tensor | N
     a centre-cropped view of a channels-last tensor.  With ``scale`` / ``shift``: followed by ``relu(. * scale + shift)``."""
     from tiatoolbox_amd import _lib
 
+    if not (x.is_cuda and y.is_cuda):
+        msg = "hip_upsample2x_add expects CUDA tensors."
+        raise ValueError(msg)
     n, c, h, w = x.shape
     ok_y = (y.is_cuda and y.dtype == torch.float32 and y.shape == (n, c, 2 * h, 2 * w) and y.stride(1) == 1 and y.stride(3) == c
             and y.stride(2) % 4 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0)
