@@ -327,11 +327,25 @@ class EngineABC:
         worth it for long runs at one batch shape (resnet18 fp16, 1024 x 224^2: 43 -> 36 ms per pass on MI355X), costly
         when batch sizes vary.  The switch is process-global in torch, so it is set for the run and restored after."""
         prev = torch.backends.cudnn.benchmark
-        torch.backends.cudnn.benchmark = bool(getattr(self, "miopen_find", False))
+        torch.backends.cudnn.benchmark = self._use_miopen_find()
         try:
             yield
         finally:
             torch.backends.cudnn.benchmark = prev
+
+    def _use_miopen_find(self) -> bool:
+        """An explicit ``miopen_find`` wins.  Otherwise: on when the inference copy is one of the fused float32 graphs -- they
+        leave only the 3-channel stem (and small class heads) on MIOpen, whose immediate mode picks a naive kernel for
+        float32 NHWC (HoVer-Net's stem at batch 32: 7.8 ms instead of 0.5 ms, ``profiles/r02t_*``), so one search per
+        shape is cheap and pays at once; off for graphs that run mostly on MIOpen (a search per convolution shape)."""
+        explicit = getattr(self, "miopen_find", None)
+        if explicit is not None:
+            return bool(explicit)
+        fast = self._fast_model
+        if fast is None:
+            return False
+        names = {type(m).__name__ for m in fast.modules()}
+        return bool(names & {"MfmaResNet", "FusedHoVerNet", "FusedUNet"})
 
     def invalidate_inference_cache(self) -> None:
         """Drop the derived (BN-folded / cast) inference copy; it is rebuilt on the next run."""
