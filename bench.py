@@ -7,20 +7,23 @@
 ``--gpus N`` with N > 1 started plainly re-launches itself as ``python -m torch.distributed.run --nproc-per-node N``
 (one rank per GPU, RCCL); started under ``torch.distributed.run`` it reads RANK / WORLD_SIZE / LOCAL_RANK as usual.
 
-Headline workload = BASELINE.json configs[1]: ``PatchPredictor("resnet18-kather100k")`` on 4096 synthetic 224x224x3
-uint8 patches per GPU (G-he, seeded; seeded random weights -- pretrained weights are unreachable offline), Macenko
-pre-normalisation fitted on the reference's target image crop.  One *step* = one call of the API the metric names,
+Headline workload = the configuration BASELINE.json's ``metric`` is quoted on: ``PatchPredictor("resnet18-kather100k")``
+on 4096 synthetic **256x256x3** uint8 patches per GPU (G-he, seeded; seeded random weights -- pretrained weights are
+unreachable offline), Macenko pre-normalisation fitted on the reference's target image crop (BASELINE ``configs[1]`` is
+the same call on 224x224 patches: reported under ``extras.patch_224``).  One *step* = one call of the API the metric names,
 
     PatchPredictor.run(patches, patch_mode=True, return_probabilities=True, stain_normalizer=macenko)
 
-over the rank's resident patches: per-patch Macenko statistics (HIP, f64), fused normalise -> ``ToTensor`` apply
-(HIP, the reference's f64 per-pixel arithmetic by default), resnet18 forward in **float32** (the reference's
-arithmetic, ``vanilla.py:242``), softmax, argmax, the RCCL all-gather of the probabilities (N > 1) and the copy of the
-result dict to host NumPy.  For ``value`` the uint8 patches are already resident in HBM when the timed region starts
+over the rank's resident patches: per-patch Macenko statistics (HIP, f64), the normalising apply kernel (HIP, the
+reference's f64 per-pixel arithmetic by default, uint8 out like the reference), resnet18 forward in **float32** on
+hand-written kernels only (stem: uint8 in, ``ToTensor``'s 1/255 on load, conv7x7 + bias + ReLU + max-pool; blocks: MFMA
+implicit GEMM -- the reference's arithmetic, ``vanilla.py:242``), softmax, argmax, the RCCL all-gather of the probabilities
+(N > 1) and the copy of the result dict to host NumPy.  For ``value`` the uint8 patches are already resident in HBM when the timed region starts
 (the engine's torch-tensor overload); the same call on HOST NumPy patches (H2D over PCIe included) is timed right after
 and reported as ``host_inclusive``.  Extras on rank 0 at N=1: the fp16 backbone with its measured max |dp| against the
 fp32 probabilities of the same batch (tolerance 1e-3, ``tests/engines/test_patch_predictor.py:719`` of the reference),
-and the 256x256 patch size BASELINE's metric string quotes.
+and the 224x224 patch size of BASELINE configs[1].  With N > 1 the line also carries every rank's own step time and the
+time of the all-gather alone (``per_rank``), so that a scaling run explains itself.
 """
 
 from __future__ import annotations
@@ -38,7 +41,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = {"float16": 2500.0, "bfloat16": 2500.0, "float32": 157.3}
-RESNET18_GFLOP_224 = 3.64  # 1.82 GMAC per 224x224 patch
+RESNET18_GFLOP_224 = 3.64  # 1.82 GMAC per 224x224 patch; scales with the pixel count (4.75 at 256x256)
 
 
 def parse() -> argparse.Namespace:
@@ -48,16 +51,14 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="patch", choices=["patch", "semantic", "hovernet", "vahadane"])
     ap.add_argument("--patches", type=int, default=4096, help="patches per GPU per step")
-    ap.add_argument("--patch-size", type=int, default=224)
+    ap.add_argument("--patch-size", type=int, default=256, help="BASELINE.json metric: 256 (configs[1]: 224)")
     ap.add_argument("--micro-batch", type=int, default=1024, help="engine batch_size (CNN forward batch)")
     ap.add_argument("--dtype", default=os.environ.get("TIA_BENCH_DTYPE", "float32"),
                     choices=["float32", "float16", "bfloat16"], help="CNN arithmetic (reference: float32)")
     ap.add_argument("--precision", default="f64", choices=["f32", "f64"],
                     help="per-pixel arithmetic of the stain apply kernel (reference: f64; statistics are always f64)")
-    ap.add_argument("--conv-backend", default=os.environ.get("TIA_CONV_BACKEND", "mfma"), choices=["miopen", "mfma"],
-                    help="resnet block convolutions: MIOpen + HIP epilogues, or the hand-written MFMA implicit GEMM (fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip host-inclusive / fp16 / 256^2 extra measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip host-inclusive / fp16 / 224^2 extra measurements")
     ap.add_argument("--cpu-sample", type=int, default=64)
     ap.add_argument("--slide", type=int, default=20000, help="--config semantic: slide edge in pixels")
     return ap.parse_args()
@@ -153,25 +154,29 @@ def cpu_baseline(target, patches, model_cpu, sample: int) -> dict:
     }
 
 
-def pmc_traffic(kernel_substr: str) -> dict | None:
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this round
-    (``scripts/final_profile.sh``: FETCH_SIZE and WRITE_SIZE in separate runs, same 4096 x 224^2 workload).
-    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the bytes actually read -- calibrated here
-    on the apply kernels, whose reads are known: 2 x 301.6 MB = the 616.6 MB input -- WRITE_SIZE is taken as is."""
+def pmc_traffic(kernel_substr: str, stem: str) -> dict | None:
+    """HBM-side bytes per launch of a kernel from this round's committed rocprofv3 --pmc passes
+    (``profiles/*_<stem>_pmc_FETCH_SIZE.txt`` / ``..._WRITE_SIZE.txt``: separate runs over the same workload; mean over the
+    dispatches of every kernel whose name contains ``kernel_substr``, weighted by dispatch count).
+    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the bytes actually read -- calibrated here on the
+    apply kernels, whose reads are known (2 x 301.6 MB = the 616.6 MB input); WRITE_SIZE is taken as is.  Units: KiB."""
     import re
 
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = sorted((ROOT / "profiles").glob(f"*_stain_pmc_{counter}.txt"))
+        files = sorted((ROOT / "profiles").glob(f"*_{stem}_pmc_{counter}.txt"))
         if not files:
             return None
+        tot, cnt = 0.0, 0
         for line in files[-1].read_text().splitlines():
-            m = re.search(rf"{counter} mean=\s*([0-9.]+) n=\s*\d+\s+(.*)", line)
-            if m and kernel_substr in m.group(2):
-                vals[counter] = float(m.group(1)) * 1024.0
-                vals["file_" + counter] = files[-1].name
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None
+            m = re.search(rf"{counter} mean=\s*([0-9.]+) n=\s*(\d+)\s+(.*)", line)
+            if m and kernel_substr in m.group(3):
+                tot += float(m.group(1)) * int(m.group(2))
+                cnt += int(m.group(2))
+        if cnt == 0:
+            return None
+        vals[counter] = tot / cnt * 1024.0
+        vals["file_" + counter] = files[-1].name
     return {"bytes": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
             "source": f"profiles/{vals['file_FETCH_SIZE']} (x2, gfx950) + profiles/{vals['file_WRITE_SIZE']}"}
 
@@ -191,8 +196,9 @@ def ev_time(fn, reps: int = 10) -> float:
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-def conv_mfma_roofline(model, unit_batch):
-    """HIP-event time and algorithmic flops of the hand-written convolution launches of one trunk forward."""
+def trunk_roofline(model, u8_batch):
+    """HIP-event times and algorithmic flops of the hand-written convolution kernels of one trunk forward: the stem kernel
+    (one launch) and the block convolutions (conv_mfma_f32_kernel, 19 launches for resnet18)."""
     import torch
 
     from tiatoolbox_amd.models.architecture.fused import MfmaResNet
@@ -201,11 +207,11 @@ def conv_mfma_roofline(model, unit_batch):
     if trunk is None:
         return None
     with torch.inference_mode():
-        x = unit_batch.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
-        from tiatoolbox_amd.models.architecture.fused import _conv_nobias, hip_bias_relu_maxpool
-
-        feat = hip_bias_relu_maxpool(_conv_nobias(x, trunk.stem), trunk.stem.bias)
-        nb, _, h, w = feat.shape
+        feat = trunk.stem_forward(u8_batch)
+        nb, hin, win = u8_batch.shape[0], u8_batch.shape[1], u8_batch.shape[2]
+        ho, wo = (hin - 1) // 2 + 1, (win - 1) // 2 + 1
+        stem_flops = 2 * nb * ho * wo * 64 * 147
+        _, _, h, w = feat.shape
         flops, launches = 0, 0
         for blk in trunk.blocks:
             s = blk.conv1.stride[0]
@@ -216,8 +222,10 @@ def conv_mfma_roofline(model, unit_batch):
                 launches += 1
             h, w = ho, wo
         seconds = ev_time(lambda: trunk.blocks(feat), reps=5)
+        stem_seconds = ev_time(lambda: trunk.stem_forward(u8_batch), reps=5)
     return {"seconds": seconds, "launches": launches, "flops_per_launch": flops // launches,
-            "ms_per_launch": seconds / launches * 1e3, "tflops": flops / seconds / 1e12}
+            "ms_per_launch": seconds / launches * 1e3, "tflops": flops / seconds / 1e12,
+            "stem_seconds": stem_seconds, "stem_flops": stem_flops, "stem_tflops": stem_flops / stem_seconds / 1e12}
 
 
 def self_spawn(args: argparse.Namespace) -> None:
@@ -269,11 +277,10 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                             verbose=False)
 
     def run(images, dtype: str = args.dtype):
-        # miopen_find: MIOpen searches its solvers once per convolution shape (first warm-up step); engine option
         size = tuple(int(v) for v in images.shape[1:3])
         return engine.run(images, patch_mode=True, return_probabilities=True, stain_normalizer=norm,
-                          patch_input_shape=size, compute_dtype=dtype, conv_backend=args.conv_backend,
-                          miopen_find=os.environ.get("TIA_MIOPEN_FIND", "1") == "1")
+                          patch_input_shape=size, compute_dtype=dtype,
+                          miopen_find=(dtype != "float32"))  # library convolutions exist only on the fp16 / bf16 extras
 
     def barrier() -> None:
         if world_size > 1:
@@ -288,14 +295,34 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
         t0 = time.perf_counter()
         for _ in range(steps):
             out = run(images, dtype)
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0  # this rank's own time, before it waits for the others
         barrier()
-        return time.perf_counter() - t0, out
+        return time.perf_counter() - t0, out, own
 
-    run(x)  # library set-up (MIOpen solver search, lazy module loads) outside any step, whatever --warmup is
-    elapsed, out = timed(x, args.steps, args.warmup)
+    run(x)  # lazy set-up (module loads, weight packing, workspace growth) outside any step, whatever --warmup is
+    elapsed, out, own = timed(x, args.steps, args.warmup)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    per_rank = None
     if world_size > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        # diagnostics for the scaling run: every rank's own step time, and the all-gather of the probabilities alone
+        owns = torch.zeros(world_size, dtype=torch.float64, device=device)
+        owns[rank] = own / args.steps * 1e3
+        torch.distributed.all_reduce(owns)
+        local = torch.rand((n, 9), device=device)
+        tdist.all_gather_rows(local, n * world_size)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            tdist.all_gather_rows(local, n * world_size)
+        barrier()
+        per_rank = {"own_ms_per_step": [round(float(v), 3) for v in owns.cpu().tolist()],
+                    "allgather_probabilities_ms": round((time.perf_counter() - t0) / 20 * 1e3, 4),
+                    "allgather_bytes_per_rank": n * 9 * 4,
+                    "what": ("own = rank-local wall time per step before the closing barrier (the step already contains the "
+                             "all-gather, which synchronises the ranks); allgather = 20 back-to-back padded "
+                             "all_gather_into_tensor calls of the [patches_per_gpu, 9] float32 probabilities")}
     elapsed = float(t.item())
     probs = out["probabilities"]
     assert probs.shape == (n * world_size, 9) and np.isfinite(probs).all()
@@ -305,63 +332,59 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
 
     total = n * world_size * args.steps
     line = {
-        "metric": "patches/s, Macenko stain-norm + resnet18 PatchPredictor.run() (synthetic patch batches)",
+        "metric": "patches/s (256x256x3), Macenko stain-norm + resnet18 PatchPredictor.run() (synthetic patch batches)",
         "value": round(total / elapsed, 2), "unit": "patches/s", "n_gpus": world_size, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": (f"BASELINE configs[1]: PatchPredictor(resnet18-kather100k, seeded random weights).run() "
-                                f"on {n} synthetic {hw}x{hw}x3 uint8 patches per GPU resident in HBM, Macenko pre-norm "
-                                f"(statistics f64, per-pixel {args.precision}), CNN {args.dtype}; BASELINE's metric "
-                                f"string quotes 256x256x3: see extras.patch_256"),
+        "config": {"workload": (f"BASELINE.json metric configuration: PatchPredictor(resnet18-kather100k, seeded random "
+                                f"weights).run() on {n} synthetic {hw}x{hw}x3 uint8 patches per GPU resident in HBM, Macenko "
+                                f"pre-norm (statistics f64, per-pixel {args.precision}), CNN {args.dtype} on hand-written "
+                                f"kernels (stem + MFMA block convolutions); configs[1] (224x224): extras.patch_224"),
                    "api": "PatchPredictor.run(images, patch_mode=True, return_probabilities=True, stain_normalizer=...)",
                    "patches_per_gpu": n, "patch_size": hw, "engine_batch_size": args.micro_batch,
-                   "conv_backend": args.conv_backend,
                    "parallelism": f"dp{world_size} (patch-sharded, all_gather of probabilities)"},
     }
+    if per_rank is not None:
+        line["per_rank"] = per_rank
 
     # ---- per-kernel timing with HIP events on the launch stream ------------------------------------------------
     dtype_t = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}[args.dtype]
     xs = x[:n]
+    mb = args.micro_batch
     params = norm.extractor.stats_params(target_stain=norm.stain_matrix_target, target_maxc=norm.maxC_target)
-    out_kind = {torch.float16: _lib.OUT_UNIT_F16, torch.bfloat16: _lib.OUT_UNIT_BF16,
-                torch.float32: _lib.OUT_UNIT_F32}[dtype_t]
+    # float32: the apply kernel writes the reference's uint8 result and the stem kernel reads it (ToTensor on load);
+    # fp16 / bf16: the apply kernel writes the unit-scaled half tensor for the library convolutions
+    out_kind = {torch.float16: _lib.OUT_UNIT_F16, torch.bfloat16: _lib.OUT_UNIT_BF16, torch.float32: _lib.OUT_U8}[dtype_t]
     math = _lib.MATH_F32 if args.precision == "f32" else _lib.MATH_F64
-    unit = torch.empty((n, hw, hw, 3), dtype=dtype_t, device=device)
+    unit = torch.empty((n, hw, hw, 3), dtype=torch.uint8 if dtype_t == torch.float32 else dtype_t, device=device)
     stats = dev.stain_stats(xs, params)
     t_stats = ev_time(lambda: dev.stain_stats(xs, params))
     t_apply = ev_time(lambda: dev.stain_apply(xs, stats, norm.stain_matrix_target, out_kind=out_kind, math=math,
                                               out=unit))
-    model_dev = engine._inference_model(dtype_t)  # noqa: SLF001  (the engine's own BN-folded, HIP-epilogue copy)
+    model_dev = engine._inference_model(dtype_t)  # noqa: SLF001  (the engine's own BN-folded inference copy)
 
     def cnn():
         with torch.inference_mode(), engine._miopen_scope():  # noqa: SLF001
-            for s in range(0, n, args.micro_batch):
-                model_dev(unit[s:s + args.micro_batch].permute(0, 3, 1, 2))
+            for s in range(0, n, mb):
+                model_dev(unit[s:s + mb].permute(0, 3, 1, 2))
 
     t_cnn = ev_time(cnn, reps=3)
-    from tiatoolbox_amd.models.architecture.fused import hip_bias_act_
-
-    act = torch.randn((args.micro_batch, 64, hw // 4, hw // 4), device=device).to(dtype_t).contiguous(
-        memory_format=torch.channels_last)
-    res = torch.randn_like(act)
-    bias = torch.randn(64, device=device).to(dtype_t)
-    t_epi = ev_time(lambda: hip_bias_act_(act, bias, res))
     px = n * hw * hw
     kernels = {
         # algorithmic bytes: stats reads the patch once (H*W*3 B); apply reads u8 + writes the CNN input
         "stain_stats_kernel": {"seconds": t_stats, "alg_bytes": px * 3},
         "stain_apply_kernel": {"seconds": t_apply, "alg_bytes": px * 3 * (1 + unit.element_size())},
-        "bias_act_kernel(layer1, +residual)": {"seconds": t_epi, "alg_bytes": act.numel() * act.element_size() * 3},
     }
     for k in kernels.values():
         k["achieved_GBs"] = k["alg_bytes"] / k["seconds"] / 1e9
         k["frac"] = k["achieved_GBs"] / HBM_PEAK_GBS
     flops = RESNET18_GFLOP_224 * (hw / 224.0) ** 2 * 1e9 * n
-    hbm_kernels = {
-        name: {"bound": "hbm", "achieved": round(k["achieved_GBs"], 2), "unit": "GB/s", "frac": round(k["frac"], 5),
-               "launch_ms": round(k["seconds"] * 1e3, 4), "algorithmic_bytes": k["alg_bytes"]}
+    other = {
+        name: {"bound": "hbm", "achieved": round(k["achieved_GBs"], 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(k["frac"], 5), "launch_ms": round(k["seconds"] * 1e3, 4), "algorithmic_bytes": k["alg_bytes"]}
         for name, k in kernels.items()}
-    conv = conv_mfma_roofline(model_dev, unit[:args.micro_batch]) if args.dtype == "float32" else None
+    steps_mb = (n + mb - 1) // mb
+    conv = trunk_roofline(model_dev, unit[:mb]) if args.dtype == "float32" else None
     if conv is not None:
         # the hand-written kernel a step spends most of its time in: the MFMA implicit-GEMM convolution (MFMA-bound)
         dominant = "conv_mfma_f32_kernel"
@@ -370,80 +393,75 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
             "peak": MFMA_PEAK_TFLOPS["float32"], "unit": "TFLOP/s",
             "frac": round(conv["tflops"] / MFMA_PEAK_TFLOPS["float32"], 5), "traffic": None,
             "algorithmic_flops": conv["flops_per_launch"], "launch_ms": round(conv["ms_per_launch"], 4),
-            "launches_per_step": conv["launches"] * ((n + args.micro_batch - 1) // args.micro_batch),
+            "launches_per_step": conv["launches"] * steps_mb,
             "what": (f"average over the {conv['launches']} BasicBlock convolutions of one resnet18 forward on "
-                     f"{args.micro_batch} patches (2*M*Cout*Cin*k*k flops each, fp32 MFMA 32x32x2, epilogue fused)"),
-            "share_of_step": round(conv["seconds"] * ((n + args.micro_batch - 1) // args.micro_batch)
-                                   / (elapsed / args.steps), 3),
-            "other_kernels": hbm_kernels,
+                     f"{mb} patches of {hw}x{hw} (2*M*Cout*Cin*k*k flops each, fp32 MFMA 32x32x2, epilogue fused)"),
+            "share_of_step": round(conv["seconds"] * steps_mb / (elapsed / args.steps), 3),
         }
+        other["stem7x7_pool_kernel"] = {
+            "bound": "mfma", "achieved": round(conv["stem_tflops"], 2), "peak": MFMA_PEAK_TFLOPS["float32"],
+            "unit": "TFLOP/s", "frac": round(conv["stem_tflops"] / MFMA_PEAK_TFLOPS["float32"], 5),
+            "launch_ms": round(conv["stem_seconds"] * 1e3, 4), "algorithmic_flops": conv["stem_flops"],
+            "what": (f"uint8 patches -> conv7x7/2 (3->64, K = 147) + bias + ReLU + maxpool3x3/2, one launch per {mb} patches; "
+                     "flops = 2*Ho*Wo*64*147 per patch (the conv rows recomputed at chunk seams are not counted)")}
+        pmc_c = pmc_traffic("conv_mfma_f32_kernel", "trunk") if (mb, hw) == (1024, 256) else None
+        if pmc_c is not None:  # PMC passes cannot run inside the timed process: this round's committed passes, same shapes
+            roofline["traffic"] = round(pmc_c["bytes"])
+            roofline["traffic_source"] = pmc_c["source"] + " (scripts/perf_trunk.py 1024 256: mean over the launches of one forward)"
     else:
-        dominant = "stain_stats_kernel"  # the longest-running hand-written kernel of a step when MIOpen convolves
+        dominant = "stain_stats_kernel"  # the longest-running hand-written kernel of a step when the library convolves
         dk = kernels[dominant]
         roofline = {
             "kernel": dominant, "bound": "hbm", "achieved": round(dk["achieved_GBs"], 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(dk["frac"], 5), "traffic": None,
             "algorithmic_bytes": dk["alg_bytes"], "launch_ms": round(dk["seconds"] * 1e3, 4),
-            "other_kernels": {k: v for k, v in hbm_kernels.items() if k != dominant},
         }
-    roofline.update({
-        "backbone": {"bound": "mfma", "what": ("resnet18 forward: hand-written MFMA implicit-GEMM convolutions with fused "
-                                               "epilogues (stem: MIOpen)" if args.conv_backend == "mfma" and args.dtype == "float32"
-                                               else "resnet18 forward: MIOpen convolutions + hand-written HIP epilogues"),
-                     "achieved": round(flops / t_cnn / 1e12, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype],
-                     "unit": "TFLOP/s", "frac": round(flops / t_cnn / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5),
-                     "ms": round(t_cnn * 1e3, 3)},
-    })
-    pmc = pmc_traffic("stain_stats_kernel") if (n, hw) == (4096, 224) else None
-    if pmc is not None:  # PMC passes cannot run inside the timed process; they are this round's committed profile
+        other.pop(dominant)
+    roofline["other_kernels"] = other
+    roofline["backbone"] = {
+        "bound": "mfma", "what": ("resnet18 forward, every convolution hand-written (stem kernel + MFMA implicit GEMM with fused "
+                                  "epilogues); average pool / classifier GEMM / softmax: torch" if conv is not None
+                                  else "resnet18 forward: library convolutions + hand-written HIP epilogues"),
+        "achieved": round(flops / t_cnn / 1e12, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+        "frac": round(flops / t_cnn / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5), "ms": round(t_cnn * 1e3, 3)}
+    pmc = pmc_traffic("stain_stats_kernel", "stain") if (n, hw) == (4096, 256) else None
+    if pmc is not None:
         tgt = roofline if dominant == "stain_stats_kernel" else roofline["other_kernels"]["stain_stats_kernel"]
         tgt["traffic"] = round(pmc["bytes"])
         tgt["traffic_source"] = pmc["source"]
     line["roofline"] = roofline
 
-    # ---- extras (rank 0, single GPU): host-inclusive API call, fp16 backbone with its error, 256^2 patches --------
+    # ---- extras (rank 0, single GPU): host-inclusive API call, fp16 backbone with its error, 224^2 patches --------
     if world_size == 1 and not args.no_extras:
         extras = {}
         k_extra = max(3, min(args.steps, 5))
         host_all = np.ascontiguousarray(np.tile(host, ((n + len(host) - 1) // len(host), 1, 1, 1))[:n])
-        el, out_h = timed(host_all, k_extra, 1)
+        el, out_h, _ = timed(host_all, k_extra, 1)
         assert float((out_h["predictions"] == out["predictions"][:n]).mean()) > 0.999
         line["host_inclusive"] = {
             "value": round(n * k_extra / el, 2), "unit": "patches/s", "ms_per_step": round(el / k_extra * 1e3, 3),
             "steps": k_extra, "what": ("the same PatchPredictor.run() call on HOST NumPy uint8 patches: page-lock in "
                                        "place + H2D over PCIe (one batch ahead, copy stream) + compute + D2H of results"),
             "pcie_GBs": round(n * hw * hw * 3 * k_extra / el / 1e9, 2)}
+        del host_all
         if args.dtype == "float32":
             run(xs, "float16")
-            el16, out16 = timed(xs, k_extra, 1, "float16")
+            el16, out16, _ = timed(xs, k_extra, 1, "float16")
             dp = float(np.abs(out16["probabilities"].astype(np.float64) - probs[:n].astype(np.float64)).max())
             extras["cnn_float16"] = {
                 "value": round(n * k_extra / el16, 2), "unit": "patches/s", "ms_per_step": round(el16 / k_extra * 1e3, 3),
                 "max_abs_dprob_vs_float32": dp, "tolerance": 1e-3, "within_tolerance": bool(dp <= 1e-3),
                 "argmax_agreement": float((out16["predictions"] == out["predictions"][:n]).mean()),
-                "note": "extra only: fp16 MFMA backbone (fp32 accumulate), same batch; not the reported value"}
-        if args.dtype == "float32":
-            other = "miopen" if args.conv_backend == "mfma" else "mfma"
-            this = args.conv_backend
-            args.conv_backend = other
-            run(xs)
-            el_o, out_o = timed(xs, k_extra, 1)
-            args.conv_backend = this
-            run(xs)
-            extras[f"conv_backend_{other}"] = {
-                "value": round(n * k_extra / el_o, 2), "unit": "patches/s", "ms_per_step": round(el_o / k_extra * 1e3, 3),
-                "max_abs_dprob_vs_reported": float(np.abs(out_o["probabilities"].astype(np.float64) - probs[:n]).max()),
-                "note": ("same call with the block convolutions on MIOpen + separate HIP epilogues" if other == "miopen"
-                         else "same call with the hand-written MFMA implicit-GEMM convolutions")}
-        if hw != 256:
-            _, x256 = workload(256, n)
-            run(x256)
-            el256, o256 = timed(x256, k_extra, 1)
-            assert o256["probabilities"].shape == (n, 9)
-            extras["patch_256"] = {"value": round(n * k_extra / el256, 2), "unit": "patches/s",
-                                   "ms_per_step": round(el256 / k_extra * 1e3, 3), "dtype": args.dtype,
-                                   "workload": f"{n} synthetic 256x256x3 patches (BASELINE.json metric string), same call"}
-            del x256
+                "note": "extra only: fp16 backbone (fp32 accumulate), same batch; not the reported value"}
+        if hw != 224:
+            _, x224 = workload(224, n)
+            run(x224)
+            el224, o224, _ = timed(x224, k_extra, 1)
+            assert o224["probabilities"].shape == (n, 9)
+            extras["patch_224"] = {"value": round(n * k_extra / el224, 2), "unit": "patches/s",
+                                   "ms_per_step": round(el224 / k_extra * 1e3, 3), "dtype": args.dtype,
+                                   "workload": f"BASELINE configs[1]: {n} synthetic 224x224x3 patches, same call"}
+            del x224
         line["extras"] = extras
     if not args.no_cpu_baseline and world_size == 1:
         cpu_model, _ = get_pretrained_model("resnet18-kather100k")

@@ -118,7 +118,7 @@ def bench_semantic(args) -> dict | None:
     result = {}
 
     def step():
-        result["out"] = eng.run([reader], patch_mode=False, miopen_find=True, conv_backend=args.conv_backend)
+        result["out"] = eng.run([reader], patch_mode=False, miopen_find=True)
 
     step()  # MIOpen solver search, lazy loads
     cfg = eng._ioconfig  # noqa: SLF001
@@ -223,7 +223,7 @@ def bench_hovernet(args) -> dict | None:
     result = {}
 
     def step():
-        result["out"] = eng.run(tiles, patch_mode=True, miopen_find=True, conv_backend=args.conv_backend)
+        result["out"] = eng.run(tiles, patch_mode=True, miopen_find=True)
 
     step()
     elapsed = _timed(step, args, world_size, device)

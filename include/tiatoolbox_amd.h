@@ -416,6 +416,18 @@ int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const fl
                              int32_t relu, const float* d_post_scale, const float* d_post_shift, float* d_y2,
                              void* stream);
 
+/* The ResNet stem in one kernel: y = maxpool3x3/s2/p1(relu(conv7x7/s2/p3(X) + bias)), 3 -> 64 channels, BatchNorm folded
+ * into w / bias (CNNModel.forward -> torchvision conv1 / bn1 / relu / maxpool, models/architecture/vanilla.py:300-316).
+ *   x_is_u8 != 0: d_x is the uint8 NHWC patch batch and X = x / 255 in float32 (correctly rounded division) -- `ToTensor`
+ *   (models/dataset/classification.py:27-32) and the float32 cast of `_infer_batch` (vanilla.py:242-245) happen on load;
+ *   x_is_u8 == 0: d_x is float32 NHWC and X = x.
+ *   d_x [n,h,w,3]   d_w_packed [148,64] from tia_stem_pack_weights_f32   d_bias [64]
+ *   d_y [n,hp,wp,64] float32, hp = ((h-1)/2)/2 + 1 (likewise wp); float32 fmaf chain in (ky, kx, c) order on the matrix cores. */
+int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, float* d_y,
+                               int64_t n, int64_t h, int64_t w, void* stream);
+/* OIHW [64,3,7,7] float32 -> [148,64]: rows (ky, kx, c), one zero row at the end. */
+int tia_stem_pack_weights_f32(const float* d_w_oihw, float* d_packed, void* stream);
+
 /* y = act(x * scale[c] + shift[c]) on NHWC float32 ([rows, c], c % 4 == 0; y may alias x): an inference-mode
  * BatchNorm (+ ReLU) that sits in FRONT of a convolution and therefore cannot be folded into one -- the pre-activation
  * units of HoVer-Net (models/architecture/hovernet.py:72-261: "preact_bna" / "blk_bna"). */

@@ -299,7 +299,7 @@ def test_mfma_resnet_matches_plain_model(patches, name):
         got = mfma(x.cuda().contiguous(memory_format=torch.channels_last)).cpu()
     assert (got - ref).abs().max() < 1e-4
     eng = PatchPredictor(name, batch_size=4, device="cuda")
-    a = eng.run(patches, patch_mode=True, return_probabilities=True, conv_backend="mfma")
+    a = eng.run(patches, patch_mode=True, return_probabilities=True)
     assert any(type(m).__name__ == "MfmaResNet" for m in eng._inference_model(torch.float32).modules())
     b = PatchPredictor(name, batch_size=4).run(patches, patch_mode=True, return_probabilities=True)
     np.testing.assert_allclose(a["probabilities"], b["probabilities"], atol=1e-4)

@@ -1,0 +1,302 @@
+// The ResNet stem in ONE kernel on the gfx950 matrix cores: uint8 (or float32) NHWC patches in, pooled float32 NHWC out.
+//
+//   y = maxpool3x3/s2/p1( relu( conv7x7/s2/p3( x / 255 ) + bias ) )        3 -> 64 channels, BatchNorm folded into w / bias
+//
+// Reference: CNNModel.forward -> torchvision resnet conv1 / bn1 / relu / maxpool behind `ToTensor`
+// (models/architecture/vanilla.py:242-245, 300-316; models/dataset/classification.py:27-32: uint8 HWC -> float32 / 255).
+// Arithmetic: float32 throughout; the division by 255 is the correctly rounded one (a 256-entry table built with IEEE
+// division, = torch's `.float().div(255)`), the convolution is an fmaf chain on v_mfma_f32_32x32x2_f32 in the order
+// (ky, kx, c), bias added after the sum, then max(., 0), then the 3x3 maximum -- the order of the unfused torch ops.
+//
+// GEMM view per workgroup iteration: M = 2 conv rows x 128 conv columns (8 MFMA tiles of 32 pixels), N = 64 channels
+// (2 tiles), K = 7 * 21 = 147 (+ 1 zero row).  A workgroup (4 waves, one column group of 32 conv columns each) walks down
+// a strip of an image two conv rows = one pooled row at a time:
+//   * the 9 input rows a pair of conv rows needs sit in LDS as float32 (converted ONCE per workgroup iteration, pad
+//     columns / rows as zeros); MFMA lane (i, h) reads pixel column i, reduction index 2 s + h: with the reduction ordered
+//     (ky, kx, c) a tap row is 21 consecutive floats, so the A operand is `ring[6 i + const]` -- one ds_read_b32 with an
+//     immediate offset and NO address arithmetic in the loop (three "wrap" steps where h = 0 / 1 straddle two tap rows use
+//     a second per-lane base); B (148 x 64 weights) stays in LDS for the whole kernel
+//   * each wave owns the SAME 32 columns of both conv rows, so the vertical part of the 3x3 maximum is register-local:
+//     V = max(previous iteration's second row, row 2p, row 2p+1); only V goes to LDS (aliasing the input rows, which are
+//     dead by then) for the horizontal maximum of three columns, written out as whole 16 KB pooled rows
+//   * the next iteration's input bytes are requested before the 296 MFMAs of the current one and converted afterwards
+//   * LDS 70 KB -> two workgroups per CU: one converts / pools while the other multiplies
+// Wider images are cut into column strips of <= 128 conv columns (64 / 63 pooled columns), taller ones into row chunks
+// (one extra warm-up iteration per chunk supplies the carried row).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tiatoolbox_amd.h"
+
+namespace {
+
+constexpr int NTH = 256;
+constexpr int RS = 784;          // floats per staged input row: (2 * 128 + 5) pixels * 3 = 783, + 1 (read by the zero k row)
+constexpr int WROWS = 9;         // input rows under two conv rows: 2 * 2 + 5
+constexpr int KROWS = 148;       // 147 taps*channels + one zero row (the MFMA reduces two k per step)
+constexpr int COUT = 64;
+constexpr int REGION = 128 * 64;  // floats: V tile [128 conv columns][64 channels]  (>= WROWS * RS = 7056)
+constexpr int LUT_OFF = REGION;
+constexpr int W_OFF = REGION + 256;
+constexpr int LDS_FLOATS = W_OFF + KROWS * COUT;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct StemDims {
+    int n, h, w, ho, wo, hp, wp;
+    int chunks, rows_per_chunk;  // row chunks per image, pooled rows per chunk
+    unsigned x_bytes;            // extent of the input buffer of this launch (< 2^31), rounded up to whole dwords
+    int x_shift;                 // uint8 input: bytes between the (dword-aligned) buffer base and the first image
+};
+
+template <bool U8>
+__global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __restrict__ xin, const float* __restrict__ wpk,
+                                                             const float* __restrict__ bias, float* __restrict__ y, StemDims d) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ring = smem;
+    float* lut = smem + LUT_OFF;
+    float* Wl = smem + W_OFF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.x / d.chunks, chunk = blockIdx.x - img * d.chunks;
+    const int strip = blockIdx.y;
+    const int p0 = strip == 0 ? 0 : 64 + 63 * (strip - 1);
+    const int p1 = min(d.wp, strip == 0 ? 64 : p0 + 63);
+    const int c_start = max(0, 2 * p0 - 1);
+    const int ncols = min(d.wo, 2 * p1) - c_start;  // conv columns [c_start, c_start + ncols), <= 128
+    const int ixlo = 2 * c_start - 3;               // input pixel column under ring float 0
+    const int ixlo_c = max(ixlo, 0);
+    const int f0 = (ixlo_c - ixlo) * 3;                              // ring float of the first in-image element of a row
+    const int nb = max(0, (min(ixlo + 261, d.w) - ixlo_c) * 3);      // in-image elements of a row that the strip needs
+    const int q0 = chunk * d.rows_per_chunk, q1 = min(d.hp, q0 + d.rows_per_chunk);
+    if (q0 >= q1) return;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xin), 0, (int)d.x_bytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+
+    // ---- weights and the /255 table into LDS (once) ----
+    for (int i = tid; i < KROWS * COUT / 4; i += NTH)
+        reinterpret_cast<float4*>(Wl)[i] = reinterpret_cast<const float4*>(wpk)[i];
+    lut[tid] = __fdiv_rn((float)tid, 255.0f);
+
+    // ---- staging of the 9 input rows of pooled row `py`: request (registers), later convert + write (LDS) ----
+    // uint8: a unit = four consecutive ring floats (one 16-byte LDS store) = four consecutive input bytes, which lie in two
+    // aligned dwords (funnel-shifted together); 9 rows x 196 units.  float32: a unit = one ring float.
+    constexpr int NU = U8 ? 7 : 28;
+    unsigned ld[NU], ld2[U8 ? NU : 1];
+    auto issue_loads = [&](int py) {
+#pragma unroll
+        for (int q = 0; q < NU; ++q) {
+            const int u = tid + NTH * q;
+            if constexpr (U8) {
+                const int wr = u / 196, g = u - wr * 196;
+                const int iy = 4 * py - 3 + wr;
+                const bool ok = wr < WROWS && iy >= 0 && iy < d.h;
+                const unsigned gb = (unsigned)(((img * d.h + iy) * d.w + ixlo_c) * 3 + d.x_shift);
+                const int t = (int)(gb & 3u) + 4 * g - f0;           // byte distance from the row's aligned base
+                const int voff = (int)(gb & ~3u) + ((t >> 2) << 2);  // may lie in front of the buffer: reads as zero
+                ld[q] = __builtin_amdgcn_raw_buffer_load_b32(rx, (ok && voff >= 0) ? voff : OOB, 0, 0);
+                ld2[q] = __builtin_amdgcn_raw_buffer_load_b32(rx, (ok && voff + 4 >= 0) ? voff + 4 : OOB, 0, 0);
+            } else {
+                const int wr = u / RS, ri = u - wr * RS;
+                const int iy = 4 * py - 3 + wr, bi = ri - f0;
+                const bool ok = wr < WROWS && iy >= 0 && iy < d.h && bi >= 0 && bi < nb;
+                const int voff = (((img * d.h + iy) * d.w + ixlo_c) * 3 + bi) * 4;
+                ld[q] = __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? voff : OOB, 0, 0);
+            }
+        }
+    };
+    auto write_ring = [&](int py) {
+        if constexpr (U8) {
+            float f[NU][4];
+#pragma unroll
+            for (int q = 0; q < NU; ++q) {  // all table look-ups first (independent), then the stores
+                const int u = tid + NTH * q;
+                const int wr = u / 196, g = u - wr * 196;
+                const int iy = 4 * py - 3 + wr;
+                const unsigned gb = (unsigned)(((img * d.h + iy) * d.w + ixlo_c) * 3 + d.x_shift);
+                const unsigned sh = ((gb & 3u) + 4u * g - (unsigned)f0) & 3u;
+                const unsigned wbytes = __builtin_amdgcn_alignbyte(ld2[q], ld[q], sh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[q][e] = lut[(wbytes >> (8 * e)) & 255u];
+            }
+#pragma unroll
+            for (int q = 0; q < NU; ++q) {
+                const int u = tid + NTH * q;
+                const int wr = u / 196, g = u - wr * 196;
+                const int iy = 4 * py - 3 + wr;
+                const bool ok = iy >= 0 && iy < d.h;
+                float4 o;
+                const int bi = 4 * g - f0;
+                o.x = (ok && bi + 0 >= 0 && bi + 0 < nb) ? f[q][0] : 0.0f;
+                o.y = (ok && bi + 1 >= 0 && bi + 1 < nb) ? f[q][1] : 0.0f;
+                o.z = (ok && bi + 2 >= 0 && bi + 2 < nb) ? f[q][2] : 0.0f;
+                o.w = (ok && bi + 3 >= 0 && bi + 3 < nb) ? f[q][3] : 0.0f;
+                if (u < WROWS * 196) reinterpret_cast<float4*>(ring)[u] = o;  // ring float 4 u = row wr, float 4 g
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NU; ++q) {
+                const int u = tid + NTH * q;
+                if (u < WROWS * RS) ring[u] = __uint_as_float(ld[q]);  // out-of-image slots were loaded as zeros
+            }
+        }
+    };
+
+    f32x16 carry[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) carry[0][e] = carry[1][e] = 0.0f;
+
+    const int hh = lane >> 5;
+    const int lc = 32 * wave + (lane & 31);  // local conv column of this lane's A rows
+    const float* a_ptr = ring + 6 * lc + hh;
+    const float* aw_ptr = ring + 6 * lc + hh * (RS - 20);  // wrap steps: h = 1 starts the next tap row
+    const float* w_ptr = Wl + hh * COUT + (lane & 31);
+    const float bv0 = bias[lane & 31], bv1 = bias[32 + (lane & 31)];
+
+    const int it0 = q0 > 0 ? q0 - 1 : 0;
+    issue_loads(it0);
+    __syncthreads();  // lut ready
+    write_ring(it0);
+    __syncthreads();
+
+    for (int py = it0; py < q1; ++py) {
+        issue_loads(py + 1 < q1 ? py + 1 : py);  // next window's bytes fly behind the MFMAs (the last one re-reads its own)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KROWS / 2; ++s) {
+            const int k0 = 2 * s, ky = k0 / 21, j0 = k0 - 21 * ky;
+            const bool wrap = j0 == 20 && s != KROWS / 2 - 1;  // the last step's h = 1 is the zero row: any finite float will do
+            const int off = ky * RS + j0;
+            const float a0 = wrap ? aw_ptr[off] : a_ptr[off];
+            const float a1 = wrap ? aw_ptr[off + 2 * RS] : a_ptr[off + 2 * RS];
+            const float b0 = w_ptr[k0 * COUT], b1 = w_ptr[k0 * COUT + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();  // every wave is done with the input rows: the region becomes the V tile
+
+        // ---- bias + ReLU, vertical maximum in registers (C/D layout: channel = lane & 31, pixel = (e&3) + 8 (e>>2) + 4 h) ----
+        const bool row0 = 2 * py < d.ho, row1 = 2 * py + 1 < d.ho;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bv = j == 0 ? bv0 : bv1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int lcol = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const bool colok = lcol < ncols;
+                float r0 = acc[0][j][e] + bv, r1 = acc[1][j][e] + bv;
+                r0 = (row0 && colok && r0 > 0.0f) ? r0 : 0.0f;
+                r1 = (row1 && colok && r1 > 0.0f) ? r1 : 0.0f;
+                const float v = fmaxf(carry[j][e], fmaxf(r0, r1));
+                carry[j][e] = r1;
+                ring[lcol * COUT + j * 32 + (lane & 31)] = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- horizontal maximum of three columns, one pooled row (<= 64 x 64 floats) written as float4 ----
+        if (py >= q0) {
+            const int c4 = tid & 15;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int px = p0 + pass * 16 + (tid >> 4);
+                if (px < p1) {
+                    const int lcm = 2 * px - c_start;
+                    const float4* vrow = reinterpret_cast<const float4*>(ring) + c4;
+                    float4 m = vrow[lcm * (COUT / 4)];
+                    const float4 r = vrow[(lcm + 1) * (COUT / 4)];  // lcm + 1 <= 127: zeros where the column does not exist
+                    m.x = fmaxf(m.x, r.x), m.y = fmaxf(m.y, r.y), m.z = fmaxf(m.z, r.z), m.w = fmaxf(m.w, r.w);
+                    if (lcm > 0) {
+                        const float4 l = vrow[(lcm - 1) * (COUT / 4)];
+                        m.x = fmaxf(m.x, l.x), m.y = fmaxf(m.y, l.y), m.z = fmaxf(m.z, l.z), m.w = fmaxf(m.w, l.w);
+                    }
+                    reinterpret_cast<float4*>(y + (((long)img * d.hp + py) * d.wp + px) * COUT)[c4] = m;
+                }
+            }
+        }
+        __syncthreads();
+        if (py + 1 < q1) write_ring(py + 1);
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+namespace {
+// OIHW [64][3][7][7] -> [ky][kx][c][cout] = [147][64], followed by one zero row
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ w, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= KROWS * COUT) return;
+    const int o = i % COUT, k = i / COUT;
+    float v = 0.0f;
+    if (k < 147) {
+        const int ky = k / 21, r = k - 21 * ky, kx = r / 3, c = r - 3 * kx;
+        v = w[((o * 3 + c) * 7 + ky) * 7 + kx];
+    }
+    out[i] = v;
+}
+}  // namespace
+
+extern "C" int tia_stem_pack_weights_f32(const float* d_w_oihw, float* d_packed, void* stream) {
+    if (!d_w_oihw || !d_packed) return TIA_EINVAL;
+    hipLaunchKernelGGL(stem_pack_kernel, dim3((KROWS * COUT + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_w_oihw, d_packed);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, float* d_y,
+                                          int64_t n, int64_t h, int64_t w, void* stream) {
+    if (!d_x || !d_w_packed || !d_bias || !d_y || n <= 0 || h <= 0 || w <= 0) return TIA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_w_packed) | reinterpret_cast<uintptr_t>(d_y)) & 15) return TIA_EINVAL;
+    if (!x_is_u8 && (reinterpret_cast<uintptr_t>(d_x) & 3)) return TIA_EINVAL;
+    const long ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;  // (h + 6 - 7) / 2 + 1
+    const long hp = (ho - 1) / 2 + 1, wp = (wo - 1) / 2 + 1;  // (ho + 2 - 3) / 2 + 1
+    const long esz = x_is_u8 ? 1 : 4;
+    const long image_bytes = h * w * 3 * esz;
+    if (image_bytes > 0x7fffffffL) return TIA_ESIZE;
+    long group = 0x7fffffffL / image_bytes;  // 32-bit byte offsets inside a launch
+    if (group > 0x7fffffffL / (h * w * 3)) group = 0x7fffffffL / (h * w * 3);
+    const long strips = wp <= 64 ? 1 : 1 + (wp - 64 + 62) / 63;
+    static bool attr_set = false;
+    const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem7x7_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&stem7x7_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return TIA_ELAUNCH;
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (long first = 0; first < n; first += group) {
+        const long nb = n - first < group ? n - first : group;
+        // enough workgroups for two per CU and a second round: cut images into row chunks when the batch is small
+        long chunks = (1024 + nb * strips - 1) / (nb * strips);
+        const long max_chunks = hp >= 8 ? hp / 8 : 1;
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks < 1) chunks = 1;
+        const long rows = (hp + chunks - 1) / chunks;
+        chunks = (hp + rows - 1) / rows;
+        const char* xg = static_cast<const char*>(d_x) + first * image_bytes;
+        const int shift = x_is_u8 ? (int)(reinterpret_cast<uintptr_t>(xg) & 3) : 0;
+        xg -= shift;
+        StemDims d{(int)nb, (int)h, (int)w, (int)ho, (int)wo, (int)hp, (int)wp, (int)chunks, (int)rows,
+                   (unsigned)((nb * image_bytes + shift + 3) & ~3L), shift};
+        float* yg = d_y + first * hp * wp * COUT;
+        const dim3 grid((unsigned)(nb * chunks), (unsigned)strips);
+        if (x_is_u8)
+            hipLaunchKernelGGL(stem7x7_pool_kernel<true>, grid, dim3(NTH), lds, st, xg, d_w_packed, d_bias, yg, d);
+        else
+            hipLaunchKernelGGL(stem7x7_pool_kernel<false>, grid, dim3(NTH), lds, st, xg, d_w_packed, d_bias, yg, d);
+    }
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}

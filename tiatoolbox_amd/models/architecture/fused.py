@@ -1,16 +1,16 @@
 """Inference-time graph surgery for the CNN backbones (eval mode only).
 
-* ``fold_conv_bn``: BatchNorm folded into the preceding convolution (weights scaled,
-  bias added), removing one full read+write of every activation tensor per BN layer —
-  on MI355X the unfused BN kernels cost as much as the convolutions themselves
-  (profiles/r01_bench_rocprofv3_summary.txt).
-* ``FusedResNet``: ResNet trunk executed with MIOpen's fused convolution+bias+ReLU and
-  convolution+bias+add+ReLU entry points (``aten::miopen_convolution_relu`` /
-  ``aten::miopen_convolution_add_relu``), so the residual add and activation ride in the
-  convolution epilogue instead of separate elementwise passes.
+* ``fold_conv_bn``: BatchNorm folded into the preceding convolution (weights scaled, bias added), removing one full
+  read+write of every activation tensor per BN layer.
+* ``MfmaResNet``: float32 ResNet trunk on hand-written kernels only -- the stem (``csrc/stem_mfma.hip``: uint8 or float32
+  patches -> conv7x7 + bias + ReLU + max-pool, one kernel) and every block convolution (``csrc/conv_mfma.hip``: implicit GEMM
+  on the matrix cores with bias / residual / ReLU in the epilogue).
+* ``HipFusedResNet``: fp16 / bf16 trunk: library convolutions + the hand-written single-pass epilogues of
+  ``csrc/cnn_epilogue.hip``.
 
-State-dict compatibility is untouched: these are derived copies built from a loaded
-``CNNModel`` (reference parameter names), never the object that loads weights.
+State-dict compatibility is untouched: these are derived copies built from a loaded ``CNNModel`` (reference parameter
+names), never the object that loads weights.  Every wrapper raises on tensors it cannot take (host tensors, wrong layout):
+there is no silent torch fallback.
 """
 
 from __future__ import annotations
@@ -42,69 +42,6 @@ def fold_conv_bn(model: nn.Module) -> nn.Module:
 
     visit(model)
     return model
-
-
-def _has_miopen_fused(x: torch.Tensor) -> bool:
-    return x.is_cuda and hasattr(torch.ops.aten, "miopen_convolution_relu") and x.dtype in (
-        torch.float16, torch.float32, torch.bfloat16)
-
-
-def conv_bias_relu(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
-    if _has_miopen_fused(x):
-        return torch.ops.aten.miopen_convolution_relu(x, conv.weight, conv.bias, conv.stride, conv.padding,
-                                                      conv.dilation, conv.groups)
-    return F.relu(conv(x))
-
-
-def conv_bias_add_relu(x: torch.Tensor, conv: nn.Conv2d, z: torch.Tensor) -> torch.Tensor:
-    if _has_miopen_fused(x):
-        return torch.ops.aten.miopen_convolution_add_relu(x, conv.weight, z, 1.0, conv.bias, conv.stride,
-                                                          conv.padding, conv.dilation, conv.groups)
-    return F.relu(conv(x) + z)
-
-
-class _FusedBasic(nn.Module):
-    def __init__(self, blk: BasicBlock) -> None:
-        super().__init__()
-        self.conv1, self.conv2 = blk.conv1, blk.conv2
-        self.down = blk.downsample[0] if blk.downsample is not None else None
-
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        identity = x if self.down is None else self.down(x)
-        out = conv_bias_relu(x, self.conv1)
-        return conv_bias_add_relu(out, self.conv2, identity)
-
-
-class _FusedBottleneck(nn.Module):
-    def __init__(self, blk: Bottleneck) -> None:
-        super().__init__()
-        self.conv1, self.conv2, self.conv3 = blk.conv1, blk.conv2, blk.conv3
-        self.down = blk.downsample[0] if blk.downsample is not None else None
-
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        identity = x if self.down is None else self.down(x)
-        out = conv_bias_relu(x, self.conv1)
-        out = conv_bias_relu(out, self.conv2)
-        return conv_bias_add_relu(out, self.conv3, identity)
-
-
-class FusedResNet(nn.Module):
-    """Trunk ``conv1/bn1/relu/maxpool/layer1..4`` with folded BN and fused epilogues."""
-
-    def __init__(self, trunk: nn.Sequential) -> None:
-        super().__init__()
-        folded = fold_conv_bn(trunk)
-        self.stem = folded[0]
-        self.pool = folded[3]
-        blocks = []
-        for layer in list(folded)[4:]:
-            for blk in layer:
-                blocks.append(_FusedBasic(blk) if isinstance(blk, BasicBlock) else _FusedBottleneck(blk))
-        self.blocks = nn.Sequential(*blocks)
-
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.pool(conv_bias_relu(x, self.stem))
-        return self.blocks(x)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -316,8 +253,9 @@ def hip_scale_shift_act_view(x: torch.Tensor, scale: torch.Tensor, shift: torch.
     ok = (x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and c % 4 == 0 and x.data_ptr() % 16 == 0
           and all(x.stride(d) % 4 == 0 for d in (0, 2, 3)) and x.stride(3) >= c)
     if not ok:
-        y = x * scale[None, :, None, None] + shift[None, :, None, None]
-        return (F.relu(y) if relu else y).contiguous(memory_format=torch.channels_last)
+        msg = ("hip_scale_shift_act_view expects a float32 view with contiguous channels, c % 4 == 0, a 16-byte aligned base and "
+               f"strides that are multiples of 4 elements; got shape {tuple(x.shape)} strides {tuple(x.stride())} {x.dtype}.")
+        raise ValueError(msg)
     y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         rc = _lib.load().tia_scale_shift_act_view_nhwc_f32(x.data_ptr(), x.stride(0), x.stride(2), x.stride(3), scale.data_ptr(),
@@ -365,8 +303,9 @@ def hip_upsample2x_add(x: torch.Tensor, y: torch.Tensor, scale: torch.Tensor | N
     ok_y = (y.is_cuda and y.dtype == torch.float32 and y.shape == (n, c, 2 * h, 2 * w) and y.stride(1) == 1 and y.stride(3) == c
             and y.stride(2) % 4 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0)
     if not (_nhwc_ptr_ok(x) and x.dtype == torch.float32 and ok_y and c % 4 == 0):
-        out = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + y
-        return out if scale is None else F.relu(out * scale[None, :, None, None] + shift[None, :, None, None])
+        msg = ("hip_upsample2x_add expects float32 channels-last tensors, `y` a (cropped) view with contiguous channels of shape "
+               f"[n, c, 2h, 2w], c % 4 == 0; got x {tuple(x.shape)} {x.dtype}, y {tuple(y.shape)} strides {tuple(y.stride())}.")
+        raise ValueError(msg)
     out = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         rc = _lib.load().tia_upsample2x_add_act_nhwc_f32(x.data_ptr(), y.data_ptr(), y.stride(0), y.stride(2),
@@ -442,15 +381,54 @@ class _MfmaBottleneck(nn.Module):
         return hip_conv2d(out, self._w("conv3"), self.conv3.bias, identity, kernel=1, stride=1, padding=0, relu=True)
 
 
+def pack_stem_weights(conv: nn.Conv2d) -> torch.Tensor:
+    """OIHW ``[64, 3, 7, 7]`` -> the stem GEMM's B matrix ``[148, 64]`` (``(ky, kx, c)`` rows + one zero row)."""
+    from tiatoolbox_amd import _lib
+
+    w = conv.weight.detach().to(torch.float32).contiguous()
+    if tuple(w.shape) != (64, 3, 7, 7) or conv.stride != (2, 2) or conv.padding != (3, 3):
+        msg = f"the stem kernel is conv7x7 / stride 2 / pad 3, 3 -> 64 channels; got weight {tuple(w.shape)}."
+        raise ValueError(msg)
+    out = torch.empty((148, 64), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().tia_stem_pack_weights_f32(w.data_ptr(), out.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "tia_stem_pack_weights_f32")
+    return out
+
+
+def hip_stem_conv_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """``maxpool3x3/2(relu(conv7x7/2(x) + bias))`` in one kernel (``tia_stem_conv7x7_pool_nhwc``).
+
+    ``x``: NHWC ``[n, h, w, 3]`` contiguous CUDA tensor, ``uint8`` (scaled by 1/255 on load: ``ToTensor``) or ``float32`` (as is).
+    Returns the pooled activations as an NCHW tensor stored channels-last (``[n, 64, hp, wp]``)."""
+    from tiatoolbox_amd import _lib
+
+    if not (x.is_cuda and x.dim() == 4 and x.shape[-1] == 3 and x.is_contiguous() and x.dtype in (torch.uint8, torch.float32)):
+        msg = f"hip_stem_conv_pool expects a contiguous NHWC uint8 / float32 CUDA batch with 3 channels, got {tuple(x.shape)} {x.dtype}."
+        raise ValueError(msg)
+    n, h, w, _ = x.shape
+    hp, wp = ((h - 1) // 2) // 2 + 1, ((w - 1) // 2) // 2 + 1
+    y = torch.empty((n, 64, hp, wp), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_stem_conv7x7_pool_nhwc(x.data_ptr(), int(x.dtype == torch.uint8), w_packed.data_ptr(), bias.data_ptr(),
+                                                    y.data_ptr(), n, h, w, _lib.current_stream())
+    _lib.check(rc, "tia_stem_conv7x7_pool_nhwc")
+    return y
+
+
 class MfmaResNet(nn.Module):
-    """ResNet trunk in float32: stem = MIOpen 7x7 (3 input channels) + the fused bias/ReLU/max-pool kernel, every block
-    convolution (BasicBlock: resnet18/34; Bottleneck: resnet50/101) = the hand-written MFMA implicit GEMM with its epilogue
-    fused (BN folded, channels-last)."""
+    """ResNet trunk in float32 on hand-written kernels only: the stem (7x7 / 3 input channels + bias + ReLU + max-pool, one
+    kernel reading uint8 or float32 patches) and every block convolution (BasicBlock: resnet18/34; Bottleneck: resnet50/101) as
+    the MFMA implicit GEMM with its epilogue fused (BN folded, channels-last).  A ``uint8`` input means ``ToTensor`` has been
+    deferred into the stem: the kernel divides by 255 while it loads."""
+
+    accepts_uint8 = True
 
     def __init__(self, trunk: nn.Sequential) -> None:
         super().__init__()
         folded = fold_conv_bn(trunk)
         self.stem = folded[0]
+        self._stem_packed: torch.Tensor | None = None
         blocks = []
         for layer in list(folded)[4:]:
             for blk in layer:
@@ -460,24 +438,28 @@ class MfmaResNet(nn.Module):
                 blocks.append(_MfmaBasic(blk) if isinstance(blk, BasicBlock) else _MfmaBottleneck(blk))
         self.blocks = nn.Sequential(*blocks)
 
+    def stem_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """``x``: NCHW view of an NHWC batch (what ``infer_batch`` passes) or the NHWC batch itself."""
+        if x.shape[-1] != 3:  # NCHW view -> the NHWC memory underneath (a copy only if it was not channels-last)
+            x = x.permute(0, 2, 3, 1)
+        x = x.contiguous()
+        if x.dtype not in (torch.uint8, torch.float32):
+            x = x.to(torch.float32)
+        w = self._stem_packed
+        if w is None or w.device != self.stem.weight.device:
+            w = self._stem_packed = pack_stem_weights(self.stem)
+        return hip_stem_conv_pool(x, w, self.stem.bias)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if not x.is_contiguous(memory_format=torch.channels_last):
-            x = x.contiguous(memory_format=torch.channels_last)
-        x = hip_bias_relu_maxpool(_conv_nobias(x, self.stem), self.stem.bias)
-        return self.blocks(x)
+        return self.blocks(self.stem_forward(x))
 
 
 def fuse_cnn_model(model: nn.Module, *, epilogue_fusion: bool | str = False) -> nn.Module:
     """Derived inference copy of a ``CNNModel``/``CNNBackbone`` with BN folded into the convolutions.
 
-    ``epilogue_fusion=True`` additionally routes through ``aten::miopen_convolution_relu`` /
-    ``_add_relu``.  Measured on MI355X (ROCm 7.2, MIOpen via torch 2.10): those entry points fall
-    back to a *naive* convolution kernel for NHWC fp16 (22 s per 4096-patch pass vs 55 ms), so the
-    default is off; BN folding alone gives 70.8 -> 54.5 ms.  ``epilogue_fusion="hip"`` keeps MIOpen for
-    the convolutions (without bias) and runs bias (+ residual) + ReLU (and the stem's max-pool) as the
-    hand-written single-pass kernels of ``csrc/cnn_epilogue.hip`` (CUDA/HIP tensors only).
-    ``epilogue_fusion="mfma"`` (float32, BasicBlock trunks): every block convolution is the hand-written MFMA implicit
-    GEMM of ``csrc/conv_mfma.hip`` with bias / residual / ReLU in its epilogue; only the 3-channel stem stays on MIOpen.
+    ``epilogue_fusion="mfma"`` (float32 on the GPU): stem and block convolutions on the hand-written kernels
+    (:class:`MfmaResNet`); ``"hip"`` (fp16 / bf16 on the GPU): library convolutions (without bias) + the hand-written bias
+    (+ residual) + ReLU / max-pool passes of ``csrc/cnn_epilogue.hip``; ``False``: BN folding only (CPU).
     """
     fused = copy.deepcopy(model).eval()
     trunk = fused.feat_extract
@@ -486,6 +468,9 @@ def fuse_cnn_model(model: nn.Module, *, epilogue_fusion: bool | str = False) -> 
             fused.feat_extract = MfmaResNet(trunk)
         elif epilogue_fusion == "hip":
             fused.feat_extract = HipFusedResNet(trunk)
+        elif epilogue_fusion:
+            msg = f"unknown epilogue_fusion {epilogue_fusion!r}: 'mfma', 'hip' or False."
+            raise ValueError(msg)
         else:
-            fused.feat_extract = FusedResNet(trunk) if epilogue_fusion else fold_conv_bn(trunk)
+            fused.feat_extract = fold_conv_bn(trunk)
     return fused

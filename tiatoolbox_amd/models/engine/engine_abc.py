@@ -31,11 +31,11 @@ _DTYPES = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch
 
 
 def _clear_last_hip_error() -> None:
-    import ctypes
-
+    """Reset the sticky last-error of the HIP runtime torch itself uses (a bare ``CDLL("libamdhip64.so")`` could load a
+    second runtime whose thread-local error is not the one that was set)."""
     try:
-        ctypes.CDLL("libamdhip64.so").hipGetLastError()
-    except OSError:  # pragma: no cover  (no HIP runtime: nothing to clear)
+        torch.cuda.cudart().cudaGetLastError()
+    except Exception:  # noqa: BLE001  (no HIP runtime: nothing to clear)
         pass
 
 
@@ -124,7 +124,8 @@ class EngineABC:
         self.compute_dtype = "float32"    # arithmetic type of the CNN forward
         self.distributed = True           # shard over ranks when torch.distributed is initialised
         self.fold_batchnorm = True        # inference copy with BN folded into the convolutions
-        self.conv_backend = "mfma"        # float32 BasicBlock trunks: hand-written MFMA convolutions ("miopen": library)
+        self.miopen_find = None           # library convolutions that remain (half precision, 3-channel stems of the
+                                          # segmentation graphs): None = search solvers only for the fused float32 graphs
         self._fast_model = None
         self._fast_key = None
 
@@ -214,6 +215,8 @@ class EngineABC:
         """ref. :1211-1372: every kwarg becomes an attribute on the engine (and persists)."""
         for key in kwargs:
             setattr(self, key, kwargs.get(key))
+        if "miopen_find" not in kwargs:
+            self.miopen_find = None  # the process-global solver-search switch is chosen per run, never inherited
         if input_resolutions:
             self.input_resolutions = input_resolutions
         if patch_input_shape is not None:
@@ -271,61 +274,53 @@ class EngineABC:
         """The module used for the forward pass: parameters in ``dtype``, channels-last (MIOpen NHWC)."""
         if dtype == torch.float32 and torch.device(self.device).type != "cuda":
             return self.model
-        miopen_find = bool(getattr(self, "miopen_find", False))
-        key = (dtype, str(self.device), id(self.model), self.fold_batchnorm, miopen_find, _weights_version(self.model),
-               str(getattr(self, "conv_backend", "mfma")))
+        key = (dtype, str(self.device), id(self.model), self.fold_batchnorm, _weights_version(self.model))
         if self._fast_key != key:
             import copy
 
+            on_gpu = torch.device(self.device).type == "cuda"
             m = copy.deepcopy(self.model)
             if self.fold_batchnorm and hasattr(m, "feat_extract"):
                 from tiatoolbox_amd.models.architecture.fused import fuse_cnn_model
-
-                on_gpu = torch.device(self.device).type == "cuda"
-                # `conv_backend` (run kwarg / attribute): "mfma" (default) = the hand-written float32 MFMA implicit GEMM with
-                # its epilogue fused, for float32 runs of ResNet trunks (BasicBlock and Bottleneck); "miopen" = library
-                # convolutions + hand-written epilogues (always used for fp16 / bf16)
-                backend = str(getattr(self, "conv_backend", "mfma"))
                 from tiatoolbox_amd.models.architecture.resnet import BasicBlock, Bottleneck
 
+                # float32 on the GPU: ResNet trunks (BasicBlock and Bottleneck) run on the hand-written kernels only -- stem
+                # and block convolutions (architecture/fused.py: MfmaResNet); fp16 / bf16: library convolutions + the
+                # hand-written epilogue passes; CPU: BatchNorm folding only
                 resnet = any(isinstance(mod, (BasicBlock, Bottleneck)) for mod in m.modules())
-                use_mfma = on_gpu and backend == "mfma" and dtype == torch.float32 and resnet
+                use_mfma = on_gpu and dtype == torch.float32 and resnet
                 m = fuse_cnn_model(m, epilogue_fusion=("mfma" if use_mfma else "hip") if on_gpu else False)
-            else:
+            elif on_gpu and dtype == torch.float32:
                 from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
+                from tiatoolbox_amd.models.architecture.unet import UNetModel
 
-                if (isinstance(m, HoVerNet) and torch.device(self.device).type == "cuda" and dtype == torch.float32
-                        and str(getattr(self, "conv_backend", "mfma")) == "mfma"):
+                if isinstance(m, HoVerNet):
                     # HoVer-Net / HoVerNet+ in float32: 104 of its 144 convolutions on the hand-written MFMA kernel,
                     # BN folded or fused with the ReLU, residual adds in the epilogues (architecture/hovernet_fused.py)
                     from tiatoolbox_amd.models.architecture.hovernet_fused import FusedHoVerNet
 
                     m = FusedHoVerNet(m.to(device=self.device))
-                from tiatoolbox_amd.models.architecture.unet import UNetModel
-
-                if (isinstance(m, UNetModel) and hasattr(m.backbone, "layer1") and m.skip_type == "add"
-                        and torch.device(self.device).type == "cuda" and dtype == torch.float32
-                        and str(getattr(self, "conv_backend", "mfma")) == "mfma"):
+                elif isinstance(m, UNetModel) and hasattr(m.backbone, "layer1") and m.skip_type == "add":
                     # UNet with the ResNet-50 encoder in float32: 61 of its 63 convolutions on the MFMA kernel
                     from tiatoolbox_amd.models.architecture.unet_fused import FusedUNet
 
                     m = FusedUNet(m.to(device=self.device))
             m = m.to(device=self.device)
             m = m.to(dtype=dtype) if dtype != torch.float32 else m
-            if torch.device(self.device).type == "cuda":
+            if on_gpu:
                 m = m.to(memory_format=torch.channels_last)
-                # `miopen_find=True` (run kwarg / attribute): let MIOpen search its solvers once per convolution
-                # shape -- worth it for long runs at one batch shape (resnet18 fp16, 1024 x 224^2: 43 -> 36 ms per
-                # pass on MI355X), costly when batch sizes vary (every new shape is searched again), so off by default
             m.eval()
             self._fast_model, self._fast_key = m, key
         return self._fast_model
 
     @contextlib.contextmanager
     def _miopen_scope(self):
-        """``miopen_find=True`` (run kwarg / attribute) lets MIOpen search its solvers once per convolution shape --
-        worth it for long runs at one batch shape (resnet18 fp16, 1024 x 224^2: 43 -> 36 ms per pass on MI355X), costly
-        when batch sizes vary.  The switch is process-global in torch, so it is set for the run and restored after."""
+        """Solver search of the library convolutions that remain on a graph (half-precision trunks; the 3-channel stems and
+        class heads of the fused segmentation graphs).  ``miopen_find=True`` (run kwarg) lets MIOpen search once per
+        convolution shape -- worth it for long runs at one batch shape, costly when batch sizes vary.  The switch is
+        PROCESS-GLOBAL in torch (``torch.backends.cudnn.benchmark``): it is set for the run and restored after, so engines
+        running concurrently in threads of one process share it.  A ``miopen_find`` passed to one ``run()`` does not persist
+        (``_update_run_params`` resets it)."""
         prev = torch.backends.cudnn.benchmark
         torch.backends.cudnn.benchmark = self._use_miopen_find()
         try:
@@ -334,10 +329,11 @@ class EngineABC:
             torch.backends.cudnn.benchmark = prev
 
     def _use_miopen_find(self) -> bool:
-        """An explicit ``miopen_find`` wins.  Otherwise: on when the inference copy is one of the fused float32 graphs -- they
-        leave only the 3-channel stem (and small class heads) on MIOpen, whose immediate mode picks a naive kernel for
-        float32 NHWC (HoVer-Net's stem at batch 32: 7.8 ms instead of 0.5 ms, ``profiles/r02t_*``), so one search per
-        shape is cheap and pays at once; off for graphs that run mostly on MIOpen (a search per convolution shape)."""
+        """An explicit ``miopen_find`` wins.  Otherwise on for the fused float32 segmentation graphs: they leave only the
+        3-channel stem (and small class heads) on MIOpen, whose immediate mode picks a naive kernel for float32 NHWC
+        (HoVer-Net's stem at batch 32: 7.8 ms instead of 0.5 ms, ``profiles/r02t_*``); the WSI loops pad their tail batch to
+        ``batch_size`` so one shape is searched per run.  Off for graphs that run mostly on the library (a search per
+        shape) and for the ResNet classifiers (no library convolution left in float32)."""
         explicit = getattr(self, "miopen_find", None)
         if explicit is not None:
             return bool(explicit)
@@ -345,11 +341,43 @@ class EngineABC:
         if fast is None:
             return False
         names = {type(m).__name__ for m in fast.modules()}
-        return bool(names & {"MfmaResNet", "FusedHoVerNet", "FusedUNet"})
+        return bool(names & {"FusedHoVerNet", "FusedUNet"})
 
     def invalidate_inference_cache(self) -> None:
         """Drop the derived (BN-folded / cast) inference copy; it is rebuilt on the next run."""
         self._fast_model, self._fast_key = None, None
+
+    def _device_preproc(self, hook, batch: torch.Tensor, dtype: torch.dtype):
+        """The hook's batched device form; when the inference copy's stem reads uint8 (``accepts_uint8``) and the hook ends in
+        ``ToTensor``, that step is deferred into the stem kernel (the batch stays uint8, wrapped in ``UnitUInt8``)."""
+        if getattr(self, "_defer_unit", False) and getattr(hook, "supports_deferred_unit_scale", False):
+            return hook.device_batch(batch, dtype, defer_unit_scale=True)
+        return hook.device_batch(batch, dtype)
+
+    def _set_defer_unit(self, model, dtype: torch.dtype) -> None:
+        self._defer_unit = bool(dtype == torch.float32 and torch.device(self.device).type == "cuda"
+                                and any(getattr(m, "accepts_uint8", False) for m in model.modules()))
+
+    def _forward_batch(self, model, infer_batch, batch):
+        from tiatoolbox_amd.models.dataset.classification import UnitUInt8
+
+        if isinstance(batch, UnitUInt8):  # ToTensor deferred: the stem kernel divides by 255 while it loads the bytes
+            with torch.inference_mode():
+                return model(batch.data.permute(0, 3, 1, 2)).float()
+        return infer_batch(model, batch, device=self.device)
+
+    @contextlib.contextmanager
+    def _deferred_norm_checks(self, hook):
+        """Data-dependent stain-normaliser errors (empty tissue mask, degenerate statistics) are flags in the per-patch
+        statistics; inside this scope they are collected on the device and raised ONCE when the run's loop ends, instead of
+        one device -> host synchronisation per batch."""
+        norm = getattr(hook, "normalizer", None) or getattr(hook, "__self__", None)
+        scope = getattr(norm, "deferred_checks", None)
+        if scope is None:
+            yield
+            return
+        with scope():
+            yield
 
     def _preprocess_batch(self, dataset: PatchDataset, lo: int, hi: int, dtype: torch.dtype) -> torch.Tensor:
         """Raw patches [lo,hi) -> model-ready NHWC tensor on ``self.device``."""
@@ -362,7 +390,7 @@ class EngineABC:
                 t = t.to(dev)
             device_batch = getattr(hook, "device_batch", None)
             if device_batch is not None:
-                return device_batch(t, dtype)
+                return self._device_preproc(hook, t, dtype)
             from tiatoolbox_amd.models.models_abc import ModelABC as _MA
 
             if hook is _MA.preproc or hook is PatchDataset.preproc:
@@ -395,7 +423,7 @@ class EngineABC:
                 t = torch.from_numpy(raw)
                 t = t.pin_memory().to(dev, non_blocking=True) if raw.nbytes > (1 << 20) else t.to(dev)
             if device_batch is not None:
-                return device_batch(t, dtype)
+                return self._device_preproc(hook, t, dtype)
             if identity:  # HoVer-Net / UNet scale inside forward(): the uint8 batch goes to infer_batch untouched
                 return t
             # bare `model.preproc_func = normalizer.transform`: the reference then feeds 0..255 floats
@@ -419,21 +447,22 @@ class EngineABC:
         dev = torch.device(self.device)
         if dev.type == "cuda" and isinstance(dataloader.inputs, np.ndarray) and dataloader.inputs.dtype == np.uint8:
             self._feed = _HostFeed(dataloader.inputs, dev)
+        self._set_defer_unit(model, dtype)
         try:
-            with self._miopen_scope():
+            with self._miopen_scope(), self._deferred_norm_checks(dataloader.preproc_func):
                 for s in range(lo, hi, self.batch_size):
                     e = min(s + self.batch_size, hi)
                     if self._feed is not None:  # batch k+1 crosses PCIe while batch k computes
                         self._feed.prefetch(s, e)
                         self._feed.prefetch(e, min(e + self.batch_size, hi))
                     batch = self._preprocess_batch(dataloader, s, e, dtype)
-                    outs.append(infer_batch(model, batch, device=self.device))
+                    outs.append(self._forward_batch(model, infer_batch, batch))
         finally:
             if self._feed is not None:
                 self._feed.close()
                 self._feed = None
         if not outs:  # empty shard: a one-patch probe supplies the row shapes
-            probe = infer_batch(model, self._preprocess_batch(dataloader, 0, 1, dtype), device=self.device)
+            probe = self._forward_batch(model, infer_batch, self._preprocess_batch(dataloader, 0, 1, dtype))
             outs = [tuple(p[:0] for p in probe) if isinstance(probe, tuple) else probe[:0]]
         multi_head = isinstance(outs[0], tuple)
         heads = list(zip(*outs)) if multi_head else [outs]
@@ -542,18 +571,19 @@ class EngineABC:
         rank, world_size = tdist.world() if self.distributed else (0, 1)
         lo, hi = tdist.shard_bounds(n, rank, world_size)
         outs = []
-        with self._miopen_scope():
+        self._set_defer_unit(model, dtype)
+        with self._miopen_scope(), self._deferred_norm_checks(hook):
             for s in range(lo, hi, self.batch_size):
                 raw = reader.read_bounds_batch(coords[s:min(s + self.batch_size, hi)])
                 if device_batch is not None:
-                    batch = device_batch(raw, dtype)
+                    batch = self._device_preproc(hook, raw, dtype)
                 else:  # arbitrary user hook: per patch on the host, as Dataset.__getitem__ does in the reference
                     batch = torch.stack([torch.as_tensor(np.asarray(hook(p))) for p in raw.cpu().numpy()]).to(dev)
-                outs.append(infer_batch(model, batch, device=self.device))
+                outs.append(self._forward_batch(model, infer_batch, batch))
         if not outs:
             probe = reader.read_bounds_batch(coords[:1])
-            probe = device_batch(probe, dtype) if device_batch is not None else probe
-            outs = [infer_batch(model, probe, device=self.device)[:0]]
+            probe = self._device_preproc(hook, probe, dtype) if device_batch is not None else probe
+            outs = [self._forward_batch(model, infer_batch, probe)[:0]]
         local = torch.cat([o if isinstance(o, torch.Tensor) else torch.from_numpy(np.asarray(o)) for o in outs])
         if world_size > 1:
             local = tdist.all_gather_rows(local.to(dev), n)

@@ -195,8 +195,9 @@ def augment(img: torch.Tensor, stats: torch.Tensor, alpha_beta: torch.Tensor, y_
 
 
 def raise_on_flags(stats: torch.Tensor) -> None:
-    """Data-dependent errors detected on the device, raised like the reference does."""
-    flags = stats[:, _lib.ST_FLAGS].to(torch.int64)
+    """Data-dependent errors detected on the device, raised like the reference does.  ``stats``: the ``[N, 64]`` statistics or
+    just their flag column ``[N]``."""
+    flags = (stats[:, _lib.ST_FLAGS] if stats.dim() == 2 else stats).to(torch.int64)
     empty = torch.nonzero(flags & _lib.FLAG_EMPTY_MASK).flatten()
     if empty.numel():
         msg = "Empty tissue mask computed."

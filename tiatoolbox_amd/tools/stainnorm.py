@@ -8,6 +8,8 @@ one ``tia_stain_stats_u8`` launch (a workgroup per patch) + one streaming
 
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 import torch
 
@@ -49,6 +51,21 @@ class StainNormalizer:
         self.precision = "f64"
         self._target_batch = None
         self._target_conc = None
+        self._deferred: list | None = None
+
+    @contextlib.contextmanager
+    def deferred_checks(self):
+        """Inside this scope ``transform`` does not synchronise to look at the per-patch error flags (empty tissue mask,
+        degenerate statistics): they stay on the device and are raised ONCE, with the indices of the offending patches
+        counted over the whole scope, when it ends normally (the engines wrap a run's loop in it)."""
+        outer, self._deferred = self._deferred, []
+        try:
+            yield
+            pending = self._deferred
+        finally:
+            self._deferred = outer
+        if pending:
+            dev.raise_on_flags(torch.cat(pending))
 
     # ------------------------------------------------------------------------------ helpers
     def _source_stats(self, batch: torch.Tensor, *, with_target: bool) -> torch.Tensor:
@@ -110,7 +127,10 @@ class StainNormalizer:
         stats = self._source_stats(batch, with_target=True)
         math = _lib.MATH_F64 if self.precision == "f64" else _lib.MATH_F32
         res = dev.stain_apply(batch, stats, self.stain_matrix_target, out_kind=_OUT_KINDS[out], math=math)
-        dev.raise_on_flags(stats)
+        if self._deferred is not None:
+            self._deferred.append(stats[:, _lib.ST_FLAGS].clone())
+        else:
+            dev.raise_on_flags(stats)
         res = _tensors.from_device(res, kind)
         return (res, stats) if return_stats else res
 
