@@ -354,6 +354,17 @@ int tia_lab_convert_u8(const uint8_t* d_src, int64_t npix, const tia_lab_tables*
                        uint8_t* d_dst, void* stream);
 
 
+/* out[i, j] = lut[i, img[i, j]]: one 256-byte table per image -- the intensity map of contrast_enhancer
+ * (utils/misc.py:436-444: rescale_intensity over the [p2, p98] window, truncated to uint8) applied to a batch.
+ *   d_img, d_out [n, len] u8   d_lut [n, 256] u8   n <= 65535 */
+int tia_lut_apply_u8(const uint8_t* d_img, int64_t n, int64_t len, const uint8_t* d_lut, uint8_t* d_out, void* stream);
+
+/* Box down-sampling of an HWC uint8 image by an integer factor: integer box sum * (1.0f / area), rounded half to even --
+ * cv2.INTER_AREA at an integer scale, which is what the reference's slide thumbnail goes through
+ * (utils/transforms.py imresize; wsicore/wsireader.py:1735-1786 tissue_mask -> slide_thumbnail).
+ *   d_src [h,w,c]   d_out [h/factor, w/factor, c] */
+int tia_box_downsample_u8(const uint8_t* d_src, int64_t h, int64_t w, int64_t c, int64_t factor, uint8_t* d_out, void* stream);
+
 /* =======================================================================================
  * CNN epilogues (NHWC activations).  The convolutions themselves run in MIOpen; with BatchNorm
  * folded into the weights every conv is followed by bias (+ residual) + ReLU, which PyTorch

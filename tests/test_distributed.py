@@ -202,7 +202,8 @@ def _band_worker(rank: int, world: int, port: int, out_dir: str) -> None:
         row_ys = np.arange(0, int(np.ceil(h / stride) * stride), stride)
         plan = band_plan(row_ys, oh, h, rank, world)
         lo, hi = plan["own"]
-        assert plan["rows"] == list(range(max(lo - 1, 0), hi))  # own rows plus one leading row
+        # own rows plus one leading row; a rank without rows of its own infers nothing at all
+        assert plan["rows"] == (list(range(max(lo - 1, 0), hi)) if lo < hi else [])
         truth, truth_p = _band_truth(h, w), _band_truth(h, w, 3)
         y_lo, y_hi = plan["y_lo"], plan["y_hi"]
         got = exchange_bands(truth[y_lo:y_hi].clone(), plan, h)
@@ -229,6 +230,8 @@ def test_semantic_band_exchange_world2(tmp_path):
             assert covered[0][0] == 0 and covered[-1][1] == h
             assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
             assert sorted(r for p in plans for r in range(*p["own"])) == list(range(len(row_ys)))
+            for p in plans:  # surplus ranks (more ranks than patch rows) get no inference work
+                assert (p["rows"] == []) == (p["own"][0] >= p["own"][1])
     port = 29850 + (os.getpid() % 100)
     mp.spawn(_band_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert torch.equal(torch.load(tmp_path / "bands0.pt"), torch.load(tmp_path / "bands1.pt"))

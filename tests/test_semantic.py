@@ -147,8 +147,16 @@ def test_semantic_segmentor_wsi_mode_matches_oracle_composition():
     slide[64:480, 96:600] = synth.g_he(1, 416, 504, seed=3)[0]
     eng = SemanticSegmentor(model, batch_size=8, device="cuda")
     reader = ArrayWSIReader(slide, mpp=0.25, power=40)
-    res = eng.run([reader], patch_mode=False, ioconfig=cfg, return_probabilities=True)
-    pred, probs = res["predictions"][0], res["probabilities"][0]
+    import tempfile
+    from pathlib import Path
+
+    with tempfile.TemporaryDirectory() as tmp:
+        with pytest.raises(OSError, match="no save directory"):  # engine_abc.py:1866-1871
+            eng.run([reader], patch_mode=False, ioconfig=cfg)
+        paths = eng.run([reader], patch_mode=False, ioconfig=cfg, return_probabilities=True, save_dir=Path(tmp) / "out")
+        assert list(paths) == [0] and paths[0].name == "0.npz"
+        with np.load(paths[0]) as res:
+            pred, probs = res["predictions"], res["probabilities"]
     assert pred.shape == (600, 700) and pred.dtype == np.uint8
     # recompute from the same patches with the oracle merge
     mask_reader = reader.tissue_mask(resolution=1.25, units="power")
@@ -205,6 +213,15 @@ def test_hip_gather_patches_matches_padded_slicing():
     thumb = ArrayWSIReader(big, power=40.0).slide_thumbnail(5.0, "power").cpu().numpy()
     exp = np.rint(big.reshape(8, 8, 12, 8, 3).astype(np.float64).mean(axis=(1, 3))).astype(np.uint8)
     assert np.array_equal(thumb, exp)
+    # a factor that is not a power of two (40x -> 8x = 5; trailing rows / columns that do not fill a box are dropped): OpenCV's
+    # ResizeAreaFast arithmetic = integer box sum * float32(1 / 25), cvRound
+    odd = rng.integers(0, 256, (67, 93, 3), dtype=np.uint8)
+    thumb5 = ArrayWSIReader(odd, power=40.0).slide_thumbnail(8.0, "power").cpu().numpy()
+    sums = odd[:65, :90].reshape(13, 5, 18, 5, 3).astype(np.int64).sum(axis=(1, 3))
+    exp5 = np.rint(sums.astype(np.float32) * np.float32(1.0 / 25.0)).astype(np.uint8)
+    assert thumb5.shape == (13, 18, 3) and np.array_equal(thumb5, exp5)
+    grey = ArrayWSIReader(odd[..., 0].copy(), mpp=None, power=40.0, mode="bool").slide_thumbnail(8.0, "power").cpu().numpy()
+    assert np.array_equal(grey, exp5[..., 0])
     with pytest.raises(ValueError, match="integer down-sampling"):
         ArrayWSIReader(big, power=40.0).slide_thumbnail(3.0, "power")
 

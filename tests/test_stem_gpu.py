@@ -6,6 +6,8 @@ Reference path: ``ToTensor`` (uint8 -> float32 / 255, ``models/dataset/classific
 
 from __future__ import annotations
 
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -42,7 +44,7 @@ def test_stem_kernel_matches_unfused_torch_ops(shape):
     g = torch.Generator().manual_seed(n + h + w)
     x = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
     ref = _reference(conv, x.float().div(255))
-    conv_d = conv.cuda()
+    conv_d = copy.deepcopy(conv).cuda()
     wp = pack_stem_weights(conv_d)
     assert wp.shape == (148, 64) and float(wp[147].abs().max()) == 0.0
     got = hip_stem_conv_pool(x.cuda(), wp, conv_d.bias.detach())
@@ -68,7 +70,7 @@ def test_stem_kernel_unaligned_view_and_all_byte_values():
     g = torch.Generator().manual_seed(11)
     x = torch.randint(0, 256, (4, 37, 53, 3), generator=g, dtype=torch.uint8)
     x[0].view(-1)[:256] = torch.arange(256, dtype=torch.uint8)
-    conv_d = conv.cuda()
+    conv_d = copy.deepcopy(conv).cuda()
     wp = pack_stem_weights(conv_d)
     xd = x.cuda()
     for first in (1, 2, 3):
@@ -84,9 +86,10 @@ def test_stem_kernel_unaligned_view_and_all_byte_values():
         ident.weight.zero_()
         ident.bias.zero_()
         ident.weight[0, 0, 3, 3] = 1.0  # output channel 0 = red value of the centre tap
-    wpi = pack_stem_weights(ident.cuda())
-    got = hip_stem_conv_pool(ramp.cuda(), wpi, ident.bias.detach().cuda())
-    ref = _reference(ident.cpu(), ramp.float().div(255))
+    ident_d = copy.deepcopy(ident).cuda()
+    wpi = pack_stem_weights(ident_d)
+    got = hip_stem_conv_pool(ramp.cuda(), wpi, ident_d.bias.detach())
+    ref = _reference(ident, ramp.float().div(255))
     assert torch.equal(got.cpu(), ref)
 
 

@@ -172,7 +172,20 @@ def test_wsi_mode_end_to_end():
     cfg = get_pretrained_model("hovernet_fast-pannuke")[1]
     eng = MultiTaskSegmentor(_stub_hovernet(), batch_size=4, device="cuda")
     reader = ArrayWSIReader(slide)
-    out = eng.run([reader], patch_mode=False, ioconfig=cfg, return_probabilities=True, return_predictions=(True,))[0]
+    import tempfile
+    from pathlib import Path
+
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = eng.run([reader], patch_mode=False, ioconfig=cfg, return_probabilities=True, return_predictions=(True,),
+                        save_dir=Path(tmp) / "out")
+        with np.load(paths[0], allow_pickle=True) as saved:
+            saved = {k: saved[k] for k in saved.files}
+    out = eng.process_wsi(reader, return_predictions=(True,))  # the in-memory form of the same slide
+    assert set(saved) == ({k for k in out if k != "probabilities"} | {f"probabilities/{j}" for j in range(3)})
+    assert np.array_equal(saved["predictions"], out["predictions"])
+    assert np.array_equal(np.array(list(saved["box"])).reshape(-1, 4), np.array(list(out["box"])).reshape(-1, 4))
+    for j in range(3):
+        assert np.array_equal(saved[f"probabilities/{j}"], out["probabilities"][j])
     assert {"box", "centroid", "contours", "prob", "type", "predictions", "probabilities", "coordinates"} <= set(out)
     assert out["predictions"].shape == (900, 1300) and len(out["box"]) > 30
     npm, hv, tp = out["probabilities"]
@@ -201,7 +214,7 @@ def test_wsi_mode_end_to_end():
     assert [int(t) for t in out["type"]] == [int(t) for t in exp["info_dict"]["type"]]
     assert np.array_equal(out["predictions"], exp["predictions"])
     with pytest.raises(ValueError, match="return_labels"):
-        eng.run([reader], patch_mode=False, ioconfig=cfg, return_labels=True)
+        eng.run([reader], patch_mode=False, ioconfig=cfg, return_labels=True, save_dir="unused")
 
 
 def test_tile_sets_under_a_tissue_mask_match_reference(gold):

@@ -68,6 +68,8 @@ _SIGNATURES = {
     "tia_rgb2gray_u8": ([_P, _I64, _P, _P], C.c_int),
     "tia_hist256_u8": ([_P, _I64, _P, _P], C.c_int),
     "tia_threshold_lt_u8": ([_P, _I64, _I32, _I32, _P, _P], C.c_int),
+    "tia_lut_apply_u8": ([_P, _I64, _I64, _P, _P, _P], C.c_int),
+    "tia_box_downsample_u8": ([_P, _I64, _I64, _I64, _I64, _P, _P], C.c_int),
     "tia_ccl_label_i32": ([_P, _I64, _I64, _I64, _I32, _P, _P, _P, _P], C.c_int),
     "tia_label_area_filter_i32": ([_P, _I64, _I64, _I64, _I32, _P, _P], C.c_int),
     "tia_binary_morph_u8": ([_P, _I64, _I64, _I64, _P, _I32, _I32, _P, _P], C.c_int),

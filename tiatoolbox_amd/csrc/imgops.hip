@@ -442,6 +442,57 @@ static bool bad3(int64_t n, int64_t h, int64_t w) {
     return n <= 0 || h <= 0 || w <= 0 || n > 65535 || h * w > 0x7fffffffLL;
 }
 
+// ---- per-image byte look-up table (contrast_enhancer's intensity map, utils/misc.py:436-444) ------------------------
+// out[i, j] = lut[i, img[i, j]]: the image's 256-byte table sits in LDS, bytes go through 16 at a time.
+__global__ __launch_bounds__(BT) void lut_apply_kernel(const uint8_t* __restrict__ img, long len, const uint8_t* __restrict__ lut,
+                                                        uint8_t* __restrict__ out) {
+    __shared__ uint8_t t[256];
+    const long base = (long)blockIdx.y * len;
+    t[threadIdx.x] = lut[(long)blockIdx.y * 256 + threadIdx.x];
+    __syncthreads();
+    const uint8_t* src = img + base;
+    uint8_t* dst = out + base;
+    const long stride = (long)gridDim.x * BT;
+    long done = 0;
+    if ((((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0)) {
+        const long nv = len >> 4;
+        const uint4* q = reinterpret_cast<const uint4*>(src);
+        uint4* o = reinterpret_cast<uint4*>(dst);
+        for (long g = (long)blockIdx.x * BT + threadIdx.x; g < nv; g += stride) {
+            const uint4 v = q[g];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r[k] = (uint32_t)t[w[k] & 255u] | ((uint32_t)t[(w[k] >> 8) & 255u] << 8) | ((uint32_t)t[(w[k] >> 16) & 255u] << 16) |
+                       ((uint32_t)t[w[k] >> 24] << 24);
+            o[g] = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        done = nv << 4;
+    }
+    for (long i = done + (long)blockIdx.x * BT + threadIdx.x; i < len; i += stride) dst[i] = t[src[i]];
+}
+
+// ---- box down-sampling by an integer factor (slide thumbnail: cv2.INTER_AREA at an integer scale) -----------------------
+// OpenCV's ResizeAreaFast for uint8: integer sum of the factor x factor box, times the float scale 1 / area, cvRound
+// (round half to even) -- `saturate_cast<uchar>(sum * scale)` (modules/imgproc/src/resize.cpp).  One thread per output value.
+__global__ __launch_bounds__(BT) void box_downsample_kernel(const uint8_t* __restrict__ src, int w, int c, int factor, int th, int tw,
+                                                             uint8_t* __restrict__ out) {
+    const long total = (long)th * tw * c;
+    const float scale = 1.0f / (float)(factor * factor);
+    for (long i = (long)blockIdx.x * BT + threadIdx.x; i < total; i += (long)gridDim.x * BT) {
+        const int ch = (int)(i % c);
+        const long p = i / c;
+        const int ox = (int)(p % tw), oy = (int)(p / tw);
+        const uint8_t* s = src + ((long)oy * factor * w + (long)ox * factor) * c + ch;
+        unsigned sum = 0;
+        for (int dy = 0; dy < factor; ++dy)
+            for (int dx = 0; dx < factor; ++dx) sum += s[((long)dy * w + dx) * c];
+        float v = rintf((float)sum * scale);
+        out[i] = (uint8_t)(v > 255.0f ? 255.0f : v);
+    }
+}
+
 extern "C" int tia_rgb2gray_u8(const uint8_t* d_img, int64_t npix, uint8_t* d_gray, void* stream) {
     if (!d_img || !d_gray || npix <= 0) return TIA_EINVAL;
     hipLaunchKernelGGL(rgb2gray_kernel, dim3(nblocks(npix >> 2 ? npix >> 2 : 1)), dim3(BT), 0, (hipStream_t)stream, d_img,
@@ -514,5 +565,23 @@ extern "C" int tia_fill_holes_u8(const uint8_t* d_mask, int64_t n, int64_t h, in
     hipLaunchKernelGGL(border_mark_kernel, gb, dim3(BT), 0, st, labels, (int)h, (int)w, aux);
     dim3 grid(nblocks(hw, BT, 4096), (unsigned)n);
     hipLaunchKernelGGL(fill_apply_kernel, grid, dim3(BT), 0, st, d_mask, labels, aux, hw, d_out);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_lut_apply_u8(const uint8_t* d_img, int64_t n, int64_t len, const uint8_t* d_lut, uint8_t* d_out, void* stream) {
+    if (!d_img || !d_lut || !d_out || n <= 0 || len <= 0) return TIA_EINVAL;
+    if (n > 65535) return TIA_ESIZE;
+    dim3 grid(nblocks((len + 15) / 16, BT, 2048), (unsigned)n);
+    hipLaunchKernelGGL(lut_apply_kernel, grid, dim3(BT), 0, (hipStream_t)stream, d_img, (long)len, d_lut, d_out);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_box_downsample_u8(const uint8_t* d_src, int64_t h, int64_t w, int64_t c, int64_t factor, uint8_t* d_out,
+                                      void* stream) {
+    if (!d_src || !d_out || h <= 0 || w <= 0 || c <= 0 || factor <= 0) return TIA_EINVAL;
+    if (factor > 4096 || w > 0x7fffffffL || h / factor <= 0 || w / factor <= 0) return TIA_ESIZE;
+    const long th = h / factor, tw = w / factor;
+    hipLaunchKernelGGL(box_downsample_kernel, dim3(nblocks(th * tw * c)), dim3(BT), 0, (hipStream_t)stream, d_src, (int)w, (int)c,
+                       (int)factor, (int)th, (int)tw, d_out);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

@@ -97,6 +97,57 @@ def _weights_version(model: torch.nn.Module) -> tuple:
     return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))  # noqa: SLF001
 
 
+def prepare_engines_save_dir(save_dir, *, patch_mode: bool, overwrite: bool = False) -> Path | None:
+    """Create or validate the output directory exactly like the reference (``engine_abc.py:1832-1885``): WSI mode without
+    ``save_dir`` is an ``OSError``; an existing directory is removed first when ``overwrite`` and is a ``FileExistsError``
+    otherwise (``mkdir(parents=True)``)."""
+    import shutil
+
+    if patch_mode and save_dir is None:
+        return None
+    if save_dir is None:
+        msg = "Input WSIs detected but no save directory provided. Please provide a 'save_dir'."
+        raise OSError(msg)
+    save_dir = Path(save_dir)
+    if save_dir.exists() and overwrite:
+        shutil.rmtree(save_dir)
+    save_dir.mkdir(parents=True)
+    return save_dir
+
+
+def iter_row_outputs(infer, row_sels: list[np.ndarray], batch_size: int):
+    """Inference over the patch rows of a slide in batches of ONE size: batches run across row boundaries and only the
+    very last one is padded (its last patch repeated), so the convolution library sees a single shape per run whatever the
+    tissue mask leaves of each row (a per-row tail batch would trigger a solver search per new size).
+
+    ``infer(idx)`` maps an index array of ``batch_size`` patches to a tensor ``[batch_size, ...]`` or a tuple of such
+    tensors (one per head).  Yields ``(k, outputs)`` per row ``k`` in order -- ``outputs`` = the row's tensors (tuple if
+    ``infer`` returns tuples), ``None`` for a row without patches."""
+    flat = [np.asarray(s, dtype=np.int64) for s in row_sels if len(s)]
+    flat = np.concatenate(flat) if flat else np.zeros(0, np.int64)
+    pos, have, buf, is_tuple = 0, 0, None, False
+    for k, sel in enumerate(row_sels):
+        need = len(sel)
+        if need == 0:
+            yield k, None
+            continue
+        while have < need:
+            idx = flat[pos:pos + batch_size]
+            real = len(idx)
+            if real < batch_size:
+                idx = np.concatenate([idx, np.repeat(idx[-1:], batch_size - real)])
+            out = infer(idx)
+            is_tuple = isinstance(out, tuple)
+            out = tuple(o[:real] for o in (out if is_tuple else (out,)))
+            buf = out if buf is None else tuple(torch.cat([b, o]) for b, o in zip(buf, out))
+            have += real
+            pos += real
+        row = tuple(b[:need] for b in buf)
+        buf = tuple(b[need:] for b in buf) if have > need else None
+        have -= need
+        yield k, (row if is_tuple else row[0])
+
+
 class EngineABC:
     """Abstract engine: model + ioconfig + ``run()`` (ref. :136-1885)."""
 
@@ -532,9 +583,14 @@ class EngineABC:
         res = ioconfig.input_resolutions[0]
         units, value = res["units"], float(res["resolution"])
         native = {"mpp": reader.mpp, "power": reader.power, "baseline": 1.0}.get(units)
-        if native is None or abs(float(native) - value) > 1e-6 * max(1.0, abs(value)):  # noqa: PLR2004
+        if native is not None and np.ndim(native) > 0:  # (mpp_x, mpp_y): both components must be the requested value
+            comps = [float(v) for v in np.asarray(native, dtype=np.float64).ravel()]
+            native = comps[0] if all(abs(c - comps[0]) <= 1e-6 * max(1.0, abs(comps[0])) for c in comps) else tuple(comps)
+        if native is None or isinstance(native, tuple) or abs(float(native) - value) > 1e-6 * max(1.0, abs(value)):  # noqa: PLR2004
             msg = (f"the model reads at {value} {units} but the in-memory slide is at {native} {units}: ArrayWSIReader "
-                   "has no resolution pyramid; resample the slide first or pass a matching `input_resolutions`.")
+                   "has no resolution pyramid; resample the slide first, wrap the array as "
+                   f"`ArrayWSIReader(array, {units}={value})` if that is its true resolution, or pass a matching "
+                   "`input_resolutions`.")
             raise ValueError(msg)
 
     def get_wsi_coordinates(self, reader, mask_reader, *, min_mask_ratio: float = 0.0) -> np.ndarray:
@@ -593,8 +649,7 @@ class EngineABC:
         """Per slide: tissue mask -> patch grid -> ``infer_wsi`` -> ``post_process_patches`` -> ``<stem>.npz`` under
         ``save_dir`` (ref. ``_run_wsi_mode`` :1540-1682; arrays ``predictions``, ``coordinates`` and, on request,
         ``probabilities`` -- the members of the reference's zarr store).  Returns ``{image key: Path}``."""
-        save_dir = Path(save_dir)
-        save_dir.mkdir(parents=True, exist_ok=True)
+        save_dir = prepare_engines_save_dir(save_dir, patch_mode=False, overwrite=bool(kwargs.pop("overwrite", False)))
         out: dict = {}
         images = self.images if isinstance(self.images, (list, tuple)) else [self.images]
         for num, image in enumerate(images):
@@ -626,6 +681,6 @@ class EngineABC:
             output_type=output_type, **kwargs)
         if patch_mode:
             return self._run_patch_mode(output_type=self.output_type, save_dir=save_dir, **kwargs)
-        return self._run_wsi_mode(save_dir=save_dir, **kwargs)
+        return self._run_wsi_mode(save_dir=save_dir, overwrite=overwrite, **kwargs)
 
     predict = run  # tiatoolbox 1.x name, still used by the reference's example notebooks

@@ -10,6 +10,8 @@ Patch rows are sharded over ranks when ``torch.distributed`` is initialised.
 
 from __future__ import annotations
 
+from pathlib import Path
+
 import numpy as np
 import torch
 
@@ -82,7 +84,8 @@ def band_plan(row_ys: np.ndarray, oh: int, height: int, rank: int, world: int) -
         return lo, hi, y_lo, y_hi
 
     lo, hi, y_lo, y_hi = limits(rank)
-    return {"rows": list(range(max(lo - 1, 0), hi)), "own": (lo, hi), "y_lo": y_lo, "y_hi": y_hi,
+    # a rank without rows of its own (more ranks than patch rows) infers nothing: no leading row either
+    return {"rows": list(range(max(lo - 1, 0), hi)) if lo < hi else [], "own": (lo, hi), "y_lo": y_lo, "y_hi": y_hi,
             "bands": [limits(r)[2:] for r in range(world)], "oh": oh}
 
 
@@ -157,16 +160,19 @@ class SemanticSegmentor(PatchPredictor):
         n_ch = None
         prev = None  # (row, cnt, ys)
 
+        from tiatoolbox_amd.models.engine.engine_abc import iter_row_outputs
+
+        rows = list(plan["rows"])
+        row_sels = [np.flatnonzero((out_b[:, 1] == int(row_ys[ri])) & keep) for ri in rows]
+
+        def infer(idx):
+            return infer_batch(model, reader.read_bounds_batch(in_b[idx]), device=self.device)
+
         with self._miopen_scope():
-            for ri in plan["rows"]:
+            for k, blocks in iter_row_outputs(infer, row_sels, self.batch_size):
+                ri, sel = rows[k], row_sels[k]
                 ys = int(row_ys[ri])
-                sel = np.flatnonzero((out_b[:, 1] == ys) & keep)
-                if len(sel):
-                    outs = []
-                    for s in range(0, len(sel), self.batch_size):
-                        idx = sel[s:s + self.batch_size]
-                        outs.append(infer_batch(model, reader.read_bounds_batch(in_b[idx]), device=self.device))
-                    blocks = torch.cat(outs)
+                if blocks is not None:
                     n_ch = blocks.shape[-1]
                     row, cnt = _row_merge(blocks, out_b[sel, 0], w)
                 else:
@@ -197,45 +203,40 @@ class SemanticSegmentor(PatchPredictor):
 
     def run(self, images, *, masks=None, input_resolutions=None, patch_input_shape=None, ioconfig=None,
             patch_mode: bool = True, save_dir=None, overwrite: bool = False, output_type: str = "dict", **kwargs):
-        """Patch mode: as PatchPredictor.  WSI mode: ``images`` is a list of ``ArrayWSIReader`` / HxWx3 arrays;
-        returns ``{"predictions": [HxW uint8 ...], ...}`` (or ``.npy`` files under ``save_dir``)."""
+        """Patch mode: as PatchPredictor.  WSI mode (ref. ``engine_abc.py:1684-1829`` + ``semantic_segmentor.py:393-631``):
+        ``images`` is a list of ``ArrayWSIReader`` / HxWx3 arrays / ``.npy`` paths and ``save_dir`` is REQUIRED
+        (``OSError`` otherwise, created with the reference's ``overwrite`` rule); per slide one ``<stem>.npz`` with
+        ``predictions`` (HxW uint8), ``coordinates`` and, with ``return_probabilities=True``, ``probabilities``
+        (HxWxC float32) -- the members of the reference's zarr store; returns ``{image key: Path}``.
+        :meth:`infer_wsi` is the in-memory form (device tensors, nothing written)."""
         if patch_mode:
             return super().run(images, masks=masks, input_resolutions=input_resolutions,
                                patch_input_shape=patch_input_shape, ioconfig=ioconfig, patch_mode=True,
                                save_dir=save_dir, overwrite=overwrite, output_type=output_type, **kwargs)
-        for key, val in kwargs.items():
-            setattr(self, key, val)
-        if not isinstance(images, (list, tuple)):
-            msg = "Input must be a list of file paths or a numpy array."
-            raise TypeError(msg)
-        self._validate_input_numbers(images=images, masks=masks)
-        self._ioconfig = self._load_ioconfig(ioconfig=ioconfig)
-        self.model = self.model.to(device=self.device)
-        results: dict = {"predictions": [], "coordinates": []}
-        for i, image in enumerate(images):
-            reader = image if isinstance(image, ArrayWSIReader) else ArrayWSIReader(image)
+        self._update_run_params(images=images, masks=masks, input_resolutions=input_resolutions,
+                                patch_input_shape=patch_input_shape, save_dir=save_dir, ioconfig=ioconfig,
+                                output_type=output_type, overwrite=overwrite, patch_mode=False, **kwargs)
+        from tiatoolbox_amd.models.engine.engine_abc import prepare_engines_save_dir
+
+        save_dir = prepare_engines_save_dir(save_dir, patch_mode=False, overwrite=overwrite)
+        paths: dict = {}
+        write = tdist.world()[0] == 0 or not self.distributed
+        for i, image in enumerate(self.images):
+            reader = self._open_slide(image)
             mask_reader = None
-            if masks is not None:
-                m = masks[i]
-                mask_reader = m if isinstance(m, ArrayWSIReader) else ArrayWSIReader(m, mode="bool")
+            if self.masks is not None:
+                mask_reader = self._open_slide(self.masks[i], as_mask=True)
             elif self.auto_get_mask:
                 mask_reader = reader.tissue_mask(resolution=1.25, units="power")
             out = self.infer_wsi(reader, mask_reader, return_probabilities=bool(self.return_probabilities))
-            results["predictions"].append(out["predictions"].cpu().numpy())
-            results["coordinates"].append(out["coordinates"])
+            arrays = {"predictions": out["predictions"].cpu().numpy(), "coordinates": out["coordinates"]}
             if "probabilities" in out:
-                results.setdefault("probabilities", []).append(out["probabilities"].cpu().numpy())
-        if save_dir is not None:
-            from pathlib import Path
-
-            save_dir = Path(save_dir)
-            save_dir.mkdir(parents=True, exist_ok=overwrite or True)
-            paths = {}
-            for i, p in enumerate(results["predictions"]):
-                path = save_dir / f"{i}.predictions.npy"
-                np.save(path, p)
-                paths[i] = path
-            return paths
-        return results
+                arrays["probabilities"] = out["probabilities"].cpu().numpy()
+            key = image if isinstance(image, (str, Path)) else i
+            stem = Path(image).stem if isinstance(image, (str, Path)) else str(i)
+            paths[key] = save_dir / f"{stem}.npz"
+            if write:
+                np.savez(paths[key], **arrays)
+        return paths
 
     predict = run

@@ -78,7 +78,16 @@ def contrast_enhancer(img: np.ndarray, low_p: int = 2, high_p: int = 98) -> np.n
     x = torch.minimum(torch.maximum(v, plow), phigh)
     lut = torch.where(phigh > plow, (x - plow) / (phigh - plow) * 255.0 + 0.0, v).to(torch.uint8)
     n = batch.shape[0]
-    out = torch.gather(lut, 1, batch.reshape(n, -1).long()).reshape(batch.shape)
+    batch = batch.contiguous()
+    out = torch.empty_like(batch)
+    lut = lut.contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(batch.device):
+        for s in range(0, n, 65535):  # one 256-byte table per image, applied by tia_lut_apply_u8 (no widened copy)
+            m = min(65535, n - s)
+            rc = lib.tia_lut_apply_u8(batch[s:s + m].data_ptr(), m, batch[0].numel(), lut[s:s + m].data_ptr(),
+                                      out[s:s + m].data_ptr(), _lib.current_stream())
+            _lib.check(rc, "tia_lut_apply_u8")
     return _tensors.from_device(out, kind)
 
 

@@ -97,8 +97,19 @@ class ArrayWSIReader:
             raise ValueError(msg)
         h, w = self._dev.shape[:2]
         th, tw = h // factor, w // factor
-        x = self._dev[:th * factor, :tw * factor].reshape(th, factor, tw, factor, -1).to(torch.float32)
-        return torch.round(x.mean(dim=(1, 3))).to(torch.uint8)
+        if th == 0 or tw == 0:
+            msg = f"the slide ({h} x {w}) is smaller than one thumbnail pixel at factor {factor}."
+            raise ValueError(msg)
+        from tiatoolbox_amd import _lib
+
+        src = self._dev if self._dev.dim() == 3 else self._dev[..., None]  # noqa: PLR2004
+        src = (src.to(torch.uint8) if src.dtype != torch.uint8 else src).contiguous()
+        c = src.shape[-1]
+        out = torch.empty((th, tw, c), dtype=torch.uint8, device=src.device)
+        with torch.cuda.device(src.device):  # integer box sums on the device: no float32 copy of the slide
+            rc = _lib.load().tia_box_downsample_u8(src.data_ptr(), h, w, c, factor, out.data_ptr(), _lib.current_stream())
+        _lib.check(rc, "tia_box_downsample_u8")
+        return out if self._dev.dim() == 3 else out[..., 0]  # noqa: PLR2004
 
     def tissue_mask(self, method: str = "otsu", resolution: float = 1.25, units: str = "power", **masker_kwargs):
         """Tissue mask reader from the thumbnail (ref. ``wsireader.py:1735-1786``)."""
