@@ -76,17 +76,29 @@ struct Smem {
     unsigned wn[2];
     int wok;
     unsigned wcnt[NW];           // entries in each wave's private segment of the sweep list
+#if TIA_STATS_TIMING
     long long tm[16];   // per-phase cycle accumulators (thread 0)
     long long tlast;
+#endif
 };
 
-// phase timing: thread 0 adds the shader-clock cycles since the previous stamp to slot `i`
+// Phase timing (developer builds only: -DTIA_STATS_TIMING=1, see build.build(defines=...)): thread 0 adds the shader-clock
+// cycles since the previous stamp to slot `i` and the totals land in the statistics record (TIA_ST_CYCLES).  The product
+// library is built without it: no clock reads, no extra live state in the kernel.
+#ifndef TIA_STATS_TIMING
+#define TIA_STATS_TIMING 0
+#endif
 __device__ __forceinline__ void stamp(Smem& s, int i) {
+#if TIA_STATS_TIMING
     if (threadIdx.x == 0) {
         const long long now = clock64();
         s.tm[i] += now - s.tlast;
         s.tlast = now;
     }
+#else
+    (void)s;
+    (void)i;
+#endif
 }
 enum { TM_P1 = 0, TM_LUT, TM_P2, TM_EIG, TM_SEL_HIST, TM_SEL_FIND, TM_SEL_COLLECT, TM_SEL_SORT, TM_PHI_TOTAL,
        TM_CONC_TOTAL, TM_TOTAL };
@@ -1033,11 +1045,13 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
     for (int i = tid; i < 256 * ODR; i += NT) s.od[i] = tab->od_lut[i / ODR];
     const int odl = tid & (ODR - 1);
 #define OD(v) s.od[(v) * ODR + odl]
+#if TIA_STATS_TIMING
     if (tid == 0) {
         for (int i = 0; i < 16; ++i) s.tm[i] = 0;
         s.tlast = clock64();
     }
     const long long t_begin = clock64();
+#endif
 
     // ---- P1: per-channel byte histograms (per-wave private copies in the bins area) ------------
     // (Two copies per wave -- even / odd lanes -- were measured: no change, 79.7 k cycles either way; the pass
@@ -1439,10 +1453,12 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                     return true;
                 },
                 s, kp, nn, lo0, hi0, lo0, hi0, true, bincache, vp, vn);
+#if TIA_STATS_TIMING
         if (tid == 0) {
             s.tm[TM_PHI_TOTAL] = clock64() - t_begin;
             s.tm[15] = s.st.level[0] * 1000000 + s.st.level[1] * 100000 + (long long)s.st.cnt[0] + (long long)s.st.cnt[1] * 0;
         }
+#endif
         if (tid == 0) {
             const double min_phi = np_lerp(angle_of_key(vp[0]), angle_of_key(vn[0]), gm[0]);
             const double max_phi = np_lerp(angle_of_key(vp[1]), angle_of_key(vn[1]), gm[1]);
@@ -1690,7 +1706,9 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
         }
         if (tid == 0) {
             out[TIA_ST_MINPHI] = (double)n_iter;  // Vahadane: number of dictionary-learning iterations run
+#if TIA_STATS_TIMING
             s.tm[TM_PHI_TOTAL] = clock64() - t_begin;
+#endif
         }
     } else {
 #pragma unroll
@@ -1871,12 +1889,14 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                     return true;
                 },
                 s, kp, nn, lo0, hi0, olo0, ohi0, false, bincache, vp, vn);
+#if TIA_STATS_TIMING
         if (tid == 0) {
             s.tm[11] = s.st.level[0];
             s.tm[12] = s.st.level[1];
             s.tm[13] = (long long)s.st.cnt[0];
             s.tm[14] = (long long)s.st.cnt[1];
         }
+#endif
         maxc[0] = np_lerp(vp[0], vn[0], gm[0]);
         maxc[1] = np_lerp(vp[1], vn[1], gm[1]);
     }
@@ -1903,9 +1923,11 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
                                                 P[j * 2 + 1] * sc1 * prm.target_stain[3 + c];
         }
         out[TIA_ST_FLAGS] = (double)flags;
+#if TIA_STATS_TIMING
         s.tm[TM_TOTAL] = clock64() - t_begin;
         s.tm[TM_CONC_TOTAL] = s.tm[TM_TOTAL] - s.tm[TM_PHI_TOTAL];
         for (int i = 0; i < 16; ++i) out[TIA_ST_CYCLES + i] = (double)s.tm[i];
+#endif
     }
 }
 
