@@ -1,4 +1,5 @@
-"""world_size-2 gloo tests (CPU) for the patch-sharded multi-process path."""
+"""gloo tests (CPU, world sizes 2 / 4 / 8) for the multi-process paths: uneven shards, ranks whose shard is empty (more
+ranks than patches / patch rows / tiles), ragged instance tables, tile sharding, rank-local canvas bands."""
 
 from __future__ import annotations
 
@@ -41,12 +42,16 @@ def _worker(rank: int, world: int, port: int, n: int, out_dir: str) -> None:
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [7, 8])
-def test_all_gather_and_engine_world2(tmp_path, n):
-    port = 29600 + (os.getpid() % 200) + n
-    mp.spawn(_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
-    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
-    assert p0.shape == (5, 9) and np.array_equal(p0, p1)
+@pytest.mark.parametrize(("world", "n"), [(2, 7), (2, 8), (4, 7), (8, 3)])
+def test_all_gather_and_engine(tmp_path, world, n):
+    """``PatchPredictor`` over 5 patches on 2 / 4 / 8 ranks: shards of 3+2, 2+2+1+0 and 1+1+1+1+1+0+0+0 patches -- uneven
+    shards and ranks with an EMPTY shard (they probe one patch for the row shape and contribute zero rows)."""
+    port = 29600 + (os.getpid() % 200) + n + 16 * world
+    mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    p0 = np.load(tmp_path / "p0.npy")
+    assert p0.shape == (5, 9)
+    for r in range(1, world):
+        assert np.array_equal(p0, np.load(tmp_path / f"p{r}.npy"))
     from tiatoolbox_amd.models.engine.patch_predictor import PatchPredictor
     from tiatoolbox_amd.utils import synth
 
@@ -137,16 +142,18 @@ def _same_tables(a: dict, b: dict) -> None:
         assert np.array_equal(ha, hb)
 
 
-def test_instance_tables_gathered_across_ranks(tmp_path):
-    """MultiTaskSegmentor patch mode, world_size 2 (gloo): every rank post-processes its own shard; label maps and the
-    ragged instance tables (incl. an empty one and polygons of different lengths) are all-gathered in input order."""
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_instance_tables_gathered_across_ranks(tmp_path, world):
+    """MultiTaskSegmentor patch mode on 2 / 4 / 8 ranks (gloo): every rank post-processes its own shard; label maps and the
+    ragged instance tables (incl. an empty one and polygons of different lengths) are all-gathered in input order.  With 8
+    ranks and 5 patches three ranks hold no patch at all and still take part in every collective."""
     import pickle
 
-    port = 29900 + (os.getpid() % 150)
-    mp.spawn(_inst_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29900 + (os.getpid() % 150) + 7 * world
+    mp.spawn(_inst_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     single = _run_instance_engine()
     assert sum(len(b) for b in single["box"]) >= 5 and len(single["box"][0]) == 0
-    for rank in range(2):
+    for rank in range(world):
         with open(tmp_path / f"inst{rank}.pkl", "rb") as fh:
             _same_tables(pickle.load(fh), single)  # noqa: S301
 
@@ -168,17 +175,19 @@ def _tile_worker(rank: int, world: int, port: int, out_dir: str) -> None:
     dist.destroy_process_group()
 
 
-def test_tile_mode_sharded_across_ranks_matches_reference(tmp_path):
-    """WSI tile mode, world_size 2 (gloo): the 25 tiles are post-processed half per rank, tables and tile label maps
-    are gathered, and both ranks end with the table the REAL reference produces (tile_golden 'a')."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_tile_mode_sharded_across_ranks_matches_reference(tmp_path, world):
+    """WSI tile mode on 2 / 4 ranks (gloo): the 25 tiles are post-processed round-robin inside every shape group (uneven
+    shares), tables and tile label maps are gathered, and every rank ends with the table the REAL reference produces
+    (tile_golden 'a')."""
     import pickle
 
     import test_tile_mode as ttm
 
-    port = 30100 + (os.getpid() % 150)
-    mp.spawn(_tile_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 30100 + (os.getpid() % 150) + 11 * world
+    mp.spawn(_tile_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     gold = np.load(ttm.GOLD / "tile_golden.npz")
-    for rank in range(2):
+    for rank in range(world):
         with open(tmp_path / f"tile{rank}.pkl", "rb") as fh:
             ttm._check_table(pickle.load(fh), gold, "a")  # noqa: S301, SLF001
 
@@ -214,10 +223,13 @@ def _band_worker(rank: int, world: int, port: int, out_dir: str) -> None:
     dist.destroy_process_group()
 
 
-def test_semantic_band_exchange_world2(tmp_path):
-    """Collective logic of sharded semantic WSI inference on CPU tensors (gloo): every rank owns a contiguous band of
-    canvas rows, the bands tile the slide, and one padded all-gather rebuilds predictions and probabilities on
-    every rank (rank-local bands instead of an all-reduce of a full-size map)."""
+@pytest.mark.parametrize("world_size", [2, 4, 8])
+def test_semantic_band_exchange(tmp_path, world_size):
+    """Collective logic of sharded semantic WSI inference on CPU tensors (gloo, 2 / 4 / 8 ranks): every rank owns a
+    contiguous band of canvas rows, the bands tile the slide, and one padded all-gather rebuilds predictions and
+    probabilities on every rank (rank-local bands instead of an all-reduce of a full-size map).  The 333-row
+    slide has a single patch row: with more ranks than rows the surplus ranks own an empty band, infer nothing and still take
+    part in the exchange."""
     from tiatoolbox_amd.models.engine.semantic_segmentor import band_plan
 
     for world in (1, 2, 3, 8):  # layout properties for any world size (no process group needed)
@@ -232,6 +244,7 @@ def test_semantic_band_exchange_world2(tmp_path):
             assert sorted(r for p in plans for r in range(*p["own"])) == list(range(len(row_ys)))
             for p in plans:  # surplus ranks (more ranks than patch rows) get no inference work
                 assert (p["rows"] == []) == (p["own"][0] >= p["own"][1])
-    port = 29850 + (os.getpid() % 100)
-    mp.spawn(_band_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert torch.equal(torch.load(tmp_path / "bands0.pt"), torch.load(tmp_path / "bands1.pt"))
+    port = 29850 + (os.getpid() % 100) + 13 * world_size
+    mp.spawn(_band_worker, args=(world_size, port, str(tmp_path)), nprocs=world_size, join=True)
+    for r in range(1, world_size):
+        assert torch.equal(torch.load(tmp_path / "bands0.pt"), torch.load(tmp_path / f"bands{r}.pt"))
