@@ -25,7 +25,12 @@ norm = get_normalizer("macenko"); norm.fit(x[0])
 p = norm.extractor.stats_params(target_stain=norm.stain_matrix_target, target_maxc=norm.maxC_target)
 stats = dev.stain_stats(x, p)
 t = timeit(lambda: dev.stain_stats(x, p))
-print(f"stats   n={n} {h}x{w}: {t:.3f} ms  -> {n/t*1e3:,.0f} patches/s, {t/n*1e3:.2f} us/patch")
+print(f"stats   n={n} {h}x{w}: {t:.3f} ms  -> {n/t*1e3:,.0f} patches/s, {t/n*1e3:.2f} us/patch; "
+      f"{n*h*w*3/t/1e6:.1f} GB/s ({n*h*w*3/t/1e6/80:.2f}% of 8 TB/s); patches handed back to the streaming kernel: "
+      f"{dev.redo_count(x.device, n, h, w)}")
+ps = norm.extractor.stats_params(target_stain=norm.stain_matrix_target, target_maxc=norm.maxC_target); ps.select_mode = 1
+ts = timeit(lambda: dev.stain_stats(x, ps), reps=5)
+print(f"stats (streaming kernel only, select_mode=1): {ts:.3f} ms")
 cyc = dev.stain_stats(x, p)[:, _lib.ST_CYCLES:_lib.ST_CYCLES+16].mean(0).cpu().numpy()
 names = ["P1","LUT","P2","EIG","SEL_HIST","SEL_FIND","SEL_COLLECT","SEL_SORT","PHI_TOTAL","CONC_TOTAL","TOTAL","clv0","clv1","ccnt0","ccnt1","philv"]
 print("  cycles/patch:", ", ".join(f"{k}={v:,.0f}" for k, v in zip(names, cyc)))

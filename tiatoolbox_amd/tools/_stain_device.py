@@ -116,6 +116,17 @@ def stain_stats(img: torch.Tensor, params: _lib.StainParams, stain_given: torch.
     return stats
 
 
+def redo_count(device: torch.device, n: int, h: int, w: int) -> int:
+    """Diagnostics: how many patches of the LAST ``stain_stats`` launch of ``n`` patches of ``h x w`` on ``device`` the
+    register-resident kernel handed back to the streaming kernel (the flag array sits behind the bin cache in the workspace)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _WS.get(idx)
+    off = (n * h * w * 4 + 255) & ~255
+    if ws is None or ws.numel() < off + 4 * n:
+        return -1
+    return int(ws[off:off + 4 * n].view(torch.int32).ne(0).sum().item())
+
+
 _OUT_DTYPES = {
     _lib.OUT_U8: torch.uint8, _lib.OUT_F32: torch.float32, _lib.OUT_F64: torch.float64,
     _lib.OUT_UNIT_F16: torch.float16, _lib.OUT_UNIT_BF16: torch.bfloat16, _lib.OUT_UNIT_F32: torch.float32,
