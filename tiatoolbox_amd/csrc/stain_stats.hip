@@ -8,6 +8,8 @@
 //   P5/P6 exact 99th percentile of both stain concentrations
 // Reference: tools/stainextract.py:177-227, tools/stainnorm.py:49-66,81-85,103,
 //            utils/misc.py:261-290,405-444, utils/transforms.py:209-231.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.hpp"
@@ -1987,19 +1989,23 @@ __global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8
 constexpr int RT = 1024;
 constexpr int RW = RT / 64;
 constexpr int RG = 16;        // groups per thread
-constexpr int RSEG = 512;     // list entries per wave
-constexpr int HCOPY = 32;     // histogram copies
+constexpr int RSEG = 384;     // list entries (16 bytes: one 4-pixel group + need-bits) per wave
+constexpr int HCOPY = 32;     // histogram / OD-table copies: lane l uses copy l & 31, so a half-wave never shares a bank
+constexpr int RCAP = 2048;    // candidates per target (windows over all 65536 pixels of a 256 x 256 patch hold ~800 + slack)
 
 struct SmemR {
     double od[256];
     int ty[3][256];
     unsigned hist[256];
     unsigned cum[256];
-    unsigned hstripe[256 * HCOPY];   // P1 histogram, copy (lane & 31) of bin v at v * 32 + (lane & 31)
-    float sbuf[2][SAMPLE_TARGET];
-    unsigned list[RW * RSEG];
+    union {  // one 96 KB region, used by one phase at a time
+        unsigned hstripe[256 * HCOPY];   // P1: byte histogram, copy (lane & 31) of bin v at v * 32 + (lane & 31)
+        double odstripe[256 * HCOPY];    // P2: the float64 OD table, striped the same way (conflict-free look-ups)
+        float sbuf[2][SAMPLE_TARGET];    // selections: sample keys (window placement) ...
+        uint4 list[RW * RSEG];           // ... then the sweep's lists (the sample is consumed before the sweep starts)
+    };
     unsigned sbins[2][SNB];
-    double cand[2][CAP];
+    double cand[2][RCAP];
     double small[2][64];
     double red[RW][16];
     double tot[16];
@@ -2014,7 +2020,21 @@ struct SmemR {
     int sel_lo[2], sel_hi[2];
     unsigned wcnt[RW];
     int wok;
+#if TIA_STATS_TIMING
+    long long tm[16];
+    long long tlast;
+#endif
 };
+#if TIA_STATS_TIMING
+#define RSTAMP(i)                                  \
+    if (threadIdx.x == 0) {                        \
+        const long long now_ = clock64();          \
+        s.tm[i] += now_ - s.tlast;                 \
+        s.tlast = now_;                            \
+    }
+#else
+#define RSTAMP(i)
+#endif
 
 template <int N>
 __device__ __forceinline__ void block_sum_r(double (&v)[N], SmemR& s) {
@@ -2041,8 +2061,8 @@ __device__ __forceinline__ void block_sum_r(double (&v)[N], SmemR& s) {
 // `sweep(seg, cap, count, below0, below1)` classifies the calling thread's own pixels in float32 and appends the undecided
 // ones (colour + need-bits) to this wave's list segment.  Returns false (workgroup-uniform) when a precondition fails.
 template <class SAMPLE32, class EXACT, class SWEEP>
-__device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p, long hw, SAMPLE32&& sample32, EXACT&& exact,
-                                                  SWEEP&& sweep, SmemR& s, const unsigned long long (&k)[2],
+__device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p, long hw, bool shared_keys, SAMPLE32&& sample32,
+                                                  EXACT&& exact, SWEEP&& sweep, SmemR& s, const unsigned long long (&k)[2],
                                                   const unsigned long long (&n)[2], double (&vprev)[2], double (&vnext)[2]) {
     const int tid = threadIdx.x;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -2114,8 +2134,8 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
         smin[t] = (float)lo;
         sscale[t] = (hi > lo && sc > 0.0 && sc < 1.0e30) ? (float)sc : 0.0f;
     }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+    // (both targets of the angular selection see the same keys: one histogram then serves both)
+    for (int t = 0; t < (shared_keys ? 1 : 2); ++t)
         for (int i = tid; i < SAMPLE_TARGET; i += RT) {
             const float v = s.sbuf[t][i];
             if (v == v) {
@@ -2157,7 +2177,7 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
         unsigned local[PER], sum = 0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            local[i] = s.sbins[t][lane * PER + i];
+            local[i] = s.sbins[shared_keys ? 0 : t][lane * PER + i];
             sum += local[i];
         }
         const unsigned incl = wave_incl_scan_u32(sum);
@@ -2184,10 +2204,16 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
     }
     for (int i = tid; i < 2 * SNB; i += RT) (&s.sbins[0][0])[i] = 0u;
     __syncthreads();
+    RSTAMP(TM_SEL_FIND)
     // ---- the float32 sweep over the thread's own pixels ---------------------------------------------------------------------
     {
-        unsigned count = 0, bl0 = 0, bl1 = 0;
+        unsigned count = 0, bl0 = 0, bl1 = 0;  // count: wave-uniform; bl0 / bl1: per-lane counts of "definitely below"
         sweep(s.list + wave_id() * RSEG, (unsigned)RSEG, count, bl0, bl1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            bl0 += __shfl_down(bl0, o, 64);
+            bl1 += __shfl_down(bl1, o, 64);
+        }
         if (lane_id() == 0) {
             s.wcnt[wave_id()] = count;
             if (bl0) atomicAdd(&s.wbelow[0], (unsigned long long)bl0);
@@ -2195,6 +2221,7 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
         }
     }
     __syncthreads();
+    RSTAMP(TM_SEL_HIST)
     {
         bool over = false;
         for (int w = 0; w < RW; ++w) over = over || s.wcnt[w] > (unsigned)RSEG;
@@ -2216,21 +2243,27 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
                 }
                 acc += s.wcnt[v];
             }
-            const unsigned e = s.list[w * RSEG + (i - base)];
-            const unsigned need = e >> 24;
-            double x[2];
-            exact(e & 255u, (e >> 8) & 255u, (e >> 16) & 255u, x);
+            const uint4 en = s.list[w * RSEG + (i - base)];
+            uint32_t rr[4], gg[4], bb[4];
+            unpack_group(en.x, en.y, en.z, rr, gg, bb);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (!((need >> t) & 1u)) continue;
-                if (x[t] < s.wlo[t]) {
-                    ++bl[t];
-                } else if (!(x[t] > s.whi[t])) {
-                    const unsigned pos = atomicAdd(&s.wn[t], 1u);
-                    if (pos < (unsigned)CAP) s.cand[t][pos] = x[t];
-                    const unsigned long long key = f64_key(x[t]);
-                    mn[t] = key < mn[t] ? key : mn[t];
-                    mx[t] = key > mx[t] ? key : mx[t];
+            for (int px = 0; px < 4; ++px) {
+                const unsigned need = (en.w >> (2 * px)) & 3u;
+                if (!need) continue;
+                double x[2];
+                exact(rr[px], gg[px], bb[px], x);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (!((need >> t) & 1u)) continue;
+                    if (x[t] < s.wlo[t]) {
+                        ++bl[t];
+                    } else if (!(x[t] > s.whi[t])) {
+                        const unsigned pos = atomicAdd(&s.wn[t], 1u);
+                        if (pos < (unsigned)RCAP) s.cand[t][pos] = x[t];
+                        const unsigned long long key = f64_key(x[t]);
+                        mn[t] = key < mn[t] ? key : mn[t];
+                        mx[t] = key > mx[t] ? key : mx[t];
+                    }
                 }
             }
         }
@@ -2249,14 +2282,20 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
         }
     }
     __syncthreads();
+    RSTAMP(TM_SEL_COLLECT)
     if (tid == 0) {
         int ok = 1;
         for (int t = 0; t < 2; ++t) {
             const unsigned long long below = s.wbelow[t], nc = s.wn[t];
             const bool has_next = k[t] + 1 < n[t];
-            if (nc > (unsigned long long)CAP || k[t] < below || k[t] + (has_next ? 1 : 0) >= below + nc) ok = 0;
+            if (nc > (unsigned long long)RCAP || k[t] < below || k[t] + (has_next ? 1 : 0) >= below + nc) ok = 0;
         }
         s.wok = ok;
+#if TIA_STATS_TIMING
+        s.tm[11] += s.wn[0];
+        s.tm[12] += s.wn[1];
+        for (int w = 0; w < RW; ++w) s.tm[13] += s.wcnt[w];
+#endif
     }
     __syncthreads();
     if (!s.wok) return false;
@@ -2373,8 +2412,14 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
         vnext[t] = (k[t] + 1 < n[t]) ? s.bc[41 + 2 * t] : vprev[t];
     }
     __syncthreads();
+    RSTAMP(TM_SEL_SORT)
     return true;
 }
+
+// The patch registers are LLVM vectors: a loop over the groups with a (wave-uniform) run-time index then compiles to indexed
+// register moves (s_set_gpr_idx / v_movrel) instead of 16 unrolled copies of every sweep -- unrolled, the kernel is > 100 KB of
+// straight-line code that every wave streams through the instruction cache once per patch.
+using u32x16 = uint32_t __attribute__((ext_vector_type(16)));
 
 // Workgroup-uniform values (read from LDS or computed from such) moved to scalar registers: they are live across the sweeps,
 // and the vector registers are needed for the patch.
@@ -2444,7 +2489,8 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
     const int ng = (int)(hw >> 2);
 
     // ---- the patch: groups tid + 1024 j, all loads in flight together ------------------------------------------------------
-    uint32_t pa[RG], pb[RG], pc[RG];
+    static_assert(RG == 16, "the patch registers are 16-wide vectors");
+    u32x16 pa, pb, pc;
 #pragma unroll
     for (int j = 0; j < RG; ++j) {
         const int g = tid + RT * j;
@@ -2453,6 +2499,7 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
         pb[j] = q[gc * 3 + 1];
         pc[j] = q[gc * 3 + 2];
     }
+    const int n_slots = (ng + RT - 1) / RT;  // group slots in use (workgroup-uniform)
     double s_given[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (prm.mode == TIA_MODE_GIVEN) {
 #pragma unroll
@@ -2466,6 +2513,13 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
             redo[blockIdx.x] = 1;
         }
     };
+#if TIA_STATS_TIMING
+    if (tid == 0) {
+        for (int i = 0; i < 16; ++i) s.tm[i] = 0;
+        s.tlast = clock64();
+    }
+    const long long t_begin = clock64();
+#endif
     if (tid < TIA_STATS_STRIDE) out[tid] = 0.0;
     if (tid < 256) s.od[tid] = tab->od_lut[tid];
     for (int i = tid; i < 256 * HCOPY; i += RT) s.hstripe[i] = 0u;
@@ -2474,8 +2528,8 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
     // ---- P1: byte histogram of all three channels together (the percentiles are over the flattened image) ------------------
     {
         unsigned* hs = s.hstripe + (lane & (HCOPY - 1));
-#pragma unroll
-        for (int j = 0; j < RG; ++j) {
+#pragma unroll 1
+        for (int j = 0; j < n_slots; ++j) {
             if (tid + RT * j < ng) {
                 const uint32_t w[3] = {pa[j], pb[j], pc[j]};
 #pragma unroll
@@ -2487,10 +2541,10 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
                         atomicAdd(hs + v * HCOPY, 1u);
                     }
             }
-            __builtin_amdgcn_sched_barrier(0);  // one group at a time: the unrolled loop must not pile up live values
         }
     }
     __syncthreads();
+    RSTAMP(TM_P1)
     if (tid < 256) {
         unsigned tot = 0;
 #pragma unroll 8
@@ -2555,52 +2609,70 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
         s.ty[2][tid] = tab->ty[2][ce];
     }
     __syncthreads();
+    RSTAMP(TM_LUT)
     const int y_thr = prm.y_thr;
-    auto seg_push = [&](bool need, unsigned entry, unsigned* seg, unsigned cap, unsigned& count) {
+    // append one 16-byte entry (a 4-pixel group + its need-bits) per lane that has one to this wave's private list segment:
+    // position = wave count (uniform) + number of appending lanes below this one (v_mbcnt); no atomics
+    auto seg_push = [&](bool need, const uint4& entry, uint4* seg, unsigned cap, unsigned& count) {
         const unsigned long long m = __ballot(need);
         const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         const unsigned pos = count + before;
         if (need && pos < cap) seg[pos] = entry;
         count += (unsigned)__popcll(m);
     };
+    auto sgn = [](float v) -> unsigned { return __float_as_uint(v) >> 31; };  // 1 iff v < 0 (v is never NaN where it counts)
 
     unsigned flags = 0;
     if (prm.mode == TIA_MODE_MACENKO) {
         // ---- P2: tissue mask (kept as bits in two registers) + OD moments, out of the registers --------------------------------
+        for (int i = tid; i < 256 * HCOPY; i += RT) s.odstripe[i] = s.od[i / HCOPY];  // the histogram is consumed: its LDS takes
+        __syncthreads();                                                              // the striped OD table
+        const double* ods = s.odstripe + (lane & (HCOPY - 1));
         double acc[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) acc[i] = 0.0;
         unsigned long long tmask = 0ull;
+#pragma unroll 1
+        for (int j = 0; j < n_slots; ++j) {
+            const bool valid = tid + RT * j < ng;
+            uint32_t rr[4], gg[4], bb[4];
+            unpack_group(pa[j], pb[j], pc[j], rr, gg, bb);
+            // the luminance look-ups of all four pixels and the OD look-ups of two at a time are in flight together; the
+            // accumulation order (pixel 0, 1, 2, 3 of the group) is that of stain_stats_kernel
+            int lum[4];
 #pragma unroll
-        for (int j = 0; j < RG; ++j) {
-            if (tid + RT * j < ng) {
-                // one pixel at a time (the patch already holds 48 registers and the moments 20): bytes r0 g0 b0 r1 | g1 b1 r2 g2 |
-                // b2 r3 g3 b3; the accumulation order (pixel 0, 1, 2, 3 of the group) is that of stain_stats_kernel
+            for (int i = 0; i < 4; ++i) lum[i] = s.ty[0][rr[i]] + s.ty[1][gg[i]] + s.ty[2][bb[i]];
+            unsigned nib = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t r = i == 0 ? (pa[j] & 255u) : i == 1 ? (pa[j] >> 24) : i == 2 ? ((pb[j] >> 16) & 255u) : ((pc[j] >> 8) & 255u);
-                    const uint32_t g = i == 0 ? ((pa[j] >> 8) & 255u) : i == 1 ? (pb[j] & 255u) : i == 2 ? (pb[j] >> 24) : ((pc[j] >> 16) & 255u);
-                    const uint32_t b = i == 0 ? ((pa[j] >> 16) & 255u) : i == 1 ? ((pb[j] >> 8) & 255u) : i == 2 ? (pc[j] & 255u) : (pc[j] >> 24);
-                    const double x = s.od[r], y = s.od[g], z = s.od[b];
-                    const int lum = s.ty[0][r] + s.ty[1][g] + s.ty[2][b];
-                    if (((lum + (1 << 11)) >> 12) < y_thr) {
-                        tmask |= 1ull << (4 * j + i);
+            for (int h2 = 0; h2 < 2; ++h2) {
+                double x[2], y[2], z[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    x[i] = ods[rr[2 * h2 + i] * HCOPY];
+                    y[i] = ods[gg[2 * h2 + i] * HCOPY];
+                    z[i] = ods[bb[2 * h2 + i] * HCOPY];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (valid && ((lum[2 * h2 + i] + (1 << 11)) >> 12) < y_thr) {
+                        nib |= 1u << (2 * h2 + i);
                         acc[0] += 1.0;
-                        acc[1] += x;
-                        acc[2] += y;
-                        acc[3] += z;
-                        acc[4] = __builtin_fma(x, x, acc[4]);
-                        acc[5] = __builtin_fma(x, y, acc[5]);
-                        acc[6] = __builtin_fma(x, z, acc[6]);
-                        acc[7] = __builtin_fma(y, y, acc[7]);
-                        acc[8] = __builtin_fma(y, z, acc[8]);
-                        acc[9] = __builtin_fma(z, z, acc[9]);
+                        acc[1] += x[i];
+                        acc[2] += y[i];
+                        acc[3] += z[i];
+                        acc[4] = __builtin_fma(x[i], x[i], acc[4]);
+                        acc[5] = __builtin_fma(x[i], y[i], acc[5]);
+                        acc[6] = __builtin_fma(x[i], z[i], acc[6]);
+                        acc[7] = __builtin_fma(y[i], y[i], acc[7]);
+                        acc[8] = __builtin_fma(y[i], z[i], acc[8]);
+                        acc[9] = __builtin_fma(z[i], z[i], acc[9]);
                     }
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            tmask |= (unsigned long long)nib << (4 * j);
         }
         block_sum_r(acc, s);
+        RSTAMP(TM_P2)
         const double nt = acc[0];
         const unsigned long long n_tissue = (unsigned long long)nt;
         if (n_tissue == 0) {
@@ -2625,6 +2697,7 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
             out[TIA_ST_NTISSUE] = nt;
         }
         __syncthreads();
+        RSTAMP(TM_EIG)
         // the eigenvectors stay in LDS (s.bc[2..7]); only the float32 images the sweep needs go to (scalar) registers
 
         // ---- P3: exact percentiles of phi over the tissue pixels (see stain_stats_kernel for the error budget) ------------------
@@ -2645,7 +2718,7 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
             y = fmaf(-ey2, lb, fmaf(-ey1, lg, fmaf(-ey0, lr, ky)));
         };
         const bool ok = window_select_reg(
-            p, hw,
+            p, hw, true,
             [&](long, uint32_t r, uint32_t g, uint32_t b, float (&v)[2]) -> unsigned {
                 const int t = s.ty[0][r] + s.ty[1][g] + s.ty[2][b];
                 if (!(((t + (1 << 11)) >> 12) < y_thr)) return 0u;
@@ -2662,33 +2735,37 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
                 const double p1 = dot3(ox, oy, oz, s.bc[5], s.bc[6], s.bc[7]);
                 x[0] = x[1] = pseudo_angle(p1, p0);
             },
-            [&](unsigned* seg, unsigned cap, unsigned& count, unsigned& bl0, unsigned& bl1) {
+            [&](uint4* seg, unsigned cap, unsigned& count, unsigned& bl0, unsigned& bl1) {
                 const double w[4] = {s.wlo[0], s.whi[0], s.wlo[1], s.whi[1]};
                 bool edges_ok = true;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) edges_ok = edges_ok && (!(fabs(w[i]) < 1e300) || fabs(w[i]) <= 1.0);
+                const unsigned eok = edges_ok ? 1u : 0u;
                 const float lo0 = uni((float)w[0]), hi0 = uni((float)w[1]), lo1 = uni((float)w[2]), hi1 = uni((float)w[3]);
-#pragma unroll
-                for (int j = 0; j < RG; ++j) {
-                    if (RT * j >= ng) continue;  // workgroup-uniform (no `break`: the loop must unroll fully, static indices)
-                    const bool valid = tid + RT * j < ng;
+                // all predicates as 0 / 1 integers from sign bits (VALU only: no compare -> scalar mask -> select round trips):
+                // below <=> s + tol < 0, above <=> tol - s < 0, plain <=> tol - x < 0; NaNs (an infinite edge times d = 0) can
+                // only arise where plain = 0, which masks them
+#pragma unroll 1
+                for (int j = 0; j < n_slots; ++j) {
+                    const unsigned valid = tid + RT * j < ng ? 1u : 0u;
                     uint32_t rr[4], gg[4], bb[4];
                     unpack_group(pa[j], pb[j], pc[j], rr, gg, bb);
+                    unsigned fl = 0u;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const bool tissue = valid && ((tmask >> (4 * j + i)) & 1ull);
+                        const unsigned tb = (unsigned)(tmask >> (4 * j + i)) & valid;
                         float x, y;
                         proj(rr[i], gg[i], bb[i], x, y);
                         const float d = fabsf(x) + fabsf(y);
-                        const bool plain = edges_ok && x > tol;
-                        const bool below0 = plain && fmaf(-lo0, d, y) < -tol, above0 = plain && fmaf(-hi0, d, y) > tol;
-                        const bool below1 = plain && fmaf(-lo1, d, y) < -tol, above1 = plain && fmaf(-hi1, d, y) > tol;
-                        bl0 += (unsigned)__popcll(__ballot(tissue && below0));
-                        bl1 += (unsigned)__popcll(__ballot(tissue && below1));
-                        const unsigned need = (tissue && !below0 && !above0 ? 1u : 0u) | (tissue && !below1 && !above1 ? 2u : 0u);
-                        seg_push(need != 0u, rr[i] | (gg[i] << 8) | (bb[i] << 16) | (need << 24), seg, cap, count);
+                        const unsigned pl = sgn(tol - x) & eok;
+                        const unsigned bel0 = sgn(fmaf(-lo0, d, y) + tol), abv0 = sgn(tol - fmaf(-hi0, d, y));
+                        const unsigned bel1 = sgn(fmaf(-lo1, d, y) + tol), abv1 = sgn(tol - fmaf(-hi1, d, y));
+                        bl0 += tb & pl & bel0;
+                        bl1 += tb & pl & bel1;
+                        const unsigned dec0 = pl & (bel0 | abv0), dec1 = pl & (bel1 | abv1);
+                        fl |= ((tb & (dec0 ^ 1u)) | ((tb & (dec1 ^ 1u)) << 1)) << (2 * i);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    seg_push(fl != 0u, make_uint4(pa[j], pb[j], pc[j], fl), seg, cap, count);
                 }
             },
             s, kp, nn, vp, vn);
@@ -2712,6 +2789,9 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
             for (int i = 0; i < 6; ++i) s.bc[8 + i] = prm.mode == TIA_MODE_GIVEN ? s_given[i] : prm.stain_fixed[i];
     }
 
+#if TIA_STATS_TIMING
+    if (tid == 0) s.tm[TM_PHI_TOTAL] = clock64() - t_begin;
+#endif
     // ---- pseudo-inverse (stain matrix S = s.bc[8..13], P = s.bc[14..19]: both stay in LDS) ---------------------------------------
     if (tid == 0) {
         double S[6], P[6];
@@ -2754,7 +2834,7 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
             c1 = fmaf(-b2, lb, fmaf(-b1, lg, fmaf(-b0, lr, kb)));
         };
         const bool ok = window_select_reg(
-            p, hw,
+            p, hw, false,
             [&](long, uint32_t r, uint32_t g, uint32_t b, float (&v)[2]) -> unsigned {
                 conc32(r, g, b, v[0], v[1]);
                 return 3u;
@@ -2764,28 +2844,28 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
                 x[0] = dot3(ox, oy, oz, P[0], P[2], P[4]);  // P read from LDS at the point of use
                 x[1] = dot3(ox, oy, oz, P[1], P[3], P[5]);
             },
-            [&](unsigned* seg, unsigned cap, unsigned& count, unsigned& bl0, unsigned& bl1) {
+            [&](uint4* seg, unsigned cap, unsigned& count, unsigned& bl0, unsigned& bl1) {
                 const float lo0 = uni((float)s.wlo[0]), hi0 = uni((float)s.whi[0]), lo1 = uni((float)s.wlo[1]), hi1 = uni((float)s.whi[1]);
                 auto slack = [](float v) { return fabsf(v) < 3e38f ? 2.4e-7f * fabsf(v) : 0.0f; };
                 const float t0 = uni(tol0 + slack(lo0) + slack(hi0)), t1 = uni(tol1 + slack(lo1) + slack(hi1));
-#pragma unroll
-                for (int j = 0; j < RG; ++j) {
-                    if (RT * j >= ng) continue;  // workgroup-uniform (no `break`: the loop must unroll fully, static indices)
-                    const bool valid = tid + RT * j < ng;
+                // below <=> (c + t) - lo < 0, above <=> hi - (c - t) < 0 (differences of finite / infinite floats: never NaN here)
+#pragma unroll 1
+                for (int j = 0; j < n_slots; ++j) {
+                    const unsigned valid = tid + RT * j < ng ? 1u : 0u;
                     uint32_t rr[4], gg[4], bb[4];
                     unpack_group(pa[j], pb[j], pc[j], rr, gg, bb);
+                    unsigned fl = 0u;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float c0, c1;
                         conc32(rr[i], gg[i], bb[i], c0, c1);
-                        const bool below0 = c0 + t0 < lo0, above0 = c0 - t0 > hi0;
-                        const bool below1 = c1 + t1 < lo1, above1 = c1 - t1 > hi1;
-                        bl0 += (unsigned)__popcll(__ballot(valid && below0));
-                        bl1 += (unsigned)__popcll(__ballot(valid && below1));
-                        const unsigned need = (valid && !below0 && !above0 ? 1u : 0u) | (valid && !below1 && !above1 ? 2u : 0u);
-                        seg_push(need != 0u, rr[i] | (gg[i] << 8) | (bb[i] << 16) | (need << 24), seg, cap, count);
+                        const unsigned bel0 = sgn((c0 + t0) - lo0), abv0 = sgn(hi0 - (c0 - t0));
+                        const unsigned bel1 = sgn((c1 + t1) - lo1), abv1 = sgn(hi1 - (c1 - t1));
+                        bl0 += valid & bel0;
+                        bl1 += valid & bel1;
+                        fl |= ((valid & ((bel0 | abv0) ^ 1u)) | ((valid & ((bel1 | abv1) ^ 1u)) << 1)) << (2 * i);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    seg_push(fl != 0u, make_uint4(pa[j], pb[j], pc[j], fl), seg, cap, count);
                 }
             },
             s, kp, nn, vp, vn);
@@ -2820,6 +2900,11 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
                                                 P[j * 2 + 1] * sc1 * prm.target_stain[3 + c];
         }
         out[TIA_ST_FLAGS] = (double)flags;
+#if TIA_STATS_TIMING
+        s.tm[TM_TOTAL] = clock64() - t_begin;
+        s.tm[TM_CONC_TOTAL] = s.tm[TM_TOTAL] - s.tm[TM_PHI_TOTAL];
+        for (int i = 0; i < 16; ++i) out[TIA_ST_CYCLES + i] = (double)s.tm[i];
+#endif
     }
 }
 
@@ -2862,9 +2947,15 @@ extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, in
                            binws, dictws, (const int*)nullptr);
         return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
     }
-    // Patches of <= 65536 pixels in whole 4-pixel groups go through the register-resident kernel (the patch is read from HBM
-    // once); whatever it hands back -- and every other case -- through the streaming kernel.  Both give the same bits.
-    const bool reg_ok = params->select_mode == 0 && (hw & 3) == 0 && hw <= (long)tia::RT * tia::RG * 4 &&
+    // Patches of up to 13 x 4096 pixels (224 x 224 and smaller) in whole 4-pixel groups go through the register-resident kernel
+    // (the patch is read from HBM once); whatever it hands back -- and every other case -- through the streaming kernel.  Both
+    // give the same bits.  Measured on MI355X (profiles/r03d_perf_stain*.txt): both kernels are bound by the vector ALU (about 150
+    // instructions per pixel over the four sweeps, ~4 cycles each per wave), so the single read buys HBM traffic (1.25 GB instead of
+    // 3.9 GB per 4096 x 224^2), not time; at 256 x 256 one 1024-thread workgroup per CU (16 register slots per thread) is slower than
+    // two streaming workgroups that overlap each other's single-lane phases, so those patches stay on the streaming kernel.
+    static const bool reg_all = getenv("TIA_STATS_REG_ALL") != nullptr;  // developer switch: every eligible size
+    const long reg_limit = reg_all ? (long)tia::RT * tia::RG * 4 : (long)tia::RT * 13 * 4;
+    const bool reg_ok = params->select_mode == 0 && (hw & 3) == 0 && hw <= reg_limit &&
                         (reinterpret_cast<uintptr_t>(d_img) & 3) == 0 && aligned &&
                         ws_bytes >= tia_stain_stats_workspace_bytes_mode(n, h, w, params->mode);
     if (reg_ok) {
