@@ -433,11 +433,25 @@ int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const fl
  *   (models/dataset/classification.py:27-32) and the float32 cast of `_infer_batch` (vanilla.py:242-245) happen on load;
  *   x_is_u8 == 0: d_x is float32 NHWC and X = x.
  *   d_x [n,h,w,3]   d_w_packed [148,64] from tia_stem_pack_weights_f32   d_bias [64]
- *   d_y [n,hp,wp,64] float32, hp = ((h-1)/2)/2 + 1 (likewise wp); float32 fmaf chain in (ky, kx, c) order on the matrix cores. */
-int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, float* d_y,
-                               int64_t n, int64_t h, int64_t w, void* stream);
+ *   d_y [n,hp,wp,64] of y_dtype (TIA_DT_F32; TIA_DT_F16 / TIA_DT_BF16: rounded once, for the half-precision trunk),
+ *   hp = ((h-1)/2)/2 + 1 (likewise wp); arithmetic: a float32 fmaf chain in (ky, kx, c) order on the matrix cores. */
+int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, void* d_y,
+                               int32_t y_dtype, int64_t n, int64_t h, int64_t w, void* stream);
 /* OIHW [64,3,7,7] float32 -> [148,64]: rows (ky, kx, c), one zero row at the end. */
 int tia_stem_pack_weights_f32(const float* d_w_oihw, float* d_packed, void* stream);
+
+/* Half-precision sibling of tia_conv2d_nhwc_f32 for `compute_dtype="float16"|"bfloat16"` runs of the engines (an extension:
+ * the reference computes in float32, vanilla.py:242; results are held to its own 1e-3 tolerance on the probabilities,
+ * tests/engines/test_patch_predictor.py:712-722): implicit GEMM on v_mfma_f32_32x32x16_f16 / _bf16, float32 accumulate;
+ * bias + residual + ReLU in float32, ONE rounding to half on the way out.
+ *   d_x [n,h,w,cin] half   d_w_packed from tia_conv_pack_weights_h   d_bias [cout] float32 or NULL
+ *   d_residual [n,ho,wo,cout] half or NULL   d_y [n,ho,wo,cout] half.   cin % 32 == 0, cout % 64 == 0, 16-byte aligned. */
+int tia_conv2d_nhwc_h(const void* d_x, const void* d_w_packed, const float* d_bias, const void* d_residual, void* d_y,
+                      int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                      int64_t pad, int32_t dtype, int32_t relu, void* stream);
+/* OIHW float32 weights -> [kh][kw][cin/8][cout][8] halves of `dtype` (a lane's 8 k-values of its column contiguous). */
+int tia_conv_pack_weights_h(const float* d_w_oihw, int64_t cout, int64_t cin, int64_t kh, int64_t kw, int32_t dtype,
+                            void* d_packed, void* stream);
 
 /* y = act(x * scale[c] + shift[c]) on NHWC float32 ([rows, c], c % 4 == 0; y may alias x): an inference-mode
  * BatchNorm (+ ReLU) that sits in FRONT of a convolution and therefore cannot be folded into one -- the pre-activation

@@ -390,3 +390,64 @@ def test_deep_feature_extractor_gpu_matches_cpu(patches):
         padded = np.pad(slide, ((0, 300), (0, 300), (0, 0)), constant_values=255)
         again = eng.run(np.stack([padded[y0:y1, x0:x1] for x0, y0, x1, y1 in coords]), **kw)["probabilities"]
         np.testing.assert_allclose(feats, again, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_hip_mfma_conv_half_matches_torch_cpu_fp32(dtype):
+    """``tia_conv2d_nhwc_h`` (fp16 / bf16 MFMA implicit GEMM, float32 accumulate, fused bias + residual + ReLU) against a float32
+    convolution on the CPU of the SAME half-rounded inputs and weights: what remains is the float32 summation order and the one
+    rounding of the result to half.  ResNet layer shapes, odd image sizes, partial pixel tiles, both tile widths."""
+    from tiatoolbox_amd.models.architecture.fused import hip_conv2d_h, pack_conv_weights_h
+
+    dt = getattr(torch, dtype)
+    eps = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    g = torch.Generator().manual_seed(7)
+    cases = [(2, 64, 64, 56, 56, 3, 1), (2, 64, 128, 56, 56, 3, 2), (3, 64, 128, 56, 56, 1, 2), (2, 128, 128, 28, 28, 3, 1),
+             (2, 256, 512, 14, 14, 3, 2), (5, 512, 512, 7, 7, 3, 1), (1, 32, 64, 13, 9, 3, 1), (3, 96, 192, 11, 17, 1, 1),
+             (1, 64, 256, 31, 33, 1, 1)]
+    for n, cin, cout, h, w, k, s in cases:
+        pad = 1 if k == 3 else 0
+        conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=pad)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+            conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        x = torch.randn((n, cin, h, w), generator=g).to(dt)
+        ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+        res = torch.randn((n, cout, ho, wo), generator=g).to(dt)
+        w_half = conv.weight.detach().to(dt)
+        with torch.inference_mode():
+            ref = F.relu(F.conv2d(x.float(), w_half.float(), conv.bias, s, pad) + res.float())
+            ref_plain = F.conv2d(x.float(), w_half.float(), None, s, pad)
+        conv_d = torch.nn.Conv2d(cin, cout, k, stride=s, padding=pad).cuda()
+        conv_d.load_state_dict(conv.state_dict())
+        wp = pack_conv_weights_h(conv_d, dt)
+        assert wp.shape == (k, k, cin // 8, cout, 8) and wp.dtype == dt
+        xd = x.cuda().contiguous(memory_format=torch.channels_last)
+        rd = res.cuda().contiguous(memory_format=torch.channels_last)
+        got = hip_conv2d_h(xd, wp, conv_d.bias.detach(), rd, cout=cout, kernel=k, stride=s, padding=pad, relu=True)
+        assert got.dtype == dt and got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+        err = (got.float().cpu() - ref).abs()
+        tol = eps * ref.abs() + 1e-4 * ref.abs().max()  # half rounding of the result + float32 accumulation order
+        assert bool((err <= tol).all()), (dtype, (n, cin, cout, h, w, k, s), float((err - tol).max()))
+        got_plain = hip_conv2d_h(xd, wp, None, None, cout=cout, kernel=k, stride=s, padding=pad, relu=False)
+        err = (got_plain.float().cpu() - ref_plain).abs()
+        assert bool((err <= eps * ref_plain.abs() + 1e-4 * ref_plain.abs().max()).all()), (dtype, (n, cin, cout, h, w, k, s))
+    with pytest.raises(ValueError, match="fp16 / bf16"):
+        hip_conv2d_h(xd.float(), wp, None, None, cout=cout, kernel=k, stride=s, padding=pad, relu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_half_precision_run_uses_the_handwritten_convolutions(patches, dtype):
+    """``compute_dtype="float16"|"bfloat16"``: the inference copy is the same ``MfmaResNet`` (stem kernel + ``tia_conv2d_nhwc_h``),
+    packed from the float32 parameters; probabilities within the reference's 1e-3 (fp16) of the float32 run."""
+    eng = PatchPredictor("resnet18-kather100k", batch_size=4, device="cuda")
+    ref = eng.run(patches, patch_mode=True, return_probabilities=True)
+    got = eng.run(patches, patch_mode=True, return_probabilities=True, compute_dtype=dtype)
+    fast = eng._inference_model(getattr(torch, dtype))  # noqa: SLF001
+    trunk = [m for m in fast.modules() if type(m).__name__ == "MfmaResNet"]
+    assert len(trunk) == 1 and trunk[0].stem.weight.dtype == getattr(torch, dtype)
+    assert all(b._bias32 for b in trunk[0].blocks)  # noqa: SLF001  (float32 biases kept from before the cast)
+    err = np.abs(got["probabilities"] - ref["probabilities"]).max()
+    assert err <= (1e-3 if dtype == "float16" else 2e-2), err

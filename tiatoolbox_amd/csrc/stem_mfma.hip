@@ -47,11 +47,12 @@ struct StemDims {
     int chunks, rows_per_chunk;  // row chunks per image, pooled rows per chunk
     unsigned x_bytes;            // extent of the input buffer of this launch (< 2^31), rounded up to whole dwords
     int x_shift;                 // uint8 input: bytes between the (dword-aligned) buffer base and the first image
+    int out_dtype;               // TIA_DT_F32 | TIA_DT_F16 | TIA_DT_BF16: type of the pooled output (arithmetic is float32 either way)
 };
 
 template <bool U8>
 __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __restrict__ xin, const float* __restrict__ wpk,
-                                                             const float* __restrict__ bias, float* __restrict__ y, StemDims d) {
+                                                             const float* __restrict__ bias, void* __restrict__ yout, StemDims d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ring = smem;
     float* lut = smem + LUT_OFF;
@@ -220,7 +221,26 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
                         const float4 l = vrow[(lcm - 1) * (COUT / 4)];
                         m.x = fmaxf(m.x, l.x), m.y = fmaxf(m.y, l.y), m.z = fmaxf(m.z, l.z), m.w = fmaxf(m.w, l.w);
                     }
-                    reinterpret_cast<float4*>(y + (((long)img * d.hp + py) * d.wp + px) * COUT)[c4] = m;
+                    const long o = (((long)img * d.hp + py) * d.wp + px) * COUT + 4 * c4;
+                    if (d.out_dtype == TIA_DT_F32) {
+                        *reinterpret_cast<float4*>(static_cast<float*>(yout) + o) = m;
+                    } else {  // one rounding to half (round to nearest even) for the fp16 / bf16 trunk
+                        unsigned short hv[4];
+                        const float mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (d.out_dtype == TIA_DT_BF16) {
+                                unsigned u = __float_as_uint(mv[k]);
+                                u += 0x7fffu + ((u >> 16) & 1u);  // values are finite and >= 0 here (after ReLU)
+                                hv[k] = (unsigned short)(u >> 16);
+                            } else {
+                                const _Float16 hh = (_Float16)mv[k];
+                                __builtin_memcpy(&hv[k], &hh, 2);
+                            }
+                        }
+                        *reinterpret_cast<uint2*>(static_cast<unsigned short*>(yout) + o) =
+                            make_uint2((unsigned)hv[0] | ((unsigned)hv[1] << 16), (unsigned)hv[2] | ((unsigned)hv[3] << 16));
+                    }
                 }
             }
         }
@@ -253,9 +273,10 @@ extern "C" int tia_stem_pack_weights_f32(const float* d_w_oihw, float* d_packed,
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
-extern "C" int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, float* d_y,
-                                          int64_t n, int64_t h, int64_t w, void* stream) {
+extern "C" int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, void* d_y,
+                                          int32_t y_dtype, int64_t n, int64_t h, int64_t w, void* stream) {
     if (!d_x || !d_w_packed || !d_bias || !d_y || n <= 0 || h <= 0 || w <= 0) return TIA_EINVAL;
+    if (y_dtype != TIA_DT_F32 && y_dtype != TIA_DT_F16 && y_dtype != TIA_DT_BF16) return TIA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w_packed) | reinterpret_cast<uintptr_t>(d_y)) & 15) return TIA_EINVAL;
     if (!x_is_u8 && (reinterpret_cast<uintptr_t>(d_x) & 3)) return TIA_EINVAL;
     const long ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;  // (h + 6 - 7) / 2 + 1
@@ -290,8 +311,8 @@ extern "C" int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, cons
         const int shift = x_is_u8 ? (int)(reinterpret_cast<uintptr_t>(xg) & 3) : 0;
         xg -= shift;
         StemDims d{(int)nb, (int)h, (int)w, (int)ho, (int)wo, (int)hp, (int)wp, (int)chunks, (int)rows,
-                   (unsigned)((nb * image_bytes + shift + 3) & ~3L), shift};
-        float* yg = d_y + first * hp * wp * COUT;
+                   (unsigned)((nb * image_bytes + shift + 3) & ~3L), shift, (int)y_dtype};
+        char* yg = static_cast<char*>(d_y) + first * hp * wp * COUT * (y_dtype == TIA_DT_F32 ? 4 : 2);
         const dim3 grid((unsigned)(nb * chunks), (unsigned)strips);
         if (x_is_u8)
             hipLaunchKernelGGL(stem7x7_pool_kernel<true>, grid, dim3(NTH), lds, st, xg, d_w_packed, d_bias, yg, d);

@@ -316,6 +316,46 @@ def hip_upsample2x_add(x: torch.Tensor, y: torch.Tensor, scale: torch.Tensor | N
     return out
 
 
+def hip_conv2d_h(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor | None, residual: torch.Tensor | None, *,
+                 cout: int, kernel: int, stride: int, padding: int, relu: bool) -> torch.Tensor:
+    """``relu(conv2d(x, w) + bias + residual)`` on an fp16 / bf16 channels-last CUDA tensor (``tia_conv2d_nhwc_h``: MFMA with
+    float32 accumulation; ``bias`` float32; one rounding to half at the end)."""
+    from tiatoolbox_amd import _lib
+
+    if not (_nhwc_ptr_ok(x) and x.dtype in (torch.float16, torch.bfloat16)):
+        msg = "hip_conv2d_h expects an fp16 / bf16 channels-last CUDA tensor."
+        raise ValueError(msg)
+    n, cin, h, w = x.shape
+    ho = (h + 2 * padding - kernel) // stride + 1
+    wo = (w + 2 * padding - kernel) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if residual is not None and not (_nhwc_ptr_ok(residual) and residual.dtype == x.dtype and residual.shape == y.shape):
+        msg = "hip_conv2d_h: residual must be a channels-last CUDA tensor of the output's dtype and shape."
+        raise ValueError(msg)
+    if bias is not None and bias.dtype != torch.float32:
+        msg = "hip_conv2d_h takes the bias in float32."
+        raise ValueError(msg)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_conv2d_nhwc_h(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                                           residual.data_ptr() if residual is not None else 0, y.data_ptr(), n, h, w, cin, cout,
+                                           kernel, kernel, stride, padding, _DT[x.dtype], int(relu), _lib.current_stream())
+    _lib.check(rc, "tia_conv2d_nhwc_h")
+    return y
+
+
+def pack_conv_weights_h(conv: nn.Conv2d, dtype: torch.dtype) -> torch.Tensor:
+    """OIHW -> ``[kh, kw, cin/8, cout, 8]`` halves of ``dtype`` on the convolution's device (``tia_conv_pack_weights_h``)."""
+    from tiatoolbox_amd import _lib
+
+    w = conv.weight.detach().to(torch.float32).contiguous()
+    cout, cin, kh, kw = w.shape
+    out = torch.empty((kh, kw, cin // 8, cout, 8), dtype=dtype, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().tia_conv_pack_weights_h(w.data_ptr(), cout, cin, kh, kw, _DT[dtype], out.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "tia_conv_pack_weights_h")
+    return out
+
+
 def pack_conv_weights(conv: nn.Conv2d) -> torch.Tensor:
     """OIHW -> ``[kh, kw, cin, cout]`` float32 on the convolution's device (``tia_conv_pack_weights_f32``)."""
     from tiatoolbox_amd import _lib
@@ -329,56 +369,82 @@ def pack_conv_weights(conv: nn.Conv2d) -> torch.Tensor:
     return out
 
 
-class _MfmaBasic(nn.Module):
+class _MfmaBlock(nn.Module):
+    """Shared machinery of the hand-written blocks: per-convolution packed weights (float32: ``[kh, kw, cin, cout]``; fp16 /
+    bf16: ``[kh, kw, cin/8, cout, 8]``), float32 biases, and one launch per convolution with its epilogue fused."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self._packed: dict[tuple[str, torch.dtype], torch.Tensor] = {}
+        self._bias32: dict[str, torch.Tensor] = {}
+
+    def _w(self, name: str, dtype: torch.dtype) -> torch.Tensor:
+        conv = getattr(self, name)
+        cached = self._packed.get((name, dtype))
+        if cached is None or cached.device != conv.weight.device:
+            cached = pack_conv_weights(conv) if dtype == torch.float32 else pack_conv_weights_h(conv, dtype)
+            self._packed[(name, dtype)] = cached
+        return cached
+
+    def _b(self, name: str) -> torch.Tensor | None:
+        conv = getattr(self, name)
+        if conv.bias is None:
+            return None
+        cached = self._bias32.get(name)  # kept from before a cast to half (`prepare`): the kernels add the bias in float32
+        if cached is not None and cached.device == conv.bias.device:
+            return cached
+        if conv.bias.dtype == torch.float32:
+            return conv.bias
+        cached = self._bias32[name] = conv.bias.detach().float().contiguous()
+        return cached
+
+    def prepare(self, dtype: torch.dtype) -> None:
+        """Pack the weights for ``dtype`` and keep float32 biases NOW, from the float32 parameters (call before the module is
+        cast to half: packing afterwards would start from weights and biases already rounded to half)."""
+        for name in ("conv1", "conv2", "conv3", "down"):
+            conv = getattr(self, name, None)
+            if conv is None:
+                continue
+            self._w(name, dtype)
+            if conv.bias is not None:
+                self._bias32[name] = conv.bias.detach().float().clone().contiguous()
+
+    def _conv(self, name: str, x: torch.Tensor, residual: torch.Tensor | None, *, relu: bool) -> torch.Tensor:
+        conv = getattr(self, name)
+        k, st, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        if x.dtype == torch.float32:
+            return hip_conv2d(x, self._w(name, x.dtype), self._b(name), residual, kernel=k, stride=st, padding=pad, relu=relu)
+        return hip_conv2d_h(x, self._w(name, x.dtype), self._b(name), residual, cout=conv.out_channels, kernel=k, stride=st,
+                            padding=pad, relu=relu)
+
+
+class _MfmaBasic(_MfmaBlock):
     """BasicBlock as three launches: (downsample) / conv1+bias+ReLU / conv2+bias+residual+ReLU."""
 
     def __init__(self, blk: BasicBlock) -> None:
         super().__init__()
         self.conv1, self.conv2 = blk.conv1, blk.conv2
         self.down = blk.downsample[0] if blk.downsample is not None else None
-        self._packed: dict[str, torch.Tensor] = {}
-
-    def _w(self, name: str) -> torch.Tensor:
-        conv = getattr(self, name)
-        cached = self._packed.get(name)
-        if cached is None or cached.device != conv.weight.device:
-            cached = self._packed[name] = pack_conv_weights(conv)
-        return cached
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        s = self.conv1.stride[0]
-        identity = x
-        if self.down is not None:
-            identity = hip_conv2d(x, self._w("down"), self.down.bias, None, kernel=1, stride=self.down.stride[0], padding=0,
-                                  relu=False)
-        out = hip_conv2d(x, self._w("conv1"), self.conv1.bias, None, kernel=3, stride=s, padding=1, relu=True)
-        return hip_conv2d(out, self._w("conv2"), self.conv2.bias, identity, kernel=3, stride=1, padding=1, relu=True)
+        identity = x if self.down is None else self._conv("down", x, None, relu=False)
+        out = self._conv("conv1", x, None, relu=True)
+        return self._conv("conv2", out, identity, relu=True)
 
 
-class _MfmaBottleneck(nn.Module):
+class _MfmaBottleneck(_MfmaBlock):
     """Bottleneck as (downsample) / 1x1+bias+ReLU / 3x3+bias+ReLU / 1x1+bias+residual+ReLU launches."""
 
     def __init__(self, blk: Bottleneck) -> None:
         super().__init__()
         self.conv1, self.conv2, self.conv3 = blk.conv1, blk.conv2, blk.conv3
         self.down = blk.downsample[0] if blk.downsample is not None else None
-        self._packed: dict[str, torch.Tensor] = {}
-
-    def _w(self, name: str) -> torch.Tensor:
-        conv = getattr(self, name)
-        cached = self._packed.get(name)
-        if cached is None or cached.device != conv.weight.device:
-            cached = self._packed[name] = pack_conv_weights(conv)
-        return cached
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        identity = x
-        if self.down is not None:
-            identity = hip_conv2d(x, self._w("down"), self.down.bias, None, kernel=1, stride=self.down.stride[0], padding=0,
-                                  relu=False)
-        out = hip_conv2d(x, self._w("conv1"), self.conv1.bias, None, kernel=1, stride=self.conv1.stride[0], padding=0, relu=True)
-        out = hip_conv2d(out, self._w("conv2"), self.conv2.bias, None, kernel=3, stride=self.conv2.stride[0], padding=1, relu=True)
-        return hip_conv2d(out, self._w("conv3"), self.conv3.bias, identity, kernel=1, stride=1, padding=0, relu=True)
+        identity = x if self.down is None else self._conv("down", x, None, relu=False)
+        out = self._conv("conv1", x, None, relu=True)
+        out = self._conv("conv2", out, None, relu=True)
+        return self._conv("conv3", out, identity, relu=True)
 
 
 def pack_stem_weights(conv: nn.Conv2d) -> torch.Tensor:
@@ -396,11 +462,13 @@ def pack_stem_weights(conv: nn.Conv2d) -> torch.Tensor:
     return out
 
 
-def hip_stem_conv_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+def hip_stem_conv_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, *,
+                       out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """``maxpool3x3/2(relu(conv7x7/2(x) + bias))`` in one kernel (``tia_stem_conv7x7_pool_nhwc``).
 
     ``x``: NHWC ``[n, h, w, 3]`` contiguous CUDA tensor, ``uint8`` (scaled by 1/255 on load: ``ToTensor``) or ``float32`` (as is).
-    Returns the pooled activations as an NCHW tensor stored channels-last (``[n, 64, hp, wp]``)."""
+    Returns the pooled activations as an NCHW tensor stored channels-last (``[n, 64, hp, wp]``) of ``out_dtype`` (float32
+    arithmetic; fp16 / bf16 = one rounding at the end, for the half-precision trunk)."""
     from tiatoolbox_amd import _lib
 
     if not (x.is_cuda and x.dim() == 4 and x.shape[-1] == 3 and x.is_contiguous() and x.dtype in (torch.uint8, torch.float32)):
@@ -408,19 +476,21 @@ def hip_stem_conv_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tens
         raise ValueError(msg)
     n, h, w, _ = x.shape
     hp, wp = ((h - 1) // 2) // 2 + 1, ((w - 1) // 2) // 2 + 1
-    y = torch.empty((n, 64, hp, wp), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    y = torch.empty((n, 64, hp, wp), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         rc = _lib.load().tia_stem_conv7x7_pool_nhwc(x.data_ptr(), int(x.dtype == torch.uint8), w_packed.data_ptr(), bias.data_ptr(),
-                                                    y.data_ptr(), n, h, w, _lib.current_stream())
+                                                    y.data_ptr(), _DT[out_dtype], n, h, w, _lib.current_stream())
     _lib.check(rc, "tia_stem_conv7x7_pool_nhwc")
     return y
 
 
 class MfmaResNet(nn.Module):
-    """ResNet trunk in float32 on hand-written kernels only: the stem (7x7 / 3 input channels + bias + ReLU + max-pool, one
+    """ResNet trunk on hand-written kernels only: the stem (7x7 / 3 input channels + bias + ReLU + max-pool, one float32 MFMA
     kernel reading uint8 or float32 patches) and every block convolution (BasicBlock: resnet18/34; Bottleneck: resnet50/101) as
-    the MFMA implicit GEMM with its epilogue fused (BN folded, channels-last).  A ``uint8`` input means ``ToTensor`` has been
-    deferred into the stem: the kernel divides by 255 while it loads."""
+    an MFMA implicit GEMM with its epilogue fused (BN folded, channels-last) -- ``tia_conv2d_nhwc_f32`` for float32 (the
+    reference's arithmetic), ``tia_conv2d_nhwc_h`` once the module has been cast to fp16 / bf16 (float32 accumulation; the stem
+    then rounds its float32 result to half once).  A ``uint8`` input means ``ToTensor`` has been deferred into the stem: the
+    kernel divides by 255 while it loads."""
 
     accepts_uint8 = True
 
@@ -448,10 +518,19 @@ class MfmaResNet(nn.Module):
         w = self._stem_packed
         if w is None or w.device != self.stem.weight.device:
             w = self._stem_packed = pack_stem_weights(self.stem)
-        return hip_stem_conv_pool(x, w, self.stem.bias)
+            self._stem_bias = self.stem.bias.detach().float().contiguous()
+        return hip_stem_conv_pool(x, w, self._stem_bias, out_dtype=self.stem.weight.dtype)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.blocks(self.stem_forward(x))
+
+    def prepare(self, dtype: torch.dtype) -> None:
+        """Pack every convolution for ``dtype`` from the float32 parameters (the engine calls this on the device, before it
+        casts the inference copy to half)."""
+        self._stem_packed = pack_stem_weights(self.stem)
+        self._stem_bias = self.stem.bias.detach().float().clone().contiguous()
+        for blk in self.blocks:
+            blk.prepare(dtype)
 
 
 def fuse_cnn_model(model: nn.Module, *, epilogue_fusion: bool | str = False) -> nn.Module:

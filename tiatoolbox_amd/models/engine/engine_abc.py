@@ -335,11 +335,12 @@ class EngineABC:
                 from tiatoolbox_amd.models.architecture.fused import fuse_cnn_model
                 from tiatoolbox_amd.models.architecture.resnet import BasicBlock, Bottleneck
 
-                # float32 on the GPU: ResNet trunks (BasicBlock and Bottleneck) run on the hand-written kernels only -- stem
-                # and block convolutions (architecture/fused.py: MfmaResNet); fp16 / bf16: library convolutions + the
-                # hand-written epilogue passes; CPU: BatchNorm folding only
+                # on the GPU ResNet trunks (BasicBlock and Bottleneck) run on the hand-written kernels only -- stem and block
+                # convolutions (architecture/fused.py: MfmaResNet; float32: tia_conv2d_nhwc_f32, fp16 / bf16:
+                # tia_conv2d_nhwc_h); other trunks in half precision: library convolutions + the hand-written epilogue
+                # passes; CPU: BatchNorm folding only
                 resnet = any(isinstance(mod, (BasicBlock, Bottleneck)) for mod in m.modules())
-                use_mfma = on_gpu and dtype == torch.float32 and resnet
+                use_mfma = on_gpu and resnet
                 m = fuse_cnn_model(m, epilogue_fusion=("mfma" if use_mfma else "hip") if on_gpu else False)
             elif on_gpu and dtype == torch.float32:
                 from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
@@ -357,6 +358,10 @@ class EngineABC:
 
                     m = FusedUNet(m.to(device=self.device))
             m = m.to(device=self.device)
+            if on_gpu:  # hand-written trunks pack their weights (and keep float32 biases) from the float32 parameters
+                for mod in m.modules():
+                    if type(mod).__name__ == "MfmaResNet":
+                        mod.prepare(dtype)
             m = m.to(dtype=dtype) if dtype != torch.float32 else m
             if on_gpu:
                 m = m.to(memory_format=torch.channels_last)
@@ -405,8 +410,8 @@ class EngineABC:
             return hook.device_batch(batch, dtype, defer_unit_scale=True)
         return hook.device_batch(batch, dtype)
 
-    def _set_defer_unit(self, model, dtype: torch.dtype) -> None:
-        self._defer_unit = bool(dtype == torch.float32 and torch.device(self.device).type == "cuda"
+    def _set_defer_unit(self, model, dtype: torch.dtype) -> None:  # noqa: ARG002
+        self._defer_unit = bool(torch.device(self.device).type == "cuda"
                                 and any(getattr(m, "accepts_uint8", False) for m in model.modules()))
 
     def _forward_batch(self, model, infer_batch, batch):
