@@ -5,6 +5,7 @@ from __future__ import annotations
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F  # noqa: N812
 
 from tiatoolbox_amd.models.engine.patch_predictor import PatchPredictor
 from tiatoolbox_amd.utils import synth

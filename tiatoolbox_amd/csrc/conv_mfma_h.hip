@@ -14,9 +14,13 @@
 //         ds_read_b128 services together (rows distinct mod 16) then cover all 16 quads of the 256-byte bank row;
 //       B slice [4 k-chunks][BN columns][8 halves]: the weights are pre-packed [tap][cin/8][cout][8], so a lane's 8 k-values
 //         of its column are contiguous in memory AND in LDS, and lanes walk the columns (linear, conflict-free)
-//   * two LDS stages: the global loads of slice s+1 are issued before the MFMAs of slice s and written to the other stage
-//     after them -- one barrier per slice.  Loads go through buffer descriptors (per slot: byte offset of tap (0,0) + one bit
-//     per kernel row / column, as in conv_mfma.hip); a padding tap gets an out-of-range offset and reads as zeros
+//   * two LDS stages filled by LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without passing through registers or the
+//     ds_write path, which at ~80 B/clk/CU was the bottleneck of the register-staged first version: 508 -> see profiles/r03*):
+//     the DMA of slice s+1 is issued before the MFMAs of slice s and lands in the other stage -- one barrier per slice.  The
+//     LDS image of a DMA is lane-linear, so the XOR swizzle of the A slice sits on the SOURCE side: the thread that fills
+//     position P fetches chunk (P & 3) ^ ((P >> 4) & 3) of pixel P >> 2.  Loads go through buffer descriptors (per slot: byte
+//     offset of tap (0,0) + one bit per kernel row / column, as in conv_mfma.hip); a padding tap gets an out-of-range offset
+//     and the DMA writes zeros
 //   * epilogue through LDS in two column halves: accumulators -> float32 tile [128][BN/2] -> rows re-read 8 columns per lane,
 //     + bias + residual (16-byte loads), ReLU, ONE rounding to half, 16-byte stores (whole 128- or 256-byte output rows)
 //   * blockIdx remapped so that each XCD walks a contiguous range of pixel tiles
@@ -71,6 +75,13 @@ __device__ __forceinline__ unsigned short f32_to_half(float x) {  // round to ne
     }
 }
 
+// 16 bytes per lane from a buffer straight into LDS (buffer_load_dwordx4 ... lds): the wave's 64 lanes fill the 1 KB at
+// `lds_wave_base` in lane order; an out-of-range `voffset` writes zeros.  (A __device__ function: the builtin must not be seen by
+// the host pass, which otherwise drops the kernel's launch stub.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
 template <int BN, bool BF>
 __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restrict__ x, const void* __restrict__ wk,
                                                           const float* __restrict__ bias, const void* __restrict__ res,
@@ -96,8 +107,9 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restr
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)d.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wk), 0, (int)d.w_bytes, 0x00020000);
 
-    // ---- A staging: thread -> 2 (pixel, 16-byte chunk) slots: pixel = tid / 4 + 64 r, chunk = tid % 4 ----
-    const int chunk = tid & 3;
+    // ---- A staging: thread -> LDS positions P = tid + 256 r (r = 0, 1; 16-byte units, lane-linear as the DMA writes them):
+    //      pixel = P >> 2 = tid / 4 + 64 r, source chunk = (P & 3) ^ ((pixel >> 2) & 3) = (tid & 3) ^ ((tid >> 4) & 3) ----
+    const int chunk = (tid & 3) ^ ((tid >> 4) & 3);
     int cen[2];
     unsigned msk[2];
 #pragma unroll
@@ -115,13 +127,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restr
         for (int t = 0; t < d.kw; ++t) cols |= (unsigned)((unsigned)(ix0 + t) < (unsigned)d.w) << (16 + t);
         msk[r] = pvalid ? (rows | cols) : 0u;
     }
-    // LDS positions (16-byte units) of the thread's A slots: pixel * 4 + (chunk ^ ((pixel >> 2) & 3))
-    int a_pos[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int p = (tid >> 2) + 64 * r;
-        a_pos[r] = p * 4 + (chunk ^ ((p >> 2) & 3));
-    }
     // B slots: linear index idx = tid + 256 r over [4 k-chunks][BN columns]; global: ((tap * cin/8 + c0/8 + kc) * cout + n0 + col) * 16
     int b_off[B_SLOTS];
 #pragma unroll
@@ -132,32 +137,26 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restr
     }
 
     int s_kh = 0, s_kw = 0, s_c0 = 0;
-    u32x4 ra[2], rb[B_SLOTS];
-    auto load_slice = [&]() {
+    // DMA of the slice under the cursor into `stage`: wave w, instruction r writes the 1 KB at position (w * 64 + 256 r) * 16
+    auto dma_slice = [&](int stage) {
         const int sdelta = ((s_kh * d.w + s_kw) * d.cin + s_c0) * 2;
         const unsigned sel = (1u << s_kh) | (1u << (16 + s_kw));
         const int swrow = ((s_kh * d.kw + s_kw) * (d.cin >> 3) + (s_c0 >> 3)) * d.cout * 16;
+        unsigned char* sa = smem + stage * STAGE + wave * 1024;
+        unsigned char* sb = smem + stage * STAGE + A_BYTES + wave * 1024;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const bool ok = (msk[r] & sel) == sel;
-            ra[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? cen[r] + sdelta : OOB, 0, 0);
+            dma16(rx, sa + r * 4096, ok ? cen[r] + sdelta : OOB, 0);
         }
 #pragma unroll
-        for (int r = 0; r < B_SLOTS; ++r) rb[r] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_off[r], swrow, 0);
+        for (int r = 0; r < B_SLOTS; ++r) dma16(rw, sb + r * 4096, b_off[r], swrow);
     };
     auto next_slice = [&]() {
         int c0 = s_c0 + BK, kw = s_kw, kh = s_kh;
         if (c0 == d.cin) { c0 = 0; ++kw; }
         if (kw == d.kw) { kw = 0; ++kh; }
         if (kh < d.kh) { s_c0 = c0; s_kw = kw; s_kh = kh; }
-    };
-    auto store_slice = [&](int stage) {
-        u32x4* sa = reinterpret_cast<u32x4*>(smem + stage * STAGE);
-        u32x4* sb = reinterpret_cast<u32x4*>(smem + stage * STAGE + A_BYTES);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) sa[a_pos[r]] = ra[r];
-#pragma unroll
-        for (int r = 0; r < B_SLOTS; ++r) sb[tid + NTH * r] = rb[r];
     };
 
     f32x16 acc[2][NTILE];
@@ -181,14 +180,13 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restr
     const int fb0 = (lane >> 5) * BN + wn * (BN / 2) + (lane & 31);
 
     const int n_slices = d.kh * d.kw * (d.cin / BK);
-    load_slice();
-    store_slice(0);
-    __syncthreads();
+    dma_slice(0);
+    __syncthreads();  // (waits for the DMA: an LDS-DMA is a pending LDS write, so the barrier's release carries vmcnt(0))
     for (int sidx = 0; sidx < n_slices; ++sidx) {
         const int cur = sidx & 1;
         next_slice();
-        load_slice();  // the next slice's global loads fly behind this slice's MFMAs (the last iteration re-reads its own)
-        __builtin_amdgcn_sched_barrier(0);
+        dma_slice(cur ^ 1);  // the next slice lands in the other stage behind this slice's MFMAs (the last iteration re-fetches
+                             // its own slice: no control flow around the loads); nobody reads that stage any more
         const u32x4* sa = reinterpret_cast<const u32x4*>(smem + cur * STAGE);
         const u32x4* sb = reinterpret_cast<const u32x4*>(smem + cur * STAGE + A_BYTES);
         u32x4 a[2][2], b[2][NTILE];
@@ -205,8 +203,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restr
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NTILE; ++j) acc[i][j] = mma<BF>(a[q][i], b[q][j], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
-        store_slice(cur ^ 1);  // nobody reads that stage any more (everyone passed the previous barrier)
         __syncthreads();
     }
 
