@@ -106,7 +106,7 @@ def test_stem_wrapper_refuses_what_it_cannot_take():
         hip_stem_conv_pool(torch.zeros((1, 3, 8, 8), dtype=torch.uint8, device="cuda"), wp, conv.bias.detach())
     with pytest.raises(ValueError, match="stem kernel"):
         pack_stem_weights(torch.nn.Conv2d(3, 64, 3, 1, 1).cuda())
-    assert _lib.load().tia_stem_conv7x7_pool_nhwc(0, 1, 0, 0, 0, 1, 8, 8, None) != 0
+    assert _lib.load().tia_stem_conv7x7_pool_nhwc(0, 1, 0, 0, 0, 0, 1, 8, 8, None) != 0
 
 
 @pytest.mark.gpu

@@ -14,9 +14,9 @@
 //         ds_read_b128 services together (rows distinct mod 16) then cover all 16 quads of the 256-byte bank row;
 //       B slice [4 k-chunks][BN columns][8 halves]: the weights are pre-packed [tap][cin/8][cout][8], so a lane's 8 k-values
 //         of its column are contiguous in memory AND in LDS, and lanes walk the columns (linear, conflict-free)
-//   * two LDS stages filled by LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without passing through registers or the
+//   * a ring of three LDS stages filled by LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without passing through registers or the
 //     ds_write path, which at ~80 B/clk/CU was the bottleneck of the register-staged first version: 508 -> see profiles/r03*):
-//     the DMA of slice s+1 is issued before the MFMAs of slice s and lands in the other stage -- one barrier per slice.  The
+//     the DMA of slice s+2 is issued before the MFMAs of slice s, one raw barrier and one counted vmcnt per slice.  The
 //     LDS image of a DMA is lane-linear, so the XOR swizzle of the A slice sits on the SOURCE side: the thread that fills
 //     position P fetches chunk (P & 3) ^ ((P >> 4) & 3) of pixel P >> 2.  Loads go through buffer descriptors (per slot: byte
 //     offset of tap (0,0) + one bit per kernel row / column, as in conv_mfma.hip); a padding tap gets an out-of-range offset
@@ -26,13 +26,13 @@
 //   * blockIdx remapped so that each XCD walks a contiguous range of pixel tiles
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/tiatoolbox_amd.h"
 
 namespace {
 
 constexpr int BM = 128;
-constexpr int BK = 32;
 constexpr int NTH = 256;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -82,16 +82,23 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
-template <int BN, bool BF>
+template <int BN, bool BF, int BK>
 __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restrict__ x, const void* __restrict__ wk,
                                                           const float* __restrict__ bias, const void* __restrict__ res,
                                                           void* __restrict__ y, ConvDimsH d, int relu, int m_tiles) {
+    static_assert(BK == 32 || BK == 64, "slices of 32 or 64 input channels");
     constexpr int NTILE = BN / 64;
-    constexpr int A_BYTES = BM * BK * 2;             // 8 KB per stage
-    constexpr int B_BYTES = BK * BN * 2;             // 8 / 4 KB per stage
+    constexpr int CH = BK / 8;                       // 16-byte chunks (8 halves) per pixel and slice
+    constexpr int KS = BK / 16;                      // MFMA k-steps per slice
+    constexpr int SH = CH == 4 ? 2 : 1;              // swizzle: chunk ^ ((pixel >> SH) & (CH - 1)) spreads 16 rows over 16 quads
+    constexpr int A_BYTES = BM * BK * 2;             // 8 | 16 KB per stage
+    constexpr int B_BYTES = BK * BN * 2;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int B_SLOTS = (BK / 8) * BN / NTH;     // 16-byte weight chunks per thread and slice: 2 (BN 128) | 1 (BN 64)
-    constexpr int LDS_BYTES = 2 * STAGE > BM * (BN / 2) * 4 ? 2 * STAGE : BM * (BN / 2) * 4;
+    constexpr int A_SLOTS = BM * CH / NTH;           // 16-byte pixel chunks per thread and slice: 2 | 4
+    constexpr int B_SLOTS = CH * BN / NTH;           // 16-byte weight chunks per thread and slice
+    constexpr int NSTAGE = BK == 32 ? 3 : 2;         // LDS ring (BK 32: slice s is consumed while s+1 and s+2 are in flight)
+    constexpr int DMA_PER_SLICE = A_SLOTS + B_SLOTS; // LDS-DMA instructions a thread issues per slice (vmcnt bookkeeping)
+    constexpr int LDS_BYTES = NSTAGE * STAGE > BM * (BN / 2) * 4 ? NSTAGE * STAGE : BM * (BN / 2) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int bid = blockIdx.x;
@@ -107,14 +114,14 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restr
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)d.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wk), 0, (int)d.w_bytes, 0x00020000);
 
-    // ---- A staging: thread -> LDS positions P = tid + 256 r (r = 0, 1; 16-byte units, lane-linear as the DMA writes them):
-    //      pixel = P >> 2 = tid / 4 + 64 r, source chunk = (P & 3) ^ ((pixel >> 2) & 3) = (tid & 3) ^ ((tid >> 4) & 3) ----
-    const int chunk = (tid & 3) ^ ((tid >> 4) & 3);
-    int cen[2];
-    unsigned msk[2];
+    // ---- A staging: thread -> LDS positions P = tid + 256 r (16-byte units, lane-linear as the DMA writes them):
+    //      pixel = P / CH = tid / CH + (256 / CH) r, source chunk = (P % CH) ^ ((pixel >> SH) & (CH - 1)), the same for every r ----
+    const int chunk = (tid & (CH - 1)) ^ (((tid / CH) >> SH) & (CH - 1));
+    int cen[A_SLOTS];
+    unsigned msk[A_SLOTS];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const long m = m0 + (tid >> 2) + 64 * r;
+    for (int r = 0; r < A_SLOTS; ++r) {
+        const long m = m0 + tid / CH + (NTH / CH) * r;
         const bool pvalid = m < m_total;
         const int mm = pvalid ? (int)m : 0;
         const int b = mm / (d.ho * d.wo);
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restr
         for (int t = 0; t < d.kw; ++t) cols |= (unsigned)((unsigned)(ix0 + t) < (unsigned)d.w) << (16 + t);
         msk[r] = pvalid ? (rows | cols) : 0u;
     }
-    // B slots: linear index idx = tid + 256 r over [4 k-chunks][BN columns]; global: ((tap * cin/8 + c0/8 + kc) * cout + n0 + col) * 16
+    // B slots: linear index idx = tid + 256 r over [CH k-chunks][BN columns]; global: ((tap * cin/8 + c0/8 + kc) * cout + n0 + col) * 16
     int b_off[B_SLOTS];
 #pragma unroll
     for (int r = 0; r < B_SLOTS; ++r) {
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restr
         unsigned char* sa = smem + stage * STAGE + wave * 1024;
         unsigned char* sb = smem + stage * STAGE + A_BYTES + wave * 1024;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < A_SLOTS; ++r) {
             const bool ok = (msk[r] & sel) == sel;
             dma16(rx, sa + r * 4096, ok ? cen[r] + sdelta : OOB, 0);
         }
@@ -168,43 +175,76 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restr
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     // fragment positions (16-byte units): A tile i, k-step q: pixel p = wm*64 + i*32 + (lane & 31), chunk c = 2 q + (lane >> 5)
-    int fa[2][2];
+    int fa[2][KS];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < KS; ++q) {
             const int p = wm * 64 + i * 32 + (lane & 31), c = 2 * q + (lane >> 5);
-            fa[i][q] = p * 4 + (c ^ ((p >> 2) & 3));
+            fa[i][q] = p * CH + (c ^ ((p >> SH) & (CH - 1)));
         }
     // B tile j, k-step q: k-chunk 2 q + (lane >> 5), column wn * (BN/2) + j*32 + (lane & 31)
     const int fb0 = (lane >> 5) * BN + wn * (BN / 2) + (lane & 31);
 
-    const int n_slices = d.kh * d.kw * (d.cin / BK);
-    dma_slice(0);
-    __syncthreads();  // (waits for the DMA: an LDS-DMA is a pending LDS write, so the barrier's release carries vmcnt(0))
-    for (int sidx = 0; sidx < n_slices; ++sidx) {
-        const int cur = sidx & 1;
-        next_slice();
-        dma_slice(cur ^ 1);  // the next slice lands in the other stage behind this slice's MFMAs (the last iteration re-fetches
-                             // its own slice: no control flow around the loads); nobody reads that stage any more
-        const u32x4* sa = reinterpret_cast<const u32x4*>(smem + cur * STAGE);
-        const u32x4* sb = reinterpret_cast<const u32x4*>(smem + cur * STAGE + A_BYTES);
-        u32x4 a[2][2], b[2][NTILE];
+    auto compute = [&](int stage) {
+        const u32x4* sa = reinterpret_cast<const u32x4*>(smem + stage * STAGE);
+        const u32x4* sb = reinterpret_cast<const u32x4*>(smem + stage * STAGE + A_BYTES);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < KS; ++q) {
+            u32x4 a[2], b[NTILE];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[q][i] = sa[fa[i][q]];
+            for (int i = 0; i < 2; ++i) a[i] = sa[fa[i][q]];
 #pragma unroll
-            for (int j = 0; j < NTILE; ++j) b[q][j] = sb[fb0 + 2 * q * BN + j * 32];
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
+            for (int j = 0; j < NTILE; ++j) b[j] = sb[fb0 + 2 * q * BN + j * 32];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NTILE; ++j) acc[i][j] = mma<BF>(a[q][i], b[q][j], acc[i][j]);
-        __syncthreads();
+                for (int j = 0; j < NTILE; ++j) acc[i][j] = mma<BF>(a[i], b[j], acc[i][j]);
+        }
+    };
+
+    const int n_slices = d.kh * d.kw * (d.cin / BK);
+    if constexpr (NSTAGE == 3) {
+        // Three-stage ring with COUNTED waits: the DMA of slice s+2 is issued at the top of iteration s, and the iteration ends
+        // by waiting only for slice s+1 (vmcnt(DMA_PER_SLICE): the instructions just issued for s+2 stay in flight across the
+        // barrier).  Raw s_barrier: __syncthreads() would drain the DMA queue (an LDS-DMA is a pending LDS write).  A stage is
+        // read in the iteration AFTER the wait + barrier that retired it; every LDS read of a stage has returned (lgkmcnt(0))
+        // before the wave arrives at the barrier behind which the stage is refilled.
+        dma_slice(0);
+        next_slice();
+        dma_slice(1);
+        if constexpr (DMA_PER_SLICE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int sidx = 0; sidx < n_slices; ++sidx) {
+            next_slice();
+            int nxt2 = cur + 2;
+            nxt2 = nxt2 >= NSTAGE ? nxt2 - NSTAGE : nxt2;
+            dma_slice(nxt2);  // past the last slice the cursor stays put: the tail re-fetches the last slice (no control flow)
+            compute(cur);
+            if constexpr (DMA_PER_SLICE == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+        }
+    } else {
+        // Two stages of 64-channel slices (whole 128-byte lines per pixel, 4 k-steps = 16 MFMAs per wave between barriers): the
+        // DMA of slice s+1 is issued before the MFMAs of slice s and must have landed at the barrier that ends the iteration.
+        dma_slice(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int sidx = 0; sidx < n_slices; ++sidx) {
+            const int cur = sidx & 1;
+            next_slice();
+            dma_slice(cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's surplus DMAs must land before the epilogue reuses the LDS
+    __syncthreads();
 
     // ---- epilogue: per column half h (= the waves with wn == h): accumulators -> float32 LDS tile [128][BN/2], then every thread
     //      takes rows x 8-column chunks: + bias + residual, ReLU, round once, 16-byte stores ----
@@ -308,7 +348,7 @@ extern "C" int tia_conv2d_nhwc_h(const void* d_x, const void* d_w_packed, const 
                                  int64_t pad, int32_t dtype, int32_t relu, void* stream) {
     if (!d_x || !d_w_packed || !d_y || n <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return TIA_EINVAL;
     if (dtype != TIA_DT_F16 && dtype != TIA_DT_BF16) return TIA_EINVAL;
-    if (cin % BK != 0 || cout % 64 != 0) return TIA_ESIZE;
+    if (cin % 32 != 0 || cout % 64 != 0) return TIA_ESIZE;
     if (((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_w_packed) | reinterpret_cast<uintptr_t>(d_y) |
           reinterpret_cast<uintptr_t>(d_residual) | reinterpret_cast<uintptr_t>(d_bias)) & 15) != 0)
         return TIA_EINVAL;
@@ -332,19 +372,23 @@ extern "C" int tia_conv2d_nhwc_h(const void* d_x, const void* d_w_packed, const 
         const char* rg = d_residual ? static_cast<const char*>(d_residual) + first * ho * wo * cout * 2 : nullptr;
         char* yg = static_cast<char*>(d_y) + first * ho * wo * cout * 2;
         const long grid_x = ((m_tiles + 7) / 8) * 8;
-        if (cout % 128 == 0) {
-            const dim3 grid((unsigned)grid_x, (unsigned)(cout / 128));
-            if (bf)
-                hipLaunchKernelGGL((conv_mfma_h_kernel<128, true>), grid, dim3(NTH), 0, st, xg, d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles);
-            else
-                hipLaunchKernelGGL((conv_mfma_h_kernel<128, false>), grid, dim3(NTH), 0, st, xg, d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles);
+        // 64-channel slices (two stages, 16 MFMAs per barrier, whole cache lines per pixel) measured no faster than 32-channel
+        // slices in a three-stage ring (profiles/r03e_perf_conv_h*.txt: 527 vs 539 TF/s over the resnet18 trunk; slower on the
+        // 1x1 convolutions): both sit on the global -> LDS byte rate, not on latency or barriers.  Kept as a developer switch.
+        static const bool want64 = getenv("TIA_CONVH_BK64") != nullptr;
+        const bool bk64 = cin % 64 == 0 && want64;
+        const bool wide = cout % 128 == 0;
+        const dim3 grid((unsigned)grid_x, (unsigned)(cout / (wide ? 128 : 64)));
+#define TIA_LAUNCH_H(BN_, BF_, BK_) \
+    hipLaunchKernelGGL((conv_mfma_h_kernel<BN_, BF_, BK_>), grid, dim3(NTH), 0, st, xg, d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles)
+        if (wide) {
+            if (bf) { if (bk64) TIA_LAUNCH_H(128, true, 64); else TIA_LAUNCH_H(128, true, 32); }
+            else { if (bk64) TIA_LAUNCH_H(128, false, 64); else TIA_LAUNCH_H(128, false, 32); }
         } else {
-            const dim3 grid((unsigned)grid_x, (unsigned)(cout / 64));
-            if (bf)
-                hipLaunchKernelGGL((conv_mfma_h_kernel<64, true>), grid, dim3(NTH), 0, st, xg, d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles);
-            else
-                hipLaunchKernelGGL((conv_mfma_h_kernel<64, false>), grid, dim3(NTH), 0, st, xg, d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles);
+            if (bf) { if (bk64) TIA_LAUNCH_H(64, true, 64); else TIA_LAUNCH_H(64, true, 32); }
+            else { if (bk64) TIA_LAUNCH_H(64, false, 64); else TIA_LAUNCH_H(64, false, 32); }
         }
+#undef TIA_LAUNCH_H
     }
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
