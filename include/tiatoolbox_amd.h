@@ -434,9 +434,11 @@ int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const fl
  *   x_is_u8 == 0: d_x is float32 NHWC and X = x.
  *   d_x [n,h,w,3]   d_w_packed [148,64] from tia_stem_pack_weights_f32   d_bias [64]
  *   d_y [n,hp,wp,64] of y_dtype (TIA_DT_F32; TIA_DT_F16 / TIA_DT_BF16: rounded once, for the half-precision trunk),
- *   hp = ((h-1)/2)/2 + 1 (likewise wp); arithmetic: a float32 fmaf chain in (ky, kx, c) order on the matrix cores. */
+ *   hp = ((h-1)/2)/2 + 1 (likewise wp); arithmetic: a float32 fmaf chain in (ky, kx, c) order on the matrix cores.
+ *   d_conv_out (may be NULL): also write relu(conv + bias) BEFORE the pooling, [n,ho,wo,64] float32, ho = (h-1)/2 + 1 -- the
+ *   first skip connection of the UNet decoder (models/architecture/unet.py:356-372, ResNetEncoder features). */
 int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, void* d_y,
-                               int32_t y_dtype, int64_t n, int64_t h, int64_t w, void* stream);
+                               int32_t y_dtype, float* d_conv_out, int64_t n, int64_t h, int64_t w, void* stream);
 /* OIHW [64,3,7,7] float32 -> [148,64]: rows (ky, kx, c), one zero row at the end. */
 int tia_stem_pack_weights_f32(const float* d_w_oihw, float* d_packed, void* stream);
 

@@ -62,8 +62,20 @@ def torch_kernels(monkeypatch):
         out = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + y
         return out if scale is None else F.relu(out * scale[None, :, None, None] + shift[None, :, None, None])
 
+    def stem(x_nhwc, wp, bias, *, out_dtype=torch.float32, return_conv=False):  # noqa: ARG001
+        w = wp[:147].view(7, 7, 3, 64).permute(3, 2, 0, 1)
+        xf = x_nhwc.float().div(255) if x_nhwc.dtype == torch.uint8 else x_nhwc
+        conv = F.relu(F.conv2d(xf.permute(0, 3, 1, 2), w, bias, 2, 3))
+        pooled = F.max_pool2d(conv, 3, 2, 1)
+        return (pooled, conv) if return_conv else pooled
+
+    def pack_stem(weight):
+        return torch.cat([weight.detach().permute(2, 3, 1, 0).reshape(147, 64), torch.zeros(1, 64)])
+
     monkeypatch.setattr(hf, "hip_upsample2x_add", up)
     monkeypatch.setattr(uf, "hip_upsample2x_add", up)
+    monkeypatch.setattr(uf, "hip_stem_conv_pool", stem)
+    monkeypatch.setattr(uf, "pack_stem_weights", pack_stem)
     return hf, uf
 
 

@@ -228,7 +228,7 @@ def test_hip_gather_patches_matches_padded_slicing():
 
 @pytest.mark.gpu
 def test_fused_unet_forward_matches_plain_module():
-    """``FusedUNet`` (61 of 63 convolutions on the MFMA kernel: Bottlenecks as conv+BN+ReLU / conv+BN+identity+ReLU
+    """``FusedUNet`` (stem on the stem kernel, 61 of the other 62 convolutions on the MFMA kernel: Bottlenecks as conv+BN+ReLU / conv+BN+identity+ReLU
     launches, up-sampling fused with the skip add, decoder pre-activations in one pass) against the plain torch module
     on the CPU in float32 with randomised BN statistics: logits within 2e-4 of their range; and it is what the engine
     runs for float32 on the GPU."""
@@ -255,5 +255,11 @@ def test_fused_unet_forward_matches_plain_module():
         got = FusedUNet(copy.deepcopy(model).cuda()).cuda()(x.cuda().contiguous(memory_format=torch.channels_last)).cpu()
     assert got.shape == ref.shape == (2, 5, 128, 160)
     assert (got - ref).abs().max() <= 2e-4 * max(float(ref.abs().max()), 1.0)
+    # the uint8 batch as `infer_batch` hands it over (NCHW view of the NHWC bytes): the stem kernel's x / 255 on load
+    with torch.inference_mode():
+        fused = FusedUNet(copy.deepcopy(model).cuda()).cuda()
+        xb = x.to(torch.uint8).permute(0, 2, 3, 1).contiguous().cuda()
+        got_u8 = fused(xb.permute(0, 3, 1, 2)).cpu()
+    assert torch.equal(got_u8, got)
     eng = SemanticSegmentor(model, batch_size=2, device="cuda")
     assert type(eng._inference_model(torch.float32)).__name__ == "FusedUNet"

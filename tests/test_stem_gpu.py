@@ -51,6 +51,13 @@ def test_stem_kernel_matches_unfused_torch_ops(shape):
     assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
     err = (got.cpu() - ref).abs().max().item()
     assert err <= 1e-5, err  # float32 summation order only
+    # the pre-pool activation as a second output (the UNet's first skip connection); the pooled output does not change
+    got2, conv_out = hip_stem_conv_pool(x.cuda(), wp, conv_d.bias.detach(), return_conv=True)
+    with torch.inference_mode():
+        ref_conv = F.relu(F.conv2d(x.float().div(255).permute(0, 3, 1, 2), conv.weight, conv.bias, 2, 3))
+    assert torch.equal(got2, got) and conv_out.shape == ref_conv.shape
+    assert (conv_out.cpu() - ref_conv).abs().max().item() <= 1e-5
+    assert torch.equal(F.max_pool2d(conv_out, 3, 2, 1), got)  # the two outputs are the same numbers
     # float32 input: same values, no 1/255 on load
     xf = x.float().div(255)
     got_f = hip_stem_conv_pool(xf.cuda(), wp, conv_d.bias.detach())
@@ -106,7 +113,7 @@ def test_stem_wrapper_refuses_what_it_cannot_take():
         hip_stem_conv_pool(torch.zeros((1, 3, 8, 8), dtype=torch.uint8, device="cuda"), wp, conv.bias.detach())
     with pytest.raises(ValueError, match="stem kernel"):
         pack_stem_weights(torch.nn.Conv2d(3, 64, 3, 1, 1).cuda())
-    assert _lib.load().tia_stem_conv7x7_pool_nhwc(0, 1, 0, 0, 0, 0, 1, 8, 8, None) != 0
+    assert _lib.load().tia_stem_conv7x7_pool_nhwc(0, 1, 0, 0, 0, 0, 0, 1, 8, 8, None) != 0
 
 
 @pytest.mark.gpu

@@ -52,7 +52,7 @@ struct StemDims {
 
 template <bool U8>
 __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __restrict__ xin, const float* __restrict__ wpk,
-                                                             const float* __restrict__ bias, void* __restrict__ yout, StemDims d) {
+                                                             const float* __restrict__ bias, void* __restrict__ yout, float* __restrict__ yconv, StemDims d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ring = smem;
     float* lut = smem + LUT_OFF;
@@ -201,6 +201,11 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
                 const float v = fmaxf(carry[j][e], fmaxf(r0, r1));
                 carry[j][e] = r1;
                 ring[lcol * COUT + j * 32 + (lane & 31)] = v;
+                if (yconv != nullptr && py >= q0 && colok) {  // the pre-pool activation too (UNet's first skip connection)
+                    float* o = yconv + (((long)img * d.ho + 2 * py) * d.wo + c_start + lcol) * COUT + j * 32 + (lane & 31);
+                    if (row0) o[0] = r0;
+                    if (row1) o[(long)d.wo * COUT] = r1;
+                }
             }
         }
         __syncthreads();
@@ -274,7 +279,7 @@ extern "C" int tia_stem_pack_weights_f32(const float* d_w_oihw, float* d_packed,
 }
 
 extern "C" int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, void* d_y,
-                                          int32_t y_dtype, int64_t n, int64_t h, int64_t w, void* stream) {
+                                          int32_t y_dtype, float* d_conv_out, int64_t n, int64_t h, int64_t w, void* stream) {
     if (!d_x || !d_w_packed || !d_bias || !d_y || n <= 0 || h <= 0 || w <= 0) return TIA_EINVAL;
     if (y_dtype != TIA_DT_F32 && y_dtype != TIA_DT_F16 && y_dtype != TIA_DT_BF16) return TIA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w_packed) | reinterpret_cast<uintptr_t>(d_y)) & 15) return TIA_EINVAL;
@@ -313,11 +318,12 @@ extern "C" int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, cons
         StemDims d{(int)nb, (int)h, (int)w, (int)ho, (int)wo, (int)hp, (int)wp, (int)chunks, (int)rows,
                    (unsigned)((nb * image_bytes + shift + 3) & ~3L), shift, (int)y_dtype};
         char* yg = static_cast<char*>(d_y) + first * hp * wp * COUT * (y_dtype == TIA_DT_F32 ? 4 : 2);
+        float* cg = d_conv_out ? d_conv_out + first * ho * wo * COUT : nullptr;
         const dim3 grid((unsigned)(nb * chunks), (unsigned)strips);
         if (x_is_u8)
-            hipLaunchKernelGGL(stem7x7_pool_kernel<true>, grid, dim3(NTH), lds, st, xg, d_w_packed, d_bias, yg, d);
+            hipLaunchKernelGGL(stem7x7_pool_kernel<true>, grid, dim3(NTH), lds, st, xg, d_w_packed, d_bias, yg, cg, d);
         else
-            hipLaunchKernelGGL(stem7x7_pool_kernel<false>, grid, dim3(NTH), lds, st, xg, d_w_packed, d_bias, yg, d);
+            hipLaunchKernelGGL(stem7x7_pool_kernel<false>, grid, dim3(NTH), lds, st, xg, d_w_packed, d_bias, yg, cg, d);
     }
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

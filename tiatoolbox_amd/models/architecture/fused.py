@@ -447,12 +447,15 @@ class _MfmaBottleneck(_MfmaBlock):
         return self._conv("conv3", out, identity, relu=True)
 
 
-def pack_stem_weights(conv: nn.Conv2d) -> torch.Tensor:
-    """OIHW ``[64, 3, 7, 7]`` -> the stem GEMM's B matrix ``[148, 64]`` (``(ky, kx, c)`` rows + one zero row)."""
+def pack_stem_weights(conv) -> torch.Tensor:
+    """OIHW ``[64, 3, 7, 7]`` -> the stem GEMM's B matrix ``[148, 64]`` (``(ky, kx, c)`` rows + one zero row).  ``conv``: the
+    ``nn.Conv2d`` (stride 2, padding 3 are checked) or its (BN-folded) weight tensor."""
     from tiatoolbox_amd import _lib
 
-    w = conv.weight.detach().to(torch.float32).contiguous()
-    if tuple(w.shape) != (64, 3, 7, 7) or conv.stride != (2, 2) or conv.padding != (3, 3):
+    weight = conv.weight if isinstance(conv, nn.Module) else conv
+    w = weight.detach().to(torch.float32).contiguous()
+    geometry_ok = not isinstance(conv, nn.Conv2d) or (conv.stride == (2, 2) and conv.padding == (3, 3))
+    if tuple(w.shape) != (64, 3, 7, 7) or not geometry_ok:
         msg = f"the stem kernel is conv7x7 / stride 2 / pad 3, 3 -> 64 channels; got weight {tuple(w.shape)}."
         raise ValueError(msg)
     out = torch.empty((148, 64), dtype=torch.float32, device=w.device)
@@ -463,12 +466,13 @@ def pack_stem_weights(conv: nn.Conv2d) -> torch.Tensor:
 
 
 def hip_stem_conv_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, *,
-                       out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                       out_dtype: torch.dtype = torch.float32, return_conv: bool = False):
     """``maxpool3x3/2(relu(conv7x7/2(x) + bias))`` in one kernel (``tia_stem_conv7x7_pool_nhwc``).
 
     ``x``: NHWC ``[n, h, w, 3]`` contiguous CUDA tensor, ``uint8`` (scaled by 1/255 on load: ``ToTensor``) or ``float32`` (as is).
     Returns the pooled activations as an NCHW tensor stored channels-last (``[n, 64, hp, wp]``) of ``out_dtype`` (float32
-    arithmetic; fp16 / bf16 = one rounding at the end, for the half-precision trunk)."""
+    arithmetic; fp16 / bf16 = one rounding at the end, for the half-precision trunk).  ``return_conv=True``: ``(pooled, conv)``
+    with ``conv = relu(conv7x7(x) + bias)`` before the pooling (``[n, 64, ho, wo]`` float32, the UNet's first skip)."""
     from tiatoolbox_amd import _lib
 
     if not (x.is_cuda and x.dim() == 4 and x.shape[-1] == 3 and x.is_contiguous() and x.dtype in (torch.uint8, torch.float32)):
@@ -477,11 +481,16 @@ def hip_stem_conv_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tens
     n, h, w, _ = x.shape
     hp, wp = ((h - 1) // 2) // 2 + 1, ((w - 1) // 2) // 2 + 1
     y = torch.empty((n, 64, hp, wp), dtype=out_dtype, device=x.device, memory_format=torch.channels_last)
+    conv = None
+    if return_conv:
+        conv = torch.empty((n, 64, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device,
+                           memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         rc = _lib.load().tia_stem_conv7x7_pool_nhwc(x.data_ptr(), int(x.dtype == torch.uint8), w_packed.data_ptr(), bias.data_ptr(),
-                                                    y.data_ptr(), _DT[out_dtype], n, h, w, _lib.current_stream())
+                                                    y.data_ptr(), _DT[out_dtype], conv.data_ptr() if conv is not None else 0, n, h, w,
+                                                    _lib.current_stream())
     _lib.check(rc, "tia_stem_conv7x7_pool_nhwc")
-    return y
+    return (y, conv) if return_conv else y
 
 
 class MfmaResNet(nn.Module):

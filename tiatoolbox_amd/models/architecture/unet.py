@@ -137,9 +137,12 @@ class UNetModel(ModelABC):
         if not isinstance(batch_data, torch.Tensor):
             batch_data = torch.as_tensor(np.asarray(batch_data))
         param = next(model.parameters())
-        imgs = batch_data.to(device).to(param.dtype).permute(0, 3, 1, 2)
-        if torch.device(device).type == "cuda":
-            imgs = imgs.contiguous(memory_format=torch.channels_last)
+        if getattr(model, "accepts_uint8", False) and batch_data.dtype == torch.uint8 and batch_data.is_cuda:
+            imgs = batch_data.permute(0, 3, 1, 2)  # the fused graph's stem kernel reads the bytes (x / 255 on load)
+        else:
+            imgs = batch_data.to(device).to(param.dtype).permute(0, 3, 1, 2)
+            if torch.device(device).type == "cuda":
+                imgs = imgs.contiguous(memory_format=torch.channels_last)
         _, _, h, w = imgs.shape
         model.eval()
         with torch.inference_mode():

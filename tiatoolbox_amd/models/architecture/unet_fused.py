@@ -8,7 +8,9 @@ Same arithmetic graph as ``UNetModel.forward`` (reference ``models/architecture/
 * decoder (pre-activation blocks ``BN -> ReLU -> conv -> BN -> ReLU -> conv`` after ``upsample2x(x) + skip``): the
   up-sampling, the skip add and the first BN + ReLU in one pass, the second BN folded into the first
   convolution;
-* the 3-channel 7x7 stem and the final ``64 -> n_classes`` 1x1 stay on MIOpen; the max-pool is torch's.
+* the stem -- ``x / 255`` (on load, from the uint8 patch), 7x7 / 2 convolution + BN + ReLU AND the 3x3 / 2 max-pool -- is ONE
+  launch of the hand-written stem kernel, which also writes the pre-pool activation (the decoder's first skip connection);
+* only the final ``64 -> n_classes`` 1x1 stays on the library.
 
 Built from a loaded model (reference parameter names); float32, CUDA, channels-last only.
 """
@@ -19,7 +21,7 @@ import torch
 import torch.nn.functional as F  # noqa: N812
 from torch import nn
 
-from tiatoolbox_amd.models.architecture.fused import hip_upsample2x_add
+from tiatoolbox_amd.models.architecture.fused import hip_stem_conv_pool, hip_upsample2x_add, pack_stem_weights
 from tiatoolbox_amd.models.architecture.hovernet_fused import _BnAct, _cl, _Conv
 from tiatoolbox_amd.models.architecture.resnet import Bottleneck
 
@@ -49,9 +51,13 @@ class FusedUNet(nn.Module):
         if not hasattr(bb, "layer1") or model.skip_type != "add":
             msg = "FusedUNet covers the ResNet-50 encoder with additive skip connections."
             raise TypeError(msg)
-        self.stem = _Conv(bb.conv1, bb.bn1)
-        self.stem_pad = bb.conv1.padding[0]
-        self.maxpool = bb.maxpool
+        self.stem = _Conv(bb.conv1, bb.bn1)  # BN folded; executed by the stem kernel (7x7 / stride 2 / pad 3 + 3x3 / 2 max-pool)
+        mp = bb.maxpool
+        if (bb.conv1.stride != (2, 2) or bb.conv1.padding != (3, 3) or (mp.kernel_size, mp.stride, mp.padding) != (3, 2, 1)
+                or bb.conv1.weight.shape != (64, 3, 7, 7)):
+            msg = "FusedUNet expects the torchvision ResNet stem (conv 7x7 / 2 / pad 3, 3 -> 64; max-pool 3 / 2 / 1)."
+            raise TypeError(msg)
+        self._stem_packed: torch.Tensor | None = None
         self.layers = nn.ModuleList(nn.Sequential(*[_FusedBottleneckMfma(b) for b in layer])
                                     for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4))
         self.conv1x1 = _Conv(model.conv1x1)
@@ -70,10 +76,15 @@ class FusedUNet(nn.Module):
             self.up.append(stage)
         self.clf = _Conv(model.clf)
 
+    accepts_uint8 = True  # `infer_batch` hands the uint8 batch over as it is: the stem kernel divides by 255 while it loads
+
     def forward(self, imgs: torch.Tensor, *args, **kwargs) -> torch.Tensor:  # noqa: ARG002
-        x = _cl(imgs / 255.0)
-        feats = [self.stem(x, pads=(self.stem_pad, self.stem_pad), relu=True)]
-        x = self.maxpool(feats[0])
+        if self._stem_packed is None or self._stem_packed.device != self.stem.weight.device:
+            self._stem_packed = pack_stem_weights(self.stem.weight)
+        x = imgs.permute(0, 2, 3, 1)  # the NHWC batch under the NCHW view
+        x = x.contiguous() if x.dtype == torch.uint8 else (x.to(torch.float32) / 255.0).contiguous()
+        x, conv = hip_stem_conv_pool(x, self._stem_packed, self.stem.bias, return_conv=True)
+        feats = [conv]
         for layer in self.layers:
             x = layer(x)
             feats.append(x)
