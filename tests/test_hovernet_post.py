@@ -527,6 +527,23 @@ def test_columnar_instance_table_equals_per_instance_assembly():
                 assert np.array_equal(table["contours"][j], v["contours"]) and table["contours"][j].dtype == np.int32
                 assert table["type"][j] == v["type"] and table["prob"][j] == v["prob"]
     assert hd.table_from_stats(np.zeros((3, 8), np.int64), None) is None
+    # the batch-wide assembly (one NumPy pass per column over all planes) == the per-plane one; an empty plane gives None
+    stats_b = np.stack([stats, np.zeros_like(stats), stats[::-1]])
+    types_b = np.stack([types, np.zeros_like(types), types[::-1]])
+    meta_b = np.stack([meta, np.zeros_like(meta), meta[::-1]])
+    for ty in (types_b, None):
+        tables = hd.tables_from_stats_batch(stats_b, ty, meta=meta_b, points=points)
+        assert len(tables) == 3 and tables[1] is None
+        for i in (0, 2):
+            one = hd.table_from_stats(stats_b[i], ty[i] if ty is not None else None, meta=meta_b[i], points=points)
+            assert np.array_equal(tables[i]["ids"], one["ids"]) and np.array_equal(tables[i]["box"], one["box"])
+            np.testing.assert_array_equal(tables[i]["centroid"], one["centroid"])
+            for col in ("contours", "type", "prob"):
+                assert tables[i][col].dtype == object and len(tables[i][col]) == len(one[col])
+                for a, b in zip(tables[i][col], one[col]):
+                    assert type(a) is type(b) and np.array_equal(a, b)
+    assert hd.tables_from_stats_batch(np.zeros((2, 3, 8), np.int64), None, meta=np.zeros((2, 3, 4), np.int32),
+                                      points=np.zeros((0, 2), np.int32)) == [None, None]
 
 
 def _pop_hole_classic(a: list, smaller) -> tuple:

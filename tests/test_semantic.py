@@ -260,6 +260,7 @@ def test_fused_unet_forward_matches_plain_module():
         fused = FusedUNet(copy.deepcopy(model).cuda()).cuda()
         xb = x.to(torch.uint8).permute(0, 2, 3, 1).contiguous().cuda()
         got_u8 = fused(xb.permute(0, 3, 1, 2)).cpu()
-    assert torch.equal(got_u8, got)
+    # (not torch.equal: the final 64 -> n_classes 1x1 is a library call whose solver may differ between the two calls)
+    assert (got_u8 - got).abs().max() <= 1e-5 * max(float(ref.abs().max()), 1.0)
     eng = SemanticSegmentor(model, batch_size=2, device="cuda")
     assert type(eng._inference_model(torch.float32)).__name__ == "FusedUNet"

@@ -62,6 +62,7 @@ def test_stem_kernel_matches_unfused_torch_ops(shape):
     xf = x.float().div(255)
     got_f = hip_stem_conv_pool(xf.cuda(), wp, conv_d.bias.detach())
     assert torch.equal(got_f, got)  # the uint8 path divides exactly like torch does
+    assert torch.equal(hip_stem_conv_pool(xf.cuda(), wp, conv_d.bias.detach(), return_conv=True)[1], conv_out)
     # unscaled floats (a hook that feeds 0..255) go through as they are
     got_raw = hip_stem_conv_pool(x.float().cuda(), wp, conv_d.bias.detach())
     ref_raw = _reference(conv, x.float())

@@ -1024,7 +1024,10 @@ __device__ __noinline__ double normal_of(unsigned long long key) {
 // DL = true: the TIA_MODE_VAHADANE instantiation (dictionary learning instead of the Macenko branch); kept apart so that
 // its extra live state does not cost the Macenko / fixed-matrix kernel registers.
 template <bool DL>
-__global__ __launch_bounds__(NT, DL ? 2 : 4) void stain_stats_kernel(const uint8_t* __restrict__ img, long hw,
+#ifndef TIA_STATS_WPE
+#define TIA_STATS_WPE 4  // waves per SIMD the Macenko / fixed-matrix instantiation is compiled for (2 work-groups per CU by LDS)
+#endif
+__global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel(const uint8_t* __restrict__ img, long hw,
                                                           const tia_stain_tables* __restrict__ tab,
                                                           tia_stain_params prm,
                                                           double* __restrict__ stats,

@@ -306,3 +306,45 @@ def table_from_stats(stats: np.ndarray, types: np.ndarray | None, offset=(0, 0),
         for j in range(ids.size):
             kind[j], prob[j] = int(top[j]), float(p[j])
     return {"ids": ids, "box": box, "centroid": centroid, "contours": contours, "prob": prob, "type": kind}
+
+
+def tables_from_stats_batch(stats: np.ndarray, types: np.ndarray | None, *, meta: np.ndarray, points: np.ndarray) -> list:
+    """:func:`table_from_stats` (offset 0) for every plane of a batch at once: the columns are computed over ALL instances of
+    the batch in one NumPy pass each and cut into per-plane views; what stays per instance is one slice of the vertex
+    buffer.  ``stats [N, K, 8]``, ``types [N, K, T]`` or ``None``, ``meta [N, K, 4]``; returns ``N`` tables (``None`` for a
+    plane without instances).  Same container types as ``HoVerNet._pack``."""
+    n, k = stats.shape[:2]
+    keep = (stats[:, :, 0] > 0) & (meta[:, :, 2] >= 3)  # noqa: PLR2004  (hovernet.py:695-699)
+    plane, ids = np.nonzero(keep)                        # row-major: plane by plane, ascending instance id
+    if plane.size == 0:
+        return [None] * n
+    st = stats[plane, ids].astype(np.int64)
+    area, xmin, ymin, xmax, ymax, sumx, sumy = (st[:, j] for j in range(7))
+    areaf = area.astype(np.float64)
+    centroid = np.stack([(sumx - area * xmin).astype(np.float64) / areaf + xmin,
+                         (sumy - area * ymin).astype(np.float64) / areaf + ymin], axis=1)
+    box = np.stack([xmin, ymin, xmax + 1, ymax + 1], axis=1)
+    first = meta[plane, ids, 3].astype(np.int64)
+    last = first + meta[plane, ids, 2].astype(np.int64)
+    pts = points.astype(np.int32, copy=False)
+    contours = np.empty(plane.size, dtype=object)
+    contours[:] = [pts[a:b] for a, b in zip(first.tolist(), last.tolist())]
+    if types is not None:
+        votes = types[plane, ids].astype(np.int64)
+        rows = np.arange(plane.size)
+        top = np.argmax(votes, axis=1)                      # most votes, ties to the smaller class
+        if votes.shape[1] > 1:
+            runner = np.argmax(votes[:, 1:], axis=1) + 1    # best non-background class ...
+            top = np.where((top == 0) & (votes[rows, runner] > 0), runner, top)  # ... if background won and one exists
+        kind = top.astype(object)                           # Python ints / floats, like the reference's dict values
+        prob = (votes[rows, top] / (areaf + 1.0e-6)).astype(object)
+    else:
+        kind = np.full(plane.size, None, dtype=object)
+        prob = np.full(plane.size, None, dtype=object)
+    cuts = np.searchsorted(plane, np.arange(n + 1)).tolist()
+    out = []
+    for i in range(n):
+        a, b = cuts[i], cuts[i + 1]
+        out.append(None if a == b else {"ids": ids[a:b], "box": box[a:b], "centroid": centroid[a:b], "contours": contours[a:b],
+                                        "prob": prob[a:b], "type": kind[a:b]})
+    return out

@@ -327,11 +327,9 @@ class HoVerNet(ModelABC):
         stats_h = stats.cpu().numpy()
         types_h = types.cpu().numpy() if types is not None else None
         inst_h = inst.cpu().numpy()
-        outs = []
-        for i in range(inst.shape[0]):  # column-wise assembly: no per-instance Python arithmetic
-            table = hd.table_from_stats(stats_h[i], types_h[i] if types_h is not None else None, meta=meta[i], points=points)
-            outs.append(self._pack_table(inst_h[i], table))
-        return outs
+        # batch-wide column assembly: one NumPy pass per column over all instances of all planes, then per-plane views
+        tables = hd.tables_from_stats_batch(stats_h, types_h, meta=meta, points=points)
+        return [self._pack_table(inst_h[i], tables[i]) for i in range(inst.shape[0])]
 
     def _pack_table(self, pred_inst, table: dict | None) -> dict:
         if table is None:
