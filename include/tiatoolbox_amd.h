@@ -416,6 +416,22 @@ int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed, const floa
                            int64_t kw, int64_t stride, int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo,
                            int32_t relu, void* stream);
 
+/* Convolution over a THIN input (c * kw <= 32, e.g. the 3-channel 7x7 stem of HoVer-Net, models/architecture/hovernet.py:
+ * 287-300 `conv0`): d_x [n,h,w,c] float32 NHWC, ALREADY padded horizontally by the caller ((wo-1)*stride + kw <= w, and at least 32 floats from the last output
+ * column's first tap to the end of its row: (w - (wo-1)*stride) * c >= 32); rows are
+ * padded by pad_top / ho like tia_conv2d_nhwc_f32_ex.  d_w_packed: [kh][32][cout] float32 with row kx * c + ch = w[o][ch][ky][kx]
+ * and zero rows from kw * c on.  Same kernel and arithmetic as tia_conv2d_nhwc_f32 (K = 32 * kh). */
+int tia_conv2d_thin_nhwc_f32(const float* d_x, const float* d_w_packed, const float* d_bias, float* d_y, int64_t n, int64_t h,
+                             int64_t w, int64_t c, int64_t cout, int64_t kh, int64_t kw, int64_t stride, int64_t pad_top,
+                             int64_t ho, int64_t wo, int32_t relu, void* stream);
+
+/* 1x1 convolution with FEW output channels (the class heads: cin = 64 -> cout <= 8; hovernet.py:196-199 `u0/conv`,
+ * unet.py:336 `clf`), optionally with the BatchNorm + ReLU that precedes it applied on load:
+ *   y[p][o] = bias[o] + sum_c w[o][c] * pre(x[p][c]),  pre(v) = relu(v * pre_scale[c] + pre_shift[c]) or v (both NULL).
+ * d_x [npix,64], d_w [cout][64] (the OIHW tensor), d_y [npix,cout], all float32; HBM-bound (one read of x). */
+int tia_conv1x1_head_nhwc_f32(const float* d_x, int64_t npix, const float* d_w, const float* d_bias, const float* d_pre_scale,
+                              const float* d_pre_shift, int32_t cout, float* d_y, void* stream);
+
 /* tia_conv2d_nhwc_f32_ex with a second, post-activated output produced in the same epilogue:
  *   v  = act(conv(x, w) + bias [+ residual])      -> d_y   (may be NULL when only d_y2 is wanted)
  *   y2 = relu(v * post_scale[c] + post_shift[c])   -> d_y2  (required)

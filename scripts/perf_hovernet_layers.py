@@ -42,7 +42,7 @@ def conv_label(a, k, out):
     first = out[1] if isinstance(out, tuple) else out
     n, co, ho, wo = first.shape
     ci = x.shape[1]
-    kind = "mfma" if self.mfma_ok else ("grouped" if self.grouped_ok else "library")
+    kind = ("mfma" if self.mfma_ok else "grouped" if self.grouped_ok else "thin" if self.thin_ok else "head" if self.head_ok else "library")
     flops = 2.0 * n * ho * wo * co * (ci // self.groups) * self.kernel * self.kernel
     nbytes = 4.0 * (x.numel() + first.numel() + (k["residual"].numel() if k.get("residual") is not None else 0))
     return (f"conv {kind:7s} {self.kernel}x{self.kernel}/{self.stride} {ci:4d}->{co:4d} out {ho}x{wo}"

@@ -72,6 +72,26 @@ def torch_kernels(monkeypatch):
     def pack_stem(weight):
         return torch.cat([weight.detach().permute(2, 3, 1, 0).reshape(147, 64), torch.zeros(1, 64)])
 
+    def thin(x, wp, bias, *, kernel, stride, pad_lo, pad_hi, relu):
+        c = x.shape[1]
+        w = wp[:, :kernel * c].reshape(kernel, kernel, c, -1).permute(3, 2, 0, 1)
+        y = F.conv2d(F.pad(x, (pad_lo, pad_hi, pad_lo, pad_hi)), w, bias, stride)
+        return F.relu(y) if relu else y
+
+    def pack_thin(weight):
+        cout, c, kh, kw = weight.shape
+        packed = torch.zeros((kh, 32, cout))
+        packed[:, :kw * c] = weight.detach().permute(2, 3, 1, 0).reshape(kh, kw * c, cout)
+        return packed
+
+    def head(x, weight, bias, *, pre_scale=None, pre_shift=None):
+        if pre_scale is not None:
+            x = F.relu(x * pre_scale[None, :, None, None] + pre_shift[None, :, None, None])
+        return F.conv2d(x, weight.reshape(weight.shape[0], 64, 1, 1), bias)
+
+    monkeypatch.setattr(hf, "hip_conv2d_thin", thin)
+    monkeypatch.setattr(hf, "pack_thin_conv_weights", pack_thin)
+    monkeypatch.setattr(hf, "hip_conv1x1_head", head)
     monkeypatch.setattr(hf, "hip_upsample2x_add", up)
     monkeypatch.setattr(uf, "hip_upsample2x_add", up)
     monkeypatch.setattr(uf, "hip_stem_conv_pool", stem)

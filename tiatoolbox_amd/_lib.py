@@ -91,6 +91,8 @@ _SIGNATURES = {
     "tia_conv2d_nhwc_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     "tia_conv2d_nhwc_f32_ex": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P],
                                C.c_int),
+    "tia_conv2d_thin_nhwc_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
+    "tia_conv1x1_head_nhwc_f32": ([_P, _I64, _P, _P, _P, _P, _I32, _P, _P], C.c_int),
     "tia_conv2d_post_nhwc_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32,
                                   _P, _P, _P, _P], C.c_int),
     "tia_stem_conv7x7_pool_nhwc": ([_P, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _I64, _P], C.c_int),

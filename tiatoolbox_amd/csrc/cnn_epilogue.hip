@@ -313,6 +313,80 @@ __global__ __launch_bounds__(ET) void grouped_conv_valid_kernel(const float* __r
     }
 }
 
+
+// ---- class heads: 1x1 convolution 64 -> COUT <= 8 channels, optionally with the preceding BatchNorm + ReLU on load ----------
+// HBM-bound (256 B read per pixel, 4 * COUT written).  16 lanes share a pixel (one float4 of its 64 channels each: a wave
+// reads 4 pixels = 1 KB contiguous), multiply by their slice of the weights and fold the 16 partial sums with a butterfly
+// of lane exchanges; lanes 0 .. COUT-1 of each 16 then write the pixel's outputs (4 * COUT contiguous floats per wave).
+template <int COUT>
+__global__ __launch_bounds__(256) void head1x1_kernel(const float4* __restrict__ x, long npix, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, const float* __restrict__ ps,
+                                                      const float* __restrict__ pt, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63, q = lane & 15, sub = lane >> 4;
+    float wr[COUT][4];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[o][i] = w[o * 64 + 4 * q + i];
+    float sc[4] = {1.0f, 1.0f, 1.0f, 1.0f}, sh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool pre = ps != nullptr;
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc[i] = ps[4 * q + i];
+            sh[i] = pt[4 * q + i];
+        }
+    }
+    float bo = 0.0f;
+    if (bias && q < COUT) bo = bias[q];
+    const long groups = (npix + 3) / 4;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), waves = (long)gridDim.x * 4;
+    constexpr int U = 4;  // groups in flight per wave
+    for (long g0 = wave * U; g0 < groups; g0 += waves * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pix = (g0 + u) * 4 + sub;
+            v[u] = pix < npix ? x[pix * 16 + q] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float a[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (pre) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = __fadd_rn(__fmul_rn(a[i], sc[i]), sh[i]);  // rounded like batch_norm, then relu
+                    a[i] = t > 0.0f ? t : 0.0f;
+                }
+            }
+            float part[COUT];
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                float t = a[0] * wr[o][0];
+                t = fmaf(a[1], wr[o][1], t);
+                t = fmaf(a[2], wr[o][2], t);
+                part[o] = fmaf(a[3], wr[o][3], t);
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) part[o] += __shfl_xor(part[o], m, 64);
+            float mine = part[0];
+#pragma unroll
+            for (int o = 1; o < COUT; ++o) mine = q == o ? part[o] : mine;
+            const long pix = (g0 + u) * 4 + sub;
+            if (q < COUT && pix < npix) y[pix * COUT + q] = mine + bo;
+        }
+    }
+}
+
+template <int COUT>
+static void launch_head(const float* x, long npix, const float* w, const float* bias, const float* ps, const float* pt, float* y,
+                        hipStream_t st) {
+    long blocks = ((npix + 3) / 4 + 15) / 16;  // 4 waves x 4 groups per pass
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipLaunchKernelGGL(head1x1_kernel<COUT>, dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)x, npix, w, bias, ps, pt, y);
+}
 }  // namespace tia
 
 using namespace tia;
@@ -412,5 +486,23 @@ extern "C" int tia_grouped_conv_valid_nhwc_f32(const float* d_x, const float* d_
     hipLaunchKernelGGL((grouped_conv_valid_kernel<32, 8>), dim3((unsigned)blocks, (unsigned)groups), dim3(ET), 0, (hipStream_t)stream, d_x,
                        d_w_packed, d_y, (int)n, (int)h, (int)w, (int)groups, (int)k, (long)y_image_stride, (long)y_row_stride,
                        (long)y_pixel_stride);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_conv1x1_head_nhwc_f32(const float* d_x, int64_t npix, const float* d_w, const float* d_bias, const float* d_pre_scale,
+                                         const float* d_pre_shift, int32_t cout, float* d_y, void* stream) {
+    if (!d_x || !d_w || !d_y || npix <= 0 || cout < 1 || cout > 8 || ((d_pre_scale == nullptr) != (d_pre_shift == nullptr))) return TIA_EINVAL;
+    if (reinterpret_cast<uintptr_t>(d_x) & 15) return TIA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    switch (cout) {
+        case 1: launch_head<1>(d_x, npix, d_w, d_bias, d_pre_scale, d_pre_shift, d_y, st); break;
+        case 2: launch_head<2>(d_x, npix, d_w, d_bias, d_pre_scale, d_pre_shift, d_y, st); break;
+        case 3: launch_head<3>(d_x, npix, d_w, d_bias, d_pre_scale, d_pre_shift, d_y, st); break;
+        case 4: launch_head<4>(d_x, npix, d_w, d_bias, d_pre_scale, d_pre_shift, d_y, st); break;
+        case 5: launch_head<5>(d_x, npix, d_w, d_bias, d_pre_scale, d_pre_shift, d_y, st); break;
+        case 6: launch_head<6>(d_x, npix, d_w, d_bias, d_pre_scale, d_pre_shift, d_y, st); break;
+        case 7: launch_head<7>(d_x, npix, d_w, d_bias, d_pre_scale, d_pre_shift, d_y, st); break;
+        default: launch_head<8>(d_x, npix, d_w, d_bias, d_pre_scale, d_pre_shift, d_y, st); break;
+    }
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

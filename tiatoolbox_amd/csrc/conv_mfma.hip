@@ -38,6 +38,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 struct ConvDims {
     int n, h, w, cin, cout, ho, wo, kh, kw, stride, pad_y, pad_x;  // pad_* = zero rows / columns in front (top, left)
     unsigned x_bytes, w_bytes;  // buffer extents of this launch (both < 2^31: the host splits the batch)
+    int pstride;  // floats between horizontally adjacent input pixels: cin, except for the row-packed thin-input form below
 };
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
         const int rem = mm - b * d.ho * d.wo;                                                  \
         const int oy = rem / d.wo, ox = rem - oy * d.wo;                                       \
         const int iy0 = oy * d.stride - d.pad_y, ix0 = ox * d.stride - d.pad_x;                    \
-        cen_##R = (((b * d.h + iy0) * d.w + ix0) * d.cin + 4 * quad) * 4;                      \
+        cen_##R = (((b * d.h + iy0) * d.w + ix0) * d.pstride + 4 * quad) * 4;                      \
         unsigned rows = 0, cols = 0;                                                           \
         for (int t = 0; t < d.kh; ++t) rows |= (unsigned)((unsigned)(iy0 + t) < (unsigned)d.h) << t;        \
         for (int t = 0; t < d.kw; ++t) cols |= (unsigned)((unsigned)(ix0 + t) < (unsigned)d.w) << (16 + t); \
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
     }
 #define TIA_LOAD_SLICE()                                                                                      \
     {                                                                                                         \
-        const int sdelta = ((s_kh * d.w + s_kw) * d.cin + s_c0) * 4;                                          \
+        const int sdelta = ((s_kh * d.w + s_kw) * d.pstride + s_c0) * 4;                                          \
         const unsigned sel = (1u << s_kh) | (1u << (16 + s_kw));                                              \
         const int swrow = (((s_kh * d.kw + s_kw) * d.cin + s_c0) * d.cout + n0) * 4;                          \
         TIA_LOAD_A(0) TIA_LOAD_A(1) TIA_LOAD_A(2) TIA_LOAD_A(3)                                               \
@@ -291,19 +292,21 @@ extern "C" int tia_conv_pack_weights_f32(const float* d_w_oihw, int64_t cout, in
 static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y, int64_t n,
                        int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t stride, int64_t pad_top,
                        int64_t pad_left, int64_t ho, int64_t wo, int32_t relu, const float* d_post_scale, const float* d_post_shift,
-                       float* d_y2, void* stream) {
+                       float* d_y2, void* stream, int64_t pstride = 0) {
     const bool with_post = d_y2 != nullptr;
+    if (pstride <= 0) pstride = cin;
     if (with_post && (!d_post_scale || !d_post_shift)) return TIA_EINVAL;
     if (!d_x || !d_w_packed || (!d_y && !with_post) || n <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0)
         return TIA_EINVAL;
     if (cin % BK != 0 || cout % 64 != 0) return TIA_ESIZE;
-    if (((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_w_packed)) & 15) != 0) return TIA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_w_packed) & 15) != 0 || (reinterpret_cast<uintptr_t>(d_x) & (pstride % 4 == 0 ? 15 : 3)) != 0)
+        return TIA_EINVAL;
     // every output pixel must see at least its first tap row / column start inside [-(k-1), h): rows and columns beyond the
     // image on either side read as zeros (that is how asymmetric "same" padding is expressed: pad_top / pad_left + ho / wo)
     if (ho <= 0 || wo <= 0 || kh > 16 || kw > 16 || pad_top >= kh || pad_left >= kw) return TIA_EINVAL;
     if ((ho - 1) * stride - pad_top >= h || (wo - 1) * stride - pad_left >= w) return TIA_EINVAL;
     // the kernel addresses its input with 32-bit byte offsets: images go in groups of < 2 GiB
-    const long image_bytes = h * w * cin * 4, w_bytes = kh * kw * cin * cout * 4;
+    const long image_bytes = h * w * pstride * 4, w_bytes = kh * kw * cin * cout * 4;
     if (image_bytes > 0x7fffffffL || w_bytes > 0x7fffffffL || ho * wo > 0x7fffffffL / 4) return TIA_ESIZE;
     long group = 0x7fffffffL / image_bytes;
     if (group * ho * wo > 0x7fffffffL / 2) group = 0x7fffffffL / 2 / (ho * wo);
@@ -314,8 +317,8 @@ static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d
         const long m_total = nb * ho * wo;
         const long m_tiles = (m_total + BM - 1) / BM;
         ConvDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)kh, (int)kw, (int)stride, (int)pad_top,
-                   (int)pad_left, (unsigned)(nb * image_bytes), (unsigned)w_bytes};
-        const float* xg = d_x + first * h * w * cin;
+                   (int)pad_left, (unsigned)(nb * image_bytes), (unsigned)w_bytes, (int)pstride};
+        const float* xg = d_x + first * h * w * pstride;
         const float* rg = d_residual ? d_residual + first * ho * wo * cout : nullptr;
         float* yg = d_y ? d_y + first * ho * wo * cout : nullptr;
         const ConvPost post{d_post_scale, d_post_shift, with_post ? d_y2 + first * ho * wo * cout : nullptr};
@@ -352,6 +355,20 @@ extern "C" int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed,
     if (!d_y) return TIA_EINVAL;
     return conv2d_impl(d_x, d_w_packed, d_bias, d_residual, d_y, n, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo, relu,
                        nullptr, nullptr, nullptr, stream);
+}
+
+// Thin-input form (an RGB stem: c = 3): in NHWC the kw * c values under one row of taps are CONTIGUOUS, so a kh x kw
+// convolution over c channels is a kh x 1 convolution over 32 "row-packed" channels whose pixels lie c floats apart --
+// the same kernel with a pixel stride, weights [kh][32][cout] with rows >= kw * c zero (what they multiply is the rest of
+// the 32-float read: finite image data, or zeros beyond the buffer).  The caller pads the rows horizontally.
+extern "C" int tia_conv2d_thin_nhwc_f32(const float* d_x, const float* d_w_packed, const float* d_bias, float* d_y, int64_t n, int64_t h,
+                                        int64_t w, int64_t c, int64_t cout, int64_t kh, int64_t kw, int64_t stride, int64_t pad_top,
+                                        int64_t ho, int64_t wo, int32_t relu, void* stream) {
+    if (!d_y || c <= 0 || kw <= 0 || c * kw > BK || stride <= 0 || wo <= 0) return TIA_EINVAL;
+    // horizontally "valid" (the padding columns are in the input), and the 32-float read of the last output column stays in its row
+    if ((wo - 1) * stride + kw > w || (w - (wo - 1) * stride) * c < BK) return TIA_EINVAL;
+    return conv2d_impl(d_x, d_w_packed, d_bias, nullptr, d_y, n, h, w, BK, cout, kh, 1, stride, pad_top, 0, ho, wo, relu, nullptr,
+                       nullptr, nullptr, stream, c);
 }
 
 extern "C" int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,

@@ -194,6 +194,72 @@ def hip_conv2d_ex(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor | 
     return y
 
 
+def pack_thin_conv_weights(weight: torch.Tensor) -> torch.Tensor:
+    """OIHW ``[cout, c, kh, kw]`` with ``c * kw <= 32`` -> ``[kh][32][cout]`` (row ``kx * c + ch``; zero rows behind): the
+    row-packed form :func:`hip_conv2d_thin` multiplies with."""
+    cout, c, kh, kw = weight.shape
+    if c * kw > 32 or cout % 64 != 0:  # noqa: PLR2004
+        msg = f"thin-input convolution needs c * kw <= 32 and cout % 64 == 0; got weight {tuple(weight.shape)}."
+        raise ValueError(msg)
+    rows = weight.detach().to(torch.float32).permute(2, 3, 1, 0).reshape(kh, kw * c, cout)
+    packed = torch.zeros((kh, 32, cout), dtype=torch.float32, device=weight.device)
+    packed[:, :kw * c] = rows
+    return packed.contiguous()
+
+
+def hip_conv2d_thin(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor | None, *, kernel: int, stride: int, pad_lo: int,
+                    pad_hi: int, relu: bool) -> torch.Tensor:
+    """Convolution of a few-channel image (``c * kernel <= 32``: HoVer-Net's RGB 7x7 stem) on the MFMA kernel
+    (``tia_conv2d_thin_nhwc_f32``): the ``kernel * c`` values under a row of taps are contiguous in NHWC, so they are read
+    as one 32-wide slice.  ``x``: float32 channels-last ``[n, c, h, w]``; the horizontal padding (``pad_lo`` / ``pad_hi`` zero
+    columns, plus the few that keep the last slice inside its row) is materialised here, the vertical one is the kernel's."""
+    from tiatoolbox_amd import _lib
+
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):  # noqa: PLR2004
+        msg = "hip_conv2d_thin expects a float32 CUDA tensor [n, c, h, w]."
+        raise ValueError(msg)
+    n, c, h, w = x.shape
+    cout = w_packed.shape[-1]
+    ho = (h + pad_lo + pad_hi - kernel) // stride + 1
+    wo = (w + pad_lo + pad_hi - kernel) // stride + 1
+    need = (wo - 1) * stride + -(-32 // c)  # columns the last output's 32-float read covers
+    extra = max(need - (w + pad_lo + pad_hi), 0)
+    rows = x.permute(0, 2, 3, 1)  # NHWC
+    wp = w + pad_lo + pad_hi + extra
+    xp = torch.zeros((n, h, wp, c), dtype=torch.float32, device=x.device)
+    xp[:, :, pad_lo:pad_lo + w] = rows
+    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_conv2d_thin_nhwc_f32(xp.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                                                  y.data_ptr(), n, h, wp, c, cout, kernel, kernel, stride, pad_lo, ho, wo, int(relu),
+                                                  _lib.current_stream())
+    _lib.check(rc, "tia_conv2d_thin_nhwc_f32")
+    return y
+
+
+def hip_conv1x1_head(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None, *, pre_scale: torch.Tensor | None = None,
+                     pre_shift: torch.Tensor | None = None) -> torch.Tensor:
+    """A class head: 1x1 convolution ``64 -> cout <= 8`` (``tia_conv1x1_head_nhwc_f32``), optionally of
+    ``relu(x * pre_scale[c] + pre_shift[c])`` (the BatchNorm + ReLU in front of HoVer-Net's ``u0/conv``) without writing
+    that intermediate.  ``x``: float32 channels-last ``[n, 64, h, w]``; ``weight``: ``[cout, 64]`` (or OIHW 1x1)."""
+    from tiatoolbox_amd import _lib
+
+    if not (_nhwc_ptr_ok(x) and x.dtype == torch.float32 and x.shape[1] == 64):  # noqa: PLR2004
+        msg = "hip_conv1x1_head expects a float32 channels-last CUDA tensor with 64 channels."
+        raise ValueError(msg)
+    n, _, h, w = x.shape
+    cout = weight.shape[0]
+    wmat = weight.detach().reshape(cout, 64).to(torch.float32).contiguous()
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_conv1x1_head_nhwc_f32(x.data_ptr(), n * h * w, wmat.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                                                   pre_scale.data_ptr() if pre_scale is not None else 0,
+                                                   pre_shift.data_ptr() if pre_shift is not None else 0, cout, y.data_ptr(),
+                                                   _lib.current_stream())
+    _lib.check(rc, "tia_conv1x1_head_nhwc_f32")
+    return y
+
+
 def hip_conv2d_post(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor | None, residual: torch.Tensor | None, *,
                     kernel: int, stride: int, pad_lo: int, pad_hi: int, relu: bool, post_scale: torch.Tensor,
                     post_shift: torch.Tensor, want_raw: bool = True) -> tuple[torch.Tensor | None, torch.Tensor]:

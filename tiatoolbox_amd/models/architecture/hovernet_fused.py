@@ -11,8 +11,10 @@ pre-activation ResNet-50 encoder, the decoders' ``conva`` / ``convf`` and the de
 * ``BN -> ReLU -> conv`` (pre-activations, ``blk_bna``): one ``tia_scale_shift_act_nhwc_f32`` pass instead of two;
 * TensorFlow "same" padding of the strided 3x3: expressed by the convolution's explicit front padding / output size.
 
-The 3-channel stem, the grouped convolutions of the dense units (32 -> 8 channels per group) and the final
-``64 -> n_out`` 1x1 stay on MIOpen.  Built from a loaded model (reference parameter names), never the object that loads
+The other convolutions are hand-written too: the 3-channel 7x7 stem runs on the same MFMA kernel in its row-packed
+thin-input form (``tia_conv2d_thin_nhwc_f32``), the dense units' grouped convolutions (32 -> 8 channels per group) on
+``tia_grouped_conv_valid_nhwc_f32``, and the final ``BN -> ReLU -> 64 -> n_out`` 1x1 of every branch is one launch of
+``tia_conv1x1_head_nhwc_f32``.  Built from a loaded model (reference parameter names), never the object that loads
 weights; float32, CUDA, channels-last only.
 """
 
@@ -24,9 +26,10 @@ import torch
 import torch.nn.functional as F  # noqa: N812
 from torch import nn
 
-from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv2d_ex, hip_conv2d_post, hip_grouped_conv_valid,
-                                                      hip_scale_shift_act, hip_scale_shift_act_view, hip_upsample2x_add,
-                                                      pack_conv_weights)
+from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv1x1_head, hip_conv2d_ex, hip_conv2d_post,
+                                                      hip_conv2d_thin, hip_grouped_conv_valid, hip_scale_shift_act,
+                                                      hip_scale_shift_act_view, hip_upsample2x_add, pack_conv_weights,
+                                                      pack_thin_conv_weights)
 from tiatoolbox_amd.models.architecture.hovernet import centre_crop_to_shape
 from tiatoolbox_amd.models.architecture.utils import centre_crop
 
@@ -62,6 +65,11 @@ class _Conv(nn.Module):
         self.kernel, self.stride = conv.kernel_size[0], conv.stride[0]
         self.mfma_ok = conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
         self.groups = conv.groups
+        # few input channels (the RGB stem): row-packed form of the MFMA kernel; few output channels (a class head): the head kernel
+        self.thin_ok = (conv.groups == 1 and conv.in_channels < 32 and conv.in_channels * conv.kernel_size[1] <= 32  # noqa: PLR2004
+                        and conv.out_channels % 64 == 0 and conv.kernel_size[0] == conv.kernel_size[1])
+        self.head_ok = (conv.groups == 1 and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.in_channels == 64  # noqa: PLR2004
+                        and conv.out_channels <= 8)  # noqa: PLR2004
         # the dense units' grouped convolution: 32 -> 8 channels per group, stride 1, no bias
         self.grouped_ok = (conv.groups > 1 and conv.in_channels // conv.groups == 32 and conv.out_channels // conv.groups == 8
                            and conv.stride[0] == 1 and bias is None)
@@ -70,7 +78,18 @@ class _Conv(nn.Module):
         self._packed: torch.Tensor | None = None
 
     def forward(self, x: torch.Tensor, *, pads: tuple[int, int] = (0, 0), relu: bool = False,
-                residual: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+                residual: torch.Tensor | None = None, out: torch.Tensor | None = None, pre: "_BnAct | None" = None) -> torch.Tensor:
+        if self.head_ok and pads == (0, 0) and not relu and residual is None:
+            # `pre`: the BatchNorm + ReLU in front of the head, applied on load
+            return hip_conv1x1_head(_cl(x), self.weight, self.bias, pre_scale=pre.scale if pre is not None else None,
+                                    pre_shift=pre.shift if pre is not None else None)
+        if pre is not None:
+            x = pre(x)
+        if self.thin_ok and residual is None:
+            if self._packed is None or self._packed.device != self.weight.device:
+                self._packed = pack_thin_conv_weights(self.weight)
+            return hip_conv2d_thin(x, self._packed, self.bias, kernel=self.kernel, stride=self.stride, pad_lo=pads[0], pad_hi=pads[1],
+                                   relu=relu)
         if self.grouped_ok and pads == (0, 0) and not relu and residual is None:
             if self._packed is None or self._packed.device != self.weight.device:
                 g, k = self.groups, self.kernel
@@ -228,5 +247,5 @@ class FusedHoVerNet(nn.Module):
             u2 = br.u2f(br.u2d(br.u2a(hip_upsample2x_add(_cl(u3), d1))))
             u1_in = hip_upsample2x_add(_cl(u2), d0)
             u1 = br.u1a(u1_in, pads=_same_pads(u1_in.shape[2], br.u1_ksize, 1))
-            out[name] = br.u0(br.u0bn(u1, inplace=True))
+            out[name] = br.u0(u1, pre=br.u0bn)  # BN + ReLU + 1x1 head: one launch
         return out
