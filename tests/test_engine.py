@@ -406,7 +406,11 @@ def test_hip_mfma_conv_half_matches_torch_cpu_fp32(dtype):
     g = torch.Generator().manual_seed(7)
     cases = [(2, 64, 64, 56, 56, 3, 1), (2, 64, 128, 56, 56, 3, 2), (3, 64, 128, 56, 56, 1, 2), (2, 128, 128, 28, 28, 3, 1),
              (2, 256, 512, 14, 14, 3, 2), (5, 512, 512, 7, 7, 3, 1), (1, 32, 64, 13, 9, 3, 1), (3, 96, 192, 11, 17, 1, 1),
-             (1, 64, 256, 31, 33, 1, 1)]
+             (1, 64, 256, 31, 33, 1, 1),
+             # 3x3 / stride 1 on maps that 16 x 16 pixel blocks cover well: the tap-reuse kernel (whole blocks, clipped blocks,
+             # one clipped block, several channel slices, both tile widths)
+             (3, 64, 64, 32, 32, 3, 1), (2, 128, 256, 16, 16, 3, 1), (1, 96, 128, 30, 31, 3, 1), (1, 64, 64, 15, 16, 3, 1),
+             (2, 256, 128, 14, 16, 3, 1), (1, 32, 192, 64, 48, 3, 1)]
     for n, cin, cout, h, w, k, s in cases:
         pad = 1 if k == 3 else 0
         conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=pad)
