@@ -196,35 +196,63 @@ def ev_time(fn, reps: int = 10) -> float:
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+def spatial_conv(k: int, stride: int, ho: int, wo: int) -> bool:
+    """Which kernel a block convolution runs on (mirror of ``conv3x3_spatial_ok``, csrc/conv3x3_spatial.hpp): 3x3 / stride 1 on
+    a map that 16 x 16 pixel blocks cover to >= 7/8 -> ``conv3x3_spatial_kernel``; otherwise ``conv_mfma_f32_kernel``."""
+    tiles = ((ho + 15) // 16) * ((wo + 15) // 16)
+    return k == 3 and stride == 1 and 8 * ho * wo >= 7 * tiles * 256  # noqa: PLR2004
+
+
 def trunk_roofline(model, u8_batch):
     """HIP-event times and algorithmic flops of the hand-written convolution kernels of one trunk forward: the stem kernel
-    (one launch) and the block convolutions (conv_mfma_f32_kernel, 19 launches for resnet18)."""
+    (one launch) and the block convolutions, split by kernel -- ``conv3x3_spatial_kernel`` (3x3 / stride 1, tap reuse) and
+    ``conv_mfma_f32_kernel`` (strided, 1x1 and small-map convolutions).  Per-launch events (one sync per launch, kernel time
+    only) give the split; the total is timed separately over whole forwards without syncs."""
     import torch
 
+    import tiatoolbox_amd.models.architecture.fused as fused
     from tiatoolbox_amd.models.architecture.fused import MfmaResNet
 
     trunk = next((m for m in model.modules() if isinstance(m, MfmaResNet)), None)
     if trunk is None:
         return None
+    fam = {"conv3x3_spatial_kernel": [0, 0.0, 0], "conv_mfma_f32_kernel": [0, 0.0, 0]}  # launches, seconds, flops
+    plain = fused.hip_conv2d
+
+    def timed(x, w, b, residual, *, kernel, stride, padding, relu):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = plain(x, w, b, residual, kernel=kernel, stride=stride, padding=padding, relu=relu)
+        e1.record()
+        e1.synchronize()
+        n, co, ho, wo = y.shape
+        f = fam["conv3x3_spatial_kernel" if spatial_conv(kernel, stride, ho, wo) else "conv_mfma_f32_kernel"]
+        f[0] += 1
+        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[2] += 2 * n * ho * wo * co * x.shape[1] * kernel * kernel
+        return y
+
+    reps = 3
     with torch.inference_mode():
         feat = trunk.stem_forward(u8_batch)
         nb, hin, win = u8_batch.shape[0], u8_batch.shape[1], u8_batch.shape[2]
         ho, wo = (hin - 1) // 2 + 1, (win - 1) // 2 + 1
         stem_flops = 2 * nb * ho * wo * 64 * 147
-        _, _, h, w = feat.shape
-        flops, launches = 0, 0
-        for blk in trunk.blocks:
-            s = blk.conv1.stride[0]
-            ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
-            convs = [(blk.conv1, ho, wo), (blk.conv2, ho, wo)] + ([(blk.down, ho, wo)] if blk.down is not None else [])
-            for c, oh, ow in convs:
-                flops += 2 * nb * oh * ow * c.out_channels * c.in_channels * c.kernel_size[0] * c.kernel_size[1]
-                launches += 1
-            h, w = ho, wo
+        trunk.blocks(feat)
+        fused.hip_conv2d = timed
+        try:
+            for _ in range(reps):
+                trunk.blocks(feat)
+        finally:
+            fused.hip_conv2d = plain
         seconds = ev_time(lambda: trunk.blocks(feat), reps=5)
         stem_seconds = ev_time(lambda: trunk.stem_forward(u8_batch), reps=5)
+    launches = sum(f[0] for f in fam.values()) // reps
+    flops = sum(f[2] for f in fam.values()) // reps
+    kernels = {name: {"launches": f[0] // reps, "seconds": f[1] / reps, "flops": f[2] // reps,
+                      "tflops": f[2] / f[1] / 1e12 if f[1] > 0 else 0.0} for name, f in fam.items() if f[0]}
     return {"seconds": seconds, "launches": launches, "flops_per_launch": flops // launches,
-            "ms_per_launch": seconds / launches * 1e3, "tflops": flops / seconds / 1e12,
+            "ms_per_launch": seconds / launches * 1e3, "tflops": flops / seconds / 1e12, "kernels": kernels,
             "stem_seconds": stem_seconds, "stem_flops": stem_flops, "stem_tflops": stem_flops / stem_seconds / 1e12}
 
 
@@ -386,25 +414,41 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
     steps_mb = (n + mb - 1) // mb
     conv = trunk_roofline(model_dev, unit[:mb]) if args.dtype == "float32" else None
     if conv is not None:
-        # the hand-written kernel a step spends most of its time in: the MFMA implicit-GEMM convolution (MFMA-bound)
-        dominant = "conv_mfma_f32_kernel"
+        # the hand-written kernel a step spends most of its time in (MFMA-bound): of the two block-convolution kernels the one
+        # with the larger share of the trunk; the other one and the whole trunk are listed beside it
+        fams = conv["kernels"]
+        dominant = max(fams, key=lambda k: fams[k]["seconds"])
+        dk = fams[dominant]
+        desc = {"conv3x3_spatial_kernel": "3x3 / stride-1 convolutions, 16x16 pixel blocks with tap reuse (LDS-DMA patch + weight ring)",
+                "conv_mfma_f32_kernel": "strided 3x3, 1x1 and small-map convolutions, 128-pixel slices"}
         roofline = {
-            "kernel": dominant, "bound": "mfma", "achieved": round(conv["tflops"], 2),
+            "kernel": dominant, "bound": "mfma", "achieved": round(dk["tflops"], 2),
             "peak": MFMA_PEAK_TFLOPS["float32"], "unit": "TFLOP/s",
-            "frac": round(conv["tflops"] / MFMA_PEAK_TFLOPS["float32"], 5), "traffic": None,
-            "algorithmic_flops": conv["flops_per_launch"], "launch_ms": round(conv["ms_per_launch"], 4),
-            "launches_per_step": conv["launches"] * steps_mb,
-            "what": (f"average over the {conv['launches']} BasicBlock convolutions of one resnet18 forward on "
-                     f"{mb} patches of {hw}x{hw} (2*M*Cout*Cin*k*k flops each, fp32 MFMA 32x32x2, epilogue fused)"),
-            "share_of_step": round(conv["seconds"] * steps_mb / (elapsed / args.steps), 3),
+            "frac": round(dk["tflops"] / MFMA_PEAK_TFLOPS["float32"], 5), "traffic": None,
+            "algorithmic_flops": dk["flops"] // dk["launches"], "launch_ms": round(dk["seconds"] / dk["launches"] * 1e3, 4),
+            "launches_per_step": dk["launches"] * steps_mb,
+            "what": (f"average over the {dk['launches']} launches of this kernel in one resnet18 forward on {mb} patches of "
+                     f"{hw}x{hw} ({desc[dominant]}; 2*M*Cout*Cin*k*k flops each, fp32 MFMA 32x32x2, bias + residual + ReLU fused); "
+                     "per-launch HIP events on the launch stream"),
+            "share_of_step": round(dk["seconds"] * steps_mb / (elapsed / args.steps), 3),
+            "trunk": {"what": f"all {conv['launches']} block convolutions of one forward, timed back to back",
+                      "achieved": round(conv["tflops"], 2), "frac": round(conv["tflops"] / MFMA_PEAK_TFLOPS["float32"], 5),
+                      "ms": round(conv["seconds"] * 1e3, 3),
+                      "share_of_step": round(conv["seconds"] * steps_mb / (elapsed / args.steps), 3)},
         }
+        for name, k in fams.items():
+            if name != dominant:
+                other[name] = {"bound": "mfma", "achieved": round(k["tflops"], 2), "peak": MFMA_PEAK_TFLOPS["float32"],
+                               "unit": "TFLOP/s", "frac": round(k["tflops"] / MFMA_PEAK_TFLOPS["float32"], 5),
+                               "launch_ms": round(k["seconds"] / k["launches"] * 1e3, 4), "launches_per_step": k["launches"] * steps_mb,
+                               "algorithmic_flops": k["flops"] // k["launches"], "what": desc[name]}
         other["stem7x7_pool_kernel"] = {
             "bound": "mfma", "achieved": round(conv["stem_tflops"], 2), "peak": MFMA_PEAK_TFLOPS["float32"],
             "unit": "TFLOP/s", "frac": round(conv["stem_tflops"] / MFMA_PEAK_TFLOPS["float32"], 5),
             "launch_ms": round(conv["stem_seconds"] * 1e3, 4), "algorithmic_flops": conv["stem_flops"],
             "what": (f"uint8 patches -> conv7x7/2 (3->64, K = 147) + bias + ReLU + maxpool3x3/2, one launch per {mb} patches; "
                      "flops = 2*Ho*Wo*64*147 per patch (the conv rows recomputed at chunk seams are not counted)")}
-        pmc_c = pmc_traffic("conv_mfma_f32_kernel", "trunk") if (mb, hw) == (1024, 256) else None
+        pmc_c = pmc_traffic(dominant, "trunk") if (mb, hw) == (1024, 256) else None
         if pmc_c is not None:  # PMC passes cannot run inside the timed process: this round's committed passes, same shapes
             roofline["traffic"] = round(pmc_c["bytes"])
             roofline["traffic_source"] = pmc_c["source"] + " (scripts/perf_trunk.py 1024 256: mean over the launches of one forward)"

@@ -29,7 +29,10 @@ extern "C" {
 #define TIA_ELAUNCH (-2)  /* hipLaunch / runtime failure (hipGetLastError() != success)  */
 #define TIA_ESIZE (-3)    /* size outside what the kernel supports                        */
 
-#define TIA_ABI_VERSION 2
+/* Version 3 (round 3): + tia_stem_pack_weights_f32 / tia_stem_conv7x7_pool_nhwc, tia_conv_pack_weights_h / tia_conv2d_nhwc_h,
+ * tia_conv2d_thin_nhwc_f32, tia_conv1x1_head_nhwc_f32, tia_lut_apply_u8, tia_box_downsample_u8; the workspace of
+ * tia_stain_stats_u8 grew by one int32 flag per patch (tia_stain_stats_workspace_bytes_mode reports it). */
+#define TIA_ABI_VERSION 3
 int tia_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------

@@ -279,7 +279,9 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
     g = torch.Generator().manual_seed(0)
     cases = [(3, 64, 64, 56, 3, 1), (2, 64, 128, 56, 3, 2), (2, 64, 128, 56, 1, 2), (3, 128, 128, 28, 3, 1),
              (2, 128, 256, 28, 3, 2), (5, 256, 256, 14, 3, 1), (2, 256, 512, 14, 3, 2), (7, 512, 512, 7, 3, 1),
-             (1, 32, 64, 9, 3, 1), (2, 64, 64, 13, 3, 2)]
+             (1, 32, 64, 9, 3, 1), (2, 64, 64, 13, 3, 2),
+             # 3x3 / stride 1 on maps covered well by 16 x 16 pixel blocks: the tap-reuse kernel (whole / clipped blocks, both widths)
+             (2, 64, 64, 32, 3, 1), (1, 96, 128, 30, 3, 1), (2, 32, 192, 48, 3, 1), (1, 256, 64, 16, 3, 1)]
     for n, cin, cout, hw, k, stride in cases:
         pad = 1 if k == 3 else 0
         conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=True)
@@ -302,6 +304,18 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
             assert got.shape == exp.shape and got.is_contiguous(memory_format=torch.channels_last)
             err = (got.cpu() - exp).abs().max().item()
             assert err <= 1e-4, (n, cin, cout, hw, k, stride, use_res, relu, err)
+    # explicit borders (`tia_conv2d_nhwc_f32_ex`): a valid 3x3 (HoVer-Net's decoder) and "same" given as 1 / 1, rectangular map
+    from tiatoolbox_amd.models.architecture.fused import hip_conv2d_ex
+
+    conv = torch.nn.Conv2d(64, 128, 3, bias=True)
+    x = torch.randn((2, 64, 48, 32), generator=g)  # 46x30 | 48x32 | 47x31 outputs: the tap-reuse kernel; 50x34: the slice kernel
+    dev_conv = conv.cuda()
+    wp = pack_conv_weights(dev_conv)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    for lo, hi in ((0, 0), (1, 1), (0, 1), (2, 2)):
+        exp = F.relu(F.conv2d(F.pad(x, (lo, hi, lo, hi)), conv.weight.cpu(), conv.bias.cpu()))
+        got = hip_conv2d_ex(xd, wp, dev_conv.bias, None, kernel=3, stride=1, pad_lo=lo, pad_hi=hi, relu=True)
+        assert got.shape == exp.shape and (got.cpu() - exp).abs().max().item() <= 1e-4, (lo, hi)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,350 @@
+// 3x3 / stride-1 NHWC convolution with TAP REUSE on the gfx950 matrix cores, float32 (v_mfma_f32_32x32x2_f32: the reference's
+// arithmetic) and fp16 / bf16 (v_mfma_f32_32x32x16_*, float32 accumulate), bias + residual + ReLU fused.  Call sites in the
+// reference: the 3x3 convolutions of torchvision's BasicBlock / Bottleneck behind CNNModel.forward (models/architecture/
+// vanilla.py:300-316), UNetModel's encoder / decoder blocks (unet.py:356-417), HoVerNet's residual units (hovernet.py:405-454).
+//
+// The slice kernels (conv_mfma.hip, conv_mfma_h.hip) fetch a [128 pixels] x [32 channels] operand per tap, so a pixel's
+// channels cross the global -> LDS path nine times, and they pay a barrier pair (f32) or a DMA-bound slice (half) per 64 / 8
+// MFMAs.  Here a workgroup owns a 16 x 16 block of output pixels of ONE image:
+//   * the 18 x 18 input patch of a 64-byte channel slice (16 float32 / 32 half channels) is brought in ONCE and read by all nine
+//     taps; 256 pixels share every weight slice (8 KB per tap and channel slice): 0.36 KB moved per output pixel, tap group and
+//     slice instead of 1.1 KB
+//   * 512 threads = 8 waves as 4 (M: four pixel rows each) x 2 (N); MFMA tile i of a wave = two 16-pixel rows; BN = 128 | 64
+//   * patch in LDS, in 16-byte units: pixel (py, px) at py * 96 + px * 5 (+ unit 0..3; the fifth unit is padding): the 16 lanes
+//     a ds_read_b128 services together hold pixels {0-3, 12-15} of one row and {4-11} of the next; with a pixel pitch of 5 units
+//     and a row pitch of 0 mod 16 they fall into 16 different 16-byte bank groups for every tap shift, and a tap, a k-step or
+//     the second MFMA tile is an IMMEDIATE offset on one base register per lane.  Double-buffered; the next slice's patch arrives
+//     by LDS-DMA in four pieces behind taps 0-3 (the DMA image is lane-linear: padding units fetch out of range = zeros)
+//   * weights: ring of three 8 KB stages, one LDS-DMA instruction per thread and tap; one raw s_barrier and one COUNTED vmcnt per
+//     tap (the younger DMAs stay in flight across the barrier)
+//   * float32: a lane's k values of a slice are channels 8 hi .. 8 hi + 7 (hi = lane >> 5): two 16-byte reads feed eight
+//     MFMAs per tile; the weight stage is the [16 channels][BN] block of the [tap][cin][cout] packing, read by dword
+//     half: a lane's 8 halves of k-chunk 2 q + hi are one 16-byte read on both sides ([tap][cin/8][cout][8] packing)
+//   * epilogue through LDS in two column halves: float32 tile [256][BN/2] -> + bias + residual, ReLU, (one rounding), 16-byte stores
+//   * blockIdx remapped so that each XCD walks a contiguous range of pixel blocks
+#include "conv3x3_spatial.hpp"
+
+#include <stdlib.h>
+
+#include "../../include/tiatoolbox_amd.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using b8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+constexpr int OOB = (int)0x80000000;
+constexpr int K_F32 = 0, K_F16 = 1, K_BF16 = 2;
+
+struct SpDims {
+    int h, w, cin, cout, ho, wo, pad_y, pad_x;
+    unsigned x_bytes, w_bytes;
+};
+
+template <int KIND>
+__device__ __forceinline__ f32x16 mma_h(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if constexpr (KIND == K_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const b8*>(&a), *reinterpret_cast<const b8*>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&a), *reinterpret_cast<const h8*>(&b), c, 0, 0, 0);
+}
+template <int KIND>
+__device__ __forceinline__ float half_to_f32(unsigned short v) {
+    if constexpr (KIND == K_BF16) return __uint_as_float((unsigned)v << 16);
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return (float)h;
+}
+template <int KIND>
+__device__ __forceinline__ unsigned short f32_to_half(float x) {  // round to nearest even
+    if constexpr (KIND == K_BF16) {
+        unsigned u = __float_as_uint(x);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    } else {
+        const _Float16 h = (_Float16)x;
+        unsigned short v;
+        __builtin_memcpy(&v, &h, 2);
+        return v;
+    }
+}
+
+// 16 bytes per lane from a buffer straight into LDS: the wave's 64 lanes fill the 1 KB at `lds_wave_base` in lane order; an
+// out-of-range `voffset` writes zeros.  (A __device__ function: the builtin must not be seen by the host pass.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
+template <int BN, int KIND>
+__global__ __launch_bounds__(512, 4) void conv3x3_spatial_kernel(const void* __restrict__ x, const void* __restrict__ wk,
+                                                                const float* __restrict__ bias, const void* __restrict__ res,
+                                                                void* __restrict__ y, SpDims d, int relu, int m_tiles, int tiles_x,
+                                                                int tiles_per_image) {
+    constexpr bool F32 = KIND == K_F32;
+    constexpr int ES = F32 ? 4 : 2;       // bytes per element
+    constexpr int SC = 64 / ES;           // channels per 64-byte slice: 16 | 32
+    constexpr int NT = 512, NTILE = BN / 64, PW = 18, PIX = 5, ROW = 96;
+    constexpr int A_UNITS = PW * ROW;     // 1728 units: 3 whole DMA rounds of 512 + 192
+    constexpr int A_BYTES = A_UNITS * 16;
+    constexpr int B_BYTES = NT * 16;      // one unit per thread (BN = 64: the upper half idles)
+    constexpr int DUMP = 2 * A_BYTES + 3 * B_BYTES;  // 1 KB that the idle waves of the fourth patch piece write their zeros to
+    constexpr int LDS_BYTES = DUMP + 1024;
+    static_assert(LDS_BYTES >= 256 * (BN / 2) * 4, "epilogue tile");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int bid = blockIdx.x;
+    const int per_xcd = (m_tiles + 7) / 8;
+    const int mt_id = (bid % 8) * per_xcd + bid / 8;
+    if (mt_id >= m_tiles) return;
+    const int img = mt_id / tiles_per_image, trem = mt_id - img * tiles_per_image;
+    const int ty0 = (trem / tiles_x) * 16, tx0 = (trem - (trem / tiles_x) * tiles_x) * 16;
+    const int n0 = blockIdx.y * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)d.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wk), 0, (int)d.w_bytes, 0x00020000);
+
+    // patch staging: unit U = 512 r + tid -> row U / 96, pixel (U % 96) / 5, unit-of-slice (U % 96) % 5 (4 = padding)
+    int cen[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int u = NT * r + tid;
+        const int py = u / ROW, rem = u - py * ROW;
+        const int px = rem / PIX, chunk = rem - px * PIX;
+        const int iy = ty0 - d.pad_y + py, ix = tx0 - d.pad_x + px;
+        const bool inside = py < PW && px < PW && chunk < 4 && (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
+        cen[r] = inside ? ((img * d.h + iy) * d.w + ix) * d.cin * ES + 16 * chunk : OOB;
+    }
+    // weight staging: one unit per thread and tap
+    //   half:    [4 k-chunks][BN columns] units of 8 halves; global ((tap * cin/8 + 4 cs + kc) * cout + n0 + col) * 16
+    //   float32: [16 channels][BN / 4] units of 4 columns; global ((tap * cin + 16 cs + k) * cout + n0) * 4 + 16 * colunit
+    int b_off, b_tap_stride, b_cs_stride;
+    if constexpr (F32) {
+        const int k = tid / (BN / 4), cu = tid - k * (BN / 4);
+        b_off = k < 16 ? (k * d.cout + n0) * 4 + 16 * cu : OOB;
+        b_tap_stride = d.cin * d.cout * 4;
+        b_cs_stride = 16 * d.cout * 4;
+    } else {
+        const int kc = tid / BN, col = tid - kc * BN;
+        b_off = kc < 4 ? (kc * d.cout + n0 + col) * 16 : OOB;
+        b_tap_stride = (d.cin >> 3) * d.cout * 16;
+        b_cs_stride = 4 * d.cout * 16;
+    }
+    const int n_cs = d.cin / SC, last = 9 * n_cs - 1;
+
+    unsigned char* const abuf0 = smem;
+    unsigned char* const bring = smem + 2 * A_BYTES;
+    auto dma_a = [&](int buf, int r, int cs) {
+        // the fourth piece covers units 1536 .. 1727 (waves 0-2); the other waves' lanes are all out of range: zeros to the dump
+        unsigned char* dst = (r == 3 && wave >= 3) ? smem + DUMP : abuf0 + buf * A_BYTES + r * (NT * 16) + wave * 1024;
+        dma16(rx, dst, cen[r], cs * 64);
+    };
+    // weight slice of flattened step s = cs * 9 + tap (clamped: the tail re-fetches the last slice)
+    auto dma_b = [&](int stage, int s) {
+        s = s < last ? s : last;
+        const int cs = s / 9, tap = s - cs * 9;
+        dma16(rw, bring + stage * B_BYTES + wave * 1024, b_off, tap * b_tap_stride + cs * b_cs_stride);
+    };
+
+    f32x16 acc[2][NTILE];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // one base per lane (units): MFMA row = lane & 31 -> pixel row 4 wm + (row >> 4) (+ 2 i), column row & 15;
+    // half: k-chunk (lane >> 5) + 2 q; float32: units 2 (lane >> 5), + 1 = channels 8 hi .. 8 hi + 7
+    const int hi = lane >> 5;
+    const int fa0 = (4 * wm + ((lane & 31) >> 4)) * ROW + (lane & 15) * PIX + (F32 ? 2 * hi : hi);
+
+    auto compute = [&](int buf, int stage, int tap) {
+        const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES) + fa0;
+        const int shift = (tap / 3) * ROW + (tap % 3) * PIX;
+        if constexpr (F32) {
+            const float* sb = reinterpret_cast<const float*>(bring + stage * B_BYTES) + (8 * hi) * BN + wn * (BN / 2) + (lane & 31);
+            u32x4 a[2][2];
+            float b[NTILE][8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i][0] = sa[shift + i * 2 * ROW];
+                a[i][1] = sa[shift + i * 2 * ROW + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < NTILE; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) b[j][k] = sb[k * BN + j * 32];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTILE; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i][k >> 2][k & 3]), b[j][k], acc[i][j], 0, 0, 0);
+        } else {
+            const u32x4* sb = reinterpret_cast<const u32x4*>(bring + stage * B_BYTES) + hi * BN + wn * (BN / 2) + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                u32x4 a[2], b[NTILE];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = sa[shift + i * 2 * ROW + 2 * q];
+#pragma unroll
+                for (int j = 0; j < NTILE; ++j) b[j] = sb[2 * q * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTILE; ++j) acc[i][j] = mma_h<KIND>(a[i], b[j], acc[i][j]);
+            }
+        }
+    };
+
+    // prologue: patch of slice 0, weight slices 0 and 1
+    dma_a(0, 0, 0);
+    dma_a(0, 1, 0);
+    dma_a(0, 2, 0);
+    dma_a(0, 3, 0);
+    dma_b(0, 0);
+    dma_b(1, 1);
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int cs = 0; cs < n_cs; ++cs) {
+        const int buf = cs & 1, s0 = cs * 9;
+        const int cs_next = cs + 1 < n_cs ? cs + 1 : cs;  // past the end: the idle buffer is refilled with the same slice
+        // Per tap: the weight slice two steps ahead goes out first, then (taps 0-3) one piece of the next patch; the wait at the end
+        // lets exactly the instructions younger than weight slice s + 1 stay in flight (queue, oldest first, "|" = must have landed:
+        // t=0: B(s+1) | B(s+2) A0;   t=1: B(s+2) | A0 B(s+3) A1;   t=2: A0 B(s+3) | A1 B(s+4) A2;   t=3: A1 B(s+4) | A2 B(s+5) A3;
+        // t=4: A2 B(s+5) | A3 B(s+6);   t=5: A3 B(s+6) | B(s+7);   t>=6: B(s+1) | B(s+2)).
+        // lgkmcnt(0): every LDS read of the stage refilled next has returned before the barrier.
+#define TIA_TAP(T, VM)                                                              \
+        dma_b((T + 2) % 3, s0 + T + 2);                                             \
+        if (T < 4) dma_a(buf ^ 1, T, cs_next);                                      \
+        compute(buf, T % 3, T);                                                     \
+        asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");           \
+        __builtin_amdgcn_s_barrier();
+        TIA_TAP(0, 2)
+        TIA_TAP(1, 3)
+        TIA_TAP(2, 3)
+        TIA_TAP(3, 3)
+        TIA_TAP(4, 2)
+        TIA_TAP(5, 1)
+        TIA_TAP(6, 1)
+        TIA_TAP(7, 1)
+        TIA_TAP(8, 1)
+#undef TIA_TAP
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- epilogue: per column half (= the waves with wn == half): accumulators -> float32 LDS tile [256][BN/2], then every
+    //      thread takes rows x 8-column chunks: + bias + residual, ReLU, (round once), 16-byte stores.
+    //      Row m of the block = pixel (ty0 + m / 16, tx0 + m % 16). ----
+    constexpr int HB = BN / 2, CHUNKS = 256 * HB / 8;
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wn == half) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NTILE; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        tile[row * HB + j * 32 + (lane & 31)] = acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < CHUNKS; idx += NT) {
+            const int row = idx / (HB / 8), cc = idx - row * (HB / 8);
+            const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
+            if (oy < d.ho && ox < d.wo) {
+                const long m = ((long)img * d.ho + oy) * d.wo + ox;
+                const int col0 = n0 + half * HB + cc * 8;
+                const float4 v0 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8);
+                const float4 v1 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if (bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bias + col0), b1 = *reinterpret_cast<const float4*>(bias + col0 + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if constexpr (F32) {
+                    float* yo = static_cast<float*>(y) + m * d.cout + col0;
+                    if (res) {
+                        const float* rp = static_cast<const float*>(res) + m * d.cout + col0;
+                        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
+                    }
+                    *reinterpret_cast<float4*>(yo) = float4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<float4*>(yo + 4) = float4{v[4], v[5], v[6], v[7]};
+                } else {
+                    const unsigned short* resh = static_cast<const unsigned short*>(res);
+                    unsigned short* yh = static_cast<unsigned short*>(y);
+                    if (res) {
+                        const u32x4 rv = *reinterpret_cast<const u32x4*>(resh + m * d.cout + col0);
+                        const unsigned rw4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            v[2 * k] += half_to_f32<KIND>((unsigned short)(rw4[k] & 0xffffu));
+                            v[2 * k + 1] += half_to_f32<KIND>((unsigned short)(rw4[k] >> 16));
+                        }
+                    }
+                    unsigned o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float a0 = v[2 * k], a1 = v[2 * k + 1];
+                        if (relu) {
+                            a0 = a0 > 0.0f ? a0 : 0.0f;
+                            a1 = a1 > 0.0f ? a1 : 0.0f;
+                        }
+                        o[k] = (unsigned)f32_to_half<KIND>(a0) | ((unsigned)f32_to_half<KIND>(a1) << 16);
+                    }
+                    *reinterpret_cast<u32x4*>(yh + m * d.cout + col0) = u32x4{o[0], o[1], o[2], o[3]};
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+namespace tia {
+
+bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bias, const void* residual, void* y, long nb, long h,
+                            long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo, int dtype, int relu,
+                            hipStream_t stream) {
+    static const bool disabled = getenv("TIA_CONV_NO_SPATIAL") != nullptr;
+    const int es = dtype == TIA_DT_F32 ? 4 : 2;
+    if (disabled || cin % (64 / es) != 0 || cout % 64 != 0 || pad_top > 2 || pad_left > 2) return false;
+    const long tiles_y = (ho + 15) / 16, tiles_x = (wo + 15) / 16;
+    const long tiles = nb * tiles_y * tiles_x;
+    const SpDims d{(int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
+                   (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es)};
+    const bool wide = cout % 128 == 0;
+    const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / (wide ? 128 : 64)));
+#define TIA_LAUNCH_SP(BN_, KIND_)                                                                                                 \
+    hipLaunchKernelGGL((conv3x3_spatial_kernel<BN_, KIND_>), grid, dim3(512), 0, stream, x, w_packed, bias, residual, y, d, relu, \
+                       (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x))
+    if (dtype == TIA_DT_F32) {
+        if (wide) TIA_LAUNCH_SP(128, K_F32); else TIA_LAUNCH_SP(64, K_F32);
+    } else if (dtype == TIA_DT_F16) {
+        if (wide) TIA_LAUNCH_SP(128, K_F16); else TIA_LAUNCH_SP(64, K_F16);
+    } else {
+        if (wide) TIA_LAUNCH_SP(128, K_BF16); else TIA_LAUNCH_SP(64, K_BF16);
+    }
+#undef TIA_LAUNCH_SP
+    return true;
+}
+
+}  // namespace tia

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "../../include/tiatoolbox_amd.h"
+#include "conv3x3_spatial.hpp"
 
 namespace {
 
@@ -322,6 +323,10 @@ static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d
         const float* rg = d_residual ? d_residual + first * ho * wo * cout : nullptr;
         float* yg = d_y ? d_y + first * ho * wo * cout : nullptr;
         const ConvPost post{d_post_scale, d_post_shift, with_post ? d_y2 + first * ho * wo * cout : nullptr};
+        // 3x3 / stride 1 on maps that 16 x 16 pixel blocks cover with little waste: the tap-reuse kernel (conv3x3_spatial.hip)
+        if (!with_post && pstride == cin && tia::conv3x3_spatial_ok(kh, kw, stride, ho, wo) &&
+            tia::conv3x3_spatial_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, pad_top, pad_left, ho, wo, TIA_DT_F32, relu, st))
+            continue;
         const long grid_x = ((m_tiles + 7) / 8) * 8;  // whole rounds over the 8 XCDs (surplus workgroups exit at once)
         static const bool force64 = getenv("TIA_CONV_BN64") != nullptr;  // developer switches (tile-shape experiments)
         static const bool no_rule = getenv("TIA_CONV_NO_1X1_RULE") != nullptr;

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "../../include/tiatoolbox_amd.h"
+#include "conv3x3_spatial.hpp"
 
 namespace {
 
@@ -307,201 +308,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_h_kernel(const void* __restr
 }
 
 
-// ---- 3x3 / stride 1 / pad 1 with tap reuse: a workgroup owns a 16 x 16 block of output pixels of ONE image ------------------
-// The byte rate of the global -> LDS path bounds the kernel above (profiles/r03f_*: matrix pipe 35 % busy, LDS 22 %, waves parked
-// on the DMA counters 58 %), so this form moves fewer bytes per flop: the 18 x 18 input patch of a 32-channel slice is brought
-// in ONCE and read by all nine taps (20.7 KB instead of 9 x 16 KB), and 256 pixels share every weight slice (8 KB per tap and
-// channel slice) -- 0.36 KB per output pixel, tap group and channel slice instead of 1.1 KB.
-//   * 512 threads = 8 waves as 4 (M: four pixel rows each) x 2 (N); MFMA tile i of a wave = two 16-pixel rows
-//   * patch in LDS, in 16-byte units: pixel (py, px) at py * 96 + px * 5 (+ chunk 0..3; the fifth unit is padding): the 16 lanes a
-//     ds_read_b128 services together hold pixels {0-3, 12-15} of one row and {4-11} of the next; with a pixel pitch of 5 units
-//     and a row pitch of 0 mod 16 they fall into 16 different 16-byte bank groups for every tap shift, and a tap, a k-step or the
-//     second MFMA tile is an IMMEDIATE offset on one base register per lane.  Double-buffered; the next channel slice's patch
-//     arrives in four LDS-DMA pieces behind taps 0-3 (the DMA image is lane-linear: padding units fetch out of range = zeros)
-//   * weights: ring of three 8 KB stages, one LDS-DMA instruction per thread and tap; counted vmcnt per tap position
-template <int BN, bool BF>
-__global__ __launch_bounds__(512, 4) void conv3x3_h_kernel(const void* __restrict__ x, const void* __restrict__ wk,
-                                                          const float* __restrict__ bias, const void* __restrict__ res,
-                                                          void* __restrict__ y, ConvDimsH d, int relu, int m_tiles, int tiles_x,
-                                                          int tiles_per_image) {
-    constexpr int NT = 512, NTILE = BN / 64, PW = 18, PIX = 5, ROW = 96;
-    constexpr int A_UNITS = PW * ROW;     // 1728 units: 3 whole DMA rounds of 512 + 192
-    constexpr int A_BYTES = A_UNITS * 16;
-    constexpr int B_BYTES = NT * 16;      // one unit per thread: [4 k-chunks][BN columns][8 halves] (BN = 64: the upper half idles)
-    constexpr int DUMP = 2 * A_BYTES + 3 * B_BYTES;  // 1 KB that the idle waves of the fourth patch piece write their zeros to
-    constexpr int LDS_BYTES = DUMP + 1024;
-    static_assert(LDS_BYTES >= 256 * (BN / 2) * 4, "epilogue tile");
-    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-
-    const int bid = blockIdx.x;
-    const int per_xcd = (m_tiles + 7) / 8;
-    const int mt_id = (bid % 8) * per_xcd + bid / 8;
-    if (mt_id >= m_tiles) return;
-    const int img = mt_id / tiles_per_image, trem = mt_id - img * tiles_per_image;
-    const int ty0 = (trem / tiles_x) * 16, tx0 = (trem - (trem / tiles_x) * tiles_x) * 16;
-    const int n0 = blockIdx.y * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)d.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wk), 0, (int)d.w_bytes, 0x00020000);
-
-    // patch staging: unit U = 512 r + tid -> row U / 96, pixel (U % 96) / 5, chunk (U % 96) % 5 (4 = padding)
-    int cen[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int u = NT * r + tid;
-        const int py = u / ROW, rem = u - py * ROW;
-        const int px = rem / PIX, chunk = rem - px * PIX;
-        const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-        const bool inside = py < PW && px < PW && chunk < 4 && (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
-        cen[r] = inside ? (((img * d.h + iy) * d.w + ix) * d.cin + 8 * chunk) * 2 : OOB;
-    }
-    const int b_kc = tid / BN, b_col = tid - b_kc * BN;
-    const int b_off = b_kc < 4 ? (b_kc * d.cout + n0 + b_col) * 16 : OOB;
-    const int n_cs = d.cin >> 5, last = 9 * n_cs - 1;
-
-    unsigned char* const abuf0 = smem;
-    unsigned char* const bring = smem + 2 * A_BYTES;
-    auto dma_a = [&](int buf, int r, int cs) {
-        // the fourth piece covers units 1536 .. 1727 (waves 0-2); the other waves' lanes are all out of range: zeros to the dump
-        unsigned char* dst = (r == 3 && wave >= 3) ? smem + DUMP : abuf0 + buf * A_BYTES + r * (NT * 16) + wave * 1024;
-        dma16(rx, dst, cen[r], cs * 64);
-    };
-    // weight slice of flattened step s = cs * 9 + tap (clamped: the tail re-fetches the last slice)
-    auto dma_b = [&](int stage, int s) {
-        s = s < last ? s : last;
-        const int cs = s / 9, tap = s - cs * 9;
-        dma16(rw, bring + stage * B_BYTES + wave * 1024, b_off, (tap * (d.cin >> 3) + cs * 4) * d.cout * 16);
-    };
-
-    f32x16 acc[2][NTILE];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NTILE; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    // one base per lane (units): MFMA row = lane & 31 -> pixel row 4 wm + (row >> 4) (+ 2 i), column row & 15; k-chunk lane >> 5 (+ 2 q)
-    const int fa0 = (4 * wm + ((lane & 31) >> 4)) * ROW + (lane & 15) * PIX + (lane >> 5);
-    const int fb0 = (lane >> 5) * BN + wn * (BN / 2) + (lane & 31);
-
-    auto compute = [&](int buf, int stage, int tap) {
-        const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES) + fa0;
-        const u32x4* sb = reinterpret_cast<const u32x4*>(bring + stage * B_BYTES) + fb0;
-        const int shift = (tap / 3) * ROW + (tap % 3) * PIX;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            u32x4 a[2], b[NTILE];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = sa[shift + i * 2 * ROW + 2 * q];
-#pragma unroll
-            for (int j = 0; j < NTILE; ++j) b[j] = sb[2 * q * BN + j * 32];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NTILE; ++j) acc[i][j] = mma<BF>(a[i], b[j], acc[i][j]);
-        }
-    };
-
-    // prologue: patch of slice 0, weight slices 0 and 1
-    dma_a(0, 0, 0);
-    dma_a(0, 1, 0);
-    dma_a(0, 2, 0);
-    dma_a(0, 3, 0);
-    dma_b(0, 0);
-    dma_b(1, 1);
-    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int cs = 0; cs < n_cs; ++cs) {
-        const int buf = cs & 1, s0 = cs * 9;
-        const int cs_next = cs + 1 < n_cs ? cs + 1 : cs;  // past the end: the idle buffer is refilled with the same slice
-        // Per tap: the weight slice two steps ahead goes out first, then (taps 0-3) one piece of the next patch; the wait at the end
-        // lets exactly the instructions younger than weight slice s + 1 stay in flight (queue, oldest first, "|" = must have landed:
-        // t=0: B(s+1) | B(s+2) A0;   t=1: B(s+2) | A0 B(s+3) A1;   t=2: A0 B(s+3) | A1 B(s+4) A2;   t=3: A1 B(s+4) | A2 B(s+5) A3;
-        // t=4: A2 B(s+5) | A3 B(s+6);   t=5: A3 B(s+6) | B(s+7);   t>=6: B(s+1) | B(s+2)).
-        // lgkmcnt(0): every LDS read of the stage refilled next has returned before the barrier.
-#define TIA_TAP(T, VM)                                                              \
-        dma_b((T + 2) % 3, s0 + T + 2);                                             \
-        if (T < 4) dma_a(buf ^ 1, T, cs_next);                                      \
-        compute(buf, T % 3, T);                                                     \
-        asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");           \
-        __builtin_amdgcn_s_barrier();
-        TIA_TAP(0, 2)
-        TIA_TAP(1, 3)
-        TIA_TAP(2, 3)
-        TIA_TAP(3, 3)
-        TIA_TAP(4, 2)
-        TIA_TAP(5, 1)
-        TIA_TAP(6, 1)
-        TIA_TAP(7, 1)
-        TIA_TAP(8, 1)
-#undef TIA_TAP
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- epilogue (as above, 256 rows): row m of the block = pixel (ty0 + m / 16, tx0 + m % 16) ----
-    constexpr int HB = BN / 2, CHUNKS = 256 * HB / 8;
-    float* tile = reinterpret_cast<float*>(smem);
-    const unsigned short* resh = reinterpret_cast<const unsigned short*>(res);
-    unsigned short* yh = reinterpret_cast<unsigned short*>(y);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (wn == h) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NTILE; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        tile[row * HB + j * 32 + (lane & 31)] = acc[i][j][e];
-                    }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < CHUNKS; idx += NT) {
-            const int row = idx / (HB / 8), cc = idx - row * (HB / 8);
-            const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
-            if (oy < d.ho && ox < d.wo) {
-                const long m = ((long)img * d.ho + oy) * d.wo + ox;
-                const int col0 = n0 + h * HB + cc * 8;
-                const float4 v0 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8);
-                const float4 v1 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8 + 4);
-                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                if (bias) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(bias + col0), b1 = *reinterpret_cast<const float4*>(bias + col0 + 4);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                }
-                if (res) {
-                    const u32x4 rv = *reinterpret_cast<const u32x4*>(resh + m * d.cout + col0);
-                    const unsigned rw4[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v[2 * k] += half_to_f32<BF>((unsigned short)(rw4[k] & 0xffffu));
-                        v[2 * k + 1] += half_to_f32<BF>((unsigned short)(rw4[k] >> 16));
-                    }
-                }
-                unsigned o[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float a0 = v[2 * k], a1 = v[2 * k + 1];
-                    if (relu) {
-                        a0 = a0 > 0.0f ? a0 : 0.0f;
-                        a1 = a1 > 0.0f ? a1 : 0.0f;
-                    }
-                    o[k] = (unsigned)f32_to_half<BF>(a0) | ((unsigned)f32_to_half<BF>(a1) << 16);
-                }
-                *reinterpret_cast<u32x4*>(yh + m * d.cout + col0) = u32x4{o[0], o[1], o[2], o[3]};
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // OIHW float32 -> [kh][kw][cin/8][cout][8] halves (the GEMM's B matrix with a lane's 8 k-values contiguous)
 template <bool BF>
 __global__ __launch_bounds__(256) void pack_weights_h_kernel(const float* __restrict__ w, int cout, int cin, int kh, int kw,
@@ -567,20 +373,10 @@ extern "C" int tia_conv2d_nhwc_h(const void* d_x, const void* d_w_packed, const 
         const char* xg = static_cast<const char*>(d_x) + first * image_bytes;
         const char* rg = d_residual ? static_cast<const char*>(d_residual) + first * ho * wo * cout * 2 : nullptr;
         char* yg = static_cast<char*>(d_y) + first * ho * wo * cout * 2;
-        // 3x3 / stride 1 / pad 1 on maps that 16 x 16 pixel blocks cover with little waste: the tap-reuse form
-        static const bool no_spatial = getenv("TIA_CONVH_NO_SPATIAL") != nullptr;
-        const long tiles_y = (ho + 15) / 16, tiles_x = (wo + 15) / 16;
-        if (!no_spatial && kh == 3 && kw == 3 && stride == 1 && pad == 1 && 4 * ho * wo >= 3 * tiles_y * tiles_x * 256) {
-            const long tiles = nb * tiles_y * tiles_x;
-            const dim3 sgrid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / (cout % 128 == 0 ? 128 : 64)));
-#define TIA_LAUNCH_S(BN_, BF_) \
-    hipLaunchKernelGGL((conv3x3_h_kernel<BN_, BF_>), sgrid, dim3(512), 0, st, xg, d_w_packed, d_bias, rg, yg, d, relu, (int)tiles, \
-                       (int)tiles_x, (int)(tiles_y * tiles_x))
-            if (cout % 128 == 0) { if (bf) TIA_LAUNCH_S(128, true); else TIA_LAUNCH_S(128, false); }
-            else { if (bf) TIA_LAUNCH_S(64, true); else TIA_LAUNCH_S(64, false); }
-#undef TIA_LAUNCH_S
+        // 3x3 / stride 1 on maps that 16 x 16 pixel blocks cover with little waste: the tap-reuse form (conv3x3_spatial.hip)
+        if (tia::conv3x3_spatial_ok(kh, kw, stride, ho, wo) &&
+            tia::conv3x3_spatial_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, pad, pad, ho, wo, dtype, relu, st))
             continue;
-        }
         const long grid_x = ((m_tiles + 7) / 8) * 8;
         // 64-channel slices (two stages, 16 MFMAs per barrier, whole cache lines per pixel) measured no faster than 32-channel
         // slices in a three-stage ring (profiles/r03e_perf_conv_h*.txt: 527 vs 539 TF/s over the resnet18 trunk; slower on the
