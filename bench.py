@@ -307,8 +307,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
     def run(images, dtype: str = args.dtype):
         size = tuple(int(v) for v in images.shape[1:3])
         return engine.run(images, patch_mode=True, return_probabilities=True, stain_normalizer=norm,
-                          patch_input_shape=size, compute_dtype=dtype,
-                          miopen_find=(dtype != "float32"))  # library convolutions exist only on the fp16 / bf16 extras
+                          patch_input_shape=size, compute_dtype=dtype)
 
     def barrier() -> None:
         if world_size > 1:

@@ -124,7 +124,7 @@ def bench_semantic(args) -> dict | None:
     scratch = Path(tempfile.mkdtemp(prefix="tia_sem_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None))
 
     def step():
-        result["out"] = eng.run([reader], patch_mode=False, miopen_find=True, save_dir=scratch / "out", overwrite=True)
+        result["out"] = eng.run([reader], patch_mode=False, save_dir=scratch / "out", overwrite=True)
 
     step()  # lazy loads, weight packing
     cfg = eng._ioconfig  # noqa: SLF001
@@ -232,7 +232,7 @@ def bench_hovernet(args) -> dict | None:
     result = {}
 
     def step():
-        result["out"] = eng.run(tiles, patch_mode=True, miopen_find=True)
+        result["out"] = eng.run(tiles, patch_mode=True)
 
     step()
     elapsed = _timed(step, args, world_size, device)

@@ -175,8 +175,7 @@ class EngineABC:
         self.compute_dtype = "float32"    # arithmetic type of the CNN forward
         self.distributed = True           # shard over ranks when torch.distributed is initialised
         self.fold_batchnorm = True        # inference copy with BN folded into the convolutions
-        self.miopen_find = None           # library convolutions that remain (half precision, 3-channel stems of the
-                                          # segmentation graphs): None = search solvers only for the fused float32 graphs
+        self.miopen_find = None           # True: MIOpen solver search for graphs that still run as plain torch modules
         self._fast_model = None
         self._fast_key = None
 
@@ -371,8 +370,7 @@ class EngineABC:
 
     @contextlib.contextmanager
     def _miopen_scope(self):
-        """Solver search of the library convolutions that remain on a graph (half-precision trunks; the 3-channel stems and
-        class heads of the fused segmentation graphs).  ``miopen_find=True`` (run kwarg) lets MIOpen search once per
+        """Solver search of library convolutions (plain torch modules only: see ``_use_miopen_find``).  ``miopen_find=True`` (run kwarg) lets MIOpen search once per
         convolution shape -- worth it for long runs at one batch shape, costly when batch sizes vary.  The switch is
         PROCESS-GLOBAL in torch (``torch.backends.cudnn.benchmark``): it is set for the run and restored after, so engines
         running concurrently in threads of one process share it.  A ``miopen_find`` passed to one ``run()`` does not persist
@@ -385,19 +383,11 @@ class EngineABC:
             torch.backends.cudnn.benchmark = prev
 
     def _use_miopen_find(self) -> bool:
-        """An explicit ``miopen_find`` wins.  Otherwise on for the fused float32 segmentation graphs: they leave only the
-        3-channel stem (and small class heads) on MIOpen, whose immediate mode picks a naive kernel for float32 NHWC
-        (HoVer-Net's stem at batch 32: 7.8 ms instead of 0.5 ms, ``profiles/r02t_*``); the WSI loops pad their tail batch to
-        ``batch_size`` so one shape is searched per run.  Off for graphs that run mostly on the library (a search per
-        shape) and for the ResNet classifiers (no library convolution left in float32)."""
-        explicit = getattr(self, "miopen_find", None)
-        if explicit is not None:
-            return bool(explicit)
-        fast = self._fast_model
-        if fast is None:
-            return False
-        names = {type(m).__name__ for m in fast.modules()}
-        return bool(names & {"FusedHoVerNet", "FusedUNet"})
+        """Only an explicit ``miopen_find=True`` switches the library's solver search on.  The float32 inference copies (ResNet
+        classifiers, ``FusedHoVerNet``, ``FusedUNet``) launch no library convolution at all since round 3; the switch matters
+        for what still runs as a plain torch module (half-precision segmentation networks, user-supplied architectures),
+        where MIOpen's immediate mode can pick a naive NHWC kernel."""
+        return bool(getattr(self, "miopen_find", None))
 
     def invalidate_inference_cache(self) -> None:
         """Drop the derived (BN-folded / cast) inference copy; it is rebuilt on the next run."""
