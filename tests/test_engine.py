@@ -281,7 +281,9 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
              (2, 128, 256, 28, 3, 2), (5, 256, 256, 14, 3, 1), (2, 256, 512, 14, 3, 2), (7, 512, 512, 7, 3, 1),
              (1, 32, 64, 9, 3, 1), (2, 64, 64, 13, 3, 2),
              # 3x3 / stride 1 on maps covered well by 16 x 16 pixel blocks: the tap-reuse kernel (whole / clipped blocks, both widths)
-             (2, 64, 64, 32, 3, 1), (1, 96, 128, 30, 3, 1), (2, 32, 192, 48, 3, 1), (1, 256, 64, 16, 3, 1)]
+             (2, 64, 64, 32, 3, 1), (1, 96, 128, 30, 3, 1), (2, 32, 192, 48, 3, 1), (1, 256, 64, 16, 3, 1),
+             # 8 x 8 maps: two images per block (odd batch: the last block holds one image)
+             (5, 256, 512, 8, 3, 1), (4, 64, 64, 8, 3, 1), (1, 32, 128, 8, 3, 1)]
     for n, cin, cout, hw, k, stride in cases:
         pad = 1 if k == 3 else 0
         conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=True)
@@ -424,7 +426,8 @@ def test_hip_mfma_conv_half_matches_torch_cpu_fp32(dtype):
              # 3x3 / stride 1 on maps that 16 x 16 pixel blocks cover well: the tap-reuse kernel (whole blocks, clipped blocks,
              # one clipped block, several channel slices, both tile widths)
              (3, 64, 64, 32, 32, 3, 1), (2, 128, 256, 16, 16, 3, 1), (1, 96, 128, 30, 31, 3, 1), (1, 64, 64, 15, 16, 3, 1),
-             (2, 256, 128, 14, 16, 3, 1), (1, 32, 192, 64, 48, 3, 1)]
+             (2, 256, 128, 14, 16, 3, 1), (1, 32, 192, 64, 48, 3, 1),
+             (5, 512, 512, 8, 8, 3, 1), (3, 64, 128, 7, 8, 3, 1), (2, 128, 64, 8, 8, 3, 1)]
     for n, cin, cout, h, w, k, s in cases:
         pad = 1 if k == 3 else 0
         conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=pad)

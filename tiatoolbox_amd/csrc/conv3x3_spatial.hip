@@ -38,7 +38,7 @@ constexpr int OOB = (int)0x80000000;
 constexpr int K_F32 = 0, K_F16 = 1, K_BF16 = 2;
 
 struct SpDims {
-    int h, w, cin, cout, ho, wo, pad_y, pad_x;
+    int n, h, w, cin, cout, ho, wo, pad_y, pad_x;
     unsigned x_bytes, w_bytes;
 };
 
@@ -77,21 +77,43 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
-template <int BN, int KIND>
-__global__ __launch_bounds__(512, 4) void conv3x3_spatial_kernel(const void* __restrict__ x, const void* __restrict__ wk,
+// Block geometries.  G16: one image, 16 x 16 output pixels, 8 waves (4 x 2).  G8 (maps of at most 8 x 8, e.g. resnet layer 4 at
+// 256^2 patches): TWO images of 8 x 8, 4 waves (2 x 2, wave row = image); an MFMA tile is four 8-pixel rows, and the row pitch is
+// 8 mod 16 units, which puts the four rows' lanes of a ds_read_b128 group ({0-3} {12-15} {20-23} {24-27}) on 16 different bank
+// groups the same way (k-space: {0-3}, 8+{4-7}, 16+{4-7}, 24+{0-3}).
+struct G16 {
+    static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 18, PWD = 18, ROW = 96, IMG = 18 * 96, MROWS = 2, WAVES_M = 4;
+};
+struct G8 {
+    static constexpr int NT = 256, G = 2, TH = 8, TW = 8, PH = 10, PWD = 10, ROW = 56, IMG = 10 * 56, MROWS = 4, WAVES_M = 2;
+};
+
+// s_waitcnt vmcnt(VM) lgkmcnt(0) (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] = 7 (no wait) | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+template <int VM>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+    __builtin_amdgcn_s_waitcnt((VM & 15) | (7 << 4) | ((VM >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+
+template <int BN, int KIND, typename GEO>
+__global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spatial_kernel(const void* __restrict__ x, const void* __restrict__ wk,
                                                                 const float* __restrict__ bias, const void* __restrict__ res,
                                                                 void* __restrict__ y, SpDims d, int relu, int m_tiles, int tiles_x,
                                                                 int tiles_per_image) {
     constexpr bool F32 = KIND == K_F32;
     constexpr int ES = F32 ? 4 : 2;       // bytes per element
     constexpr int SC = 64 / ES;           // channels per 64-byte slice: 16 | 32
-    constexpr int NT = 512, NTILE = BN / 64, PW = 18, PIX = 5, ROW = 96;
-    constexpr int A_UNITS = PW * ROW;     // 1728 units: 3 whole DMA rounds of 512 + 192
+    constexpr int NT = GEO::NT, NTILE = BN / 64, PIX = 5, ROW = GEO::ROW;
+    constexpr int BLOCK_PX = GEO::G * GEO::TH * GEO::TW;                 // 256 | 128 output pixels = GEMM rows of the block
+    constexpr int A_UNITS = (GEO::G * GEO::IMG + 63) / 64 * 64;           // patch units, whole waves: 1728 | 1152
+    constexpr int NA = (A_UNITS + NT - 1) / NT;                           // DMA pieces per patch: 4 | 5 (the last one partial)
+    constexpr int NB = 512 / NT;                                          // DMA pieces per weight slice (512 units): 1 | 2
     constexpr int A_BYTES = A_UNITS * 16;
-    constexpr int B_BYTES = NT * 16;      // one unit per thread (BN = 64: the upper half idles)
-    constexpr int DUMP = 2 * A_BYTES + 3 * B_BYTES;  // 1 KB that the idle waves of the fourth patch piece write their zeros to
+    constexpr int B_BYTES = 512 * 16;     // (BN = 64: the upper half idles)
+    constexpr int DUMP = 2 * A_BYTES + 3 * B_BYTES;  // 1 KB that the idle waves of the last patch piece write their zeros to
     constexpr int LDS_BYTES = DUMP + 1024;
-    static_assert(LDS_BYTES >= 256 * (BN / 2) * 4, "epilogue tile");
+    static_assert(NA <= 7, "the last patch piece must have landed by tap 8");
+    static_assert(LDS_BYTES >= BLOCK_PX * (BN / 2) * 4, "epilogue tile");
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -99,8 +121,10 @@ __global__ __launch_bounds__(512, 4) void conv3x3_spatial_kernel(const void* __r
     const int per_xcd = (m_tiles + 7) / 8;
     const int mt_id = (bid % 8) * per_xcd + bid / 8;
     if (mt_id >= m_tiles) return;
-    const int img = mt_id / tiles_per_image, trem = mt_id - img * tiles_per_image;
-    const int ty0 = (trem / tiles_x) * 16, tx0 = (trem - (trem / tiles_x) * tiles_x) * 16;
+    // G16: block = (image, 16 x 16 tile); G8: block = images 2 mt_id, 2 mt_id + 1 (tiles_per_image = 1, tile origin 0)
+    const int img = GEO::G == 1 ? mt_id / tiles_per_image : mt_id * GEO::G;
+    const int trem = GEO::G == 1 ? mt_id - img * tiles_per_image : 0;
+    const int ty0 = (trem / tiles_x) * GEO::TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * GEO::TW;
     const int n0 = blockIdx.y * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -108,29 +132,38 @@ __global__ __launch_bounds__(512, 4) void conv3x3_spatial_kernel(const void* __r
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)d.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wk), 0, (int)d.w_bytes, 0x00020000);
 
-    // patch staging: unit U = 512 r + tid -> row U / 96, pixel (U % 96) / 5, unit-of-slice (U % 96) % 5 (4 = padding)
-    int cen[4];
+    // patch staging: unit U = NT r + tid -> image U / IMG, row (U % IMG) / ROW, pixel (.. % ROW) / 5, unit-of-slice .. % 5 (4 = padding)
+    int cen[NA];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NA; ++r) {
         const int u = NT * r + tid;
-        const int py = u / ROW, rem = u - py * ROW;
+        const int g = u / GEO::IMG, ug = u - g * GEO::IMG;
+        const int py = ug / ROW, rem = ug - py * ROW;
         const int px = rem / PIX, chunk = rem - px * PIX;
         const int iy = ty0 - d.pad_y + py, ix = tx0 - d.pad_x + px;
-        const bool inside = py < PW && px < PW && chunk < 4 && (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
-        cen[r] = inside ? ((img * d.h + iy) * d.w + ix) * d.cin * ES + 16 * chunk : OOB;
+        const bool inside = g < GEO::G && img + g < d.n && py < GEO::PH && px < GEO::PWD && chunk < 4 && (unsigned)iy < (unsigned)d.h &&
+                            (unsigned)ix < (unsigned)d.w;
+        cen[r] = inside ? (((img + g) * d.h + iy) * d.w + ix) * d.cin * ES + 16 * chunk : OOB;
     }
     // weight staging: one unit per thread and tap
     //   half:    [4 k-chunks][BN columns] units of 8 halves; global ((tap * cin/8 + 4 cs + kc) * cout + n0 + col) * 16
     //   float32: [16 channels][BN / 4] units of 4 columns; global ((tap * cin + 16 cs + k) * cout + n0) * 4 + 16 * colunit
-    int b_off, b_tap_stride, b_cs_stride;
+    int b_off[NB], b_tap_stride, b_cs_stride;
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        const int idx = NT * p + tid;
+        if constexpr (F32) {
+            const int k = idx / (BN / 4), cu = idx - k * (BN / 4);
+            b_off[p] = k < 16 ? (k * d.cout + n0) * 4 + 16 * cu : OOB;
+        } else {
+            const int kc = idx / BN, col = idx - kc * BN;
+            b_off[p] = kc < 4 ? (kc * d.cout + n0 + col) * 16 : OOB;
+        }
+    }
     if constexpr (F32) {
-        const int k = tid / (BN / 4), cu = tid - k * (BN / 4);
-        b_off = k < 16 ? (k * d.cout + n0) * 4 + 16 * cu : OOB;
         b_tap_stride = d.cin * d.cout * 4;
         b_cs_stride = 16 * d.cout * 4;
     } else {
-        const int kc = tid / BN, col = tid - kc * BN;
-        b_off = kc < 4 ? (kc * d.cout + n0 + col) * 16 : OOB;
         b_tap_stride = (d.cin >> 3) * d.cout * 16;
         b_cs_stride = 4 * d.cout * 16;
     }
@@ -139,15 +172,17 @@ __global__ __launch_bounds__(512, 4) void conv3x3_spatial_kernel(const void* __r
     unsigned char* const abuf0 = smem;
     unsigned char* const bring = smem + 2 * A_BYTES;
     auto dma_a = [&](int buf, int r, int cs) {
-        // the fourth piece covers units 1536 .. 1727 (waves 0-2); the other waves' lanes are all out of range: zeros to the dump
-        unsigned char* dst = (r == 3 && wave >= 3) ? smem + DUMP : abuf0 + buf * A_BYTES + r * (NT * 16) + wave * 1024;
+        // the last piece is partial: the waves past the end of the patch (all their lanes out of range) send their zeros to the dump
+        unsigned char* dst = (NT * r + wave * 64 >= A_UNITS) ? smem + DUMP : abuf0 + buf * A_BYTES + r * (NT * 16) + wave * 1024;
         dma16(rx, dst, cen[r], cs * 64);
     };
     // weight slice of flattened step s = cs * 9 + tap (clamped: the tail re-fetches the last slice)
     auto dma_b = [&](int stage, int s) {
         s = s < last ? s : last;
         const int cs = s / 9, tap = s - cs * 9;
-        dma16(rw, bring + stage * B_BYTES + wave * 1024, b_off, tap * b_tap_stride + cs * b_cs_stride);
+#pragma unroll
+        for (int p = 0; p < NB; ++p)
+            dma16(rw, bring + stage * B_BYTES + p * (NT * 16) + wave * 1024, b_off[p], tap * b_tap_stride + cs * b_cs_stride);
     };
 
     f32x16 acc[2][NTILE];
@@ -158,10 +193,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_spatial_kernel(const void* __r
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // one base per lane (units): MFMA row = lane & 31 -> pixel row 4 wm + (row >> 4) (+ 2 i), column row & 15;
-    // half: k-chunk (lane >> 5) + 2 q; float32: units 2 (lane >> 5), + 1 = channels 8 hi .. 8 hi + 7
+    // one base per lane (units): a wave owns 64 GEMM rows = 64 / TW pixel rows (G16: rows 4 wm ..; G8: image wm); MFMA row =
+    // lane & 31 -> pixel row (row / TW) (+ MROWS i), column row % TW; half: k-chunk (lane >> 5) + 2 q; float32: units 2 (lane >> 5), + 1
     const int hi = lane >> 5;
-    const int fa0 = (4 * wm + ((lane & 31) >> 4)) * ROW + (lane & 15) * PIX + (F32 ? 2 * hi : hi);
+    const int wave_base = GEO::G == 1 ? (64 / GEO::TW) * wm * ROW : wm * GEO::IMG;
+    const int fa0 = wave_base + ((lane & 31) / GEO::TW) * ROW + ((lane & 31) % GEO::TW) * PIX + (F32 ? 2 * hi : hi);
 
     auto compute = [&](int buf, int stage, int tap) {
         const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES) + fa0;
@@ -172,8 +208,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_spatial_kernel(const void* __r
             float b[NTILE][8];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[i][0] = sa[shift + i * 2 * ROW];
-                a[i][1] = sa[shift + i * 2 * ROW + 1];
+                a[i][0] = sa[shift + i * GEO::MROWS * ROW];
+                a[i][1] = sa[shift + i * GEO::MROWS * ROW + 1];
             }
 #pragma unroll
             for (int j = 0; j < NTILE; ++j)
@@ -192,7 +228,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_spatial_kernel(const void* __r
             for (int q = 0; q < 2; ++q) {
                 u32x4 a[2], b[NTILE];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = sa[shift + i * 2 * ROW + 2 * q];
+                for (int i = 0; i < 2; ++i) a[i] = sa[shift + i * GEO::MROWS * ROW + 2 * q];
 #pragma unroll
                 for (int j = 0; j < NTILE; ++j) b[j] = sb[2 * q * BN + j * 32];
 #pragma unroll
@@ -204,46 +240,44 @@ __global__ __launch_bounds__(512, 4) void conv3x3_spatial_kernel(const void* __r
     };
 
     // prologue: patch of slice 0, weight slices 0 and 1
-    dma_a(0, 0, 0);
-    dma_a(0, 1, 0);
-    dma_a(0, 2, 0);
-    dma_a(0, 3, 0);
+#pragma unroll
+    for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
     dma_b(0, 0);
     dma_b(1, 1);
-    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    wait_vm_lgkm0<NB>();  // everything but weight slice 1
     __builtin_amdgcn_s_barrier();
     for (int cs = 0; cs < n_cs; ++cs) {
         const int buf = cs & 1, s0 = cs * 9;
         const int cs_next = cs + 1 < n_cs ? cs + 1 : cs;  // past the end: the idle buffer is refilled with the same slice
-        // Per tap: the weight slice two steps ahead goes out first, then (taps 0-3) one piece of the next patch; the wait at the end
-        // lets exactly the instructions younger than weight slice s + 1 stay in flight (queue, oldest first, "|" = must have landed:
-        // t=0: B(s+1) | B(s+2) A0;   t=1: B(s+2) | A0 B(s+3) A1;   t=2: A0 B(s+3) | A1 B(s+4) A2;   t=3: A1 B(s+4) | A2 B(s+5) A3;
-        // t=4: A2 B(s+5) | A3 B(s+6);   t=5: A3 B(s+6) | B(s+7);   t>=6: B(s+1) | B(s+2)).
+        // Per tap T: the weight slice two steps ahead goes out first (NB instructions), then (T < NA) one piece of the next patch.
+        // The wait at the end lets exactly the instructions YOUNGER than weight slice s + 1 stay in flight: piece T - 1 of the patch
+        // (issued right after slice s + 1), slice s + 2, piece T.  (G16: 2 3 3 3 2 1 1 1 1; G8: 3 4 4 4 4 3 2 2 2.)  A patch piece is
+        // thus complete two taps after its issue, the last one by tap NA + 1 <= 8.
         // lgkmcnt(0): every LDS read of the stage refilled next has returned before the barrier.
-#define TIA_TAP(T, VM)                                                              \
-        dma_b((T + 2) % 3, s0 + T + 2);                                             \
-        if (T < 4) dma_a(buf ^ 1, T, cs_next);                                      \
-        compute(buf, T % 3, T);                                                     \
-        asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");           \
+#define TIA_TAP(T)                                                                          \
+        dma_b((T + 2) % 3, s0 + T + 2);                                                     \
+        if (T < NA) dma_a(buf ^ 1, T, cs_next);                                             \
+        compute(buf, T % 3, T);                                                             \
+        wait_vm_lgkm0<((T >= 1 && T - 1 < NA) ? 1 : 0) + NB + (T < NA ? 1 : 0)>();          \
         __builtin_amdgcn_s_barrier();
-        TIA_TAP(0, 2)
-        TIA_TAP(1, 3)
-        TIA_TAP(2, 3)
-        TIA_TAP(3, 3)
-        TIA_TAP(4, 2)
-        TIA_TAP(5, 1)
-        TIA_TAP(6, 1)
-        TIA_TAP(7, 1)
-        TIA_TAP(8, 1)
+        TIA_TAP(0)
+        TIA_TAP(1)
+        TIA_TAP(2)
+        TIA_TAP(3)
+        TIA_TAP(4)
+        TIA_TAP(5)
+        TIA_TAP(6)
+        TIA_TAP(7)
+        TIA_TAP(8)
 #undef TIA_TAP
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- epilogue: per column half (= the waves with wn == half): accumulators -> float32 LDS tile [256][BN/2], then every
+    // ---- epilogue: per column half (= the waves with wn == half): accumulators -> float32 LDS tile [BLOCK_PX][BN/2], then every
     //      thread takes rows x 8-column chunks: + bias + residual, ReLU, (round once), 16-byte stores.
-    //      Row m of the block = pixel (ty0 + m / 16, tx0 + m % 16). ----
-    constexpr int HB = BN / 2, CHUNKS = 256 * HB / 8;
+    //      Row m of the block = image m / (TH TW), pixel (ty0 + (m % (TH TW)) / TW, tx0 + m % TW). ----
+    constexpr int HB = BN / 2, CHUNKS = BLOCK_PX * HB / 8;
     float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -261,9 +295,10 @@ __global__ __launch_bounds__(512, 4) void conv3x3_spatial_kernel(const void* __r
         __syncthreads();
         for (int idx = tid; idx < CHUNKS; idx += NT) {
             const int row = idx / (HB / 8), cc = idx - row * (HB / 8);
-            const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
-            if (oy < d.ho && ox < d.wo) {
-                const long m = ((long)img * d.ho + oy) * d.wo + ox;
+            const int g = row / (GEO::TH * GEO::TW), rg = row - g * (GEO::TH * GEO::TW);
+            const int oy = ty0 + rg / GEO::TW, ox = tx0 + rg % GEO::TW;
+            if (oy < d.ho && ox < d.wo && img + g < d.n) {
+                const long m = ((long)(img + g) * d.ho + oy) * d.wo + ox;
                 const int col0 = n0 + half * HB + cc * 8;
                 const float4 v0 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8);
                 const float4 v1 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8 + 4);
@@ -327,15 +362,22 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
     static const bool disabled = getenv("TIA_CONV_NO_SPATIAL") != nullptr;
     const int es = dtype == TIA_DT_F32 ? 4 : 2;
     if (disabled || cin % (64 / es) != 0 || cout % 64 != 0 || pad_top > 2 || pad_left > 2) return false;
-    const long tiles_y = (ho + 15) / 16, tiles_x = (wo + 15) / 16;
-    const long tiles = nb * tiles_y * tiles_x;
-    const SpDims d{(int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
+    const bool small = ho <= 8 && wo <= 8;  // G8: two images of (at most) 8 x 8 per block
+    const long tiles_y = small ? 1 : (ho + 15) / 16, tiles_x = small ? 1 : (wo + 15) / 16;
+    const long tiles = small ? (nb + 1) / 2 : nb * tiles_y * tiles_x;
+    const SpDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
                    (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es)};
     const bool wide = cout % 128 == 0;
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / (wide ? 128 : 64)));
-#define TIA_LAUNCH_SP(BN_, KIND_)                                                                                                 \
-    hipLaunchKernelGGL((conv3x3_spatial_kernel<BN_, KIND_>), grid, dim3(512), 0, stream, x, w_packed, bias, residual, y, d, relu, \
-                       (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x))
+#define TIA_LAUNCH_SP(BN_, KIND_)                                                                                                  \
+    do {                                                                                                                           \
+        if (small)                                                                                                                 \
+            hipLaunchKernelGGL((conv3x3_spatial_kernel<BN_, KIND_, G8>), grid, dim3(G8::NT), 0, stream, x, w_packed, bias, residual, y, \
+                               d, relu, (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x));                                       \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((conv3x3_spatial_kernel<BN_, KIND_, G16>), grid, dim3(G16::NT), 0, stream, x, w_packed, bias, residual, \
+                               y, d, relu, (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x));                                    \
+    } while (0)
     if (dtype == TIA_DT_F32) {
         if (wide) TIA_LAUNCH_SP(128, K_F32); else TIA_LAUNCH_SP(64, K_F32);
     } else if (dtype == TIA_DT_F16) {

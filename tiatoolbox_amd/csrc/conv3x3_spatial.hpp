@@ -6,10 +6,13 @@
 
 namespace tia {
 
-// 3x3, stride 1, and 16 x 16 pixel blocks waste at most an eighth of their pixels on this map (measured: below that the slice kernels win)
+// 3x3, stride 1, and the kernel's pixel blocks -- 16 x 16 of one image, or two images of at most 8 x 8 -- waste at most an eighth
+// of their pixels on this map (measured: below that the slice kernels win)
 inline bool conv3x3_spatial_ok(long kh, long kw, long stride, long ho, long wo) {
+    if (kh != 3 || kw != 3 || stride != 1) return false;
+    if (ho <= 8 && wo <= 8) return 8 * ho * wo >= 7 * 64;
     const long tiles = ((ho + 15) / 16) * ((wo + 15) / 16);
-    return kh == 3 && kw == 3 && stride == 1 && 8 * ho * wo >= 7 * tiles * 256;
+    return 8 * ho * wo >= 7 * tiles * 256;
 }
 
 // One launch over `nb` images (input extent < 2 GiB: the callers split the batch).  dtype: TIA_DT_F32 | _F16 | _BF16.
