@@ -30,7 +30,7 @@ extern "C" {
 #define TIA_ESIZE (-3)    /* size outside what the kernel supports                        */
 
 /* Version 3 (round 3): + tia_stem_pack_weights_f32 / tia_stem_conv7x7_pool_nhwc, tia_conv_pack_weights_h / tia_conv2d_nhwc_h,
- * tia_conv2d_thin_nhwc_f32, tia_conv1x1_head_nhwc_f32, tia_lut_apply_u8, tia_box_downsample_u8; the workspace of
+ * tia_stem_pack_weights_h / tia_stem_conv7x7_pool_nhwc_h, tia_conv2d_thin_nhwc_f32, tia_conv1x1_head_nhwc_f32, tia_lut_apply_u8, tia_box_downsample_u8; the workspace of
  * tia_stain_stats_u8 grew by one int32 flag per patch (tia_stain_stats_workspace_bytes_mode reports it). */
 #define TIA_ABI_VERSION 3
 int tia_abi_version(void);
@@ -458,6 +458,15 @@ int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const fl
  *   first skip connection of the UNet decoder (models/architecture/unet.py:356-372, ResNetEncoder features). */
 int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, void* d_y,
                                int32_t y_dtype, float* d_conv_out, int64_t n, int64_t h, int64_t w, void* stream);
+
+/* The same stem on the HALF matrix cores, for compute_dtype = float16 | bfloat16 of the engines (an extension: the reference runs
+ * float32; `model.half()(ToTensor(x).half())` is what it mirrors): x / 255 and the weights rounded to `dtype`, float32
+ * accumulation (v_mfma_f32_32x32x16_f16 / _bf16, K = 7 * 24 = 168 padded to 176), bias + ReLU + max-pool in float32, one rounding
+ * of the pooled result.  d_w_packed_h: [22][64][8] halves from tia_stem_pack_weights_h (row k = 24 ky + 3 kx + c of the
+ * OIHW float32 tensor); d_y [n,hp,wp,64] of `dtype` (TIA_DT_F16 | TIA_DT_BF16). */
+int tia_stem_pack_weights_h(const float* d_w_oihw, int32_t dtype, void* d_packed, void* stream);
+int tia_stem_conv7x7_pool_nhwc_h(const void* d_x, int32_t x_is_u8, const void* d_w_packed_h, const float* d_bias, void* d_y,
+                                 int32_t dtype, int64_t n, int64_t h, int64_t w, void* stream);
 /* OIHW [64,3,7,7] float32 -> [148,64]: rows (ky, kx, c), one zero row at the end. */
 int tia_stem_pack_weights_f32(const float* d_w_oihw, float* d_packed, void* stream);
 

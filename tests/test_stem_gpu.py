@@ -70,6 +70,41 @@ def test_stem_kernel_matches_unfused_torch_ops(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+@pytest.mark.parametrize("shape", [(3, 224, 224), (2, 256, 256), (2, 37, 53), (1, 70, 600), (1, 520, 64), (5, 8, 8), (1, 131, 258)])
+def test_half_stem_kernel_matches_float32_convolution_of_the_rounded_operands(shape, dtype):
+    """``tia_stem_conv7x7_pool_nhwc_h`` (half matrix cores, float32 accumulate) against the unfused float32 ops on the CPU applied
+    to the SAME half-rounded inputs (``x / 255`` rounded to half) and weights: what remains is the float32 summation order and the
+    one rounding of the pooled result."""
+    from tiatoolbox_amd.models.architecture.fused import hip_stem_conv_pool_h, pack_stem_weights_h
+
+    dt = getattr(torch, dtype)
+    eps = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    n, h, w = shape
+    conv = _stem_parts(seed=h * 1000 + w + 1)
+    g = torch.Generator().manual_seed(n + h + w)
+    x = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+    xh = x.float().div(255).to(dt).float()
+    wh = conv.weight.detach().to(dt).float()
+    with torch.inference_mode():
+        ref = F.max_pool2d(F.relu(F.conv2d(xh.permute(0, 3, 1, 2), wh, conv.bias, 2, 3)), 3, 2, 1)
+    wp = pack_stem_weights_h(conv.weight.detach().cuda(), dt)
+    assert wp.shape == (22, 64, 8) and wp.dtype == dt and float(wp[21].float().abs().max()) == 0.0  # k >= 168: zero padding
+    bias = conv.bias.detach().cuda()
+    got = hip_stem_conv_pool_h(x.cuda(), wp, bias, dtype=dt)
+    assert got.dtype == dt and got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    err = (got.float().cpu() - ref).abs()
+    assert bool((err <= eps * ref.abs() + 1e-4).all()), float((err - eps * ref.abs()).max())
+    # float32 input holding the same values: rounded to half on staging, same result
+    got_f = hip_stem_conv_pool_h(x.float().div(255).cuda(), wp, bias, dtype=dt)
+    assert torch.equal(got_f, got)
+    # sliced batch (base address not 4-byte aligned)
+    if n > 1:
+        got_v = hip_stem_conv_pool_h(x.cuda()[1:], wp, bias, dtype=dt)
+        assert torch.equal(got_v, got[1:])
+
+
+@pytest.mark.gpu
 def test_stem_kernel_unaligned_view_and_all_byte_values():
     """A batch view whose base address is not 4-byte aligned (odd image size, sliced batch), and every byte value."""
     from tiatoolbox_amd.models.architecture.fused import hip_stem_conv_pool, pack_stem_weights

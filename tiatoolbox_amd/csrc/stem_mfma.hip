@@ -40,7 +40,34 @@ constexpr int LUT_OFF = REGION;
 constexpr int W_OFF = REGION + 256;
 constexpr int LDS_FLOATS = W_OFF + KROWS * COUT;
 
+// half-precision matrix-core variant (MMA = 1: fp16, 2: bf16; `compute_dtype="float16" | "bfloat16"` of the engines): the staged
+// rows and the weights are halves (x / 255 rounded to half = what `model.half()(ToTensor(x).half())` feeds its first convolution),
+// the reduction is ordered (ky, 24-padded kx * 3 + c): 7 * 24 = 168 -> 11 k-steps of v_mfma_f32_32x32x16 (float32 accumulate);
+// an MFMA lane's 8 k-values are the 8 consecutive halves ring16[ky][6 lc + {0, 8, 16} ..] (dword-aligned: four ds_read_b32)
+constexpr int RS16 = 792;         // halves per staged row: 198 units of 4 (783 used; the k-padding reads up to element 785)
+constexpr int KH = 176;           // 7 * 24 = 168, padded to whole k-steps of 16
+constexpr int LUT16_OFF_B = REGION * 4;                 // byte offsets in the half variant's LDS
+constexpr int W16_OFF_B = LUT16_OFF_B + 512;
+constexpr int LDS_BYTES_H = W16_OFF_B + KH * COUT * 2;  // 55,808 B
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using h8v = __attribute__((ext_vector_type(8))) _Float16;
+using b8v = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <int MMA>
+__device__ __forceinline__ unsigned short to_half_bits(float x) {  // round to nearest even (finite inputs)
+    if constexpr (MMA == 2) {
+        unsigned u = __float_as_uint(x);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    } else {
+        const _Float16 h = (_Float16)x;
+        unsigned short v;
+        __builtin_memcpy(&v, &h, 2);
+        return v;
+    }
+}
 
 struct StemDims {
     int n, h, w, ho, wo, hp, wp;
@@ -50,13 +77,20 @@ struct StemDims {
     int out_dtype;               // TIA_DT_F32 | TIA_DT_F16 | TIA_DT_BF16: type of the pooled output (arithmetic is float32 either way)
 };
 
-template <bool U8>
-__global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __restrict__ xin, const float* __restrict__ wpk,
+template <bool U8, int MMA = 0>
+__global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __restrict__ xin, const void* __restrict__ wpk_v,
                                                              const float* __restrict__ bias, void* __restrict__ yout, float* __restrict__ yconv, StemDims d) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool HALF = MMA != 0;
+    constexpr int UPR = HALF ? 198 : 196;  // 4-element staging units per row
+    constexpr int RSE = HALF ? RS16 : RS;  // elements per staged row
+    const float* wpk = static_cast<const float*>(wpk_v);
     float* ring = smem;
+    unsigned short* ring16 = reinterpret_cast<unsigned short*>(smem);
     float* lut = smem + LUT_OFF;
+    unsigned short* lut16 = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(smem) + LUT16_OFF_B);
     float* Wl = smem + W_OFF;
+    const u32x4* Wh = reinterpret_cast<const u32x4*>(reinterpret_cast<unsigned char*>(smem) + W16_OFF_B);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img = blockIdx.x / d.chunks, chunk = blockIdx.x - img * d.chunks;
@@ -76,21 +110,26 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
     constexpr int OOB = (int)0x80000000;
 
     // ---- weights and the /255 table into LDS (once) ----
-    for (int i = tid; i < KROWS * COUT / 4; i += NTH)
-        reinterpret_cast<float4*>(Wl)[i] = reinterpret_cast<const float4*>(wpk)[i];
-    lut[tid] = __fdiv_rn((float)tid, 255.0f);
+    if constexpr (HALF) {
+        for (int i = tid; i < KH * COUT * 2 / 16; i += NTH) const_cast<u32x4*>(Wh)[i] = static_cast<const u32x4*>(wpk_v)[i];
+        lut16[tid] = to_half_bits<MMA>(__fdiv_rn((float)tid, 255.0f));
+    } else {
+        for (int i = tid; i < KROWS * COUT / 4; i += NTH)
+            reinterpret_cast<float4*>(Wl)[i] = reinterpret_cast<const float4*>(wpk)[i];
+        lut[tid] = __fdiv_rn((float)tid, 255.0f);
+    }
 
     // ---- staging of the 9 input rows of pooled row `py`: request (registers), later convert + write (LDS) ----
     // uint8: a unit = four consecutive ring floats (one 16-byte LDS store) = four consecutive input bytes, which lie in two
     // aligned dwords (funnel-shifted together); 9 rows x 196 units.  float32: a unit = one ring float.
-    constexpr int NU = U8 ? 7 : 28;
+    constexpr int NU = U8 ? 7 : 28;  // 7 * 256 >= 9 * 198 units; 28 * 256 >= 9 * 792 elements
     unsigned ld[NU], ld2[U8 ? NU : 1];
     auto issue_loads = [&](int py) {
 #pragma unroll
         for (int q = 0; q < NU; ++q) {
             const int u = tid + NTH * q;
             if constexpr (U8) {
-                const int wr = u / 196, g = u - wr * 196;
+                const int wr = u / UPR, g = u - wr * UPR;
                 const int iy = 4 * py - 3 + wr;
                 const bool ok = wr < WROWS && iy >= 0 && iy < d.h;
                 const unsigned gb = (unsigned)(((img * d.h + iy) * d.w + ixlo_c) * 3 + d.x_shift);
@@ -99,7 +138,7 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
                 ld[q] = __builtin_amdgcn_raw_buffer_load_b32(rx, (ok && voff >= 0) ? voff : OOB, 0, 0);
                 ld2[q] = __builtin_amdgcn_raw_buffer_load_b32(rx, (ok && voff + 4 >= 0) ? voff + 4 : OOB, 0, 0);
             } else {
-                const int wr = u / RS, ri = u - wr * RS;
+                const int wr = u / RSE, ri = u - wr * RSE;
                 const int iy = 4 * py - 3 + wr, bi = ri - f0;
                 const bool ok = wr < WROWS && iy >= 0 && iy < d.h && bi >= 0 && bi < nb;
                 const int voff = (((img * d.h + iy) * d.w + ixlo_c) * 3 + bi) * 4;
@@ -110,36 +149,51 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
     auto write_ring = [&](int py) {
         if constexpr (U8) {
             float f[NU][4];
+            unsigned short hq[NU][4];
 #pragma unroll
             for (int q = 0; q < NU; ++q) {  // all table look-ups first (independent), then the stores
                 const int u = tid + NTH * q;
-                const int wr = u / 196, g = u - wr * 196;
+                const int wr = u / UPR, g = u - wr * UPR;
                 const int iy = 4 * py - 3 + wr;
                 const unsigned gb = (unsigned)(((img * d.h + iy) * d.w + ixlo_c) * 3 + d.x_shift);
                 const unsigned sh = ((gb & 3u) + 4u * g - (unsigned)f0) & 3u;
                 const unsigned wbytes = __builtin_amdgcn_alignbyte(ld2[q], ld[q], sh);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f[q][e] = lut[(wbytes >> (8 * e)) & 255u];
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (HALF) hq[q][e] = lut16[(wbytes >> (8 * e)) & 255u];
+                    else f[q][e] = lut[(wbytes >> (8 * e)) & 255u];
+                }
             }
 #pragma unroll
             for (int q = 0; q < NU; ++q) {
                 const int u = tid + NTH * q;
-                const int wr = u / 196, g = u - wr * 196;
+                const int wr = u / UPR, g = u - wr * UPR;
                 const int iy = 4 * py - 3 + wr;
                 const bool ok = iy >= 0 && iy < d.h;
-                float4 o;
                 const int bi = 4 * g - f0;
-                o.x = (ok && bi + 0 >= 0 && bi + 0 < nb) ? f[q][0] : 0.0f;
-                o.y = (ok && bi + 1 >= 0 && bi + 1 < nb) ? f[q][1] : 0.0f;
-                o.z = (ok && bi + 2 >= 0 && bi + 2 < nb) ? f[q][2] : 0.0f;
-                o.w = (ok && bi + 3 >= 0 && bi + 3 < nb) ? f[q][3] : 0.0f;
-                if (u < WROWS * 196) reinterpret_cast<float4*>(ring)[u] = o;  // ring float 4 u = row wr, float 4 g
+                if constexpr (HALF) {
+                    unsigned short o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (ok && bi + e >= 0 && bi + e < nb) ? hq[q][e] : (unsigned short)0;
+                    if (u < WROWS * UPR)  // ring half 4 u = row wr, half 4 g
+                        reinterpret_cast<uint2*>(ring16)[u] = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+                } else {
+                    float4 o;
+                    o.x = (ok && bi + 0 >= 0 && bi + 0 < nb) ? f[q][0] : 0.0f;
+                    o.y = (ok && bi + 1 >= 0 && bi + 1 < nb) ? f[q][1] : 0.0f;
+                    o.z = (ok && bi + 2 >= 0 && bi + 2 < nb) ? f[q][2] : 0.0f;
+                    o.w = (ok && bi + 3 >= 0 && bi + 3 < nb) ? f[q][3] : 0.0f;
+                    if (u < WROWS * UPR) reinterpret_cast<float4*>(ring)[u] = o;  // ring float 4 u = row wr, float 4 g
+                }
             }
         } else {
 #pragma unroll
             for (int q = 0; q < NU; ++q) {
                 const int u = tid + NTH * q;
-                if (u < WROWS * RS) ring[u] = __uint_as_float(ld[q]);  // out-of-image slots were loaded as zeros
+                if (u < WROWS * RSE) {  // out-of-image slots were loaded as zeros
+                    if constexpr (HALF) ring16[u] = to_half_bits<MMA>(__uint_as_float(ld[q]));
+                    else ring[u] = __uint_as_float(ld[q]);
+                }
             }
         }
     };
@@ -171,6 +225,36 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.0f;
+        if constexpr (HALF) {
+            // k-step s, lane half h: k0 = 16 s + 8 h = 24 ky + j0 with j0 in {0, 8, 16}; h = 1 is "+8 halves" of h = 0 except
+            // when s % 3 == 1, where it is the start of the next tap row (second base pointer, like the wrap steps above)
+            const unsigned* pa = reinterpret_cast<const unsigned*>(ring16 + 6 * lc + 8 * hh);
+            const unsigned* pb = reinterpret_cast<const unsigned*>(ring16 + 6 * lc + hh * (RS16 - 16));
+            const u32x4* wv = Wh + hh * COUT + (lane & 31);
+#pragma unroll
+            for (int s = 0; s < KH / 16; ++s) {
+                const int k0 = 16 * s, ky = k0 / 24, j0 = k0 - 24 * ky;       // of the h = 0 half
+                const unsigned* p = (s % 3 == 1 ? pb : pa) + (ky * RS16 + j0) / 2;
+                u32x4 a0 = u32x4{p[0], p[1], p[2], p[3]};
+                u32x4 a1 = u32x4{p[RS16], p[RS16 + 1], p[RS16 + 2], p[RS16 + 3]};  // second conv row: two input rows down
+                if (s == KH / 16 - 1) {  // k >= 168 (h = 1 of the last step): zero weights, and the row read does not exist
+                    a0 = hh ? u32x4{0u, 0u, 0u, 0u} : a0;
+                    a1 = hh ? u32x4{0u, 0u, 0u, 0u} : a1;
+                }
+                const u32x4 b0 = wv[2 * s * COUT], b1 = wv[2 * s * COUT + 32];
+                if constexpr (MMA == 2) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<b8v*>(&a0), *reinterpret_cast<const b8v*>(&b0), acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<b8v*>(&a0), *reinterpret_cast<const b8v*>(&b1), acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<b8v*>(&a1), *reinterpret_cast<const b8v*>(&b0), acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<b8v*>(&a1), *reinterpret_cast<const b8v*>(&b1), acc[1][1], 0, 0, 0);
+                } else {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<h8v*>(&a0), *reinterpret_cast<const h8v*>(&b0), acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<h8v*>(&a0), *reinterpret_cast<const h8v*>(&b1), acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<h8v*>(&a1), *reinterpret_cast<const h8v*>(&b0), acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<h8v*>(&a1), *reinterpret_cast<const h8v*>(&b1), acc[1][1], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < KROWS / 2; ++s) {
             const int k0 = 2 * s, ky = k0 / 21, j0 = k0 - 21 * ky;
@@ -183,6 +267,7 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
         }
         __syncthreads();  // every wave is done with the input rows: the region becomes the V tile
 
@@ -270,6 +355,20 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
     }
     out[i] = v;
 }
+// OIHW [64][3][7][7] -> [k / 8][cout][8] halves with k = 24 ky + 3 kx + c (kx * 3 + c >= 21 and k >= 168: zeros)
+template <int MMA>
+__global__ __launch_bounds__(256) void stem_pack_h_kernel(const float* __restrict__ w, unsigned short* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= KH * COUT) return;
+    const int e = i & 7, o = (i >> 3) % COUT, chunk = i / (8 * COUT);
+    const int k = chunk * 8 + e, ky = k / 24, j = k - 24 * ky;
+    float v = 0.0f;
+    if (ky < 7 && j < 21) {
+        const int kx = j / 3, c = j - 3 * kx;
+        v = w[((o * 3 + c) * 7 + ky) * 7 + kx];
+    }
+    out[i] = to_half_bits<MMA>(v);
+}
 }  // namespace
 
 extern "C" int tia_stem_pack_weights_f32(const float* d_w_oihw, float* d_packed, void* stream) {
@@ -278,8 +377,21 @@ extern "C" int tia_stem_pack_weights_f32(const float* d_w_oihw, float* d_packed,
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
-extern "C" int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, void* d_y,
-                                          int32_t y_dtype, float* d_conv_out, int64_t n, int64_t h, int64_t w, void* stream) {
+
+extern "C" int tia_stem_pack_weights_h(const float* d_w_oihw, int32_t dtype, void* d_packed, void* stream) {
+    if (!d_w_oihw || !d_packed || (dtype != TIA_DT_F16 && dtype != TIA_DT_BF16)) return TIA_EINVAL;
+    const dim3 grid((KH * COUT + 255) / 256);
+    if (dtype == TIA_DT_BF16)
+        hipLaunchKernelGGL(stem_pack_h_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, d_w_oihw, (unsigned short*)d_packed);
+    else
+        hipLaunchKernelGGL(stem_pack_h_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, d_w_oihw, (unsigned short*)d_packed);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+// mma: 0 = float32 matrix cores (weights [148][64] float32), TIA_DT_F16 / TIA_DT_BF16 = half matrix cores (weights packed by
+// tia_stem_pack_weights_h; the output type is then that half type)
+static int stem_impl(const void* d_x, int32_t x_is_u8, const void* d_w_packed, const float* d_bias, void* d_y, int32_t y_dtype,
+                     float* d_conv_out, int64_t n, int64_t h, int64_t w, int32_t mma, void* stream) {
     if (!d_x || !d_w_packed || !d_bias || !d_y || n <= 0 || h <= 0 || w <= 0) return TIA_EINVAL;
     if (y_dtype != TIA_DT_F32 && y_dtype != TIA_DT_F16 && y_dtype != TIA_DT_BF16) return TIA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w_packed) | reinterpret_cast<uintptr_t>(d_y)) & 15) return TIA_EINVAL;
@@ -292,16 +404,21 @@ extern "C" int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, cons
     long group = 0x7fffffffL / image_bytes;  // 32-bit byte offsets inside a launch
     if (group > 0x7fffffffL / (h * w * 3)) group = 0x7fffffffL / (h * w * 3);
     const long strips = wp <= 64 ? 1 : 1 + (wp - 64 + 62) / 63;
+    using Kernel = void (*)(const void*, const void*, const float*, void*, float*, StemDims);
+    const Kernel kernels[3][2] = {{stem7x7_pool_kernel<false, 0>, stem7x7_pool_kernel<true, 0>},
+                                  {stem7x7_pool_kernel<false, 1>, stem7x7_pool_kernel<true, 1>},
+                                  {stem7x7_pool_kernel<false, 2>, stem7x7_pool_kernel<true, 2>}};
     static bool attr_set = false;
-    const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem7x7_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&stem7x7_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return TIA_ELAUNCH;
+        for (int m = 0; m < 3; ++m)
+            for (int u = 0; u < 2; ++u)
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[m][u]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        m == 0 ? (int)(LDS_FLOATS * sizeof(float)) : LDS_BYTES_H) != hipSuccess)
+                    return TIA_ELAUNCH;
         attr_set = true;
     }
+    const int mi = mma == TIA_DT_F16 ? 1 : (mma == TIA_DT_BF16 ? 2 : 0);
+    const size_t lds = mi == 0 ? (size_t)LDS_FLOATS * sizeof(float) : (size_t)LDS_BYTES_H;
     hipStream_t st = (hipStream_t)stream;
     for (long first = 0; first < n; first += group) {
         const long nb = n - first < group ? n - first : group;
@@ -320,10 +437,19 @@ extern "C" int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, cons
         char* yg = static_cast<char*>(d_y) + first * hp * wp * COUT * (y_dtype == TIA_DT_F32 ? 4 : 2);
         float* cg = d_conv_out ? d_conv_out + first * ho * wo * COUT : nullptr;
         const dim3 grid((unsigned)(nb * chunks), (unsigned)strips);
-        if (x_is_u8)
-            hipLaunchKernelGGL(stem7x7_pool_kernel<true>, grid, dim3(NTH), lds, st, xg, d_w_packed, d_bias, yg, cg, d);
-        else
-            hipLaunchKernelGGL(stem7x7_pool_kernel<false>, grid, dim3(NTH), lds, st, xg, d_w_packed, d_bias, yg, cg, d);
+        hipLaunchKernelGGL(kernels[mi][x_is_u8 ? 1 : 0], grid, dim3(NTH), lds, st, static_cast<const void*>(xg), d_w_packed, d_bias,
+                           static_cast<void*>(yg), cg, d);
     }
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_stem_conv7x7_pool_nhwc(const void* d_x, int32_t x_is_u8, const float* d_w_packed, const float* d_bias, void* d_y,
+                                          int32_t y_dtype, float* d_conv_out, int64_t n, int64_t h, int64_t w, void* stream) {
+    return stem_impl(d_x, x_is_u8, d_w_packed, d_bias, d_y, y_dtype, d_conv_out, n, h, w, 0, stream);
+}
+
+extern "C" int tia_stem_conv7x7_pool_nhwc_h(const void* d_x, int32_t x_is_u8, const void* d_w_packed_h, const float* d_bias, void* d_y,
+                                            int32_t dtype, int64_t n, int64_t h, int64_t w, void* stream) {
+    if (dtype != TIA_DT_F16 && dtype != TIA_DT_BF16) return TIA_EINVAL;
+    return stem_impl(d_x, x_is_u8, d_w_packed_h, d_bias, d_y, dtype, nullptr, n, h, w, dtype, stream);
 }

@@ -531,6 +531,43 @@ def pack_stem_weights(conv) -> torch.Tensor:
     return out
 
 
+def pack_stem_weights_h(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """OIHW float32 ``[64, 3, 7, 7]`` -> the half stem's B matrix ``[22, 64, 8]`` (k = 24 ky + 3 kx + c, zero padded to 176)."""
+    from tiatoolbox_amd import _lib
+
+    w = weight.detach().to(torch.float32).contiguous()
+    if tuple(w.shape) != (64, 3, 7, 7) or dtype not in (torch.float16, torch.bfloat16) or not w.is_cuda:
+        msg = f"pack_stem_weights_h expects a CUDA float32 weight [64, 3, 7, 7] and fp16 / bf16; got {tuple(w.shape)}, {dtype}."
+        raise ValueError(msg)
+    out = torch.empty((22, 64, 8), dtype=dtype, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().tia_stem_pack_weights_h(w.data_ptr(), _DT[dtype], out.data_ptr(), _lib.current_stream())
+    _lib.check(rc, "tia_stem_pack_weights_h")
+    return out
+
+
+def hip_stem_conv_pool_h(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, *, dtype: torch.dtype) -> torch.Tensor:
+    """:func:`hip_stem_conv_pool` on the half matrix cores (``tia_stem_conv7x7_pool_nhwc_h``): ``x / 255`` and the weights
+    rounded to ``dtype`` (what ``model.half()`` feeds its first convolution), float32 accumulation, bias + ReLU + max-pool in
+    float32, ONE rounding of the pooled result to ``dtype``.  ``x``: NHWC uint8 or float32 CUDA batch."""
+    from tiatoolbox_amd import _lib
+
+    if not (x.is_cuda and x.dim() == 4 and x.shape[-1] == 3 and x.is_contiguous() and x.dtype in (torch.uint8, torch.float32)):  # noqa: PLR2004
+        msg = "hip_stem_conv_pool_h expects a contiguous NHWC uint8 / float32 CUDA batch with 3 channels."
+        raise ValueError(msg)
+    if w_packed.dtype != dtype or tuple(w_packed.shape) != (22, 64, 8):
+        msg = "hip_stem_conv_pool_h expects weights packed by pack_stem_weights_h for the same dtype."
+        raise ValueError(msg)
+    n, h, w, _ = x.shape
+    hp, wp = ((h - 1) // 2) // 2 + 1, ((w - 1) // 2) // 2 + 1
+    y = torch.empty((n, 64, hp, wp), dtype=dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_stem_conv7x7_pool_nhwc_h(x.data_ptr(), int(x.dtype == torch.uint8), w_packed.data_ptr(), bias.data_ptr(),
+                                                      y.data_ptr(), _DT[dtype], n, h, w, _lib.current_stream())
+    _lib.check(rc, "tia_stem_conv7x7_pool_nhwc_h")
+    return y
+
+
 def hip_stem_conv_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, *,
                        out_dtype: torch.dtype = torch.float32, return_conv: bool = False):
     """``maxpool3x3/2(relu(conv7x7/2(x) + bias))`` in one kernel (``tia_stem_conv7x7_pool_nhwc``).
@@ -564,7 +601,7 @@ class MfmaResNet(nn.Module):
     kernel reading uint8 or float32 patches) and every block convolution (BasicBlock: resnet18/34; Bottleneck: resnet50/101) as
     an MFMA implicit GEMM with its epilogue fused (BN folded, channels-last) -- ``tia_conv2d_nhwc_f32`` for float32 (the
     reference's arithmetic), ``tia_conv2d_nhwc_h`` once the module has been cast to fp16 / bf16 (float32 accumulation; the stem
-    then rounds its float32 result to half once).  A ``uint8`` input means ``ToTensor`` has been deferred into the stem: the
+    is then ``tia_stem_conv7x7_pool_nhwc_h``: half inputs and weights on the half matrix cores, one rounding of the result).  A ``uint8`` input means ``ToTensor`` has been deferred into the stem: the
     kernel divides by 255 while it loads."""
 
     accepts_uint8 = True
@@ -574,6 +611,7 @@ class MfmaResNet(nn.Module):
         folded = fold_conv_bn(trunk)
         self.stem = folded[0]
         self._stem_packed: torch.Tensor | None = None
+        self._stem_packed_dtype: torch.dtype | None = None
         blocks = []
         for layer in list(folded)[4:]:
             for blk in layer:
@@ -590,11 +628,14 @@ class MfmaResNet(nn.Module):
         x = x.contiguous()
         if x.dtype not in (torch.uint8, torch.float32):
             x = x.to(torch.float32)
+        dtype = self.stem.weight.dtype
         w = self._stem_packed
-        if w is None or w.device != self.stem.weight.device:
-            w = self._stem_packed = pack_stem_weights(self.stem)
-            self._stem_bias = self.stem.bias.detach().float().contiguous()
-        return hip_stem_conv_pool(x, w, self._stem_bias, out_dtype=self.stem.weight.dtype)
+        if w is None or w.device != self.stem.weight.device or self._stem_packed_dtype != dtype:
+            self.prepare_stem(dtype)
+            w = self._stem_packed
+        if dtype == torch.float32:
+            return hip_stem_conv_pool(x, w, self._stem_bias)
+        return hip_stem_conv_pool_h(x, w, self._stem_bias, dtype=dtype)  # half matrix cores, float32 accumulate
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.blocks(self.stem_forward(x))
@@ -602,10 +643,15 @@ class MfmaResNet(nn.Module):
     def prepare(self, dtype: torch.dtype) -> None:
         """Pack every convolution for ``dtype`` from the float32 parameters (the engine calls this on the device, before it
         casts the inference copy to half)."""
-        self._stem_packed = pack_stem_weights(self.stem)
-        self._stem_bias = self.stem.bias.detach().float().clone().contiguous()
+        self.prepare_stem(dtype)
         for blk in self.blocks:
             blk.prepare(dtype)
+
+    def prepare_stem(self, dtype: torch.dtype) -> None:
+        weight = self.stem.weight.detach().float()
+        self._stem_packed = pack_stem_weights(weight) if dtype == torch.float32 else pack_stem_weights_h(weight, dtype)
+        self._stem_packed_dtype = dtype
+        self._stem_bias = self.stem.bias.detach().float().clone().contiguous()
 
 
 def fuse_cnn_model(model: nn.Module, *, epilogue_fusion: bool | str = False) -> nn.Module:
