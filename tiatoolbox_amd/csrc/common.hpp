@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "tiatoolbox_amd.h"
 
@@ -208,5 +209,18 @@ __device__ __forceinline__ void unpack_group(uint32_t a, uint32_t b, uint32_t c,
     r[2] = (b >> 16) & 255u;  g[2] = b >> 24;           bl[2] = c & 255u;
     r[3] = (c >> 8) & 255u;   g[3] = (c >> 16) & 255u;  bl[3] = c >> 24;
 }
+
+// ---- LDS-resident labelling of small planes (imgops.hip; internal interface shared with hover_post.hip) ---------------------
+constexpr long kCclTileMaxPixels = 36864;  // int32 union-find of one plane in LDS: 147,456 of the CU's 163,840 bytes
+inline bool ccl_tile_enabled() {           // developer switch: TIA_NO_CCL_TILE=1 keeps the multi-launch path (parity audit)
+    static const bool on = getenv("TIA_NO_CCL_TILE") == nullptr;
+    return on;
+}
+// labels (1-based, raster order of the components' first pixels; 0 = background or removed) of n planes of h x w <= 36,864
+// pixels in one launch.  src_kind 0: uint8 mask != 0; 1: uint8 mask == 0; 2: float32 map >= 0.5.  min_keep > 0: components with
+// fewer pixels become 0 (their numbers are not re-used); areas (nullable): [n][h*w + 1] component areas by label.
+int ccl_tile_label(const void* src, int src_kind, long n, int h, int w, int conn, int min_keep, int* labels, int* count, int* areas,
+                   hipStream_t st);
+int fill_holes_tile(const uint8_t* mask, long n, int h, int w, uint8_t* out, hipStream_t st);
 
 }  // namespace tia

@@ -1018,11 +1018,17 @@ static int hover_proc_impl(const float* d_np, const float* d_hv, int64_t n, int6
     dim3 grid(hblocks(hw), (unsigned)n);
     int rc;
     // 1. blb = remove_small_objects(label(np >= 0.5), max_size=9) > 0
-    hipLaunchKernelGGL(np_threshold_kernel, dim3(hblocks((long)n * hw, HT, 65535)), dim3(HT), 0, st, d_np, (long)n * hw, blb_mask);
-    rc = tia_ccl_label_i32(blb_mask, n, h, w, 4, blob_lab, cnt_blob, ws_int, st);
-    if (rc != TIA_OK) return rc;
-    rc = tia_label_area_filter_i32(blob_lab, n, h, w, 10, ws_int, st);  // areas stay in ws_int
-    if (rc != TIA_OK) return rc;
+    const bool tile = ccl_tile_enabled() && hw <= kCclTileMaxPixels;  // small planes: threshold + labelling + area filter in ONE launch
+    if (tile) {
+        rc = ccl_tile_label(d_np, 2, (long)n, (int)h, (int)w, 4, 10, blob_lab, cnt_blob, ws_int, st);  // areas -> ws_int
+        if (rc != TIA_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(np_threshold_kernel, dim3(hblocks((long)n * hw, HT, 65535)), dim3(HT), 0, st, d_np, (long)n * hw, blb_mask);
+        rc = tia_ccl_label_i32(blb_mask, n, h, w, 4, blob_lab, cnt_blob, ws_int, st);
+        if (rc != TIA_OK) return rc;
+        rc = tia_label_area_filter_i32(blob_lab, n, h, w, 10, ws_int, st);  // areas stay in ws_int
+        if (rc != TIA_OK) return rc;
+    }
     // blob bounding boxes + heap offsets need the areas: do them before ws_int is reused
     hipLaunchKernelGGL(bbox_reset_kernel, dim3(hblocks((long)n * (hw + 1), HT, 65535)), dim3(HT), 0, st, bbox, (long)n * (hw + 1));
     hipLaunchKernelGGL(ws_offsets_kernel, dim3((unsigned)n), dim3(1024), 0, st, areas, cnt_blob, hw, 10, offs);
@@ -1059,10 +1065,15 @@ static int hover_proc_impl(const float* d_np, const float* d_hv, int64_t n, int6
     if (rc != TIA_OK) return rc;
     rc = tia_binary_morph_u8(tmp_a, n, h, w, se_offs, 17, 0, tmp_b, st);
     if (rc != TIA_OK) return rc;
-    rc = tia_ccl_label_i32(tmp_b, n, h, w, 4, mark_lab, d_ninst, ws_int, st);
-    if (rc != TIA_OK) return rc;
-    rc = tia_label_area_filter_i32(mark_lab, n, h, w, obj_size, ws_int, st);
-    if (rc != TIA_OK) return rc;
+    if (tile) {
+        rc = ccl_tile_label(tmp_b, 0, (long)n, (int)h, (int)w, 4, obj_size, mark_lab, d_ninst, ws_int, st);
+        if (rc != TIA_OK) return rc;
+    } else {
+        rc = tia_ccl_label_i32(tmp_b, n, h, w, 4, mark_lab, d_ninst, ws_int, st);
+        if (rc != TIA_OK) return rc;
+        rc = tia_label_area_filter_i32(mark_lab, n, h, w, obj_size, ws_int, st);
+        if (rc != TIA_OK) return rc;
+    }
     if (!tap(taps.markers, mark_lab, plane_i32)) return TIA_ELAUNCH;
 
     // 5. watershed(dist, markers, mask = blb)

@@ -265,6 +265,169 @@ static int ccl_run(const uint8_t* d_mask, long n, int h, int w, int conn, int* d
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
+// ---- small planes: the whole labelling in ONE launch, union-find resident in LDS ----------------------------------------
+// One 1024-thread workgroup per plane of at most 36,864 pixels (HoVer-Net's 164 x 164 head maps): forest initialisation (runs cut
+// at wave boundaries, as above), merge, flatten, raster-order ranking of the roots and -- optionally -- the area filter
+// (skimage.morphology.remove_small_objects) without leaving the CU.  Same labels as ccl_run + tia_label_area_filter_i32:
+// a component's root is its raster-first pixel, ranks follow the roots' raster order (= skimage.measure.label's numbering).
+// After flattening, a root's slot is re-used as its record: 0x80000000 | area << 15 | rank (rank < 2^15: at most hw / 2
+// components; area < 2^16), background stays 0xffffffff, every other foreground pixel holds the index of its root.
+//   SRC 0: foreground = mask byte != 0;  1: foreground = mask byte == 0 (background labelling);  2: float32 map >= 0.5
+__device__ __forceinline__ int lds_find(const int* L, int i) {
+    int p = L[i];
+    while (p != i) {
+        i = p;
+        p = L[i];
+    }
+    return i;
+}
+__device__ __forceinline__ void lds_union(int* L, int a, int b) {
+    while (true) {
+        a = lds_find(L, a);
+        b = lds_find(L, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+template <int SRC>
+__device__ __forceinline__ void tile_forest(const void* __restrict__ src, long plane_off, int h, int w, int conn8, int* L) {
+    const int hw = h * w, tid = threadIdx.x, lane = tid & 63;
+    for (int base = 0; base < hw; base += 1024) {  // same trip count for every lane: the ballots need whole waves
+        const int i = base + tid;
+        const bool inb = i < hw;
+        bool fg = false;
+        if (inb) {
+            if constexpr (SRC == 2) fg = static_cast<const float*>(src)[plane_off + i] >= 0.5f;
+            else if constexpr (SRC == 1) fg = static_cast<const uint8_t*>(src)[plane_off + i] == 0;
+            else fg = static_cast<const uint8_t*>(src)[plane_off + i] != 0;
+        }
+        const int x = inb ? i % w : 0;
+        const bool prev_fg = __shfl_up((int)fg, 1) != 0;
+        const bool start = fg && (lane == 0 || x == 0 || !prev_fg);
+        const unsigned long long starts = __ballot(start);
+        if (!inb) continue;
+        if (fg) {
+            const unsigned long long below = starts & ((2ull << lane) - 1ull);
+            L[i] = i - lane + (63 - __builtin_clzll(below));
+        } else {
+            L[i] = -1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < hw; i += 1024) {
+        if (L[i] < 0) continue;
+        const int y = i / w, x = i - y * w;
+        const bool left = x > 0 && L[i - 1] >= 0;
+        if (left && (i & 63) == 0) lds_union(L, i, i - 1);  // run cut at a wave boundary by the initialisation
+        if (y == 0) continue;
+        const bool up = L[i - w] >= 0;
+        const bool upleft = x > 0 && L[i - w - 1] >= 0;
+        if (up) {
+            if (!left || !upleft) lds_union(L, i, i - w);  // first column of the overlap with the run above
+        } else if (conn8) {
+            if (upleft && !left) lds_union(L, i, i - w - 1);
+            if (x < w - 1 && L[i - w + 1] >= 0 && !(L[i + 1] >= 0)) lds_union(L, i, i - w + 1);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < hw; i += 1024)
+        if (L[i] >= 0) L[i] = lds_find(L, i);
+    __syncthreads();
+}
+
+template <int SRC>
+__global__ __launch_bounds__(1024) void ccl_tile_kernel(const void* __restrict__ src, int h, int w, int conn8, int min_keep,
+                                                         int* __restrict__ labels, int* __restrict__ count, int* __restrict__ areas) {
+    extern __shared__ int L[];
+    __shared__ unsigned wtot[16];
+    __shared__ unsigned s_running;
+    const int hw = h * w, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long plane_off = (long)blockIdx.x * hw;
+    tile_forest<SRC>(src, plane_off, h, w, conn8, L);
+    // rank the roots in raster order (4 consecutive pixels per lane and round), leave each root's record in its slot
+    if (tid == 0) s_running = 0;
+    __syncthreads();
+    for (int base = 0; base < hw; base += 4096) {
+        const int i0 = base + 4 * tid;
+        unsigned f[4], c = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[k] = (i0 + k < hw && L[i0 + k] == i0 + k) ? 1u : 0u;
+            c += f[k];
+        }
+        const unsigned incl = wave_incl_scan_u32(c);
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        unsigned before = s_running + incl - c, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned x = wtot[q];
+            before += q < wv ? x : 0u;
+            tot += x;
+        }
+        __syncthreads();
+        if (tid == 0) s_running += tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (f[k]) L[i0 + k] = (int)(0x80000000u | ++before);
+        __syncthreads();
+    }
+    const unsigned ncomp = s_running;
+    if (tid == 0) count[blockIdx.x] = (int)ncomp;
+    // areas: one LDS add per foreground pixel on its root's record (the root counts itself)
+    for (int i = tid; i < hw; i += 1024) {
+        const int v = L[i];
+        if (v == -1) continue;
+        atomicAdd(reinterpret_cast<unsigned*>(&L[v < 0 ? i : v]), 1u << 15);
+    }
+    __syncthreads();
+    int* a = areas ? areas + (size_t)blockIdx.x * (hw + 1) : nullptr;
+    if (a && tid == 0) a[0] = 0;
+    int* out = labels + plane_off;
+    for (int i = tid; i < hw; i += 1024) {
+        const int v = L[i];
+        int lab = 0;
+        if (v != -1) {
+            const unsigned rec = (unsigned)(v < 0 ? v : L[v]);
+            const int rank = (int)(rec & 0x7fffu), area = (int)((rec >> 15) & 0xffffu);
+            if (v < 0 && a) a[rank] = area;  // the root publishes its component's area
+            lab = area >= min_keep ? rank : 0;
+        }
+        out[i] = lab;
+    }
+}
+
+// scipy.ndimage.binary_fill_holes on a small plane: background components (4-connectivity) that do not reach the frame
+__global__ __launch_bounds__(1024) void fill_holes_tile_kernel(const uint8_t* __restrict__ mask, int h, int w, uint8_t* __restrict__ out) {
+    extern __shared__ int L[];
+    const int hw = h * w, tid = threadIdx.x;
+    const long plane_off = (long)blockIdx.x * hw;
+    tile_forest<1>(mask, plane_off, h, w, 0, L);
+    const int nb = 2 * w + 2 * h;
+    for (int k = tid; k < nb; k += 1024) {
+        int i;
+        if (k < w) i = k;
+        else if (k < 2 * w) i = (h - 1) * w + (k - w);
+        else if (k < 2 * w + h) i = (k - 2 * w) * w;
+        else i = (k - 2 * w - h) * w + (w - 1);
+        const int v = L[i];
+        if (v >= 0) atomicOr(&L[v & 0x3fffffff], 0x40000000);  // v: the root (a root's own slot may already carry the flag)
+    }
+    __syncthreads();
+    for (int i = tid; i < hw; i += 1024) {
+        const int v = L[i];
+        const bool hole = v >= 0 && (L[v & 0x3fffffff] & 0x40000000) == 0;
+        out[plane_off + i] = (mask[plane_off + i] != 0 || hole) ? 1 : 0;
+    }
+}
+
 // ---- label areas -----------------------------------------------------------------------------------------
 // Areas by run aggregation: a lane holds 4 consecutive pixels; lanes whose 4 pixels carry one label merge
 // with their neighbours through a ballot (one update per run of lanes instead of one per pixel), and every
@@ -438,6 +601,47 @@ __global__ __launch_bounds__(BT) void fill_apply_kernel(const uint8_t* __restric
 
 using namespace tia;
 
+// ---- host side of the LDS-resident small-plane kernels (internal interface, common.hpp) -------------------------------------
+namespace tia {
+template <typename K>
+static bool tile_lds_ok(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+int ccl_tile_label(const void* src, int src_kind, long n, int h, int w, int conn, int min_keep, int* labels, int* count, int* areas,
+                   hipStream_t st) {
+    const size_t lds = (size_t)h * w * sizeof(int);
+    static bool ready = false;
+    if (!ready) {
+        const size_t cap = (size_t)kCclTileMaxPixels * sizeof(int);
+        if (!tile_lds_ok(ccl_tile_kernel<0>, cap) || !tile_lds_ok(ccl_tile_kernel<1>, cap) || !tile_lds_ok(ccl_tile_kernel<2>, cap) ||
+            !tile_lds_ok(fill_holes_tile_kernel, cap))
+            return TIA_ELAUNCH;
+        ready = true;
+    }
+    const int c8 = conn == 8 ? 1 : 0;
+    if (src_kind == 2)
+        hipLaunchKernelGGL(ccl_tile_kernel<2>, dim3((unsigned)n), dim3(1024), lds, st, src, h, w, c8, min_keep, labels, count, areas);
+    else if (src_kind == 1)
+        hipLaunchKernelGGL(ccl_tile_kernel<1>, dim3((unsigned)n), dim3(1024), lds, st, src, h, w, c8, min_keep, labels, count, areas);
+    else
+        hipLaunchKernelGGL(ccl_tile_kernel<0>, dim3((unsigned)n), dim3(1024), lds, st, src, h, w, c8, min_keep, labels, count, areas);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+int fill_holes_tile(const uint8_t* mask, long n, int h, int w, uint8_t* out, hipStream_t st) {
+    int rc = TIA_OK;
+    {
+        static bool ready = false;
+        if (!ready) {
+            if (!tile_lds_ok(fill_holes_tile_kernel, (size_t)kCclTileMaxPixels * sizeof(int))) return TIA_ELAUNCH;
+            ready = true;
+        }
+    }
+    hipLaunchKernelGGL(fill_holes_tile_kernel, dim3((unsigned)n), dim3(1024), (size_t)h * w * sizeof(int), st, mask, h, w, out);
+    if (hipGetLastError() != hipSuccess) rc = TIA_ELAUNCH;
+    return rc;
+}
+}  // namespace tia
+
 static bool bad3(int64_t n, int64_t h, int64_t w) {
     return n <= 0 || h <= 0 || w <= 0 || n > 65535 || h * w > 0x7fffffffLL;
 }
@@ -520,6 +724,8 @@ extern "C" int tia_ccl_label_i32(const uint8_t* d_mask, int64_t n, int64_t h, in
     if (!d_mask || !d_labels || !d_count || !d_ws) return TIA_EINVAL;
     if (bad3(n, h, w)) return TIA_ESIZE;
     if (connectivity != 4 && connectivity != 8) return TIA_EINVAL;
+    if (ccl_tile_enabled() && h * w <= kCclTileMaxPixels)  // small planes: one launch, union-find in LDS (d_ws stays unused)
+        return ccl_tile_label(d_mask, 0, n, (int)h, (int)w, connectivity, 0, d_labels, d_count, nullptr, (hipStream_t)stream);
     return ccl_run(d_mask, n, (int)h, (int)w, connectivity, d_labels, d_count, d_ws, false, (hipStream_t)stream);
 }
 
@@ -555,6 +761,7 @@ extern "C" int tia_fill_holes_u8(const uint8_t* d_mask, int64_t n, int64_t h, in
     if (bad3(n, h, w)) return TIA_ESIZE;
     const long hw = (long)h * w;
     hipStream_t st = (hipStream_t)stream;
+    if (ccl_tile_enabled() && hw <= kCclTileMaxPixels) return fill_holes_tile(d_mask, n, (int)h, (int)w, d_out, st);
     int32_t* labels = d_ws;
     int32_t* aux = d_ws + (size_t)n * hw;        // ranks, then border flags
     int32_t* counts = d_ws + 2 * (size_t)n * hw;  // [n] component counts (unused by the caller)
