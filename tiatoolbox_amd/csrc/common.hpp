@@ -219,8 +219,15 @@ inline bool ccl_tile_enabled() {           // developer switch: TIA_NO_CCL_TILE=
 // labels (1-based, raster order of the components' first pixels; 0 = background or removed) of n planes of h x w <= 36,864
 // pixels in one launch.  src_kind 0: uint8 mask != 0; 1: uint8 mask == 0; 2: float32 map >= 0.5.  min_keep > 0: components with
 // fewer pixels become 0 (their numbers are not re-used); areas (nullable): [n][h*w + 1] component areas by label.
+// offs / bbox (nullable): heap-segment offsets and bounding-box reset of the labels (HoVer-Net's blob stage)
 int ccl_tile_label(const void* src, int src_kind, long n, int h, int w, int conn, int min_keep, int* labels, int* count, int* areas,
-                   hipStream_t st);
+                   hipStream_t st, int* offs = nullptr, int* bbox = nullptr);
 int fill_holes_tile(const uint8_t* mask, long n, int h, int w, uint8_t* out, hipStream_t st);
+// HoVer-Net's marker pipeline (fill holes -> 5x5 elliptical opening -> label -> area filter) of n planes in one launch;
+// union-find + one byte plane in LDS: h * w <= 32,000
+constexpr long kMarkerTileMaxPixels = 32000;
+// blob / inst / bbox (nullable together): also write the watershed's initial state (inst, blob bounding boxes)
+int marker_tile(const uint8_t* marker0, long n, int h, int w, int min_keep, int* labels, int* count, int* areas, hipStream_t st,
+                const int* blob = nullptr, int* inst = nullptr, int* bbox = nullptr);
 
 }  // namespace tia

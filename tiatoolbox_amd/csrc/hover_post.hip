@@ -3,6 +3,7 @@
 // priority flood run independently per connected mask blob (the global skimage heap restricted
 // to one blob pops in the same order as a private heap, because a blob's entries are only ever
 // inserted by pops of that blob), one lane per blob with its heap segment in global memory.
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -25,6 +26,12 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     i %= period;
     if (i < 0) i += period;
     return i >= n ? period - i : i;
+}
+
+// the same for -n < i < 2 n - 1 (one reflection at most): no integer division
+__device__ __forceinline__ int reflect101_near(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
 }
 
 __global__ __launch_bounds__(256) void np_threshold_kernel(const float* __restrict__ np_map, long n, uint8_t* __restrict__ mask) {
@@ -215,6 +222,227 @@ __global__ __launch_bounds__(HT) void gauss3_neg_kernel(const double* __restrict
         }
         d[i] = -(r[1] * 0.5 + (r[0] + r[2]) * 0.25);
     }
+}
+
+// ---- small planes: min / max, both Sobel filters, their min / max and the energy landscape in ONE launch ------------------
+// One 1024-thread workgroup per plane.  The separable filter runs in bands of output rows: the row pass of the band's rows
+// (+ the ksize / 2 rows above and below) goes to an LDS buffer, the column pass reads it from there (the multi-launch form
+// sends the whole f64 row-pass plane through HBM).  Per-pixel arithmetic = sobel_row_kernel / sobel_col_kernel / energy_kernel
+// above, operation for operation; min / max are order-independent.  After the last band the workgroup knows the range of
+// both gradient planes and turns them into the energy landscape + marker seed (re-reading the planes it just wrote).
+__device__ __forceinline__ void block_minmax2(MinMax2 m, double (*red)[4], double* out4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = __shfl_down(m.v[k], o, 64);
+        m.merge(t);
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave_id()][k] = m.v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m.merge(red[i]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out4[k] = m.v[k];
+    }
+    __syncthreads();
+}
+
+// KS: the filter size at compile time (21: HoVer-Net, 11: HoVerNet+) -- the tap loops are then fully unrolled and the taps are
+// scalar registers; with a run-time index every tap is a scalar load from the kernel arguments.  KS = 0: any size.
+#ifdef TIA_TILE_TIMING
+__device__ long long g_tile_stamps[16];
+#define TSTAMP(I) if (blockIdx.x == 0 && threadIdx.x == 0) g_tile_stamps[I] = clock64()
+#else
+#define TSTAMP(I)
+#endif
+
+template <int KS>
+__global__ __launch_bounds__(1024) void sobel_energy_tile_kernel(const float* __restrict__ hv, int h, int w, const SobelTaps kd,
+                                                                  const SobelTaps ks, int ksize_rt, int band, int n,
+                                                                  const int* __restrict__ blob, double* __restrict__ sob_h,
+                                                                  double* __restrict__ sob_v, double* __restrict__ dist0,
+                                                                  uint8_t* __restrict__ marker0, double* __restrict__ mm,
+                                                                  double* __restrict__ dist) {
+    extern __shared__ double rb[];  // row-pass band: (band + ksize - 1) rows x w doubles, then the same rows of the normalised input
+    __shared__ double red[16][4];
+    __shared__ double s_in[4], s_out[4];  // min / max: (h, v) of the input maps, then of the two gradient planes
+    const int ksize = KS ? KS : ksize_rt;
+    const int plane = blockIdx.x, tid = threadIdx.x, hw = h * w, anchor = ksize / 2;
+    float* inb = reinterpret_cast<float*>(rb + (size_t)(band + ksize - 1) * w);
+    const bool near = h > anchor && w > anchor;  // border taps reflect once at most (otherwise: the general form)
+    auto refl = [&](int i, int nn) { return near ? reflect101_near(i, nn) : reflect101(i, nn); };
+    const size_t off = (size_t)plane * hw;
+    const float2* in2 = reinterpret_cast<const float2*>(hv + off * 2);
+    TSTAMP(0);
+    {
+        MinMax2 m;
+        m.init();
+#pragma unroll 8  // one workgroup per CU: the loads of several rounds must be in flight together
+        for (int i = tid; i < hw; i += 1024) {
+            const float2 a = in2[i];
+            m.add((double)a.x, (double)a.y);
+        }
+        block_minmax2(m, red, s_in);
+    }
+    if (tid == 0) {
+        mm[plane * 2] = s_in[0];
+        mm[plane * 2 + 1] = s_in[1];
+        mm[2 * n + plane * 2] = s_in[2];
+        mm[2 * n + plane * 2 + 1] = s_in[3];
+    }
+    TSTAMP(1);
+    MinMax2 mo;
+    mo.init();
+#pragma unroll  // both copies: which tap set is the row filter must be known at compile time (a run-time choice turns every tap
+                // into a scalar load from the kernel arguments, ~200 cycles that one workgroup per CU cannot hide)
+    for (int ch = 0; ch < 2; ++ch) {
+        // h: dx = 1 -> row taps = derivative, column taps = smoothing (symmetric); v: the other way round (antisymmetric)
+        const SobelTaps& kx = ch == 0 ? kd : ks;
+        const SobelTaps& ky = ch == 0 ? ks : kd;
+        const bool symmetric = ch == 0;
+        double scale, shift;
+        norm_params(s_in + 2 * ch, scale, shift);
+        const float a = (float)scale, b = (float)shift;
+        const float* src = hv + off * 2 + ch;
+        double* dst = (ch == 0 ? sob_h : sob_v) + off;
+        double vmin = 1.0 / 0.0, vmax = -1.0 / 0.0;
+        for (int y0 = 0; y0 < h; y0 += band) {
+            const int y1 = min(h, y0 + band);  // output rows [y0, y1)
+            const int lo = max(0, y0 - anchor), hi = min(h - 1, y1 - 1 + anchor);
+            const int nrow = (hi - lo + 1) * w;
+            // the band's input rows, normalised (f32 arithmetic, as convertTo does for CV_32F sources), to LDS
+#pragma unroll 8
+            for (int i = tid; i < nrow; i += 1024) inb[i] = src[((size_t)lo * w + i) * 2] * a + b;
+            __syncthreads();
+            if (ch == 0 && y0 == 0) TSTAMP(2);
+            // row pass, two pixels per lane and round (independent accumulation chains); taps in ascending order
+            for (int i = tid; i < nrow; i += 2048) {
+                const int i2 = i + 1024;
+                const bool two = i2 < nrow;
+                const int r0 = i / w, x0 = i - r0 * w, r1 = two ? i2 / w : r0, x1 = two ? i2 - r1 * w : x0;
+                const float* p0 = inb + r0 * w;
+                const float* p1 = inb + r1 * w;
+                double acc0 = 0.0, acc1 = 0.0;
+                if (x0 >= anchor && x0 + anchor < w && x1 >= anchor && x1 + anchor < w) {
+                    p0 += x0 - anchor;
+                    p1 += x1 - anchor;
+#pragma unroll
+                    for (int k = 0; k < ksize; ++k) {
+                        const double t0 = kx.v[k] * (double)p0[k];
+                        const double t1 = kx.v[k] * (double)p1[k];
+                        acc0 = (k == 0) ? t0 : acc0 + t0;
+                        acc1 = (k == 0) ? t1 : acc1 + t1;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < ksize; ++k) {
+                        const double t0 = kx.v[k] * (double)p0[refl(x0 + k - anchor, w)];
+                        const double t1 = kx.v[k] * (double)p1[refl(x1 + k - anchor, w)];
+                        acc0 = (k == 0) ? t0 : acc0 + t0;
+                        acc1 = (k == 0) ? t1 : acc1 + t1;
+                    }
+                }
+                rb[i] = acc0;
+                if (two) rb[i2] = acc1;
+            }
+            __syncthreads();
+            if (ch == 0 && y0 == 0) TSTAMP(3);
+            const int nout = (y1 - y0) * w;
+            for (int i = tid; i < nout; i += 2048) {
+                const int i2 = i + 1024;
+                const bool two = i2 < nout;
+                const int r0 = i / w, x0 = i - r0 * w, r1 = two ? i2 / w : r0, x1 = two ? i2 - r1 * w : x0;
+                const int ya = y0 + r0, yb = y0 + r1;
+                const double* c0 = rb + (ya - lo) * w + x0;
+                const double* c1 = rb + (yb - lo) * w + x1;
+                double acc0 = symmetric ? (ky.v[anchor] * c0[0] + 0.0) : 0.0;
+                double acc1 = symmetric ? (ky.v[anchor] * c1[0] + 0.0) : 0.0;
+                if (ya >= anchor && ya + anchor < h && yb >= anchor && yb + anchor < h) {
+#pragma unroll
+                    for (int k = 1; k <= anchor; ++k) {
+                        const double up0 = c0[k * w], dn0 = c0[-k * w], up1 = c1[k * w], dn1 = c1[-k * w];
+                        acc0 = acc0 + ky.v[anchor + k] * (symmetric ? (up0 + dn0) : (up0 - dn0));
+                        acc1 = acc1 + ky.v[anchor + k] * (symmetric ? (up1 + dn1) : (up1 - dn1));
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 1; k <= anchor; ++k) {
+                        const double up0 = rb[(refl(ya + k, h) - lo) * w + x0], dn0 = rb[(refl(ya - k, h) - lo) * w + x0];
+                        const double up1 = rb[(refl(yb + k, h) - lo) * w + x1], dn1 = rb[(refl(yb - k, h) - lo) * w + x1];
+                        acc0 = acc0 + ky.v[anchor + k] * (symmetric ? (up0 + dn0) : (up0 - dn0));
+                        acc1 = acc1 + ky.v[anchor + k] * (symmetric ? (up1 + dn1) : (up1 - dn1));
+                    }
+                }
+                dst[ya * w + x0] = acc0;
+                vmin = acc0 < vmin ? acc0 : vmin;
+                vmax = acc0 > vmax ? acc0 : vmax;
+                if (two) {
+                    dst[yb * w + x1] = acc1;
+                    vmin = acc1 < vmin ? acc1 : vmin;
+                    vmax = acc1 > vmax ? acc1 : vmax;
+                }
+            }
+            __syncthreads();
+        }
+        if (ch == 0) TSTAMP(4);
+        mo.v[2 * ch] = vmin;
+        mo.v[2 * ch + 1] = vmax;
+    }
+    TSTAMP(5);
+    // (workgroup scope: an agent-scope fence writes the XCD's whole L2 back -- measured 150 us here)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the gradient planes are re-read below by other lanes of this workgroup
+    block_minmax2(mo, red, s_out);
+    if (tid == 0) {
+        mm[4 * n + plane * 2] = s_out[0];
+        mm[4 * n + plane * 2 + 1] = s_out[1];
+        mm[6 * n + plane * 2] = s_out[2];
+        mm[6 * n + plane * 2 + 1] = s_out[3];
+    }
+    TSTAMP(6);
+    double sh_s, sh_b, sv_s, sv_b;
+    norm_params(s_out, sh_s, sh_b);
+    norm_params(s_out + 2, sv_s, sv_b);
+    // Plain loads are coherent here: the planes were written by THIS workgroup (fence + barrier above), this CU has not read
+    // these addresses before in this launch, and its L1 starts a launch empty -- no stale line can exist.
+    const double* gh = sob_h + off;
+    const double* gv = sob_v + off;
+#pragma unroll 4
+    for (int i = tid; i < hw; i += 1024) {
+        const int blb = blob[off + i] > 0 ? 1 : 0;
+        const float nh = (float)(gh[i] * sh_s + sh_b);  // f64 -> f32 convertTo
+        const float nv = (float)(gv[i] * sv_s + sv_b);
+        const float sh = 1.0f - nh, sv = 1.0f - nv;      // 1 - float32
+        const float ov32 = sh > sv ? sh : sv;            // np.maximum (float32)
+        double overall = (double)ov32 - (double)(1 - blb);
+        if (overall < 0.0) overall = 0.0;
+        dist0[off + i] = (1.0 - overall) * (double)blb;
+        int mk = blb - (overall >= 0.4 ? 1 : 0);
+        marker0[off + i] = mk < 0 ? 0 : (uint8_t)mk;
+    }
+    TSTAMP(7);
+    if (dist == nullptr) return;
+    // dist = -GaussianBlur3x3(dist0) (= gauss3_neg_kernel), reading back the plane this workgroup just wrote
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    TSTAMP(8);
+    const double* sg = dist0 + off;
+#pragma unroll 2
+    for (int i = tid; i < hw; i += 1024) {
+        const int y = i / w, x = i - y * w;
+        const int xm = refl(x - 1, w), xp = refl(x + 1, w);
+        double r[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double* row = sg + (long)refl(y + j - 1, h) * w;
+            r[j] = row[x] * 0.5 + (row[xm] + row[xp]) * 0.25;
+        }
+        dist[off + i] = -(r[1] * 0.5 + (r[0] + r[2]) * 0.25);
+    }
+    TSTAMP(9);
 }
 
 // ---- watershed -----------------------------------------------------------------------------------------------------
@@ -934,10 +1162,10 @@ extern "C" size_t tia_hover_workspace_bytes(int64_t n, int64_t h, int64_t w) {
 static int launch_watershed(const int* blob_lab, const int* mark_lab, const double* dist, const int* areas, const int* offs,
                             const int* cnt_blob, int* bbox, HeapItem* heaps, unsigned long long* relax_l,
                             unsigned long long* relax_dl, int* done, int* d_inst, long n, int h, int w, int min_keep,
-                            hipStream_t st) {
+                            hipStream_t st, bool init_done = false) {
     const long hw = (long)h * w;
     dim3 grid(hblocks(hw), (unsigned)n);
-    hipLaunchKernelGGL(ws_init_kernel, grid, dim3(HT), 0, st, blob_lab, mark_lab, h, w, d_inst, bbox);
+    if (!init_done) hipLaunchKernelGGL(ws_init_kernel, grid, dim3(HT), 0, st, blob_lab, mark_lab, h, w, d_inst, bbox);
     const long max_labels = hw / 2 + 2;
     long fx = (max_labels + 63) / 64, fcap = 65536 / n > 4 ? 65536 / n : 4;  // lanes stride over labels beyond the cap
     dim3 fgrid((unsigned)n, (unsigned)(fx < fcap ? fx : fcap));
@@ -1019,26 +1247,64 @@ static int hover_proc_impl(const float* d_np, const float* d_hv, int64_t n, int6
     int rc;
     // 1. blb = remove_small_objects(label(np >= 0.5), max_size=9) > 0
     const bool tile = ccl_tile_enabled() && hw <= kCclTileMaxPixels;  // small planes: threshold + labelling + area filter in ONE launch
-    if (tile) {
-        rc = ccl_tile_label(d_np, 2, (long)n, (int)h, (int)w, 4, 10, blob_lab, cnt_blob, ws_int, st);  // areas -> ws_int
+    // the fully fused path: every stage of a plane as a tile-resident kernel (6 launches in all)
+    const long band_rows_max = (144L * 1024) / (w * 12) - (ksize - 1);  // f64 row-pass band + f32 input band in LDS
+    const bool fused = tile && hw <= kMarkerTileMaxPixels && band_rows_max >= 8;
+    int* areas_keep = (int*)dist;
+    if (fused) {
+        // threshold + labelling + area filter + heap offsets + bounding-box reset (areas stay in ws_int: nothing below reuses it)
+        rc = ccl_tile_label(d_np, 2, (long)n, (int)h, (int)w, 4, 10, blob_lab, cnt_blob, ws_int, st, offs, bbox);
         if (rc != TIA_OK) return rc;
     } else {
-        hipLaunchKernelGGL(np_threshold_kernel, dim3(hblocks((long)n * hw, HT, 65535)), dim3(HT), 0, st, d_np, (long)n * hw, blb_mask);
-        rc = tia_ccl_label_i32(blb_mask, n, h, w, 4, blob_lab, cnt_blob, ws_int, st);
-        if (rc != TIA_OK) return rc;
-        rc = tia_label_area_filter_i32(blob_lab, n, h, w, 10, ws_int, st);  // areas stay in ws_int
-        if (rc != TIA_OK) return rc;
+        if (tile) {
+            rc = ccl_tile_label(d_np, 2, (long)n, (int)h, (int)w, 4, 10, blob_lab, cnt_blob, ws_int, st);  // areas -> ws_int
+            if (rc != TIA_OK) return rc;
+        } else {
+            hipLaunchKernelGGL(np_threshold_kernel, dim3(hblocks((long)n * hw, HT, 65535)), dim3(HT), 0, st, d_np, (long)n * hw, blb_mask);
+            rc = tia_ccl_label_i32(blb_mask, n, h, w, 4, blob_lab, cnt_blob, ws_int, st);
+            if (rc != TIA_OK) return rc;
+            rc = tia_label_area_filter_i32(blob_lab, n, h, w, 10, ws_int, st);  // areas stay in ws_int
+            if (rc != TIA_OK) return rc;
+        }
+        // blob bounding boxes + heap offsets need the areas: do them before ws_int is reused
+        hipLaunchKernelGGL(bbox_reset_kernel, dim3(hblocks((long)n * (hw + 1), HT, 65535)), dim3(HT), 0, st, bbox, (long)n * (hw + 1));
+        hipLaunchKernelGGL(ws_offsets_kernel, dim3((unsigned)n), dim3(1024), 0, st, areas, cnt_blob, hw, 10, offs);
+        // ws_int is scratch for the marker pipeline below: park the blob areas in `dist` (unused until step 5)
+        if (hipMemcpyAsync(areas_keep, areas, (size_t)n * (hw + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return TIA_ELAUNCH;
     }
-    // blob bounding boxes + heap offsets need the areas: do them before ws_int is reused
-    hipLaunchKernelGGL(bbox_reset_kernel, dim3(hblocks((long)n * (hw + 1), HT, 65535)), dim3(HT), 0, st, bbox, (long)n * (hw + 1));
-    hipLaunchKernelGGL(ws_offsets_kernel, dim3((unsigned)n), dim3(1024), 0, st, areas, cnt_blob, hw, 10, offs);
-    // ws_int is scratch for the marker pipeline below: park the blob areas in `dist` (unused until step 5)
-    int* areas_keep = (int*)dist;
-    if (hipMemcpyAsync(areas_keep, areas, (size_t)n * (hw + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return TIA_ELAUNCH;
 
-    // 2. Sobel of the normalised h / v maps
+    // 2. Sobel of the normalised h / v maps, 3. energy + marker seed
     SobelTaps kd, ks;
     sobel_taps_host(ksize, kd, ks);
+    // small planes: min / max + both filters + energy in one launch, the row pass staged in LDS in bands of rows
+    const bool tile_sobel = tile && band_rows_max >= 8;
+    if (tile_sobel) {
+        const int band = (int)(band_rows_max < h ? band_rows_max : h);
+        const size_t lds = (size_t)(band + ksize - 1) * w * 12;
+        using SobelKernel = void (*)(const float*, int, int, const SobelTaps, const SobelTaps, int, int, int, const int*, double*, double*,
+                                     double*, uint8_t*, double*, double*);
+        static const SobelKernel variants[3] = {sobel_energy_tile_kernel<21>, sobel_energy_tile_kernel<11>, sobel_energy_tile_kernel<0>};
+        static bool ready = false;
+        if (!ready) {
+            for (const SobelKernel k : variants)
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+                    return TIA_ELAUNCH;
+            ready = true;
+        }
+        hipLaunchKernelGGL(variants[ksize == 21 ? 0 : (ksize == 11 ? 1 : 2)], dim3((unsigned)n), dim3(1024), lds, st, d_hv, (int)h, (int)w, kd,
+                           ks, ksize, band, (int)n, (const int*)blob_lab, sob_h, sob_v, dist0, tmp_a, mm, fused ? dist : (double*)nullptr);
+#ifdef TIA_TILE_TIMING
+        {
+            long long hst[16];
+            hipStreamSynchronize(st);
+            hipMemcpyFromSymbol(hst, HIP_SYMBOL(g_tile_stamps), sizeof(hst));
+            fprintf(stderr, "sobel tile stamps (cycles @100MHz? clock64):");
+            for (int i = 1; i < 10; ++i) fprintf(stderr, " %lld", hst[i] - hst[i - 1]);
+            fprintf(stderr, "\n");
+        }
+#endif
+        if (!tap(taps.sobel_h, sob_h, plane_f64) || !tap(taps.sobel_v, sob_v, plane_f64)) return TIA_ELAUNCH;
+    } else {
     hipLaunchKernelGGL(minmax_hv_kernel, dim3((unsigned)n), dim3(1024), 0, st, d_hv, hw, mm, mm + 2 * n);
     // h: dx=1 -> kx = derivative taps, ky = smoothing taps (symmetric column filter)
     hipLaunchKernelGGL(sobel_row_kernel, grid, dim3(HT), 0, st, d_hv, 0, (int)h, (int)w, mm, kd, ksize, rowbuf);
@@ -1051,42 +1317,53 @@ static int hover_proc_impl(const float* d_np, const float* d_hv, int64_t n, int6
 
     // 3. energy, marker seed
     hipLaunchKernelGGL(energy_kernel, grid, dim3(HT), 0, st, sob_h, sob_v, mm + 4 * n, mm + 6 * n, blob_lab, hw, dist0, tmp_a);
+    }
 
     // 4. marker = label(open5x5(fill_holes(marker0))), small objects removed
-    rc = tia_fill_holes_u8(tmp_a, n, h, w, tmp_b, ws_int, st);
-    if (rc != TIA_OK) return rc;
-    {
-        // 5x5 ellipse: rows 00100 / 11111 / 11111 / 11111 / 00100 (cv2.getStructuringElement)
-        static const int host_offs[17 * 2] = {-2, 0,  -1, -2, -1, -1, -1, 0, -1, 1, -1, 2, 0, -2, 0, -1, 0, 0,
-                                              0,  1,  0,  2,  1,  -2, 1,  -1, 1, 0, 1,  1, 1, 2,  2, 0};
-        if (hipMemcpyAsync(se_offs, host_offs, sizeof(host_offs), hipMemcpyHostToDevice, st) != hipSuccess) return TIA_ELAUNCH;
-    }
-    rc = tia_binary_morph_u8(tmp_b, n, h, w, se_offs, 17, 1, tmp_a, st);
-    if (rc != TIA_OK) return rc;
-    rc = tia_binary_morph_u8(tmp_a, n, h, w, se_offs, 17, 0, tmp_b, st);
-    if (rc != TIA_OK) return rc;
-    if (tile) {
-        rc = ccl_tile_label(tmp_b, 0, (long)n, (int)h, (int)w, 4, obj_size, mark_lab, d_ninst, ws_int, st);
+    if (fused) {  // the whole marker pipeline of a plane + the watershed's initial state in one launch, resident in LDS
+        rc = marker_tile(tmp_a, (long)n, (int)h, (int)w, obj_size, mark_lab, d_ninst, nullptr, st, blob_lab, d_inst, bbox);
+        if (rc != TIA_OK) return rc;
+    } else if (tile && hw <= kMarkerTileMaxPixels) {
+        rc = marker_tile(tmp_a, (long)n, (int)h, (int)w, obj_size, mark_lab, d_ninst, ws_int, st);
         if (rc != TIA_OK) return rc;
     } else {
-        rc = tia_ccl_label_i32(tmp_b, n, h, w, 4, mark_lab, d_ninst, ws_int, st);
+        rc = tia_fill_holes_u8(tmp_a, n, h, w, tmp_b, ws_int, st);
         if (rc != TIA_OK) return rc;
-        rc = tia_label_area_filter_i32(mark_lab, n, h, w, obj_size, ws_int, st);
+        {
+            // 5x5 ellipse: rows 00100 / 11111 / 11111 / 11111 / 00100 (cv2.getStructuringElement)
+            static const int host_offs[17 * 2] = {-2, 0,  -1, -2, -1, -1, -1, 0, -1, 1, -1, 2, 0, -2, 0, -1, 0, 0,
+                                                  0,  1,  0,  2,  1,  -2, 1,  -1, 1, 0, 1,  1, 1, 2,  2, 0};
+            if (hipMemcpyAsync(se_offs, host_offs, sizeof(host_offs), hipMemcpyHostToDevice, st) != hipSuccess) return TIA_ELAUNCH;
+        }
+        rc = tia_binary_morph_u8(tmp_b, n, h, w, se_offs, 17, 1, tmp_a, st);
         if (rc != TIA_OK) return rc;
+        rc = tia_binary_morph_u8(tmp_a, n, h, w, se_offs, 17, 0, tmp_b, st);
+        if (rc != TIA_OK) return rc;
+        if (tile) {
+            rc = ccl_tile_label(tmp_b, 0, (long)n, (int)h, (int)w, 4, obj_size, mark_lab, d_ninst, ws_int, st);
+            if (rc != TIA_OK) return rc;
+        } else {
+            rc = tia_ccl_label_i32(tmp_b, n, h, w, 4, mark_lab, d_ninst, ws_int, st);
+            if (rc != TIA_OK) return rc;
+            rc = tia_label_area_filter_i32(mark_lab, n, h, w, obj_size, ws_int, st);
+            if (rc != TIA_OK) return rc;
+        }
     }
     if (!tap(taps.markers, mark_lab, plane_i32)) return TIA_ELAUNCH;
 
     // 5. watershed(dist, markers, mask = blb)
-    // areas_keep lives in `dist`: move it to ws_int (free again) before dist is written
-    if (hipMemcpyAsync(ws_int, areas_keep, (size_t)n * (hw + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return TIA_ELAUNCH;
-    hipLaunchKernelGGL(gauss3_neg_kernel, grid, dim3(HT), 0, st, dist0, (int)h, (int)w, dist);
+    if (!fused) {
+        // areas_keep lives in `dist`: move it to ws_int (free again) before dist is written
+        if (hipMemcpyAsync(ws_int, areas_keep, (size_t)n * (hw + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return TIA_ELAUNCH;
+        hipLaunchKernelGGL(gauss3_neg_kernel, grid, dim3(HT), 0, st, dist0, (int)h, (int)w, dist);
+    }
     if (!tap(taps.dist, dist, plane_f64)) return TIA_ELAUNCH;
     if (taps.blobs)
         hipLaunchKernelGGL(blob_indicator_kernel, dim3(hblocks((long)n * hw, HT, 65535)), dim3(HT), 0, st, blob_lab, (long)n * hw,
                            taps.blobs);
     // the Sobel planes and the row buffer are free by now: relaxation state and per-blob flags
     return launch_watershed(blob_lab, mark_lab, dist, ws_int, offs, cnt_blob, bbox, heaps, (unsigned long long*)sob_h,
-                            (unsigned long long*)sob_v, (int*)rowbuf, d_inst, (long)n, (int)h, (int)w, 10, st);
+                            (unsigned long long*)sob_v, (int*)rowbuf, d_inst, (long)n, (int)h, (int)w, 10, st, /*init_done=*/fused);
 }
 
 extern "C" int tia_hover_proc_np_hv_f32(const float* d_np, const float* d_hv, int64_t n, int64_t h, int64_t w,

@@ -299,6 +299,7 @@ __device__ __forceinline__ void lds_union(int* L, int a, int b) {
 template <int SRC>
 __device__ __forceinline__ void tile_forest(const void* __restrict__ src, long plane_off, int h, int w, int conn8, int* L) {
     const int hw = h * w, tid = threadIdx.x, lane = tid & 63;
+#pragma unroll 4  // one workgroup per CU: several rounds of source loads in flight
     for (int base = 0; base < hw; base += 1024) {  // same trip count for every lane: the ballots need whole waves
         const int i = base + tid;
         const bool inb = i < hw;
@@ -342,15 +343,14 @@ __device__ __forceinline__ void tile_forest(const void* __restrict__ src, long p
     __syncthreads();
 }
 
-template <int SRC>
-__global__ __launch_bounds__(1024) void ccl_tile_kernel(const void* __restrict__ src, int h, int w, int conn8, int min_keep,
-                                                         int* __restrict__ labels, int* __restrict__ count, int* __restrict__ areas) {
-    extern __shared__ int L[];
+// second half of the small-plane labelling (after tile_forest): rank the roots in raster order, component areas, area filter,
+// labels / count / areas to global memory
+template <typename Emit>
+__device__ __forceinline__ unsigned tile_rank_filter(int* L, int hw, int min_keep, int* __restrict__ count_slot, int* __restrict__ a,
+                                                     Emit emit) {
     __shared__ unsigned wtot[16];
     __shared__ unsigned s_running;
-    const int hw = h * w, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long plane_off = (long)blockIdx.x * hw;
-    tile_forest<SRC>(src, plane_off, h, w, conn8, L);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // rank the roots in raster order (4 consecutive pixels per lane and round), leave each root's record in its slot
     if (tid == 0) s_running = 0;
     __syncthreads();
@@ -379,8 +379,7 @@ __global__ __launch_bounds__(1024) void ccl_tile_kernel(const void* __restrict__
             if (f[k]) L[i0 + k] = (int)(0x80000000u | ++before);
         __syncthreads();
     }
-    const unsigned ncomp = s_running;
-    if (tid == 0) count[blockIdx.x] = (int)ncomp;
+    if (tid == 0) *count_slot = (int)s_running;
     // areas: one LDS add per foreground pixel on its root's record (the root counts itself)
     for (int i = tid; i < hw; i += 1024) {
         const int v = L[i];
@@ -388,11 +387,11 @@ __global__ __launch_bounds__(1024) void ccl_tile_kernel(const void* __restrict__
         atomicAdd(reinterpret_cast<unsigned*>(&L[v < 0 ? i : v]), 1u << 15);
     }
     __syncthreads();
-    int* a = areas ? areas + (size_t)blockIdx.x * (hw + 1) : nullptr;
     if (a && tid == 0) a[0] = 0;
-    int* out = labels + plane_off;
-    for (int i = tid; i < hw; i += 1024) {
-        const int v = L[i];
+    for (int base = 0; base < hw; base += 1024) {  // whole waves (emit may ballot)
+        const int i = base + tid;
+        const bool valid = i < hw;
+        const int v = valid ? L[i] : -1;
         int lab = 0;
         if (v != -1) {
             const unsigned rec = (unsigned)(v < 0 ? v : L[v]);
@@ -400,8 +399,135 @@ __global__ __launch_bounds__(1024) void ccl_tile_kernel(const void* __restrict__
             if (v < 0 && a) a[rank] = area;  // the root publishes its component's area
             lab = area >= min_keep ? rank : 0;
         }
-        out[i] = lab;
+        emit(i, valid, lab);
     }
+    return s_running;
+}
+
+// offs / bbox (both nullable, HoVer-Net's blob stage): per-label heap-segment offsets (exclusive scan of the surviving components'
+// areas = ws_offsets_kernel) and the reset of the labels' bounding boxes, so that the watershed needs no launch of its own for them
+template <int SRC>
+__global__ __launch_bounds__(1024) void ccl_tile_kernel(const void* __restrict__ src, int h, int w, int conn8, int min_keep,
+                                                         int* __restrict__ labels, int* __restrict__ count, int* __restrict__ areas,
+                                                         int* __restrict__ offs, int* __restrict__ bbox) {
+    extern __shared__ int L[];
+    __shared__ unsigned otot[16];
+    const int hw = h * w, tid = threadIdx.x;
+    const long plane_off = (long)blockIdx.x * hw;
+    tile_forest<SRC>(src, plane_off, h, w, conn8, L);
+    int* out = labels + plane_off;
+    int* a = areas ? areas + (size_t)blockIdx.x * (hw + 1) : nullptr;
+    const unsigned ncomp = tile_rank_filter(L, hw, min_keep, count + blockIdx.x, a, [&](int i, bool valid, int lab) {
+        if (valid) out[i] = lab;
+    });
+    if (offs == nullptr || a == nullptr) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (not __threadfence(): agent scope writes the whole L2 back)
+    __syncthreads();  // the areas (written by the roots' lanes) are complete
+    const int* av = a;  // written by this workgroup before the fence + barrier; never read by this CU before: plain loads are coherent
+    int* o = offs + (size_t)blockIdx.x * (hw + 1);
+    const int k = (int)ncomp + 1;  // labels 0 .. ncomp
+    const int chunk = (k + 1023) / 1024;
+    const int lo = tid * chunk, hi = lo + chunk < k ? lo + chunk : k;
+    unsigned c = 0;
+    for (int i = lo; i < hi; ++i) {
+        const int ar = av[i];
+        c += (i > 0 && ar >= min_keep) ? (unsigned)ar : 0u;
+    }
+    const unsigned incl = wave_incl_scan_u32(c);
+    if ((tid & 63) == 63) otot[tid >> 6] = incl;
+    __syncthreads();
+    unsigned before = incl - c;
+    for (int wv = 0; wv < (tid >> 6); ++wv) before += otot[wv];
+    for (int i = lo; i < hi; ++i) {
+        o[i] = (int)before;
+        const int ar = av[i];
+        before += (i > 0 && ar >= min_keep) ? (unsigned)ar : 0u;
+    }
+    if (bbox) {
+        int4* bb = reinterpret_cast<int4*>(bbox + (size_t)blockIdx.x * (hw + 1) * 4);
+        for (int l = tid; l < k; l += 1024) bb[l] = make_int4(0x7fffffff, -1, 0x7fffffff, -1);
+    }
+}
+
+// HoVer-Net's marker pipeline on a small plane in ONE launch (hovernet.py:604-614): binary_fill_holes -> 5x5 elliptical opening
+// (cv2.morphologyEx(MORPH_OPEN): erode, then dilate; outside the image the erosion sees 1, the dilation 0) -> label (4-connectivity)
+// -> remove_small_objects.  LDS: the union-find array (re-used as the second byte plane during the opening) + one byte plane.
+// blob / inst / bbox (nullable together): also the watershed's initial state (= ws_init_kernel, hover_post.hip): inst = marker
+// label inside a blob, -1 for unlabelled blob pixels, 0 outside; bounding boxes of the blobs (one set of atomics per run).
+__global__ __launch_bounds__(1024) void marker_tile_kernel(const uint8_t* __restrict__ marker0, int h, int w, int min_keep,
+                                                           int* __restrict__ labels, int* __restrict__ count, int* __restrict__ areas,
+                                                           const int* __restrict__ blob, int* __restrict__ inst, int* __restrict__ bbox) {
+    extern __shared__ int L[];
+    const int hw = h * w, tid = threadIdx.x;
+    const long plane_off = (long)blockIdx.x * hw;
+    uint8_t* A = reinterpret_cast<uint8_t*>(L + hw);
+    uint8_t* B = reinterpret_cast<uint8_t*>(L);
+    // fill holes: background components that do not reach the frame
+    tile_forest<1>(marker0, plane_off, h, w, 0, L);
+    const int nb = 2 * w + 2 * h;
+    for (int k = tid; k < nb; k += 1024) {
+        int i;
+        if (k < w) i = k;
+        else if (k < 2 * w) i = (h - 1) * w + (k - w);
+        else if (k < 2 * w + h) i = (k - 2 * w) * w;
+        else i = (k - 2 * w - h) * w + (w - 1);
+        const int v = L[i];
+        if (v >= 0) atomicOr(&L[v & 0x3fffffff], 0x40000000);
+    }
+    __syncthreads();
+    for (int i = tid; i < hw; i += 1024) {
+        const int v = L[i];
+        const bool hole = v >= 0 && (L[v & 0x3fffffff] & 0x40000000) == 0;
+        A[i] = (marker0[plane_off + i] != 0 || hole) ? 1 : 0;
+    }
+    __syncthreads();
+    // 5x5 ellipse: rows 00100 / 11111 / 11111 / 11111 / 00100 (cv2.getStructuringElement(MORPH_ELLIPSE, (5, 5)))
+    auto morph = [&](const uint8_t* src, uint8_t* dst, bool erode) {
+        for (int i = tid; i < hw; i += 1024) {
+            const int y = i / w, x = i - y * w;
+            bool all = true, any = false;
+#pragma unroll
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int r = (dy == -2 || dy == 2) ? 0 : 2;
+#pragma unroll
+                for (int dx = -2; dx <= 2; ++dx) {
+                    if (dx < -r || dx > r) continue;
+                    const int yy = y + dy, xx = x + dx;
+                    const bool inside = yy >= 0 && yy < h && xx >= 0 && xx < w;
+                    const bool v = inside ? src[yy * w + xx] != 0 : erode;
+                    all = all && v;
+                    any = any || v;
+                }
+            }
+            dst[i] = (erode ? all : any) ? 1 : 0;
+        }
+        __syncthreads();
+    };
+    morph(A, B, true);
+    morph(B, A, false);
+    tile_forest<0>(A, 0, h, w, 0, L);
+    int* out = labels + plane_off;
+    int* bb = bbox ? bbox + (size_t)blockIdx.x * (hw + 1) * 4 : nullptr;
+    const int lane = tid & 63;
+    tile_rank_filter(L, hw, min_keep, count + blockIdx.x, areas ? areas + (size_t)blockIdx.x * (hw + 1) : nullptr,
+                     [&](int i, bool valid, int lab) {
+                         if (valid) out[i] = lab;
+                         if (blob == nullptr) return;
+                         const int b = valid ? blob[plane_off + i] : 0;
+                         if (valid) inst[plane_off + i] = b > 0 ? (lab > 0 ? lab : -1) : 0;
+                         const int y = i / w, x = i - y * w;
+                         const int pb = __shfl_up(b, 1);
+                         const bool head = lane == 0 || b != pb || x == 0;
+                         const unsigned long long heads = __ballot(head);
+                         if (head && b > 0) {
+                             const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+                             const int len = (above ? __builtin_ctzll(above) : 64) - lane;
+                             atomicMin(&bb[b * 4 + 0], y);
+                             atomicMax(&bb[b * 4 + 1], y);
+                             atomicMin(&bb[b * 4 + 2], x);
+                             atomicMax(&bb[b * 4 + 3], x + len - 1);
+                         }
+                     });
 }
 
 // scipy.ndimage.binary_fill_holes on a small plane: background components (4-connectivity) that do not reach the frame
@@ -608,7 +734,7 @@ static bool tile_lds_ok(K kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 int ccl_tile_label(const void* src, int src_kind, long n, int h, int w, int conn, int min_keep, int* labels, int* count, int* areas,
-                   hipStream_t st) {
+                   hipStream_t st, int* offs, int* bbox) {
     const size_t lds = (size_t)h * w * sizeof(int);
     static bool ready = false;
     if (!ready) {
@@ -620,11 +746,25 @@ int ccl_tile_label(const void* src, int src_kind, long n, int h, int w, int conn
     }
     const int c8 = conn == 8 ? 1 : 0;
     if (src_kind == 2)
-        hipLaunchKernelGGL(ccl_tile_kernel<2>, dim3((unsigned)n), dim3(1024), lds, st, src, h, w, c8, min_keep, labels, count, areas);
+        hipLaunchKernelGGL(ccl_tile_kernel<2>, dim3((unsigned)n), dim3(1024), lds, st, src, h, w, c8, min_keep, labels, count, areas, offs,
+                           bbox);
     else if (src_kind == 1)
-        hipLaunchKernelGGL(ccl_tile_kernel<1>, dim3((unsigned)n), dim3(1024), lds, st, src, h, w, c8, min_keep, labels, count, areas);
+        hipLaunchKernelGGL(ccl_tile_kernel<1>, dim3((unsigned)n), dim3(1024), lds, st, src, h, w, c8, min_keep, labels, count, areas, offs,
+                           bbox);
     else
-        hipLaunchKernelGGL(ccl_tile_kernel<0>, dim3((unsigned)n), dim3(1024), lds, st, src, h, w, c8, min_keep, labels, count, areas);
+        hipLaunchKernelGGL(ccl_tile_kernel<0>, dim3((unsigned)n), dim3(1024), lds, st, src, h, w, c8, min_keep, labels, count, areas, offs,
+                           bbox);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+int marker_tile(const uint8_t* marker0, long n, int h, int w, int min_keep, int* labels, int* count, int* areas, hipStream_t st,
+                const int* blob, int* inst, int* bbox) {
+    static bool ready = false;
+    if (!ready) {
+        if (!tile_lds_ok(marker_tile_kernel, (size_t)kMarkerTileMaxPixels * 5)) return TIA_ELAUNCH;
+        ready = true;
+    }
+    hipLaunchKernelGGL(marker_tile_kernel, dim3((unsigned)n), dim3(1024), (size_t)h * w * 5, st, marker0, h, w, min_keep, labels, count, areas,
+                       blob, inst, bbox);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 int fill_holes_tile(const uint8_t* mask, long n, int h, int w, uint8_t* out, hipStream_t st) {
