@@ -269,7 +269,7 @@ def bench_hovernet(args) -> dict | None:
                    "tiles_per_gpu": n,
                    "parallelism": f"dp{world_size} (tile-sharded; label maps and ragged instance tables all-gathered)"},
         "roofline": {
-            "kernel": "hover _proc_np_hv (15 kernels: CCL x3, Sobel f64, morphology, watershed by relaxation)", "bound": "hbm",
+            "kernel": "hover _proc_np_hv (6 launches: tile-resident labelling / Sobel f64 + energy / marker pipeline, watershed by relaxation)", "bound": "hbm",
             "achieved": round(alg / t_proc / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(alg / t_proc / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": alg,
             "launch_ms": round(t_proc * 1e3, 3),

@@ -127,7 +127,10 @@ def test_hip_proc_np_hv_vs_oracle_more_shapes():
 
     from tiatoolbox_amd.models.architecture import _hover_device as hd
 
-    for (h, w, seed, nb) in ((64, 80, 5, 6), (164, 164, 6, 60), (256, 256, 7, 90), (33, 47, 8, 3)):
+    # 164^2 and smaller: the six-launch tile-resident path; 256^2: the multi-launch path; 190^2 (> 32,000 pixels: labelling in
+    # LDS, marker pipeline multi-launch), 181 x 176 (just under the limit), 40 x 700 (rows too wide for the Sobel bands): the mixes
+    for (h, w, seed, nb) in ((64, 80, 5, 6), (164, 164, 6, 60), (256, 256, 7, 90), (33, 47, 8, 3), (190, 190, 9, 70), (181, 176, 10, 60),
+                             (40, 700, 11, 40)):
         npm, hv, _ = oh.synth_maps(3, h, w, seed=seed, n_blobs=nb)
         inst, _ = hd.proc_np_hv(torch.from_numpy(npm).cuda(), torch.from_numpy(hv).cuda())
         got = inst.cpu().numpy()
