@@ -198,9 +198,14 @@ def ev_time(fn, reps: int = 10) -> float:
 
 def spatial_conv(k: int, stride: int, ho: int, wo: int) -> bool:
     """Which kernel a block convolution runs on (mirror of ``conv3x3_spatial_ok``, csrc/conv3x3_spatial.hpp): 3x3 / stride 1 on
-    a map that 16 x 16 pixel blocks cover to >= 7/8 -> ``conv3x3_spatial_kernel``; otherwise ``conv_mfma_f32_kernel``."""
+    a map that the kernel's pixel blocks -- 16 x 16 of one image, or two images of at most 8 x 8 -- cover to >= 7/8 ->
+    ``conv3x3_spatial_kernel``; otherwise ``conv_mfma_f32_kernel``."""
+    if k != 3 or stride != 1:  # noqa: PLR2004
+        return False
+    if ho <= 8 and wo <= 8:  # noqa: PLR2004
+        return 8 * ho * wo >= 7 * 64
     tiles = ((ho + 15) // 16) * ((wo + 15) // 16)
-    return k == 3 and stride == 1 and 8 * ho * wo >= 7 * tiles * 256  # noqa: PLR2004
+    return 8 * ho * wo >= 7 * tiles * 256
 
 
 def trunk_roofline(model, u8_batch):
@@ -418,8 +423,8 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
         fams = conv["kernels"]
         dominant = max(fams, key=lambda k: fams[k]["seconds"])
         dk = fams[dominant]
-        desc = {"conv3x3_spatial_kernel": "3x3 / stride-1 convolutions, 16x16 pixel blocks with tap reuse (LDS-DMA patch + weight ring)",
-                "conv_mfma_f32_kernel": "strided 3x3, 1x1 and small-map convolutions, 128-pixel slices"}
+        desc = {"conv3x3_spatial_kernel": "3x3 / stride-1 convolutions, 16x16 (or 2 x 8x8) pixel blocks with tap reuse (LDS-DMA patch + weight ring)",
+                "conv_mfma_f32_kernel": "strided 3x3 and 1x1 convolutions, 128-pixel slices"}
         roofline = {
             "kernel": dominant, "bound": "mfma", "achieved": round(dk["tflops"], 2),
             "peak": MFMA_PEAK_TFLOPS["float32"], "unit": "TFLOP/s",
