@@ -20,7 +20,7 @@ m, _ = get_pretrained_model("resnet18-kather100k"); m.eval()
 n = 4096
 for dtype in (torch.float16, torch.bfloat16, torch.float32):
     x = torch.rand(n, 224, 224, 3, device="cuda").to(dtype)
-    variants = {"plain": m, "folded": fuse_cnn_model(m, epilogue_fusion=False), "hip": fuse_cnn_model(m, epilogue_fusion="hip")}
+    variants = {"plain": m, "folded": fuse_cnn_model(m, epilogue_fusion=False), "mfma": fuse_cnn_model(m, epilogue_fusion="mfma")}
     ref = None
     for name, mod in variants.items():
         mod = mod.to("cuda").to(dtype).to(memory_format=torch.channels_last).eval()

@@ -156,25 +156,17 @@ def test_hip_epilogue_kernels_match_torch(dtype):
 
 
 @pytest.mark.gpu
-def test_hip_fused_resnet_matches_plain_model(patches):
-    from tiatoolbox_amd.models.architecture import get_pretrained_model
-    from tiatoolbox_amd.models.architecture.fused import fuse_cnn_model
+def test_fuse_cnn_model_has_no_library_convolution_option():
+    """The only GPU form of a ResNet classifier is the hand-written trunk (float32 and, after ``prepare`` + ``.half()``, half): the
+    library-convolution variant of earlier rounds is gone."""
+    from tiatoolbox_amd.models.architecture import fused, get_pretrained_model
 
     model, _ = get_pretrained_model("resnet18-kather100k")
-    for mod in model.modules():  # non-trivial BN statistics
-        if isinstance(mod, torch.nn.BatchNorm2d):
-            mod.running_mean.normal_(0, 0.1)
-            mod.running_var.uniform_(0.5, 1.5)
-            mod.weight.data.uniform_(0.5, 1.5)
-            mod.bias.data.normal_(0, 0.1)
-    x = (torch.from_numpy(patches).float() / 255).permute(0, 3, 1, 2)
-    with torch.inference_mode():
-        ref = model.eval()(x)
-        hip = fuse_cnn_model(model, epilogue_fusion="hip").cuda().to(memory_format=torch.channels_last)
-        got = hip(x.cuda().contiguous(memory_format=torch.channels_last)).cpu()
-        got16 = hip.half()(x.cuda().half().contiguous(memory_format=torch.channels_last)).float().cpu()
-    assert (got - ref).abs().max() < 1e-4
-    assert (got16 - ref).abs().max() < 5e-3
+    with pytest.raises(ValueError, match="'mfma' or False"):
+        fused.fuse_cnn_model(model, epilogue_fusion="hip")
+    assert not hasattr(fused, "HipFusedResNet")
+    m = fused.fuse_cnn_model(model, epilogue_fusion="mfma")
+    assert type(m.feat_extract).__name__ == "MfmaResNet"
 
 
 def test_wsi_mode_contracts_without_gpu(tmp_path):

@@ -5,8 +5,7 @@
 * ``MfmaResNet``: float32 ResNet trunk on hand-written kernels only -- the stem (``csrc/stem_mfma.hip``: uint8 or float32
   patches -> conv7x7 + bias + ReLU + max-pool, one kernel) and every block convolution (``csrc/conv_mfma.hip``: implicit GEMM
   on the matrix cores with bias / residual / ReLU in the epilogue).
-* ``HipFusedResNet``: fp16 / bf16 trunk: library convolutions + the hand-written single-pass epilogues of
-  ``csrc/cnn_epilogue.hip``.
+  In fp16 / bf16 the same module runs on ``tia_stem_conv7x7_pool_nhwc_h`` / ``tia_conv2d_nhwc_h`` (no library convolution).
 
 State-dict compatibility is untouched: these are derived copies built from a loaded ``CNNModel`` (reference parameter
 names), never the object that loads weights.  Every wrapper raises on tensors it cannot take (host tensors, wrong layout):
@@ -83,62 +82,6 @@ def hip_bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
                                                     _lib.current_stream())
     _lib.check(rc, "tia_bias_relu_maxpool_nhwc")
     return out
-
-
-def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
-    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
-    return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
-
-
-class _HipBasic(nn.Module):
-    def __init__(self, blk: BasicBlock) -> None:
-        super().__init__()
-        self.conv1, self.conv2 = blk.conv1, blk.conv2
-        self.down = blk.downsample[0] if blk.downsample is not None else None
-
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.down is None:
-            identity = x
-        else:
-            identity = hip_bias_act_(_conv_nobias(x, self.down), self.down.bias, relu=False)
-        out = hip_bias_act_(_conv_nobias(x, self.conv1), self.conv1.bias)
-        return hip_bias_act_(_conv_nobias(out, self.conv2), self.conv2.bias, identity)
-
-
-class _HipBottleneck(nn.Module):
-    def __init__(self, blk: Bottleneck) -> None:
-        super().__init__()
-        self.conv1, self.conv2, self.conv3 = blk.conv1, blk.conv2, blk.conv3
-        self.down = blk.downsample[0] if blk.downsample is not None else None
-
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.down is None:
-            identity = x
-        else:
-            identity = hip_bias_act_(_conv_nobias(x, self.down), self.down.bias, relu=False)
-        out = hip_bias_act_(_conv_nobias(x, self.conv1), self.conv1.bias)
-        out = hip_bias_act_(_conv_nobias(out, self.conv2), self.conv2.bias)
-        return hip_bias_act_(_conv_nobias(out, self.conv3), self.conv3.bias, identity)
-
-
-class HipFusedResNet(nn.Module):
-    """ResNet trunk: MIOpen convolutions + hand-written HIP epilogues (BN folded, channels-last, CUDA only)."""
-
-    def __init__(self, trunk: nn.Sequential) -> None:
-        super().__init__()
-        folded = fold_conv_bn(trunk)
-        self.stem = folded[0]
-        blocks = []
-        for layer in list(folded)[4:]:
-            for blk in layer:
-                blocks.append(_HipBasic(blk) if isinstance(blk, BasicBlock) else _HipBottleneck(blk))
-        self.blocks = nn.Sequential(*blocks)
-
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if not x.is_contiguous(memory_format=torch.channels_last):
-            x = x.contiguous(memory_format=torch.channels_last)
-        x = hip_bias_relu_maxpool(_conv_nobias(x, self.stem), self.stem.bias)
-        return self.blocks(x)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -657,19 +600,16 @@ class MfmaResNet(nn.Module):
 def fuse_cnn_model(model: nn.Module, *, epilogue_fusion: bool | str = False) -> nn.Module:
     """Derived inference copy of a ``CNNModel``/``CNNBackbone`` with BN folded into the convolutions.
 
-    ``epilogue_fusion="mfma"`` (float32 on the GPU): stem and block convolutions on the hand-written kernels
-    (:class:`MfmaResNet`); ``"hip"`` (fp16 / bf16 on the GPU): library convolutions (without bias) + the hand-written bias
-    (+ residual) + ReLU / max-pool passes of ``csrc/cnn_epilogue.hip``; ``False``: BN folding only (CPU).
+    ``epilogue_fusion="mfma"`` (GPU, any dtype): stem and block convolutions on the hand-written kernels
+    (:class:`MfmaResNet`); ``False``: BN folding only (CPU).
     """
     fused = copy.deepcopy(model).eval()
     trunk = fused.feat_extract
     if isinstance(trunk, nn.Sequential) and len(trunk) == 8 and isinstance(trunk[0], nn.Conv2d):
         if epilogue_fusion == "mfma":
             fused.feat_extract = MfmaResNet(trunk)
-        elif epilogue_fusion == "hip":
-            fused.feat_extract = HipFusedResNet(trunk)
         elif epilogue_fusion:
-            msg = f"unknown epilogue_fusion {epilogue_fusion!r}: 'mfma', 'hip' or False."
+            msg = f"unknown epilogue_fusion {epilogue_fusion!r}: 'mfma' or False."
             raise ValueError(msg)
         else:
             fused.feat_extract = fold_conv_bn(trunk)

@@ -336,11 +336,10 @@ class EngineABC:
 
                 # on the GPU ResNet trunks (BasicBlock and Bottleneck) run on the hand-written kernels only -- stem and block
                 # convolutions (architecture/fused.py: MfmaResNet; float32: tia_conv2d_nhwc_f32, fp16 / bf16:
-                # tia_conv2d_nhwc_h); other trunks in half precision: library convolutions + the hand-written epilogue
-                # passes; CPU: BatchNorm folding only
+                # tia_conv2d_nhwc_h); every other trunk, and the CPU: BatchNorm folding only
                 resnet = any(isinstance(mod, (BasicBlock, Bottleneck)) for mod in m.modules())
                 use_mfma = on_gpu and resnet
-                m = fuse_cnn_model(m, epilogue_fusion=("mfma" if use_mfma else "hip") if on_gpu else False)
+                m = fuse_cnn_model(m, epilogue_fusion="mfma" if use_mfma else False)
             elif on_gpu and dtype == torch.float32:
                 from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
                 from tiatoolbox_amd.models.architecture.unet import UNetModel
