@@ -310,6 +310,12 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
         exp = F.relu(F.conv2d(F.pad(x, (lo, hi, lo, hi)), conv.weight.cpu(), conv.bias.cpu()))
         got = hip_conv2d_ex(xd, wp, dev_conv.bias, None, kernel=3, stride=1, pad_lo=lo, pad_hi=hi, relu=True)
         assert got.shape == exp.shape and (got.cpu() - exp).abs().max().item() <= 1e-4, (lo, hi)
+    # two zero rows / columns in front on the tap-reuse kernel (46x30 -> 48x32: whole 16x16 blocks)
+    x2 = torch.randn((1, 64, 46, 30), generator=g)
+    exp = F.relu(F.conv2d(F.pad(x2, (2, 2, 2, 2)), conv.weight.cpu(), conv.bias.cpu()))
+    got = hip_conv2d_ex(x2.cuda().contiguous(memory_format=torch.channels_last), wp, dev_conv.bias, None, kernel=3, stride=1,
+                        pad_lo=2, pad_hi=2, relu=True)
+    assert got.shape == exp.shape == (1, 128, 48, 32) and (got.cpu() - exp).abs().max().item() <= 1e-4
 
 
 @pytest.mark.gpu
