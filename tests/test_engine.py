@@ -275,7 +275,11 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
              # 3x3 / stride 1 on maps covered well by 16 x 16 pixel blocks: the tap-reuse kernel (whole / clipped blocks, both widths)
              (2, 64, 64, 32, 3, 1), (1, 96, 128, 30, 3, 1), (2, 32, 192, 48, 3, 1), (1, 256, 64, 16, 3, 1),
              # 8 x 8 maps: two images per block (odd batch: the last block holds one image)
-             (5, 256, 512, 8, 3, 1), (4, 64, 64, 8, 3, 1), (1, 32, 128, 8, 3, 1)]
+             (5, 256, 512, 8, 3, 1), (4, 64, 64, 8, 3, 1), (1, 32, 128, 8, 3, 1),
+             # 1x1 (the ring GEMM): stride 1 and 2, few and many channel slices, pixel counts that are no multiple of 256
+             (2, 256, 64, 20, 1, 1), (1, 64, 256, 31, 1, 1), (3, 1024, 256, 9, 1, 1), (1, 96, 192, 11, 1, 1), (2, 128, 256, 27, 1, 2),
+             # ... and large enough for the ring GEMM's dispatch rule (>= 384 workgroups of 256 pixels x 128 channels)
+             (2, 64, 128, 224, 1, 1), (4, 64, 256, 224, 1, 2), (3, 96, 128, 187, 1, 1)]
     for n, cin, cout, hw, k, stride in cases:
         pad = 1 if k == 3 else 0
         conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=True)

@@ -352,6 +352,163 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     }
 }
 
+
+// ---- 1x1 convolutions (float32): the same machinery without taps ---------------------------------------------------------------
+// A plain GEMM over 256 consecutive output pixels x BN channels: per 16-channel slice the pixels' 64-byte runs (pixel pitch 5
+// units, the same bank argument) and the [16][BN] weight block arrive by LDS-DMA into the idle one of two stages while the eight
+// waves issue the 32 MFMAs of the current one; one barrier and one vmcnt(0) per slice (the DMA has a whole MFMA phase to land)
+// instead of the slice kernel's register staging and barrier pair.  Strided 1x1 (ResNet down-sampling) only changes which input
+// pixel an output pixel reads.
+struct PwDims {
+    int n, h, w, cin, cout, ho, wo, stride;
+    unsigned x_bytes, w_bytes;
+};
+
+template <int BN>
+__global__ __launch_bounds__(512, 4) void conv1x1_ring_kernel(const float* __restrict__ x, const float* __restrict__ wk,
+                                                             const float* __restrict__ bias, const float* __restrict__ res,
+                                                             float* __restrict__ y, PwDims d, int relu, int m_tiles) {
+    constexpr int NT = 512, NTILE = BN / 64, PIX = 5;
+    constexpr int A_UNITS = 256 * PIX;   // 1280 units: two whole DMA rounds of 512 + 256
+    constexpr int A_BYTES = A_UNITS * 16;
+    constexpr int B_BYTES = NT * 16;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int DUMP = 2 * STAGE;
+    constexpr int EPI = 256 * (BN / 2) * 4;
+    constexpr int LDS_BYTES = (DUMP + 1024) > EPI ? (DUMP + 1024) : EPI;
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int bid = blockIdx.x;
+    const int per_xcd = (m_tiles + 7) / 8;
+    const int mt_id = (bid % 8) * per_xcd + bid / 8;
+    if (mt_id >= m_tiles) return;
+    const long m0 = (long)mt_id * 256;
+    const long m_total = (long)d.n * d.ho * d.wo;
+    const int n0 = blockIdx.y * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)d.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)d.w_bytes, 0x00020000);
+
+    int cen[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int u = NT * r + tid;
+        const int p = u / PIX, chunk = u - p * PIX;
+        const long m = m0 + p;
+        const bool ok = p < 256 && chunk < 4 && m < m_total;
+        const int mm = ok ? (int)m : 0;
+        const int b = mm / (d.ho * d.wo), rem = mm - b * d.ho * d.wo;
+        const int oy = rem / d.wo, ox = rem - oy * d.wo;
+        cen[r] = ok ? (((b * d.h + oy * d.stride) * d.w + ox * d.stride) * d.cin) * 4 + 16 * chunk : OOB;
+    }
+    const int bk = tid / (BN / 4), bcu = tid - bk * (BN / 4);
+    const int b_off = bk < 16 ? (bk * d.cout + n0) * 4 + 16 * bcu : OOB;
+    const int n_cs = d.cin >> 4;
+
+    auto dma_stage = [&](int stage, int cs) {
+        unsigned char* sa = smem + stage * STAGE;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            unsigned char* dst = (NT * r + wave * 64 >= A_UNITS) ? smem + DUMP : sa + r * (NT * 16) + wave * 1024;
+            dma16(rx, dst, cen[r], cs * 64);
+        }
+        dma16(rw, sa + A_BYTES + wave * 1024, b_off, cs * 16 * d.cout * 4);
+    };
+
+    f32x16 acc[2][NTILE];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int hi = lane >> 5;
+    const int fa0 = (wm * 64 + (lane & 31)) * PIX + 2 * hi;  // MFMA row = pixel wm * 64 + 32 i + (lane & 31); channels 8 hi .. 8 hi + 7
+    const int fb0 = (8 * hi) * BN + wn * (BN / 2) + (lane & 31);
+
+    dma_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int cs = 0; cs < n_cs; ++cs) {
+        const int stage = cs & 1;
+        dma_stage(stage ^ 1, cs + 1 < n_cs ? cs + 1 : cs);  // past the end: the idle stage is refilled with the same slice
+        const u32x4* sa = reinterpret_cast<const u32x4*>(smem + stage * STAGE) + fa0;
+        const float* sb = reinterpret_cast<const float*>(smem + stage * STAGE + A_BYTES) + fb0;
+        u32x4 a[2][2];
+        float b[NTILE][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[i][0] = sa[i * 32 * PIX];
+            a[i][1] = sa[i * 32 * PIX + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b[j][k] = sb[k * BN + j * 32];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NTILE; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i][k >> 2][k & 3]), b[j][k], acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    __syncthreads();
+
+    constexpr int HB = BN / 2, CHUNKS = 256 * HB / 8;
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wn == half) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NTILE; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        tile[row * HB + j * 32 + (lane & 31)] = acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < CHUNKS; idx += NT) {
+            const int row = idx / (HB / 8), cc = idx - row * (HB / 8);
+            const long m = m0 + row;
+            if (m < m_total) {
+                const int col0 = n0 + half * HB + cc * 8;
+                const float4 v0 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8);
+                const float4 v1 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if (bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bias + col0), b1 = *reinterpret_cast<const float4*>(bias + col0 + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                float* yo = y + m * d.cout + col0;
+                if (res) {
+                    const float* rp = res + m * d.cout + col0;
+                    const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                    v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                }
+                if (relu) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
+                }
+                *reinterpret_cast<float4*>(yo) = float4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<float4*>(yo + 4) = float4{v[4], v[5], v[6], v[7]};
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 namespace tia {
@@ -386,6 +543,21 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
         if (wide) TIA_LAUNCH_SP(128, K_BF16); else TIA_LAUNCH_SP(64, K_BF16);
     }
 #undef TIA_LAUNCH_SP
+    return true;
+}
+
+bool conv1x1_ring_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, long nb, long h, long w,
+                         long cin, long cout, long stride, long ho, long wo, int relu, hipStream_t stream) {
+    static const bool disabled = getenv("TIA_CONV_NO_RING") != nullptr;
+    if (disabled || cin % 16 != 0 || cout % 128 != 0) return false;
+    const long m_total = nb * ho * wo, tiles = (m_total + 255) / 256;
+    // measured (profiles/r03u_unet_layers*.txt): with 64 output channels (half the MFMAs per barrier) and with fewer than ~1.5
+    // workgroups per CU (256-pixel blocks: small maps at small batches) the slice kernel is the faster one
+    if (tiles * (cout / 128) < 384) return false;
+    const PwDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)stride, (unsigned)(nb * h * w * cin * 4),
+                   (unsigned)(cin * cout * 4)};
+    const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / 128));
+    hipLaunchKernelGGL(conv1x1_ring_kernel<128>, grid, dim3(512), 0, stream, x, w_packed, bias, residual, y, d, relu, (int)tiles);
     return true;
 }
 

@@ -24,4 +24,9 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
                             long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo, int dtype, int relu,
                             hipStream_t stream);
 
+// 1x1 convolutions (float32, stride >= 1, no padding) as a GEMM over 256-pixel blocks with both operands arriving by LDS-DMA in a
+// two-stage ring; weights packed [cin][cout] (tia_conv_pack_weights_f32 of a 1x1 kernel).  false: disabled (TIA_CONV_NO_RING).
+bool conv1x1_ring_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, long nb, long h, long w,
+                         long cin, long cout, long stride, long ho, long wo, int relu, hipStream_t stream);
+
 }  // namespace tia
