@@ -622,9 +622,17 @@ class EngineABC:
         lo, hi = tdist.shard_bounds(n, rank, world_size)
         outs = []
         self._set_defer_unit(model, dtype)
+        # the shard's patch bounds go to the device once (a per-batch upload is a synchronous copy: the host would wait for the
+        # previous batch's kernels before it can launch the next forward)
+        c_np = np.ascontiguousarray(np.asarray(coords[lo:hi]).reshape(-1, 4), dtype=np.int32)
+        size = (int(c_np[0, 2] - c_np[0, 0]), int(c_np[0, 3] - c_np[0, 1])) if len(c_np) else (0, 0)
+        uniform = len(c_np) > 0 and bool(np.all(c_np[:, 2] - c_np[:, 0] == size[0]) and np.all(c_np[:, 3] - c_np[:, 1] == size[1]))
+        coords_dev = torch.from_numpy(c_np).to(dev) if uniform else None
         with self._miopen_scope(), self._deferred_norm_checks(hook):
             for s in range(lo, hi, self.batch_size):
-                raw = reader.read_bounds_batch(coords[s:min(s + self.batch_size, hi)])
+                e = min(s + self.batch_size, hi)
+                raw = (reader.read_bounds_batch(coords_dev[s - lo:e - lo], size=size) if coords_dev is not None
+                       else reader.read_bounds_batch(coords[s:e]))
                 if device_batch is not None:
                     batch = self._device_preproc(hook, raw, dtype)
                 else:  # arbitrary user hook: per patch on the host, as Dataset.__getitem__ does in the reference

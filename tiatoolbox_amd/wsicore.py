@@ -41,11 +41,29 @@ class ArrayWSIReader:
         return int(self._dev.shape[1]), int(self._dev.shape[0])  # (width, height)
 
     # ------------------------------------------------------------------------------- reads
-    def read_bounds_batch(self, bounds: np.ndarray, pad_value: int = 255) -> torch.Tensor:
+    def read_bounds_batch(self, bounds, pad_value: int = 255, *, size: tuple[int, int] | None = None) -> torch.Tensor:
         """Stack of equally-sized regions ``[x0, y0, x1, y1]`` (baseline pixels), ``pad_value`` outside the slide:
-        one gather launch (``tia_gather_patches_u8``) writes the whole ``[M, ph, pw, C]`` batch."""
+        one gather launch (``tia_gather_patches_u8``) writes the whole ``[M, ph, pw, C]`` batch.
+
+        ``bounds`` may already be an ``int32 [M, 4]`` tensor on the slide's device (with ``size=(pw, ph)``): the WSI loops
+        upload every patch's bounds once and pass slices, so that no batch waits on a host -> device copy."""
         from tiatoolbox_amd import _lib
 
+        if isinstance(bounds, torch.Tensor) and bounds.is_cuda:
+            if size is None or bounds.dtype != torch.int32 or bounds.dim() != 2 or bounds.shape[1] != 4 or not bounds.is_contiguous():  # noqa: PLR2004
+                msg = "device bounds: a contiguous int32 [M, 4] tensor together with size=(pw, ph)."
+                raise ValueError(msg)
+            src = self._dev if self._dev.dim() == 3 else self._dev[..., None]  # noqa: PLR2004
+            pw, ph = int(size[0]), int(size[1])
+            if src.dtype != torch.uint8 or not src.is_contiguous() or (ph * pw * src.shape[2]) % 4 != 0 or len(bounds) > 65535:  # noqa: PLR2004
+                return self.read_bounds_batch(bounds.cpu().numpy(), pad_value)
+            sh, sw, c = src.shape
+            out = torch.empty((len(bounds), ph, pw, c), dtype=torch.uint8, device=src.device)
+            with torch.cuda.device(src.device):
+                rc = _lib.load().tia_gather_patches_u8(src.data_ptr(), sh, sw, c, bounds.data_ptr(), len(bounds), ph, pw, int(pad_value),
+                                                       out.data_ptr(), _lib.current_stream())
+            _lib.check(rc, "tia_gather_patches_u8")
+            return out if self._dev.dim() == 3 else out[..., 0]  # noqa: PLR2004
         bounds = np.ascontiguousarray(np.asarray(bounds).reshape(-1, 4), dtype=np.int32)
         sizes = np.unique(np.stack([bounds[:, 2] - bounds[:, 0], bounds[:, 3] - bounds[:, 1]], axis=1), axis=0)
         if len(sizes) != 1:
