@@ -351,8 +351,25 @@ class MultiTaskSegmentor(EngineABC):
         plan_rows = list(plan["rows"])
         row_sels = [np.flatnonzero(keep & (out_b[:, 1] - min_y == int(row_ys[ri]))) for ri in plan_rows]
 
+        # bounds and row offsets to the device once, in the order `iter_row_outputs` consumes them (see SemanticSegmentor.infer_wsi)
+        flat = np.concatenate([s for s in row_sels if len(s)]) if any(len(s) for s in row_sels) else np.zeros(0, np.int64)
+        bs = int(self.batch_size)
+        size = (int(in_b[0, 2] - in_b[0, 0]), int(in_b[0, 3] - in_b[0, 1])) if len(in_b) else (0, 0)
+        uniform = len(in_b) > 0 and bool(np.all(in_b[:, 2] - in_b[:, 0] == size[0]) and np.all(in_b[:, 3] - in_b[:, 1] == size[1]))
+        bounds_dev = xs_dev = None
+        if uniform and len(flat):
+            padded = np.concatenate([flat, np.repeat(flat[-1:], bs)])
+            bounds_dev = torch.from_numpy(np.ascontiguousarray(in_b[padded], dtype=np.int32)).to(dev)
+            xs_dev = torch.from_numpy(np.ascontiguousarray(out_b[flat, 0] - min_x, dtype=np.int32)).to(dev)
+        row_starts = np.concatenate([[0], np.cumsum([len(s) for s in row_sels])])
+        state = {"pos": 0}
+
         def infer(idx):
-            return tuple(infer_batch(model, reader.read_bounds_batch(in_b[idx]), device=self.device))
+            if bounds_dev is None:
+                return tuple(infer_batch(model, reader.read_bounds_batch(in_b[idx]), device=self.device))
+            p = state["pos"]
+            state["pos"] = p + min(bs, len(flat) - p)
+            return tuple(infer_batch(model, reader.read_bounds_batch(bounds_dev[p:p + bs], size=size), device=self.device))
 
         with self._miopen_scope():
             for k, outs in iter_row_outputs(infer, row_sels, self.batch_size):
@@ -363,7 +380,8 @@ class MultiTaskSegmentor(EngineABC):
                     blocks = [o.float().contiguous() for o in outs]
                     if heads is None:
                         heads = [torch.zeros((band_h, rw, b.shape[-1]), dtype=torch.float32, device=dev) for b in blocks]
-                    rows = [(*_row_merge(b, out_b[sel, 0] - min_x, rw), ys) for b in blocks]
+                    xs = xs_dev[int(row_starts[k]):int(row_starts[k + 1])] if xs_dev is not None else out_b[sel, 0] - min_x
+                    rows = [(*_row_merge(b, xs, rw), ys) for b in blocks]
                 if heads is None:
                     continue  # nothing inferred yet: the maps start as zeros
                 if rows is None:
