@@ -210,8 +210,8 @@ def spatial_conv(k: int, stride: int, ho: int, wo: int) -> bool:
 
 def trunk_roofline(model, u8_batch):
     """HIP-event times and algorithmic flops of the hand-written convolution kernels of one trunk forward: the stem kernel
-    (one launch) and the block convolutions, split by kernel -- ``conv3x3_spatial_kernel`` (3x3 / stride 1, tap reuse) and
-    ``conv_mfma_f32_kernel`` (strided, 1x1 and small-map convolutions).  Per-launch events (one sync per launch, kernel time
+    (one launch) and the block convolutions, split by kernel -- ``conv3x3_spatial_kernel`` (3x3 / stride 1, tap reuse),
+    ``conv1x1_ring_kernel`` (1x1) and ``conv_mfma_f32_kernel`` (strided 3x3).  Per-launch events (one sync per launch, kernel time
     only) give the split; the total is timed separately over whole forwards without syncs."""
     import torch
 
@@ -221,7 +221,7 @@ def trunk_roofline(model, u8_batch):
     trunk = next((m for m in model.modules() if isinstance(m, MfmaResNet)), None)
     if trunk is None:
         return None
-    fam = {"conv3x3_spatial_kernel": [0, 0.0, 0], "conv_mfma_f32_kernel": [0, 0.0, 0]}  # launches, seconds, flops
+    fam = {"conv3x3_spatial_kernel": [0, 0.0, 0], "conv1x1_ring_kernel": [0, 0.0, 0], "conv_mfma_f32_kernel": [0, 0.0, 0]}  # launches, s, flops
     plain = fused.hip_conv2d
 
     def timed(x, w, b, residual, *, kernel, stride, padding, relu):
@@ -231,7 +231,13 @@ def trunk_roofline(model, u8_batch):
         e1.record()
         e1.synchronize()
         n, co, ho, wo = y.shape
-        f = fam["conv3x3_spatial_kernel" if spatial_conv(kernel, stride, ho, wo) else "conv_mfma_f32_kernel"]
+        if spatial_conv(kernel, stride, ho, wo):
+            name = "conv3x3_spatial_kernel"
+        elif kernel == 1 and co % 128 == 0 and ((n * ho * wo + 255) // 256) * (co // 128) >= 384:  # noqa: PLR2004
+            name = "conv1x1_ring_kernel"  # mirror of conv1x1_ring_launch's rule (csrc/conv3x3_spatial.hip)
+        else:
+            name = "conv_mfma_f32_kernel"
+        f = fam[name]
         f[0] += 1
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += 2 * n * ho * wo * co * x.shape[1] * kernel * kernel
@@ -424,7 +430,8 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
         dominant = max(fams, key=lambda k: fams[k]["seconds"])
         dk = fams[dominant]
         desc = {"conv3x3_spatial_kernel": "3x3 / stride-1 convolutions, 16x16 (or 2 x 8x8) pixel blocks with tap reuse (LDS-DMA patch + weight ring)",
-                "conv_mfma_f32_kernel": "strided 3x3 and 1x1 convolutions, 128-pixel slices"}
+                "conv1x1_ring_kernel": "1x1 convolutions as a GEMM over 256-pixel blocks, both operands by LDS-DMA (two-stage ring)",
+                "conv_mfma_f32_kernel": "strided 3x3 (and small 1x1) convolutions, 128-pixel slices"}
         roofline = {
             "kernel": dominant, "bound": "mfma", "achieved": round(dk["tflops"], 2),
             "peak": MFMA_PEAK_TFLOPS["float32"], "unit": "TFLOP/s",
