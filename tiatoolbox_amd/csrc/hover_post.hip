@@ -3,7 +3,6 @@
 // priority flood run independently per connected mask blob (the global skimage heap restricted
 // to one blob pops in the same order as a private heap, because a blob's entries are only ever
 // inserted by pops of that blob), one lane per blob with its heap segment in global memory.
-#include <cstdio>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -253,13 +252,6 @@ __device__ __forceinline__ void block_minmax2(MinMax2 m, double (*red)[4], doubl
 
 // KS: the filter size at compile time (21: HoVer-Net, 11: HoVerNet+) -- the tap loops are then fully unrolled and the taps are
 // scalar registers; with a run-time index every tap is a scalar load from the kernel arguments.  KS = 0: any size.
-#ifdef TIA_TILE_TIMING
-__device__ long long g_tile_stamps[16];
-#define TSTAMP(I) if (blockIdx.x == 0 && threadIdx.x == 0) g_tile_stamps[I] = clock64()
-#else
-#define TSTAMP(I)
-#endif
-
 template <int KS>
 __global__ __launch_bounds__(1024) void sobel_energy_tile_kernel(const float* __restrict__ hv, int h, int w, const SobelTaps kd,
                                                                   const SobelTaps ks, int ksize_rt, int band, int n,
@@ -277,7 +269,6 @@ __global__ __launch_bounds__(1024) void sobel_energy_tile_kernel(const float* __
     auto refl = [&](int i, int nn) { return near ? reflect101_near(i, nn) : reflect101(i, nn); };
     const size_t off = (size_t)plane * hw;
     const float2* in2 = reinterpret_cast<const float2*>(hv + off * 2);
-    TSTAMP(0);
     {
         MinMax2 m;
         m.init();
@@ -294,7 +285,6 @@ __global__ __launch_bounds__(1024) void sobel_energy_tile_kernel(const float* __
         mm[2 * n + plane * 2] = s_in[2];
         mm[2 * n + plane * 2 + 1] = s_in[3];
     }
-    TSTAMP(1);
     MinMax2 mo;
     mo.init();
 #pragma unroll  // both copies: which tap set is the row filter must be known at compile time (a run-time choice turns every tap
@@ -318,7 +308,6 @@ __global__ __launch_bounds__(1024) void sobel_energy_tile_kernel(const float* __
 #pragma unroll 8
             for (int i = tid; i < nrow; i += 1024) inb[i] = src[((size_t)lo * w + i) * 2] * a + b;
             __syncthreads();
-            if (ch == 0 && y0 == 0) TSTAMP(2);
             // row pass, two pixels per lane and round (independent accumulation chains); taps in ascending order
             for (int i = tid; i < nrow; i += 2048) {
                 const int i2 = i + 1024;
@@ -350,7 +339,6 @@ __global__ __launch_bounds__(1024) void sobel_energy_tile_kernel(const float* __
                 if (two) rb[i2] = acc1;
             }
             __syncthreads();
-            if (ch == 0 && y0 == 0) TSTAMP(3);
             const int nout = (y1 - y0) * w;
             for (int i = tid; i < nout; i += 2048) {
                 const int i2 = i + 1024;
@@ -388,11 +376,9 @@ __global__ __launch_bounds__(1024) void sobel_energy_tile_kernel(const float* __
             }
             __syncthreads();
         }
-        if (ch == 0) TSTAMP(4);
         mo.v[2 * ch] = vmin;
         mo.v[2 * ch + 1] = vmax;
     }
-    TSTAMP(5);
     // (workgroup scope: an agent-scope fence writes the XCD's whole L2 back -- measured 150 us here)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the gradient planes are re-read below by other lanes of this workgroup
     block_minmax2(mo, red, s_out);
@@ -402,7 +388,6 @@ __global__ __launch_bounds__(1024) void sobel_energy_tile_kernel(const float* __
         mm[6 * n + plane * 2] = s_out[2];
         mm[6 * n + plane * 2 + 1] = s_out[3];
     }
-    TSTAMP(6);
     double sh_s, sh_b, sv_s, sv_b;
     norm_params(s_out, sh_s, sh_b);
     norm_params(s_out + 2, sv_s, sv_b);
@@ -423,12 +408,10 @@ __global__ __launch_bounds__(1024) void sobel_energy_tile_kernel(const float* __
         int mk = blb - (overall >= 0.4 ? 1 : 0);
         marker0[off + i] = mk < 0 ? 0 : (uint8_t)mk;
     }
-    TSTAMP(7);
     if (dist == nullptr) return;
     // dist = -GaussianBlur3x3(dist0) (= gauss3_neg_kernel), reading back the plane this workgroup just wrote
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    TSTAMP(8);
     const double* sg = dist0 + off;
 #pragma unroll 2
     for (int i = tid; i < hw; i += 1024) {
@@ -442,7 +425,6 @@ __global__ __launch_bounds__(1024) void sobel_energy_tile_kernel(const float* __
         }
         dist[off + i] = -(r[1] * 0.5 + (r[0] + r[2]) * 0.25);
     }
-    TSTAMP(9);
 }
 
 // ---- watershed -----------------------------------------------------------------------------------------------------
@@ -1293,16 +1275,6 @@ static int hover_proc_impl(const float* d_np, const float* d_hv, int64_t n, int6
         }
         hipLaunchKernelGGL(variants[ksize == 21 ? 0 : (ksize == 11 ? 1 : 2)], dim3((unsigned)n), dim3(1024), lds, st, d_hv, (int)h, (int)w, kd,
                            ks, ksize, band, (int)n, (const int*)blob_lab, sob_h, sob_v, dist0, tmp_a, mm, fused ? dist : (double*)nullptr);
-#ifdef TIA_TILE_TIMING
-        {
-            long long hst[16];
-            hipStreamSynchronize(st);
-            hipMemcpyFromSymbol(hst, HIP_SYMBOL(g_tile_stamps), sizeof(hst));
-            fprintf(stderr, "sobel tile stamps (cycles @100MHz? clock64):");
-            for (int i = 1; i < 10; ++i) fprintf(stderr, " %lld", hst[i] - hst[i - 1]);
-            fprintf(stderr, "\n");
-        }
-#endif
         if (!tap(taps.sobel_h, sob_h, plane_f64) || !tap(taps.sobel_v, sob_v, plane_f64)) return TIA_ELAUNCH;
     } else {
     hipLaunchKernelGGL(minmax_hv_kernel, dim3((unsigned)n), dim3(1024), 0, st, d_hv, hw, mm, mm + 2 * n);
