@@ -159,3 +159,44 @@ def install() -> None:
     skimage.filters.threshold_otsu = skref.threshold_otsu_u8
     skimage.morphology.remove_small_objects = lambda ar, max_size=None, **_: skref.remove_small_objects(ar, max_size)
     skimage.segmentation.watershed = lambda image, markers=None, mask=None: skref.watershed(image, markers, mask)
+
+
+def bind_torchvision_resnet() -> None:
+    """Bind ``torchvision.models.resnet.ResNet`` / ``Bottleneck`` (absent here) to a restatement with torchvision's constructor,
+    attribute names and forward, built on this repo's ``Bottleneck`` (itself a restatement of torchvision's block).  With it the
+    reference's ``ResNetEncoder`` / ``UNetModel`` (models/architecture/unet.py) instantiate and run: decoder, skip connections,
+    up-sampling, ``infer_batch`` are then the REAL reference code; the encoder blocks are this shim (stated in DESIGN.md section 2)."""
+    import torch
+    from torch import nn
+
+    install()
+    import torchvision.models.resnet as tv  # the placeholder module
+
+    from tiatoolbox_amd.models.architecture.resnet import Bottleneck, _make_layer
+
+    class ResNet(nn.Module):
+        def __init__(self, block, layers, num_classes: int = 1000, **_) -> None:
+            super().__init__()
+            self.inplanes = 64
+            self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+            self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+            inplanes = 64
+            self.layer1, inplanes = _make_layer(block, inplanes, 64, layers[0], 1)
+            self.layer2, inplanes = _make_layer(block, inplanes, 128, layers[1], 2)
+            self.layer3, inplanes = _make_layer(block, inplanes, 256, layers[2], 2)
+            self.layer4, inplanes = _make_layer(block, inplanes, 512, layers[3], 2)
+            self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+            self.fc = nn.Linear(inplanes, num_classes)
+
+        def _forward_impl(self, x):
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            return self.fc(torch.flatten(self.avgpool(x), 1))
+
+        def forward(self, x):
+            return self._forward_impl(x)
+
+    tv.ResNet = ResNet
+    tv.Bottleneck = Bottleneck
