@@ -32,8 +32,17 @@ extern "C" {
 /* Version 3 (round 3): + tia_stem_pack_weights_f32 / tia_stem_conv7x7_pool_nhwc, tia_conv_pack_weights_h / tia_conv2d_nhwc_h,
  * tia_stem_pack_weights_h / tia_stem_conv7x7_pool_nhwc_h, tia_conv2d_thin_nhwc_f32, tia_conv1x1_head_nhwc_f32, tia_lut_apply_u8, tia_box_downsample_u8; the workspace of
  * tia_stain_stats_u8 grew by one int32 flag per patch (tia_stain_stats_workspace_bytes_mode reports it). */
-#define TIA_ABI_VERSION 3
+/* Version 4 (round 4): + tia_rgb2od_u8 (the stand-alone OD transform, with the reference's in-place side effect on request),
+ * tia_clear_last_error; TIA_MATH_F64 of tia_stain_apply_u8 evaluates exp() with the library's own float64 kernel
+ * (TIA_MATH_F64_REF keeps the device libm's exp). */
+#define TIA_ABI_VERSION 4
 int tia_abi_version(void);
+
+/* Reads-and-clears the HIP runtime's sticky last-error value as THIS library sees it (every entry point returns
+ * `hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH`).  Call it after a host-side HIP call that is allowed to be
+ * refused (hipHostRegister of already-pinned memory) so that the refusal does not surface as a later TIA_ELAUNCH.
+ * Returns the value that was pending (0 = none). */
+int tia_clear_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
  * Stain tables (device buffer, built once by the host; layout = struct tia_stain_tables).
@@ -127,8 +136,12 @@ int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
 #define TIA_OUT_UNIT_BF16 4
 #define TIA_OUT_UNIT_F32 5
 
-#define TIA_MATH_F64 0 /* reference order of operations in f64 (stainnorm.py:102-107)             */
+#define TIA_MATH_F64 0 /* float64 throughout; exp() evaluated by the kernel's own table + cubic (relative error
+                          <= 4e-15, i.e. < 1e-12 on the 0..255 scale), 3x3 matrix TIA_ST_M fused in float64  */
 #define TIA_MATH_F32 1 /* fused 3x3 matrix in f32: |err| <= 1e-4 on the pre-cast float            */
+#define TIA_MATH_F64_REF 2 /* the reference's order of operations in f64 (stainnorm.py:102-107) with the device
+                              library's exp(): parity audit of TIA_MATH_F64, and its in-kernel fall-back for patches
+                              whose exponent range is not safe for the table arithmetic           */
 
 /*
  * out = 255*exp(-(OD(img) . pinv . diag(scale) . S_target)), clipped to [0,255].
@@ -164,6 +177,13 @@ int tia_stain_augment_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
 int tia_luminosity_mask_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
                            const tia_stain_tables* d_tables, const double* d_stats, int32_t y_thr,
                            int32_t zero_to_one, uint8_t* d_mask, void* stream);
+
+/*
+ * rgb2od (utils/transforms.py:209-231) of `nbytes` uint8 values of any shape: d_od[i] = max(-ln(max(d_img[i],1)/255), 1e-6)
+ * as float64 (table look-up: the 256 possible results, computed on the host with NumPy's own log).  mutate = 1 also
+ * performs the reference's side effect on its argument, `img[img == 0] = 1` (:229-230), in place on d_img.
+ */
+int tia_rgb2od_u8(uint8_t* d_img, int64_t nbytes, const tia_stain_tables* d_tables, int32_t mutate, double* d_od, void* stream);
 
 
 /* =======================================================================================

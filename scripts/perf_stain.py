@@ -39,7 +39,7 @@ pr.mode = _lib.MODE_FIXED; pr.stain_fixed[:] = [0.65,0.70,0.29,0.07,0.99,0.11]
 t = timeit(lambda: dev.stain_stats(x, pr))
 print(f"stats(fixed S) : {t:.3f} ms  -> {n/t*1e3:,.0f} patches/s")
 byts = 2 * n * h * w * 3
-for math, mname in ((_lib.MATH_F32, "f32"), (_lib.MATH_F64, "f64")):
+for math, mname in ((_lib.MATH_F32, "f32"), (_lib.MATH_F64, "f64"), (_lib.MATH_F64_REF, "f64_ref(libm exp)")):
     for ok, oname in ((_lib.OUT_U8, "u8"), (_lib.OUT_UNIT_F16, "unit_f16")):
         out = dev.stain_apply(x, stats, norm.stain_matrix_target, out_kind=ok, math=math)
         t = timeit(lambda: dev.stain_apply(x, stats, norm.stain_matrix_target, out_kind=ok, math=math, out=out))

@@ -248,3 +248,53 @@ def test_semantic_band_exchange(tmp_path, world_size):
     mp.spawn(_band_worker, args=(world_size, port, str(tmp_path)), nprocs=world_size, join=True)
     for r in range(1, world_size):
         assert torch.equal(torch.load(tmp_path / "bands0.pt"), torch.load(tmp_path / f"bands{r}.pt"))
+
+
+# ------------------------------------------------------------------ output directory of WSI runs across ranks
+def _save_dir_worker(rank: int, world: int, port: int, root: str) -> None:
+    from pathlib import Path
+
+    from tiatoolbox_amd.models.engine.engine_abc import outputs_written, prepare_engines_save_dir
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    tdist.init_from_env("gloo")
+    root_p = Path(root)
+    # 1. fresh directory: only rank 0 creates it, nobody raises, every rank gets the same path
+    d = prepare_engines_save_dir(root_p / "run", patch_mode=False, overwrite=False, distributed=True)
+    assert d == root_p / "run" and d.is_dir()
+    if rank == 0:
+        (d / "slide.npz").write_bytes(b"x")
+    outputs_written(True)
+    assert (d / "slide.npz").exists()          # the returned paths exist on every rank when run() returns
+    dist.barrier()
+    # 2. it exists now: EVERY rank raises FileExistsError (nobody is left waiting in a collective)
+    try:
+        prepare_engines_save_dir(root_p / "run", patch_mode=False, overwrite=False, distributed=True)
+    except FileExistsError:
+        pass
+    else:
+        raise AssertionError(f"rank {rank}: no FileExistsError")
+    assert (d / "slide.npz").exists()
+    dist.barrier()
+    # 3. overwrite=True: removed and re-created ONCE (by rank 0); the old file is gone, the directory is there on all ranks
+    d2 = prepare_engines_save_dir(root_p / "run", patch_mode=False, overwrite=True, distributed=True)
+    assert d2.is_dir() and not (d2 / "slide.npz").exists()
+    dist.barrier()
+    # 4. the WSI-mode contract without save_dir is unchanged, and patch mode needs no directory
+    try:
+        prepare_engines_save_dir(None, patch_mode=False, distributed=True)
+    except OSError as exc:
+        assert "no save directory" in str(exc)
+    assert prepare_engines_save_dir(None, patch_mode=True, distributed=True) is None
+    (root_p / f"ok{rank}").write_text("1")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_wsi_save_dir_is_prepared_by_rank_zero_only(tmp_path, world):
+    """Every rank calls ``run(..., patch_mode=False, save_dir=...)``; the reference's ``mkdir(parents=True)`` /
+    ``rmtree`` rule (``engine_abc.py:1832-1885``) must be applied once, by rank 0, with its outcome raised everywhere."""
+    port = 29900 + (os.getpid() % 150) + world
+    mp.spawn(_save_dir_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))

@@ -475,3 +475,56 @@ def test_half_precision_run_uses_the_handwritten_convolutions(patches, dtype):
     assert all(b._bias32 for b in trunk[0].blocks)  # noqa: SLF001  (float32 biases kept from before the cast)
     err = np.abs(got["probabilities"] - ref["probabilities"]).max()
     assert err <= (1e-3 if dtype == "float16" else 2e-2), err
+
+
+def test_deferred_totensor_only_for_stock_classifiers():
+    """``ToTensor`` is folded into the stem kernel (the batch stays uint8 and ``model(...)`` is called directly) only when the
+    model is EXACTLY ``CNNModel`` / ``CNNBackbone`` with the stock ``infer_batch`` on the uint8-reading trunk: a subclass with its
+    own ``forward`` / ``infer_batch`` (pre-processing inside the model), an instance-level ``infer_batch`` override, or a
+    segmentation model (whose ``infer_batch`` crops / soft-maxes) must keep the ordinary path.  Host logic: no GPU needed."""
+    import types
+
+    from tiatoolbox_amd.models.architecture.vanilla import CNNBackbone, CNNModel
+    from tiatoolbox_amd.models.engine.engine_abc import EngineABC
+
+    class Trunk(torch.nn.Module):
+        accepts_uint8 = True
+
+    def decide(model, fast=None):
+        eng = types.SimpleNamespace(device="cuda", model=model)
+        fast = fast if fast is not None else model
+        EngineABC._set_defer_unit(eng, fast, torch.float32)  # noqa: SLF001
+        return eng._defer_unit  # noqa: SLF001
+
+    stock = CNNModel("resnet18", num_classes=3)
+    stock.feat_extract = Trunk()
+    assert decide(stock) is True
+    back = CNNBackbone("resnet18")
+    back.feat_extract = Trunk()
+    assert decide(back) is True
+    plain = CNNModel("resnet18", num_classes=3)            # trunk that does not read uint8
+    assert decide(plain) is False
+
+    class Custom(CNNModel):
+        def forward(self, imgs):
+            return super().forward(imgs * 2.0)
+
+    sub = Custom("resnet18", num_classes=3)
+    sub.feat_extract = Trunk()
+    assert decide(sub) is False
+    inst = CNNModel("resnet18", num_classes=3)
+    inst.feat_extract = Trunk()
+    inst.infer_batch = lambda model, batch_data, device="cpu": None  # noqa: ARG005
+    assert decide(inst) is False
+
+    class Seg(torch.nn.Module):                              # e.g. FusedUNet: uint8-capable, but not a classifier
+        accepts_uint8 = True
+
+        def __init__(self):
+            super().__init__()
+            self.feat_extract = Trunk()
+
+    assert decide(Seg()) is False
+    eng = types.SimpleNamespace(device="cpu", model=stock)
+    EngineABC._set_defer_unit(eng, stock, torch.float32)  # noqa: SLF001
+    assert eng._defer_unit is False  # noqa: SLF001

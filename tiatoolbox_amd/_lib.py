@@ -20,7 +20,7 @@ ST_MINPHI, ST_MAXPHI, ST_COV, ST_EVEC, ST_FLAGS, ST_PINV, ST_M, ST_SCALE = 11, 1
 FLAG_EMPTY_MASK, FLAG_DEGENERATE = 1, 2
 MODE_MACENKO, MODE_FIXED, MODE_VAHADANE, MODE_GIVEN = 0, 1, 2, 3
 OUT_U8, OUT_F32, OUT_F64, OUT_UNIT_F16, OUT_UNIT_BF16, OUT_UNIT_F32 = 0, 1, 2, 3, 4, 5
-MATH_F64, MATH_F32 = 0, 1
+MATH_F64, MATH_F32, MATH_F64_REF = 0, 1, 2
 
 _ERRORS = {-1: "TIA_EINVAL (bad argument)", -2: "TIA_ELAUNCH (HIP launch failed)",
            -3: "TIA_ESIZE (size not supported)"}
@@ -65,6 +65,8 @@ _SIGNATURES = {
     "tia_stain_concentrations_f64": ([_P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
     "tia_stain_augment_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _I32, _P], C.c_int),
     "tia_luminosity_mask_u8": ([_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _P, _P], C.c_int),
+    "tia_rgb2od_u8": ([_P, _I64, _P, _I32, _P, _P], C.c_int),
+    "tia_clear_last_error": ([], C.c_int),
     "tia_rgb2gray_u8": ([_P, _I64, _P, _P], C.c_int),
     "tia_hist256_u8": ([_P, _I64, _P, _P], C.c_int),
     "tia_threshold_lt_u8": ([_P, _I64, _I32, _I32, _P, _P], C.c_int),

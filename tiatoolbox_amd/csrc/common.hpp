@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "tiatoolbox_amd.h"
 
 #ifndef TIA_UNIFORM
@@ -13,6 +15,23 @@
 namespace tia {
 
 constexpr int kWave = 64;
+
+// Per-device one-time host set-up (hipFuncSetAttribute is a per-DEVICE property of a kernel; a process-wide `static bool`
+// would leave the second GPU of a process without it).  `ensure(setup)` runs `setup()` -> bool until it has succeeded once on
+// the calling thread's current device; concurrent first calls may both run it (the set-ups are idempotent), the flag itself
+// is atomic.
+struct DeviceOnce {
+    std::atomic<unsigned char> done[64] = {};
+    template <class F>
+    bool ensure(F&& setup) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+        if (done[d].load(std::memory_order_acquire)) return true;
+        if (!setup()) return false;
+        done[d].store(1, std::memory_order_release);
+        return true;
+    }
+};
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
@@ -212,10 +231,10 @@ __device__ __forceinline__ void unpack_group(uint32_t a, uint32_t b, uint32_t c,
 
 // ---- LDS-resident labelling of small planes (imgops.hip; internal interface shared with hover_post.hip) ---------------------
 constexpr long kCclTileMaxPixels = 36864;  // int32 union-find of one plane in LDS: 147,456 of the CU's 163,840 bytes
-inline bool ccl_tile_enabled() {           // developer switch: TIA_NO_CCL_TILE=1 keeps the multi-launch path (parity audit)
-    static const bool on = getenv("TIA_NO_CCL_TILE") == nullptr;
-    return on;
-}
+// Whether the tile-resident (LDS) kernels serve the current device: false with the developer switch TIA_NO_CCL_TILE=1 (parity
+// audit of the multi-launch path) and on a device that refuses their dynamic LDS size (up to 147 KB; gfx950 has 160 KB per
+// CU) -- the callers then take the multi-launch path instead of failing.  Sets the kernels' LDS attribute once per device.
+bool ccl_tile_enabled();
 // labels (1-based, raster order of the components' first pixels; 0 = background or removed) of n planes of h x w <= 36,864
 // pixels in one launch.  src_kind 0: uint8 mask != 0; 1: uint8 mask == 0; 2: float32 map >= 0.5.  min_keep > 0: components with
 // fewer pixels become 0 (their numbers are not re-used); areas (nullable): [n][h*w + 1] component areas by label.

@@ -1259,20 +1259,23 @@ static int hover_proc_impl(const float* d_np, const float* d_hv, int64_t n, int6
     SobelTaps kd, ks;
     sobel_taps_host(ksize, kd, ks);
     // small planes: min / max + both filters + energy in one launch, the row pass staged in LDS in bands of rows
-    const bool tile_sobel = tile && band_rows_max >= 8;
+    using SobelKernel = void (*)(const float*, int, int, const SobelTaps, const SobelTaps, int, int, int, const int*, double*, double*,
+                                 double*, uint8_t*, double*, double*);
+    static const SobelKernel variants[3] = {sobel_energy_tile_kernel<21>, sobel_energy_tile_kernel<11>, sobel_energy_tile_kernel<0>};
+    static DeviceOnce sobel_once;
+    bool tile_sobel = tile && band_rows_max >= 8;
+    if (tile_sobel && !sobel_once.ensure([] {
+            for (const SobelKernel k : variants)
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+                    return false;
+            return true;
+        })) {
+        (void)hipGetLastError();  // a device without 144 KB of LDS per workgroup: the multi-launch Sobel below serves it
+        tile_sobel = false;
+    }
     if (tile_sobel) {
         const int band = (int)(band_rows_max < h ? band_rows_max : h);
         const size_t lds = (size_t)(band + ksize - 1) * w * 12;
-        using SobelKernel = void (*)(const float*, int, int, const SobelTaps, const SobelTaps, int, int, int, const int*, double*, double*,
-                                     double*, uint8_t*, double*, double*);
-        static const SobelKernel variants[3] = {sobel_energy_tile_kernel<21>, sobel_energy_tile_kernel<11>, sobel_energy_tile_kernel<0>};
-        static bool ready = false;
-        if (!ready) {
-            for (const SobelKernel k : variants)
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
-                    return TIA_ELAUNCH;
-            ready = true;
-        }
         hipLaunchKernelGGL(variants[ksize == 21 ? 0 : (ksize == 11 ? 1 : 2)], dim3((unsigned)n), dim3(1024), lds, st, d_hv, (int)h, (int)w, kd,
                            ks, ksize, band, (int)n, (const int*)blob_lab, sob_h, sob_v, dist0, tmp_a, mm, fused ? dist : (double*)nullptr);
         if (!tap(taps.sobel_h, sob_h, plane_f64) || !tap(taps.sobel_v, sob_v, plane_f64)) return TIA_ELAUNCH;

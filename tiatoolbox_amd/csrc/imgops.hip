@@ -733,17 +733,29 @@ template <typename K>
 static bool tile_lds_ok(K kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
+bool ccl_tile_enabled() {
+    static const bool on = getenv("TIA_NO_CCL_TILE") == nullptr;
+    if (!on) return false;
+    static DeviceOnce once;
+    static std::atomic<unsigned char> refused[64] = {};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    if (refused[d].load(std::memory_order_acquire)) return false;
+    const bool ok = once.ensure([] {
+        const size_t cap = (size_t)kCclTileMaxPixels * sizeof(int);
+        return tile_lds_ok(ccl_tile_kernel<0>, cap) && tile_lds_ok(ccl_tile_kernel<1>, cap) && tile_lds_ok(ccl_tile_kernel<2>, cap) &&
+               tile_lds_ok(fill_holes_tile_kernel, cap) && tile_lds_ok(marker_tile_kernel, (size_t)kMarkerTileMaxPixels * 5);
+    });
+    if (!ok) {
+        (void)hipGetLastError();  // the refusal is handled here (multi-launch path): do not leave it for the next launch check
+        refused[d].store(1, std::memory_order_release);
+    }
+    return ok;
+}
 int ccl_tile_label(const void* src, int src_kind, long n, int h, int w, int conn, int min_keep, int* labels, int* count, int* areas,
                    hipStream_t st, int* offs, int* bbox) {
     const size_t lds = (size_t)h * w * sizeof(int);
-    static bool ready = false;
-    if (!ready) {
-        const size_t cap = (size_t)kCclTileMaxPixels * sizeof(int);
-        if (!tile_lds_ok(ccl_tile_kernel<0>, cap) || !tile_lds_ok(ccl_tile_kernel<1>, cap) || !tile_lds_ok(ccl_tile_kernel<2>, cap) ||
-            !tile_lds_ok(fill_holes_tile_kernel, cap))
-            return TIA_ELAUNCH;
-        ready = true;
-    }
+    if (!ccl_tile_enabled()) return TIA_ELAUNCH;  // callers ask ccl_tile_enabled() first
     const int c8 = conn == 8 ? 1 : 0;
     if (src_kind == 2)
         hipLaunchKernelGGL(ccl_tile_kernel<2>, dim3((unsigned)n), dim3(1024), lds, st, src, h, w, c8, min_keep, labels, count, areas, offs,
@@ -758,27 +770,15 @@ int ccl_tile_label(const void* src, int src_kind, long n, int h, int w, int conn
 }
 int marker_tile(const uint8_t* marker0, long n, int h, int w, int min_keep, int* labels, int* count, int* areas, hipStream_t st,
                 const int* blob, int* inst, int* bbox) {
-    static bool ready = false;
-    if (!ready) {
-        if (!tile_lds_ok(marker_tile_kernel, (size_t)kMarkerTileMaxPixels * 5)) return TIA_ELAUNCH;
-        ready = true;
-    }
+    if (!ccl_tile_enabled()) return TIA_ELAUNCH;
     hipLaunchKernelGGL(marker_tile_kernel, dim3((unsigned)n), dim3(1024), (size_t)h * w * 5, st, marker0, h, w, min_keep, labels, count, areas,
                        blob, inst, bbox);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 int fill_holes_tile(const uint8_t* mask, long n, int h, int w, uint8_t* out, hipStream_t st) {
-    int rc = TIA_OK;
-    {
-        static bool ready = false;
-        if (!ready) {
-            if (!tile_lds_ok(fill_holes_tile_kernel, (size_t)kCclTileMaxPixels * sizeof(int))) return TIA_ELAUNCH;
-            ready = true;
-        }
-    }
+    if (!ccl_tile_enabled()) return TIA_ELAUNCH;
     hipLaunchKernelGGL(fill_holes_tile_kernel, dim3((unsigned)n), dim3(1024), (size_t)h * w * sizeof(int), st, mask, h, w, out);
-    if (hipGetLastError() != hipSuccess) rc = TIA_ELAUNCH;
-    return rc;
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 }  // namespace tia
 

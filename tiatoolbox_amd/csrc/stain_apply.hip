@@ -152,9 +152,10 @@ struct ApplyCtx<TIA_MATH_F32> {
     }
 };
 
-// f64: the reference's order of operations (concentrations, rescale, recomposition, exp).
+// f64, libm: the reference's order of operations (concentrations, rescale, recomposition, exp) with the device
+// library's exp() -- TIA_MATH_F64_REF, and the fall-back of TIA_MATH_F64 for patches whose exponent range is not safe.
 template <>
-struct ApplyCtx<TIA_MATH_F64> {
+struct ApplyCtx<TIA_MATH_F64_REF> {
     double p[6], sc[2], st[6];
     const double* lut;
     __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, double (&o)[3]) const {
@@ -174,47 +175,63 @@ struct ApplyCtx<TIA_MATH_F64> {
     }
 };
 
-template <int MATH, int OUT>
-__global__ __launch_bounds__(AT) void stain_apply_kernel(const uint8_t* __restrict__ img, long hw,
-                                                          const tia_stain_tables* __restrict__ tab,
-                                                          const double* __restrict__ stats, StainT tgt,
-                                                          void* __restrict__ out_v) {
+// f64, own exp (TIA_MATH_F64): 255 * exp(-(OD . M)) = T[n & 1023] * 2^(n >> 10) * (1 + r q(r)) with
+//   a = OD . (M * -1024/ln 2) = n + r,  n = rint(a) (magic-number add: no conversion instruction),  |r| <= 1/2,
+//   T[i] = 255 * 2^(i/1024) (exp2_table.inc, correctly rounded),  1 + r q(r) = the cubic Taylor polynomial of
+//   2^(r/1024) (remainder (ln2/2048)^4/24 = 5.5e-16 relative), 2^(n >> 10) added into the exponent field.
+// 16 float64 operations per channel instead of the ~45 of the library's exp(); relative error <= 4e-15 for
+// |a| < 2^15 (the rounding of a dominates), i.e. < 1e-12 on the 0..255 scale -- the 1e-4 contract and every
+// tolerance of tests/test_stain_gpu.py hold unchanged.  M = TIA_ST_M (pinv . diag(scale) . S_target fused by the
+// statistics kernel in float64); the product differs from the reference's order of operations by a few ulp of t.
+// Safe while 5.5414 * sum_j |m[j][c]| < 2^19 (exponent arithmetic stays inside the normal range; results above
+// 255 are clipped like the reference's): checked per patch by the caller, which otherwise takes the libm context.
+#include "exp2_table.inc.h"
+constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
+struct ApplyCtxFast {
+    double m[9];
+    const double* lut;
+    const double* etab;
+    __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, double (&o)[3]) const {
+        const double x = lut[r], y = lut[g], z = lut[b];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double a = __builtin_fma(z, m[6 + c], __builtin_fma(y, m[3 + c], x * m[c]));
+            const double big = a + kMagic;
+            const int lo = __double2loint(big);
+            const double rr = a - (big - kMagic);
+            const double q = __builtin_fma(rr, __builtin_fma(rr, 0x1.c6b08d704a0bfp-35, 0x1.ebfbdff82c58ep-23), 0x1.62e42fefa39efp-11);
+            const double t = etab[lo & 1023];
+            double v = __builtin_fma(t, rr * q, t);
+            v = __hiloint2double(__double2hiint(v) + ((lo >> 10) << 20), __double2loint(v));
+            o[c] = __builtin_fmin(v, 255.0);  // trans[trans > 255] = 255 (the value is positive by construction)
+        }
+    }
+    // m = M * (-1024 / ln 2); returns whether the exponent arithmetic is safe for every byte value
+    __device__ __forceinline__ bool load(const double* __restrict__ st) {
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                m[j * 3 + c] = st[TIA_ST_M + j * 3 + c] * -0x1.71547652b82fep+10;
+                s += fabs(m[j * 3 + c]);
+            }
+            ok = ok && (s * 5.5414 < 524288.0);  // also false for NaN / inf
+        }
+        return ok;
+    }
+};
+
+// one 12-byte group (4 whole pixels) per lane and step, U independent groups in flight
+template <int OUT, int U, class Ctx, class F>
+__device__ __forceinline__ void sweep12(const Ctx& ctx, const uint8_t* __restrict__ src, typename Out<OUT>::T* __restrict__ dst,
+                                        long hw) {
     using O = Out<OUT>;
     using T = typename O::T;
-    using F = typename std::conditional<MATH == TIA_MATH_F32, float, double>::type;
-    constexpr int LUTN = (MATH == TIA_MATH_F32) ? 256 * REP : 256;
-    __shared__ F lut[LUTN];
-
-    const long patch = blockIdx.y;
-    const double* st = stats + patch * TIA_STATS_STRIDE;
-    ApplyCtx<MATH> ctx;
-    if constexpr (MATH == TIA_MATH_F32) {
-        for (int i = threadIdx.x; i < LUTN; i += AT) lut[i] = tab->od_lut_f32[i / REP];
-        const double nl2e = -1.4426950408889634;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) ctx.m[i] = (float)(st[TIA_ST_M + i] * nl2e);
-        ctx.lut = lut;
-        ctx.bank = threadIdx.x & (REP - 1);
-    } else {
-        for (int i = threadIdx.x; i < LUTN; i += AT) lut[i] = tab->od_lut[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            ctx.p[i] = st[TIA_ST_PINV + i];
-            ctx.st[i] = tgt.s[i];
-        }
-        ctx.sc[0] = st[TIA_ST_SCALE + 0];
-        ctx.sc[1] = st[TIA_ST_SCALE + 1];
-        ctx.lut = lut;
-    }
-    __syncthreads();
-
-    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
-    T* dst = reinterpret_cast<T*>(out_v) + (size_t)patch * (size_t)hw * 3u;
-
     if ((hw & 3) == 0) {
         const long ng = hw >> 2;
         const long stride = (long)gridDim.x * AT;
-        constexpr int U = (MATH == TIA_MATH_F32) ? 4 : 2;  // independent 12-byte groups in flight per lane
         for (long g0 = (long)blockIdx.x * AT + threadIdx.x; g0 < ng; g0 += stride * U) {
             uint32_t a[U], b[U], c[U];
 #pragma unroll
@@ -255,6 +272,67 @@ __global__ __launch_bounds__(AT) void stain_apply_kernel(const uint8_t* __restri
     }
 }
 
+__device__ __forceinline__ void load_ref_ctx(ApplyCtx<TIA_MATH_F64_REF>& ctx, const double* __restrict__ st, const StainT& tgt,
+                                             const double* lut) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        ctx.p[i] = st[TIA_ST_PINV + i];
+        ctx.st[i] = tgt.s[i];
+    }
+    ctx.sc[0] = st[TIA_ST_SCALE + 0];
+    ctx.sc[1] = st[TIA_ST_SCALE + 1];
+    ctx.lut = lut;
+}
+
+template <int MATH, int OUT>
+__global__ __launch_bounds__(AT) void stain_apply_kernel(const uint8_t* __restrict__ img, long hw,
+                                                          const tia_stain_tables* __restrict__ tab,
+                                                          const double* __restrict__ stats, StainT tgt,
+                                                          void* __restrict__ out_v) {
+    using T = typename Out<OUT>::T;
+    using F = typename std::conditional<MATH == TIA_MATH_F32, float, double>::type;
+    constexpr int LUTN = (MATH == TIA_MATH_F32) ? 256 * REP : 256;
+    __shared__ F lut[LUTN];
+
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
+    T* dst = reinterpret_cast<T*>(out_v) + (size_t)patch * (size_t)hw * 3u;
+    if constexpr (MATH == TIA_MATH_F32) {
+        ApplyCtx<TIA_MATH_F32> ctx;
+        for (int i = threadIdx.x; i < LUTN; i += AT) lut[i] = tab->od_lut_f32[i / REP];
+        const double nl2e = -1.4426950408889634;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ctx.m[i] = (float)(st[TIA_ST_M + i] * nl2e);
+        ctx.lut = lut;
+        ctx.bank = threadIdx.x & (REP - 1);
+        __syncthreads();
+        sweep12<OUT, 4, ApplyCtx<TIA_MATH_F32>, float>(ctx, src, dst, hw);
+    } else if constexpr (MATH == TIA_MATH_F64_REF) {
+        for (int i = threadIdx.x; i < LUTN; i += AT) lut[i] = tab->od_lut[i];
+        ApplyCtx<TIA_MATH_F64_REF> ctx;
+        load_ref_ctx(ctx, st, tgt, lut);
+        __syncthreads();
+        sweep12<OUT, 2, ApplyCtx<TIA_MATH_F64_REF>, double>(ctx, src, dst, hw);
+    } else {
+        __shared__ double etab[1024];
+        for (int i = threadIdx.x; i < LUTN; i += AT) lut[i] = tab->od_lut[i];
+        for (int i = threadIdx.x; i < 1024; i += AT) etab[i] = kExp2Tab255[i];
+        ApplyCtxFast fast;
+        const bool ok = fast.load(st);
+        fast.lut = lut;
+        fast.etab = etab;
+        __syncthreads();
+        if (ok) {
+            sweep12<OUT, 2, ApplyCtxFast, double>(fast, src, dst, hw);
+        } else {
+            ApplyCtx<TIA_MATH_F64_REF> ctx;
+            load_ref_ctx(ctx, st, tgt, lut);
+            sweep12<OUT, 1, ApplyCtx<TIA_MATH_F64_REF>, double>(ctx, src, dst, hw);
+        }
+    }
+}
+
 // ---- wide variant: 16-byte global accesses through a wave-private LDS transpose -------------------
 // A wave owns 3072 contiguous input bytes (1024 pixels) per step: three fully coalesced 16 B/lane
 // loads land in LDS linearly, each lane then reads back ITS 48 contiguous bytes (16 whole pixels;
@@ -262,35 +340,16 @@ __global__ __launch_bounds__(AT) void stain_apply_kernel(const uint8_t* __restri
 // 48*sizeof(T) output bytes back to LDS and the wave stores them as coalesced 16 B/lane rows.
 // 12-byte loads / 8-byte stores plateau at ~4.4 TB/s on MI355X; 16-byte accesses are what the
 // memory path is built for (MI355X_MICROARCH.md: 8-B accesses run at 0.54-0.70x the 16-B rate).
-template <int OUT>
-__global__ __launch_bounds__(AT) void stain_apply_wide_kernel(const uint8_t* __restrict__ img, long hw,
-                                                               const tia_stain_tables* __restrict__ tab,
-                                                               const double* __restrict__ stats,
-                                                               void* __restrict__ out_v) {
+template <int OUT, class Ctx, class F>
+__device__ __forceinline__ void sweep_wide(const Ctx& ctx, uint8_t* __restrict__ mine, const uint8_t* __restrict__ src,
+                                           uint8_t* __restrict__ dst, long hw) {
     using O = Out<OUT>;
     using T = typename O::T;
     constexpr int TS = sizeof(T);
     static_assert(TS == 1 || TS == 2, "wide path is for 1- and 2-byte outputs");
-    constexpr int CHUNK = 3072;                     // input bytes per wave step
-    __shared__ float lut[256 * REP];
-    __shared__ __attribute__((aligned(16))) uint8_t stage[AT / 64][CHUNK * TS];
+    constexpr int CHUNK = 3072;  // input bytes per wave step
     using v4 = __attribute__((ext_vector_type(4))) unsigned;
-
-    const long patch = blockIdx.y;
-    const double* st = stats + patch * TIA_STATS_STRIDE;
-    ApplyCtx<TIA_MATH_F32> ctx;
-    for (int i = threadIdx.x; i < 256 * REP; i += AT) lut[i] = tab->od_lut_f32[i / REP];
-    const double nl2e = -1.4426950408889634;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) ctx.m[i] = (float)(st[TIA_ST_M + i] * nl2e);
-    ctx.lut = lut;
-    ctx.bank = threadIdx.x & (REP - 1);
-    __syncthreads();
-
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint8_t* mine = stage[wv];
-    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
-    uint8_t* dst = reinterpret_cast<uint8_t*>(out_v) + (size_t)patch * (size_t)hw * 3u * TS;
     const long nchunks = hw * 3 / CHUNK;
     const long wstride = (long)gridDim.x * (AT / 64);
     for (long c = (long)blockIdx.x * (AT / 64) + wv; c < nchunks; c += wstride) {
@@ -316,7 +375,7 @@ __global__ __launch_bounds__(AT) void stain_apply_wide_kernel(const uint8_t* __r
 #pragma unroll
         for (int q = 0; q < 4; ++q) {  // four groups of 4 pixels (12 bytes = 3 dwords each)
             const uint32_t a = w[q * 3], b = w[q * 3 + 1], cc = w[q * 3 + 2];
-            float o[4][3];
+            F o[4][3];
             ctx.pixel(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u, o[0]);
             ctx.pixel(a >> 24, b & 255u, (b >> 8) & 255u, o[1]);
             ctx.pixel((b >> 16) & 255u, b >> 24, cc & 255u, o[2]);
@@ -338,6 +397,49 @@ __global__ __launch_bounds__(AT) void stain_apply_wide_kernel(const uint8_t* __r
             __builtin_nontemporal_store(t, gdst + k * 64 + lane);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int MATH, int OUT>
+__global__ __launch_bounds__(AT) void stain_apply_wide_kernel(const uint8_t* __restrict__ img, long hw,
+                                                               const tia_stain_tables* __restrict__ tab,
+                                                               const double* __restrict__ stats, StainT tgt,
+                                                               void* __restrict__ out_v) {
+    constexpr int TS = sizeof(typename Out<OUT>::T);
+    __shared__ __attribute__((aligned(16))) uint8_t stage[AT / 64][3072 * TS];
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    uint8_t* mine = stage[threadIdx.x >> 6];
+    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
+    uint8_t* dst = reinterpret_cast<uint8_t*>(out_v) + (size_t)patch * (size_t)hw * 3u * TS;
+    if constexpr (MATH == TIA_MATH_F32) {
+        __shared__ float lut[256 * REP];
+        ApplyCtx<TIA_MATH_F32> ctx;
+        for (int i = threadIdx.x; i < 256 * REP; i += AT) lut[i] = tab->od_lut_f32[i / REP];
+        const double nl2e = -1.4426950408889634;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ctx.m[i] = (float)(st[TIA_ST_M + i] * nl2e);
+        ctx.lut = lut;
+        ctx.bank = threadIdx.x & (REP - 1);
+        __syncthreads();
+        sweep_wide<OUT, ApplyCtx<TIA_MATH_F32>, float>(ctx, mine, src, dst, hw);
+    } else {
+        __shared__ double lut[256];
+        __shared__ double etab[1024];
+        for (int i = threadIdx.x; i < 256; i += AT) lut[i] = tab->od_lut[i];
+        for (int i = threadIdx.x; i < 1024; i += AT) etab[i] = kExp2Tab255[i];
+        ApplyCtxFast fast;
+        const bool ok = fast.load(st);
+        fast.lut = lut;
+        fast.etab = etab;
+        __syncthreads();
+        if (ok) {
+            sweep_wide<OUT, ApplyCtxFast, double>(fast, mine, src, dst, hw);
+        } else {
+            ApplyCtx<TIA_MATH_F64_REF> ctx;
+            load_ref_ctx(ctx, st, tgt, lut);
+            sweep12<OUT, 1, ApplyCtx<TIA_MATH_F64_REF>, double>(ctx, src, reinterpret_cast<typename Out<OUT>::T*>(dst), hw);
+        }
     }
 }
 
@@ -550,6 +652,53 @@ __global__ __launch_bounds__(AT) void stain_augment_kernel(const uint8_t* __rest
     }
 }
 
+// ---- stand-alone rgb2od (utils/transforms.py:209-231) ----------------------------------------------
+// One dword (4 bytes) per lane and step: 4 table look-ups, two 16-byte stores (a lane's 32 output bytes are
+// contiguous, a wave's 2 KB too).  `mutate` reproduces the reference's side effect `img[img == 0] = 1`
+// (the dword is only written back when it held a zero byte).  Output-bound: 8 bytes out per byte in.
+__global__ __launch_bounds__(AT) void rgb2od_kernel(uint8_t* __restrict__ img, long nbytes,
+                                                     const tia_stain_tables* __restrict__ tab, int mutate,
+                                                     double* __restrict__ od, int vec_ok) {
+    __shared__ double lut[256];
+    for (int i = threadIdx.x; i < 256; i += AT) lut[i] = tab->od_lut[i];
+    __syncthreads();
+    const long stride = (long)gridDim.x * AT;
+    long done = 0;
+    if (vec_ok) {
+        const long nd = nbytes >> 2;
+        uint32_t* q = reinterpret_cast<uint32_t*>(img);
+        double2* o = reinterpret_cast<double2*>(od);
+        for (long d = (long)blockIdx.x * AT + threadIdx.x; d < nd; d += stride) {
+            const uint32_t w = q[d];
+            double2 lo, hi;
+            lo.x = lut[w & 255u];
+            lo.y = lut[(w >> 8) & 255u];
+            hi.x = lut[(w >> 16) & 255u];
+            hi.y = lut[w >> 24];
+            __builtin_nontemporal_store(lo.x, &o[2 * d].x);
+            __builtin_nontemporal_store(lo.y, &o[2 * d].y);
+            __builtin_nontemporal_store(hi.x, &o[2 * d + 1].x);
+            __builtin_nontemporal_store(hi.y, &o[2 * d + 1].y);
+            if (mutate) {
+                // a byte is zero <=> (w - 0x01010101) & ~w & 0x80808080 has its top bit set (exact per byte only
+                // below the first zero byte, so build the replacement byte by byte)
+                uint32_t z = 0;
+                if ((w & 0x000000ffu) == 0) z |= 0x00000001u;
+                if ((w & 0x0000ff00u) == 0) z |= 0x00000100u;
+                if ((w & 0x00ff0000u) == 0) z |= 0x00010000u;
+                if ((w & 0xff000000u) == 0) z |= 0x01000000u;
+                if (z) q[d] = w | z;
+            }
+        }
+        done = nd << 2;
+    }
+    for (long i = done + (long)blockIdx.x * AT + threadIdx.x; i < nbytes; i += stride) {
+        const uint32_t v = img[i];
+        od[i] = lut[v];
+        if (mutate && v == 0) img[i] = 1;
+    }
+}
+
 static inline unsigned blocks_x(long work_items, long n_patches) {
     // enough workgroups to fill 256 CUs several times over, but few per patch when the batch is
     // large so the per-block table set-up is amortised.
@@ -571,9 +720,10 @@ static int launch_apply(const uint8_t* d_img, int64_t n, long hw, const tia_stai
                         hipStream_t stream) {
     const long ng = (hw & 3) == 0 ? (hw >> 2) : hw;
     dim3 grid(blocks_x(ng, n), (unsigned)n);
-    if constexpr (MATH == TIA_MATH_F32) {
+    if constexpr (MATH != TIA_MATH_F64_REF) {
+        static const bool no_wide = getenv("TIA_APPLY_NO_WIDE") != nullptr;  // developer switch (A/B measurements)
         const bool aligned = ((reinterpret_cast<uintptr_t>(d_img) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-        if ((hw * 3) % 3072 == 0 && aligned &&
+        if ((hw * 3) % 3072 == 0 && aligned && !(no_wide && MATH == TIA_MATH_F64) &&
             (out_kind == TIA_OUT_U8 || out_kind == TIA_OUT_UNIT_F16 || out_kind == TIA_OUT_UNIT_BF16)) {
             const long nchunks = hw * 3 / 3072;
             long bx = (nchunks + 3) / 4;                       // one step per wave ...
@@ -581,11 +731,11 @@ static int launch_apply(const uint8_t* d_img, int64_t n, long hw, const tia_stai
             if (bx > want) bx = want;
             dim3 wgrid((unsigned)(bx < 1 ? 1 : bx), (unsigned)n);
             if (out_kind == TIA_OUT_U8)
-                hipLaunchKernelGGL((stain_apply_wide_kernel<TIA_OUT_U8>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, out);
+                hipLaunchKernelGGL((stain_apply_wide_kernel<MATH, TIA_OUT_U8>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, tgt, out);
             else if (out_kind == TIA_OUT_UNIT_F16)
-                hipLaunchKernelGGL((stain_apply_wide_kernel<TIA_OUT_UNIT_F16>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, out);
+                hipLaunchKernelGGL((stain_apply_wide_kernel<MATH, TIA_OUT_UNIT_F16>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, tgt, out);
             else
-                hipLaunchKernelGGL((stain_apply_wide_kernel<TIA_OUT_UNIT_BF16>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, out);
+                hipLaunchKernelGGL((stain_apply_wide_kernel<MATH, TIA_OUT_UNIT_BF16>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, tgt, out);
             return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
         }
     }
@@ -623,9 +773,12 @@ extern "C" int tia_stain_apply_u8(const uint8_t* d_img, int64_t n, int64_t h, in
     if (!d_img || !d_tables || !d_stats || !d_out) return TIA_EINVAL;
     if (bad_dims(n, h, w)) return n > 65535 ? TIA_ESIZE : TIA_EINVAL;
     tia::StainT tgt{};
-    if (math == TIA_MATH_F64) {
+    if (math == TIA_MATH_F64 || math == TIA_MATH_F64_REF) {
         if (!h_target_stain) return TIA_EINVAL;
         for (int i = 0; i < 6; ++i) tgt.s[i] = h_target_stain[i];
+        if (math == TIA_MATH_F64_REF)
+            return tia::launch_apply<TIA_MATH_F64_REF>(d_img, n, (long)h * w, d_tables, d_stats, tgt, d_out, out_kind,
+                                                       (hipStream_t)stream);
         return tia::launch_apply<TIA_MATH_F64>(d_img, n, (long)h * w, d_tables, d_stats, tgt, d_out,
                                                out_kind, (hipStream_t)stream);
     }
@@ -689,3 +842,20 @@ extern "C" int tia_luminosity_mask_u8(const uint8_t* d_img, int64_t n, int64_t h
                        d_mask);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
+
+extern "C" int tia_rgb2od_u8(uint8_t* d_img, int64_t nbytes, const tia_stain_tables* d_tables, int32_t mutate,
+                             double* d_od, void* stream) {
+    if (!d_img || !d_tables || !d_od || nbytes <= 0) return TIA_EINVAL;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(d_img) & 3) == 0 && (reinterpret_cast<uintptr_t>(d_od) & 15) == 0) ? 1 : 0;
+    long blocks = (nbytes / 4 + tia::AT - 1) / tia::AT;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(tia::rgb2od_kernel, dim3((unsigned)blocks), dim3(tia::AT), 0, (hipStream_t)stream, d_img, (long)nbytes,
+                       d_tables, mutate, d_od, vec_ok);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+// Clears (and returns) the HIP runtime's sticky last-error value of THIS library's runtime instance -- the one every entry
+// point's `hipGetLastError() == hipSuccess` check reads.  A host-side call that was refused on purpose (hipHostRegister of
+// memory that is already pinned) must not turn the next launch into a spurious TIA_ELAUNCH.
+extern "C" int tia_clear_last_error(void) { return (int)hipGetLastError(); }

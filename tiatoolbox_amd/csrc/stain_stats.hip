@@ -2963,13 +2963,12 @@ extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, in
                         ws_bytes >= tia_stain_stats_workspace_bytes_mode(n, h, w, params->mode);
     if (reg_ok) {
         int* redo = (int*)((char*)d_ws + align256s(tia_stain_stats_workspace_bytes(n, h, w)));
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tia::stain_stats_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)sizeof(tia::SmemR)) != hipSuccess)
-                return TIA_ELAUNCH;
-            attr_set = true;
-        }
+        static tia::DeviceOnce attr_once;  // the dynamic-LDS attribute is per device
+        if (!attr_once.ensure([] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&tia::stain_stats_reg_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(tia::SmemR)) == hipSuccess;
+            }))
+            return TIA_ELAUNCH;
         if (hipMemsetAsync(redo, 0, (size_t)n * sizeof(int), st) != hipSuccess) return TIA_ELAUNCH;
         hipLaunchKernelGGL(tia::stain_stats_reg_kernel, dim3((unsigned)n), dim3(tia::RT), sizeof(tia::SmemR), st, d_img, hw, d_tables,
                            *params, d_stats, redo);

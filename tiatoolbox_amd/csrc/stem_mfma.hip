@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include "../../include/tiatoolbox_amd.h"
+#include "common.hpp"
 
 namespace {
 
@@ -408,15 +409,16 @@ static int stem_impl(const void* d_x, int32_t x_is_u8, const void* d_w_packed, c
     const Kernel kernels[3][2] = {{stem7x7_pool_kernel<false, 0>, stem7x7_pool_kernel<true, 0>},
                                   {stem7x7_pool_kernel<false, 1>, stem7x7_pool_kernel<true, 1>},
                                   {stem7x7_pool_kernel<false, 2>, stem7x7_pool_kernel<true, 2>}};
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (int m = 0; m < 3; ++m)
-            for (int u = 0; u < 2; ++u)
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[m][u]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        m == 0 ? (int)(LDS_FLOATS * sizeof(float)) : LDS_BYTES_H) != hipSuccess)
-                    return TIA_ELAUNCH;
-        attr_set = true;
-    }
+    static tia::DeviceOnce attr_once;  // the dynamic-LDS attribute is per device
+    if (!attr_once.ensure([&] {
+            for (int m = 0; m < 3; ++m)
+                for (int u = 0; u < 2; ++u)
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[m][u]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            m == 0 ? (int)(LDS_FLOATS * sizeof(float)) : LDS_BYTES_H) != hipSuccess)
+                        return false;
+            return true;
+        }))
+        return TIA_ELAUNCH;
     const int mi = mma == TIA_DT_F16 ? 1 : (mma == TIA_DT_BF16 ? 2 : 0);
     const size_t lds = mi == 0 ? (size_t)LDS_FLOATS * sizeof(float) : (size_t)LDS_BYTES_H;
     hipStream_t st = (hipStream_t)stream;

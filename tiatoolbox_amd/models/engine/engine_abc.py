@@ -30,13 +30,16 @@ _DTYPES = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch
            "fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
 
 
-def _clear_last_hip_error() -> None:
-    """Reset the sticky last-error of the HIP runtime torch itself uses (a bare ``CDLL("libamdhip64.so")`` could load a
-    second runtime whose thread-local error is not the one that was set)."""
-    try:
-        torch.cuda.cudart().cudaGetLastError()
-    except Exception:  # noqa: BLE001  (no HIP runtime: nothing to clear)
-        pass
+def _clear_last_hip_error() -> int:
+    """Read-and-clear the HIP runtime's sticky last-error through the product library itself (``tia_clear_last_error``):
+    it links the runtime instance whose ``hipGetLastError()`` every ``tia_*`` entry point checks after its launches
+    (``torch.cuda.cudart()`` does not expose ``cudaGetLastError``).  Returns the value that was pending."""
+    from tiatoolbox_amd import _lib
+
+    return int(_lib.load().tia_clear_last_error())
+
+
+_WARNED_NO_PIN = False
 
 
 class _HostFeed:
@@ -63,6 +66,11 @@ class _HostFeed:
                 # a refused registration (mmap'd / already registered memory) leaves the runtime's sticky last-error
                 # set; clear it so the next launch check (tia_* entry points return hipGetLastError()) is not blamed
                 _clear_last_hip_error()
+                global _WARNED_NO_PIN  # noqa: PLW0603
+                if not _WARNED_NO_PIN:
+                    _WARNED_NO_PIN = True
+                    logger.warning("hipHostRegister refused the input array (%d bytes): host patches are copied synchronously, "
+                                   "batch by batch, instead of one batch ahead on the copy stream.", array.nbytes)
 
     def prefetch(self, lo: int, hi: int) -> None:
         if not self.registered or (lo, hi) in self._pending or lo >= hi:
@@ -97,22 +105,52 @@ def _weights_version(model: torch.nn.Module) -> tuple:
     return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))  # noqa: SLF001
 
 
-def prepare_engines_save_dir(save_dir, *, patch_mode: bool, overwrite: bool = False) -> Path | None:
-    """Create or validate the output directory exactly like the reference (``engine_abc.py:1832-1885``): WSI mode without
-    ``save_dir`` is an ``OSError``; an existing directory is removed first when ``overwrite`` and is a ``FileExistsError``
-    otherwise (``mkdir(parents=True)``)."""
+def _make_save_dir(save_dir: Path, overwrite: bool) -> None:
     import shutil
 
+    if save_dir.exists() and overwrite:
+        shutil.rmtree(save_dir)
+    save_dir.mkdir(parents=True)
+
+
+def prepare_engines_save_dir(save_dir, *, patch_mode: bool, overwrite: bool = False, distributed: bool = False) -> Path | None:
+    """Create or validate the output directory exactly like the reference (``engine_abc.py:1832-1885``): WSI mode without
+    ``save_dir`` is an ``OSError``; an existing directory is removed first when ``overwrite`` and is a ``FileExistsError``
+    otherwise (``mkdir(parents=True)``).
+
+    ``distributed`` (one process per GPU, every rank calls ``run()``): rank 0 alone removes / creates the directory and
+    broadcasts the outcome, so that the other ranks neither trip over the directory rank 0 has just made nor remove it,
+    and a refusal (``FileExistsError``, permissions) is raised by EVERY rank instead of leaving the others waiting in the
+    run's first collective."""
     if patch_mode and save_dir is None:
         return None
     if save_dir is None:
         msg = "Input WSIs detected but no save directory provided. Please provide a 'save_dir'."
         raise OSError(msg)
     save_dir = Path(save_dir)
-    if save_dir.exists() and overwrite:
-        shutil.rmtree(save_dir)
-    save_dir.mkdir(parents=True)
+    rank, world_size = tdist.world() if distributed else (0, 1)
+    if world_size == 1:
+        _make_save_dir(save_dir, overwrite)
+        return save_dir
+    outcome: list = [None]
+    if rank == 0:
+        try:
+            _make_save_dir(save_dir, overwrite)
+        except OSError as exc:  # FileExistsError, PermissionError, ...
+            outcome[0] = (type(exc).__name__, exc.errno, str(exc))
+    torch.distributed.broadcast_object_list(outcome, src=0)
+    if outcome[0] is not None:
+        name, errno_, text = outcome[0]
+        cls = {"FileExistsError": FileExistsError, "PermissionError": PermissionError,
+               "NotADirectoryError": NotADirectoryError}.get(name, OSError)
+        raise cls(errno_, text) if errno_ is not None else cls(text)
     return save_dir
+
+
+def outputs_written(distributed: bool) -> None:
+    """Rank 0 writes a WSI run's files; the paths ``run()`` returns must exist on every rank when it returns."""
+    if distributed and tdist.is_distributed():
+        torch.distributed.barrier()
 
 
 def iter_row_outputs(infer, row_sels: list[np.ndarray], batch_size: int):
@@ -400,8 +438,19 @@ class EngineABC:
         return hook.device_batch(batch, dtype)
 
     def _set_defer_unit(self, model, dtype: torch.dtype) -> None:  # noqa: ARG002
-        self._defer_unit = bool(torch.device(self.device).type == "cuda"
-                                and any(getattr(m, "accepts_uint8", False) for m in model.modules()))
+        """``ToTensor`` may be deferred into the stem kernel only for the stock classifiers: the inference copy is EXACTLY a
+        ``CNNModel`` / ``CNNBackbone`` (not a subclass with its own ``forward`` / ``infer_batch``, whose pre-processing inside
+        the model would then see raw bytes) whose trunk is the uint8-reading :class:`MfmaResNet`.  Segmentation models (``FusedUNet``
+        reads uint8 through its own ``infer_batch``) never take this path: their ``infer_batch`` also crops and soft-maxes."""
+        from tiatoolbox_amd.models.architecture.vanilla import CNNBackbone, CNNModel
+
+        stock = type(model) in (CNNModel, CNNBackbone) and type(self.model) in (CNNModel, CNNBackbone)
+        if stock:
+            own = type(self.model).__dict__.get("infer_batch")
+            bound = getattr(self.model, "infer_batch", None)
+            stock = own is not None and getattr(own, "__func__", own) is getattr(bound, "__func__", bound)
+        self._defer_unit = bool(torch.device(self.device).type == "cuda" and stock
+                                and getattr(getattr(model, "feat_extract", None), "accepts_uint8", False))
 
     def _forward_batch(self, model, infer_batch, batch):
         from tiatoolbox_amd.models.dataset.classification import UnitUInt8
@@ -651,7 +700,8 @@ class EngineABC:
         """Per slide: tissue mask -> patch grid -> ``infer_wsi`` -> ``post_process_patches`` -> ``<stem>.npz`` under
         ``save_dir`` (ref. ``_run_wsi_mode`` :1540-1682; arrays ``predictions``, ``coordinates`` and, on request,
         ``probabilities`` -- the members of the reference's zarr store).  Returns ``{image key: Path}``."""
-        save_dir = prepare_engines_save_dir(save_dir, patch_mode=False, overwrite=bool(kwargs.pop("overwrite", False)))
+        save_dir = prepare_engines_save_dir(save_dir, patch_mode=False, overwrite=bool(kwargs.pop("overwrite", False)),
+                                            distributed=self.distributed)
         out: dict = {}
         images = self.images if isinstance(self.images, (list, tuple)) else [self.images]
         for num, image in enumerate(images):
@@ -672,6 +722,7 @@ class EngineABC:
             if tdist.world()[0] == 0 or not self.distributed:
                 np.savez(path, **arrays)
             out[key] = path
+        outputs_written(self.distributed)
         return out
 
     def run(self, images, *, masks=None, input_resolutions=None, patch_input_shape=None, ioconfig=None,

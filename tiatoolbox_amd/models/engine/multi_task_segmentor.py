@@ -599,9 +599,9 @@ class MultiTaskSegmentor(EngineABC):
         from pathlib import Path
 
         from tiatoolbox_amd import distributed as tdist
-        from tiatoolbox_amd.models.engine.engine_abc import prepare_engines_save_dir
+        from tiatoolbox_amd.models.engine.engine_abc import outputs_written, prepare_engines_save_dir
 
-        save_dir = prepare_engines_save_dir(save_dir, patch_mode=False, overwrite=overwrite)
+        save_dir = prepare_engines_save_dir(save_dir, patch_mode=False, overwrite=overwrite, distributed=self.distributed)
         write = tdist.world()[0] == 0 or not self.distributed
         paths: dict = {}
         for i, image in enumerate(self.images):
@@ -621,6 +621,7 @@ class MultiTaskSegmentor(EngineABC):
                     else:
                         flat[name] = np.asarray(val)
                 np.savez(paths[key], **flat)
+        outputs_written(self.distributed)
         return paths
 
     def process_wsi(self, image, mask=None, *, return_predictions=None, auto_get_mask: bool = True) -> dict:

@@ -1,9 +1,9 @@
 """``rgb2od`` / ``od2rgb`` (API of reference ``tiatoolbox/utils/transforms.py:209-256``).
 
-Inside the kernels the OD conversion is a 256-entry table look-up fused with whatever
-consumes it; these stand-alone functions exist for API compatibility.  Unlike the
-reference, ``rgb2od`` does **not** write into its argument (the reference replaces zeros
-by ones in place, ``transforms.py:229-230``).
+Inside the stain kernels the OD conversion is a 256-entry table look-up fused with whatever
+consumes it; the stand-alone ``rgb2od`` is ``tia_rgb2od_u8`` (same table, one streaming launch).
+Like the reference (``transforms.py:229-230``) it replaces zeros by ones **in its argument**:
+a writable NumPy array or a CUDA tensor is edited in place (``mutate=False`` switches that off).
 """
 
 from __future__ import annotations
@@ -11,14 +11,43 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from tiatoolbox_amd.utils import _tensors, cvtables
+from tiatoolbox_amd import _lib
+from tiatoolbox_amd.utils import _tensors
 
 
-def rgb2od(img):
-    """``max(-log(max(img,1)/255), 1e-6)`` as float64, same container kind as ``img``."""
-    batch, kind = _tensors.to_device_batch(img)
-    lut = torch.from_numpy(cvtables.od_lut()).to(batch.device)
-    return _tensors.from_device(lut[batch.long()], kind)
+def rgb2od(img, *, mutate: bool = True):
+    """``max(-log(max(img,1)/255), 1e-6)`` as float64, any shape, same container kind as ``img``.
+
+    Side effect as in the reference: ``img[img == 0] = 1`` (uint8 NumPy arrays that are writable, and
+    uint8 CUDA tensors; other inputs are converted to a uint8 copy first, like ``np.asarray(..., uint8)``).
+    """
+    from tiatoolbox_amd.tools import _stain_device as dev
+
+    is_tensor = isinstance(img, torch.Tensor)
+    if is_tensor:
+        src = img if img.is_cuda else img.to(_tensors.default_device())
+        if src.dtype != torch.uint8:
+            src = src.to(torch.uint8)
+        same_storage = src is img and img.is_contiguous()
+        dev_img = src.contiguous()
+    else:
+        arr = np.asarray(img)
+        same_storage = False
+        dev_img = torch.from_numpy(np.ascontiguousarray(arr.astype(np.uint8, copy=False))).to(_tensors.default_device())
+    out = torch.empty(dev_img.shape, dtype=torch.float64, device=dev_img.device)
+    if dev_img.numel():
+        lib = _lib.load()
+        with torch.cuda.device(dev_img.device):
+            rc = lib.tia_rgb2od_u8(dev_img.data_ptr(), dev_img.numel(), dev.tables(dev_img.device).data_ptr(),
+                                   int(bool(mutate)), out.data_ptr(), _lib.current_stream())
+        _lib.check(rc, "tia_rgb2od_u8")
+    if mutate:
+        if is_tensor:
+            if not same_storage and img.dtype == torch.uint8:
+                img.copy_(dev_img)          # host tensor / non-contiguous view: hand the edit back
+        elif isinstance(img, np.ndarray) and img.dtype == np.uint8 and img.flags.writeable:
+            np.copyto(img, dev_img.cpu().numpy())
+    return out if is_tensor else out.cpu().numpy()
 
 
 def od2rgb(od: np.ndarray) -> np.ndarray:
