@@ -280,6 +280,32 @@ def self_spawn(args: argparse.Namespace) -> None:
     os.execvp(sys.executable, cmd)  # noqa: S606
 
 
+def verify_ranks(args: argparse.Namespace, world_size: int, local_rank: int) -> None:
+    """Fail loudly instead of reporting an N-GPU number that was not measured on N GPUs: the process group must have
+    ``--gpus`` ranks, and no two ranks may sit on the same device (same host + device index, or same device UUID)."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {world_size} rank(s)")
+    if world_size == 1:
+        return
+    if not dist.is_initialized() or dist.get_world_size() != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: torch.distributed is not initialised with that many ranks")
+    if dist.get_backend() != "nccl":
+        raise SystemExit(f"--gpus {args.gpus}: backend {dist.get_backend()!r}, expected 'nccl' (RCCL)")
+    if torch.cuda.device_count() < 1 or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank with LOCAL_RANK={local_rank} sees {torch.cuda.device_count()} device(s)")
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    mine = (socket.gethostname(), torch.cuda.current_device(), str(getattr(props, "uuid", "")))
+    seen: list = [None] * world_size
+    dist.all_gather_object(seen, mine)
+    if len({(h, d) for h, d, _ in seen}) != world_size or (all(u for _, _, u in seen) and len({u for _, _, u in seen}) != world_size):
+        raise SystemExit(f"--gpus {args.gpus}: ranks share a device: {seen}")
+
+
 def bench_patch(args: argparse.Namespace) -> dict | None:
     import logging
 
@@ -296,6 +322,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
     rank, world_size, local_rank = tdist.init_from_env()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    verify_ranks(args, world_size, local_rank)
     logging.getLogger("tiatoolbox_amd").setLevel(logging.ERROR)
     n, hw = args.patches, args.patch_size
     target = np.load(ROOT / "tests" / "golden" / "target_crop_256.npy")

@@ -36,6 +36,9 @@ def _setup(args):
 
     rank, world_size, local_rank = tdist.init_from_env()
     torch.cuda.set_device(local_rank)
+    import bench
+
+    bench.verify_ranks(args, world_size, local_rank)
     logging.getLogger("tiatoolbox_amd").setLevel(logging.ERROR)
     return rank, world_size, torch.device("cuda", local_rank)
 

@@ -298,3 +298,73 @@ def test_wsi_save_dir_is_prepared_by_rank_zero_only(tmp_path, world):
     port = 29900 + (os.getpid() % 150) + world
     mp.spawn(_save_dir_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+# ------------------------------------------------------------------ several tasks per patch across ranks (HoVerNet+-like)
+class _CpuTwoTaskNet(_CpuInstanceNet):
+    """Nuclei table + a 'layer' table with DIFFERENT columns (no centroid / prob), like ``HoVerNetPlus.postproc``."""
+
+    tasks = ("nuclei_segmentation", "layer_segmentation")
+
+    def postproc(self, raw_maps, offset=(0, 0)):
+        nuclei = super().postproc(raw_maps, offset)[0]
+        npm = np.asarray(raw_maps[0])[..., 0]
+        layer = (npm > 0.5).astype(np.uint8) + (npm > 0.9).astype(np.uint8)
+        classes = [int(c) for c in np.unique(layer) if c]
+        table = {"box": np.array([[0, 0, 48, 48]] * len(classes)).reshape(-1, 4),
+                 "contours": [np.argwhere(layer == c)[:5].astype(np.int32) for c in classes],
+                 "type": np.array(classes, dtype=np.uint8)}
+        return nuclei, {"task_type": self.tasks[1], "predictions": layer, "info_dict": table, "seg_type": "semantic"}
+
+
+def _run_two_task_engine():
+    from tiatoolbox_amd.models.engine.io_config import IOInstanceSegmentorConfig
+    from tiatoolbox_amd.models.engine.multi_task_segmentor import MultiTaskSegmentor
+
+    res = {"units": "baseline", "resolution": 1.0}
+    cfg = IOInstanceSegmentorConfig(input_resolutions=[res], output_resolutions=[res, res, res], patch_input_shape=[64, 64],
+                                    patch_output_shape=[48, 48], stride_shape=[48, 48], margin=8, tile_shape=[96, 96])
+    eng = MultiTaskSegmentor(_CpuTwoTaskNet(), batch_size=2, device="cpu")
+    return eng.run(_instance_patches(), patch_mode=True, ioconfig=cfg, return_probabilities=True)
+
+
+def _two_task_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import pickle
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    tdist.init_from_env("gloo")
+    out = _run_two_task_engine()
+    with open(os.path.join(out_dir, f"two{rank}.pkl"), "wb") as fh:
+        pickle.dump(out, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_multi_task_tables_gathered_across_ranks(tmp_path, world):
+    """Patch-sharded run of a model with SEVERAL tasks (the reference's multi-head path, ``multi_task_segmentor.py:1556-1730``):
+    one sub-dict per task, every task's label maps and columns in input order on every rank -- 2 ranks (3 + 2 patches) and
+    8 ranks (three of them without a patch)."""
+    import pickle
+
+    port = 29700 + (os.getpid() % 150) + 5 * world
+    mp.spawn(_two_task_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    single = _run_two_task_engine()
+    assert set(single) == {"nuclei_segmentation", "layer_segmentation", "probabilities"}
+    for rank in range(world):
+        with open(tmp_path / f"two{rank}.pkl", "rb") as fh:
+            got = pickle.load(fh)  # noqa: S301
+        assert set(got) == set(single)
+        for task in ("nuclei_segmentation", "layer_segmentation"):
+            a, b = got[task], single[task]
+            assert set(a) == set(b) and a["seg_type"] == b["seg_type"]
+            assert np.array_equal(a["predictions"], b["predictions"])
+            for key in set(a) - {"predictions", "seg_type"}:
+                assert len(a[key]) == len(b[key]) == 5
+                for ra, rb in zip(a[key], b[key]):
+                    if key == "contours":
+                        assert len(ra) == len(rb) and all(np.array_equal(x, y) for x, y in zip(ra, rb))
+                    else:
+                        assert np.array_equal(np.asarray(ra, dtype=object), np.asarray(rb, dtype=object))
+        for ha, hb in zip(got["probabilities"], single["probabilities"]):
+            assert np.array_equal(ha, hb)

@@ -92,6 +92,20 @@ def all_gather_ragged(local: torch.Tensor) -> tuple[torch.Tensor, list[int]]:
     return torch.cat(parts), lens_h
 
 
+def all_gather_objects(obj) -> list:
+    """One picklable host object per rank, returned in rank order on every rank (``[obj]`` when not distributed).
+
+    For the small, irregular host-side records of multi-task post-processing (HoVerNet+: nuclei table + layer table per
+    patch / tile, with different columns per task); on the ``nccl`` backend the pickled bytes travel through RCCL as byte
+    tensors on the current device.  The single-task hot path uses the packed numeric gather below instead."""
+    if not is_distributed():
+        return [obj]
+    _, world_size = world()
+    out: list = [None] * world_size
+    dist.all_gather_object(out, obj)
+    return out
+
+
 _TABLE_KEYS = ("box", "centroid", "contours", "prob", "type")
 
 

@@ -2,8 +2,11 @@
 
 Only the entries of the benchmark configs are registered.  Pretrained weights live on the
 HuggingFace hub (``TIACentre/TIAToolbox_pretrained_weights``), unreachable from here: pass a
-local ``.pth`` via ``weights=``; otherwise the model keeps its seeded random initialisation
-and a warning is logged.  Parameter names match the reference so its files load unchanged.
+local ``.pth`` via ``weights=``, or keep ``<name>.pth`` where the reference caches its
+downloads -- ``$TIA_WEIGHTS_DIR``, ``$TIATOOLBOX_HOME/models`` or ``~/.tiatoolbox/models``
+(``fetch_pretrained_weights``, ref. :27-68); otherwise the model keeps its seeded random
+initialisation and a warning is logged.  Parameter names match the reference so its files
+load unchanged.
 """
 
 from __future__ import annotations
@@ -82,6 +85,24 @@ PRETRAINED_INFO = {
 }
 
 
+def local_pretrained_weights(model_name: str) -> Path | None:
+    """``<model_name>.pth`` in the first existing of ``$TIA_WEIGHTS_DIR``, ``$TIATOOLBOX_HOME/models``,
+    ``~/.tiatoolbox/models`` (the reference's download cache, ``architecture/__init__.py:57-68``); ``None`` if absent."""
+    import os
+
+    roots = []
+    if os.environ.get("TIA_WEIGHTS_DIR"):
+        roots.append(Path(os.environ["TIA_WEIGHTS_DIR"]))
+    if os.environ.get("TIATOOLBOX_HOME"):
+        roots.append(Path(os.environ["TIATOOLBOX_HOME"]) / "models")
+    roots.append(Path.home() / ".tiatoolbox" / "models")
+    for root in roots:
+        cand = root / f"{model_name}.pth"
+        if cand.is_file():
+            return cand
+    return None
+
+
 def _create(arch: str, kwargs: dict):
     mod_name, cls_name = arch.split(".")
     import importlib
@@ -121,6 +142,8 @@ def get_pretrained_model(pretrained_model: str | None = None, pretrained_weights
         torch.random.set_rng_state(gen_state)
     if info.get("dataset"):
         model.preproc_func = predefined_preproc_func(info["dataset"])
+    if pretrained_weights is None:
+        pretrained_weights = local_pretrained_weights(pretrained_model)
     if pretrained_weights is not None:
         model.load_weights_from_file(pretrained_weights)
     else:

@@ -496,9 +496,24 @@ class MultiTaskSegmentor(EngineABC):
         model = self.model.module if hasattr(self.model, "module") else self.model
         task_type = model.tasks[0]
         mine = owned[rank]
-        if any(len(results[i]) != 1 for i in mine):
-            msg = "Tile sharding across processes supports single-task models."
-            raise NotImplementedError(msg)
+        if any(len(results[i]) != 1 for i in mine) or len(getattr(model, "tasks", ())) > 1:
+            # several tasks per tile (HoVerNet+: nuclei + layers, different columns per task): the tiles' host records are
+            # exchanged as objects, one gather for the whole slide (ref. :1556-1730 keeps one sub-table per task)
+            payload = {}
+            for i in mine:
+                payload[i] = tuple({k: (v if (k != "predictions" or want_predictions) else None) for k, v in task.items()}
+                                   for task in results[i])
+            out: list = [None] * len(results)
+            for part in tdist.all_gather_objects(payload):
+                for i, tasks_ in part.items():
+                    fixed = []
+                    for task in tasks_:
+                        task = dict(task)
+                        if task.get("predictions") is None:  # not requested: the merge below never reads it
+                            task["predictions"] = np.zeros((0, 0), np.int32)
+                        fixed.append(task)
+                    out[i] = tuple(fixed)
+            return out
         tables = tdist.gather_instance_tables([results[i][0]["info_dict"] for i in mine], device)
         order = [i for tiles in owned for i in tiles]
         preds: dict[int, np.ndarray] = {}
@@ -522,15 +537,11 @@ class MultiTaskSegmentor(EngineABC):
         """Several tasks per patch (HoVerNet+: nuclei + layers): the model's ``postproc`` per patch on device-resident
         heads; every task gets its own sub-dict ``{predictions, <info columns>}`` (ref. :1556-1685, :1706-1730)."""
         heads = raw_predictions["probabilities"]
-        if "shard" in raw_predictions:
-            msg = "patch-sharded runs of multi-task models are not supported; run one process."
-            raise NotImplementedError(msg)
         n = heads[0].shape[0]
         per_task: dict[str, list[dict]] = {}
         for i in range(n):
             for task in model.postproc([h[i] for h in heads], offset=(0, 0)):
                 per_task.setdefault(task["task_type"], []).append(task)
-        self.tasks = set(per_task) or set(model.tasks)
         out: dict = {}
         for name, items in per_task.items():
             preds = [t["predictions"] for t in items]
@@ -539,6 +550,27 @@ class MultiTaskSegmentor(EngineABC):
             for key in items[0]["info_dict"]:
                 sub[key] = [t["info_dict"][key] for t in items]
             out[name] = sub
+        if "shard" in raw_predictions:
+            # patch-sharded run: every rank post-processed its contiguous shard; the per-task label maps and tables (host
+            # records, different columns per task) are gathered in rank order = input order; empty shards contribute nothing
+            from tiatoolbox_amd import distributed as tdist
+
+            parts = tdist.all_gather_objects(out)
+            names = [name for part in parts for name in part]
+            merged: dict = {}
+            for name in dict.fromkeys(names):
+                have = [part[name] for part in parts if name in part]
+                sub = {"predictions": np.concatenate([h["predictions"] for h in have]), "seg_type": have[0]["seg_type"]}
+                for key in have[0]:
+                    if key not in ("predictions", "seg_type"):
+                        sub[key] = [row for h in have for row in h[key]]
+                merged[name] = sub
+            out = merged
+            if self.return_probabilities:
+                _, _, n_total = raw_predictions["shard"]
+                heads = [tdist.all_gather_rows(h if isinstance(h, torch.Tensor) else torch.from_numpy(np.asarray(h)), n_total)
+                         for h in heads]
+        self.tasks = set(out) or set(model.tasks)
         if self.return_probabilities:
             out["probabilities"] = [h.cpu().numpy() if isinstance(h, torch.Tensor) else h for h in heads]
         return out
