@@ -528,3 +528,43 @@ def test_deferred_totensor_only_for_stock_classifiers():
     eng = types.SimpleNamespace(device="cpu", model=stock)
     EngineABC._set_defer_unit(eng, stock, torch.float32)  # noqa: SLF001
     assert eng._defer_unit is False  # noqa: SLF001
+
+
+@pytest.mark.gpu
+def test_gpu_logits_match_cpu_fp32_with_spread_predictions():
+    """Logits-level parity on a model whose outputs are NOT degenerate: seeded random weights with randomised BatchNorm
+    statistics and a classifier re-scaled until the CPU predictions cover several classes (an untrained network puts every
+    patch in one class, which makes a 1e-4 comparison of softmax outputs weaker than it looks).  Compared: log-probabilities
+    (= logits up to the per-patch log-sum-exp), relative to the logit spread, on 224^2 and 256^2 patches; arg-max identical."""
+    results = {}
+    for side in (224, 256):
+        patches = synth.g_he(12, side, side, seed=side)
+        cpu_eng = PatchPredictor("resnet18-kather100k", batch_size=6)
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for m in cpu_eng.model.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.2)
+                    m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                    m.weight.copy_(1.0 + 0.3 * torch.randn(m.weight.shape, generator=g))
+                    m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+            feats = cpu_eng.model.pool(cpu_eng.model.feat_extract(
+                torch.from_numpy(patches).float().div(255).permute(0, 3, 1, 2))).flatten(1)
+            feats = feats - feats.mean(0, keepdim=True)
+            # classifier rows = directions that separate the patches: logits spread over several units
+            w = torch.linalg.svd(feats, full_matrices=False)[2][:9]
+            cpu_eng.model.classifier.weight.copy_(w * (4.0 / (feats @ w.T).abs().max()))
+            cpu_eng.model.classifier.bias.zero_()
+        kw = {"patch_mode": True, "return_probabilities": True, "patch_input_shape": (side, side)}
+        cpu = cpu_eng.run(patches, **kw)
+        assert len(set(np.asarray(cpu["predictions"]).tolist())) >= 3, "the construction must spread the predictions"
+        gpu_eng = PatchPredictor("resnet18-kather100k", batch_size=4, device="cuda")
+        gpu_eng.model.load_state_dict(cpu_eng.model.state_dict())
+        gpu = gpu_eng.run(patches, **kw)
+        lp_c, lp_g = np.log(np.maximum(cpu["probabilities"], 1e-30)), np.log(np.maximum(gpu["probabilities"], 1e-30))
+        spread = float(lp_c.max() - lp_c.min())
+        err = float(np.abs(lp_c - lp_g).max())
+        results[side] = (err, spread)
+        assert err <= 1e-4 * max(spread, 1.0), (side, err, spread)
+        assert np.array_equal(gpu["predictions"], cpu["predictions"])
+    print("log-probability error / spread:", results)
