@@ -568,3 +568,28 @@ def test_gpu_logits_match_cpu_fp32_with_spread_predictions():
         assert err <= 1e-4 * max(spread, 1.0), (side, err, spread)
         assert np.array_equal(gpu["predictions"], cpu["predictions"])
     print("log-probability error / spread:", results)
+
+
+@pytest.mark.gpu
+def test_chunked_prenormalisation_equals_per_batch(target_image):
+    """Device-resident patch lists are stain-normalised in chunks of ``stain_chunk`` patches (one statistics launch per chunk)
+    instead of per CNN micro-batch: per-patch statistics are independent, so the probabilities must be bit-identical to the
+    per-micro-batch path (host NumPy input) for chunk sizes that divide the run evenly, raggedly, and not at all."""
+    from tiatoolbox_amd.tools.stainnorm import get_normalizer
+
+    patches = synth.g_he(11, 224, 224, seed=12)
+    norm = get_normalizer("macenko")
+    norm.fit(target_image)
+    eng = PatchPredictor("resnet18-kather100k", batch_size=4, device="cuda")
+    kw = {"patch_mode": True, "return_probabilities": True, "stain_normalizer": norm}
+    host = eng.run(patches, **kw)["probabilities"]
+    dev = torch.from_numpy(patches).cuda()
+    for chunk in (4096, 8, 4, 3, 5):
+        eng.stain_chunk = chunk
+        got = eng.run(dev, **kw)["probabilities"]
+        assert np.array_equal(got, host), chunk
+    white = dev.clone()
+    white[9] = 255
+    eng.stain_chunk = 8
+    with pytest.raises(ValueError, match="Empty tissue mask"):   # flags raised once per run, also from the second chunk
+        eng.run(white, **kw)

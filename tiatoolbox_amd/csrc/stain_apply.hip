@@ -129,6 +129,17 @@ __device__ __forceinline__ void store12(T* __restrict__ dst, const Pack12<T>& pk
     }
 }
 
+// Wave-private LDS exchange point: every lane's LDS stores before it are visible to every lane's LDS loads after it.
+// The fences are what tells the COMPILER: a lane never reads back an address it wrote itself in these transposes (the data
+// comes from other lanes), so in-thread alias analysis alone would let it hoist the loads out of the loop / above the stores
+// (seen: one of the three read-backs became loop-invariant).  Wavefront scope: no cache maintenance, no extra waits (LDS
+// operations of a wave execute in order).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- stain apply ---------------------------------------------------------------------------------
 template <int MATH>
 struct ApplyCtx;
@@ -195,15 +206,16 @@ struct ApplyCtxFast {
         const double x = lut[r], y = lut[g], z = lut[b];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const double a = __builtin_fma(z, m[6 + c], __builtin_fma(y, m[3 + c], x * m[c]));
+            // exp(-t) >= 1 <=> a >= 0: clipping a at 0 IS the reference's `trans[trans > 255] = 255` (n = 0, r = 0 gives
+            // T[0] = 255 exactly), one v_min_f64 on a canonical operand instead of a min on the bit-assembled result
+            const double a = __builtin_fmin(__builtin_fma(z, m[6 + c], __builtin_fma(y, m[3 + c], x * m[c])), 0.0);
             const double big = a + kMagic;
             const int lo = __double2loint(big);
             const double rr = a - (big - kMagic);
             const double q = __builtin_fma(rr, __builtin_fma(rr, 0x1.c6b08d704a0bfp-35, 0x1.ebfbdff82c58ep-23), 0x1.62e42fefa39efp-11);
             const double t = etab[lo & 1023];
-            double v = __builtin_fma(t, rr * q, t);
-            v = __hiloint2double(__double2hiint(v) + ((lo >> 10) << 20), __double2loint(v));
-            o[c] = __builtin_fmin(v, 255.0);  // trans[trans > 255] = 255 (the value is positive by construction)
+            const double v = __builtin_fma(t, rr * q, t);
+            o[c] = __hiloint2double(__double2hiint(v) + ((lo >> 10) << 20), __double2loint(v));
         }
     }
     // m = M * (-1024 / ln 2); returns whether the exponent arithmetic is safe for every byte value
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(AT) void stain_apply_kernel(const uint8_t* __restri
 // 12-byte loads / 8-byte stores plateau at ~4.4 TB/s on MI355X; 16-byte accesses are what the
 // memory path is built for (MI355X_MICROARCH.md: 8-B accesses run at 0.54-0.70x the 16-B rate).
 template <int OUT, class Ctx, class F>
-__device__ __forceinline__ void sweep_wide(const Ctx& ctx, uint8_t* __restrict__ mine, const uint8_t* __restrict__ src,
+__device__ __forceinline__ void sweep_wide(const Ctx& ctx, uint8_t* mine, const uint8_t* __restrict__ src,
                                            uint8_t* __restrict__ dst, long hw) {
     using O = Out<OUT>;
     using T = typename O::T;
@@ -359,8 +371,7 @@ __device__ __forceinline__ void sweep_wide(const Ctx& ctx, uint8_t* __restrict__
         for (int k = 0; k < 3; ++k) in[k] = __builtin_nontemporal_load(gsrc + k * 64 + lane);
 #pragma unroll
         for (int k = 0; k < 3; ++k) *reinterpret_cast<v4*>(mine + k * 1024 + lane * 16) = in[k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         uint32_t w[12];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -370,7 +381,7 @@ __device__ __forceinline__ void sweep_wide(const Ctx& ctx, uint8_t* __restrict__
             w[j * 4 + 2] = t.z;
             w[j * 4 + 3] = t.w;
         }
-        __builtin_amdgcn_wave_barrier();  // everyone has read its pixels before the region is reused
+        wave_lds_sync();  // everyone has read its pixels before the region is reused
         alignas(16) T res[48];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {  // four groups of 4 pixels (12 bytes = 3 dwords each)
@@ -388,15 +399,14 @@ __device__ __forceinline__ void sweep_wide(const Ctx& ctx, uint8_t* __restrict__
         const v4* rv = reinterpret_cast<const v4*>(res);
 #pragma unroll
         for (int j = 0; j < 3 * TS; ++j) *reinterpret_cast<v4*>(mine + lane * 48 * TS + j * 16) = rv[j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         v4* gdst = reinterpret_cast<v4*>(dst + c * CHUNK * TS);
 #pragma unroll
         for (int k = 0; k < 3 * TS; ++k) {
             const v4 t = *reinterpret_cast<const v4*>(mine + k * 1024 + lane * 16);
             __builtin_nontemporal_store(t, gdst + k * 64 + lane);
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
     }
 }
 
@@ -515,8 +525,7 @@ __global__ __launch_bounds__(AT) void stain_augment_wide_kernel(const uint8_t* _
         for (int k = 0; k < 3; ++k) in[k] = __builtin_nontemporal_load(gsrc + k * 64 + lane);
 #pragma unroll
         for (int k = 0; k < 3; ++k) *reinterpret_cast<v4*>(mine + k * 1024 + lane * 16) = in[k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         uint32_t w[12];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(AT) void stain_augment_wide_kernel(const uint8_t* _
             w[j * 4 + 2] = t.z;
             w[j * 4 + 3] = t.w;
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         alignas(16) uint8_t res[48];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -544,15 +553,14 @@ __global__ __launch_bounds__(AT) void stain_augment_wide_kernel(const uint8_t* _
         const v4* rv = reinterpret_cast<const v4*>(res);
 #pragma unroll
         for (int j = 0; j < 3; ++j) *reinterpret_cast<v4*>(mine + lane * 48 + j * 16) = rv[j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         v4* gdst = reinterpret_cast<v4*>(dst + c * CHUNK);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const v4 t = *reinterpret_cast<const v4*>(mine + k * 1024 + lane * 16);
             __builtin_nontemporal_store(t, gdst + k * 64 + lane);
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
     }
 }
 

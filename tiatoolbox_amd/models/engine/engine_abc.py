@@ -437,6 +437,28 @@ class EngineABC:
             return hook.device_batch(batch, dtype, defer_unit_scale=True)
         return hook.device_batch(batch, dtype)
 
+    def _prenormalized(self, hook, inputs: torch.Tensor, lo: int, hi: int):
+        """Stain normalisation of a device-resident patch list in CHUNKS of ``stain_chunk`` patches (default 4096, at most 2 GiB
+        of pixels), not per CNN micro-batch: the statistics kernel runs one workgroup per patch, two resident per CU, so a
+        1024-patch launch is two rounds with a ragged tail (1.27 ms per 1024 against 2.45 ms per 4096 in one launch,
+        ``profiles/r03p_bench_rocprofv3_summary.txt``).  Returns the micro-batch ``[lo, hi)`` of the cached uint8 result
+        wrapped for the stem kernel, or ``None`` when the fast path does not apply (then the hook runs per micro-batch)."""
+        from tiatoolbox_amd.models.dataset.classification import StainNormPreproc, UnitUInt8
+
+        span = getattr(self, "_shard_span", None)
+        if (span is None or not isinstance(hook, StainNormPreproc) or not getattr(self, "_defer_unit", False)
+                or not hook.supports_deferred_unit_scale or inputs.dtype != torch.uint8 or not inputs.is_cuda):
+            return None
+        per_patch = int(inputs[0].numel())
+        limit = max(1, min(int(getattr(self, "stain_chunk", 4096)), (2 << 30) // max(per_patch, 1)))
+        chunk = max(self.batch_size, limit // self.batch_size * self.batch_size)
+        c0 = span[0] + (lo - span[0]) // chunk * chunk
+        c1 = min(c0 + chunk, span[1])
+        cache = getattr(self, "_norm_cache", None)
+        if cache is None or cache[0] != c0 or cache[1] != c1:
+            self._norm_cache = cache = (c0, c1, hook.normalizer.transform(inputs[c0:c1], out="uint8"))
+        return UnitUInt8(cache[2][lo - c0:hi - c0])
+
     def _set_defer_unit(self, model, dtype: torch.dtype) -> None:  # noqa: ARG002
         """``ToTensor`` may be deferred into the stem kernel only for the stock classifiers: the inference copy is EXACTLY a
         ``CNNModel`` / ``CNNBackbone`` (not a subclass with its own ``forward`` / ``infer_batch``, whose pre-processing inside
@@ -484,6 +506,10 @@ class EngineABC:
                 t = t.to(dev)
             device_batch = getattr(hook, "device_batch", None)
             if device_batch is not None:
+                if t.device == dataset.inputs.device:
+                    pre = self._prenormalized(hook, dataset.inputs, lo, hi)
+                    if pre is not None:
+                        return pre
                 return self._device_preproc(hook, t, dtype)
             from tiatoolbox_amd.models.models_abc import ModelABC as _MA
 
@@ -542,6 +568,7 @@ class EngineABC:
         if dev.type == "cuda" and isinstance(dataloader.inputs, np.ndarray) and dataloader.inputs.dtype == np.uint8:
             self._feed = _HostFeed(dataloader.inputs, dev)
         self._set_defer_unit(model, dtype)
+        self._shard_span, self._norm_cache = (lo, hi), None
         try:
             with self._miopen_scope(), self._deferred_norm_checks(dataloader.preproc_func):
                 for s in range(lo, hi, self.batch_size):
@@ -555,6 +582,7 @@ class EngineABC:
             if self._feed is not None:
                 self._feed.close()
                 self._feed = None
+            self._shard_span, self._norm_cache = None, None
         if not outs:  # empty shard: a one-patch probe supplies the row shapes
             probe = self._forward_batch(model, infer_batch, self._preprocess_batch(dataloader, 0, 1, dtype))
             outs = [tuple(p[:0] for p in probe) if isinstance(probe, tuple) else probe[:0]]
