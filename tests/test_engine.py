@@ -541,6 +541,7 @@ def test_gpu_logits_match_cpu_fp32_with_spread_predictions():
         patches = synth.g_he(12, side, side, seed=side)
         cpu_eng = PatchPredictor("resnet18-kather100k", batch_size=6)
         g = torch.Generator().manual_seed(5)
+        cpu_eng.model.eval()
         with torch.no_grad():
             for m in cpu_eng.model.modules():
                 if isinstance(m, torch.nn.BatchNorm2d):
@@ -550,11 +551,13 @@ def test_gpu_logits_match_cpu_fp32_with_spread_predictions():
                     m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
             feats = cpu_eng.model.pool(cpu_eng.model.feat_extract(
                 torch.from_numpy(patches).float().div(255).permute(0, 3, 1, 2))).flatten(1)
-            feats = feats - feats.mean(0, keepdim=True)
-            # classifier rows = directions that separate the patches: logits spread over several units
-            w = torch.linalg.svd(feats, full_matrices=False)[2][:9]
-            cpu_eng.model.classifier.weight.copy_(w * (4.0 / (feats @ w.T).abs().max()))
-            cpu_eng.model.classifier.bias.zero_()
+            mean = feats.mean(0, keepdim=True)
+            # classifier rows = directions that separate the patches (principal axes of the centred features, the mean
+            # taken out through the bias): logits spread over several units
+            w = torch.linalg.svd(feats - mean, full_matrices=False)[2][:9]
+            w = w * (4.0 / ((feats - mean) @ w.T).abs().max())
+            cpu_eng.model.classifier.weight.copy_(w)
+            cpu_eng.model.classifier.bias.copy_(-(mean @ w.T).flatten())
         kw = {"patch_mode": True, "return_probabilities": True, "patch_input_shape": (side, side)}
         cpu = cpu_eng.run(patches, **kw)
         assert len(set(np.asarray(cpu["predictions"]).tolist())) >= 3, "the construction must spread the predictions"

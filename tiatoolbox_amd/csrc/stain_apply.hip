@@ -382,7 +382,7 @@ __device__ __forceinline__ void sweep_wide(const Ctx& ctx, uint8_t* mine, const 
             w[j * 4 + 3] = t.w;
         }
         wave_lds_sync();  // everyone has read its pixels before the region is reused
-        alignas(16) T res[48];
+        alignas(16) uint32_t res[12 * TS];  // the lane's 48 output values, packed
 #pragma unroll
         for (int q = 0; q < 4; ++q) {  // four groups of 4 pixels (12 bytes = 3 dwords each)
             const uint32_t a = w[q * 3], b = w[q * 3 + 1], cc = w[q * 3 + 2];
@@ -391,10 +391,31 @@ __device__ __forceinline__ void sweep_wide(const Ctx& ctx, uint8_t* mine, const 
             ctx.pixel(a >> 24, b & 255u, (b >> 8) & 255u, o[1]);
             ctx.pixel((b >> 16) & 255u, b >> 24, cc & 255u, o[2]);
             ctx.pixel((cc >> 8) & 255u, (cc >> 16) & 255u, cc >> 24, o[3]);
+            // explicit packing, group by group (left to the vectoriser, the uint8 / float64 instantiation gathered the bytes of
+            // all 16 pixels first: 268 live registers, one wave per SIMD)
+            uint32_t bits[12];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) res[q * 12 + i * 3 + ch] = O::cvt(o[i][ch]);
+                for (int ch = 0; ch < 3; ++ch) {
+                    const T t = O::cvt(o[i][ch]);
+                    if constexpr (TS == 1) {
+                        bits[i * 3 + ch] = (uint32_t)t;
+                    } else {
+                        unsigned short h;
+                        __builtin_memcpy(&h, &t, 2);
+                        bits[i * 3 + ch] = h;
+                    }
+                }
+            if constexpr (TS == 1) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    res[q * 3 + k] = bits[4 * k] | (bits[4 * k + 1] << 8) | (bits[4 * k + 2] << 16) | (bits[4 * k + 3] << 24);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) res[q * 6 + k] = bits[2 * k] | (bits[2 * k + 1] << 16);
+            }
+            if constexpr (sizeof(F) == 8) __builtin_amdgcn_sched_barrier(0);  // float64: one group at a time
         }
         const v4* rv = reinterpret_cast<const v4*>(res);
 #pragma unroll
