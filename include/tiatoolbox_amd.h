@@ -34,7 +34,7 @@ extern "C" {
  * tia_stain_stats_u8 grew by one int32 flag per patch (tia_stain_stats_workspace_bytes_mode reports it). */
 /* Version 4 (round 4): + tia_rgb2od_u8 (the stand-alone OD transform, with the reference's in-place side effect on request),
  * tia_clear_last_error; TIA_MATH_F64 of tia_stain_apply_u8 evaluates exp() with the library's own float64 kernel
- * (TIA_MATH_F64_REF keeps the device libm's exp). */
+ * (TIA_MATH_F64_REF keeps the device libm's exp); tia_conv3x3_geometry (dispatch diagnostics). */
 #define TIA_ABI_VERSION 4
 int tia_abi_version(void);
 
@@ -438,6 +438,13 @@ int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed, const floa
                            float* d_y, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh,
                            int64_t kw, int64_t stride, int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo,
                            int32_t relu, void* stream);
+
+/* Which block geometry tia_conv2d_nhwc_f32(_ex) / tia_conv2d_nhwc_h use for a 3x3 / stride-1 convolution of an [h, w] map to
+ * [ho, wo] (diagnostics for tests and profiles; host only, no launch).  Returns 0: the slice implicit-GEMM kernel; 1: tap reuse
+ * on 16 x 16 pixel blocks; 2: tap reuse, two images of at most 8 x 8 per block; 3 / 4: tap reuse on bands of geom[1] rows of a
+ * geom[0]-column strip of the batch stacked into one tall image (4: the 7-wide form, one workgroup per CU).
+ * geom[0..3] = strip width, rows per band, LDS row pitch (16-byte units), strips per image row (zeros unless 3 / 4). */
+int tia_conv3x3_geometry(int64_t h, int64_t w, int64_t ho, int64_t wo, int64_t pad_top, int64_t pad_left, int32_t geom[4]);
 
 /* Convolution over a THIN input (c * kw <= 32, e.g. the 3-channel 7x7 stem of HoVer-Net, models/architecture/hovernet.py:
  * 287-300 `conv0`): d_x [n,h,w,c] float32 NHWC, ALREADY padded horizontally by the caller ((wo-1)*stride + kw <= w, and at least 32 floats from the last output

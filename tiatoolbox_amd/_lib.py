@@ -93,6 +93,7 @@ _SIGNATURES = {
     "tia_conv2d_nhwc_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     "tia_conv2d_nhwc_f32_ex": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P],
                                C.c_int),
+    "tia_conv3x3_geometry": ([_I64, _I64, _I64, _I64, _I64, _I64, C.POINTER(C.c_int32)], C.c_int),
     "tia_conv2d_thin_nhwc_f32": ([_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     "tia_conv1x1_head_nhwc_f32": ([_P, _I64, _P, _P, _P, _P, _I32, _P, _P], C.c_int),
     "tia_conv2d_post_nhwc_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32,

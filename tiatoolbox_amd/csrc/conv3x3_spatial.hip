@@ -40,6 +40,8 @@ constexpr int K_F32 = 0, K_F16 = 1, K_BF16 = 2;
 struct SpDims {
     int n, h, w, cin, cout, ho, wo, pad_y, pad_x;
     unsigned x_bytes, w_bytes;
+    // band geometry (GB / GB7 below): strip width, rows per band, LDS row pitch in 16-byte units, image pitch h + 1, strips per row
+    int bw, br, brow, bhp1, strips;
 };
 
 template <int KIND>
@@ -83,9 +85,34 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
 // groups the same way (k-space: {0-3}, 8+{4-7}, 16+{4-7}, 24+{0-3}).
 struct G16 {
     static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 18, PWD = 18, ROW = 96, IMG = 18 * 96, MROWS = 2, WAVES_M = 4;
+    static constexpr bool BAND = false;
+    static constexpr int PER_CU = 2;
 };
 struct G8 {
     static constexpr int NT = 256, G = 2, TH = 8, TW = 8, PH = 10, PWD = 10, ROW = 56, IMG = 10 * 56, MROWS = 4, WAVES_M = 2;
+    static constexpr bool BAND = false;
+    static constexpr int PER_CU = 2;
+};
+// Band geometry ("same" 3x3 convolutions on maps that 16 x 16 blocks cover badly: 56 / 28 / 14 / 7 of 224^2 patches).  The
+// images of the batch are stacked into one tall virtual image with ONE zero row between neighbours (image pitch h + 1 rows: the
+// zero row is the bottom halo of one image and the top halo of the next), cut into column strips of `bw` columns, and a block
+// owns `br` consecutive virtual rows of a strip -- its br * bw <= 256 output pixels are the block's GEMM rows in row-major
+// order (linearised: an MFMA tile is 32 consecutive pixels, wherever the row ends), rows >= br * bw idle.  Nothing has to divide
+// anything: bands run across image boundaries (gap rows are computed and dropped: 1 / (h + 1) of the work), so a 28-wide strip
+// takes br = 9 (252 of 256 rows busy) at 96.7 % (56^2 maps, two strips) / 95.0 % (28^2), 14-wide br = 18 at 91.9 %, 7-wide br = 36
+// at 86.1 % -- against 76.6 % for 16 x 16 blocks on all four.  LDS row pitch = 5 bw mod 16 units (>= 5 (bw + 2)): unit address
+// = 5 p + const mod 16 for the linear pixel index p, so the 16 lanes of a ds_read_b128 group (pixels p0 + {0-3, 12-15, 20-27})
+// still hit 16 different bank groups for every tap shift.  GB: patch <= 1728 units, two workgroups per CU; GB7 (7-wide): 1984
+// units, one workgroup (8 waves) per CU -- what the 8 x 8 geometry also runs with.
+struct GB {
+    static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 0, PWD = 0, ROW = 0, IMG = 1728, MROWS = 0, WAVES_M = 4;
+    static constexpr bool BAND = true;
+    static constexpr int PER_CU = 2;
+};
+struct GB7 {
+    static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 0, PWD = 0, ROW = 0, IMG = 1984, MROWS = 0, WAVES_M = 4;
+    static constexpr bool BAND = true;
+    static constexpr int PER_CU = 1;
 };
 
 // s_waitcnt vmcnt(VM) lgkmcnt(0) (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] = 7 (no wait) | lgkmcnt[11:8] | vmcnt[5:4] << 14)
@@ -96,14 +123,16 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 }
 
 template <int BN, int KIND, typename GEO>
-__global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spatial_kernel(const void* __restrict__ x, const void* __restrict__ wk,
+__global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 2 * GEO::PER_CU : 2) void conv3x3_spatial_kernel(const void* __restrict__ x, const void* __restrict__ wk,
                                                                 const float* __restrict__ bias, const void* __restrict__ res,
                                                                 void* __restrict__ y, SpDims d, int relu, int m_tiles, int tiles_x,
                                                                 int tiles_per_image) {
     constexpr bool F32 = KIND == K_F32;
     constexpr int ES = F32 ? 4 : 2;       // bytes per element
     constexpr int SC = 64 / ES;           // channels per 64-byte slice: 16 | 32
-    constexpr int NT = GEO::NT, NTILE = BN / 64, PIX = 5, ROW = GEO::ROW;
+    constexpr int NT = GEO::NT, NTILE = BN / 64, PIX = 5;
+    constexpr bool BAND = GEO::BAND;
+    const int ROW = BAND ? d.brow : GEO::ROW;  // (a compile-time constant for the fixed geometries)
     constexpr int BLOCK_PX = GEO::G * GEO::TH * GEO::TW;                 // 256 | 128 output pixels = GEMM rows of the block
     constexpr int A_UNITS = (GEO::G * GEO::IMG + 63) / 64 * 64;           // patch units, whole waves: 1728 | 1152
     constexpr int NA = (A_UNITS + NT - 1) / NT;                           // DMA pieces per patch: 4 | 5 (the last one partial)
@@ -114,7 +143,7 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     constexpr int LDS_BYTES = DUMP + 1024;
     static_assert(NA <= 7, "the last patch piece must have landed by tap 8");
     static_assert(LDS_BYTES >= BLOCK_PX * (BN / 2) * 4, "epilogue tile");
-    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    static_assert(GEO::PER_CU * LDS_BYTES <= 160 * 1024, "workgroups per CU");
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int bid = blockIdx.x;
@@ -122,9 +151,11 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     const int mt_id = (bid % 8) * per_xcd + bid / 8;
     if (mt_id >= m_tiles) return;
     // G16: block = (image, 16 x 16 tile); G8: block = images 2 mt_id, 2 mt_id + 1 (tiles_per_image = 1, tile origin 0)
-    const int img = GEO::G == 1 ? mt_id / tiles_per_image : mt_id * GEO::G;
+    // band: block = (band of br virtual rows, strip); ty0 = first virtual output row
+    const int img = BAND ? 0 : (GEO::G == 1 ? mt_id / tiles_per_image : mt_id * GEO::G);
     const int trem = GEO::G == 1 ? mt_id - img * tiles_per_image : 0;
-    const int ty0 = (trem / tiles_x) * GEO::TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * GEO::TW;
+    const int ty0 = BAND ? (mt_id / d.strips) * d.br : (trem / tiles_x) * GEO::TH;
+    const int tx0 = BAND ? (mt_id % d.strips) * d.bw : (trem - (trem / tiles_x) * tiles_x) * GEO::TW;
     const int n0 = blockIdx.y * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -137,13 +168,22 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
         const int u = NT * r + tid;
-        const int g = u / GEO::IMG, ug = u - g * GEO::IMG;
-        const int py = ug / ROW, rem = ug - py * ROW;
-        const int px = rem / PIX, chunk = rem - px * PIX;
-        const int iy = ty0 - d.pad_y + py, ix = tx0 - d.pad_x + px;
-        const bool inside = g < GEO::G && img + g < d.n && py < GEO::PH && px < GEO::PWD && chunk < 4 && (unsigned)iy < (unsigned)d.h &&
-                            (unsigned)ix < (unsigned)d.w;
-        cen[r] = inside ? (((img + g) * d.h + iy) * d.w + ix) * d.cin * ES + 16 * chunk : OOB;
+        if constexpr (BAND) {
+            const int py = u / ROW, rem = u - py * ROW;
+            const int px = rem / PIX, chunk = rem - px * PIX;
+            const int vy = ty0 - 1 + py, ix = tx0 - 1 + px;       // virtual input row; "same" padding: one row / column in front
+            const int g = vy >= 0 ? vy / d.bhp1 : 0, iy = vy - g * d.bhp1;  // image, row in the image (== h: the zero row between images)
+            const bool inside = vy >= 0 && py < d.br + 2 && px < d.bw + 2 && chunk < 4 && g < d.n && iy < d.h && (unsigned)ix < (unsigned)d.w;
+            cen[r] = inside ? ((g * d.h + iy) * d.w + ix) * d.cin * ES + 16 * chunk : OOB;
+        } else {
+            const int g = u / GEO::IMG, ug = u - g * GEO::IMG;
+            const int py = ug / ROW, rem = ug - py * ROW;
+            const int px = rem / PIX, chunk = rem - px * PIX;
+            const int iy = ty0 - d.pad_y + py, ix = tx0 - d.pad_x + px;
+            const bool inside = g < GEO::G && img + g < d.n && py < GEO::PH && px < GEO::PWD && chunk < 4 && (unsigned)iy < (unsigned)d.h &&
+                                (unsigned)ix < (unsigned)d.w;
+            cen[r] = inside ? (((img + g) * d.h + iy) * d.w + ix) * d.cin * ES + 16 * chunk : OOB;
+        }
     }
     // weight staging: one unit per thread and tap
     //   half:    [4 k-chunks][BN columns] units of 8 halves; global ((tap * cin/8 + 4 cs + kc) * cout + n0 + col) * 16
@@ -196,11 +236,23 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     // one base per lane (units): a wave owns 64 GEMM rows = 64 / TW pixel rows (G16: rows 4 wm ..; G8: image wm); MFMA row =
     // lane & 31 -> pixel row (row / TW) (+ MROWS i), column row % TW; half: k-chunk (lane >> 5) + 2 q; float32: units 2 (lane >> 5), + 1
     const int hi = lane >> 5;
-    const int wave_base = GEO::G == 1 ? (64 / GEO::TW) * wm * ROW : wm * GEO::IMG;
-    const int fa0 = wave_base + ((lane & 31) / GEO::TW) * ROW + ((lane & 31) % GEO::TW) * PIX + (F32 ? 2 * hi : hi);
+    int fa[2];  // per MFMA tile of the wave: LDS unit of the lane's pixel at tap (0, 0)
+    if constexpr (BAND) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = wm * 64 + i * 32 + (lane & 31);  // linear pixel of the block; idle rows read pixel 0 (results dropped)
+            m = m < d.br * d.bw ? m : 0;
+            const int r = m / d.bw;
+            fa[i] = r * ROW + (m - r * d.bw) * PIX + (F32 ? 2 * hi : hi);
+        }
+    } else {
+        const int wave_base = GEO::G == 1 ? (64 / GEO::TW) * wm * ROW : wm * GEO::IMG;
+        fa[0] = wave_base + ((lane & 31) / GEO::TW) * ROW + ((lane & 31) % GEO::TW) * PIX + (F32 ? 2 * hi : hi);
+        fa[1] = fa[0] + GEO::MROWS * ROW;
+    }
 
     auto compute = [&](int buf, int stage, int tap) {
-        const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES) + fa0;
+        const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES);
         const int shift = (tap / 3) * ROW + (tap % 3) * PIX;
         if constexpr (F32) {
             const float* sb = reinterpret_cast<const float*>(bring + stage * B_BYTES) + (8 * hi) * BN + wn * (BN / 2) + (lane & 31);
@@ -208,8 +260,8 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
             float b[NTILE][8];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[i][0] = sa[shift + i * GEO::MROWS * ROW];
-                a[i][1] = sa[shift + i * GEO::MROWS * ROW + 1];
+                a[i][0] = sa[fa[i] + shift];
+                a[i][1] = sa[fa[i] + shift + 1];
             }
 #pragma unroll
             for (int j = 0; j < NTILE; ++j)
@@ -228,7 +280,7 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
             for (int q = 0; q < 2; ++q) {
                 u32x4 a[2], b[NTILE];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = sa[shift + i * GEO::MROWS * ROW + 2 * q];
+                for (int i = 0; i < 2; ++i) a[i] = sa[fa[i] + shift + 2 * q];
 #pragma unroll
                 for (int j = 0; j < NTILE; ++j) b[j] = sb[2 * q * BN + j * 32];
 #pragma unroll
@@ -295,9 +347,22 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
         __syncthreads();
         for (int idx = tid; idx < CHUNKS; idx += NT) {
             const int row = idx / (HB / 8), cc = idx - row * (HB / 8);
-            const int g = row / (GEO::TH * GEO::TW), rg = row - g * (GEO::TH * GEO::TW);
-            const int oy = ty0 + rg / GEO::TW, ox = tx0 + rg % GEO::TW;
-            if (oy < d.ho && ox < d.wo && img + g < d.n) {
+            int g, oy, ox;
+            bool live;
+            if constexpr (BAND) {
+                const int r = row / d.bw, vy = ty0 + r;
+                g = vy / d.bhp1;
+                oy = vy - g * d.bhp1;
+                ox = tx0 + (row - r * d.bw);
+                live = row < d.br * d.bw && oy < d.ho && g < d.n;  // (oy == ho: the zero row between two images)
+            } else {
+                g = row / (GEO::TH * GEO::TW);
+                const int rg = row - g * (GEO::TH * GEO::TW);
+                oy = ty0 + rg / GEO::TW;
+                ox = tx0 + rg % GEO::TW;
+                live = oy < d.ho && ox < d.wo && img + g < d.n;
+            }
+            if (live) {
                 const long m = ((long)(img + g) * d.ho + oy) * d.wo + ox;
                 const int col0 = n0 + half * HB + cc * 8;
                 const float4 v0 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8);
@@ -519,21 +584,28 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
     static const bool disabled = getenv("TIA_CONV_NO_SPATIAL") != nullptr;
     const int es = dtype == TIA_DT_F32 ? 4 : 2;
     if (disabled || cin % (64 / es) != 0 || cout % 64 != 0 || pad_top > 2 || pad_left > 2) return false;
-    const bool small = ho <= 8 && wo <= 8;  // G8: two images of (at most) 8 x 8 per block
+    const SpPlan plan = conv3x3_spatial_plan(3, 3, 1, h, w, ho, wo, pad_top, pad_left);
+    if (plan.kind == 0) return false;
+    const bool small = plan.kind == 2;  // G8: two images of (at most) 8 x 8 per block
+    const bool band = plan.kind >= 3;
     const long tiles_y = small ? 1 : (ho + 15) / 16, tiles_x = small ? 1 : (wo + 15) / 16;
-    const long tiles = small ? (nb + 1) / 2 : nb * tiles_y * tiles_x;
+    // band: the batch as one image of nb * (h + 1) - 1 rows (no zero row behind the last image), cut into bands of br rows
+    const long tiles = band ? ((nb * (h + 1) - 1 + plan.br - 1) / plan.br) * plan.strips : (small ? (nb + 1) / 2 : nb * tiles_y * tiles_x);
     const SpDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
-                   (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es)};
+                   (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es), plan.bw, plan.br, plan.brow, (int)(h + 1), plan.strips};
     const bool wide = cout % 128 == 0;
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / (wide ? 128 : 64)));
+#define TIA_LAUNCH_GEO(BN_, KIND_, GEO_)                                                                                           \
+    hipLaunchKernelGGL((conv3x3_spatial_kernel<BN_, KIND_, GEO_>), grid, dim3(GEO_::NT), 0, stream, x, w_packed, bias, residual, y, d, \
+                       relu, (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x))
 #define TIA_LAUNCH_SP(BN_, KIND_)                                                                                                  \
     do {                                                                                                                           \
-        if (small)                                                                                                                 \
-            hipLaunchKernelGGL((conv3x3_spatial_kernel<BN_, KIND_, G8>), grid, dim3(G8::NT), 0, stream, x, w_packed, bias, residual, y, \
-                               d, relu, (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x));                                       \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((conv3x3_spatial_kernel<BN_, KIND_, G16>), grid, dim3(G16::NT), 0, stream, x, w_packed, bias, residual, \
-                               y, d, relu, (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x));                                    \
+        switch (plan.kind) {                                                                                                       \
+            case 1: TIA_LAUNCH_GEO(BN_, KIND_, G16); break;                                                                        \
+            case 2: TIA_LAUNCH_GEO(BN_, KIND_, G8); break;                                                                         \
+            case 3: TIA_LAUNCH_GEO(BN_, KIND_, GB); break;                                                                         \
+            default: TIA_LAUNCH_GEO(BN_, KIND_, GB7); break;                                                                       \
+        }                                                                                                                          \
     } while (0)
     if (dtype == TIA_DT_F32) {
         if (wide) TIA_LAUNCH_SP(128, K_F32); else TIA_LAUNCH_SP(64, K_F32);
@@ -543,6 +615,7 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
         if (wide) TIA_LAUNCH_SP(128, K_BF16); else TIA_LAUNCH_SP(64, K_BF16);
     }
 #undef TIA_LAUNCH_SP
+#undef TIA_LAUNCH_GEO
     return true;
 }
 
