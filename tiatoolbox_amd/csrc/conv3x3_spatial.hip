@@ -41,8 +41,20 @@ struct SpDims {
     int n, h, w, cin, cout, ho, wo, pad_y, pad_x;
     unsigned x_bytes, w_bytes;
     // band geometry (GB / GB7 below): strip width, rows per band, LDS row pitch in 16-byte units, image pitch h + 1, strips per row
-    int bw, br, brow, bhp1, strips;
+    int bw, br, brow, bhp1, strips, bpix;
+    float inv_bw, inv_brow, inv_bhp1;  // reciprocals for fdiv() below
 };
+
+// n / d for 0 <= n < 2^24, 0 < d < 2^24 with the reciprocal computed on the host: a float estimate and one correction step each
+// way (|n * inv - n / d| < 1 for these ranges) -- 8 instructions instead of the ~35 of a run-time integer division; the band
+// geometry's prologue and epilogue are full of divisions by run-time strip widths and image pitches.
+__device__ __forceinline__ int fdiv(int n, int d, float inv) {
+    int q = (int)((float)n * inv);
+    const int r = n - q * d;
+    q += r >= d ? 1 : 0;
+    q -= r < 0 ? 1 : 0;
+    return q;
+}
 
 template <int KIND>
 __device__ __forceinline__ f32x16 mma_h(const u32x4& a, const u32x4& b, const f32x16& c) {
@@ -86,12 +98,10 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
 struct G16 {
     static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 18, PWD = 18, ROW = 96, IMG = 18 * 96, MROWS = 2, WAVES_M = 4;
     static constexpr bool BAND = false;
-    static constexpr int PER_CU = 2;
 };
 struct G8 {
     static constexpr int NT = 256, G = 2, TH = 8, TW = 8, PH = 10, PWD = 10, ROW = 56, IMG = 10 * 56, MROWS = 4, WAVES_M = 2;
     static constexpr bool BAND = false;
-    static constexpr int PER_CU = 2;
 };
 // Band geometry ("same" 3x3 convolutions on maps that 16 x 16 blocks cover badly: 56 / 28 / 14 / 7 of 224^2 patches).  The
 // images of the batch are stacked into one tall virtual image with ONE zero row between neighbours (image pitch h + 1 rows: the
@@ -102,17 +112,13 @@ struct G8 {
 // takes br = 9 (252 of 256 rows busy) at 96.7 % (56^2 maps, two strips) / 95.0 % (28^2), 14-wide br = 18 at 91.9 %, 7-wide br = 36
 // at 86.1 % -- against 76.6 % for 16 x 16 blocks on all four.  LDS row pitch = 5 bw mod 16 units (>= 5 (bw + 2)): unit address
 // = 5 p + const mod 16 for the linear pixel index p, so the 16 lanes of a ds_read_b128 group (pixels p0 + {0-3, 12-15, 20-27})
-// still hit 16 different bank groups for every tap shift.  GB: patch <= 1728 units, two workgroups per CU; GB7 (7-wide): 1984
-// units, one workgroup (8 waves) per CU -- what the 8 x 8 geometry also runs with.
+// still hit 16 different bank groups for every tap shift.  That matters for the half kernels only (their MFMAs are 16 x shorter);
+// float32 takes a pixel pitch of 4 units (no padding unit, 4-way conflicts on 4 reads per 32 MFMAs: 3 % of the LDS time), which
+// is what lets the 7-wide band (38 rows) fit the patch buffer with two workgroups per CU.  A one-workgroup-per-CU form with a
+// larger patch was measured and lost to the slice kernel (profiles/r04c_*: 106.6 vs 114.0 TFLOP/s on 512 -> 512 @ 7 x 7).
 struct GB {
     static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 0, PWD = 0, ROW = 0, IMG = 1728, MROWS = 0, WAVES_M = 4;
     static constexpr bool BAND = true;
-    static constexpr int PER_CU = 2;
-};
-struct GB7 {
-    static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 0, PWD = 0, ROW = 0, IMG = 1984, MROWS = 0, WAVES_M = 4;
-    static constexpr bool BAND = true;
-    static constexpr int PER_CU = 1;
 };
 
 // s_waitcnt vmcnt(VM) lgkmcnt(0) (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] = 7 (no wait) | lgkmcnt[11:8] | vmcnt[5:4] << 14)
@@ -123,15 +129,16 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 }
 
 template <int BN, int KIND, typename GEO>
-__global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 2 * GEO::PER_CU : 2) void conv3x3_spatial_kernel(const void* __restrict__ x, const void* __restrict__ wk,
+__global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spatial_kernel(const void* __restrict__ x, const void* __restrict__ wk,
                                                                 const float* __restrict__ bias, const void* __restrict__ res,
                                                                 void* __restrict__ y, SpDims d, int relu, int m_tiles, int tiles_x,
                                                                 int tiles_per_image) {
     constexpr bool F32 = KIND == K_F32;
     constexpr int ES = F32 ? 4 : 2;       // bytes per element
     constexpr int SC = 64 / ES;           // channels per 64-byte slice: 16 | 32
-    constexpr int NT = GEO::NT, NTILE = BN / 64, PIX = 5;
+    constexpr int NT = GEO::NT, NTILE = BN / 64;
     constexpr bool BAND = GEO::BAND;
+    const int PIX = BAND ? d.bpix : 5;  // units per pixel in the LDS patch
     const int ROW = BAND ? d.brow : GEO::ROW;  // (a compile-time constant for the fixed geometries)
     constexpr int BLOCK_PX = GEO::G * GEO::TH * GEO::TW;                 // 256 | 128 output pixels = GEMM rows of the block
     constexpr int A_UNITS = (GEO::G * GEO::IMG + 63) / 64 * 64;           // patch units, whole waves: 1728 | 1152
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 2 * GEO::PER_CU : 2) void
     constexpr int LDS_BYTES = DUMP + 1024;
     static_assert(NA <= 7, "the last patch piece must have landed by tap 8");
     static_assert(LDS_BYTES >= BLOCK_PX * (BN / 2) * 4, "epilogue tile");
-    static_assert(GEO::PER_CU * LDS_BYTES <= 160 * 1024, "workgroups per CU");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int bid = blockIdx.x;
@@ -169,10 +176,10 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 2 * GEO::PER_CU : 2) void
     for (int r = 0; r < NA; ++r) {
         const int u = NT * r + tid;
         if constexpr (BAND) {
-            const int py = u / ROW, rem = u - py * ROW;
-            const int px = rem / PIX, chunk = rem - px * PIX;
+            const int py = fdiv(u, ROW, d.inv_brow), rem = u - py * ROW;
+            const int px = PIX == 4 ? rem >> 2 : rem / 5, chunk = rem - px * PIX;
             const int vy = ty0 - 1 + py, ix = tx0 - 1 + px;       // virtual input row; "same" padding: one row / column in front
-            const int g = vy >= 0 ? vy / d.bhp1 : 0, iy = vy - g * d.bhp1;  // image, row in the image (== h: the zero row between images)
+            const int g = vy >= 0 ? fdiv(vy, d.bhp1, d.inv_bhp1) : 0, iy = vy - g * d.bhp1;  // image, row in it (== h: the zero row)
             const bool inside = vy >= 0 && py < d.br + 2 && px < d.bw + 2 && chunk < 4 && g < d.n && iy < d.h && (unsigned)ix < (unsigned)d.w;
             cen[r] = inside ? ((g * d.h + iy) * d.w + ix) * d.cin * ES + 16 * chunk : OOB;
         } else {
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 2 * GEO::PER_CU : 2) void
         for (int i = 0; i < 2; ++i) {
             int m = wm * 64 + i * 32 + (lane & 31);  // linear pixel of the block; idle rows read pixel 0 (results dropped)
             m = m < d.br * d.bw ? m : 0;
-            const int r = m / d.bw;
+            const int r = fdiv(m, d.bw, d.inv_bw);
             fa[i] = r * ROW + (m - r * d.bw) * PIX + (F32 ? 2 * hi : hi);
         }
     } else {
@@ -350,8 +357,8 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 2 * GEO::PER_CU : 2) void
             int g, oy, ox;
             bool live;
             if constexpr (BAND) {
-                const int r = row / d.bw, vy = ty0 + r;
-                g = vy / d.bhp1;
+                const int r = fdiv(row, d.bw, d.inv_bw), vy = ty0 + r;
+                g = fdiv(vy, d.bhp1, d.inv_bhp1);
                 oy = vy - g * d.bhp1;
                 ox = tx0 + (row - r * d.bw);
                 live = row < d.br * d.bw && oy < d.ho && g < d.n;  // (oy == ho: the zero row between two images)
@@ -584,15 +591,17 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
     static const bool disabled = getenv("TIA_CONV_NO_SPATIAL") != nullptr;
     const int es = dtype == TIA_DT_F32 ? 4 : 2;
     if (disabled || cin % (64 / es) != 0 || cout % 64 != 0 || pad_top > 2 || pad_left > 2) return false;
-    const SpPlan plan = conv3x3_spatial_plan(3, 3, 1, h, w, ho, wo, pad_top, pad_left);
+    const SpPlan plan = conv3x3_spatial_plan(3, 3, 1, h, w, ho, wo, pad_top, pad_left, dtype == TIA_DT_F32);
     if (plan.kind == 0) return false;
     const bool small = plan.kind == 2;  // G8: two images of (at most) 8 x 8 per block
     const bool band = plan.kind >= 3;
+    if (band && nb * (h + 1) >= (1L << 24)) return false;  // fdiv() range (never reached: the callers keep the input below 2 GiB)
     const long tiles_y = small ? 1 : (ho + 15) / 16, tiles_x = small ? 1 : (wo + 15) / 16;
     // band: the batch as one image of nb * (h + 1) - 1 rows (no zero row behind the last image), cut into bands of br rows
     const long tiles = band ? ((nb * (h + 1) - 1 + plan.br - 1) / plan.br) * plan.strips : (small ? (nb + 1) / 2 : nb * tiles_y * tiles_x);
     const SpDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
-                   (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es), plan.bw, plan.br, plan.brow, (int)(h + 1), plan.strips};
+                   (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es), plan.bw, plan.br, plan.brow, (int)(h + 1), plan.strips,
+                   plan.bpix, band ? 1.0f / (float)plan.bw : 0.0f, band ? 1.0f / (float)plan.brow : 0.0f, 1.0f / (float)(h + 1)};
     const bool wide = cout % 128 == 0;
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / (wide ? 128 : 64)));
 #define TIA_LAUNCH_GEO(BN_, KIND_, GEO_)                                                                                           \
@@ -603,8 +612,7 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
         switch (plan.kind) {                                                                                                       \
             case 1: TIA_LAUNCH_GEO(BN_, KIND_, G16); break;                                                                        \
             case 2: TIA_LAUNCH_GEO(BN_, KIND_, G8); break;                                                                         \
-            case 3: TIA_LAUNCH_GEO(BN_, KIND_, GB); break;                                                                         \
-            default: TIA_LAUNCH_GEO(BN_, KIND_, GB7); break;                                                                       \
+            default: TIA_LAUNCH_GEO(BN_, KIND_, GB); break;                                                                        \
         }                                                                                                                          \
     } while (0)
     if (dtype == TIA_DT_F32) {

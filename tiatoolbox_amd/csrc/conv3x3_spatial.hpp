@@ -8,16 +8,17 @@
 namespace tia {
 
 // Which block geometry of the tap-reuse kernel serves a 3x3 / stride-1 convolution, if any.
-//   kind 1: 16 x 16 pixel blocks of one image;  2: two images of at most 8 x 8;  3 / 4: bands of `br` rows of a `bw`-column
-//   strip of the batch stacked into one tall image (conv3x3_spatial.hip: "same" padding only; 4 = the 7-wide form with the larger
-//   LDS patch, one workgroup per CU).  The fixed geometries need >= 7/8 of their pixels on the map (measured: below that the
+//   kind 1: 16 x 16 pixel blocks of one image;  2: two images of at most 8 x 8;  3: bands of `br` rows of a `bw`-column strip of
+//   the batch stacked into one tall image (conv3x3_spatial.hip: "same" padding only; LDS pixel pitch `bpix` units: 4 for float32,
+//   5 = bank-conflict free for the half kernels).  The fixed geometries need >= 7/8 of their pixels on the map (measured: below that the
 //   slice kernels win -- e.g. 76.6 % on the 56 / 28 / 14 / 7 maps of 224^2 patches); the band geometry is taken when it keeps more
 //   of the block busy than they do: busy = (br * bw / 256) * (h / (h + 1)).
 struct SpPlan {
-    int kind, bw, br, brow, strips;
+    int kind, bw, br, brow, strips, bpix;
 };
-inline SpPlan conv3x3_spatial_plan(long kh, long kw, long stride, long h, long w, long ho, long wo, long pad_top, long pad_left) {
-    SpPlan none{0, 0, 0, 0, 0};
+inline SpPlan conv3x3_spatial_plan(long kh, long kw, long stride, long h, long w, long ho, long wo, long pad_top, long pad_left,
+                                   bool f32) {
+    SpPlan none{0, 0, 0, 0, 0, 0};
     if (kh != 3 || kw != 3 || stride != 1) return none;
     long num = 0, den = 1;  // busy fraction of the best fixed geometry
     int kind = 0;
@@ -26,7 +27,7 @@ inline SpPlan conv3x3_spatial_plan(long kh, long kw, long stride, long h, long w
     } else {
         num = ho * wo, den = ((ho + 15) / 16) * ((wo + 15) / 16) * 256, kind = 1;
     }
-    SpPlan best = (8 * num >= 7 * den) ? SpPlan{kind, 0, 0, 0, 0} : none;
+    SpPlan best = (8 * num >= 7 * den) ? SpPlan{kind, 0, 0, 0, 0, 0} : none;
     double busy = best.kind ? (double)num / (double)den : 0.0;
     static const bool no_band = getenv("TIA_CONV_NO_BAND") != nullptr;  // developer switch (A/B measurements)
     if (!no_band && pad_top == 1 && pad_left == 1 && ho == h && wo == w && h >= 2) {
@@ -35,26 +36,25 @@ inline SpPlan conv3x3_spatial_plan(long kh, long kw, long stride, long h, long w
             const long bw = wo / strips;
             if (bw > 128 || bw < 4) continue;
             const long br = 256 / bw;
-            long brow = 5 * (bw + 2);
-            while (brow % 16 != (5 * bw) % 16) ++brow;  // unit address = 5 p + const (mod 16) along the linear pixel index p
-            const long units = (br + 2) * brow;
-            const int k = units <= 1728 ? 3 : (units <= 1984 ? 4 : 0);
-            if (!k) continue;
+            const long bpix = f32 ? 4 : 5;
+            long brow = bpix * (bw + 2);
+            if (!f32)
+                while (brow % 16 != (5 * bw) % 16) ++brow;  // unit address = 5 p + const (mod 16) along the linear pixel index p
+            if ((br + 2) * brow > 1728) continue;
+            const int k = 3;
             const double b = ((double)(br * bw) / 256.0) * ((double)h / (double)(h + 1));
-            // the band form pays integer divisions in its prologue / epilogue and (kind 4) half the occupancy: take it only for a
-            // clear gain over a fixed geometry; on its own it has to beat the 7/8 the slice kernels are worth
-            // ... and between band forms of (nearly) the same busy fraction the one with two workgroups per CU wins
-            const bool better = b > busy + 0.03 || (k == 3 && best.kind == 4 && b > busy - 0.005);
-            if (better && b >= 0.85) {
+            // the band form pays divisions in its prologue / epilogue: take it only for a clear gain over a fixed geometry; on its
+            // own it has to be worth about the 7/8 the slice kernels get out of the matrix pipe
+            if (b > busy + 0.03 && b >= 0.85) {
                 busy = b;
-                best = SpPlan{k, (int)bw, (int)br, (int)brow, (int)strips};
+                best = SpPlan{k, (int)bw, (int)br, (int)brow, (int)strips, (int)bpix};
             }
         }
     }
     return best;
 }
-inline bool conv3x3_spatial_ok(long kh, long kw, long stride, long h, long w, long ho, long wo, long pad_top, long pad_left) {
-    return conv3x3_spatial_plan(kh, kw, stride, h, w, ho, wo, pad_top, pad_left).kind != 0;
+inline bool conv3x3_spatial_ok(long kh, long kw, long stride, long h, long w, long ho, long wo, long pad_top, long pad_left, bool f32) {
+    return conv3x3_spatial_plan(kh, kw, stride, h, w, ho, wo, pad_top, pad_left, f32).kind != 0;
 }
 
 // One launch over `nb` images (input extent < 2 GiB: the callers split the batch).  dtype: TIA_DT_F32 | _F16 | _BF16.

@@ -324,7 +324,7 @@ static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d
         float* yg = d_y ? d_y + first * ho * wo * cout : nullptr;
         const ConvPost post{d_post_scale, d_post_shift, with_post ? d_y2 + first * ho * wo * cout : nullptr};
         // 3x3 / stride 1 on maps that 16 x 16 pixel blocks cover with little waste: the tap-reuse kernel (conv3x3_spatial.hip)
-        if (!with_post && pstride == cin && tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad_top, pad_left) &&
+        if (!with_post && pstride == cin && tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad_top, pad_left, true) &&
             tia::conv3x3_spatial_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, pad_top, pad_left, ho, wo, TIA_DT_F32, relu, st))
             continue;
         // 1x1 (any stride, no padding): the LDS-DMA ring GEMM of conv3x3_spatial.hip
@@ -367,7 +367,7 @@ extern "C" int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed,
 }
 
 extern "C" int tia_conv3x3_geometry(int64_t h, int64_t w, int64_t ho, int64_t wo, int64_t pad_top, int64_t pad_left, int32_t geom[4]) {
-    const tia::SpPlan plan = tia::conv3x3_spatial_plan(3, 3, 1, h, w, ho, wo, pad_top, pad_left);
+    const tia::SpPlan plan = tia::conv3x3_spatial_plan(3, 3, 1, h, w, ho, wo, pad_top, pad_left, true);
     if (geom) {
         geom[0] = plan.bw;
         geom[1] = plan.br;

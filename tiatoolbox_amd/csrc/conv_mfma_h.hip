@@ -374,7 +374,7 @@ extern "C" int tia_conv2d_nhwc_h(const void* d_x, const void* d_w_packed, const 
         const char* rg = d_residual ? static_cast<const char*>(d_residual) + first * ho * wo * cout * 2 : nullptr;
         char* yg = static_cast<char*>(d_y) + first * ho * wo * cout * 2;
         // 3x3 / stride 1 on maps that 16 x 16 pixel blocks cover with little waste: the tap-reuse form (conv3x3_spatial.hip)
-        if (tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad, pad) &&
+        if (tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad, pad, false) &&
             tia::conv3x3_spatial_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, pad, pad, ho, wo, dtype, relu, st))
             continue;
         const long grid_x = ((m_tiles + 7) / 8) * 8;
