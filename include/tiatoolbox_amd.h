@@ -34,7 +34,7 @@ extern "C" {
  * tia_stain_stats_u8 grew by one int32 flag per patch (tia_stain_stats_workspace_bytes_mode reports it). */
 /* Version 4 (round 4): + tia_rgb2od_u8 (the stand-alone OD transform, with the reference's in-place side effect on request),
  * tia_clear_last_error; TIA_MATH_F64 of tia_stain_apply_u8 evaluates exp() with the library's own float64 kernel
- * (TIA_MATH_F64_REF keeps the device libm's exp); tia_conv3x3_geometry (dispatch diagnostics). */
+ * (TIA_MATH_F64_REF keeps the device libm's exp); tia_conv3x3_geometry, tia_stain_stats_path (dispatch diagnostics). */
 #define TIA_ABI_VERSION 4
 int tia_abi_version(void);
 
@@ -127,6 +127,10 @@ size_t tia_stain_stats_workspace_bytes_mode(int64_t n, int64_t h, int64_t w, int
 int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
                        const tia_stain_tables* d_tables, const tia_stain_params* params,
                        double* d_stats, void* d_ws, size_t ws_bytes, void* stream);
+/* Which of the two statistics kernels serves patches of h x w with these parameters, given an aligned, full-size workspace
+ * (diagnostics for tests and profiles; host only): 0 = the streaming kernel (the patch is re-read per sweep), 1 = the
+ * register-resident kernel (one read; patches it hands back go through the streaming kernel).  Same bits either way. */
+int tia_stain_stats_path(int64_t h, int64_t w, const tia_stain_params* params /* host */);
 
 /* Output kinds of tia_stain_apply_u8 */
 #define TIA_OUT_U8 0       /* uint8 NHWC, astype(uint8) truncation   (stainnorm.py:110-113)          */

@@ -399,10 +399,11 @@ def test_metric_size_batch_against_oracle(target_image):
     patches spread over the batch, each with content no other patch has.  At 256^2 the statistics come from the STREAMING
     kernel (the register-resident one serves patches of at most 224^2): asserted through the hand-back diagnostics.  Stain
     matrix / maxC to 1e-9, float64 pre-cast pixels to 1e-4 (north-star tolerance), uint8 within 1 LSB on < 2e-4 of the bytes."""
+    import ctypes
+
     import torch
 
     from tiatoolbox_amd import _lib
-    from tiatoolbox_amd.tools import _stain_device as dev
     from tiatoolbox_amd.tools.stainnorm import get_normalizer
     from tiatoolbox_amd.utils import synth
 
@@ -415,8 +416,10 @@ def test_metric_size_batch_against_oracle(target_image):
     norm = get_normalizer("macenko")
     norm.fit(target_image)
     out, stats = norm.transform(batch, return_stats=True)
-    handed_back = dev.redo_count(batch.device, n, side, side)
-    assert handed_back in (-1, 0), f"256^2 must run on the streaming kernel (register-resident hand-backs: {handed_back})"
+    prm = norm.extractor.stats_params(target_stain=norm.stain_matrix_target, target_maxc=norm.maxC_target)
+    lib = _lib.load()
+    assert lib.tia_stain_stats_path(side, side, ctypes.byref(prm)) == 0, "256^2 patches are served by the streaming kernel"
+    assert lib.tia_stain_stats_path(224, 224, ctypes.byref(prm)) == 1    # (the register-resident one: the 224^2 test above)
     pre = norm.transform(batch, out="float64")
     ref = ostain.get_normalizer("macenko")
     ref.fit(target_image.copy())

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "tia_stain_stats_workspace_bytes": ([_I64, _I64, _I64], C.c_size_t),
     "tia_stain_stats_workspace_bytes_mode": ([_I64, _I64, _I64, _I32], C.c_size_t),
     "tia_stain_stats_u8": ([_P, _I64, _I64, _I64, _P, C.POINTER(StainParams), _P, _P, C.c_size_t, _P], C.c_int),
+    "tia_stain_stats_path": ([_I64, _I64, C.POINTER(StainParams)], C.c_int),
     "tia_stain_apply_u8": ([_P, _I64, _I64, _I64, _P, _P, C.POINTER(C.c_double), _P, _I32, _I32, _P], C.c_int),
     "tia_stain_concentrations_f64": ([_P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
     "tia_stain_augment_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _I32, _I32, _I32, _P, _I32, _P], C.c_int),

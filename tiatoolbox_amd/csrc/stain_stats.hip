@@ -2928,6 +2928,18 @@ extern "C" size_t tia_stain_stats_workspace_bytes_mode(int64_t n, int64_t h, int
     return total + align256s((size_t)n * sizeof(int));
 }
 
+// patches of this shape (in whole 4-pixel groups, window selection on) may go through the register-resident kernel
+static bool stats_reg_shape(long hw, const tia_stain_params* params) {
+    static const bool reg_all = getenv("TIA_STATS_REG_ALL") != nullptr;  // developer switch: every eligible size
+    const long reg_limit = reg_all ? (long)tia::RT * tia::RG * 4 : (long)tia::RT * 13 * 4;
+    return params->mode != TIA_MODE_VAHADANE && params->select_mode == 0 && (hw & 3) == 0 && hw <= reg_limit;
+}
+
+extern "C" int tia_stain_stats_path(int64_t h, int64_t w, const tia_stain_params* params) {
+    if (!params || h <= 0 || w <= 0) return TIA_EINVAL;
+    return stats_reg_shape((long)h * (long)w, params) ? 1 : 0;
+}
+
 extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
                                    const tia_stain_tables* d_tables, const tia_stain_params* params,
                                    double* d_stats, void* d_ws, size_t ws_bytes, void* stream) {
@@ -2956,9 +2968,7 @@ extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, in
     // instructions per pixel over the four sweeps, ~4 cycles each per wave), so the single read buys HBM traffic (1.25 GB instead of
     // 3.9 GB per 4096 x 224^2), not time; at 256 x 256 one 1024-thread workgroup per CU (16 register slots per thread) is slower than
     // two streaming workgroups that overlap each other's single-lane phases, so those patches stay on the streaming kernel.
-    static const bool reg_all = getenv("TIA_STATS_REG_ALL") != nullptr;  // developer switch: every eligible size
-    const long reg_limit = reg_all ? (long)tia::RT * tia::RG * 4 : (long)tia::RT * 13 * 4;
-    const bool reg_ok = params->select_mode == 0 && (hw & 3) == 0 && hw <= reg_limit &&
+    const bool reg_ok = stats_reg_shape(hw, params) &&
                         (reinterpret_cast<uintptr_t>(d_img) & 3) == 0 && aligned &&
                         ws_bytes >= tia_stain_stats_workspace_bytes_mode(n, h, w, params->mode);
     if (reg_ok) {
