@@ -43,9 +43,10 @@ inline SpPlan conv3x3_spatial_plan(long kh, long kw, long stride, long h, long w
             if ((br + 2) * brow > 1728) continue;
             const int k = 3;
             const double b = ((double)(br * bw) / 256.0) * ((double)h / (double)(h + 1));
-            // the band form pays divisions in its prologue / epilogue: take it only for a clear gain over a fixed geometry; on its
-            // own it has to be worth about the 7/8 the slice kernels get out of the matrix pipe
-            if (b > busy + 0.03 && b >= 0.85) {
+            // take it only for a clear gain over a fixed geometry, and only above 0.88: measured at batch 1024 (profiles/
+            // r04e_conv_probe.txt) the tap-reuse kernel sustains ~130 TFLOP/s of raw MFMA work against ~117 for the slice kernel,
+            // so the 7-wide band (0.861 busy: 112.4 TFLOP/s) loses to the slice kernel (117.2) while 14 / 28-wide ones win
+            if (b > busy + 0.03 && b >= 0.88) {
                 busy = b;
                 best = SpPlan{k, (int)bw, (int)br, (int)brow, (int)strips, (int)bpix};
             }
