@@ -512,6 +512,17 @@ __device__ __forceinline__ void select2(const uint8_t* __restrict__ p, long hw, 
 }
 
 
+// Sample k of a window-placing sample: one pixel from every window [k stride, (k + 1) stride) of the flat pixel index, at a
+// pseudo-random offset inside it (a stratified sample).  A plain multiple of the stride is a set of image COLUMNS whenever the
+// stride divides the row length (256 x 256: stride 16 = 16 columns out of 256): neighbouring rows are correlated in real and
+// synthetic tissue alike, the sample then carries far fewer independent values than its size, the 3.5-sigma rank window derived
+// from that size is too narrow, and the selection has to be redone by the histogram path (measured: 15 % of the selections at
+// 256 x 256, none at 224 x 224 where the stride of 13 walks diagonally).  Results never depend on the sample; only the cost does.
+__device__ __forceinline__ long sample_index(long k, long stride) {
+    const unsigned h = ((unsigned)k * 2654435761u) >> 8;
+    return k * stride + (long)(stride > 1 ? h % (unsigned)stride : 0u);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Window selection: the same exact order statistics as select2 from ONE sweep over the pixels.
 //   1. a <= 4096-pixel sample, evaluated in float32 on the VALU, places per target a key window [wlo, whi] that holds
@@ -552,7 +563,7 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             // branch-free (clamped index): a conditional load would be waited for on its own, one memory latency per sample
-            const long idx = ((long)j * NT + tid) * stride;
+            const long idx = sample_index((long)j * NT + tid, stride);
             const long ic = idx < hw ? idx : hw - 1;
             rgb[j] = (uint32_t)p[3 * ic] | ((uint32_t)p[3 * ic + 1] << 8) | ((uint32_t)p[3 * ic + 2] << 16);
         }
@@ -560,7 +571,7 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
         unsigned cnt[2] = {0u, 0u};
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
-            const long idx = ((long)j * NT + tid) * stride;
+            const long idx = sample_index((long)j * NT + tid, stride);
             float v[2] = {0.0f, 0.0f};
             const unsigned valid = idx < hw ? sample32(idx, rgb[j] & 255u, (rgb[j] >> 8) & 255u, (rgb[j] >> 16) & 255u, v) : 0u;
 #pragma unroll
@@ -593,7 +604,12 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
     }
     __syncthreads();
     const unsigned ns[2] = {s.wn[0], s.wn[1]};
-    if (ns[0] < 64u || ns[1] < 64u) return false;  // too small to place a window: the histogram path handles it
+    if (ns[0] < 64u || ns[1] < 64u) {  // too small to place a window: the histogram path handles it
+#if TIA_STATS_TIMING
+        if (tid == 0) s.tm[13] += 2;
+#endif
+        return false;
+    }
     float smin[2], sscale[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -688,6 +704,9 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
     {
         bool over = false;
         for (int w = 0; w < NW; ++w) over = over || s.wcnt[w] > SEG;
+#if TIA_STATS_TIMING
+        if (over && tid == 0) s.tm[13] += 30;
+#endif
         if (over) return false;  // uniform
     }
     // ---- exact classification of the listed pixels ----------------------------------------------------------------------
@@ -775,6 +794,11 @@ __device__ __forceinline__ bool window_select2(const uint8_t* __restrict__ p, lo
             const unsigned long long below = s.wbelow[t], nc = s.wn[t];
             const bool has_next = k[t] + 1 < n[t];
             if (nc > (unsigned long long)CAP || k[t] < below || k[t] + (has_next ? 1 : 0) >= below + nc) ok = 0;
+#if TIA_STATS_TIMING
+            if (nc > (unsigned long long)CAP) s.tm[13] += 400;
+            else if (k[t] < below || k[t] + (has_next ? 1 : 0) >= below + nc) s.tm[13] += 5000;
+            s.tm[14] += (long long)nc;
+#endif
         }
         s.wok = ok;
     }
@@ -1062,13 +1086,52 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
     const long long t_begin = clock64();
 #endif
 
+    const bool grp = groups_ok(p, hw);
+    if constexpr (!DL) {
+        // ---- P1: byte histogram of all three channels together (the contrast-enhancer percentiles are over the flattened image;
+        //      only the dictionary-learning instantiation needs per-channel sums).  32 copies in the 32 KB bins area: lane l adds
+        //      to copy l & 31 of bin v at v * 32 + (l & 31), so the 32 lanes an LDS atomic services together never share a bank
+        //      whatever the bytes are -- the layout the register-resident kernel uses (per-wave per-channel copies sat on bank
+        //      conflicts of data-dependent addresses: 102 k cycles per 256 x 256 patch against ~25 k, profiles/r04f_*).
+        unsigned* hs = &s.bins[0][0];
+        for (int i = tid; i < 2 * NB; i += NT) hs[i] = 0u;
+        __syncthreads();
+        hs += lane_id() & 31;
+        auto add = [&](uint32_t v) {
+            if (z1) v = v ? v : 1u;
+            atomicAdd(hs + v * 32u, 1u);
+        };
+        if (grp) {
+            for_each_group<NT>(p, hw, [&](long, uint32_t a, uint32_t b, uint32_t c, const WaveGroup&) {
+                const uint32_t w[3] = {a, b, c};
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) add((w[d] >> (8 * e)) & 255u);
+            });
+        } else {
+            for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
+                add(r);
+                add(g);
+                add(b);
+            });
+        }
+        __syncthreads();
+        stamp(s, TM_P1);
+        if (tid < 256) {
+            unsigned tot = 0;
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) tot += (&s.bins[0][0])[tid * 32 + ((c + lane_id()) & 31)];  // rotated: no bank conflicts
+            s.hist[tid] = tot;
+        }
+        __syncthreads();
+    } else {
     // ---- P1: per-channel byte histograms (per-wave private copies in the bins area) ------------
     // (Two copies per wave -- even / odd lanes -- were measured: no change, 79.7 k cycles either way; the pass
     //  sits on the LDS atomic issue rate, ~11 cycles per wave instruction per CU, not on address conflicts.)
     unsigned* wh = &s.bins[0][0] + wave_id() * 768;
     for (int i = tid; i < NW * 768; i += NT) (&s.bins[0][0])[i] = 0;
     __syncthreads();
-    const bool grp = groups_ok(p, hw);
     if (grp) {
         for_each_group<NT>(p, hw, [&](long, uint32_t a, uint32_t b, uint32_t c, const WaveGroup& wg) {
             uint32_t rr[4], gg[4], bb[4];
@@ -1118,6 +1181,7 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
     if (tid < 6) s.chm[tid] = chm[tid];
     }
     __syncthreads();
+    }
     if (tid < 64) {  // inclusive prefix over 256 bins: 4 consecutive bins per lane + one wave scan
         const unsigned h0 = s.hist[tid * 4], h1 = s.hist[tid * 4 + 1], h2 = s.hist[tid * 4 + 2], h3 = s.hist[tid * 4 + 3];
         const unsigned incl = wave_incl_scan_u32(h0 + h1 + h2 + h3);
@@ -1784,44 +1848,65 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
         kp[1] = kp[0];
         kn[1] = kn[0];
         gm[1] = gm[0];
-        // rigorous value bounds from the byte range: od in [od(bmax), od(bmin)]
-        const double oa = OD(bmax), ob = OD(bmin);
+        // value bounds and the first histogram window of the histogram path -- needed only when that path runs
         double lo0[2], hi0[2], olo0[2], ohi0[2];
-        const double inv_n = 1.0 / (double)hw;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            double lo = 0.0, hi = 0.0, mu = 0.0;
-            double mj[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const double c = P[j * 2 + t];
-                const double u = c * oa, w = c * ob;
-                lo += u < w ? u : w;
-                hi += u < w ? w : u;
-                mj[j] = s.chm[j] * inv_n;
-                mu += c * mj[j];
+        auto histogram_ranges = [&]() {
+            if constexpr (!DL) {
+                // per-channel moments of od over ALL pixels (the dictionary-learning instantiation has them from its per-channel
+                // byte histograms; here P1 keeps one histogram of all bytes): one extra sweep, on the fall-back / audit path only.
+                // They only place the first histogram window: the selection is exact for any window.
+                double cm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                for_each_pixel<NT>(p, hw, [&](long, uint32_t r, uint32_t g, uint32_t b) {
+                    const double x = OD(r), y = OD(g), z = OD(b);
+                    cm[0] += x;
+                    cm[1] += y;
+                    cm[2] += z;
+                    cm[3] = __builtin_fma(x, x, cm[3]);
+                    cm[4] = __builtin_fma(y, y, cm[4]);
+                    cm[5] = __builtin_fma(z, z, cm[5]);
+                });
+                block_sum(cm, s);
+                if (tid < 6) s.chm[tid] = cm[tid];
+                __syncthreads();
             }
-            // sigma(C_t) <= sum_c |P[c][t]| sigma(od_c) (per-channel moments come from the byte histograms of P1)
-            const double cxx = s.chm[3] * inv_n - mj[0] * mj[0], cyy = s.chm[4] * inv_n - mj[1] * mj[1];
-            const double czz = s.chm[5] * inv_n - mj[2] * mj[2];
-            const double sdev = fabs(P[0 + t]) * sqrt(cxx > 0.0 ? cxx : 0.0) + fabs(P[2 + t]) * sqrt(cyy > 0.0 ? cyy : 0.0) +
-                                fabs(P[4 + t]) * sqrt(czz > 0.0 ? czz : 0.0);
-            const double var = sdev * sdev;
-            const double sg = sqrt(var) * 1.000001 + 1e-12 * (fabs(mu) + 1.0);
-            const double pad = 1e-9 * (fabs(lo) + fabs(hi)) + 1e-12;
-            olo0[t] = lo - pad;
-            ohi0[t] = hi + pad;
-            // histogram window: Chebyshev keeps the 99th percentile inside mu + 12 sigma
-            double wlo = mu - 8.0 * sg, whi = mu + 12.0 * sg;
-            wlo = wlo > olo0[t] ? wlo : olo0[t];
-            whi = whi < ohi0[t] ? whi : ohi0[t];
-            if (!(whi > wlo)) {
-                wlo = olo0[t];
-                whi = ohi0[t];
+            // rigorous value bounds from the byte range: od in [od(bmax), od(bmin)]
+            const double oa = OD(bmax), ob = OD(bmin);
+            const double inv_n = 1.0 / (double)hw;
+    #pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                double lo = 0.0, hi = 0.0, mu = 0.0;
+                double mj[3];
+    #pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double c = P[j * 2 + t];
+                    const double u = c * oa, w = c * ob;
+                    lo += u < w ? u : w;
+                    hi += u < w ? w : u;
+                    mj[j] = s.chm[j] * inv_n;
+                    mu += c * mj[j];
+                }
+                // sigma(C_t) <= sum_c |P[c][t]| sigma(od_c) (per-channel moments come from the byte histograms of P1)
+                const double cxx = s.chm[3] * inv_n - mj[0] * mj[0], cyy = s.chm[4] * inv_n - mj[1] * mj[1];
+                const double czz = s.chm[5] * inv_n - mj[2] * mj[2];
+                const double sdev = fabs(P[0 + t]) * sqrt(cxx > 0.0 ? cxx : 0.0) + fabs(P[2 + t]) * sqrt(cyy > 0.0 ? cyy : 0.0) +
+                                    fabs(P[4 + t]) * sqrt(czz > 0.0 ? czz : 0.0);
+                const double var = sdev * sdev;
+                const double sg = sqrt(var) * 1.000001 + 1e-12 * (fabs(mu) + 1.0);
+                const double pad = 1e-9 * (fabs(lo) + fabs(hi)) + 1e-12;
+                olo0[t] = lo - pad;
+                ohi0[t] = hi + pad;
+                // histogram window: Chebyshev keeps the 99th percentile inside mu + 12 sigma
+                double wlo = mu - 8.0 * sg, whi = mu + 12.0 * sg;
+                wlo = wlo > olo0[t] ? wlo : olo0[t];
+                whi = whi < ohi0[t] ? whi : ohi0[t];
+                if (!(whi > wlo)) {
+                    wlo = olo0[t];
+                    whi = ohi0[t];
+                }
+                lo0[t] = wlo;
+                hi0[t] = whi;
             }
-            lo0[t] = wlo;
-            hi0[t] = whi;
-        }
+        };
         double vp[2], vn[2];
         bool conc_done = false;
         if (prm.select_mode == 0) {
@@ -1882,6 +1967,7 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                 },
                 s, kp, nn, vp, vn);
         }
+        if (!conc_done) histogram_ranges();
         if (!conc_done)
         select2(p, hw,
                 [&](long, uint32_t r, uint32_t g, uint32_t b, double (&x)[2]) -> unsigned {
@@ -1935,9 +2021,7 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
 #if TIA_STATS_TIMING
         if (tid == 0) {
             s.tm[11] = s.st.level[0];
-            s.tm[12] = s.st.level[1];
-            s.tm[13] = (long long)s.st.cnt[0];
-            s.tm[14] = (long long)s.st.cnt[1];
+            s.tm[12] = s.st.level[1];  // (13: failure codes of the window selections, 14: their candidate counts)
         }
 #endif
         maxc[0] = np_lerp(vp[0], vn[0], gm[0]);
@@ -2087,7 +2171,7 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
         uint32_t rgb[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
-            const long idx = ((long)j * RT + tid) * stride;
+            const long idx = sample_index((long)j * RT + tid, stride);
             const long ic = idx < hw ? idx : hw - 1;
             rgb[j] = (uint32_t)p[3 * ic] | ((uint32_t)p[3 * ic + 1] << 8) | ((uint32_t)p[3 * ic + 2] << 16);
         }
@@ -2095,7 +2179,7 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
         unsigned cnt[2] = {0u, 0u};
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
-            const long idx = ((long)j * RT + tid) * stride;
+            const long idx = sample_index((long)j * RT + tid, stride);
             float v[2] = {0.0f, 0.0f};
             const unsigned valid = idx < hw ? sample32(idx, rgb[j] & 255u, (rgb[j] >> 8) & 255u, (rgb[j] >> 16) & 255u, v) : 0u;
 #pragma unroll
