@@ -461,6 +461,7 @@ def test_rgb2od_standalone_kernel_and_side_effect(uniform_patches):
     cases = [uniform_patches[0].copy(), uniform_patches.copy(), rng.integers(0, 4, (1001, 3), dtype=np.uint8),
              rng.integers(0, 3, (7,), dtype=np.uint8), np.zeros((5, 5, 3), np.uint8)]
     for arr in cases:
+        arr.flat[arr.size // 2] = 0
         mine, theirs = arr.copy(), arr.copy()
         assert (mine == 0).any()
         exp = ostain.rgb2od(theirs)                      # mutates ``theirs``
