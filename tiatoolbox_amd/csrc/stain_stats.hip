@@ -31,6 +31,8 @@ constexpr int BPT = NB / NT;     // bins per thread in the scan
 constexpr int MASK_WORDS = 2048;  // tissue-mask bits of patches up to 65536 pixels (256x256); larger ones recompute
 constexpr int SNB = 1024;         // bins of the sample histograms that place the selection windows
 constexpr int SAMPLE_TARGET = 4096;  // pixels sampled to place a window
+constexpr int DL_HIST = 2;           // dictionary-learning iterations whose atom updates can be replayed per pixel (the
+                                     // reference runs max_iter = 3: two rounds of updates, stainextract.py:313)
 
 struct SelState {
     double lo[2][MAXLEVEL + 1];
@@ -69,6 +71,7 @@ struct Smem {
     SelState st;
     double bc[48];
     double chm[6];      // per-channel sum(od), sum(od^2) over all pixels
+    double dlh[DL_HIST][14];  // dictionary learning: per iteration c0[3] a00 a01 | c1[3] a10 a11 | akk0 akk1 n0 n1 (replay, below)
     unsigned long long ubc[8];
     int ibc[8];
     unsigned mbits[MASK_WORDS];  // tissue mask bits of the patch (when it fits)
@@ -1594,6 +1597,62 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
         //      everything else is a handful of whole-patch reductions between sweeps.
         double2* __restrict__ dict = dictws + (size_t)blockIdx.x * (size_t)hw;
         const double alpha = prm.dl_alpha;
+        // REPLAY instead of a materialised dictionary.  In _update_dict the value of atom k at pixel p only depends on x_p (its three
+        // OD values) and on per-iteration SCALARS (the codes, A = code^T code, the atom norms): d_k <- max(0, d_k + (x_p . c_k -
+        // A_k . d) / A_kk), then / max(norm, 1).  So instead of reading and writing the 2 x N float64 dictionary on every one of the
+        // 7 sweeps that follow its initialisation (32 bytes per pixel and sweep from HBM: what this kernel spent its time on), each
+        // sweep recomputes a pixel's atom values from x_p by replaying the iterations so far from the scalars in LDS (s.dlh):
+        // the same operations in the same order, so every bit of the result is what the materialised form gives (which stays as
+        // the path for the rare unused-atom re-draw -- its random values cannot be replayed cheaply -- entered by writing the
+        // replayed state out once -- and for more than DL_HIST iterations).
+        bool mat = prm.dl_max_iter - 1 > DL_HIST;  // true: the dictionary lives in `dict` (uniform)
+        // the recorded scalars as wave-uniform values (scalar registers), refreshed from LDS before every sweep
+        double h[DL_HIST][14];
+        auto load_hist = [&]() {
+#pragma unroll
+            for (int j = 0; j < DL_HIST; ++j)
+#pragma unroll
+                for (int c = 0; c < 14; ++c) {
+                    const double v = s.dlh[j][c];
+                    const long long bits = __double_as_longlong(v);
+                    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(bits >> 32));
+                    h[j][c] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                }
+        };
+        // state of pixel (x, y, z) after `full` completed iterations, plus (stage 1) the update of atom 0 of the next one, or
+        // (stage 2) that update, its normalisation and the update of atom 1 -- exactly what `dict[idx]` holds at those points
+        // one recorded iteration applied to (d.x, d.y): up to and including step `st` (1: atom 0; 2: + its normalisation and atom 1;
+        // 3: + atom 1's normalisation)
+        auto replay_step = [&](const double (&hj)[14], int st, double x, double y, double z, double2& d) {
+            {
+                const double bk = x * hj[0] + y * hj[1] + z * hj[2];
+                const double ad = hj[3] * d.x + hj[4] * d.y;
+                const double v = d.x + (bk - ad) / hj[10];
+                d.x = v < 0.0 ? 0.0 : v;
+            }
+            if (st == 1) return;
+            {
+                d.x = d.x / hj[12];
+                const double bk = x * hj[5] + y * hj[6] + z * hj[7];
+                const double ad = hj[8] * d.x + hj[9] * d.y;
+                const double v = d.y + (bk - ad) / hj[11];
+                d.y = v < 0.0 ? 0.0 : v;
+            }
+            if (st == 2) return;
+            d.y = d.y / hj[13];
+        };
+        static_assert(DL_HIST == 2, "replay() spells its two recorded iterations out (constant indices keep them in registers)");
+        auto replay = [&](double x, double y, double z, double u00, double u10, double u20, double u01, double u11, double u21, int full,
+                          int stage) -> double2 {
+            double2 d;
+            d.x = dot3(x, y, z, u00, u10, u20);
+            d.y = dot3(x, y, z, u01, u11, u21);
+            const int st0 = full > 0 ? 3 : stage;
+            if (st0) replay_step(h[0], st0, x, y, z, d);
+            const int st1 = full > 1 ? 3 : (full == 1 ? stage : 0);
+            if (st1) replay_step(h[1], st1, x, y, z, d);
+            return d;
+        };
         // S0: uncentred second moments of the tissue OD (X X^T), tissue sums, all-pixel cross moments
         double acc[10];
 #pragma unroll
@@ -1671,15 +1730,25 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
             gc[8] = __builtin_fma(d1, z, gc[8]);
         };
         gram_cov_reset();
+        const double u00 = code[0][0], u10 = code[1][0], u20 = code[2][0], u01 = code[0][1], u11 = code[1][1], u21 = code[2][1];
         for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
             if (!is_tissue(r, g, b)) return;
             const double x = OD(r), y = OD(g), z = OD(b);
             const double d0 = dot3(x, y, z, code[0][0], code[1][0], code[2][0]);
             const double d1 = dot3(x, y, z, code[0][1], code[1][1], code[2][1]);
-            dict[idx] = make_double2(d0, d1);
+            if (mat) dict[idx] = make_double2(d0, d1);
             gram_cov_add(d0, d1, x, y, z);
         });
         block_sum(gc, s);
+        // replayed state -> `dict` (from here on the materialised form runs): `full` completed iterations + `stage`
+        auto materialise = [&](int full, int stage) {
+            load_hist();
+            for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+                if (!is_tissue(r, g, b)) return;
+                dict[idx] = replay(OD(r), OD(g), OD(b), u00, u10, u20, u01, u11, u21, full, stage);
+            });
+            mat = true;
+        };
         double cost_prev = 0.0;
         int n_iter = 0;
         for (int it = 0; it < prm.dl_max_iter; ++it) {
@@ -1717,9 +1786,22 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                 break;
             }
             double nrm0 = 1.0, nrm1 = 1.0;
+            // the scalars of this iteration's atom updates (all lanes hold the same values; lane 0 publishes them)
+            if (!mat) {
+                __syncthreads();
+                if (tid == 0) {
+                    double* hj = s.dlh[it];
+                    hj[0] = code[0][0], hj[1] = code[1][0], hj[2] = code[2][0], hj[3] = A[0][0], hj[4] = A[0][1];
+                    hj[5] = code[0][1], hj[6] = code[1][1], hj[7] = code[2][1], hj[8] = A[1][0], hj[9] = A[1][1];
+                    hj[10] = A[0][0], hj[11] = A[1][1], hj[12] = 1.0, hj[13] = 1.0;
+                }
+                __syncthreads();
+                load_hist();
+            }
             auto update_atom = [&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 const bool used = A[k][k] > 1e-6;
+                if (!used && !mat) materialise(it, k);  // (k = 1: atom 0 of this iteration already updated, not yet normalised)
                 int pick = 0;
                 double level = 0.0;
                 if (!used) {  // atom (almost) never used: re-draw it from the data plus a little noise
@@ -1743,14 +1825,14 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                     for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
                         if (!is_tissue(r, g, b)) return;
                         const double x = OD(r), y = OD(g), z = OD(b);
-                        double2 d = dict[idx];
+                        double2 d = mat ? dict[idx] : replay(x, y, z, u00, u10, u20, u01, u11, u21, it, k);
                         if (k == 1) d.x = d.x / n0;  // dictionary[0] /= max(norm, 1)
                         const double bk = x * ck0 + y * ck1 + z * ck2;           // B[:, k]
                         const double ad = ak0 * d.x + ak1 * d.y;                 // A[k] @ dictionary
                         double v = (k == 0 ? d.x : d.y) + (bk - ad) / akk;
                         v = v < 0.0 ? 0.0 : v;  // positive_dict
                         if (k == 0) d.x = v; else d.y = v;
-                        dict[idx] = d;
+                        if (mat) dict[idx] = d;
                         nn2[0] = __builtin_fma(v, v, nn2[0]);
                     });
                 } else {  // rare: plain loop, keeps the transcendental code out of the unrolled sweep
@@ -1770,6 +1852,11 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                 block_sum(nn2, s);
                 const double nv = sqrt(nn2[0]);
                 (k == 0 ? nrm0 : nrm1) = nv > 1.0 ? nv : 1.0;
+                if (!mat) {  // the norm joins the iteration's record (block_sum ended with a barrier: nobody is reading s.dlh)
+                    if (tid == 0) s.dlh[it][12 + k] = nv > 1.0 ? nv : 1.0;
+                    __syncthreads();
+                    load_hist();
+                }
             };
             update_atom(std::integral_constant<int, 0>{});
             update_atom(std::integral_constant<int, 1>{});
@@ -1780,9 +1867,9 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
             for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
                 if (!is_tissue(r, g, b)) return;
                 const double x = OD(r), y = OD(g), z = OD(b);
-                double2 d = dict[idx];
+                double2 d = mat ? dict[idx] : replay(x, y, z, u00, u10, u20, u01, u11, u21, it, 2);
                 d.y = d.y / n1;
-                dict[idx] = d;
+                if (mat) dict[idx] = d;
                 const double ex = x - (code[0][0] * d.x + code[0][1] * d.y);
                 const double ey = y - (code[1][0] * d.x + code[1][1] * d.y);
                 const double ez = z - (code[2][0] * d.x + code[2][1] * d.y);
