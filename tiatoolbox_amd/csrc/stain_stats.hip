@@ -71,7 +71,7 @@ struct Smem {
     SelState st;
     double bc[48];
     double chm[6];      // per-channel sum(od), sum(od^2) over all pixels
-    double dlh[DL_HIST][14];  // dictionary learning: per iteration c0[3] a00 a01 | c1[3] a10 a11 | akk0 akk1 n0 n1 (replay, below)
+    double dlh[DL_HIST][18];  // dictionary learning: per iteration c0[3] a00 a01 | c1[3] a10 a11 | akk0 akk1 n0 n1 | their reciprocals
     unsigned long long ubc[8];
     int ibc[8];
     unsigned mbits[MASK_WORDS];  // tissue mask bits of the patch (when it fits)
@@ -1605,14 +1605,23 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
         // the same operations in the same order, so every bit of the result is what the materialised form gives (which stays as
         // the path for the rare unused-atom re-draw -- its random values cannot be replayed cheaply -- entered by writing the
         // replayed state out once -- and for more than DL_HIST iterations).
-        bool mat = prm.dl_max_iter - 1 > DL_HIST;  // true: the dictionary lives in `dict` (uniform)
+        // Divisions: every divisor of the updates is a per-iteration scalar, so the replayed steps (and the sweeps' own last
+        // steps) divide with Markstein's sequence q = a y, r = fma(-b, q, a), q' = fma(r, y, q) on the correctly rounded reciprocal
+        // y = 1 / b computed once per sweep: q' IS the correctly rounded quotient a / b (y correctly rounded, q faithful), in three
+        // full-rate instructions instead of the ~15 partly quarter-rate ones of a float64 division.  The materialised form keeps
+        // the plain divisions; `dl_materialise` selects it for the whole run (parity audit: both must give the same bits).
+        bool mat = prm.dl_max_iter - 1 > DL_HIST || prm.dl_materialise != 0;  // true: the dictionary lives in `dict` (uniform)
+        auto div_by = [](double a, double b, double y) -> double {
+            const double q = a * y;
+            return __builtin_fma(__builtin_fma(-b, q, a), y, q);
+        };
         // the recorded scalars as wave-uniform values (scalar registers), refreshed from LDS before every sweep
-        double h[DL_HIST][14];
+        double h[DL_HIST][18];
         auto load_hist = [&]() {
 #pragma unroll
             for (int j = 0; j < DL_HIST; ++j)
 #pragma unroll
-                for (int c = 0; c < 14; ++c) {
+                for (int c = 0; c < 18; ++c) {
                     const double v = s.dlh[j][c];
                     const long long bits = __double_as_longlong(v);
                     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(bits >> 32));
@@ -1623,23 +1632,23 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
         // (stage 2) that update, its normalisation and the update of atom 1 -- exactly what `dict[idx]` holds at those points
         // one recorded iteration applied to (d.x, d.y): up to and including step `st` (1: atom 0; 2: + its normalisation and atom 1;
         // 3: + atom 1's normalisation)
-        auto replay_step = [&](const double (&hj)[14], int st, double x, double y, double z, double2& d) {
+        auto replay_step = [&](const double (&hj)[18], int st, double x, double y, double z, double2& d) {
             {
                 const double bk = x * hj[0] + y * hj[1] + z * hj[2];
                 const double ad = hj[3] * d.x + hj[4] * d.y;
-                const double v = d.x + (bk - ad) / hj[10];
+                const double v = d.x + div_by(bk - ad, hj[10], hj[14]);
                 d.x = v < 0.0 ? 0.0 : v;
             }
             if (st == 1) return;
             {
-                d.x = d.x / hj[12];
+                d.x = div_by(d.x, hj[12], hj[16]);
                 const double bk = x * hj[5] + y * hj[6] + z * hj[7];
                 const double ad = hj[8] * d.x + hj[9] * d.y;
-                const double v = d.y + (bk - ad) / hj[11];
+                const double v = d.y + div_by(bk - ad, hj[11], hj[15]);
                 d.y = v < 0.0 ? 0.0 : v;
             }
             if (st == 2) return;
-            d.y = d.y / hj[13];
+            d.y = div_by(d.y, hj[13], hj[17]);
         };
         static_assert(DL_HIST == 2, "replay() spells its two recorded iterations out (constant indices keep them in registers)");
         auto replay = [&](double x, double y, double z, double u00, double u10, double u20, double u01, double u11, double u21, int full,
@@ -1794,6 +1803,7 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                     hj[0] = code[0][0], hj[1] = code[1][0], hj[2] = code[2][0], hj[3] = A[0][0], hj[4] = A[0][1];
                     hj[5] = code[0][1], hj[6] = code[1][1], hj[7] = code[2][1], hj[8] = A[1][0], hj[9] = A[1][1];
                     hj[10] = A[0][0], hj[11] = A[1][1], hj[12] = 1.0, hj[13] = 1.0;
+                    hj[14] = 1.0 / A[0][0], hj[15] = 1.0 / A[1][1], hj[16] = 1.0, hj[17] = 1.0;
                 }
                 __syncthreads();
                 load_hist();
@@ -1818,6 +1828,7 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                 const double akk = A[k][k], ak0 = A[k][0], ak1 = A[k][1];
                 const double ck0 = code[0][k], ck1 = code[1][k], ck2 = code[2][k];
                 const double n0 = nrm0;  // atom 0 is divided by its norm lazily, while atom 1 is updated
+                const double inv_n0 = 1.0 / n0, inv_akk = 1.0 / akk;
                 double nn2[1] = {0.0};
                 const unsigned long long nkey = mix64((unsigned long long)prm.dl_seed ^ ((unsigned long long)blockIdx.x << 32) ^
                                                       (unsigned long long)(it * 2 + k + 1));
@@ -1826,10 +1837,10 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                         if (!is_tissue(r, g, b)) return;
                         const double x = OD(r), y = OD(g), z = OD(b);
                         double2 d = mat ? dict[idx] : replay(x, y, z, u00, u10, u20, u01, u11, u21, it, k);
-                        if (k == 1) d.x = d.x / n0;  // dictionary[0] /= max(norm, 1)
+                        if (k == 1) d.x = mat ? d.x / n0 : div_by(d.x, n0, inv_n0);  // dictionary[0] /= max(norm, 1)
                         const double bk = x * ck0 + y * ck1 + z * ck2;           // B[:, k]
                         const double ad = ak0 * d.x + ak1 * d.y;                 // A[k] @ dictionary
-                        double v = (k == 0 ? d.x : d.y) + (bk - ad) / akk;
+                        double v = (k == 0 ? d.x : d.y) + (mat ? (bk - ad) / akk : div_by(bk - ad, akk, inv_akk));
                         v = v < 0.0 ? 0.0 : v;  // positive_dict
                         if (k == 0) d.x = v; else d.y = v;
                         if (mat) dict[idx] = d;
@@ -1853,7 +1864,10 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                 const double nv = sqrt(nn2[0]);
                 (k == 0 ? nrm0 : nrm1) = nv > 1.0 ? nv : 1.0;
                 if (!mat) {  // the norm joins the iteration's record (block_sum ended with a barrier: nobody is reading s.dlh)
-                    if (tid == 0) s.dlh[it][12 + k] = nv > 1.0 ? nv : 1.0;
+                    if (tid == 0) {
+                        s.dlh[it][12 + k] = nv > 1.0 ? nv : 1.0;
+                        s.dlh[it][16 + k] = 1.0 / (nv > 1.0 ? nv : 1.0);
+                    }
                     __syncthreads();
                     load_hist();
                 }
@@ -1861,14 +1875,14 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
             update_atom(std::integral_constant<int, 0>{});
             update_atom(std::integral_constant<int, 1>{});
             // atom 1's normalisation is applied in the sweep that evaluates the cost and prepares the next coding
-            const double n1 = nrm1;
+            const double n1 = nrm1, inv_n1 = 1.0 / nrm1;
             double cst[1] = {0.0};
             gram_cov_reset();
             for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
                 if (!is_tissue(r, g, b)) return;
                 const double x = OD(r), y = OD(g), z = OD(b);
                 double2 d = mat ? dict[idx] : replay(x, y, z, u00, u10, u20, u01, u11, u21, it, 2);
-                d.y = d.y / n1;
+                d.y = mat ? d.y / n1 : div_by(d.y, n1, inv_n1);
                 if (mat) dict[idx] = d;
                 const double ex = x - (code[0][0] * d.x + code[0][1] * d.y);
                 const double ey = y - (code[1][0] * d.x + code[1][1] * d.y);

@@ -33,7 +33,10 @@ def rgb2od(img, *, mutate: bool = True):
     else:
         arr = np.asarray(img)
         same_storage = False
-        dev_img = torch.from_numpy(np.ascontiguousarray(arr.astype(np.uint8, copy=False))).to(_tensors.default_device())
+        host = np.ascontiguousarray(arr.astype(np.uint8, copy=False))
+        if not host.flags.writeable:  # torch refuses to wrap read-only memory silently
+            host = host.copy()
+        dev_img = torch.from_numpy(host).to(_tensors.default_device())
     out = torch.empty(dev_img.shape, dtype=torch.float64, device=dev_img.device)
     if dev_img.numel():
         lib = _lib.load()
