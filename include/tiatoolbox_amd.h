@@ -106,10 +106,7 @@ typedef struct tia_stain_params {
     int32_t dl_seed;        /* stream of the unused-atom re-draw (the reference is unseeded)  */
     int32_t select_mode;    /* order statistics: 0 = sample-placed windows (one float32 sweep + exact candidates) with the
                                histogram path as fall-back; 1 = histogram path only (same results; parity audit)       */
-    int32_t dl_materialise; /* TIA_MODE_VAHADANE: 0 = the atom values of a pixel are recomputed per sweep from per-iteration scalars
-                               (no dictionary traffic, divisions by Markstein's reciprocal sequence); 1 = the 2 x N float64
-                               dictionary is kept in the workspace and read / written by every sweep, plain divisions (same
-                               results bit for bit; parity audit).  Was `reserved` (0) before ABI version 4. */
+    int32_t reserved;
 } tia_stain_params;
 
 /*

@@ -31,8 +31,6 @@ constexpr int BPT = NB / NT;     // bins per thread in the scan
 constexpr int MASK_WORDS = 2048;  // tissue-mask bits of patches up to 65536 pixels (256x256); larger ones recompute
 constexpr int SNB = 1024;         // bins of the sample histograms that place the selection windows
 constexpr int SAMPLE_TARGET = 4096;  // pixels sampled to place a window
-constexpr int DL_HIST = 2;           // dictionary-learning iterations whose atom updates can be replayed per pixel (the
-                                     // reference runs max_iter = 3: two rounds of updates, stainextract.py:313)
 
 struct SelState {
     double lo[2][MAXLEVEL + 1];
@@ -71,7 +69,6 @@ struct Smem {
     SelState st;
     double bc[48];
     double chm[6];      // per-channel sum(od), sum(od^2) over all pixels
-    double dlh[DL_HIST][18];  // dictionary learning: per iteration c0[3] a00 a01 | c1[3] a10 a11 | akk0 akk1 n0 n1 | their reciprocals
     unsigned long long ubc[8];
     int ibc[8];
     unsigned mbits[MASK_WORDS];  // tissue mask bits of the patch (when it fits)
@@ -1050,11 +1047,77 @@ __device__ __noinline__ double normal_of(unsigned long long key) {
 // ---------------------------------------------------------------------------------------
 // DL = true: the TIA_MODE_VAHADANE instantiation (dictionary learning instead of the Macenko branch); kept apart so that
 // its extra live state does not cost the Macenko / fixed-matrix kernel registers.
+// Sweep over a patch TOGETHER WITH its per-pixel float64 pairs (the Vahadane dictionary: 2 x N as double2[N]), software-pipelined:
+// a lane owns 4-pixel groups (12 image bytes and 64 contiguous dictionary bytes), and the NEXT group's image words and dictionary
+// entries are requested before the current group is processed.  `f(idx, r, g, b, d)` is called per pixel in ascending order
+// (the per-pixel sweep's order, so thread-local sums come out bit-identical) and may modify `d`; with STORE every entry of the
+// group is written back (entries `f` does not touch -- non-tissue pixels -- are rewritten with what was loaded).  The dictionary-
+// learning instantiation runs one workgroup per CU at two waves per SIMD: a sweep that tests the tissue mask first and only then
+// asks for the pixel's dictionary entry pays one full memory latency per PIXEL with nothing to hide it behind (measured: 4.5 ms per
+// sweep over 8192 x 256^2 for 26 GB/s x ... of traffic); here one latency per group is overlapped with the previous group's work.
+template <int NT_, bool LOAD, bool STORE, class F>
+__device__ __forceinline__ void for_each_pixel_dict(const uint8_t* __restrict__ p, long hw, double2* __restrict__ dict, F&& f) {
+    if (!groups_ok(p, hw)) {
+        for (long i = threadIdx.x; i < hw; i += NT_) {
+            double2 d = LOAD ? dict[i] : make_double2(0.0, 0.0);
+            f(i, (uint32_t)p[3 * i], (uint32_t)p[3 * i + 1], (uint32_t)p[3 * i + 2], d);
+            if (STORE) dict[i] = d;
+        }
+        return;
+    }
+    const long ng = hw >> 2;
+    const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
+    long g = threadIdx.x;
+    uint32_t a = 0, b = 0, c = 0;
+    double2 d[4], nd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = nd[i] = make_double2(0.0, 0.0);
+    if (g < ng) {
+        a = q[g * 3 + 0];
+        b = q[g * 3 + 1];
+        c = q[g * 3 + 2];
+        if (LOAD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = dict[g * 4 + i];
+        }
+    }
+    while (g < ng) {
+        const long gn = g + NT_;
+        uint32_t na = 0, nb = 0, nc = 0;
+        if (gn < ng) {
+            na = q[gn * 3 + 0];
+            nb = q[gn * 3 + 1];
+            nc = q[gn * 3 + 2];
+            if (LOAD) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nd[i] = dict[gn * 4 + i];
+            }
+        }
+        uint32_t rr[4], gg[4], bb[4];
+        unpack_group(a, b, c, rr, gg, bb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f(g * 4 + i, rr[i], gg[i], bb[i], d[i]);
+        if (STORE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dict[g * 4 + i] = d[i];
+        }
+        a = na;
+        b = nb;
+        c = nc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = nd[i];
+        g = gn;
+    }
+}
+
 template <bool DL>
 #ifndef TIA_STATS_WPE
 #define TIA_STATS_WPE 4  // waves per SIMD the Macenko / fixed-matrix instantiation is compiled for (2 work-groups per CU by LDS)
 #endif
-__global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel(const uint8_t* __restrict__ img, long hw,
+#ifndef TIA_STATS_WPE_DL
+#define TIA_STATS_WPE_DL 2  // ... and the dictionary-learning instantiation (2: 256 VGPRs, one work-group per CU)
+#endif
+__global__ __launch_bounds__(NT, DL ? TIA_STATS_WPE_DL : TIA_STATS_WPE) void stain_stats_kernel(const uint8_t* __restrict__ img, long hw,
                                                           const tia_stain_tables* __restrict__ tab,
                                                           tia_stain_params prm,
                                                           double* __restrict__ stats,
@@ -1597,71 +1660,6 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
         //      everything else is a handful of whole-patch reductions between sweeps.
         double2* __restrict__ dict = dictws + (size_t)blockIdx.x * (size_t)hw;
         const double alpha = prm.dl_alpha;
-        // REPLAY instead of a materialised dictionary.  In _update_dict the value of atom k at pixel p only depends on x_p (its three
-        // OD values) and on per-iteration SCALARS (the codes, A = code^T code, the atom norms): d_k <- max(0, d_k + (x_p . c_k -
-        // A_k . d) / A_kk), then / max(norm, 1).  So instead of reading and writing the 2 x N float64 dictionary on every one of the
-        // 7 sweeps that follow its initialisation (32 bytes per pixel and sweep from HBM: what this kernel spent its time on), each
-        // sweep recomputes a pixel's atom values from x_p by replaying the iterations so far from the scalars in LDS (s.dlh):
-        // the same operations in the same order, so every bit of the result is what the materialised form gives (which stays as
-        // the path for the rare unused-atom re-draw -- its random values cannot be replayed cheaply -- entered by writing the
-        // replayed state out once -- and for more than DL_HIST iterations).
-        // Divisions: every divisor of the updates is a per-iteration scalar, so the replayed steps (and the sweeps' own last
-        // steps) divide with Markstein's sequence q = a y, r = fma(-b, q, a), q' = fma(r, y, q) on the correctly rounded reciprocal
-        // y = 1 / b computed once per sweep: q' IS the correctly rounded quotient a / b (y correctly rounded, q faithful), in three
-        // full-rate instructions instead of the ~15 partly quarter-rate ones of a float64 division.  The materialised form keeps
-        // the plain divisions; `dl_materialise` selects it for the whole run (parity audit: both must give the same bits).
-        bool mat = prm.dl_max_iter - 1 > DL_HIST || prm.dl_materialise != 0;  // true: the dictionary lives in `dict` (uniform)
-        auto div_by = [](double a, double b, double y) -> double {
-            const double q = a * y;
-            return __builtin_fma(__builtin_fma(-b, q, a), y, q);
-        };
-        // the recorded scalars as wave-uniform values (scalar registers), refreshed from LDS before every sweep
-        double h[DL_HIST][18];
-        auto load_hist = [&]() {
-#pragma unroll
-            for (int j = 0; j < DL_HIST; ++j)
-#pragma unroll
-                for (int c = 0; c < 18; ++c) {
-                    const double v = s.dlh[j][c];
-                    const long long bits = __double_as_longlong(v);
-                    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bits), hi = __builtin_amdgcn_readfirstlane((unsigned)(bits >> 32));
-                    h[j][c] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-                }
-        };
-        // state of pixel (x, y, z) after `full` completed iterations, plus (stage 1) the update of atom 0 of the next one, or
-        // (stage 2) that update, its normalisation and the update of atom 1 -- exactly what `dict[idx]` holds at those points
-        // one recorded iteration applied to (d.x, d.y): up to and including step `st` (1: atom 0; 2: + its normalisation and atom 1;
-        // 3: + atom 1's normalisation)
-        auto replay_step = [&](const double (&hj)[18], int st, double x, double y, double z, double2& d) {
-            {
-                const double bk = x * hj[0] + y * hj[1] + z * hj[2];
-                const double ad = hj[3] * d.x + hj[4] * d.y;
-                const double v = d.x + div_by(bk - ad, hj[10], hj[14]);
-                d.x = v < 0.0 ? 0.0 : v;
-            }
-            if (st == 1) return;
-            {
-                d.x = div_by(d.x, hj[12], hj[16]);
-                const double bk = x * hj[5] + y * hj[6] + z * hj[7];
-                const double ad = hj[8] * d.x + hj[9] * d.y;
-                const double v = d.y + div_by(bk - ad, hj[11], hj[15]);
-                d.y = v < 0.0 ? 0.0 : v;
-            }
-            if (st == 2) return;
-            d.y = div_by(d.y, hj[13], hj[17]);
-        };
-        static_assert(DL_HIST == 2, "replay() spells its two recorded iterations out (constant indices keep them in registers)");
-        auto replay = [&](double x, double y, double z, double u00, double u10, double u20, double u01, double u11, double u21, int full,
-                          int stage) -> double2 {
-            double2 d;
-            d.x = dot3(x, y, z, u00, u10, u20);
-            d.y = dot3(x, y, z, u01, u11, u21);
-            const int st0 = full > 0 ? 3 : stage;
-            if (st0) replay_step(h[0], st0, x, y, z, d);
-            const int st1 = full > 1 ? 3 : (full == 1 ? stage : 0);
-            if (st1) replay_step(h[1], st1, x, y, z, d);
-            return d;
-        };
         // S0: uncentred second moments of the tissue OD (X X^T), tissue sums, all-pixel cross moments
         double acc[10];
 #pragma unroll
@@ -1739,25 +1737,15 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
             gc[8] = __builtin_fma(d1, z, gc[8]);
         };
         gram_cov_reset();
-        const double u00 = code[0][0], u10 = code[1][0], u20 = code[2][0], u01 = code[0][1], u11 = code[1][1], u21 = code[2][1];
-        for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+        for_each_pixel_dict<NT, false, true>(p, hw, dict, [&](long, uint32_t r, uint32_t g, uint32_t b, double2& d) {
             if (!is_tissue(r, g, b)) return;
             const double x = OD(r), y = OD(g), z = OD(b);
             const double d0 = dot3(x, y, z, code[0][0], code[1][0], code[2][0]);
             const double d1 = dot3(x, y, z, code[0][1], code[1][1], code[2][1]);
-            if (mat) dict[idx] = make_double2(d0, d1);
+            d = make_double2(d0, d1);
             gram_cov_add(d0, d1, x, y, z);
         });
         block_sum(gc, s);
-        // replayed state -> `dict` (from here on the materialised form runs): `full` completed iterations + `stage`
-        auto materialise = [&](int full, int stage) {
-            load_hist();
-            for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
-                if (!is_tissue(r, g, b)) return;
-                dict[idx] = replay(OD(r), OD(g), OD(b), u00, u10, u20, u01, u11, u21, full, stage);
-            });
-            mat = true;
-        };
         double cost_prev = 0.0;
         int n_iter = 0;
         for (int it = 0; it < prm.dl_max_iter; ++it) {
@@ -1795,23 +1783,9 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                 break;
             }
             double nrm0 = 1.0, nrm1 = 1.0;
-            // the scalars of this iteration's atom updates (all lanes hold the same values; lane 0 publishes them)
-            if (!mat) {
-                __syncthreads();
-                if (tid == 0) {
-                    double* hj = s.dlh[it];
-                    hj[0] = code[0][0], hj[1] = code[1][0], hj[2] = code[2][0], hj[3] = A[0][0], hj[4] = A[0][1];
-                    hj[5] = code[0][1], hj[6] = code[1][1], hj[7] = code[2][1], hj[8] = A[1][0], hj[9] = A[1][1];
-                    hj[10] = A[0][0], hj[11] = A[1][1], hj[12] = 1.0, hj[13] = 1.0;
-                    hj[14] = 1.0 / A[0][0], hj[15] = 1.0 / A[1][1], hj[16] = 1.0, hj[17] = 1.0;
-                }
-                __syncthreads();
-                load_hist();
-            }
             auto update_atom = [&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 const bool used = A[k][k] > 1e-6;
-                if (!used && !mat) materialise(it, k);  // (k = 1: atom 0 of this iteration already updated, not yet normalised)
                 int pick = 0;
                 double level = 0.0;
                 if (!used) {  // atom (almost) never used: re-draw it from the data plus a little noise
@@ -1828,22 +1802,19 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                 const double akk = A[k][k], ak0 = A[k][0], ak1 = A[k][1];
                 const double ck0 = code[0][k], ck1 = code[1][k], ck2 = code[2][k];
                 const double n0 = nrm0;  // atom 0 is divided by its norm lazily, while atom 1 is updated
-                const double inv_n0 = 1.0 / n0, inv_akk = 1.0 / akk;
                 double nn2[1] = {0.0};
                 const unsigned long long nkey = mix64((unsigned long long)prm.dl_seed ^ ((unsigned long long)blockIdx.x << 32) ^
                                                       (unsigned long long)(it * 2 + k + 1));
                 if (used) {
-                    for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+                    for_each_pixel_dict<NT, true, true>(p, hw, dict, [&](long, uint32_t r, uint32_t g, uint32_t b, double2& d) {
                         if (!is_tissue(r, g, b)) return;
                         const double x = OD(r), y = OD(g), z = OD(b);
-                        double2 d = mat ? dict[idx] : replay(x, y, z, u00, u10, u20, u01, u11, u21, it, k);
-                        if (k == 1) d.x = mat ? d.x / n0 : div_by(d.x, n0, inv_n0);  // dictionary[0] /= max(norm, 1)
+                        if (k == 1) d.x = d.x / n0;  // dictionary[0] /= max(norm, 1)
                         const double bk = x * ck0 + y * ck1 + z * ck2;           // B[:, k]
                         const double ad = ak0 * d.x + ak1 * d.y;                 // A[k] @ dictionary
-                        double v = (k == 0 ? d.x : d.y) + (mat ? (bk - ad) / akk : div_by(bk - ad, akk, inv_akk));
+                        double v = (k == 0 ? d.x : d.y) + (bk - ad) / akk;
                         v = v < 0.0 ? 0.0 : v;  // positive_dict
                         if (k == 0) d.x = v; else d.y = v;
-                        if (mat) dict[idx] = d;
                         nn2[0] = __builtin_fma(v, v, nn2[0]);
                     });
                 } else {  // rare: plain loop, keeps the transcendental code out of the unrolled sweep
@@ -1863,27 +1834,17 @@ __global__ __launch_bounds__(NT, DL ? 2 : TIA_STATS_WPE) void stain_stats_kernel
                 block_sum(nn2, s);
                 const double nv = sqrt(nn2[0]);
                 (k == 0 ? nrm0 : nrm1) = nv > 1.0 ? nv : 1.0;
-                if (!mat) {  // the norm joins the iteration's record (block_sum ended with a barrier: nobody is reading s.dlh)
-                    if (tid == 0) {
-                        s.dlh[it][12 + k] = nv > 1.0 ? nv : 1.0;
-                        s.dlh[it][16 + k] = 1.0 / (nv > 1.0 ? nv : 1.0);
-                    }
-                    __syncthreads();
-                    load_hist();
-                }
             };
             update_atom(std::integral_constant<int, 0>{});
             update_atom(std::integral_constant<int, 1>{});
             // atom 1's normalisation is applied in the sweep that evaluates the cost and prepares the next coding
-            const double n1 = nrm1, inv_n1 = 1.0 / nrm1;
+            const double n1 = nrm1;
             double cst[1] = {0.0};
             gram_cov_reset();
-            for_each_pixel<NT>(p, hw, [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+            for_each_pixel_dict<NT, true, true>(p, hw, dict, [&](long, uint32_t r, uint32_t g, uint32_t b, double2& d) {
                 if (!is_tissue(r, g, b)) return;
                 const double x = OD(r), y = OD(g), z = OD(b);
-                double2 d = mat ? dict[idx] : replay(x, y, z, u00, u10, u20, u01, u11, u21, it, 2);
-                d.y = mat ? d.y / n1 : div_by(d.y, n1, inv_n1);
-                if (mat) dict[idx] = d;
+                d.y = d.y / n1;
                 const double ex = x - (code[0][0] * d.x + code[0][1] * d.y);
                 const double ey = y - (code[1][0] * d.x + code[1][1] * d.y);
                 const double ez = z - (code[2][0] * d.x + code[2][1] * d.y);
