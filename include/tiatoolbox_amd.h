@@ -106,7 +106,10 @@ typedef struct tia_stain_params {
     int32_t dl_seed;        /* stream of the unused-atom re-draw (the reference is unseeded)  */
     int32_t select_mode;    /* order statistics: 0 = sample-placed windows (one float32 sweep + exact candidates) with the
                                histogram path as fall-back; 1 = histogram path only (same results; parity audit)       */
-    int32_t reserved;
+    int32_t dl_one_kernel;  /* TIA_MODE_VAHADANE, parity audit: 0 = the kernel pair (dictionary learning by per-pixel replay of
+                               the atom updates -- no dictionary in memory -- followed by the common tail); 1 = the one-kernel form
+                               that keeps the 2 x N float64 dictionary in the workspace.  Same results bit for bit.  (Was
+                               `reserved`, 0, before ABI version 4.) */
 } tia_stain_params;
 
 /*

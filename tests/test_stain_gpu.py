@@ -556,3 +556,36 @@ def test_refused_host_register_does_not_poison_the_next_launch(he_patches):
         assert norm.transform(arr).shape == arr.shape                     # would raise HipLibraryError(TIA_ELAUNCH) otherwise
     finally:
         lib.tia_clear_last_error()
+
+
+@pytest.mark.gpu
+def test_vahadane_kernel_pair_equals_one_kernel_form(he_patches, target_image):
+    """Default Vahadane statistics = two kernels: dictionary learning that REPLAYS a pixel's atom updates from per-iteration
+    scalars (no 2 x N dictionary in memory; divisions by those scalars through Markstein's reciprocal sequence), then the common
+    tail.  ``dl_one_kernel=True`` keeps the dictionary in the workspace (plain divisions).  Same arithmetic on the same values in
+    the same order: every statistic must be BIT-identical -- H&E-like patches, uniform noise (an atom can become unused: the
+    hand-back path), odd sizes, a large image, several regularisers, a white patch (empty mask), and more iterations than the
+    replay records (handed back as a whole)."""
+    import torch
+
+    from tiatoolbox_amd import _lib
+    from tiatoolbox_amd.tools import _stain_device as dev
+
+    target = np.array([[0.55, 0.76, 0.35], [0.1, 0.96, 0.27]])
+    mixed = he_patches.copy()
+    mixed[3] = 255
+    batches = [mixed, synth.g_he(6, 224, 224, seed=40), synth.g_uniform(4, 128, 128, seed=6), synth.g_he(3, 37, 41, seed=41),
+               np.ascontiguousarray(np.tile(target_image, (2, 2, 1))[None, :500, :470])]
+    checked = 0
+    for batch in batches:
+        x = torch.from_numpy(batch).cuda()
+        for alpha in (0.1, 0.02, 0.6, 5.0):
+            for iters in (3, 2, 1, 6):
+                kw = {"mode": _lib.MODE_VAHADANE, "dl_alpha": alpha, "dl_max_iter": iters, "target_stain": target,
+                      "target_maxc": np.array([[1.9, 1.0]])}
+                a = dev.stain_stats(x, dev.make_params(**kw)).cpu().numpy()[:, :_lib.ST_CYCLES]
+                b = dev.stain_stats(x, dev.make_params(dl_one_kernel=True, **kw)).cpu().numpy()[:, :_lib.ST_CYCLES]
+                same = (a == b) | (np.isnan(a) & np.isnan(b))
+                assert same.all(), (batch.shape, alpha, iters, np.argwhere(~same)[:5], a[~same][:5], b[~same][:5])
+                checked += a.shape[0]
+    assert checked >= 300

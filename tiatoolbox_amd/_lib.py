@@ -38,7 +38,7 @@ class StainParams(C.Structure):
         ("target_stain", C.c_double * 6), ("target_maxc", C.c_double * 2), ("y_thr", C.c_int32),
         ("mode", C.c_int32), ("has_target", C.c_int32), ("zero_to_one", C.c_int32),
         ("dl_alpha", C.c_double), ("dl_tol", C.c_double), ("dl_max_iter", C.c_int32), ("dl_seed", C.c_int32),
-        ("select_mode", C.c_int32), ("reserved", C.c_int32),
+        ("select_mode", C.c_int32), ("dl_one_kernel", C.c_int32),
     ]
 
 

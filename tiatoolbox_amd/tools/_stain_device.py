@@ -60,9 +60,11 @@ def as_batch(img: torch.Tensor) -> torch.Tensor:
 def make_params(*, mode: int, luminosity_threshold: float = 0.8, angular_percentile: float = 99,
                 stain_fixed: np.ndarray | None = None, target_stain: np.ndarray | None = None,
                 target_maxc: np.ndarray | None = None, zero_to_one: bool = False, dl_alpha: float = 0.1,
-                dl_tol: float = 1e-8, dl_max_iter: int = 3, dl_seed: int = 0, select_mode: int = 0) -> _lib.StainParams:
+                dl_tol: float = 1e-8, dl_max_iter: int = 3, dl_seed: int = 0, select_mode: int = 0,
+                dl_one_kernel: bool = False) -> _lib.StainParams:
     p = _lib.StainParams()
     p.select_mode = int(select_mode)
+    p.dl_one_kernel = int(bool(dl_one_kernel))
     p.dl_alpha, p.dl_tol, p.dl_max_iter, p.dl_seed = float(dl_alpha), float(dl_tol), int(dl_max_iter), int(dl_seed)
     # np.percentile divides q by 100 in float64 (numpy/lib/_function_base_impl.py: percentile)
     p.q_img_lo = float(np.true_divide(2, 100))
