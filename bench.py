@@ -181,6 +181,35 @@ def pmc_traffic(kernel_substr: str, stem: str) -> dict | None:
             "source": f"profiles/{vals['file_FETCH_SIZE']} (x2, gfx950) + profiles/{vals['file_WRITE_SIZE']}"}
 
 
+def pmc_traffic_per_call(stem: str, kernel_substrs: tuple[str, ...], per_call_kernel: str) -> dict | None:
+    """HBM-side bytes per CALL of an operation that is several launches (``scripts/pmc_workloads.py <stem>``): the counter totals of
+    every dispatch whose kernel name contains one of ``kernel_substrs``, divided by the number of calls = the dispatch count of
+    ``per_call_kernel`` (a kernel the operation launches exactly once).  Same files, units and gfx950 correction as ``pmc_traffic``."""
+    import re
+
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = sorted((ROOT / "profiles").glob(f"*_{stem}_pmc_{counter}.txt"))
+        if not files:
+            return None
+        tot, calls = 0.0, 0
+        for line in files[-1].read_text().splitlines():
+            m = re.search(rf"{counter} mean=\s*([0-9.]+) n=\s*(\d+)\s+(.*)", line)
+            if not m:
+                continue
+            if any(k in m.group(3) for k in kernel_substrs):
+                tot += float(m.group(1)) * int(m.group(2))
+            if per_call_kernel in m.group(3):
+                calls += int(m.group(2))
+        if calls == 0:
+            return None
+        vals[counter] = tot / calls * 1024.0
+        vals["file_" + counter] = files[-1].name
+    return {"bytes": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
+            "source": f"profiles/{vals['file_FETCH_SIZE']} (x2, gfx950) + profiles/{vals['file_WRITE_SIZE']}; per call = totals over "
+                      f"{list(kernel_substrs)} / dispatches of {per_call_kernel}"}
+
+
 def ev_time(fn, reps: int = 10) -> float:
     """Average seconds per call from HIP events on the launch stream (kernels run on torch's current stream)."""
     import torch
@@ -196,16 +225,17 @@ def ev_time(fn, reps: int = 10) -> float:
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-def spatial_conv(k: int, stride: int, ho: int, wo: int) -> bool:
-    """Which kernel a block convolution runs on (mirror of ``conv3x3_spatial_ok``, csrc/conv3x3_spatial.hpp): 3x3 / stride 1 on
-    a map that the kernel's pixel blocks -- 16 x 16 of one image, or two images of at most 8 x 8 -- cover to >= 7/8 ->
-    ``conv3x3_spatial_kernel``; otherwise ``conv_mfma_f32_kernel``."""
+def spatial_conv(k: int, stride: int, h: int, w: int, ho: int, wo: int, pad: int) -> bool:
+    """Which kernel a block convolution runs on: the library's own dispatch answer (``tia_conv3x3_geometry``: 16 x 16 blocks,
+    two 8 x 8 images, or bands of a strip of the stacked batch -> ``conv3x3_spatial_kernel``; 0 -> ``conv_mfma_f32_kernel``)."""
+    import ctypes
+
+    from tiatoolbox_amd import _lib
+
     if k != 3 or stride != 1:  # noqa: PLR2004
         return False
-    if ho <= 8 and wo <= 8:  # noqa: PLR2004
-        return 8 * ho * wo >= 7 * 64
-    tiles = ((ho + 15) // 16) * ((wo + 15) // 16)
-    return 8 * ho * wo >= 7 * tiles * 256
+    geom = (ctypes.c_int32 * 4)()
+    return _lib.load().tia_conv3x3_geometry(h, w, ho, wo, pad, pad, geom) != 0
 
 
 def trunk_roofline(model, u8_batch):
@@ -231,7 +261,7 @@ def trunk_roofline(model, u8_batch):
         e1.record()
         e1.synchronize()
         n, co, ho, wo = y.shape
-        if spatial_conv(kernel, stride, ho, wo):
+        if spatial_conv(kernel, stride, x.shape[2], x.shape[3], ho, wo, padding):
             name = "conv3x3_spatial_kernel"
         elif kernel == 1 and co % 128 == 0 and ((n * ho * wo + 255) // 256) * (co // 128) >= 384:  # noqa: PLR2004
             name = "conv1x1_ring_kernel"  # mirror of conv1x1_ring_launch's rule (csrc/conv3x3_spatial.hip)

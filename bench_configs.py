@@ -43,6 +43,17 @@ def _setup(args):
     return rank, world_size, torch.device("cuda", local_rank)
 
 
+def _traffic(stem: str, kernel_substrs: tuple, per_call_kernel: str) -> dict:
+    """``traffic`` (HBM-side bytes per call of the timed operation) from this round's committed ``--pmc`` passes over the same
+    shapes (``scripts/pmc_workloads.py``), or ``None`` when no pass is committed."""
+    import bench
+
+    got = bench.pmc_traffic_per_call(stem, kernel_substrs, per_call_kernel)
+    if got is None:
+        return {"traffic": None}
+    return {"traffic": int(got["bytes"]), "traffic_source": got["source"]}
+
+
 def _timed(step, args, world_size: int, device) -> float:
     import torch
 
@@ -175,14 +186,17 @@ def bench_semantic(args) -> dict | None:
                    "parallelism": f"patch rows sharded over {world_size} rank(s), rank-local bands, one all-gather of the uint8 map"},
         "roofline": {
             "kernel": "row_merge_kernel", "bound": "hbm", "achieved": round(merge_bytes / t_merge / 1e9, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(merge_bytes / t_merge / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(merge_bytes / t_merge / 1e9 / HBM_PEAK_GBS, 4),
+            **_traffic("canvas", ("row_merge_kernel",), "row_merge_kernel"),
             "algorithmic_bytes": merge_bytes, "launch_ms": round(t_merge * 1e3, 4),
             "other_kernels": {
                 "finalize_kernel": {"bound": "hbm", "achieved": round(fin_bytes / t_fin / 1e9, 1), "unit": "GB/s",
-                                    "frac": round(fin_bytes / t_fin / 1e9 / HBM_PEAK_GBS, 4), "launch_ms": round(t_fin * 1e3, 4)},
+                                    "frac": round(fin_bytes / t_fin / 1e9 / HBM_PEAK_GBS, 4), "launch_ms": round(t_fin * 1e3, 4),
+                                    "algorithmic_bytes": fin_bytes, **_traffic("canvas", ("finalize_kernel",), "finalize_kernel")},
                 "gather_patches_kernel": {"bound": "hbm", "achieved": round(gather_bytes / t_gather / 1e9, 1), "unit": "GB/s",
                                           "frac": round(gather_bytes / t_gather / 1e9 / HBM_PEAK_GBS, 4),
-                                          "launch_ms": round(t_gather * 1e3, 4)}},
+                                          "launch_ms": round(t_gather * 1e3, 4), "algorithmic_bytes": gather_bytes,
+                                          **_traffic("canvas", ("gather_patches_kernel",), "gather_patches_kernel")}},
             "backbone": {"bound": "mfma", "what": ("UNet-R50 forward per 1024^2 patch, batch 8: " + type(model).__name__
                                                    + (" (every convolution hand-written: stem kernel, 61 on the MFMA kernel with BN / ReLU / "
                                                       "residual fused, class head kernel)" if type(model).__name__ == "FusedUNet" else " (MIOpen)")),
@@ -274,7 +288,8 @@ def bench_hovernet(args) -> dict | None:
         "roofline": {
             "kernel": "hover _proc_np_hv (6 launches: tile-resident labelling / Sobel f64 + energy / marker pipeline, watershed by relaxation)", "bound": "hbm",
             "achieved": round(alg / t_proc / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(alg / t_proc / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": alg,
+            "frac": round(alg / t_proc / 1e9 / HBM_PEAK_GBS, 5),
+            **_traffic("hover", ("tia::",), "sobel_energy_tile_kernel"), "algorithmic_bytes": alg,
             "launch_ms": round(t_proc * 1e3, 3),
             "workload": f"{m} synthetic head maps of 164x164 with ~{n_inst:.0f} nuclei each, 20 B/px (SURVEY 8(d))",
             "postproc_incl_tables_ms": round(t_post * 1e3, 3), "postproc_tiles_per_s": round(m / t_post, 1),
@@ -358,11 +373,14 @@ def bench_vahadane(args) -> dict | None:
                                 f"DictionaryLearning restated) + StainAugmentor over {n} synthetic 256x256x3 patches per GPU "
                                 f"(65 536 over 8 GPUs); statistics and dictionary f64, per-pixel {args.precision}"),
                    "patches_per_gpu": n, "parallelism": f"dp{world_size} (patch-sharded, no collective)"},
-        "roofline": {"kernel": "stain_stats_kernel<DL> (Vahadane)", "bound": "hbm",
-                     "achieved": round(px * 3 / t_stats / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(px * 3 / t_stats / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": px * 3,
-                     "launch_ms": round(t_stats * 1e3, 3),
-                     "note": "8 sweeps over the tissue pixels with a 16 B/px float64 dictionary read and written in each"},
+        "roofline": {"kernel": "vahadane_dl_kernel + stain_stats_kernel<false> (Vahadane statistics: dictionary learning by replay, then the common tail)",
+                     "bound": "hbm", "achieved": round(px * 3 / t_stats / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(px * 3 / t_stats / 1e9 / HBM_PEAK_GBS, 5),
+                     **_traffic("vahadane", ("vahadane_dl_kernel", "stain_stats_kernel"), "vahadane_dl_kernel"),
+                     "algorithmic_bytes": px * 3, "launch_ms": round(t_stats * 1e3, 3),
+                     "note": ("8 sweeps of float64 arithmetic per pixel with NO dictionary in memory (the atom values are replayed from "
+                              "per-iteration scalars): arithmetic-bound, not a bandwidth kernel -- the one-kernel form that keeps the "
+                              "2 x N dictionary in HBM (dl_one_kernel) takes 1.8x as long")},
     }
     # BASELINE's "fp16 OD path": the per-pixel arithmetic exists in float64 (the reference's, reported above) and float32; half
     # precision exists as an OUTPUT format of the float32 path (the CNN's input), not as OD-space arithmetic -- 11 significand
