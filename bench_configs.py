@@ -127,7 +127,7 @@ def bench_semantic(args) -> dict | None:
             h, w = min(2048, hi - y), min(2048, hi - x)
             slide[y:y + h, x:x + w] = tile[:h, :w]
     reader = ArrayWSIReader(slide, mpp=0.25, power=40.0)
-    eng = SemanticSegmentor("fcn_resnet50_unet-bcss", batch_size=int(os.environ.get("TIA_SEM_BATCH", "8")),
+    eng = SemanticSegmentor("fcn_resnet50_unet-bcss", batch_size=int(os.environ.get("TIA_SEM_BATCH", "16")),
                             device=str(device), verbose=False)
     result = {}
     import shutil

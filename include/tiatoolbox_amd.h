@@ -105,7 +105,9 @@ typedef struct tia_stain_params {
     int32_t dl_max_iter;    /* DictionaryLearning.max_iter (3; stainextract.py:313)           */
     int32_t dl_seed;        /* stream of the unused-atom re-draw (the reference is unseeded)  */
     int32_t select_mode;    /* order statistics: 0 = sample-placed windows (one float32 sweep + exact candidates) with the
-                               histogram path as fall-back; 1 = histogram path only (same results; parity audit)       */
+                               histogram path as fall-back, on the register-resident kernel where the patch fits;
+                               1 = histogram path only; 2 = windows on the streaming kernel only (same results bit for bit
+                               in all three; 1 and 2 are parity audits) */
     int32_t dl_one_kernel;  /* TIA_MODE_VAHADANE, parity audit: 0 = the kernel pair (dictionary learning by per-pixel replay of
                                the atom updates -- no dictionary in memory -- followed by the common tail); 1 = the one-kernel form
                                that keeps the 2 x N float64 dictionary in the workspace.  Same results bit for bit.  (Was

@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(NT, DL ? TIA_STATS_WPE_DL : TIA_STATS_WPE) void sta
         const double lo0[2] = {-2.0009765625, -2.0009765625}, hi0[2] = {2.0009765625, 2.0009765625};
         double vp[2], vn[2];
         bool phi_done = false;
-        if (prm.select_mode == 0) {
+        if (prm.select_mode != 1) {
             // float32 classification: with L_c = log2(max(v_c, 1)) the projections are x = Kx - sum_c ex_c L_c (ex = ln2 e1,
             // Kx = log2(255) sum_c ex_c), likewise y; for window edges kb in [-1, 1] and x > 0, key < kb <=> y - kb (|x|+|y|) < 0.
             // Error budget of s = y - kb d: |dL| <= 1 ulp(8) = 9.6e-7, constants rounded to float32 (6e-8 x 8), three FMA
@@ -1995,7 +1995,7 @@ __global__ __launch_bounds__(NT, DL ? TIA_STATS_WPE_DL : TIA_STATS_WPE) void sta
         };
         double vp[2], vn[2];
         bool conc_done = false;
-        if (prm.select_mode == 0) {
+        if (prm.select_mode != 1) {
             // C_t = sum_c P[c][t] od_c = K_t - sum_c pt_c L_c with pt = ln2 P (see the angular sweep for the error budget):
             // |dC_t| <= (9.6e-7 + 5e-7 + 1e-6 / ln2) |pt|_1 + 4 roundings of |C| <= ~4e-6 |P column|_1; eight-fold margin.
             const float ln2 = 0.6931471805599453f, l255 = 7.994353436858858f;
@@ -3492,11 +3492,15 @@ extern "C" size_t tia_stain_stats_workspace_bytes_mode(int64_t n, int64_t h, int
     return total + align256s((size_t)n * sizeof(int));
 }
 
-// patches of this shape (in whole 4-pixel groups, window selection on) may go through the register-resident kernel
+// patches of this shape (in whole 4-pixel groups, window selection on) go through the register-resident kernel: every size it
+// can hold (16 groups per thread: up to 256 x 256).  Round 3 stopped at 224 x 224 because one patch in eight was handed back at
+// 256 x 256 -- the window-placing sample was column-aligned there (sample_index) -- which made the pair slower than the streaming
+// kernel alone; with the stratified sample nothing is handed back and both take the same time (2.14 ms per 4096 x 256^2,
+// profiles/r04q_*), the register-resident one with a third of the HBM-side traffic.  select_mode 2 keeps the streaming kernel.
 static bool stats_reg_shape(long hw, const tia_stain_params* params) {
-    static const bool reg_all = getenv("TIA_STATS_REG_ALL") != nullptr;  // developer switch: every eligible size
-    const long reg_limit = reg_all ? (long)tia::RT * tia::RG * 4 : (long)tia::RT * 13 * 4;
-    return params->mode != TIA_MODE_VAHADANE && params->select_mode == 0 && (hw & 3) == 0 && hw <= reg_limit;
+    static const bool no_reg = getenv("TIA_STATS_NO_REG") != nullptr;  // developer switch (A/B measurements)
+    const long reg_limit = (long)tia::RT * tia::RG * 4;
+    return !no_reg && params->mode != TIA_MODE_VAHADANE && params->select_mode == 0 && (hw & 3) == 0 && hw <= reg_limit;
 }
 
 extern "C" int tia_stain_stats_path(int64_t h, int64_t w, const tia_stain_params* params) {
