@@ -2558,6 +2558,7 @@ constexpr int RW = RT / 64;
 constexpr int RG = 16;        // groups per thread
 constexpr int RSEG = 384;     // list entries (16 bytes: one 4-pixel group + need-bits) per wave
 constexpr int HCOPY = 32;     // histogram / OD-table copies: lane l uses copy l & 31, so a half-wave never shares a bank
+constexpr int L2COPY = 8;     // copies of the float32 log2 table (the sweeps' three transcendental instructions per pixel become look-ups)
 constexpr int RCAP = 2048;    // candidates per target (windows over all 65536 pixels of a 256 x 256 patch hold ~800 + slack)
 
 struct SmemR {
@@ -2573,6 +2574,7 @@ struct SmemR {
     };
     unsigned sbins[2][SNB];
     double cand[2][RCAP];
+    float l2[256 * L2COPY];  // log2(max(v, 1)) of every byte value as the float32 sweeps compute it, copy (lane & 7) of v at v * 8 + copy
     double small[2][64];
     double red[RW][16];
     double tot[16];
@@ -3089,6 +3091,9 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
 #endif
     if (tid < TIA_STATS_STRIDE) out[tid] = 0.0;
     if (tid < 256) s.od[tid] = tab->od_lut[tid];
+    // the SAME instruction the streaming kernel issues per pixel and channel, evaluated once per byte value: identical bits, and
+    // the two classification sweeps (12 of their ~58 issue slots per pixel were v_log_f32) read it back from LDS
+    for (int i = tid; i < 256 * L2COPY; i += RT) s.l2[i] = __log2f(fmaxf((float)(i / L2COPY), 1.0f));
     for (int i = tid; i < 256 * HCOPY; i += RT) s.hstripe[i] = 0u;
     __syncthreads();
 
@@ -3278,9 +3283,9 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
         const float ey0 = uni(ln2 * (float)s.bc[5]), ey1 = uni(ln2 * (float)s.bc[6]), ey2 = uni(ln2 * (float)s.bc[7]);
         const float kx = uni(l255 * (ex0 + ex1 + ex2)), ky = uni(l255 * (ey0 + ey1 + ey2));
         const float tol = 8.0e-5f;
+        const float* l2t = s.l2 + (lane & (L2COPY - 1));
         auto proj = [&](uint32_t r, uint32_t g, uint32_t b, float& x, float& y) {
-            const float lr = __log2f(fmaxf((float)r, 1.0f)), lg = __log2f(fmaxf((float)g, 1.0f)),
-                        lb = __log2f(fmaxf((float)b, 1.0f));
+            const float lr = l2t[r * L2COPY], lg = l2t[g * L2COPY], lb = l2t[b * L2COPY];
             x = fmaf(-ex2, lb, fmaf(-ex1, lg, fmaf(-ex0, lr, kx)));
             y = fmaf(-ey2, lb, fmaf(-ey1, lg, fmaf(-ey0, lr, ky)));
         };
@@ -3394,9 +3399,9 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
         const float ka = uni(l255 * (a0 + a1 + a2)), kb = uni(l255 * (b0 + b1 + b2));
         const float tol0 = uni(3.2e-5f * (fabsf((float)P[0]) + fabsf((float)P[2]) + fabsf((float)P[4])) + 1e-7f);
         const float tol1 = uni(3.2e-5f * (fabsf((float)P[1]) + fabsf((float)P[3]) + fabsf((float)P[5])) + 1e-7f);
+        const float* l2c = s.l2 + (lane & (L2COPY - 1));
         auto conc32 = [&](uint32_t r, uint32_t g, uint32_t b, float& c0, float& c1) {
-            const float lr = __log2f(fmaxf((float)r, 1.0f)), lg = __log2f(fmaxf((float)g, 1.0f)),
-                        lb = __log2f(fmaxf((float)b, 1.0f));
+            const float lr = l2c[r * L2COPY], lg = l2c[g * L2COPY], lb = l2c[b * L2COPY];
             c0 = fmaf(-a2, lb, fmaf(-a1, lg, fmaf(-a0, lr, ka)));
             c1 = fmaf(-b2, lb, fmaf(-b1, lg, fmaf(-b0, lr, kb)));
         };
