@@ -119,3 +119,59 @@ def test_package_level_names_of_the_reference_layout():
     assert importlib.import_module("tiatoolbox_amd.models").DeepFeatureExtractor.__name__ == "DeepFeatureExtractor"
     with pytest.raises(AttributeError):
         importlib.import_module("tiatoolbox_amd.models").NucleusDetector  # noqa: B018  (out of scope)
+
+
+def test_host_only_dispatch_queries():
+    """``tia_conv3x3_geometry`` / ``tia_stain_stats_path`` answer on the host (no launch): which block geometry a 3x3 / stride-1
+    convolution gets and which statistics kernel a patch shape gets -- the dispatch the GPU tests and the bench rely on.
+    Band geometry: strips of ``bw`` columns x ``br`` rows of the stacked batch with ``bw * br <= 256``, LDS patch
+    ``(br + 2) * row_pitch <= 1728`` units, ``bw * strips == w``; only for "same" padding, only above 0.88 busy."""
+    import ctypes
+
+    import pytest
+
+    from tiatoolbox_amd import _lib, build
+
+    if not build.LIB_PATH.exists():
+        pytest.skip("library not built (run __graft_entry__.build())")
+    lib = _lib.load()
+
+    def geometry(h, w, ho, wo, pad):
+        geom = (ctypes.c_int32 * 4)()
+        return lib.tia_conv3x3_geometry(h, w, ho, wo, pad, pad, geom), list(geom)
+
+    # resnet maps of 224^2 patches: 56 / 28 / 14 on bands, 7 on the slice kernel; of 256^2 patches: fixed geometries
+    assert geometry(56, 56, 56, 56, 1) == (3, [28, 9, 120, 2])
+    assert geometry(28, 28, 28, 28, 1) == (3, [28, 9, 120, 1])
+    assert geometry(14, 14, 14, 14, 1) == (3, [14, 18, 64, 1])
+    assert geometry(7, 7, 7, 7, 1)[0] == 0
+    for side in (64, 32, 16, 128, 512):
+        assert geometry(side, side, side, side, 1) == (1, [0, 0, 0, 0])
+    assert geometry(8, 8, 8, 8, 1)[0] == 2
+    # valid convolutions (HoVer-Net's decoder) never take the band form; 16 x 16 blocks when they cover >= 7/8
+    assert geometry(164, 164, 162, 162, 0)[0] == 0 and geometry(64, 64, 62, 62, 0)[0] == 1
+    for h in range(9, 130):
+        kind, (bw, br, pitch, strips) = geometry(h, h, h, h, 1)
+        if kind == 3:
+            assert bw * strips == h and bw * br <= 256 and (br + 2) * pitch <= 1728 and pitch >= 4 * (bw + 2)
+            assert bw * br / 256 * h / (h + 1) >= 0.88
+    # rectangular maps: the strip width divides the map width
+    kind, (bw, br, pitch, strips) = geometry(40, 56, 40, 56, 1)
+    assert kind == 3 and bw * strips == 56
+
+    from tiatoolbox_amd.tools import _stain_device as dev
+
+    for mode, expect in ((_lib.MODE_MACENKO, 1), (_lib.MODE_FIXED, 1), (_lib.MODE_VAHADANE, 0)):
+        kw = {"stain_fixed": [[0.65, 0.70, 0.29], [0.07, 0.99, 0.11]]} if mode == _lib.MODE_FIXED else {}
+        import numpy as np
+
+        prm = dev.make_params(mode=mode, **({k: np.array(v) for k, v in kw.items()}))
+        assert lib.tia_stain_stats_path(256, 256, ctypes.byref(prm)) == expect
+        assert lib.tia_stain_stats_path(224, 224, ctypes.byref(prm)) == expect
+        assert lib.tia_stain_stats_path(300, 300, ctypes.byref(prm)) == 0     # does not fit 16 groups per thread
+        assert lib.tia_stain_stats_path(37, 41, ctypes.byref(prm)) == 0       # 1517 pixels: no whole 4-pixel groups
+    for select_mode in (1, 2):
+        prm = dev.make_params(mode=_lib.MODE_MACENKO, select_mode=select_mode)
+        assert lib.tia_stain_stats_path(256, 256, ctypes.byref(prm)) == 0     # the audit modes keep the streaming kernel
+    assert lib.tia_stain_stats_path(0, 5, ctypes.byref(prm)) == -1            # TIA_EINVAL
+    assert lib.tia_clear_last_error() in (0, 3, 100, 101)                      # callable without a device (no device: hipErrorNoDevice)
