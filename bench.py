@@ -536,11 +536,19 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                                   else "resnet18 forward: library convolutions + hand-written HIP epilogues"),
         "achieved": round(flops / t_cnn / 1e12, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
         "frac": round(flops / t_cnn / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 5), "ms": round(t_cnn * 1e3, 3)}
-    pmc = pmc_traffic("stain_stats_kernel", "stain") if (n, hw) == (4096, 256) else None
+    # which of the two statistics kernels serves this shape (the library's own answer), and its HBM-side traffic per launch
+    import ctypes
+
+    reg = _lib.load().tia_stain_stats_path(hw, hw, ctypes.byref(params)) == 1
+    stats_kernel = "stain_stats_reg_kernel" if reg else "stain_stats_kernel<false>"
+    tgt = roofline if dominant == "stain_stats_kernel" else roofline["other_kernels"]["stain_stats_kernel"]
+    tgt["what"] = (f"{stats_kernel}: " + ("one 1024-thread workgroup per patch holds it in registers (one HBM read); patches it hands "
+                                         "back go through the streaming kernel" if reg else
+                                         "one 512-thread workgroup per patch, the patch re-read per sweep"))
+    pmc = pmc_traffic(stats_kernel.split("<")[0] + ("(" if reg else "<false>"), "stain") if (n, hw) == (4096, 256) else None
     if pmc is not None:
-        tgt = roofline if dominant == "stain_stats_kernel" else roofline["other_kernels"]["stain_stats_kernel"]
         tgt["traffic"] = round(pmc["bytes"])
-        tgt["traffic_source"] = pmc["source"]
+        tgt["traffic_source"] = pmc["source"] + (" (scripts/perf_stain.py 4096 256; mean over the dispatches of that kernel)")
     line["roofline"] = roofline
 
     # ---- extras (rank 0, single GPU): host-inclusive API call, fp16 backbone with its error, 224^2 patches --------

@@ -2629,8 +2629,8 @@ __device__ __forceinline__ void block_sum_r(double (&v)[N], SmemR& s) {
 // window_select2 for register-resident pixels.  `sample32(idx, r, g, b, v)` and `exact(r, g, b, x)` as there;
 // `sweep(seg, cap, count, below0, below1)` classifies the calling thread's own pixels in float32 and appends the undecided
 // ones (colour + need-bits) to this wave's list segment.  Returns false (workgroup-uniform) when a precondition fails.
-template <class SAMPLE32, class EXACT, class SWEEP>
-__device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p, long hw, bool shared_keys, SAMPLE32&& sample32,
+template <class FETCH, class SAMPLE32, class EXACT, class SWEEP>
+__device__ __forceinline__ bool window_select_reg(FETCH&& fetch, long hw, bool shared_keys, SAMPLE32&& sample32,
                                                   EXACT&& exact, SWEEP&& sweep, SmemR& s, const unsigned long long (&k)[2],
                                                   const unsigned long long (&n)[2], double (&vprev)[2], double (&vnext)[2]) {
     const int tid = threadIdx.x;
@@ -2638,7 +2638,6 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
     const float finf = __int_as_float(0x7f800000);
     if (n[0] == 0 || n[1] == 0) return false;
     constexpr int SPT = SAMPLE_TARGET / RT;  // samples per thread
-    const long stride = (hw + SAMPLE_TARGET - 1) / SAMPLE_TARGET;
     if (tid < 2) {
         s.key_max[tid] = 0ull;
         s.key_min[tid] = ~0ull;
@@ -2648,22 +2647,21 @@ __device__ __forceinline__ bool window_select_reg(const uint8_t* __restrict__ p,
     for (int i = tid; i < 2 * SNB; i += RT) (&s.sbins[0][0])[i] = 0u;
     const float fnan = __int_as_float(0x7fc00000);
     {
-        // the sample is re-read from the patch in L2 (it was streamed into the registers a moment ago): a uniform stride
-        // over the image, which the register layout (every thread holds pixels of a few narrow bands) cannot give
+        // the sample comes out of the thread's own registers: thread t holds the groups t + 1024 j -- one every 16 rows of a 256-wide
+        // patch, at a column position that runs over the whole row with t -- so one pixel from each quarter of its slots, at a hashed
+        // slot and pixel, is a stratified sample over the image (`fetch`).  (Round 3 re-read a strided sample from memory: every
+        // sampled byte pulled a whole 64-byte sector, i.e. both selections together re-read ~1.6x the patch: the kernel's HBM-side
+        // traffic was 2.8x the patch instead of ~1.2x, profiles/r04s_stain_pmc_*.)
         uint32_t rgb[SPT];
+        bool have[SPT];
 #pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const long idx = sample_index((long)j * RT + tid, stride);
-            const long ic = idx < hw ? idx : hw - 1;
-            rgb[j] = (uint32_t)p[3 * ic] | ((uint32_t)p[3 * ic + 1] << 8) | ((uint32_t)p[3 * ic + 2] << 16);
-        }
+        for (int j = 0; j < SPT; ++j) have[j] = fetch(j, rgb[j]);
         float mn[2] = {finf, finf}, mx[2] = {-finf, -finf};
         unsigned cnt[2] = {0u, 0u};
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
-            const long idx = sample_index((long)j * RT + tid, stride);
             float v[2] = {0.0f, 0.0f};
-            const unsigned valid = idx < hw ? sample32(idx, rgb[j] & 255u, (rgb[j] >> 8) & 255u, (rgb[j] >> 16) & 255u, v) : 0u;
+            const unsigned valid = have[j] ? sample32(0L, rgb[j] & 255u, (rgb[j] >> 8) & 255u, (rgb[j] >> 16) & 255u, v) : 0u;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const bool ok = (valid >> t) & 1u;
@@ -3069,6 +3067,24 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
         pc[j] = q[gc * 3 + 2];
     }
     const int n_slots = (ng + RT - 1) / RT;  // group slots in use (workgroup-uniform)
+    // sample k (of 4) of this thread for the window placement: one pixel from the k-th quarter of its slots (window_select_reg)
+    auto fetch_sample = [&](int k, uint32_t& rgb) -> bool {
+        const unsigned hsh = ((unsigned)(tid * 4 + k) * 2654435761u) >> 12;
+        const int j = ((4 * k + (int)(hsh & 3u)) * n_slots) >> 4;
+        const int i = (int)((hsh >> 2) & 3u);
+        uint32_t a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int t = 0; t < RG; ++t) {  // (a select chain: the patch registers cannot be indexed by a per-lane value)
+            a = t == j ? pa[t] : a;
+            b = t == j ? pb[t] : b;
+            c = t == j ? pc[t] : c;
+        }
+        // bytes of pixel i of the group: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+        const unsigned long long lo = (unsigned long long)a | ((unsigned long long)b << 32);
+        const unsigned long long hi = (unsigned long long)b | ((unsigned long long)c << 32);
+        rgb = i < 2 ? (uint32_t)(lo >> (24 * i)) & 0xffffffu : (uint32_t)(hi >> (24 * i - 32)) & 0xffffffu;
+        return tid + RT * j < ng;
+    };
     double s_given[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (prm.mode == TIA_MODE_GIVEN) {
 #pragma unroll
@@ -3290,7 +3306,7 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
             y = fmaf(-ey2, lb, fmaf(-ey1, lg, fmaf(-ey0, lr, ky)));
         };
         const bool ok = window_select_reg(
-            p, hw, true,
+            fetch_sample, hw, true,
             [&](long, uint32_t r, uint32_t g, uint32_t b, float (&v)[2]) -> unsigned {
                 const int t = s.ty[0][r] + s.ty[1][g] + s.ty[2][b];
                 if (!(((t + (1 << 11)) >> 12) < y_thr)) return 0u;
@@ -3406,7 +3422,7 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
             c1 = fmaf(-b2, lb, fmaf(-b1, lg, fmaf(-b0, lr, kb)));
         };
         const bool ok = window_select_reg(
-            p, hw, false,
+            fetch_sample, hw, false,
             [&](long, uint32_t r, uint32_t g, uint32_t b, float (&v)[2]) -> unsigned {
                 conc32(r, g, b, v[0], v[1]);
                 return 3u;
