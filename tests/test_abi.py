@@ -170,6 +170,7 @@ def test_host_only_dispatch_queries():
         assert lib.tia_stain_stats_path(224, 224, ctypes.byref(prm)) == expect
         assert lib.tia_stain_stats_path(300, 300, ctypes.byref(prm)) == 0     # does not fit 16 groups per thread
         assert lib.tia_stain_stats_path(37, 41, ctypes.byref(prm)) == 0       # 1517 pixels: no whole 4-pixel groups
+        assert lib.tia_stain_stats_path(32, 32, ctypes.byref(prm)) == 0       # fewer pixels than the window-placing sample
     for select_mode in (1, 2):
         prm = dev.make_params(mode=_lib.MODE_MACENKO, select_mode=select_mode)
         assert lib.tia_stain_stats_path(256, 256, ctypes.byref(prm)) == 0     # the audit modes keep the streaming kernel

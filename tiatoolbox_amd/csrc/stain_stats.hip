@@ -3044,7 +3044,8 @@ __device__ __attribute__((noinline)) void reg_stain_from_angles(const double (&v
 
 __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __restrict__ img, long hw,
                                                               const tia_stain_tables* __restrict__ tab, tia_stain_params prm,
-                                                              double* __restrict__ stats, int* __restrict__ redo) {
+                                                              double* __restrict__ stats, int* __restrict__ redo,
+                                                              uint32_t* __restrict__ sample_ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     SmemR& s = *reinterpret_cast<SmemR*>(smem_raw);
     const uint8_t* p = img + (size_t)blockIdx.x * (size_t)hw * 3u;
@@ -3067,8 +3068,16 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
         pc[j] = q[gc * 3 + 2];
     }
     const int n_slots = (ng + RT - 1) / RT;  // group slots in use (workgroup-uniform)
-    // sample k (of 4) of this thread for the window placement: one pixel from the k-th quarter of its slots (window_select_reg)
-    auto fetch_sample = [&](int k, uint32_t& rgb) -> bool {
+    // The window-placing sample: 4 pixels per thread, one from each quarter of its slots at a hashed slot and pixel (thread t holds
+    // the groups t + 1024 j -- one every 16 rows of a 256-wide patch, at a column position that runs over the whole row with t -- so
+    // this is a stratified sample over the image).  Taken HERE, while nothing else is live, and parked in 16 KB of the patch's
+    // (otherwise unused) bin-cache workspace: each selection reads its 4 values back with one coalesced load.  (Round 3 re-read a
+    // strided sample from the image: every sampled byte pulled a whole 64-byte sector, both selections together re-read ~1.6x the
+    // patch -- the kernel's HBM-side traffic was 2.8x the patch, profiles/r04s_stain_pmc_*; selecting from the registers at the
+    // point of use instead cost 45 more spilled registers and doubled the kernel's time, profiles/r04t_*.)
+    uint32_t* __restrict__ my_samples = sample_ws + (size_t)blockIdx.x * (size_t)hw;  // the patch's own 4 hw bytes of the bin cache
+#pragma unroll
+    for (int k = 0; k < SAMPLE_TARGET / RT; ++k) {
         const unsigned hsh = ((unsigned)(tid * 4 + k) * 2654435761u) >> 12;
         const int j = ((4 * k + (int)(hsh & 3u)) * n_slots) >> 4;
         const int i = (int)((hsh >> 2) & 3u);
@@ -3082,8 +3091,13 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
         // bytes of pixel i of the group: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
         const unsigned long long lo = (unsigned long long)a | ((unsigned long long)b << 32);
         const unsigned long long hi = (unsigned long long)b | ((unsigned long long)c << 32);
-        rgb = i < 2 ? (uint32_t)(lo >> (24 * i)) & 0xffffffu : (uint32_t)(hi >> (24 * i - 32)) & 0xffffffu;
-        return tid + RT * j < ng;
+        const uint32_t rgb = i < 2 ? (uint32_t)(lo >> (24 * i)) & 0xffffffu : (uint32_t)(hi >> (24 * i - 32)) & 0xffffffu;
+        my_samples[k * RT + tid] = rgb | (tid + RT * j < ng ? 0x80000000u : 0u);  // bit 31: the slot holds a pixel of the patch
+    }
+    auto fetch_sample = [&](int k, uint32_t& rgb) -> bool {
+        const uint32_t v = my_samples[k * RT + tid];
+        rgb = v & 0xffffffu;
+        return (v >> 31) != 0u;
     };
     double s_given[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (prm.mode == TIA_MODE_GIVEN) {
@@ -3521,7 +3535,9 @@ extern "C" size_t tia_stain_stats_workspace_bytes_mode(int64_t n, int64_t h, int
 static bool stats_reg_shape(long hw, const tia_stain_params* params) {
     static const bool no_reg = getenv("TIA_STATS_NO_REG") != nullptr;  // developer switch (A/B measurements)
     const long reg_limit = (long)tia::RT * tia::RG * 4;
-    return !no_reg && params->mode != TIA_MODE_VAHADANE && params->select_mode == 0 && (hw & 3) == 0 && hw <= reg_limit;
+    // (>= 4096 pixels: the sample of 4096 dwords is parked in the patch's 4 hw bytes of workspace)
+    return !no_reg && params->mode != TIA_MODE_VAHADANE && params->select_mode == 0 && (hw & 3) == 0 && hw <= reg_limit &&
+           hw >= tia::SAMPLE_TARGET;
 }
 
 extern "C" int tia_stain_stats_path(int64_t h, int64_t w, const tia_stain_params* params) {
@@ -3584,8 +3600,9 @@ extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, in
             }))
             return TIA_ELAUNCH;
         if (hipMemsetAsync(redo, 0, (size_t)n * sizeof(int), st) != hipSuccess) return TIA_ELAUNCH;
+        // (the register-resident kernel has no use for the bin cache: 16 KB per patch of it hold the window-placing sample)
         hipLaunchKernelGGL(tia::stain_stats_reg_kernel, dim3((unsigned)n), dim3(tia::RT), sizeof(tia::SmemR), st, d_img, hw, d_tables,
-                           *params, d_stats, redo);
+                           *params, d_stats, redo, reinterpret_cast<uint32_t*>(d_ws));
         hipLaunchKernelGGL(tia::stain_stats_kernel<false>, dim3((unsigned)n), dim3(tia::NT), 0, st, d_img, hw, d_tables, *params,
                            d_stats, binws, dictws, (const int*)redo);
     } else {
