@@ -3068,31 +3068,26 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
         pc[j] = q[gc * 3 + 2];
     }
     const int n_slots = (ng + RT - 1) / RT;  // group slots in use (workgroup-uniform)
-    // The window-placing sample: 4 pixels per thread, one from each quarter of its slots at a hashed slot and pixel (thread t holds
-    // the groups t + 1024 j -- one every 16 rows of a 256-wide patch, at a column position that runs over the whole row with t -- so
-    // this is a stratified sample over the image).  Taken HERE, while nothing else is live, and parked in 16 KB of the patch's
-    // (otherwise unused) bin-cache workspace: each selection reads its 4 values back with one coalesced load.  (Round 3 re-read a
-    // strided sample from the image: every sampled byte pulled a whole 64-byte sector, both selections together re-read ~1.6x the
-    // patch -- the kernel's HBM-side traffic was 2.8x the patch, profiles/r04s_stain_pmc_*; selecting from the registers at the
-    // point of use instead cost 45 more spilled registers and doubled the kernel's time, profiles/r04t_*.)
+    // The window-placing sample (4 pixels per thread: the stratified sample of sample_index) is requested HERE, right behind the
+    // patch itself -- its bytes sit in lines the workgroup's own coalesced loads are bringing into L2 at this moment -- and parked
+    // in 16 KB of the patch's (otherwise unused) bin-cache workspace once P1 has run; each selection reads its 4 values back with
+    // one coalesced load.  (Round 3 re-read the sample from the image in front of each selection, long after the lines had left
+    // L2: every sampled byte pulled a whole 64-byte sector, both selections together re-read ~1.6x the patch and the kernel's
+    // HBM-side traffic was 2.8x the patch, profiles/r04s_stain_pmc_*.  Selecting the sample out of the patch registers instead
+    // -- a per-lane select chain over the 48 registers -- was measured too: at the point of use it spilled 45 more registers (3.97 ms),
+    // at kernel start it made P1 wait for the whole patch and slowed the later sweeps (2.95 ms), profiles/r04t_*, r04u_*.)
     uint32_t* __restrict__ my_samples = sample_ws + (size_t)blockIdx.x * (size_t)hw;  // the patch's own 4 hw bytes of the bin cache
+    constexpr int SPT_R = SAMPLE_TARGET / RT;
+    uint32_t srgb[SPT_R];
+    {
+        const long sstride = (hw + SAMPLE_TARGET - 1) / SAMPLE_TARGET;
 #pragma unroll
-    for (int k = 0; k < SAMPLE_TARGET / RT; ++k) {
-        const unsigned hsh = ((unsigned)(tid * 4 + k) * 2654435761u) >> 12;
-        const int j = ((4 * k + (int)(hsh & 3u)) * n_slots) >> 4;
-        const int i = (int)((hsh >> 2) & 3u);
-        uint32_t a = 0, b = 0, c = 0;
-#pragma unroll
-        for (int t = 0; t < RG; ++t) {  // (a select chain: the patch registers cannot be indexed by a per-lane value)
-            a = t == j ? pa[t] : a;
-            b = t == j ? pb[t] : b;
-            c = t == j ? pc[t] : c;
+        for (int k = 0; k < SPT_R; ++k) {
+            const long idx = sample_index((long)k * RT + tid, sstride);
+            const long ic = idx < hw ? idx : hw - 1;
+            srgb[k] = ((uint32_t)p[3 * ic] | ((uint32_t)p[3 * ic + 1] << 8) | ((uint32_t)p[3 * ic + 2] << 16)) |
+                      (idx < hw ? 0x80000000u : 0u);  // bit 31: a pixel of the patch
         }
-        // bytes of pixel i of the group: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
-        const unsigned long long lo = (unsigned long long)a | ((unsigned long long)b << 32);
-        const unsigned long long hi = (unsigned long long)b | ((unsigned long long)c << 32);
-        const uint32_t rgb = i < 2 ? (uint32_t)(lo >> (24 * i)) & 0xffffffu : (uint32_t)(hi >> (24 * i - 32)) & 0xffffffu;
-        my_samples[k * RT + tid] = rgb | (tid + RT * j < ng ? 0x80000000u : 0u);  // bit 31: the slot holds a pixel of the patch
     }
     auto fetch_sample = [&](int k, uint32_t& rgb) -> bool {
         const uint32_t v = my_samples[k * RT + tid];
@@ -3146,6 +3141,8 @@ __global__ __launch_bounds__(RT) void stain_stats_reg_kernel(const uint8_t* __re
         }
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SPT_R; ++k) my_samples[k * RT + tid] = srgb[k];
     RSTAMP(TM_P1)
     if (tid < 256) {
         unsigned tot = 0;
