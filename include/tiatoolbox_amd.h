@@ -482,6 +482,16 @@ int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const fl
                              int32_t relu, const float* d_post_scale, const float* d_post_shift, float* d_y2,
                              void* stream);
 
+/* 1x1 convolution (any stride, no padding) whose INPUT is activated on load:
+ *   y = act(conv1x1(relu(x * pre_scale[c] + pre_shift[c]), w) + bias [+ residual])
+ * -- the "preact/bn" + ReLU in front of conv1 of HoVer-Net's residual units 2..n (models/architecture/hovernet.py:100-147),
+ * applied between the global load and the LDS store of the GEMM's A operand (product and sum rounded separately, like
+ * batch_norm + relu): the unit reads the raw residual sum of the previous unit and the activated copy is never written.
+ * pre_scale / pre_shift [cin], 16-byte aligned; other arguments as tia_conv2d_nhwc_f32_ex (ho = ceil(h / stride)). */
+int tia_conv1x1_pre_nhwc_f32(const float* d_x, const float* d_pre_scale, const float* d_pre_shift, const float* d_w_packed,
+                             const float* d_bias, const float* d_residual, float* d_y, int64_t n, int64_t h, int64_t w,
+                             int64_t cin, int64_t cout, int64_t stride, int32_t relu, void* stream);
+
 /* The ResNet stem in one kernel: y = maxpool3x3/s2/p1(relu(conv7x7/s2/p3(X) + bias)), 3 -> 64 channels, BatchNorm folded
  * into w / bias (CNNModel.forward -> torchvision conv1 / bn1 / relu / maxpool, models/architecture/vanilla.py:300-316).
  *   x_is_u8 != 0: d_x is the uint8 NHWC patch batch and X = x / 255 in float32 (correctly rounded division) -- `ToTensor`

@@ -50,7 +50,7 @@ def conv_label(a, k, out):
 
 
 hf._Conv.forward = timed(conv_label, orig_conv)
-for mod, name in ((hf, "hip_conv2d_post"), (hf, "hip_scale_shift_act"), (hf, "hip_scale_shift_act_view"), (hf, "hip_upsample2x_add"),
+for mod, name in ((hf, "hip_conv2d_post"), (hf, "hip_conv1x1_pre"), (hf, "hip_scale_shift_act"), (hf, "hip_scale_shift_act_view"), (hf, "hip_upsample2x_add"),
                   (uf, "hip_upsample2x_add"), (uf, "hip_stem_conv_pool")):
     def lab(a, k, out, name=name):
         first = out[1] if isinstance(out, tuple) else out
@@ -59,6 +59,9 @@ for mod, name in ((hf, "hip_conv2d_post"), (hf, "hip_scale_shift_act"), (hf, "hi
         if name == "hip_conv2d_post":
             n, co, ho, wo = first.shape
             flops = 2.0 * n * ho * wo * co * x.shape[1] * k["kernel"] ** 2
+        if name == "hip_conv1x1_pre":
+            n, co, ho, wo = first.shape
+            flops = 2.0 * n * ho * wo * co * x.shape[1]
         if name == "hip_stem_conv_pool":
             n, h, w, _ = x.shape
             flops = 2.0 * n * (h // 2) * (w // 2) * 64 * 147

@@ -27,6 +27,11 @@ def _conv_post(x, wp, bias, res, *, kernel, stride, pad_lo, pad_hi, relu, post_s
     return (v if want_raw else None), F.relu(v * post_scale[None, :, None, None] + post_shift[None, :, None, None])
 
 
+def _conv_pre(x, pre_scale, pre_shift, wp, bias, res=None, *, stride=1, relu=False):
+    a = F.relu(x * pre_scale[None, :, None, None] + pre_shift[None, :, None, None])
+    return _conv_ex(a, wp, bias, res, kernel=1, stride=stride, pad_lo=0, pad_hi=0, relu=relu)
+
+
 def _scale_shift(x, sc, sh, *, relu=True, inplace=False):  # noqa: ARG001
     y = x * sc[None, :, None, None] + sh[None, :, None, None]
     return F.relu(y) if relu else y
@@ -53,6 +58,7 @@ def torch_kernels(monkeypatch):
 
     monkeypatch.setattr(hf, "hip_conv2d_ex", _conv_ex)
     monkeypatch.setattr(hf, "hip_conv2d_post", _conv_post)
+    monkeypatch.setattr(hf, "hip_conv1x1_pre", _conv_pre)
     monkeypatch.setattr(hf, "pack_conv_weights", lambda conv: conv.weight.detach().permute(2, 3, 1, 0).contiguous())
     monkeypatch.setattr(hf, "hip_scale_shift_act", _scale_shift)
     monkeypatch.setattr(hf, "hip_scale_shift_act_view", lambda x, sc, sh, relu=True: _scale_shift(x, sc, sh, relu=relu))
@@ -183,6 +189,8 @@ def test_hip_wrappers_refuse_host_tensors():
     with pytest.raises(ValueError, match="channels-last CUDA"):
         fused.hip_conv2d_post(x, w, None, None, kernel=1, stride=1, pad_lo=0, pad_hi=0, relu=False,
                               post_scale=torch.ones(64), post_shift=torch.zeros(64))
+    with pytest.raises(ValueError, match="channels-last CUDA"):
+        fused.hip_conv1x1_pre(x, torch.ones(32), torch.zeros(32), w, None)
     with pytest.raises(ValueError, match="channels-last CUDA"):
         fused.hip_scale_shift_act(x, torch.ones(32), torch.zeros(32))
     with pytest.raises(ValueError, match="CUDA"):

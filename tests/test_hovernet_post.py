@@ -685,6 +685,26 @@ def test_fused_hovernet_forward_matches_plain_module(plus):
                     assert (raw.cpu() - raw_ref).abs().max() <= 1e-4
                     again = torch.relu(raw * ps.cuda()[None, :, None, None] + pt.cuda()[None, :, None, None])
                     assert (act - again).abs().max() <= 1e-6  # the two outputs are consistent with each other
+        from tiatoolbox_amd.models.architecture.fused import hip_conv1x1_pre
+
+        # activation on load (conv1 of residual units 2..n): == scale_shift_act followed by the plain convolution, bit for bit
+        # in the operand (same separately rounded product and sum), with and without stride / residual, both tile widths
+        for (cin, cout, s, with_res) in [(96, 64, 1, False), (256, 128, 1, True), (512, 256, 2, False), (1024, 512, 1, False)]:
+            conv = torch.nn.Conv2d(cin, cout, 1, stride=s, bias=True)
+            x = torch.randn((3, cin, 11, 7), generator=g)
+            sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g)
+            ref = conv(torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None])).detach()
+            res = torch.randn(ref.shape, generator=g) if with_res else None
+            dev = copy.deepcopy(conv).cuda()
+            xd = x.cuda().contiguous(memory_format=torch.channels_last)
+            rd = res.cuda().contiguous(memory_format=torch.channels_last) if with_res else None
+            got = hip_conv1x1_pre(xd, sc.cuda(), sh.cuda(), pack_conv_weights(dev), dev.bias, rd, stride=s, relu=True)
+            want = torch.relu(ref + res) if with_res else torch.relu(ref)
+            assert got.shape == want.shape
+            assert (got.cpu() - want).abs().max() <= 2e-4 * max(1.0, float(want.abs().max())), (cin, cout, s)
+            two_step = hip_conv2d_ex(hip_scale_shift_act(xd, sc.cuda(), sh.cuda()), pack_conv_weights(dev), dev.bias, rd, kernel=1,
+                                     stride=s, pad_lo=0, pad_hi=0, relu=True)
+            assert (got - two_step).abs().max() <= 1e-5 * max(1.0, float(want.abs().max())), (cin, cout, s)
         x = torch.randn((2, 96, 7, 5), generator=g)
         sc, sh = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g)
         got = hip_scale_shift_act(x.cuda().contiguous(memory_format=torch.channels_last), sc.cuda(), sh.cuda())

@@ -48,17 +48,24 @@ constexpr int OOB = (int)0x80000000;  // voffset beyond every buffer extent: the
 // second, "post-activated" output of the epilogue: y2 = relu(v * scale[c] + shift[c]) of the value v that goes to y -- the
 // BatchNorm + ReLU that FOLLOWS a residual sum in a pre-activation network (HoVer-Net: the next unit's "preact" or the
 // block's "blk_bna"), produced while the sum is still in registers.  y itself may then be null (only y2 wanted).
+// `pre_*` (PRE kernels, 1x1 only): the mirror image on the INPUT side -- the A operand is relu(x * pre_scale[c] + pre_shift[c]),
+// applied between the global load and the LDS store, so a pre-activation unit reads the raw residual sum directly and the
+// activated copy never exists in memory.
 struct ConvPost {
     const float* scale;
     const float* shift;
     float* y2;
+    const float* pre_scale;
+    const float* pre_shift;
 };
 
-template <int BN, bool POST = false>
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int BN, bool POST = false, bool PRE = false>
 __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __restrict__ x, const float* __restrict__ wk,
                                                             const float* __restrict__ bias, const float* __restrict__ res,
                                                             float* __restrict__ y, ConvDims d, int relu, int m_tiles,
-                                                            ConvPost post = ConvPost{nullptr, nullptr, nullptr}) {
+                                                            ConvPost post = ConvPost{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     constexpr int NTILE = BN / 64;       // 32-wide MFMA tiles per wave along N
     constexpr int BQ = BN / 4;           // float4 per B row
     constexpr int B_PER_THREAD = BK * BQ / NTH;
@@ -112,10 +119,21 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
     const int bvoff = ((tid / BQ) * d.cout + 4 * (tid % BQ)) * 4;  // B: row tid / BQ (+ NTH / BQ per further slot), one float4
     const int brow_step = (NTH / BQ) * d.cout * 4;
 
+    // product and sum rounded separately, like batch_norm + relu (the same arithmetic as the POST epilogue and the stand-alone
+    // scale_shift_act kernel: the three forms are interchangeable bit for bit)
+    auto pre_act = [](float v, float sc, float sh) {
+        if constexpr (PRE) {
+            const float a = __fadd_rn(__fmul_rn(v, sc), sh);
+            return a > 0.0f ? a : 0.0f;
+        } else {
+            return v;
+        }
+    };
     // slice cursor (scalar): tap (kh, kw) and first channel c0 of the slice that is staged next
     int s_kh = 0, s_kw = 0, s_c0 = 0;
     u32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     rb2 = rb3 = u32x4{0u, 0u, 0u, 0u};
+    f32x4 rps = {1.0f, 1.0f, 1.0f, 1.0f}, rpt = {0.0f, 0.0f, 0.0f, 0.0f};  // PRE: scale / shift of this thread's channel quad
 #define TIA_LOAD_A(R)                                                                                         \
     {                                                                                                         \
         const bool ok = (msk_##R & sel) == sel;                                                               \
@@ -127,6 +145,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
         const unsigned sel = (1u << s_kh) | (1u << (16 + s_kw));                                              \
         const int swrow = (((s_kh * d.kw + s_kw) * d.cin + s_c0) * d.cout + n0) * 4;                          \
         TIA_LOAD_A(0) TIA_LOAD_A(1) TIA_LOAD_A(2) TIA_LOAD_A(3)                                               \
+        if constexpr (PRE) {                                                                                  \
+            rps = *reinterpret_cast<const f32x4*>(post.pre_scale + s_c0 + 4 * quad);                          \
+            rpt = *reinterpret_cast<const f32x4*>(post.pre_shift + s_c0 + 4 * quad);                          \
+        }                                                                                                     \
         rb0 = __builtin_amdgcn_raw_buffer_load_b128(rw, bvoff, swrow, 0);                                     \
         rb1 = __builtin_amdgcn_raw_buffer_load_b128(rw, bvoff, swrow + brow_step, 0);                         \
         if (B_PER_THREAD == 4) {                                                                              \
@@ -146,10 +168,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_mfma_f32_kernel(const float* __re
 #define TIA_STORE_A(R)                                                             \
     {                                                                              \
         float* dst = As + ((tid >> 3) + 32 * R) * LDA + 4 * quad;                  \
-        dst[0] = __uint_as_float(ra##R.x);                                         \
-        dst[1] = __uint_as_float(ra##R.y);                                         \
-        dst[2] = __uint_as_float(ra##R.z);                                         \
-        dst[3] = __uint_as_float(ra##R.w);                                         \
+        dst[0] = pre_act(__uint_as_float(ra##R.x), rps.x, rpt.x);                  \
+        dst[1] = pre_act(__uint_as_float(ra##R.y), rps.y, rpt.y);                  \
+        dst[2] = pre_act(__uint_as_float(ra##R.z), rps.z, rpt.z);                  \
+        dst[3] = pre_act(__uint_as_float(ra##R.w), rps.w, rpt.w);                  \
     }
 #define TIA_STORE_SLICE()                                                                       \
     {                                                                                           \
@@ -293,9 +315,15 @@ extern "C" int tia_conv_pack_weights_f32(const float* d_w_oihw, int64_t cout, in
 static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y, int64_t n,
                        int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t stride, int64_t pad_top,
                        int64_t pad_left, int64_t ho, int64_t wo, int32_t relu, const float* d_post_scale, const float* d_post_shift,
-                       float* d_y2, void* stream, int64_t pstride = 0) {
+                       float* d_y2, void* stream, int64_t pstride = 0, const float* d_pre_scale = nullptr,
+                       const float* d_pre_shift = nullptr) {
     const bool with_post = d_y2 != nullptr;
+    const bool with_pre = d_pre_scale != nullptr;
     if (pstride <= 0) pstride = cin;
+    // activation on load: 1x1 without padding only (a padding tap must contribute zero, not relu(shift))
+    if (with_pre && (!d_pre_shift || with_post || kh != 1 || kw != 1 || pad_top != 0 || pad_left != 0 || pstride != cin ||
+                     ((reinterpret_cast<uintptr_t>(d_pre_scale) | reinterpret_cast<uintptr_t>(d_pre_shift)) & 15) != 0))
+        return TIA_EINVAL;
     if (with_post && (!d_post_scale || !d_post_shift)) return TIA_EINVAL;
     if (!d_x || !d_w_packed || (!d_y && !with_post) || n <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0)
         return TIA_EINVAL;
@@ -322,13 +350,13 @@ static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d
         const float* xg = d_x + first * h * w * pstride;
         const float* rg = d_residual ? d_residual + first * ho * wo * cout : nullptr;
         float* yg = d_y ? d_y + first * ho * wo * cout : nullptr;
-        const ConvPost post{d_post_scale, d_post_shift, with_post ? d_y2 + first * ho * wo * cout : nullptr};
+        const ConvPost post{d_post_scale, d_post_shift, with_post ? d_y2 + first * ho * wo * cout : nullptr, d_pre_scale, d_pre_shift};
         // 3x3 / stride 1 on maps that 16 x 16 pixel blocks cover with little waste: the tap-reuse kernel (conv3x3_spatial.hip)
-        if (!with_post && pstride == cin && tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad_top, pad_left, true) &&
+        if (!with_post && !with_pre && pstride == cin && tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad_top, pad_left, true) &&
             tia::conv3x3_spatial_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, pad_top, pad_left, ho, wo, TIA_DT_F32, relu, st))
             continue;
         // 1x1 (any stride, no padding): the LDS-DMA ring GEMM of conv3x3_spatial.hip
-        if (!with_post && pstride == cin && kh == 1 && kw == 1 && pad_top == 0 && pad_left == 0 &&
+        if (!with_post && !with_pre && pstride == cin && kh == 1 && kw == 1 && pad_top == 0 && pad_left == 0 &&
             tia::conv1x1_ring_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, stride, ho, wo, relu, st))
             continue;
         const long grid_x = ((m_tiles + 7) / 8) * 8;  // whole rounds over the 8 XCDs (surplus workgroups exit at once)
@@ -337,8 +365,15 @@ static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d
         // 1x1 convolutions with few input channels have only cin / 32 slices per tile: the narrower tile (more workgroups,
         // 5 instead of 3 per CU) hides their prologue / epilogue better (+15-20 % on resnet18's down-sampling convolutions)
         const bool narrow = force64 || (!no_rule && kh == 1 && kw == 1 && cin <= 256);
-        const ConvPost none{nullptr, nullptr, nullptr};
-        if (cout % 128 == 0 && !narrow) {
+        const ConvPost none{nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (with_pre) {
+            if (cout % 128 == 0 && !narrow)
+                hipLaunchKernelGGL((conv_mfma_f32_kernel<128, false, true>), dim3((unsigned)grid_x, (unsigned)(cout / 128)), dim3(NTH), 0,
+                                   st, xg, d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles, post);
+            else
+                hipLaunchKernelGGL((conv_mfma_f32_kernel<64, false, true>), dim3((unsigned)grid_x, (unsigned)(cout / 64)), dim3(NTH), 0, st,
+                                   xg, d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles, post);
+        } else if (cout % 128 == 0 && !narrow) {
             if (with_post)
                 hipLaunchKernelGGL((conv_mfma_f32_kernel<128, true>), dim3((unsigned)grid_x, (unsigned)(cout / 128)), dim3(NTH), 0, st, xg,
                                    d_w_packed, d_bias, rg, yg, d, relu, (int)m_tiles, post);
@@ -399,6 +434,15 @@ extern "C" int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packe
     if (!d_y2) return TIA_EINVAL;
     return conv2d_impl(d_x, d_w_packed, d_bias, d_residual, d_y, n, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo, relu,
                        d_post_scale, d_post_shift, d_y2, stream);
+}
+
+extern "C" int tia_conv1x1_pre_nhwc_f32(const float* d_x, const float* d_pre_scale, const float* d_pre_shift, const float* d_w_packed,
+                                       const float* d_bias, const float* d_residual, float* d_y, int64_t n, int64_t h, int64_t w,
+                                       int64_t cin, int64_t cout, int64_t stride, int32_t relu, void* stream) {
+    if (!d_y || !d_pre_scale || !d_pre_shift || h <= 0 || w <= 0 || stride <= 0) return TIA_EINVAL;
+    const long ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+    return conv2d_impl(d_x, d_w_packed, d_bias, d_residual, d_y, n, h, w, cin, cout, 1, 1, stride, 0, 0, ho, wo, relu, nullptr, nullptr,
+                       nullptr, stream, 0, d_pre_scale, d_pre_shift);
 }
 
 extern "C" int tia_conv2d_nhwc_f32(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual,

@@ -233,6 +233,32 @@ def hip_conv2d_post(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor 
     return y, y2
 
 
+def hip_conv1x1_pre(x: torch.Tensor, pre_scale: torch.Tensor, pre_shift: torch.Tensor, w_packed: torch.Tensor,
+                    bias: torch.Tensor | None, residual: torch.Tensor | None = None, *, stride: int = 1,
+                    relu: bool = False) -> torch.Tensor:
+    """``act(conv1x1(relu(x * pre_scale[c] + pre_shift[c])) + bias [+ residual])`` with the activation applied on load
+    (``tia_conv1x1_pre_nhwc_f32``): the pre-activation in front of a residual unit without an activated copy in memory."""
+    from tiatoolbox_amd import _lib
+
+    if not (_nhwc_ptr_ok(x) and x.dtype == torch.float32):
+        msg = "hip_conv1x1_pre expects a float32 channels-last CUDA tensor."
+        raise ValueError(msg)
+    n, cin, h, w = x.shape
+    cout = w_packed.shape[-1]
+    shape = (n, cout, (h - 1) // stride + 1, (w - 1) // stride + 1)
+    if residual is not None and not (_nhwc_ptr_ok(residual) and residual.dtype == torch.float32 and residual.shape == shape):
+        msg = "hip_conv1x1_pre: residual must be a float32 channels-last CUDA tensor of the output shape."
+        raise ValueError(msg)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().tia_conv1x1_pre_nhwc_f32(x.data_ptr(), pre_scale.data_ptr(), pre_shift.data_ptr(), w_packed.data_ptr(),
+                                                  bias.data_ptr() if bias is not None else 0,
+                                                  residual.data_ptr() if residual is not None else 0, y.data_ptr(), n, h, w, cin,
+                                                  cout, stride, int(relu), _lib.current_stream())
+    _lib.check(rc, "tia_conv1x1_pre_nhwc_f32")
+    return y
+
+
 def hip_scale_shift_act(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, *, relu: bool = True,
                         inplace: bool = False) -> torch.Tensor:
     """``relu(x * scale[c] + shift[c])`` on a float32 channels-last CUDA tensor (``tia_scale_shift_act_nhwc_f32``)."""

@@ -8,7 +8,10 @@ pre-activation ResNet-50 encoder, the decoders' ``conva`` / ``convf`` and the de
 * ``conv -> BN -> ReLU`` (``conv1`` / ``conv2`` of every unit, the stem): BN folded into the weights, bias + ReLU in the
   convolution's epilogue;
 * ``conv3 + shortcut``: the residual add rides in the epilogue of ``conv3``;
-* ``BN -> ReLU -> conv`` (pre-activations, ``blk_bna``): one ``tia_scale_shift_act_nhwc_f32`` pass instead of two;
+* ``BN -> ReLU -> conv1`` (the pre-activation of residual units 2..n): applied to the operand while ``conv1`` loads it
+  (``tia_conv1x1_pre_nhwc_f32``) -- the unit reads the previous raw sum, no activated copy exists in memory; ``blk_bna``
+  (after the last unit) comes out of ``conv3``'s epilogue as its only output (``tia_conv2d_post_nhwc_f32``); the dense
+  units' pre-activations are one ``tia_scale_shift_act_nhwc_f32`` pass;
 * TensorFlow "same" padding of the strided 3x3: expressed by the convolution's explicit front padding / output size.
 
 The other convolutions are hand-written too: the 3-channel 7x7 stem runs on the same MFMA kernel in its row-packed
@@ -20,13 +23,14 @@ weights; float32, CUDA, channels-last only.
 
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 
 import torch
 import torch.nn.functional as F  # noqa: N812
 from torch import nn
 
-from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv1x1_head, hip_conv2d_ex, hip_conv2d_post,
+from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv1x1_head, hip_conv1x1_pre, hip_conv2d_ex, hip_conv2d_post,
                                                       hip_conv2d_thin, hip_grouped_conv_valid, hip_scale_shift_act,
                                                       hip_scale_shift_act_view, hip_upsample2x_add, pack_conv_weights,
                                                       pack_thin_conv_weights)
@@ -121,6 +125,17 @@ def _conv_with_post(conv: "_Conv", x: torch.Tensor, residual: torch.Tensor, bn: 
                            pad_hi=0, relu=False, post_scale=bn.scale, post_shift=bn.shift, want_raw=want_raw)
 
 
+def _conv_pre_on_load(conv: "_Conv", x: torch.Tensor, bn: "_BnAct") -> torch.Tensor:
+    """``relu(conv(relu(bn(x))) + bias)`` for a 1x1 MFMA convolution, the BN + ReLU applied to the operand on load."""
+    if conv._packed is None or conv._packed.device != conv.weight.device:  # noqa: SLF001
+        conv._packed = pack_conv_weights(conv)  # noqa: SLF001
+    return hip_conv1x1_pre(_cl(x), bn.scale, bn.shift, conv._packed, conv.bias, stride=conv.stride, relu=True)  # noqa: SLF001
+
+
+# developer switch for A/B measurements: TIA_HOVER_PRE_ON_LOAD=0 keeps the second (activated) epilogue output instead
+_PRE_ON_LOAD = os.environ.get("TIA_HOVER_PRE_ON_LOAD", "1") != "0"
+
+
 class _BnAct(nn.Module):
     def __init__(self, bn: nn.BatchNorm2d) -> None:
         super().__init__()
@@ -154,14 +169,20 @@ class _FusedResidualBlock(nn.Module):
         shortcut = x if self.shortcut is None else self.shortcut(x)
         units = len(self.c1)
         a = x  # the first unit has no pre-activation
+        raw_in = False  # `a` is the raw residual sum: the unit's pre-activation is applied by conv1 on load
         for i, (c1, c2, c3) in enumerate(zip(self.c1, self.c2, self.c3)):
-            a = c1(a, relu=True)
+            a = _conv_pre_on_load(c1, a, self.pre[i]) if raw_in else c1(a, relu=True)
             a = c2(a, pads=_same_pads(a.shape[2], c2.kernel, c2.stride), relu=True)
             last = i + 1 == units
             nxt = self.out if last else self.pre[i + 1]
-            if c3.mfma_ok:
-                # conv3 + shortcut, and the BN + ReLU that follows the sum (next unit's pre-activation, or the block's
-                # blk_bna), from one epilogue; the raw sum is only kept while a later unit needs it as its shortcut
+            raw_in = not last and _PRE_ON_LOAD and c3.mfma_ok and self.c1[i + 1].mfma_ok and self.c1[i + 1].kernel == 1
+            if raw_in:
+                # conv3 + shortcut only: the next unit reads this raw sum twice (conv1 activates it on load, conv3 adds it),
+                # so the activated copy is neither written nor read back -- 3 instead of 4 passes over the widest tensor
+                a = shortcut = c3(a, residual=_cl(shortcut))
+            elif c3.mfma_ok:
+                # conv3 + shortcut, and the BN + ReLU that follows the sum (the block's blk_bna, or the next unit's
+                # pre-activation when on-load activation is off), from one epilogue
                 shortcut, a = _conv_with_post(c3, a, _cl(shortcut), nxt, want_raw=not last)
             else:
                 shortcut = c3(a, residual=_cl(shortcut))
