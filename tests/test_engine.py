@@ -283,7 +283,10 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
              # 1x1 (the ring GEMM): stride 1 and 2, few and many channel slices, pixel counts that are no multiple of 256
              (2, 256, 64, 20, 1, 1), (1, 64, 256, 31, 1, 1), (3, 1024, 256, 9, 1, 1), (1, 96, 192, 11, 1, 1), (2, 128, 256, 27, 1, 2),
              # ... and large enough for the ring GEMM's dispatch rule (>= 384 workgroups of 256 pixels x 128 channels)
-             (2, 64, 128, 224, 1, 1), (4, 64, 256, 224, 1, 2), (3, 96, 128, 187, 1, 1)]
+             (2, 64, 128, 224, 1, 1), (4, 64, 256, 224, 1, 2), (3, 96, 128, 187, 1, 1),
+             # the ring gathering 3x3 taps (layers the tap-reuse kernel leaves, >= 384 workgroups): stride 2 with "same" padding on even
+             # and odd maps, 7 x 7 maps at stride 1 (every tap pattern of a border pixel), ragged last block
+             (160, 64, 128, 56, 3, 2), (48, 32, 128, 99, 3, 2), (600, 64, 512, 7, 3, 1), (2400, 96, 128, 7, 3, 1)]
     import ctypes
 
     from tiatoolbox_amd import _lib
@@ -319,6 +322,15 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
             assert got.shape == exp.shape and got.is_contiguous(memory_format=torch.channels_last)
             err = (got.cpu() - exp).abs().max().item()
             assert err <= 1e-4, (n, cin, cout, hw, k, stride, use_res, relu, err)
+        if n >= 40:  # noqa: PLR2004
+            # against the slice kernel (the two-output epilogue form always runs on it; its raw output is the same convolution):
+            # the same float32 fmaf chains over taps and slices, channels within a 16-slice in another order -- rounding noise only
+            from tiatoolbox_amd.models.architecture.fused import hip_conv2d_post
+
+            got = hip_conv2d(xd, wp, dev_conv.bias, rd, kernel=k, stride=stride, padding=pad, relu=False)
+            raw, _ = hip_conv2d_post(xd, wp, dev_conv.bias, rd, kernel=k, stride=stride, pad_lo=pad, pad_hi=pad, relu=False,
+                                     post_scale=torch.ones(cout, device="cuda"), post_shift=torch.zeros(cout, device="cuda"))
+            assert (got - raw).abs().max().item() <= 2e-5, (n, cin, cout, hw, k, stride)
     # explicit borders (`tia_conv2d_nhwc_f32_ex`): a valid 3x3 (HoVer-Net's decoder) and "same" given as 1 / 1, rectangular map
     from tiatoolbox_amd.models.architecture.fused import hip_conv2d_ex
 

@@ -431,9 +431,14 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
 // waves issue the 32 MFMAs of the current one; one barrier and one vmcnt(0) per slice (the DMA has a whole MFMA phase to land)
 // instead of the slice kernel's register staging and barrier pair.  Strided 1x1 (ResNet down-sampling) only changes which input
 // pixel an output pixel reads.
+// The same ring also GATHERS: for a kh x kw convolution (any stride, front padding < kernel) the reduction runs over (tap, 16-channel
+// slice) in the slice kernel's order, a slice's DMA address is the pixel's tap-(0, 0) offset plus a scalar tap delta, and a tap
+// outside the image is an out-of-range offset (the DMA writes zeros) chosen with one mask test per unit -- the implicit GEMM for
+// the layers the tap-reuse kernel does not serve (stride-2 3x3, maps 16 x 16 blocks cover badly), bit-identical to the slice kernel.
 struct PwDims {
     int n, h, w, cin, cout, ho, wo, stride;
     unsigned x_bytes, w_bytes;
+    int kh, kw, pad_y, pad_x;
 };
 
 template <int BN>
@@ -464,7 +469,10 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ring_kernel(const float* __res
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)d.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, (int)d.w_bytes, 0x00020000);
 
+    // per DMA unit: byte offset of tap (0, 0) of its pixel (may lie before the buffer: only used when the tap is inside the image)
+    // and one bit per kernel row / column saying whether that row / column of taps is inside (all set for a 1x1)
     int cen[3];
+    unsigned msk[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int u = NT * r + tid;
@@ -474,20 +482,37 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ring_kernel(const float* __res
         const int mm = ok ? (int)m : 0;
         const int b = mm / (d.ho * d.wo), rem = mm - b * d.ho * d.wo;
         const int oy = rem / d.wo, ox = rem - oy * d.wo;
-        cen[r] = ok ? (((b * d.h + oy * d.stride) * d.w + ox * d.stride) * d.cin) * 4 + 16 * chunk : OOB;
+        const int iy0 = oy * d.stride - d.pad_y, ix0 = ox * d.stride - d.pad_x;
+        cen[r] = (((b * d.h + iy0) * d.w + ix0) * d.cin) * 4 + 16 * chunk;
+        unsigned rows = 0, cols = 0;
+        for (int t = 0; t < d.kh; ++t) rows |= (unsigned)((unsigned)(iy0 + t) < (unsigned)d.h) << t;
+        for (int t = 0; t < d.kw; ++t) cols |= (unsigned)((unsigned)(ix0 + t) < (unsigned)d.w) << (16 + t);
+        msk[r] = ok ? (rows | cols) : 0u;
     }
     const int bk = tid / (BN / 4), bcu = tid - bk * (BN / 4);
     const int b_off = bk < 16 ? (bk * d.cout + n0) * 4 + 16 * bcu : OOB;
     const int n_cs = d.cin >> 4;
+    const int n_slices = d.kh * d.kw * n_cs;
 
-    auto dma_stage = [&](int stage, int cs) {
+    // slice cursor (scalar): tap (s_kh, s_kw), channel slice s_cs of the slice that is requested next
+    int s_kh = 0, s_kw = 0, s_cs = 0;
+    auto dma_stage = [&](int stage) {
         unsigned char* sa = smem + stage * STAGE;
+        const int sdelta = (s_kh * d.w + s_kw) * d.cin * 4;
+        const unsigned sel = (1u << s_kh) | (1u << (16 + s_kw));
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             unsigned char* dst = (NT * r + wave * 64 >= A_UNITS) ? smem + DUMP : sa + r * (NT * 16) + wave * 1024;
-            dma16(rx, dst, cen[r], cs * 64);
+            dma16(rx, dst, (msk[r] & sel) == sel ? cen[r] + sdelta : OOB, s_cs * 64);
         }
-        dma16(rw, sa + A_BYTES + wave * 1024, b_off, cs * 16 * d.cout * 4);
+        dma16(rw, sa + A_BYTES + wave * 1024, b_off, (((s_kh * d.kw + s_kw) * d.cin) + s_cs * 16) * d.cout * 4);
+    };
+    // past the last slice the cursor stays there: the idle stage is refilled with the same slice
+    auto next_slice = [&]() {
+        int cs = s_cs + 1, kw = s_kw, kh = s_kh;
+        if (cs == n_cs) { cs = 0; ++kw; }
+        if (kw == d.kw) { kw = 0; ++kh; }
+        if (kh < d.kh) { s_cs = cs; s_kw = kw; s_kh = kh; }
     };
 
     f32x16 acc[2][NTILE];
@@ -502,12 +527,13 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ring_kernel(const float* __res
     const int fa0 = (wm * 64 + (lane & 31)) * PIX + 2 * hi;  // MFMA row = pixel wm * 64 + 32 i + (lane & 31); channels 8 hi .. 8 hi + 7
     const int fb0 = (8 * hi) * BN + wn * (BN / 2) + (lane & 31);
 
-    dma_stage(0, 0);
+    dma_stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int cs = 0; cs < n_cs; ++cs) {
-        const int stage = cs & 1;
-        dma_stage(stage ^ 1, cs + 1 < n_cs ? cs + 1 : cs);  // past the end: the idle stage is refilled with the same slice
+    for (int it = 0; it < n_slices; ++it) {
+        const int stage = it & 1;
+        next_slice();
+        dma_stage(stage ^ 1);
         const u32x4* sa = reinterpret_cast<const u32x4*>(smem + stage * STAGE) + fa0;
         const float* sb = reinterpret_cast<const float*>(smem + stage * STAGE + A_BYTES) + fb0;
         u32x4 a[2][2];
@@ -627,19 +653,38 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
     return true;
 }
 
-bool conv1x1_ring_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, long nb, long h, long w,
-                         long cin, long cout, long stride, long ho, long wo, int relu, hipStream_t stream) {
+bool conv_ring_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, long nb, long h, long w,
+                      long cin, long cout, long kh, long kw, long stride, long pad_top, long pad_left, long ho, long wo, int relu,
+                      hipStream_t stream) {
     static const bool disabled = getenv("TIA_CONV_NO_RING") != nullptr;
-    if (disabled || cin % 16 != 0 || cout % 128 != 0) return false;
+    static const bool no_taps = getenv("TIA_CONV_NO_GATHER_RING") != nullptr;  // developer switch (A/B measurements)
+    if (disabled || cin % 16 != 0 || cout % 128 != 0 || kh > 16 || kw > 16) return false;
+    if ((kh != 1 || kw != 1) && no_taps) return false;
     const long m_total = nb * ho * wo, tiles = (m_total + 255) / 256;
     // measured (profiles/r03u_unet_layers*.txt): with 64 output channels (half the MFMAs per barrier) and with fewer than ~1.5
     // workgroups per CU (256-pixel blocks: small maps at small batches) the slice kernel is the faster one
     if (tiles * (cout / 128) < 384) return false;
+    if (kh != 1 || kw != 1) {
+        // gathering taps, the ring beats the slice kernel only while its rounds of 2 workgroups per CU are full (measured,
+        // profiles/r04y_*_probe.txt: +5..+28 % at >= 0.875 full, -3..-14 % at 0.77: 7 x 7 outputs of a 1024-patch batch)
+        static const int slots = [] {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return 2 * (cus > 0 ? cus : 256);
+        }();
+        const long wgs = tiles * (cout / 128), rounds = (wgs + slots - 1) / slots;
+        if (wgs * 100 < rounds * slots * 85) return false;
+    }
     const PwDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)stride, (unsigned)(nb * h * w * cin * 4),
-                   (unsigned)(cin * cout * 4)};
+                   (unsigned)(kh * kw * cin * cout * 4), (int)kh, (int)kw, (int)pad_top, (int)pad_left};
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / 128));
     hipLaunchKernelGGL(conv1x1_ring_kernel<128>, grid, dim3(512), 0, stream, x, w_packed, bias, residual, y, d, relu, (int)tiles);
     return true;
+}
+
+bool conv1x1_ring_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, long nb, long h, long w,
+                         long cin, long cout, long stride, long ho, long wo, int relu, hipStream_t stream) {
+    return conv_ring_launch(x, w_packed, bias, residual, y, nb, h, w, cin, cout, 1, 1, stride, 0, 0, ho, wo, relu, stream);
 }
 
 }  // namespace tia

@@ -72,4 +72,10 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
 bool conv1x1_ring_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, long nb, long h, long w,
                          long cin, long cout, long stride, long ho, long wo, int relu, hipStream_t stream);
 
+// The same ring gathering kh x kw taps (any stride, front padding < kernel): the implicit GEMM for the 3x3 layers the tap-reuse
+// kernel does not serve.  false: disabled, or a shape the slice kernel handles better (cout % 128 != 0, few workgroups).
+bool conv_ring_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, long nb, long h, long w,
+                      long cin, long cout, long kh, long kw, long stride, long pad_top, long pad_left, long ho, long wo, int relu,
+                      hipStream_t stream);
+
 }  // namespace tia

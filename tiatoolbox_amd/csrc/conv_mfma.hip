@@ -355,9 +355,9 @@ static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d
         if (!with_post && !with_pre && pstride == cin && tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad_top, pad_left, true) &&
             tia::conv3x3_spatial_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, pad_top, pad_left, ho, wo, TIA_DT_F32, relu, st))
             continue;
-        // 1x1 (any stride, no padding): the LDS-DMA ring GEMM of conv3x3_spatial.hip
-        if (!with_post && !with_pre && pstride == cin && kh == 1 && kw == 1 && pad_top == 0 && pad_left == 0 &&
-            tia::conv1x1_ring_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, stride, ho, wo, relu, st))
+        // 1x1 (any stride), and the kh x kw layers the tap-reuse kernel left: the LDS-DMA ring GEMM of conv3x3_spatial.hip
+        if (!with_post && !with_pre && pstride == cin &&
+            tia::conv_ring_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo, relu, st))
             continue;
         const long grid_x = ((m_tiles + 7) / 8) * 8;  // whole rounds over the 8 XCDs (surplus workgroups exit at once)
         static const bool force64 = getenv("TIA_CONV_BN64") != nullptr;  // developer switches (tile-shape experiments)
