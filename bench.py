@@ -225,23 +225,19 @@ def ev_time(fn, reps: int = 10) -> float:
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-def spatial_conv(k: int, stride: int, h: int, w: int, ho: int, wo: int, pad: int) -> bool:
-    """Which kernel a block convolution runs on: the library's own dispatch answer (``tia_conv3x3_geometry``: 16 x 16 blocks,
-    two 8 x 8 images, or bands of a strip of the stacked batch -> ``conv3x3_spatial_kernel``; 0 -> ``conv_mfma_f32_kernel``)."""
-    import ctypes
-
+def _lib_route(n, h, w, cin, cout, k, stride, pad, ho, wo) -> int:
     from tiatoolbox_amd import _lib
 
-    if k != 3 or stride != 1:  # noqa: PLR2004
-        return False
-    geom = (ctypes.c_int32 * 4)()
-    return _lib.load().tia_conv3x3_geometry(h, w, ho, wo, pad, pad, geom) != 0
+    route = int(_lib.load().tia_conv2d_route_f32(n, h, w, cin, cout, k, k, stride, pad, pad, ho, wo))
+    if route < 0:
+        raise RuntimeError(f"tia_conv2d_route_f32 refused the shape ({route})")
+    return route
 
 
 def trunk_roofline(model, u8_batch):
     """HIP-event times and algorithmic flops of the hand-written convolution kernels of one trunk forward: the stem kernel
     (one launch) and the block convolutions, split by kernel -- ``conv3x3_spatial_kernel`` (3x3 / stride 1, tap reuse),
-    ``conv1x1_ring_kernel`` (1x1) and ``conv_mfma_f32_kernel`` (strided 3x3).  Per-launch events (one sync per launch, kernel time
+    ``conv1x1_ring_kernel`` (1x1, and strided 3x3 gathered) and ``conv_mfma_f32_kernel`` (what is left), as ``tia_conv2d_route_f32`` says.  Per-launch events (one sync per launch, kernel time
     only) give the split; the total is timed separately over whole forwards without syncs."""
     import torch
 
@@ -261,12 +257,8 @@ def trunk_roofline(model, u8_batch):
         e1.record()
         e1.synchronize()
         n, co, ho, wo = y.shape
-        if spatial_conv(kernel, stride, x.shape[2], x.shape[3], ho, wo, padding):
-            name = "conv3x3_spatial_kernel"
-        elif kernel == 1 and co % 128 == 0 and ((n * ho * wo + 255) // 256) * (co // 128) >= 384:  # noqa: PLR2004
-            name = "conv1x1_ring_kernel"  # mirror of conv1x1_ring_launch's rule (csrc/conv3x3_spatial.hip)
-        else:
-            name = "conv_mfma_f32_kernel"
+        route = _lib_route(n, x.shape[2], x.shape[3], x.shape[1], co, kernel, stride, padding, ho, wo)
+        name = ("conv_mfma_f32_kernel", "conv3x3_spatial_kernel", "conv1x1_ring_kernel")[route]  # the library's own answer
         f = fam[name]
         f[0] += 1
         f[1] += e0.elapsed_time(e1) * 1e-3
@@ -487,8 +479,8 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
         dominant = max(fams, key=lambda k: fams[k]["seconds"])
         dk = fams[dominant]
         desc = {"conv3x3_spatial_kernel": "3x3 / stride-1 convolutions, 16x16 (or 2 x 8x8) pixel blocks with tap reuse (LDS-DMA patch + weight ring)",
-                "conv1x1_ring_kernel": "1x1 convolutions as a GEMM over 256-pixel blocks, both operands by LDS-DMA (two-stage ring)",
-                "conv_mfma_f32_kernel": "strided 3x3 (and small 1x1) convolutions, 128-pixel slices"}
+                "conv1x1_ring_kernel": "1x1 and strided 3x3 convolutions as a GEMM over 256-pixel blocks, both operands by LDS-DMA (two-stage ring, taps gathered)",
+                "conv_mfma_f32_kernel": "convolutions left to the register-staged 128-pixel slice kernel (small maps / few workgroups)"}
         roofline = {
             "kernel": dominant, "bound": "mfma", "achieved": round(dk["tflops"], 2),
             "peak": MFMA_PEAK_TFLOPS["float32"], "unit": "TFLOP/s",

@@ -482,6 +482,13 @@ int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const fl
                              int32_t relu, const float* d_post_scale, const float* d_post_shift, float* d_y2,
                              void* stream);
 
+/* Host-only query (no launch): which kernel tia_conv2d_nhwc_f32[_ex] runs a float32 convolution of this shape on --
+ * 0: conv_mfma_f32_kernel (register-staged 128-pixel slices), 1: conv3x3_spatial_kernel (tap reuse; tia_conv3x3_geometry says
+ * which block geometry), 2: conv1x1_ring_kernel (LDS-DMA ring over 256-pixel blocks: 1x1, and kh x kw taps gathered).  For
+ * tests and bench.py (they ask instead of mirroring the dispatch rule); negative: TIA_EINVAL. */
+int tia_conv2d_route_f32(int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                         int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo);
+
 /* 1x1 convolution (any stride, no padding) whose INPUT is activated on load:
  *   y = act(conv1x1(relu(x * pre_scale[c] + pre_shift[c]), w) + bias [+ residual])
  * -- the "preact/bn" + ReLU in front of conv1 of HoVer-Net's residual units 2..n (models/architecture/hovernet.py:100-147),

@@ -148,6 +148,18 @@ def test_host_only_dispatch_queries():
     for side in (64, 32, 16, 128, 512):
         assert geometry(side, side, side, side, 1) == (1, [0, 0, 0, 0])
     assert geometry(8, 8, 8, 8, 1)[0] == 2
+    # the kernel a float32 convolution runs on (0 slice / 1 tap reuse / 2 LDS-DMA ring): resnet18 on a 1024-patch batch (a host
+    # without a GPU answers for 256 CUs) -- stride-2 3x3 on the gathering ring while its rounds are >= 85 % full, 7 x 7 maps and
+    # small batches on the slice kernel, 1x1 down-sampling on the ring
+    def route(n, hw, cin, cout, k, stride, pad):
+        ho = (hw + 2 * pad - k) // stride + 1
+        return lib.tia_conv2d_route_f32(n, hw, hw, cin, cout, k, k, stride, pad, pad, ho, ho)
+
+    assert route(1024, 64, 64, 64, 3, 1, 1) == 1 and route(1024, 8, 512, 512, 3, 1, 1) == 1
+    assert route(1024, 64, 64, 128, 3, 2, 1) == 2 and route(1024, 32, 128, 256, 3, 2, 1) == 2 and route(1024, 16, 256, 512, 3, 2, 1) == 2  # noqa: PLR2004
+    assert route(1024, 56, 64, 128, 3, 2, 1) == 2 and route(1024, 28, 128, 256, 3, 2, 1) == 0 and route(1024, 7, 512, 512, 3, 1, 1) == 0  # noqa: PLR2004
+    assert route(1024, 64, 64, 128, 1, 2, 0) == 2 and route(4, 64, 64, 128, 3, 2, 1) == 0 and route(1024, 64, 64, 64, 1, 1, 0) == 0  # noqa: PLR2004
+    assert route(0, 64, 64, 128, 3, 2, 1) < 0
     # valid convolutions (HoVer-Net's decoder) never take the band form; 16 x 16 blocks when they cover >= 7/8
     assert geometry(164, 164, 162, 162, 0)[0] == 0 and geometry(64, 64, 62, 62, 0)[0] == 1
     for h in range(9, 130):

@@ -323,6 +323,8 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
             err = (got.cpu() - exp).abs().max().item()
             assert err <= 1e-4, (n, cin, cout, hw, k, stride, use_res, relu, err)
         if n >= 40:  # noqa: PLR2004
+            ho_ = ref_lin.shape[2]
+            assert _lib.load().tia_conv2d_route_f32(n, hw, hw, cin, cout, k, k, stride, pad, pad, ho_, ho_) == 2  # the gathering ring  # noqa: PLR2004
             # against the slice kernel (the two-output epilogue form always runs on it; its raw output is the same convolution):
             # the same float32 fmaf chains over taps and slices, channels within a 16-slice in another order -- rounding noise only
             from tiatoolbox_amd.models.architecture.fused import hip_conv2d_post

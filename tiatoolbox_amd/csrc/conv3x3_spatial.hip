@@ -653,9 +653,7 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
     return true;
 }
 
-bool conv_ring_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, long nb, long h, long w,
-                      long cin, long cout, long kh, long kw, long stride, long pad_top, long pad_left, long ho, long wo, int relu,
-                      hipStream_t stream) {
+bool conv_ring_ok(long nb, long cin, long cout, long kh, long kw, long ho, long wo) {
     static const bool disabled = getenv("TIA_CONV_NO_RING") != nullptr;
     static const bool no_taps = getenv("TIA_CONV_NO_GATHER_RING") != nullptr;  // developer switch (A/B measurements)
     if (disabled || cin % 16 != 0 || cout % 128 != 0 || kh > 16 || kw > 16) return false;
@@ -675,6 +673,14 @@ bool conv_ring_launch(const float* x, const float* w_packed, const float* bias, 
         const long wgs = tiles * (cout / 128), rounds = (wgs + slots - 1) / slots;
         if (wgs * 100 < rounds * slots * 85) return false;
     }
+    return true;
+}
+
+bool conv_ring_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, long nb, long h, long w,
+                      long cin, long cout, long kh, long kw, long stride, long pad_top, long pad_left, long ho, long wo, int relu,
+                      hipStream_t stream) {
+    if (!conv_ring_ok(nb, cin, cout, kh, kw, ho, wo)) return false;
+    const long tiles = (nb * ho * wo + 255) / 256;
     const PwDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)stride, (unsigned)(nb * h * w * cin * 4),
                    (unsigned)(kh * kw * cin * cout * 4), (int)kh, (int)kw, (int)pad_top, (int)pad_left};
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / 128));

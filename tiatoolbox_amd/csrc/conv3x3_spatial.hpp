@@ -74,6 +74,7 @@ bool conv1x1_ring_launch(const float* x, const float* w_packed, const float* bia
 
 // The same ring gathering kh x kw taps (any stride, front padding < kernel): the implicit GEMM for the 3x3 layers the tap-reuse
 // kernel does not serve.  false: disabled, or a shape the slice kernel handles better (cout % 128 != 0, few workgroups).
+bool conv_ring_ok(long nb, long cin, long cout, long kh, long kw, long ho, long wo);  // the dispatch rule alone
 bool conv_ring_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, long nb, long h, long w,
                       long cin, long cout, long kh, long kw, long stride, long pad_top, long pad_left, long ho, long wo, int relu,
                       hipStream_t stream);

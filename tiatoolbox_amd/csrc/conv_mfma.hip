@@ -412,6 +412,16 @@ extern "C" int tia_conv3x3_geometry(int64_t h, int64_t w, int64_t ho, int64_t wo
     return plan.kind;
 }
 
+extern "C" int tia_conv2d_route_f32(int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                                    int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || ho <= 0 || wo <= 0) return TIA_EINVAL;
+    if (cin % 16 == 0 && cout % 64 == 0 && pad_top <= 2 && pad_left <= 2 && getenv("TIA_CONV_NO_SPATIAL") == nullptr &&
+        tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad_top, pad_left, true))
+        return 1;
+    // (a batch beyond 2 GiB of input is split into groups; the answer is for a group that holds all n images)
+    return tia::conv_ring_ok(n, cin, cout, kh, kw, ho, wo) ? 2 : 0;
+}
+
 // Thin-input form (an RGB stem: c = 3): in NHWC the kw * c values under one row of taps are CONTIGUOUS, so a kh x kw
 // convolution over c channels is a kh x 1 convolution over 32 "row-packed" channels whose pixels lie c floats apart --
 // the same kernel with a pixel stride, weights [kh][32][cout] with rows >= kw * c zero (what they multiply is the rest of
