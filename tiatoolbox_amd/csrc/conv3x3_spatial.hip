@@ -95,12 +95,17 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
 // 256^2 patches): TWO images of 8 x 8, 4 waves (2 x 2, wave row = image); an MFMA tile is four 8-pixel rows, and the row pitch is
 // 8 mod 16 units, which puts the four rows' lanes of a ds_read_b128 group ({0-3} {12-15} {20-23} {24-27}) on 16 different bank
 // groups the same way (k-space: {0-3}, 8+{4-7}, 16+{4-7}, 24+{0-3}).
+// WN = waves along the channel dimension.  GBN (band geometry, 64 output channels) puts four waves along the pixels: a wave then
+// owns 64 pixels x 64 channels = 2 x 2 MFMA tiles like a wave of the 128-channel kernels (32 MFMAs per tap and barrier instead of
+// 16, one LDS fragment read per MFMA instead of 1.5).  Measured (profiles/r04za_n64_*.txt): +1 % on 56^2 maps, +3.6 % on
+// HoVer-Net's 164^2 decoder layer; the same form of the 16 x 16 geometry was -1 % and is not kept -- the 64-channel layers' gap to
+// the 128-channel ones (130 vs 146 TFLOP/s) is not a barrier-interval effect.
 struct G16 {
-    static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 18, PWD = 18, ROW = 96, IMG = 18 * 96, MROWS = 2, WAVES_M = 4;
+    static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 18, PWD = 18, ROW = 96, IMG = 18 * 96, MROWS = 2, WAVES_M = 4, WN = 2;
     static constexpr bool BAND = false;
 };
 struct G8 {
-    static constexpr int NT = 256, G = 2, TH = 8, TW = 8, PH = 10, PWD = 10, ROW = 56, IMG = 10 * 56, MROWS = 4, WAVES_M = 2;
+    static constexpr int NT = 256, G = 2, TH = 8, TW = 8, PH = 10, PWD = 10, ROW = 56, IMG = 10 * 56, MROWS = 4, WAVES_M = 2, WN = 2;
     static constexpr bool BAND = false;
 };
 // Band geometry ("same" 3x3 convolutions on maps that 16 x 16 blocks cover badly: 56 / 28 / 14 / 7 of 224^2 patches).  The
@@ -117,7 +122,11 @@ struct G8 {
 // is what lets the 7-wide band (38 rows) fit the patch buffer with two workgroups per CU.  A one-workgroup-per-CU form with a
 // larger patch was measured and lost to the slice kernel (profiles/r04c_*: 106.6 vs 114.0 TFLOP/s on 512 -> 512 @ 7 x 7).
 struct GB {
-    static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 0, PWD = 0, ROW = 0, IMG = 1728, MROWS = 0, WAVES_M = 4;
+    static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 0, PWD = 0, ROW = 0, IMG = 1728, MROWS = 0, WAVES_M = 4, WN = 2;
+    static constexpr bool BAND = true;
+};
+struct GBN {
+    static constexpr int NT = 256, G = 1, TH = 16, TW = 16, PH = 0, PWD = 0, ROW = 0, IMG = 1728, MROWS = 0, WAVES_M = 4, WN = 1;
     static constexpr bool BAND = true;
 };
 
@@ -136,14 +145,16 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     constexpr bool F32 = KIND == K_F32;
     constexpr int ES = F32 ? 4 : 2;       // bytes per element
     constexpr int SC = 64 / ES;           // channels per 64-byte slice: 16 | 32
-    constexpr int NT = GEO::NT, NTILE = BN / 64;
+    constexpr int NT = GEO::NT, WN = GEO::WN, NTILE = BN / (32 * WN);
+    static_assert(WN == 2 || (WN == 1 && BN == 64), "all waves along the pixels: 64-channel tiles only");
     constexpr bool BAND = GEO::BAND;
     const int PIX = BAND ? d.bpix : 5;  // units per pixel in the LDS patch
     const int ROW = BAND ? d.brow : GEO::ROW;  // (a compile-time constant for the fixed geometries)
     constexpr int BLOCK_PX = GEO::G * GEO::TH * GEO::TW;                 // 256 | 128 output pixels = GEMM rows of the block
     constexpr int A_UNITS = (GEO::G * GEO::IMG + 63) / 64 * 64;           // patch units, whole waves: 1728 | 1152
     constexpr int NA = (A_UNITS + NT - 1) / NT;                           // DMA pieces per patch: 4 | 5 (the last one partial)
-    constexpr int NB = 512 / NT;                                          // DMA pieces per weight slice (512 units): 1 | 2
+    constexpr int B_UNITS = F32 ? 16 * BN / 4 : 4 * BN;                   // weight slice: 512 units (BN = 128) | 256
+    constexpr int NB = (B_UNITS + NT - 1) / NT;                           // DMA pieces per weight slice: 1 | 2
     constexpr int A_BYTES = A_UNITS * 16;
     constexpr int B_BYTES = 512 * 16;     // (BN = 64: the upper half idles)
     constexpr int DUMP = 2 * A_BYTES + 3 * B_BYTES;  // 1 KB that the idle waves of the last patch piece write their zeros to
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     const int tx0 = BAND ? (mt_id % d.strips) * d.bw : (trem - (trem / tiles_x) * tiles_x) * GEO::TW;
     const int n0 = blockIdx.y * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)d.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wk), 0, (int)d.w_bytes, 0x00020000);
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
         const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES);
         const int shift = (tap / 3) * ROW + (tap % 3) * PIX;
         if constexpr (F32) {
-            const float* sb = reinterpret_cast<const float*>(bring + stage * B_BYTES) + (8 * hi) * BN + wn * (BN / 2) + (lane & 31);
+            const float* sb = reinterpret_cast<const float*>(bring + stage * B_BYTES) + (8 * hi) * BN + wn * (BN / WN) + (lane & 31);
             u32x4 a[2][2];
             float b[NTILE][8];
 #pragma unroll
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
                     for (int j = 0; j < NTILE; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i][k >> 2][k & 3]), b[j][k], acc[i][j], 0, 0, 0);
         } else {
-            const u32x4* sb = reinterpret_cast<const u32x4*>(bring + stage * B_BYTES) + hi * BN + wn * (BN / 2) + (lane & 31);
+            const u32x4* sb = reinterpret_cast<const u32x4*>(bring + stage * B_BYTES) + hi * BN + wn * (BN / WN) + (lane & 31);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 u32x4 a[2], b[NTILE];
@@ -340,15 +351,17 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (wn == half) {
+        if (WN == 1 || wn == half) {
+            // WN == 2: the waves of this column half hold it in all their tiles; WN == 1: every wave holds it in tiles half * NH ..
+            constexpr int NH = WN == 2 ? NTILE : NTILE / 2;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NTILE; ++j)
+                for (int jj = 0; jj < NH; ++jj)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        tile[row * HB + j * 32 + (lane & 31)] = acc[i][j][e];
+                        tile[row * HB + jj * 32 + (lane & 31)] = acc[i][WN == 2 ? jj : half * NH + jj][e];
                     }
         }
         __syncthreads();
@@ -629,6 +642,7 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
                    (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es), plan.bw, plan.br, plan.brow, (int)(h + 1), plan.strips,
                    plan.bpix, band ? 1.0f / (float)plan.bw : 0.0f, band ? 1.0f / (float)plan.brow : 0.0f, 1.0f / (float)(h + 1)};
     const bool wide = cout % 128 == 0;
+    static const bool wide8 = getenv("TIA_CONV_N64_8WAVES") != nullptr;  // developer switch: 64-channel band tiles on the 8-wave (4 x 2) form
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / (wide ? 128 : 64)));
 #define TIA_LAUNCH_GEO(BN_, KIND_, GEO_)                                                                                           \
     hipLaunchKernelGGL((conv3x3_spatial_kernel<BN_, KIND_, GEO_>), grid, dim3(GEO_::NT), 0, stream, x, w_packed, bias, residual, y, d, \
@@ -638,7 +652,7 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
         switch (plan.kind) {                                                                                                       \
             case 1: TIA_LAUNCH_GEO(BN_, KIND_, G16); break;                                                                        \
             case 2: TIA_LAUNCH_GEO(BN_, KIND_, G8); break;                                                                         \
-            default: TIA_LAUNCH_GEO(BN_, KIND_, GB); break;                                                                        \
+            default: if (BN_ == 64 && !wide8) TIA_LAUNCH_GEO(64, KIND_, GBN); else TIA_LAUNCH_GEO(BN_, KIND_, GB); break;          \
         }                                                                                                                          \
     } while (0)
     if (dtype == TIA_DT_F32) {
