@@ -74,3 +74,33 @@ def test_load_stain_matrix(tmp_path: Path):
     assert np.all(get_normalizer("custom", tmp_path / "sm.csv").extractor.stain_matrix == RUIFROK)
     with pytest.raises(FileNotSupportedError):
         get_normalizer("custom", "/samplefile.xlsx")
+
+
+def test_stain_extract_helpers_of_the_product():
+    """The package's own host helpers (not the oracle's): ports of reference ``tests/test_stainnorm.py:16-68`` --
+    ``CustomExtractor`` shape check, ``vectors_in_correct_direction``, ``h_and_e_in_right_order``, ``dl_output_for_h_and_e``."""
+    from tiatoolbox_amd.tools import stainextract
+
+    with pytest.raises(ValueError, match=r"Stain matrix must have shape \(2, 3\) or \(3, 3\)."):
+        stainextract.CustomExtractor(np.array([0.65, 0.70, 0.29]))
+
+    e_vect = stainextract.vectors_in_correct_direction(e_vectors=np.ones([2, 2]))
+    assert np.all(e_vect == 1)
+    e_vect = np.ones([2, 2])
+    e_vect[0, 0] = -1
+    e_vect = stainextract.vectors_in_correct_direction(e_vectors=e_vect)
+    assert np.all(e_vect[:, 1] == 1) and e_vect[0, 0] == 1 and e_vect[1, 0] == -1
+    e_vect = np.ones([2, 2])
+    e_vect[0, 1] = -1
+    e_vect = stainextract.vectors_in_correct_direction(e_vectors=e_vect)
+    assert np.all(e_vect[:, 0] == 1) and e_vect[0, 1] == 1 and e_vect[1, 1] == -1
+
+    v1, v2 = np.ones(3), np.zeros(3)
+    assert np.all(stainextract.h_and_e_in_right_order(v1, v2) == np.array([v1, v2]))
+    assert np.all(stainextract.h_and_e_in_right_order(v1=v2, v2=v1) == np.array([v1, v2]))
+
+    dictionary = np.zeros([20, 15])
+    assert np.all(stainextract.dl_output_for_h_and_e(dictionary=dictionary) == dictionary)
+    dictionary[1, :] = 1
+    ordered = stainextract.dl_output_for_h_and_e(dictionary=dictionary)
+    assert ordered.shape == (2, 15) and np.all(ordered == dictionary[[1, 0], :])
