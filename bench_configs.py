@@ -119,11 +119,16 @@ def _median_time(fn, reps: int = 3) -> float:
 
 
 def _flops_of(model, x) -> float:
+    """FLOPs of one forward of the plain torch module on an input of x's shape, counted on the ``meta`` device: shapes only, no
+    kernel runs (a real forward of the plain module would go through MIOpen and put its kernels into the traces of this bench)."""
+    import copy
+
     import torch
     from torch.utils.flop_counter import FlopCounterMode
 
+    shadow = copy.deepcopy(model).to("meta").eval()
     with torch.inference_mode(), FlopCounterMode(display=False) as fc:
-        model(x)
+        shadow(torch.empty(tuple(x.shape), dtype=torch.float32, device="meta"))
     return float(fc.get_total_flops())
 
 
