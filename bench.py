@@ -178,7 +178,13 @@ def pmc_traffic(kernel_substr: str, stem: str) -> dict | None:
         vals[counter] = tot / cnt * 1024.0
         vals["file_" + counter] = files[-1].name
     return {"bytes": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
-            "source": f"profiles/{vals['file_FETCH_SIZE']} (x2, gfx950) + profiles/{vals['file_WRITE_SIZE']}"}
+            "source": f"profiles/{vals['file_FETCH_SIZE']} (x2, gfx950) + profiles/{vals['file_WRITE_SIZE']}" + _pass_commit(vals["file_FETCH_SIZE"])}
+
+
+def _pass_commit(profile_name: str) -> str:
+    """The commit whose code a committed counter pass measured (``profiles/<tag>_COMMIT.txt``, written when the pass is copied in)."""
+    note = ROOT / "profiles" / (profile_name.split("_")[0] + "_COMMIT.txt")
+    return f"; code at commit {note.read_text().strip()}" if note.exists() else ""
 
 
 def pmc_traffic_per_call(stem: str, kernel_substrs: tuple[str, ...], per_call_kernel: str) -> dict | None:
@@ -206,7 +212,7 @@ def pmc_traffic_per_call(stem: str, kernel_substrs: tuple[str, ...], per_call_ke
         vals[counter] = tot / calls * 1024.0
         vals["file_" + counter] = files[-1].name
     return {"bytes": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
-            "source": f"profiles/{vals['file_FETCH_SIZE']} (x2, gfx950) + profiles/{vals['file_WRITE_SIZE']}; per call = totals over "
+            "source": f"profiles/{vals['file_FETCH_SIZE']} (x2, gfx950) + profiles/{vals['file_WRITE_SIZE']}{_pass_commit(vals['file_FETCH_SIZE'])}; per call = totals over "
                       f"{list(kernel_substrs)} / dispatches of {per_call_kernel}"}
 
 
