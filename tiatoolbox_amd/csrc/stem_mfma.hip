@@ -70,6 +70,26 @@ __device__ __forceinline__ unsigned short to_half_bits(float x) {  // round to n
     }
 }
 
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains vmcnt, i.e. it makes
+// every wave wait for the acknowledgements of the pooled-row stores it has just issued; the loop's barriers only protect the LDS
+// regions (input rows <-> V tile), and a wave's own global loads are consumed through registers (the compiler's vmcnt waits).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Phase timing (developer builds only: -DTIA_STEM_TIMING=1, build.build(defines=...)): thread 0 of two workgroups prints the mean
+// shader-clock cycles per loop iteration of: request + MFMA loop, barrier, V tile, horizontal maximum + stores, conversion.
+#ifndef TIA_STEM_TIMING
+#define TIA_STEM_TIMING 0
+#endif
+#if TIA_STEM_TIMING
+#define SSTAMP(i) { const long long now_ = clock64(); if (threadIdx.x == 0) tm_[i] += now_ - tl_; tl_ = now_; }
+#else
+#define SSTAMP(i)
+#endif
+
 struct StemDims {
     int n, h, w, ho, wo, hp, wp;
     int chunks, rows_per_chunk;  // row chunks per image, pooled rows per chunk
@@ -147,18 +167,33 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
             }
         }
     };
+    // uint8 units: which of a unit's four bytes are image bytes of ITS row (the others belong to the neighbouring rows of the flat
+    // NHWC buffer, or to the padding columns) and the funnel-shift amount do not change from one pooled row to the next (the row
+    // base moves by 4 * w * 3 bytes): one byte mask and one shift per unit, computed once.  A masked byte reads table entry 0 = 0.0,
+    // and rows outside the image were loaded as zeros -- the conversion needs no per-element predicate.
+    unsigned cmask[U8 ? NU : 1], shv = 0;
+    if constexpr (U8) {
+#pragma unroll
+        for (int q = 0; q < NU; ++q) {
+            const int u = tid + NTH * q;
+            const int wr = u / UPR, g = u - wr * UPR;
+            const int bi = 4 * g - f0;
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m |= (bi + e >= 0 && bi + e < nb) ? 0xffu << (8 * e) : 0u;
+            cmask[q] = m;
+            const unsigned gb = (unsigned)(((img * d.h + (wr - 3)) * d.w + ixlo_c) * 3 + d.x_shift);  // row base at py = 0 (mod 4: any py)
+            shv |= (((gb & 3u) + 4u * g - (unsigned)f0) & 3u) << (2 * q);
+        }
+    }
     auto write_ring = [&](int py) {
         if constexpr (U8) {
+            (void)py;
             float f[NU][4];
             unsigned short hq[NU][4];
 #pragma unroll
             for (int q = 0; q < NU; ++q) {  // all table look-ups first (independent), then the stores
-                const int u = tid + NTH * q;
-                const int wr = u / UPR, g = u - wr * UPR;
-                const int iy = 4 * py - 3 + wr;
-                const unsigned gb = (unsigned)(((img * d.h + iy) * d.w + ixlo_c) * 3 + d.x_shift);
-                const unsigned sh = ((gb & 3u) + 4u * g - (unsigned)f0) & 3u;
-                const unsigned wbytes = __builtin_amdgcn_alignbyte(ld2[q], ld[q], sh);
+                const unsigned wbytes = __builtin_amdgcn_alignbyte(ld2[q], ld[q], (shv >> (2 * q)) & 3u) & cmask[q];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if constexpr (HALF) hq[q][e] = lut16[(wbytes >> (8 * e)) & 255u];
@@ -168,23 +203,12 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
 #pragma unroll
             for (int q = 0; q < NU; ++q) {
                 const int u = tid + NTH * q;
-                const int wr = u / UPR, g = u - wr * UPR;
-                const int iy = 4 * py - 3 + wr;
-                const bool ok = iy >= 0 && iy < d.h;
-                const int bi = 4 * g - f0;
                 if constexpr (HALF) {
-                    unsigned short o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (ok && bi + e >= 0 && bi + e < nb) ? hq[q][e] : (unsigned short)0;
                     if (u < WROWS * UPR)  // ring half 4 u = row wr, half 4 g
-                        reinterpret_cast<uint2*>(ring16)[u] = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+                        reinterpret_cast<uint2*>(ring16)[u] = make_uint2((unsigned)hq[q][0] | ((unsigned)hq[q][1] << 16),
+                                                                         (unsigned)hq[q][2] | ((unsigned)hq[q][3] << 16));
                 } else {
-                    float4 o;
-                    o.x = (ok && bi + 0 >= 0 && bi + 0 < nb) ? f[q][0] : 0.0f;
-                    o.y = (ok && bi + 1 >= 0 && bi + 1 < nb) ? f[q][1] : 0.0f;
-                    o.z = (ok && bi + 2 >= 0 && bi + 2 < nb) ? f[q][2] : 0.0f;
-                    o.w = (ok && bi + 3 >= 0 && bi + 3 < nb) ? f[q][3] : 0.0f;
-                    if (u < WROWS * UPR) reinterpret_cast<float4*>(ring)[u] = o;  // ring float 4 u = row wr, float 4 g
+                    if (u < WROWS * UPR) reinterpret_cast<float4*>(ring)[u] = float4{f[q][0], f[q][1], f[q][2], f[q][3]};  // row wr, float 4 g
                 }
             }
         } else {
@@ -216,7 +240,11 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
     write_ring(it0);
     __syncthreads();
 
+#if TIA_STEM_TIMING
+    long long tm_[6] = {0, 0, 0, 0, 0, 0}, tl_ = clock64();
+#endif
     for (int py = it0; py < q1; ++py) {
+        SSTAMP(5)
         issue_loads(py + 1 < q1 ? py + 1 : py);  // next window's bytes fly behind the MFMAs (the last one re-reads its own)
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[2][2];
@@ -270,10 +298,28 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         }
-        __syncthreads();  // every wave is done with the input rows: the region becomes the V tile
+        SSTAMP(0)
+        lds_barrier();  // every wave is done with the input rows: the region becomes the V tile
+        SSTAMP(1)
 
         // ---- bias + ReLU, vertical maximum in registers (C/D layout: channel = lane & 31, pixel = (e&3) + 8 (e>>2) + 4 h) ----
         const bool row0 = 2 * py < d.ho, row1 = 2 * py + 1 < d.ho;
+        // both conv rows on the map, all 32 columns of the wave on the map, no pre-pool output wanted (wave-uniform, the common
+        // case): 5 vector instructions per value instead of ~10 -- this phase competes for VALU issue with the MFMA stream of the
+        // CU's other workgroup and ran 2.2 x slower beside it than alone (timing build)
+        if (row0 && row1 && ncols - 32 * wave >= 32 && yconv == nullptr) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bv = j == 0 ? bv0 : bv1;
+                float* vdst = ring + (32 * wave + 4 * hh) * COUT + j * 32 + (lane & 31);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float r0 = fmaxf(acc[0][j][e] + bv, 0.0f), r1 = fmaxf(acc[1][j][e] + bv, 0.0f);
+                    vdst[((e & 3) + 8 * (e >> 2)) * COUT] = fmaxf(carry[j][e], fmaxf(r0, r1));
+                    carry[j][e] = r1;
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float bv = j == 0 ? bv0 : bv1;
@@ -294,7 +340,9 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
                 }
             }
         }
-        __syncthreads();
+        }
+        lds_barrier();
+        SSTAMP(2)
 
         // ---- horizontal maximum of three columns, one pooled row (<= 64 x 64 floats) written as float4 ----
         if (py >= q0) {
@@ -335,10 +383,17 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        SSTAMP(3)
         if (py + 1 < q1) write_ring(py + 1);
-        __syncthreads();
+        lds_barrier();
+        SSTAMP(4)
     }
+#if TIA_STEM_TIMING
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 700))
+        printf("stem wg %d: iters %d  loads+mfma %lld  barrier %lld  vtile %lld  hmax+store %lld  write_ring %lld  loop %lld\n", (int)blockIdx.x, q1 - it0,
+               tm_[0] / (q1 - it0), tm_[1] / (q1 - it0), tm_[2] / (q1 - it0), tm_[3] / (q1 - it0), tm_[4] / (q1 - it0), tm_[5] / (q1 - it0));
+#endif
 }
 
 }  // namespace
