@@ -346,27 +346,35 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
 
     // ---- epilogue: per column half (= the waves with wn == half): accumulators -> float32 LDS tile [BLOCK_PX][BN/2], then every
     //      thread takes rows x 8-column chunks: + bias + residual, ReLU, (round once), 16-byte stores.
-    //      Row m of the block = image m / (TH TW), pixel (ty0 + (m % (TH TW)) / TW, tx0 + m % TW). ----
-    constexpr int HB = BN / 2, CHUNKS = BLOCK_PX * HB / 8;
+    //      Row m of the block = image m / (TH TW), pixel (ty0 + (m % (TH TW)) / TW, tx0 + m % TW).
+    //      Order within a half (timing build: the epilogue was 27 % of a 64-channel block's life, almost all of it memory latency):
+    //      the residual and bias of ALL the thread's chunks are requested first, then the accumulators go to the tile, and only
+    //      then the sums are formed -- one exposed round trip per half instead of one per chunk; the barriers around the tile wait for
+    //      LDS only (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() would also wait for the acknowledgement of every store). ----
+    constexpr int HB = BN / 2, CHUNKS = BLOCK_PX * HB / 8, ITER = CHUNKS / NT;
+    static_assert(CHUNKS % NT == 0 && NT % (HB / 8) == 0, "whole chunk rounds; a thread keeps its column chunk");
     float* tile = reinterpret_cast<float*>(smem);
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const int cc = tid % (HB / 8);  // (idx = tid + NT * it: the same column chunk in every round)
+    // software pipeline over the thread's chunks: PF requests in flight (all of them for the 64-channel tiles; two for the
+    // 128-channel tiles, whose second-half accumulators are still in registers)
+    constexpr int PF = (BN == 128 && ITER > 2) ? ((F32 && BAND) ? 1 : 2) : ITER;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (WN == 1 || wn == half) {
-            // WN == 2: the waves of this column half hold it in all their tiles; WN == 1: every wave holds it in tiles half * NH ..
-            constexpr int NH = WN == 2 ? NTILE : NTILE / 2;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int jj = 0; jj < NH; ++jj)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        tile[row * HB + jj * 32 + (lane & 31)] = acc[i][WN == 2 ? jj : half * NH + jj][e];
-                    }
+        const int col0 = n0 + half * HB + cc * 8;
+        int mpix[ITER];  // output pixel of the chunk's row (< 2^31: the callers split the batch), -1: row not on the map
+        u32x4 rq[ITER][F32 ? 2 : 1];
+        float4 b0 = float4{0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0;
+        if (bias) {
+            b0 = *reinterpret_cast<const float4*>(bias + col0);
+            b1 = *reinterpret_cast<const float4*>(bias + col0 + 4);
         }
-        __syncthreads();
-        for (int idx = tid; idx < CHUNKS; idx += NT) {
-            const int row = idx / (HB / 8), cc = idx - row * (HB / 8);
+        auto request = [&](int it) {
+            const int row = (tid + NT * it) / (HB / 8);
             int g, oy, ox;
             bool live;
             if constexpr (BAND) {
@@ -382,24 +390,53 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
                 ox = tx0 + rg % GEO::TW;
                 live = oy < d.ho && ox < d.wo && img + g < d.n;
             }
-            if (live) {
-                const long m = ((long)(img + g) * d.ho + oy) * d.wo + ox;
-                const int col0 = n0 + half * HB + cc * 8;
-                const float4 v0 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8);
-                const float4 v1 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8 + 4);
-                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                if (bias) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(bias + col0), b1 = *reinterpret_cast<const float4*>(bias + col0 + 4);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                }
+            mpix[it] = live ? ((img + g) * d.ho + oy) * d.wo + ox : -1;
+#pragma unroll
+            for (int q = 0; q < (F32 ? 2 : 1); ++q) rq[it][q] = u32x4{0u, 0u, 0u, 0u};
+            if (res && live) {
+                const long off = (long)mpix[it] * d.cout + col0;
                 if constexpr (F32) {
-                    float* yo = static_cast<float*>(y) + m * d.cout + col0;
+                    const u32x4* rp = reinterpret_cast<const u32x4*>(static_cast<const float*>(res) + off);
+                    rq[it][0] = rp[0];
+                    rq[it][1] = rp[1];
+                } else {
+                    rq[it][0] = *reinterpret_cast<const u32x4*>(static_cast<const unsigned short*>(res) + off);
+                }
+            }
+        };
+#pragma unroll
+        for (int it = 0; it < PF; ++it) request(it);
+        if (WN == 1 || wn == half) {
+            // WN == 2: the waves of this column half hold it in all their tiles; WN == 1: every wave holds it in tiles half * NH ..
+            constexpr int NH = WN == 2 ? NTILE : NTILE / 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < NH; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        tile[row * HB + jj * 32 + (lane & 31)] = acc[i][WN == 2 ? jj : half * NH + jj][e];
+                    }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            if (it + PF < ITER) request(it + PF);
+            const int row = (tid + NT * it) / (HB / 8);
+            const float4 v0 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(tile + row * HB + cc * 8 + 4);
+            float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+            if (mpix[it] >= 0) {
+                const long off = (long)mpix[it] * d.cout + col0;
+                if constexpr (F32) {
+                    float* yo = static_cast<float*>(y) + off;
                     if (res) {
-                        const float* rp = static_cast<const float*>(res) + m * d.cout + col0;
-                        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-                        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            v[k] += __uint_as_float(rq[it][0][k]);
+                            v[4 + k] += __uint_as_float(rq[it][1][k]);
+                        }
                     }
                     if (relu) {
 #pragma unroll
@@ -408,15 +445,12 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
                     *reinterpret_cast<float4*>(yo) = float4{v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<float4*>(yo + 4) = float4{v[4], v[5], v[6], v[7]};
                 } else {
-                    const unsigned short* resh = static_cast<const unsigned short*>(res);
                     unsigned short* yh = static_cast<unsigned short*>(y);
                     if (res) {
-                        const u32x4 rv = *reinterpret_cast<const u32x4*>(resh + m * d.cout + col0);
-                        const unsigned rw4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            v[2 * k] += half_to_f32<KIND>((unsigned short)(rw4[k] & 0xffffu));
-                            v[2 * k + 1] += half_to_f32<KIND>((unsigned short)(rw4[k] >> 16));
+                            v[2 * k] += half_to_f32<KIND>((unsigned short)(rq[it][0][k] & 0xffffu));
+                            v[2 * k + 1] += half_to_f32<KIND>((unsigned short)(rq[it][0][k] >> 16));
                         }
                     }
                     unsigned o[4];
@@ -429,11 +463,11 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
                         }
                         o[k] = (unsigned)f32_to_half<KIND>(a0) | ((unsigned)f32_to_half<KIND>(a1) << 16);
                     }
-                    *reinterpret_cast<u32x4*>(yh + m * d.cout + col0) = u32x4{o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<u32x4*>(yh + off) = u32x4{o[0], o[1], o[2], o[3]};
                 }
             }
         }
-        __syncthreads();
+        if (half == 0) lds_barrier();  // the tile is re-used by the second half
     }
 }
 
