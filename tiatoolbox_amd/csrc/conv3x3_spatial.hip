@@ -137,6 +137,18 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
     asm volatile("" ::: "memory");
 }
 
+// Phase timing (developer builds only: -DTIA_SP_TIMING=1, build.build(defines=...)): thread 0 of two workgroups prints the
+// shader-clock cycles of set-up, first-data wait, tap loop and epilogue, and the shader clock itself (against the constant 100 MHz
+// clock) -- the sustained frequency under this kernel's load, which is what the MFMA peak scales with.
+#ifndef TIA_SP_TIMING
+#define TIA_SP_TIMING 0
+#endif
+#if TIA_SP_TIMING
+#define PSTAMP(i) { const long long now_ = clock64(); tm_[i] = now_ - tl_; tl_ = now_; }
+#else
+#define PSTAMP(i)
+#endif
+
 template <int BN, int KIND, typename GEO>
 __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spatial_kernel(const void* __restrict__ x, const void* __restrict__ wk,
                                                                 const float* __restrict__ bias, const void* __restrict__ res,
@@ -164,6 +176,10 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
+#if TIA_SP_TIMING
+    long long tm_[4] = {0, 0, 0, 0}, tl_ = clock64();
+    const long long t0c_ = tl_, t0w_ = wall_clock64();
+#endif
     const int bid = blockIdx.x;
     const int per_xcd = (m_tiles + 7) / 8;
     const int mt_id = (bid % 8) * per_xcd + bid / 8;
@@ -314,8 +330,10 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
     dma_b(0, 0);
     dma_b(1, 1);
+    PSTAMP(0)
     wait_vm_lgkm0<NB>();  // everything but weight slice 1
     __builtin_amdgcn_s_barrier();
+    PSTAMP(1)
     for (int cs = 0; cs < n_cs; ++cs) {
         const int buf = cs & 1, s0 = cs * 9;
         const int cs_next = cs + 1 < n_cs ? cs + 1 : cs;  // past the end: the idle buffer is refilled with the same slice
@@ -341,6 +359,7 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
         TIA_TAP(8)
 #undef TIA_TAP
     }
+    PSTAMP(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -469,6 +488,13 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
         }
         if (half == 0) lds_barrier();  // the tile is re-used by the second half
     }
+#if TIA_SP_TIMING
+    PSTAMP(3)
+    if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 64 || blockIdx.x == 3001))
+        printf("spatial wg %d (BN %d, NT %d, cin %d): setup %lld  first-data wait %lld  tap loop %lld  epilogue %lld  | shader clock %.0f MHz\n",
+               (int)blockIdx.x, BN, NT, d.cin, tm_[0], tm_[1], tm_[2], tm_[3],
+               100.0 * (double)(clock64() - t0c_) / (double)(wall_clock64() - t0w_));
+#endif
 }
 
 

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
 
 #if TIA_STEM_TIMING
     long long tm_[6] = {0, 0, 0, 0, 0, 0}, tl_ = clock64();
+    const long long t0c_ = tl_, t0w_ = wall_clock64();  // shader clock vs the constant 100 MHz clock: the sustained frequency
 #endif
     for (int py = it0; py < q1; ++py) {
         SSTAMP(5)
@@ -391,8 +392,9 @@ __global__ __launch_bounds__(NTH, 2) void stem7x7_pool_kernel(const void* __rest
     }
 #if TIA_STEM_TIMING
     if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 700))
-        printf("stem wg %d: iters %d  loads+mfma %lld  barrier %lld  vtile %lld  hmax+store %lld  write_ring %lld  loop %lld\n", (int)blockIdx.x, q1 - it0,
-               tm_[0] / (q1 - it0), tm_[1] / (q1 - it0), tm_[2] / (q1 - it0), tm_[3] / (q1 - it0), tm_[4] / (q1 - it0), tm_[5] / (q1 - it0));
+        printf("stem wg %d: iters %d  loads+mfma %lld  barrier %lld  vtile %lld  hmax+store %lld  write_ring %lld  loop %lld  | shader clock %.0f MHz\n",
+               (int)blockIdx.x, q1 - it0, tm_[0] / (q1 - it0), tm_[1] / (q1 - it0), tm_[2] / (q1 - it0), tm_[3] / (q1 - it0),
+               tm_[4] / (q1 - it0), tm_[5] / (q1 - it0), 100.0 * (double)(clock64() - t0c_) / (double)(wall_clock64() - t0w_));
 #endif
 }
 
