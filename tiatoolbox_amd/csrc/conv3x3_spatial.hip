@@ -334,9 +334,9 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     wait_vm_lgkm0<NB>();  // everything but weight slice 1
     __builtin_amdgcn_s_barrier();
     PSTAMP(1)
-    for (int cs = 0; cs < n_cs; ++cs) {
+    for (int cs = 0; cs + 1 < n_cs; ++cs) {
         const int buf = cs & 1, s0 = cs * 9;
-        const int cs_next = cs + 1 < n_cs ? cs + 1 : cs;  // past the end: the idle buffer is refilled with the same slice
+        const int cs_next = cs + 1;
         // Per tap T: the weight slice two steps ahead goes out first (NB instructions), then (T < NA) one piece of the next patch.
         // The wait at the end lets exactly the instructions YOUNGER than weight slice s + 1 stay in flight: piece T - 1 of the patch
         // (issued right after slice s + 1), slice s + 2, piece T.  (G16: 2 3 3 3 2 1 1 1 1; G8: 3 4 4 4 4 3 2 2 2.)  A patch piece is
@@ -358,6 +358,27 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
         TIA_TAP(7)
         TIA_TAP(8)
 #undef TIA_TAP
+    }
+    {
+        // the last channel slice: no patch follows (round 3 refilled the idle buffer with the same slice to keep one loop body:
+        // 1 / n_cs more patch traffic -- a quarter for the 64-channel layers -- for nothing but power); only the weight ring runs on
+        // (its last two requests re-fetch the last slice), so exactly slice s + 2 may stay in flight
+        const int buf = (n_cs - 1) & 1, s0 = (n_cs - 1) * 9;
+#define TIA_TAP_LAST(T)                                                                     \
+        dma_b((T + 2) % 3, s0 + T + 2);                                                     \
+        compute(buf, T % 3, T);                                                             \
+        wait_vm_lgkm0<NB>();                                                                \
+        __builtin_amdgcn_s_barrier();
+        TIA_TAP_LAST(0)
+        TIA_TAP_LAST(1)
+        TIA_TAP_LAST(2)
+        TIA_TAP_LAST(3)
+        TIA_TAP_LAST(4)
+        TIA_TAP_LAST(5)
+        TIA_TAP_LAST(6)
+        TIA_TAP_LAST(7)
+        TIA_TAP_LAST(8)
+#undef TIA_TAP_LAST
     }
     PSTAMP(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
