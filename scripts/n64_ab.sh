@@ -1,3 +1,4 @@
+# Round-4 GPU call: 64-channel tiles of the tap-reuse kernel, four waves along the pixels vs the 4 x 2 form (profiles/r04za_n64_*.txt).
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_engine.py tests/test_hovernet_post.py -m gpu -q -x 2>&1 | tail -4
 SH="1024,64,64,64 1024,64,64,56 32,64,64,256 8,64,64,512 32,256,64,164 1024,128,128,32"
