@@ -22,7 +22,9 @@ implicit GEMM -- the reference's arithmetic, ``vanilla.py:242``), softmax, argma
 (the engine's torch-tensor overload); the same call on HOST NumPy patches (H2D over PCIe included) is timed right after
 and reported as ``host_inclusive``.  Extras on rank 0 at N=1: the fp16 backbone with its measured max |dp| against the
 fp32 probabilities of the same batch (tolerance 1e-3, ``tests/engines/test_patch_predictor.py:719`` of the reference),
-and the 224x224 patch size of BASELINE configs[1].  With N > 1 the line also carries every rank's own step time and the
+the 224x224 patch size of BASELINE configs[1], and -- ``extras.configs`` -- a SHORT run of each of BASELINE configs[2]-[4]
+(``bench_configs.py``: semantic / hovernet / vahadane; value, step time, the config's roofline entry, a one-line CPU baseline), so
+that the driver's default ``python bench.py`` observes all five configurations (``--no-extras`` skips them).  With N > 1 the line also carries every rank's own step time and the
 time of the all-gather alone (``per_rank``), so that a scaling run explains itself.
 """
 
@@ -58,7 +60,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--precision", default="f64", choices=["f32", "f64"],
                     help="per-pixel arithmetic of the stain apply kernel (reference: f64; statistics are always f64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip host-inclusive / fp16 / 224^2 extra measurements")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip host-inclusive / fp16 / 224^2 extra measurements and the short runs of BASELINE configs[2]-[4]")
     ap.add_argument("--cpu-sample", type=int, default=64)
     ap.add_argument("--slide", type=int, default=20000, help="--config semantic: slide edge in pixels")
     return ap.parse_args()
@@ -293,6 +296,50 @@ def trunk_roofline(model, u8_batch):
     return {"seconds": seconds, "launches": launches, "flops_per_launch": flops // launches,
             "ms_per_launch": seconds / launches * 1e3, "tflops": flops / seconds / 1e12, "kernels": kernels,
             "stem_seconds": stem_seconds, "stem_flops": stem_flops, "stem_tflops": stem_flops / stem_seconds / 1e12}
+
+
+def _condense(full: dict) -> dict:
+    """The part of a ``bench_configs`` line that ``extras.configs`` carries: value, step time, the roofline of the config's own
+    dominant kernel (+ the network's forward), and a one-line CPU baseline."""
+    roof = full.get("roofline", {})
+    out = {"metric": full["metric"], "value": full["value"], "unit": full["unit"], "ms_per_step": full["ms_per_step"],
+           "steps": full["steps"], "warmup": full["warmup"], "dtype": full["dtype"], "scaling": full["scaling"],
+           "workload": full["config"]["workload"],
+           "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms",
+                                                 "algorithmic_bytes") if k in roof}}
+    if "backbone" in roof:
+        out["roofline"]["backbone"] = {k: roof["backbone"].get(k) for k in ("achieved", "peak", "unit", "frac")}
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cpu}
+    return out
+
+
+def config_extras(args: argparse.Namespace) -> dict:
+    """BASELINE configs[2]-[4] inside the default run, so the driver's bench record observes them too: a SHORT run of each
+    ``bench_configs`` function (same code as ``bench.py --config ...``; fewer steps), condensed.  A config that fails is
+    reported as ``{"error": ...}`` and does not take the headline down with it."""
+    import copy
+    import gc
+
+    import torch
+
+    import bench_configs
+
+    plan = {"vahadane": (3, 1), "hovernet": (2, 1), "semantic": (1, 1)}  # (timed steps, warm-up steps)
+    out = {}
+    for name, (steps, warmup) in plan.items():
+        a = copy.copy(args)
+        a.config, a.steps, a.warmup, a.patches = name, steps, warmup, 4096  # 4096 = "the config's own default size"
+        t0 = time.perf_counter()
+        try:
+            out[name] = _condense(getattr(bench_configs, f"bench_{name}")(a))
+        except Exception as exc:  # noqa: BLE001
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        out[name]["bench_wall_s"] = round(time.perf_counter() - t0, 1)
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 def self_spawn(args: argparse.Namespace) -> None:
@@ -580,6 +627,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                                    "ms_per_step": round(el224 / k_extra * 1e3, 3), "dtype": args.dtype,
                                    "workload": f"BASELINE configs[1]: {n} synthetic 224x224x3 patches, same call"}
             del x224
+        extras["configs"] = config_extras(args)
         line["extras"] = extras
     if not args.no_cpu_baseline and world_size == 1:
         cpu_model, _ = get_pretrained_model("resnet18-kather100k")

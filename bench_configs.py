@@ -75,12 +75,18 @@ def _vahadane_cpu_worker(job):
 
 
 def _timed(step, args, world_size: int, device) -> float:
+    """W untimed + K timed steps between barrier + synchronize; returns the MAX over ranks of the timed region.  Each rank's
+    own time (before it waits for the others at the closing barrier) is kept in ``_timed.own`` for ``_per_rank``."""
     import torch
+
+    def sync() -> None:
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize()
 
     def barrier() -> None:
         if world_size > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for _ in range(args.warmup):
         step()
@@ -88,11 +94,48 @@ def _timed(step, args, world_size: int, device) -> float:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    sync()
+    _timed.own = (time.perf_counter() - t0) / max(args.steps, 1) * 1e3
     barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     if world_size > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     return float(t.item())
+
+
+_timed.own = 0.0
+
+
+def _per_rank(world_size: int, device, collective=None, *, what: str, nbytes: int = 0, reps: int = 10) -> dict | None:
+    """The block a scaling run needs to explain itself (same shape as the headline's ``per_rank``): every rank's own step
+    time, and the config's collective alone -- ``collective()`` timed over ``reps`` back-to-back calls between barriers
+    (``None``: the config has no collective on its data path).  COLLECTIVE on every rank; returns ``None`` at N = 1."""
+    import torch
+
+    if world_size <= 1:
+        return None
+    rank = torch.distributed.get_rank()
+    owns = torch.zeros(world_size, dtype=torch.float64, device=device)
+    owns[rank] = _timed.own
+    torch.distributed.all_reduce(owns)
+    out = {"own_ms_per_step": [round(float(v), 3) for v in owns.cpu().tolist()]}
+    if collective is not None:
+        collective()
+        cuda = torch.device(device).type == "cuda"
+        torch.distributed.barrier()
+        if cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            collective()
+        if cuda:
+            torch.cuda.synchronize()
+        torch.distributed.barrier()
+        out["collective_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+        out["collective_bytes_per_rank"] = int(nbytes)
+    out["what"] = ("own = rank-local wall time per step before the closing barrier (the step already contains its collectives, "
+                   "which synchronise the ranks); collective = " + what)
+    return out
 
 
 def _ev(fn, reps: int = 5) -> float:
@@ -130,6 +173,47 @@ def _flops_of(model, x) -> float:
     with torch.inference_mode(), FlopCounterMode(display=False) as fc:
         shadow(torch.empty(tuple(x.shape), dtype=torch.float32, device="meta"))
     return float(fc.get_total_flops())
+
+
+def semantic_per_rank(out_b, oh: int, side: int, rank: int, world_size: int, device) -> dict | None:
+    """``per_rank`` of the semantic config: its one collective alone -- the all-gather of the rank-local uint8 prediction bands
+    of a ``side``-wide slide whose patch outputs are at ``out_b``.  Works on CPU tensors under gloo (tests/test_distributed.py)."""
+    import numpy as np
+    import torch
+
+    if world_size <= 1:
+        return None
+    from tiatoolbox_amd.models.engine.semantic_segmentor import band_plan, exchange_bands
+
+    plan = band_plan(np.unique(np.asarray(out_b)[:, 1]), oh, side, rank, world_size)
+    band = torch.zeros((max(plan["y_hi"] - plan["y_lo"], 0), side), dtype=torch.uint8, device=device)
+    tallest = max(max(b[1] - b[0] for b in plan["bands"]), 1)
+    return _per_rank(world_size, device, lambda: exchange_bands(band, plan, side), nbytes=tallest * side,
+                     what="exchange_bands: one padded all_gather_into_tensor of the rank-local uint8 prediction bands")
+
+
+def hovernet_per_rank(out: dict, rank: int, world_size: int, device) -> dict | None:
+    """``per_rank`` of the instance config: its collectives alone, on this rank's shard of the finished result ``out`` -- the padded
+    all-gather of the int32 label maps and the ragged gathers of the instance tables.  CPU tensors under gloo work too."""
+    import numpy as np
+    import torch
+
+    if world_size <= 1:
+        return None
+    from tiatoolbox_amd import distributed as tdist
+
+    n_total = int(out["predictions"].shape[0])
+    lo, hi = tdist.shard_bounds(n_total, rank, world_size)
+    maps = torch.from_numpy(np.ascontiguousarray(np.asarray(out["predictions"][lo:hi]).astype(np.int32))).to(device)
+    tables = [{k: out[k][i] for k in ("box", "centroid", "contours", "prob", "type")} for i in range(lo, hi)]
+
+    def gathers():
+        tdist.all_gather_rows(maps, n_total)
+        tdist.gather_instance_tables(tables, device)
+
+    return _per_rank(world_size, device, gathers, nbytes=maps.numel() * 4, reps=3,
+                     what=("all_gather_rows of the int32 label maps + gather_instance_tables (counts, boxes, centroids, types, "
+                           "probabilities, polygon lengths, packed vertices: ragged all-gathers); bytes = label maps only"))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -176,6 +260,7 @@ def bench_semantic(args) -> dict | None:
             pred = saved["predictions"]
         assert pred.shape == (side, side) and pred.dtype == np.uint8
     shutil.rmtree(scratch, ignore_errors=True)
+    per_rank = semantic_per_rank(out_b, int(cfg.patch_output_shape[0]), side, rank, world_size, device)
     if rank != 0:
         return None
     total = n_patches * args.steps
@@ -229,6 +314,8 @@ def bench_semantic(args) -> dict | None:
                          "peak": MFMA_PEAK_F32, "unit": "TFLOP/s", "frac": round(flops / t_fwd / 1e12 / MFMA_PEAK_F32, 4),
                          "ms_per_patch": round(t_fwd * 1e3, 3)}},
     }
+    if per_rank is not None:
+        line["per_rank"] = per_rank
     if not args.no_cpu_baseline and world_size == 1:
         from oracle import semantic as osem
         from tiatoolbox_amd.models.architecture import get_pretrained_model
@@ -280,6 +367,7 @@ def bench_hovernet(args) -> dict | None:
     elapsed = _timed(step, args, world_size, device)
     out = result["out"]
     assert out["predictions"].shape == (n * world_size, 164, 164)
+    per_rank = hovernet_per_rank(out, rank, world_size, device)
     if rank != 0:
         return None
     # post-processing alone, on synthetic head outputs with ~60 nuclei per 164^2 tile (HIP events)
@@ -326,6 +414,8 @@ def bench_hovernet(args) -> dict | None:
                          "peak": MFMA_PEAK_F32, "unit": "TFLOP/s", "frac": round(flops / t_fwd / 1e12 / MFMA_PEAK_F32, 4),
                          "ms_per_tile": round(t_fwd * 1e3, 3)}},
     }
+    if per_rank is not None:
+        line["per_rank"] = per_rank
     if not args.no_cpu_baseline and world_size == 1:
         from tiatoolbox_amd.models.architecture import get_pretrained_model
 
@@ -384,6 +474,7 @@ def bench_vahadane(args) -> dict | None:
     elapsed = _timed(step, args, world_size, device)
     out = result["out"]
     assert out.shape == x.shape and out.dtype == torch.uint8
+    per_rank = _per_rank(world_size, device, None, what="none (patch-sharded, the normalised patches stay on their rank)")
     if rank != 0:
         return None
     params = norm.extractor.stats_params(target_stain=norm.stain_matrix_target, target_maxc=norm.maxC_target)
@@ -407,6 +498,8 @@ def bench_vahadane(args) -> dict | None:
                               "per-iteration scalars): arithmetic-bound, not a bandwidth kernel -- the one-kernel form that keeps the "
                               "2 x N dictionary in HBM (dl_one_kernel) takes 1.8x as long")},
     }
+    if per_rank is not None:
+        line["per_rank"] = per_rank
     # BASELINE's "fp16 OD path": the per-pixel arithmetic exists in float64 (the reference's, reported above) and float32; half
     # precision exists as an OUTPUT format of the float32 path (the CNN's input), not as OD-space arithmetic -- 11 significand
     # bits cannot hold exp(-OD) to the 1e-4 the north star asks of normalised pixels.  Reported here: the float32 per-pixel path

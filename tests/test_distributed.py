@@ -368,3 +368,56 @@ def test_multi_task_tables_gathered_across_ranks(tmp_path, world):
                         assert np.array_equal(np.asarray(ra, dtype=object), np.asarray(rb, dtype=object))
         for ha, hb in zip(got["probabilities"], single["probabilities"]):
             assert np.array_equal(ha, hb)
+
+
+# ------------------------------------------------------------------ bench_configs' N > 1 paths, dry (CPU tensors, gloo)
+def _bench_dry_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import argparse
+    import json
+    import sys
+    from pathlib import Path
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    tdist.init_from_env("gloo")
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench_configs as bc
+
+    dev = torch.device("cpu")
+    args = argparse.Namespace(steps=2, warmup=1)
+    calls = []
+    # the timing harness every config shares: W + K steps, max over ranks, each rank's own time kept for per_rank
+    elapsed = bc._timed(lambda: calls.append(1), args, world, dev)  # noqa: SLF001
+    assert len(calls) == 3 and elapsed > 0
+    blocks = {}
+    # vahadane: no collective -- own times only
+    blocks["vahadane"] = bc._per_rank(world, dev, None, what="none")  # noqa: SLF001
+    # semantic: the band all-gather of a 95-row x 40-column toy slide with 10 patch rows (uneven bands at world 2 / 3)
+    out_b = np.array([[x, y, x + 12, y + 12] for y in range(0, 100, 10) for x in (0, 10, 20, 30)])
+    blocks["semantic"] = bc.semantic_per_rank(out_b, 12, 95, rank, world, dev)
+    # hovernet: label maps + ragged instance tables of the CPU instance engine's own (already gathered) result
+    res = _run_instance_engine()
+    blocks["hovernet"] = bc.hovernet_per_rank(res, rank, world, dev)
+    for name, b in blocks.items():
+        assert len(b["own_ms_per_step"]) == world and all(v >= 0 for v in b["own_ms_per_step"]), name
+        assert ("collective_ms" in b) == (name != "vahadane")
+        json.dumps(b)  # what bench.py prints must serialise
+    if rank == 0:
+        with open(os.path.join(out_dir, "per_rank.json"), "w") as fh:
+            json.dump(blocks, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_configs_multi_rank_paths_dry(tmp_path, world):
+    """``bench.py --gpus N --config semantic|hovernet|vahadane``: the code that only runs at N > 1 -- the shared timing harness
+    (own time per rank, max over ranks) and each config's ``per_rank`` block (own step times + the config's collective timed
+    alone) -- executed under gloo on CPU tensors at toy size, so that an argument or gather bug cannot first appear on the
+    8-GPU node.  (The GPU work of the configs themselves cannot run here: there is no CPU fallback.)"""
+    import json
+
+    port = 30300 + (os.getpid() % 150) + 17 * world
+    mp.spawn(_bench_dry_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    blocks = json.loads((tmp_path / "per_rank.json").read_text())
+    assert set(blocks) == {"vahadane", "semantic", "hovernet"}
+    assert blocks["semantic"]["collective_bytes_per_rank"] > 0 and blocks["hovernet"]["collective_bytes_per_rank"] > 0
