@@ -160,6 +160,10 @@ def test_host_only_dispatch_queries():
     assert route(1024, 56, 64, 128, 3, 2, 1) == 2 and route(1024, 28, 128, 256, 3, 2, 1) == 0 and route(1024, 7, 512, 512, 3, 1, 1) == 0  # noqa: PLR2004
     assert route(1024, 64, 64, 128, 1, 2, 0) == 2 and route(4, 64, 64, 128, 3, 2, 1) == 0 and route(1024, 64, 64, 64, 1, 1, 0) == 0  # noqa: PLR2004
     assert route(0, 64, 64, 128, 3, 2, 1) < 0
+    # the query runs the entry point's own shape checks: what tia_conv2d_nhwc_f32 rejects (cin % 32, cout % 64) is rejected here
+    # with the same code (TIA_ESIZE = -3), and a batch beyond 2 GiB of input is answered for one full group
+    assert route(8, 16, 48, 64, 3, 1, 1) == -3 and route(8, 16, 16, 64, 3, 1, 1) == -3 and route(8, 16, 64, 96, 3, 1, 1) == -3  # noqa: PLR2004
+    assert route(100000, 64, 64, 64, 3, 1, 1) == 1
     # valid convolutions (HoVer-Net's decoder) never take the band form; 16 x 16 blocks when they cover >= 7/8
     assert geometry(164, 164, 162, 162, 0)[0] == 0 and geometry(64, 64, 62, 62, 0)[0] == 1
     for h in range(9, 130):

@@ -286,6 +286,28 @@ def _save_dir_worker(rank: int, world: int, port: int, root: str) -> None:
     except OSError as exc:
         assert "no save directory" in str(exc)
     assert prepare_engines_save_dir(None, patch_mode=True, distributed=True) is None
+    # 5. the refusal keeps the attributes of the original exception: errno and filename travel, the message is not doubled
+    try:
+        prepare_engines_save_dir(root_p / "run", patch_mode=False, overwrite=False, distributed=True)
+    except FileExistsError as exc:
+        import errno as _errno
+
+        assert exc.errno == _errno.EEXIST and str(exc.filename) == str(root_p / "run"), (exc.errno, exc.filename)
+        assert str(exc).count("Errno") == 1, str(exc)
+    else:
+        raise AssertionError(f"rank {rank}: no FileExistsError")
+    # 6. the WRITE phase: rank 0 writes; a failing write (here: the target's directory does not exist) is raised by EVERY rank
+    #    instead of leaving the others in a barrier
+    from tiatoolbox_amd.models.engine.engine_abc import write_outputs
+
+    write_outputs(True, lambda: np.savez(d2 / "slide.npz", a=np.arange(3)))
+    assert (d2 / "slide.npz").exists()
+    try:
+        write_outputs(True, lambda: np.savez(root_p / "missing" / "slide.npz", a=np.arange(3)))
+    except FileNotFoundError as exc:
+        assert "missing" in str(exc.filename)
+    else:
+        raise AssertionError(f"rank {rank}: the failed write was not raised")
     (root_p / f"ok{rank}").write_text("1")
     dist.barrier()
     dist.destroy_process_group()
@@ -421,3 +443,74 @@ def test_bench_configs_multi_rank_paths_dry(tmp_path, world):
     blocks = json.loads((tmp_path / "per_rank.json").read_text())
     assert set(blocks) == {"vahadane", "semantic", "hovernet"}
     assert blocks["semantic"]["collective_bytes_per_rank"] > 0 and blocks["hovernet"]["collective_bytes_per_rank"] > 0
+
+
+# ------------------------------------------------------------------ tile mode with several tasks per tile across ranks
+class _OracleTwoTaskTiles:
+    """Tile post-processing of a two-task model on the CPU: the oracle's nuclei pass plus a semantic 'layer' task with a uint8
+    label map and its own columns -- drives ``_gather_tile_results``'s several-tasks branch (label maps as a flat int32 gather)."""
+
+    tasks = ("nuclei_segmentation", "layer_segmentation")
+
+    def postproc(self, maps, offset=(0, 0)):  # noqa: ARG002
+        from oracle import hovernet as oh
+        from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
+
+        npm, hv, tp = (np.asarray(m) for m in maps)
+        inst = oh.proc_np_hv(npm, hv)
+        info = oh.get_instance_info(inst, np.around(tp).astype("uint8")[..., 0])
+        nuclei = HoVerNet._pack(self, inst, info)  # noqa: SLF001
+        layer = ((npm[..., 0] > 0.5).astype(np.uint8) + (npm[..., 0] > 0.9).astype(np.uint8))
+        rows = {"box": [], "centroid": [], "contours": [], "prob": [], "type": []}
+        for c in (int(v) for v in np.unique(layer) if v):  # one record per layer class present in the tile
+            ys, xs = np.nonzero(layer == c)
+            rows["box"].append(np.array([xs.min(), ys.min(), xs.max() + 1, ys.max() + 1]))
+            rows["centroid"].append(np.array([xs.mean(), ys.mean()]))
+            rows["contours"].append(np.stack([xs[:4], ys[:4]], axis=1).astype(np.int32))
+            rows["prob"].append(1.0)
+            rows["type"].append(c)
+        table = {k: (np.array(v) if k in ("box", "centroid") and v else v) for k, v in rows.items()}
+        return nuclei, {"task_type": self.tasks[1], "predictions": layer, "info_dict": table, "seg_type": "semantic"}
+
+
+def _two_task_tiles(distributed: bool):
+    import test_tile_mode as ttm
+
+    gold = np.load(ttm.GOLD / "tile_golden.npz")
+    eng, heads, _, wsi_shape = ttm._engine(gold, "a", _OracleTwoTaskTiles())  # noqa: SLF001
+    eng.distributed = distributed
+    return eng._process_tile_mode([torch.from_numpy(h) for h in heads], wsi_shape, None, return_predictions=(True, True))  # noqa: SLF001
+
+
+def _two_task_tile_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    import pickle
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    tdist.init_from_env("gloo")
+    out = _two_task_tiles(True)
+    with open(os.path.join(out_dir, f"tt{rank}.pkl"), "wb") as fh:
+        pickle.dump(out, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_mode_with_two_tasks_sharded_across_ranks(tmp_path):
+    """WSI tile mode of a model with two tasks per tile on 3 ranks (gloo): the per-task tables travel as small host records, the
+    tile label maps (int32 instance map, uint8 layer map) as ONE flat int32 ragged gather; every rank must end with exactly the
+    single-process result -- the reference-checked nuclei table (tile_golden 'a') and both slide-sized maps, dtypes included."""
+    import pickle
+
+    import test_tile_mode as ttm
+
+    port = 30500 + (os.getpid() % 150)
+    mp.spawn(_two_task_tile_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    single = _two_task_tiles(False)
+    gold = np.load(ttm.GOLD / "tile_golden.npz")
+    ttm._check_table(single[0], gold, "a")  # noqa: SLF001
+    assert single[1]["predictions"].dtype == np.uint8 and single[1]["predictions"].any()
+    for rank in range(3):
+        with open(tmp_path / f"tt{rank}.pkl", "rb") as fh:
+            got = pickle.load(fh)  # noqa: S301
+        ttm._check_table(got[0], gold, "a")  # noqa: SLF001
+        for a, b in zip(got, single):
+            assert a["predictions"].dtype == b["predictions"].dtype and np.array_equal(a["predictions"], b["predictions"])

@@ -494,6 +494,10 @@ def test_rgb2od_standalone_kernel_and_side_effect(uniform_patches):
     ro = uniform_patches[0].copy()
     ro.setflags(write=False)                                                   # read-only input: values only
     assert np.array_equal(rgb2od(ro), ostain.rgb2od(uniform_patches[0].copy()))
+    with pytest.raises(TypeError, match="uint8"):                                # the byte kernel does not truncate silently
+        rgb2od(uniform_patches[0].astype(np.float32))
+    with pytest.raises(TypeError, match="uint8"):
+        rgb2od(torch.from_numpy(uniform_patches[0].copy()).cuda().float())
 
 
 @pytest.mark.gpu

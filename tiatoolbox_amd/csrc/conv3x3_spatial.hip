@@ -23,6 +23,7 @@
 //   * epilogue through LDS in two column halves: float32 tile [256][BN/2] -> + bias + residual, ReLU, (one rounding), 16-byte stores
 //   * blockIdx remapped so that each XCD walks a contiguous range of pixel blocks
 #include "conv3x3_spatial.hpp"
+#include <atomic>
 
 #include <stdlib.h>
 
@@ -705,17 +706,24 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ring_kernel(const float* __res
 
 namespace tia {
 
-bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bias, const void* residual, void* y, long nb, long h,
-                            long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo, int dtype, int relu,
-                            hipStream_t stream) {
+bool conv3x3_spatial_serves(long nb, long h, long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo, int dtype) {
     static const bool disabled = getenv("TIA_CONV_NO_SPATIAL") != nullptr;
     const int es = dtype == TIA_DT_F32 ? 4 : 2;
     if (disabled || cin % (64 / es) != 0 || cout % 64 != 0 || pad_top > 2 || pad_left > 2) return false;
     const SpPlan plan = conv3x3_spatial_plan(3, 3, 1, h, w, ho, wo, pad_top, pad_left, dtype == TIA_DT_F32);
     if (plan.kind == 0) return false;
+    if (plan.kind >= 3 && nb * (h + 1) >= (1L << 24)) return false;  // fdiv() range of the band geometry (the callers keep the input below 2 GiB)
+    return true;
+}
+
+bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bias, const void* residual, void* y, long nb, long h,
+                            long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo, int dtype, int relu,
+                            hipStream_t stream) {
+    const int es = dtype == TIA_DT_F32 ? 4 : 2;
+    if (!conv3x3_spatial_serves(nb, h, w, cin, cout, pad_top, pad_left, ho, wo, dtype)) return false;
+    const SpPlan plan = conv3x3_spatial_plan(3, 3, 1, h, w, ho, wo, pad_top, pad_left, dtype == TIA_DT_F32);
     const bool small = plan.kind == 2;  // G8: two images of (at most) 8 x 8 per block
     const bool band = plan.kind >= 3;
-    if (band && nb * (h + 1) >= (1L << 24)) return false;  // fdiv() range (never reached: the callers keep the input below 2 GiB)
     const long tiles_y = small ? 1 : (ho + 15) / 16, tiles_x = small ? 1 : (wo + 15) / 16;
     // band: the batch as one image of nb * (h + 1) - 1 rows (no zero row behind the last image), cut into bands of br rows
     const long tiles = band ? ((nb * (h + 1) - 1 + plan.br - 1) / plan.br) * plan.strips : (small ? (nb + 1) / 2 : nb * tiles_y * tiles_x);
@@ -748,6 +756,20 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
     return true;
 }
 
+// Compute units of the calling thread's CURRENT device, cached per device index (a process may drive several GPUs; the first caller
+// may be the host-only route query).  Without a usable device (build container): MI355X's 256.
+static long device_cu_count() {
+    static std::atomic<int> cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int cus = cached[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+        cached[dev].store(cus, std::memory_order_relaxed);
+    }
+    return cus;
+}
+
 bool conv_ring_ok(long nb, long cin, long cout, long kh, long kw, long ho, long wo) {
     static const bool disabled = getenv("TIA_CONV_NO_RING") != nullptr;
     static const bool no_taps = getenv("TIA_CONV_NO_GATHER_RING") != nullptr;  // developer switch (A/B measurements)
@@ -760,11 +782,7 @@ bool conv_ring_ok(long nb, long cin, long cout, long kh, long kw, long ho, long 
     if (kh != 1 || kw != 1) {
         // gathering taps, the ring beats the slice kernel only while its rounds of 2 workgroups per CU are full (measured,
         // profiles/r04y_*_probe.txt: +5..+28 % at >= 0.875 full, -3..-14 % at 0.77: 7 x 7 outputs of a 1024-patch batch)
-        static const int slots = [] {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            return 2 * (cus > 0 ? cus : 256);
-        }();
+        const long slots = 2 * device_cu_count();
         const long wgs = tiles * (cout / 128), rounds = (wgs + slots - 1) / slots;
         if (wgs * 100 < rounds * slots * 85) return false;
     }

@@ -58,6 +58,10 @@ inline bool conv3x3_spatial_ok(long kh, long kw, long stride, long h, long w, lo
     return conv3x3_spatial_plan(kh, kw, stride, h, w, ho, wo, pad_top, pad_left, f32).kind != 0;
 }
 
+// The whole dispatch condition of the tap-reuse kernel for one launch over `nb` images (plan + channel multiples + padding range +
+// the band geometry's row-count limit + the developer switch): what conv3x3_spatial_launch checks before it launches.
+bool conv3x3_spatial_serves(long nb, long h, long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo, int dtype);
+
 // One launch over `nb` images (input extent < 2 GiB: the callers split the batch).  dtype: TIA_DT_F32 | _F16 | _BF16.
 //   float32: weights packed [3][3][cin][cout] (tia_conv_pack_weights_f32), cin % 16 == 0
 //   half:    weights packed [3][3][cin/8][cout][8] (tia_conv_pack_weights_h), cin % 32 == 0

@@ -312,6 +312,45 @@ extern "C" int tia_conv_pack_weights_f32(const float* d_w_oihw, int64_t cout, in
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
+// ---- the ONE dispatch decision: conv2d_impl launches by it, tia_conv2d_route_f32 reports it ---------------------------------------
+enum ConvRoute { ROUTE_SLICE = 0, ROUTE_SPATIAL = 1, ROUTE_RING = 2 };
+
+// Shape checks shared by the entry points and the route query (pointer checks stay with the callers).
+static int conv2d_check_shape(int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                              int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0) return TIA_EINVAL;
+    if (cin % BK != 0 || cout % 64 != 0) return TIA_ESIZE;
+    // every output pixel must see at least its first tap row / column start inside [-(k-1), h): rows and columns beyond the
+    // image on either side read as zeros (that is how asymmetric "same" padding is expressed: pad_top / pad_left + ho / wo)
+    if (ho <= 0 || wo <= 0 || kh > 16 || kw > 16 || pad_top >= kh || pad_left >= kw) return TIA_EINVAL;
+    if ((ho - 1) * stride - pad_top >= h || (wo - 1) * stride - pad_left >= w) return TIA_EINVAL;
+    return TIA_OK;
+}
+
+// Images per launch: the kernels address their input with 32-bit byte offsets, so a batch goes in groups of < 2 GiB of input
+// (and < 2^30 output pixels).  0: a single image is already too large.
+static long conv2d_group(int64_t h, int64_t w, int64_t pstride, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t ho, int64_t wo) {
+    const long image_bytes = h * w * pstride * 4, w_bytes = kh * kw * cin * cout * 4;
+    if (image_bytes > 0x7fffffffL || w_bytes > 0x7fffffffL || ho * wo > 0x7fffffffL / 4) return 0;
+    long group = 0x7fffffffL / image_bytes;
+    if (group * ho * wo > 0x7fffffffL / 2) group = 0x7fffffffL / 2 / (ho * wo);
+    return group;
+}
+
+// Which kernel serves ONE launch over `nb` images.  `plain` = no second epilogue output, no activation on load, dense pixels
+// (pstride == cin): only those forms exist on the tap-reuse and ring kernels.
+static ConvRoute conv2d_route(bool plain, long nb, long h, long w, long cin, long cout, long kh, long kw, long stride, long pad_top,
+                              long pad_left, long ho, long wo) {
+    if (!plain) return ROUTE_SLICE;
+    // 3x3 / stride 1 on maps that 16 x 16 pixel blocks (or bands) cover with little waste: the tap-reuse kernel (conv3x3_spatial.hip)
+    if (tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad_top, pad_left, true) &&
+        tia::conv3x3_spatial_serves(nb, h, w, cin, cout, pad_top, pad_left, ho, wo, TIA_DT_F32))
+        return ROUTE_SPATIAL;
+    // 1x1 (any stride), and the kh x kw layers the tap-reuse kernel left: the LDS-DMA ring GEMM of conv3x3_spatial.hip
+    if (tia::conv_ring_ok(nb, cin, cout, kh, kw, ho, wo)) return ROUTE_RING;
+    return ROUTE_SLICE;
+}
+
 static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d_bias, const float* d_residual, float* d_y, int64_t n,
                        int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t stride, int64_t pad_top,
                        int64_t pad_left, int64_t ho, int64_t wo, int32_t relu, const float* d_post_scale, const float* d_post_shift,
@@ -325,21 +364,14 @@ static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d
                      ((reinterpret_cast<uintptr_t>(d_pre_scale) | reinterpret_cast<uintptr_t>(d_pre_shift)) & 15) != 0))
         return TIA_EINVAL;
     if (with_post && (!d_post_scale || !d_post_shift)) return TIA_EINVAL;
-    if (!d_x || !d_w_packed || (!d_y && !with_post) || n <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_top < 0 || pad_left < 0)
-        return TIA_EINVAL;
-    if (cin % BK != 0 || cout % 64 != 0) return TIA_ESIZE;
+    if (!d_x || !d_w_packed || (!d_y && !with_post)) return TIA_EINVAL;
+    if (const int rc = conv2d_check_shape(n, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo); rc != TIA_OK) return rc;
     if ((reinterpret_cast<uintptr_t>(d_w_packed) & 15) != 0 || (reinterpret_cast<uintptr_t>(d_x) & (pstride % 4 == 0 ? 15 : 3)) != 0)
         return TIA_EINVAL;
-    // every output pixel must see at least its first tap row / column start inside [-(k-1), h): rows and columns beyond the
-    // image on either side read as zeros (that is how asymmetric "same" padding is expressed: pad_top / pad_left + ho / wo)
-    if (ho <= 0 || wo <= 0 || kh > 16 || kw > 16 || pad_top >= kh || pad_left >= kw) return TIA_EINVAL;
-    if ((ho - 1) * stride - pad_top >= h || (wo - 1) * stride - pad_left >= w) return TIA_EINVAL;
-    // the kernel addresses its input with 32-bit byte offsets: images go in groups of < 2 GiB
     const long image_bytes = h * w * pstride * 4, w_bytes = kh * kw * cin * cout * 4;
-    if (image_bytes > 0x7fffffffL || w_bytes > 0x7fffffffL || ho * wo > 0x7fffffffL / 4) return TIA_ESIZE;
-    long group = 0x7fffffffL / image_bytes;
-    if (group * ho * wo > 0x7fffffffL / 2) group = 0x7fffffffL / 2 / (ho * wo);
+    const long group = conv2d_group(h, w, pstride, cin, cout, kh, kw, ho, wo);
     if (group < 1) return TIA_ESIZE;
+    const bool plain = !with_post && !with_pre && pstride == cin;
     hipStream_t st = (hipStream_t)stream;
     for (long first = 0; first < n; first += group) {
         const long nb = n - first < group ? n - first : group;
@@ -351,12 +383,11 @@ static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d
         const float* rg = d_residual ? d_residual + first * ho * wo * cout : nullptr;
         float* yg = d_y ? d_y + first * ho * wo * cout : nullptr;
         const ConvPost post{d_post_scale, d_post_shift, with_post ? d_y2 + first * ho * wo * cout : nullptr, d_pre_scale, d_pre_shift};
-        // 3x3 / stride 1 on maps that 16 x 16 pixel blocks cover with little waste: the tap-reuse kernel (conv3x3_spatial.hip)
-        if (!with_post && !with_pre && pstride == cin && tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad_top, pad_left, true) &&
+        const ConvRoute route = conv2d_route(plain, nb, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo);
+        if (route == ROUTE_SPATIAL &&
             tia::conv3x3_spatial_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, pad_top, pad_left, ho, wo, TIA_DT_F32, relu, st))
             continue;
-        // 1x1 (any stride), and the kh x kw layers the tap-reuse kernel left: the LDS-DMA ring GEMM of conv3x3_spatial.hip
-        if (!with_post && !with_pre && pstride == cin &&
+        if (route == ROUTE_RING &&
             tia::conv_ring_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo, relu, st))
             continue;
         const long grid_x = ((m_tiles + 7) / 8) * 8;  // whole rounds over the 8 XCDs (surplus workgroups exit at once)
@@ -414,12 +445,15 @@ extern "C" int tia_conv3x3_geometry(int64_t h, int64_t w, int64_t ho, int64_t wo
 
 extern "C" int tia_conv2d_route_f32(int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
                                     int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo) {
-    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || ho <= 0 || wo <= 0) return TIA_EINVAL;
-    if (cin % 16 == 0 && cout % 64 == 0 && pad_top <= 2 && pad_left <= 2 && getenv("TIA_CONV_NO_SPATIAL") == nullptr &&
-        tia::conv3x3_spatial_ok(kh, kw, stride, h, w, ho, wo, pad_top, pad_left, true))
-        return 1;
-    // (a batch beyond 2 GiB of input is split into groups; the answer is for a group that holds all n images)
-    return tia::conv_ring_ok(n, cin, cout, kh, kw, ho, wo) ? 2 : 0;
+    // the same checks, the same batch split and the same decision function as tia_conv2d_nhwc_f32(_ex): shapes the entry point
+    // rejects are rejected here with the same code
+    if (const int rc = conv2d_check_shape(n, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo); rc != TIA_OK) return rc;
+    const long group = conv2d_group(h, w, cin, cin, cout, kh, kw, ho, wo);
+    if (group < 1) return TIA_ESIZE;
+    // a batch beyond 2 GiB of input runs in groups of `group` images: the answer is the route of the FIRST group (every full group
+    // takes it; a shorter last group is decided on its own image count and may take another kernel -- tia_conv2d_route_f32 with
+    // n = n % group tells which)
+    return (int)conv2d_route(true, n < group ? n : group, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo);
 }
 
 // Thin-input form (an RGB stem: c = 3): in NHWC the kw * c values under one row of taps are CONTIGUOUS, so a kh x kw

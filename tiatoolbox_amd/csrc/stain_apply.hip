@@ -215,7 +215,9 @@ struct ApplyCtxFast {
             const double q = __builtin_fma(rr, __builtin_fma(rr, 0x1.c6b08d704a0bfp-35, 0x1.ebfbdff82c58ep-23), 0x1.62e42fefa39efp-11);
             const double t = etab[lo & 1023];
             const double v = __builtin_fma(t, rr * q, t);
-            o[c] = __hiloint2double(__double2hiint(v) + ((lo >> 10) << 20), __double2loint(v));
+            // exponent add in unsigned arithmetic (lo >> 10 is negative for every pixel darker than white: shifting it left as a
+            // signed int would be undefined behaviour; two's-complement wrap-around is what the add needs)
+            o[c] = __hiloint2double((int)((unsigned)__double2hiint(v) + ((unsigned)(lo >> 10) << 20)), __double2loint(v));
         }
     }
     // m = M * (-1024 / ln 2); returns whether the exponent arithmetic is safe for every byte value

@@ -132,23 +132,48 @@ def prepare_engines_save_dir(save_dir, *, patch_mode: bool, overwrite: bool = Fa
     if world_size == 1:
         _make_save_dir(save_dir, overwrite)
         return save_dir
-    outcome: list = [None]
-    if rank == 0:
-        try:
-            _make_save_dir(save_dir, overwrite)
-        except OSError as exc:  # FileExistsError, PermissionError, ...
-            outcome[0] = (type(exc).__name__, exc.errno, str(exc))
-    torch.distributed.broadcast_object_list(outcome, src=0)
-    if outcome[0] is not None:
-        name, errno_, text = outcome[0]
-        cls = {"FileExistsError": FileExistsError, "PermissionError": PermissionError,
-               "NotADirectoryError": NotADirectoryError}.get(name, OSError)
-        raise cls(errno_, text) if errno_ is not None else cls(text)
+    _rank0_does(lambda: _make_save_dir(save_dir, overwrite))
     return save_dir
 
 
+_OS_ERRORS = {"FileExistsError": FileExistsError, "PermissionError": PermissionError, "NotADirectoryError": NotADirectoryError,
+              "FileNotFoundError": FileNotFoundError, "IsADirectoryError": IsADirectoryError}
+
+
+def _rank0_does(action) -> None:
+    """Run a file-system ``action`` on rank 0 alone and make its outcome every rank's outcome: an ``OSError`` is broadcast as
+    ``(class name, errno, strerror, filename)`` and re-raised everywhere as the same class with the same attributes (so
+    ``exc.filename`` / ``exc.errno`` survive and the message is not doubled), instead of leaving the other ranks waiting in
+    the next collective.  The broadcast also orders the action before every rank's return.  COLLECTIVE."""
+    rank, _ = tdist.world()
+    outcome: list = [None]
+    if rank == 0:
+        try:
+            action()
+        except OSError as exc:  # FileExistsError, PermissionError, disk full, ...
+            outcome[0] = (type(exc).__name__, exc.errno, exc.strerror, exc.filename, str(exc))
+    torch.distributed.broadcast_object_list(outcome, src=0)
+    if outcome[0] is not None:
+        name, errno_, strerror, filename, text = outcome[0]
+        cls = _OS_ERRORS.get(name, OSError)
+        if errno_ is None:
+            raise cls(text)
+        raise cls(errno_, strerror, filename) if filename is not None else cls(errno_, strerror)
+
+
+def write_outputs(distributed: bool, action) -> None:
+    """Write one slide's result files: every process when not distributed; otherwise rank 0 alone, with the outcome (including
+    an ``OSError`` such as a full disk) shared by all ranks -- see :func:`_rank0_does`.  The returned paths exist on every rank
+    when this returns."""
+    if distributed and tdist.is_distributed():
+        _rank0_does(action)
+    else:
+        action()
+
+
 def outputs_written(distributed: bool) -> None:
-    """Rank 0 writes a WSI run's files; the paths ``run()`` returns must exist on every rank when it returns."""
+    """Rank 0 writes a WSI run's files; the paths ``run()`` returns must exist on every rank when it returns.  (The engines now
+    write through :func:`write_outputs`, whose broadcast already gives that guarantee; kept for callers that write themselves.)"""
     if distributed and tdist.is_distributed():
         torch.distributed.barrier()
 
@@ -747,10 +772,8 @@ class EngineABC:
             key = image if isinstance(image, (str, Path)) else num
             stem = Path(image).stem if isinstance(image, (str, Path)) else str(num)
             path = save_dir / f"{stem}.npz"
-            if tdist.world()[0] == 0 or not self.distributed:
-                np.savez(path, **arrays)
+            write_outputs(self.distributed, lambda path=path, arrays=arrays: np.savez(path, **arrays))
             out[key] = path
-        outputs_written(self.distributed)
         return out
 
     def run(self, images, *, masks=None, input_resolutions=None, patch_input_shape=None, ioconfig=None,

@@ -497,20 +497,42 @@ class MultiTaskSegmentor(EngineABC):
         task_type = model.tasks[0]
         mine = owned[rank]
         if any(len(results[i]) != 1 for i in mine) or len(getattr(model, "tasks", ())) > 1:
-            # several tasks per tile (HoVerNet+: nuclei + layers, different columns per task): the tiles' host records are
-            # exchanged as objects, one gather for the whole slide (ref. :1556-1730 keeps one sub-table per task)
-            payload = {}
+            # several tasks per tile (HoVerNet+: nuclei + layers, different columns per task): the tiles' small host records
+            # (tables with per-task columns) are exchanged as objects, one gather for the whole slide (ref. :1556-1730 keeps one
+            # sub-table per task); the tile-sized LABEL MAPS do not go through pickle -- they travel as one flat int32 payload
+            # (the ragged gather of the single-task path), described in the records by (shape, dtype) only
+            payload, maps = {}, []
             for i in mine:
-                payload[i] = tuple({k: (v if (k != "predictions" or want_predictions) else None) for k, v in task.items()}
-                                   for task in results[i])
+                recs = []
+                for task in results[i]:
+                    rec = {k: v for k, v in task.items() if k != "predictions"}
+                    rec["predictions"] = None
+                    if want_predictions:
+                        pred = task["predictions"]
+                        pred = pred.cpu().numpy() if isinstance(pred, torch.Tensor) else np.asarray(pred)
+                        rec["predictions"] = (tuple(pred.shape), pred.dtype.str)
+                        maps.append(pred.astype(np.int32, copy=False).ravel())
+                    recs.append(rec)
+                payload[i] = tuple(recs)
+            parts = tdist.all_gather_objects(payload)
+            full = None
+            if want_predictions:
+                flat = np.concatenate(maps) if maps else np.zeros(0, np.int32)
+                full = tdist.all_gather_ragged(torch.from_numpy(np.ascontiguousarray(flat)).to(device))[0].cpu().numpy()
             out: list = [None] * len(results)
-            for part in tdist.all_gather_objects(payload):
+            pos = 0
+            for part in parts:  # rank order; inside a rank its tiles in the order it packed them = ascending tile index
                 for i, tasks_ in part.items():
                     fixed = []
                     for task in tasks_:
                         task = dict(task)
-                        if task.get("predictions") is None:  # not requested: the merge below never reads it
+                        if task["predictions"] is None:  # not requested: the merge below never reads it
                             task["predictions"] = np.zeros((0, 0), np.int32)
+                        else:
+                            shape, dtype = task["predictions"]
+                            size = int(np.prod(shape))
+                            task["predictions"] = full[pos:pos + size].reshape(shape).astype(np.dtype(dtype), copy=False)
+                            pos += size
                         fixed.append(task)
                     out[i] = tuple(fixed)
             return out
@@ -631,10 +653,9 @@ class MultiTaskSegmentor(EngineABC):
         from pathlib import Path
 
         from tiatoolbox_amd import distributed as tdist
-        from tiatoolbox_amd.models.engine.engine_abc import outputs_written, prepare_engines_save_dir
+        from tiatoolbox_amd.models.engine.engine_abc import prepare_engines_save_dir, write_outputs
 
         save_dir = prepare_engines_save_dir(save_dir, patch_mode=False, overwrite=overwrite, distributed=self.distributed)
-        write = tdist.world()[0] == 0 or not self.distributed
         paths: dict = {}
         for i, image in enumerate(self.images):
             mask = self.masks[i] if self.masks is not None else None
@@ -643,7 +664,8 @@ class MultiTaskSegmentor(EngineABC):
             key = image if isinstance(image, (str, Path)) else i
             stem = Path(image).stem if isinstance(image, (str, Path)) else str(i)
             paths[key] = save_dir / f"{stem}.npz"
-            if write:
+
+            def write(out=out, path=paths[key]) -> None:
                 flat = {}
                 for name, val in out.items():
                     if isinstance(val, dict):  # several tasks: one sub-table each
@@ -652,8 +674,9 @@ class MultiTaskSegmentor(EngineABC):
                         flat.update({f"{name}/{j}": np.asarray(v) for j, v in enumerate(val)})
                     else:
                         flat[name] = np.asarray(val)
-                np.savez(paths[key], **flat)
-        outputs_written(self.distributed)
+                np.savez(path, **flat)
+
+            write_outputs(self.distributed, write)
         return paths
 
     def process_wsi(self, image, mask=None, *, return_predictions=None, auto_get_mask: bool = True) -> dict:
