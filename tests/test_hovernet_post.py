@@ -428,6 +428,30 @@ def test_hip_proc_np_hv_large_tile_properties():
         assert ndimage.label(lab == i)[1] == 1
 
 
+@pytest.mark.gpu
+def test_hip_proc_np_hv_large_tile_vs_oracle():
+    """One 1280 x 1280 plane = the WSI-mode tile of ``pretrained_model.yaml:667`` (``tile_shape`` 1024 + 2 x 128 margin) through the
+    multi-launch path (plane > 32,000 px: banded Sobel through HBM, watershed by relaxation + heap fall-back) -- the label map must
+    EQUAL ``oracle.hovernet.proc_np_hv`` of the same plane, bit for bit (about 3000 nuclei; the nine 426 x 426 synthetic fields are
+    laid edge to edge, so blobs also meet across the seams)."""
+    import torch
+
+    from tiatoolbox_amd.models.architecture import _hover_device as hd
+
+    npm, hv, _ = oh.synth_maps(9, 426, 426, seed=5, n_blobs=400)
+    big_np = np.zeros((1280, 1280, 1), np.float32)
+    big_hv = np.zeros((1280, 1280, 2), np.float32)
+    for k in range(9):
+        y, x = (k // 3) * 426 + 1, (k % 3) * 426 + 1
+        big_np[y:y + 426, x:x + 426] = npm[k]
+        big_hv[y:y + 426, x:x + 426] = hv[k]
+    exp = oh.proc_np_hv(big_np, big_hv)
+    assert exp.max() > 2500  # noqa: PLR2004
+    got, _ = hd.proc_np_hv(torch.from_numpy(big_np[None]).cuda(), torch.from_numpy(big_hv[None]).cuda())
+    got = got[0].cpu().numpy()
+    assert got.shape == exp.shape and np.array_equal(got, exp), int((got != exp).sum())
+
+
 def test_hovernet_state_dict_layout_and_shapes():
     """Parameter names follow the reference (hovernet.py:80-500) so its .pth files load strictly."""
     import torch
