@@ -71,7 +71,7 @@ typedef struct tia_stain_tables {
 #define TIA_ST_PINV 26    /* [6]  pinv(S^T) as P[j*2+i], C_i = sum_j OD_j P[j][i] (stainnorm.py:65)   */
 #define TIA_ST_M 32       /* [9]  M[j*3+c] = sum_i P[j][i]*(maxC_t[i]/maxC_s[i])*S_t[i][c]            */
 #define TIA_ST_SCALE 41   /* [2]  maxC_target / maxC_source                 (stainnorm.py:104)        */
-#define TIA_ST_CYCLES 48  /* [16] shader-clock cycles per phase (instrumentation; see stain_stats.hip) */
+#define TIA_ST_CYCLES 48  /* [16] shader-clock cycles per phase (instrumentation: -DTIA_STATS_TIMING=1 builds of stain_stats_*.hip) */
 
 #define TIA_FLAG_EMPTY_MASK 1
 #define TIA_FLAG_DEGENERATE 2
