@@ -135,6 +135,71 @@ def test_semantic_wsi_stitching_at_full_size_sampled_against_oracle():
         covered[int(y):min(int(y) + POUT, SIDE)] = True
     assert not probs[~covered].any() and bool(probs[covered].any())
 
+    # the same slide as if it did not fit the device (reference: zarr spill above `memory_threshold`,
+    # semantic_segmentor.py:552-583,1693-1730): at most TWO patch rows of canvas on the device, finished rows streamed to
+    # page-locked host memory on a copy stream -- the maps must be the resident run's, bit for bit
+    eng.device_band_rows = 2
+    out_s = eng.infer_wsi(reader, mask_reader, return_probabilities=True)
+    assert eng.last_band_streamed and not out_s["predictions"].is_cuda and not out_s["probabilities"].is_cuda
+    assert out_s["predictions"].shape == pred.shape and out_s["probabilities"].shape == probs.shape
+    for y in range(0, SIDE, 2000):
+        assert torch.equal(out_s["predictions"][y:y + 2000].to(dev), pred[y:y + 2000]), y
+        assert torch.equal(out_s["probabilities"][y:y + 2000].to(dev), probs[y:y + 2000]), y
+
+
+@pytest.mark.gpu
+def test_streamed_canvas_band_peak_memory_is_independent_of_slide_height():
+    """``CanvasBand`` in streamed mode: the device holds K chunks of ``oh`` canvas rows + the two patch rows being merged, so the
+    peak device memory of ``infer_wsi`` (beyond the slide itself) does not grow with the slide's height; the resident mode's does,
+    by the size of the maps.  The automatic switch (`memory_threshold`) picks the streamed mode when the maps would not fit."""
+    from tiatoolbox_amd.models.engine.io_config import IOSegmentorConfig
+    from tiatoolbox_amd.models.engine.semantic_segmentor import SemanticSegmentor
+    from tiatoolbox_amd.wsicore import ArrayWSIReader
+
+    dev = torch.device("cuda")
+    cfg = IOSegmentorConfig(input_resolutions=[{"units": "mpp", "resolution": 0.25}],
+                            output_resolutions=[{"units": "mpp", "resolution": 0.25}], patch_input_shape=[PIN, PIN],
+                            patch_output_shape=[POUT, POUT], stride_shape=[STRIDE, STRIDE],
+                            save_resolution={"units": "mpp", "resolution": 0.25})
+    width = 4096
+
+    def peak(height: int, rows):
+        g = torch.Generator(device="cuda").manual_seed(3)
+        reader = ArrayWSIReader(torch.randint(20, 200, (height, width, 3), dtype=torch.uint8, device=dev, generator=g), mpp=0.25, power=40.0)
+        eng = SemanticSegmentor(_StubHead(), batch_size=4, device="cuda", verbose=False)
+        eng._ioconfig = eng.ioconfig = cfg  # noqa: SLF001
+        eng.device_band_rows = rows
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        base = torch.cuda.memory_allocated()
+        torch.cuda.reset_peak_memory_stats()
+        out = eng.infer_wsi(reader, None, return_probabilities=True)
+        torch.cuda.synchronize()
+        grown = torch.cuda.max_memory_allocated() - base
+        assert out["predictions"].shape == (height, width) and eng.last_band_streamed == (rows is not None)
+        return grown, out
+
+    maps_bytes = lambda h: h * width * (1 + 4 * NCH)  # noqa: E731
+    s_short, out_short = peak(3000, 2)
+    s_tall, out_tall = peak(9000, 2)
+    r_short, res_short = peak(3000, None)
+    r_tall, _ = peak(9000, None)
+    assert abs(s_tall - s_short) < 8 << 20, (s_short, s_tall)                      # streamed: flat in the height
+    assert r_tall - r_short > 0.9 * (maps_bytes(9000) - maps_bytes(3000))          # resident: grows by the maps
+    assert s_tall < r_tall - 0.9 * maps_bytes(9000) + (64 << 20)
+    assert torch.equal(out_short["predictions"].to(dev), res_short["predictions"])
+    assert torch.equal(out_short["probabilities"].to(dev), res_short["probabilities"])
+    # the automatic switch: with a threshold of (nearly) zero per cent of the free memory every slide is "too large"
+    reader = ArrayWSIReader(torch.randint(20, 200, (3000, width, 3), dtype=torch.uint8, device=dev), mpp=0.25, power=40.0)
+    eng = SemanticSegmentor(_StubHead(), batch_size=4, device="cuda", verbose=False)
+    eng._ioconfig = eng.ioconfig = cfg  # noqa: SLF001
+    eng.memory_threshold = 1e-9
+    eng.infer_wsi(reader, None, return_probabilities=False)
+    assert eng.last_band_streamed
+    eng.memory_threshold = 80
+    eng.infer_wsi(reader, None, return_probabilities=False)
+    assert not eng.last_band_streamed
+
 
 @pytest.mark.gpu
 def test_vahadane_and_augmentor_at_full_batch_size_sampled_against_sklearn():

@@ -215,6 +215,16 @@ def test_wsi_mode_end_to_end():
     assert np.array_equal(out["predictions"], exp["predictions"])
     with pytest.raises(ValueError, match="return_labels"):
         eng.run([reader], patch_mode=False, ioconfig=cfg, return_labels=True, save_dir="unused")
+    # the same slide with the head maps STREAMED to host memory (a slide larger than HBM: at most two patch rows of canvas on the
+    # device, tile crops uploaded tile by tile): every output identical
+    eng.device_band_rows = 2
+    streamed = eng.process_wsi(reader, return_predictions=(True,))
+    assert eng.last_band_streamed
+    assert np.array_equal(streamed["predictions"], out["predictions"])
+    assert np.array_equal(np.array(list(streamed["box"])).reshape(-1, 4), np.array(list(out["box"])).reshape(-1, 4))
+    assert np.array_equal(np.concatenate(list(streamed["contours"])), np.concatenate(list(out["contours"])))
+    for a, b in zip(streamed["probabilities"], out["probabilities"]):
+        assert np.array_equal(a, b)
 
 
 def test_tile_sets_under_a_tissue_mask_match_reference(gold):

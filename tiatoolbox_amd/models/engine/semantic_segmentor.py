@@ -116,6 +116,116 @@ def exchange_bands(local: torch.Tensor, plan: dict, height: int) -> torch.Tensor
     return full
 
 
+class CanvasBand:
+    """Where a rank's finalised canvas rows go (SURVEY section 5: "device canvas band sized to HBM; spill to host pinned memory";
+    the reference spills its canvas to zarr above ``memory_threshold``, ``semantic_segmentor.py:552-583,1693-1730``).
+
+    *resident* (a slide whose maps fit the device): one device tensor ``[band_h, W, ...]`` per map, ``_finalize`` writes into it
+    at its slide row -- the round-1..4 behaviour.  *streamed* (``device_rows`` = K >= 2): the device holds a ring of K chunks of
+    ``oh`` canvas rows per map; a patch row's finished rows ``[ys, y1)`` are finalised into the next chunk and copied to a
+    page-locked HOST map on a copy stream while the next patch row is inferred; a chunk is reused only after its copy has
+    finished.  Peak device memory = K chunks + the two patch rows being merged, whatever the slide's height.  The maps come back
+    as host tensors; the bytes are the resident mode's, bit for bit (same kernel, same arguments up to the row offset).
+
+    ``maps``: ``{name: (trailing shape, dtype)}``, e.g. ``{"pred": ((), uint8), "probs": ((5,), float32)}``."""
+
+    def __init__(self, band_h: int, width: int, y_lo: int, oh: int, device: torch.device, maps: dict, *,
+                 device_rows: int | None = None) -> None:
+        self.band_h, self.width, self.y_lo, self.oh, self.device = int(band_h), int(width), int(y_lo), int(oh), device
+        self.streamed = device_rows is not None
+        self.maps = dict(maps)
+        self._slot = 0
+        if not self.streamed:
+            self.full = {k: torch.zeros((self.band_h, self.width, *shape), dtype=dt, device=device) for k, (shape, dt) in maps.items()}
+            return
+        self.k = max(2, int(device_rows))
+        self.chunks = [{k: torch.zeros((self.oh, self.width, *shape), dtype=dt, device=device) for k, (shape, dt) in maps.items()}
+                       for _ in range(self.k)]
+        self.free = [None] * self.k  # per chunk: the event after which its last copy has left the device
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.full = {k: self._host((self.band_h, self.width, *shape), dt) for k, (shape, dt) in maps.items()}
+
+    @staticmethod
+    def _host(shape, dtype) -> torch.Tensor:
+        try:
+            return torch.zeros(shape, dtype=dtype, pin_memory=True)
+        except RuntimeError:  # more than the driver will page-lock: pageable memory (the copies then block the copy stream's host side only)
+            return torch.zeros(shape, dtype=dtype)
+
+    @staticmethod
+    def bytes_needed(band_h: int, width: int, maps: dict) -> int:
+        return sum(int(band_h) * int(width) * int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dt).element_size()
+                   for shape, dt in maps.values())
+
+    def target(self, ys: int) -> tuple[dict, int]:
+        """Tensors to finalise rows starting at slide row ``ys`` into, and the slide row their row 0 stands for (``y_base``)."""
+        if not self.streamed:
+            return self.full, self.y_lo
+        ev = self.free[self._slot]
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return self.chunks[self._slot], int(ys)
+
+    def done(self, ys: int, y1: int) -> None:
+        """Rows ``[ys, y1)`` are final: streamed mode hands them to the copy stream and moves to the next chunk."""
+        if not self.streamed or y1 <= ys:
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        chunk = self.chunks[self._slot]
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(ready)
+            for k, host in self.full.items():
+                host[ys - self.y_lo:y1 - self.y_lo].copy_(chunk[k][:y1 - ys], non_blocking=True)
+            gone = torch.cuda.Event()
+            gone.record(self.copy_stream)
+        self.free[self._slot] = gone
+        self._slot = (self._slot + 1) % self.k
+
+    def result(self) -> dict:
+        if self.streamed:
+            self.copy_stream.synchronize()
+        return self.full
+
+
+def _band_device_rows(engine, nbytes: int, device: torch.device) -> int | None:
+    """``None`` = keep the band's maps resident on the device; K = stream them through a ring of K chunks (``CanvasBand``).
+    ``engine.device_band_rows`` forces K; otherwise streaming starts when the maps would take more than ``memory_threshold`` per
+    cent (the reference's run kwarg, default 80) of the device memory that is free right now."""
+    forced = getattr(engine, "device_band_rows", None)
+    if forced is not None:
+        return max(2, int(forced))
+    free, _ = torch.cuda.mem_get_info(device)
+    threshold = float(getattr(engine, "memory_threshold", 80) or 80)
+    return 4 if nbytes > free * threshold / 100.0 else None
+
+
+def exchange_bands_streamed(local: torch.Tensor, plan: dict, height: int, device: torch.device, rows: int = 2048) -> torch.Tensor:
+    """``exchange_bands`` for HOST bands of a slide that does not fit the device: the same padded all-gather, ``rows`` canvas rows at
+    a time through the device (the collective's tensors must live there under RCCL), every rank assembling the full HOST map."""
+    bands = plan["bands"]
+    world = len(bands)
+    if world == 1:
+        return local
+    tallest = max(max(b[1] - b[0] for b in bands), 1)
+    full = torch.zeros((height, *local.shape[1:]), dtype=local.dtype)
+    on_dev = device.type == "cuda"
+    for r0 in range(0, tallest, rows):
+        n = min(rows, tallest - r0)
+        pad = torch.zeros((n, *local.shape[1:]), dtype=local.dtype, device=device)
+        mine = local[r0:r0 + n]
+        if mine.shape[0]:
+            pad[: mine.shape[0]] = mine.to(device, non_blocking=False)
+        out = torch.empty((world * n, *local.shape[1:]), dtype=local.dtype, device=device)
+        torch.distributed.all_gather_into_tensor(out, pad.contiguous())
+        out_h = out.cpu() if on_dev else out
+        for r, (y_lo, y_hi) in enumerate(bands):
+            take = min(max(y_hi - y_lo - r0, 0), n)
+            if take > 0:
+                full[y_lo + r0:y_lo + r0 + take] = out_h[r * n:r * n + take]
+    return full
+
+
 class SemanticSegmentor(PatchPredictor):
     """Semantic segmentation of patches or whole (in-memory) slides (ref. :136-1821)."""
 
@@ -140,7 +250,8 @@ class SemanticSegmentor(PatchPredictor):
 
     def infer_wsi(self, reader: ArrayWSIReader, mask_reader: ArrayWSIReader | None = None, *,
                   return_probabilities: bool = False) -> dict:
-        """Tile, infer and stitch one slide; returns device tensors."""
+        """Tile, infer and stitch one slide; returns device tensors -- or, for a slide whose maps would not fit the device
+        (``memory_threshold``, or ``self.device_band_rows`` set), HOST tensors streamed there band by band (``CanvasBand``)."""
         dev = torch.device(self.device)
         if dev.type != "cuda":
             msg = "WSI-mode stitching runs on the GPU (device='cuda'); there is no CPU fallback."
@@ -158,11 +269,19 @@ class SemanticSegmentor(PatchPredictor):
         plan = band_plan(row_ys, oh, h, rank, world)
         r_lo, r_hi = plan["own"]
         y_lo, y_hi = plan["y_lo"], plan["y_hi"]
-        # rank-local band of the slide-sized maps (row 0 of the band = canvas row y_lo)
-        pred = torch.zeros((max(y_hi - y_lo, 0), w), dtype=torch.uint8, device=dev)
-        probs = None
+        # rank-local band of the slide-sized maps (row 0 of the band = canvas row y_lo): resident on the device, or -- a slide
+        # whose maps do not fit -- streamed to page-locked host memory patch row by patch row (CanvasBand)
+        band_h = max(y_hi - y_lo, 0)
+        band = None
         n_ch = None
         prev = None  # (row, cnt, ys)
+
+        def open_band(channels: int) -> CanvasBand:
+            maps = {"pred": ((), torch.uint8)}
+            if return_probabilities:
+                maps["probs"] = ((channels,), torch.float32)
+            k = _band_device_rows(self, CanvasBand.bytes_needed(band_h, w, maps), dev)
+            return CanvasBand(band_h, w, y_lo, oh, dev, maps, device_rows=k)
 
         from tiatoolbox_amd.models.engine.engine_abc import iter_row_outputs
 
@@ -205,21 +324,27 @@ class SemanticSegmentor(PatchPredictor):
                         n_ch = probe.shape[-1]
                     row = torch.zeros((oh, w, n_ch), dtype=torch.float32, device=dev)
                     cnt = torch.zeros((oh, w), dtype=torch.uint8, device=dev)
-                if return_probabilities and probs is None:
-                    probs = torch.zeros((max(y_hi - y_lo, 0), w, n_ch), dtype=torch.float32, device=dev)
+                if band is None:
+                    band = open_band(n_ch)
                 if ri >= r_lo:
                     y1 = min(int(row_ys[ri + 1]) if ri + 1 < len(row_ys) else ys + oh, h)
+                    dst, y_base = band.target(ys)
                     if prev is None:
-                        _finalize(row, cnt, ys, None, None, 0, ys, y1, probs, pred, y_base=y_lo)
+                        _finalize(row, cnt, ys, None, None, 0, ys, y1, dst.get("probs"), dst["pred"], y_base=y_base)
                     else:
-                        _finalize(prev[0], prev[1], prev[2], row, cnt, ys, ys, y1, probs, pred, y_base=y_lo)
+                        _finalize(prev[0], prev[1], prev[2], row, cnt, ys, ys, y1, dst.get("probs"), dst["pred"], y_base=y_base)
+                    band.done(ys, y1)
                 prev = (row, cnt, ys)
-        if return_probabilities and probs is None:
-            probs = torch.zeros((max(y_hi - y_lo, 0), w, n_ch or 1), dtype=torch.float32, device=dev)
+        if band is None:
+            band = open_band(n_ch or 1)
+        maps = band.result()
+        pred, probs = maps["pred"], maps.get("probs")
+        self.last_band_streamed = band.streamed
         if world > 1 and not getattr(self, "return_bands", False):
-            pred = exchange_bands(pred, plan, h)
+            gather = (lambda t: exchange_bands_streamed(t, plan, h, dev)) if band.streamed else (lambda t: exchange_bands(t, plan, h))
+            pred = gather(pred)
             if return_probabilities:
-                probs = exchange_bands(probs, plan, h)
+                probs = gather(probs)
         out = {"predictions": pred, "coordinates": out_b[keep], "band": (y_lo, y_hi)}
         if return_probabilities and probs is not None:
             out["probabilities"] = probs
