@@ -35,7 +35,7 @@ extern "C" {
 /* Version 4 (round 4): + tia_rgb2od_u8 (the stand-alone OD transform, with the reference's in-place side effect on request),
  * tia_clear_last_error; TIA_MATH_F64 of tia_stain_apply_u8 evaluates exp() with the library's own float64 kernel
  * (TIA_MATH_F64_REF keeps the device libm's exp); tia_conv3x3_geometry, tia_stain_stats_path (dispatch diagnostics). */
-#define TIA_ABI_VERSION 4
+#define TIA_ABI_VERSION 5
 int tia_abi_version(void);
 
 /* Reads-and-clears the HIP runtime's sticky last-error value as THIS library sees it (every entry point returns
@@ -481,6 +481,19 @@ int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const fl
                              int64_t kw, int64_t stride, int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo,
                              int32_t relu, const float* d_post_scale, const float* d_post_shift, float* d_y2,
                              void* stream);
+
+/* Winograd F(2x2, 3x3) form of the 3x3 / stride-1 float32 convolution (conv3x3_wino.hip; reference call sites: the 3x3 layers
+ * behind CNNModel.forward, models/architecture/vanilla.py:242-253,300-316): 16 instead of 36 multiplies per 2 x 2 outputs on the same
+ * float32 MFMA instruction, input transform in registers, weights transformed once at pack time in float64.  Same contract as
+ * tia_conv2d_nhwc_f32_ex for kh = kw = 3, stride = 1 (pad_top / pad_left in 0..2, ho / wo given; bias + residual + ReLU fused), but
+ * NOT bit-identical to it: float32 Winograd rounds differently from a direct float32 convolution (<= ~1e-5 relative, asserted in
+ * tests/test_engine.py) -- which is why nothing dispatches to it implicitly.  cin % 16 == 0, cout % 64 == 0.
+ *   tia_conv_pack_weights_wino_f32: OIHW [cout][cin][3][3] -> U = G g G^T, 16 * cin * cout floats in the kernel's stage layout
+ *   ([pos 16][cin/16][cout/64][hi 2][kq 2][64 cout][4 channels], channel = 16 cs + 8 hi + 4 kq + c4). */
+int tia_conv_pack_weights_wino_f32(const float* d_w_oihw, int64_t cout, int64_t cin, float* d_packed, void* stream);
+int tia_conv3x3_wino_nhwc_f32(const float* d_x, const float* d_u_packed, const float* d_bias, const float* d_residual, float* d_y,
+                              int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t pad_top, int64_t pad_left,
+                              int64_t ho, int64_t wo, int32_t relu, void* stream);
 
 /* Host-only query (no launch): which kernel tia_conv2d_nhwc_f32[_ex] runs a float32 convolution of this shape on --
  * 0: conv_mfma_f32_kernel (register-staged 128-pixel slices), 1: conv3x3_spatial_kernel (tap reuse; tia_conv3x3_geometry says

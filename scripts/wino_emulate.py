@@ -1,0 +1,154 @@
+"""CPU emulation of conv3x3_wino_kernel's data flow (csrc/conv3x3_wino.hip): the packed-weight layout, the LDS images the DMAs build,
+every lane's fragment addresses, the MFMA operand / result layout, the two-group output transform and the epilogue's pixel mapping --
+index formula by index formula -- against torch's conv2d.  A developer check of the kernel's bookkeeping that needs no GPU
+(`python scripts/wino_emulate.py`); the GPU parity tests are tests/test_engine.py::test_winograd_*."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+OOB = None
+
+
+def pack(w):  # wino_pack_kernel
+    cout, cin = w.shape[:2]
+    n_cs, n_cb = cin // 16, cout // 64
+    out = np.zeros(16 * cin * cout, np.float32)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+    for o in range(cout):
+        for c in range(cin):
+            U = G @ w[o, c].astype(np.float64) @ G.T
+            cs, hi, kq, c4, cb, col = c >> 4, (c >> 3) & 1, (c >> 2) & 1, c & 3, o >> 6, o & 63
+            for i in range(4):
+                for j in range(4):
+                    block = ((i * 4 + j) * n_cs + cs) * n_cb + cb
+                    out[block * 1024 + ((hi * 2 + kq) * 64 + col) * 4 + c4] = np.float32(U[i, j])
+    return out
+
+
+def run_block(x, upk, geo, mt_id, cb, pad, ho, wo, tiles_x, tiles_per_image):
+    n, h, w, cin = x.shape
+    cout = upk.size // (16 * cin)
+    G, TH, TW, PH, PWD, ROW, IMG = geo
+    NT, PIX = 512, 5
+    A_UNITS = (G * IMG + 63) // 64 * 64
+    NA = (A_UNITS + NT - 1) // NT
+    n_cs, n_cb = cin // 16, cout // 64
+    pos_stride = n_cs * n_cb * 4096
+    img = mt_id // tiles_per_image if G == 1 else mt_id * G
+    trem = mt_id - img * tiles_per_image if G == 1 else 0
+    ty0, tx0 = (trem // tiles_x) * TH, (trem % tiles_x) * TW
+    xf = x.reshape(-1)
+    acc = np.zeros((8, 2, 4, 32, 32), np.float32)  # [wave][half][j][row][col]
+    for cs in range(n_cs):
+        # ---- patch image
+        abuf = np.zeros((A_UNITS, 4), np.float32)
+        for r in range(NA):
+            for tid in range(NT):
+                un = NT * r + tid
+                wave = tid >> 6
+                if NT * r + wave * 64 >= A_UNITS:
+                    continue  # dump
+                g, ug = divmod(un, IMG)
+                py, rem = divmod(ug, ROW)
+                px, chunk = divmod(rem, PIX)
+                iy, ix = ty0 - pad + py, tx0 - pad + px
+                inside = g < G and img + g < n and py < PH and px < PWD and chunk < 4 and 0 <= iy < h and 0 <= ix < w
+                if inside:
+                    off = ((((img + g) * h + iy) * w + ix) * cin * 4 + 16 * chunk + cs * 64) // 4
+                    abuf[un] = xf[off:off + 4]
+        for half in range(2):
+            # ---- weight stage
+            wst = np.zeros((2048, 4), np.float32)
+            for q in range(4):
+                i, j0 = 2 * (q >> 1) + half, 2 * (q & 1)
+                soff = (i * 4 + j0) * pos_stride + (cs * n_cb + cb) * 4096
+                for wave in range(8):
+                    for lane in range(64):
+                        voff = (wave & 3) * 1024 + lane * 16 + (wave >> 2) * pos_stride
+                        src = (soff + voff) // 4
+                        wst[q * 512 + wave * 64 + lane] = upk[src:src + 4]
+            # ---- compute
+            for wave in range(8):
+                pg, wm, wn = wave >> 2, (wave >> 1) & 1, wave & 1
+                i = 2 * pg + half
+                ra = 0 if i == 0 else (2 if i == 2 else 1)
+                rb = 2 if i == 0 else (2 if i == 1 else (1 if i == 2 else 3))
+                sg = 1.0 if i == 1 else -1.0
+                V = np.zeros((4, 64, 8), np.float32)
+                Wv = np.zeros((4, 64, 8), np.float32)
+                for lane in range(64):
+                    hi = lane >> 5
+                    t = 32 * wm + (lane & 31)
+                    if G == 1:
+                        fa = 2 * (t >> 3) * ROW + 2 * (t & 7) * PIX + 2 * hi
+                    else:
+                        fa = (t >> 4) * IMG + 2 * ((t >> 2) & 3) * ROW + 2 * (t & 3) * PIX + 2 * hi
+                    fb = pg * 4 * 256 + hi * 128 + wn * 32 + (lane & 31)
+                    R = np.zeros((4, 8), np.float32)
+                    for c in range(4):
+                        a = np.concatenate([abuf[fa + ra * ROW + c * PIX], abuf[fa + ra * ROW + c * PIX + 1]])
+                        b = np.concatenate([abuf[fa + rb * ROW + c * PIX], abuf[fa + rb * ROW + c * PIX + 1]])
+                        R[c] = (b * np.float32(sg) + a).astype(np.float32)
+                    V[0, lane] = R[0] - R[2]
+                    V[1, lane] = R[1] + R[2]
+                    V[2, lane] = R[2] - R[1]
+                    V[3, lane] = R[1] - R[3]
+                    for j in range(4):
+                        Wv[j, lane] = np.concatenate([wst[fb + j * 256], wst[fb + j * 256 + 64]])
+                for j in range(4):
+                    for k in range(8):
+                        A = np.stack([V[j, :32, k], V[j, 32:, k]], axis=1)      # [row][kidx]
+                        B = np.stack([Wv[j, :32, k], Wv[j, 32:, k]], axis=0)    # [kidx][col]
+                        acc[wave, half, j] += (A @ B).astype(np.float32)
+    # ---- output transform + tile
+    tile = np.zeros((G * TH * TW, 64), np.float32)
+    for wave in list(range(4)) + list(range(4, 8)):
+        pg, wm, wn = wave >> 2, (wave >> 1) & 1, wave & 1
+        a = acc[wave]
+        z00, z01 = a[0, 0] + a[0, 1] + a[0, 2], a[0, 1] - a[0, 2] - a[0, 3]
+        z10, z11 = a[1, 0] + a[1, 1] + a[1, 2], a[1, 1] - a[1, 2] - a[1, 3]
+        yp = [[z00 + z10, z01 + z11], [z10, z11]] if pg == 0 else [[z00, z01], [-z00 - z10, -z01 - z11]]
+        for row in range(32):
+            tt = 32 * wm + row
+            m00 = 2 * (tt >> 3) * TW + 2 * (tt & 7) if G == 1 else (tt >> 4) * TH * TW + 2 * ((tt >> 2) & 3) * TW + 2 * (tt & 3)
+            for aa in range(2):
+                for bb in range(2):
+                    tile[m00 + aa * TW + bb, wn * 32:wn * 32 + 32] += yp[aa][bb][row]
+    out = {}
+    for row in range(G * TH * TW):
+        g, rg = divmod(row, TH * TW)
+        oy, ox = ty0 + rg // TW, tx0 + rg % TW
+        if oy < ho and ox < wo and img + g < n:
+            out[(img + g, oy, ox)] = tile[row]
+    return out
+
+
+def check(n, hw, cin, cout, pad, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, hw, hw, cin)).astype(np.float32)
+    wgt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    ho = wo = hw + 2 * pad - 2
+    ref = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(wgt), padding=pad).permute(0, 2, 3, 1).numpy()
+    upk = pack(wgt)
+    small = ho <= 8 and wo <= 8
+    geo = (4, 8, 8, 10, 10, 52, 520) if small else (1, 16, 16, 18, 18, 96, 18 * 96)
+    tiles_y = 1 if small else (ho + 15) // 16
+    tiles_x = 1 if small else (wo + 15) // 16
+    tiles = (n + 3) // 4 if small else n * tiles_y * tiles_x
+    got = np.full_like(ref, np.nan)
+    for mt in range(tiles):
+        for cb in range(cout // 64):
+            for (b, oy, ox), v in run_block(x, upk, geo, mt, cb, pad, ho, wo, tiles_x, tiles_y * tiles_x).items():
+                got[b, oy, ox, cb * 64:cb * 64 + 64] = v
+    assert not np.isnan(got).any(), "outputs not covered"
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    print(f"n={n} hw={hw} cin={cin} cout={cout} pad={pad}: rel err {err:.2e}")
+    assert err < 2e-5, err
+
+
+if __name__ == "__main__":
+    check(1, 16, 16, 64, 1)
+    check(5, 7, 32, 64, 1)       # W8 geometry, odd map, a partial block of images
+    check(1, 20, 16, 128, 1)     # partial blocks, two channel blocks
+    check(2, 12, 16, 64, 0)      # valid convolution
+    print("emulation ok")

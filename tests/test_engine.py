@@ -627,3 +627,75 @@ def test_chunked_prenormalisation_equals_per_batch(target_image):
     eng.stain_chunk = 8
     with pytest.raises(ValueError, match="Empty tissue mask"):   # flags raised once per run, also from the second chunk
         eng.run(white, **kw)
+
+
+@pytest.mark.gpu
+def test_winograd_conv_matches_torch_cpu_fp32():
+    """``tia_conv3x3_wino_nhwc_f32`` (Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32: float32 in, float32 accumulate, weights
+    transformed once in float64) against ``torch.nn.functional.conv2d`` on the CPU in float32 -- every 3x3 / stride-1 shape of
+    resnet18 at 256^2 and 224^2 patches (16 x 16 blocks whole and clipped, maps of at most 8 x 8 four images per block incl. a
+    partial block), odd maps, valid / pad-2 borders, 64 .. 512 channels, all epilogue variants.  Gate of VERDICT r04 #2:
+    max |delta| <= 1e-5 relative to the largest output magnitude; the direct kernel on the same input is the second reference."""
+    import torch.nn.functional as F  # noqa: N812
+
+    from tiatoolbox_amd.models.architecture.fused import hip_conv2d, hip_conv3x3_wino, pack_conv_weights, pack_conv_weights_wino
+
+    g = torch.Generator().manual_seed(5)
+    cases = [(3, 64, 64, 64, 1), (2, 128, 128, 32, 1), (2, 256, 256, 16, 1), (9, 512, 512, 8, 1),      # 256^2 patches' maps
+             (2, 64, 64, 56, 1), (3, 128, 128, 28, 1), (5, 256, 256, 14, 1), (6, 512, 512, 7, 1),      # 224^2 patches' maps
+             (1, 16, 64, 16, 1), (2, 32, 192, 20, 0), (2, 16, 64, 19, 2), (1, 48, 128, 9, 1), (7, 64, 64, 5, 1), (1, 64, 64, 33, 1)]
+    worst = 0.0
+    for n, cin, cout, hw, pad in cases:
+        conv = torch.nn.Conv2d(cin, cout, 3, padding=pad, bias=True)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+            conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        x = torch.randn((n, cin, hw, hw), generator=g)
+        ref_lin = F.conv2d(x, conv.weight, conv.bias, padding=pad)
+        res = torch.randn(ref_lin.shape, generator=g)
+        dev_conv = conv.cuda()
+        up = pack_conv_weights_wino(dev_conv)
+        assert up.shape == (16, cin // 16, cout // 64, 2, 2, 64, 4)
+        # the packed weights ARE G g G^T (float64 transform, rounded once): position (0, 0) is the tap (0, 0), (3, 3) the tap (2, 2)
+        w = conv.weight.detach().cpu()
+        u = up.cpu().permute(0, 2, 5, 1, 3, 4, 6).reshape(16, cout, cin)  # [pos][cout][cin]
+        assert torch.equal(u[0], w[:, :, 0, 0]) and torch.equal(u[15], w[:, :, 2, 2])
+        gm = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+        assert torch.allclose(u.reshape(4, 4, cout, cin).permute(2, 3, 0, 1), (gm @ w.double() @ gm.T).float(), rtol=0, atol=1e-7)
+        xd = x.cuda().contiguous(memory_format=torch.channels_last)
+        rd = res.cuda().contiguous(memory_format=torch.channels_last)
+        scale = ref_lin.abs().max().item()
+        for use_res, relu in ((False, False), (False, True), (True, True)):
+            exp = ref_lin + (res if use_res else 0)
+            exp = torch.relu(exp) if relu else exp
+            got = hip_conv3x3_wino(xd, up, dev_conv.bias, rd if use_res else None, padding=pad, relu=relu)
+            assert got.shape == exp.shape and got.is_contiguous(memory_format=torch.channels_last)
+            err = (got.cpu() - exp).abs().max().item() / scale
+            worst = max(worst, err)
+            assert err <= 1e-5, (n, cin, cout, hw, pad, use_res, relu, err)
+        if pad == 1 and cin % 32 == 0:  # ... and the direct kernel's result for the same launch: the two agree to rounding
+            direct = hip_conv2d(xd, pack_conv_weights(dev_conv), dev_conv.bias, rd, kernel=3, stride=1, padding=1, relu=False)
+            got = hip_conv3x3_wino(xd, up, dev_conv.bias, rd, padding=1, relu=False)
+            assert (got - direct).abs().max().item() / scale <= 1e-5
+    assert worst > 0.0  # (a bit-identical result would mean the direct kernel ran)
+    with pytest.raises(ValueError, match="Winograd"):
+        pack_conv_weights_wino(torch.nn.Conv2d(24, 64, 3).cuda())
+
+
+@pytest.mark.gpu
+def test_winograd_patch_predictor_within_tolerance_of_direct():
+    """``PatchPredictor.run(..., conv_algo="winograd")``: the float32 3x3 / stride-1 block convolutions through F(2x2, 3x3).  The
+    probabilities stay within 1e-5 of the direct float32 path (the reference's own fp16 tolerance is 1e-3,
+    ``tests/engines/test_patch_predictor.py:719``), predictions agree, and the run really took the other kernel."""
+    from tiatoolbox_amd.models.engine.patch_predictor import PatchPredictor
+    from tiatoolbox_amd.utils import synth
+
+    patches = synth.g_he(24, 224, 224, seed=9)
+    eng = PatchPredictor("resnet18-kather100k", batch_size=16, device="cuda", verbose=False)
+    direct = eng.run(patches, patch_mode=True, return_probabilities=True)
+    wino = eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo="winograd")
+    dp = np.abs(np.asarray(wino["probabilities"], np.float64) - np.asarray(direct["probabilities"], np.float64)).max()
+    assert 0.0 < dp <= 1e-5, dp
+    assert np.array_equal(wino["predictions"], direct["predictions"])
+    again = eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo="direct")
+    assert np.array_equal(again["probabilities"], direct["probabilities"])  # the switch goes back

@@ -100,6 +100,8 @@ _SIGNATURES = {
     "tia_conv2d_post_nhwc_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32,
                                   _P, _P, _P, _P], C.c_int),
     "tia_conv2d_route_f32": ([_I64] * 12, C.c_int),
+    "tia_conv_pack_weights_wino_f32": ([_P, _I64, _I64, _P, _P], C.c_int),
+    "tia_conv3x3_wino_nhwc_f32": ([_P, _P, _P, _P, _P] + [_I64] * 9 + [_I32, _P], C.c_int),
     "tia_conv1x1_pre_nhwc_f32": ([_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     "tia_stem_pack_weights_h": ([_P, _I32, _P, _P], C.c_int),
     "tia_stem_conv7x7_pool_nhwc_h": ([_P, _I32, _P, _P, _P, _I32, _I64, _I64, _I64, _P], C.c_int),

@@ -236,6 +236,7 @@ class EngineABC:
         self.output_type = None
         # MI355X extensions (plain attributes, settable through run(**kwargs) like every other)
         self.compute_dtype = "float32"    # arithmetic type of the CNN forward
+        self.conv_algo = "direct"         # float32 3x3 / stride-1 block convolutions: "direct" | "winograd" (F(2x2, 3x3), opt-in)
         self.distributed = True           # shard over ranks when torch.distributed is initialised
         self.fold_batchnorm = True        # inference copy with BN folded into the convolutions
         self.miopen_find = None           # True: MIOpen solver search for graphs that still run as plain torch modules
@@ -387,7 +388,8 @@ class EngineABC:
         """The module used for the forward pass: parameters in ``dtype``, channels-last (MIOpen NHWC)."""
         if dtype == torch.float32 and torch.device(self.device).type != "cuda":
             return self.model
-        key = (dtype, str(self.device), id(self.model), self.fold_batchnorm, _weights_version(self.model))
+        algo = str(getattr(self, "conv_algo", None) or "direct")
+        key = (dtype, str(self.device), id(self.model), self.fold_batchnorm, _weights_version(self.model), algo)
         if self._fast_key != key:
             import copy
 
@@ -422,6 +424,7 @@ class EngineABC:
             if on_gpu:  # hand-written trunks pack their weights (and keep float32 biases) from the float32 parameters
                 for mod in m.modules():
                     if type(mod).__name__ == "MfmaResNet":
+                        mod.set_conv_algo(algo)  # run kwarg `conv_algo="winograd"`: opt-in float32 Winograd for the 3x3 / stride-1 layers
                         mod.prepare(dtype)
             m = m.to(dtype=dtype) if dtype != torch.float32 else m
             if on_gpu:
