@@ -28,7 +28,7 @@ for f in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), re
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     lines.append(f"# {os.path.relpath(f, src)}  (rocprofv3 --pmc), mean per dispatch")
     for k, ctrs in acc.items():
-        if "tia" not in k and "conv_mfma" not in k and "stem7x7" not in k:
+        if "tia" not in k and "conv_mfma" not in k and "stem7x7" not in k and "wino" not in k:
             continue
         for c, vals in ctrs.items():
             lines.append(f"{c:>14} mean={sum(vals)/len(vals):16.1f} n={len(vals):5d}  {k[:120]}")

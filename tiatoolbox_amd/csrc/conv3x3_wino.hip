@@ -42,6 +42,7 @@ struct WinoDims {
     int n, h, w, cin, cout, ho, wo, pad_y, pad_x;
     unsigned x_bytes, u_bytes;
     int pos_stride;  // bytes between consecutive positions of the packed weights: (cin / 16) * (cout / 64) * 4096
+    int abl;         // timing builds only (TIA_WINO_ABL): 1 no weight DMA in the loop, 2 no patch DMA, 4 weight DMA out of range (zeros), 8 half of it
 };
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, int voffset, int soffset) {
@@ -59,7 +60,25 @@ struct W8 {
     static constexpr int G = 4, TH = 8, TW = 8, PH = 10, PWD = 10, ROW = 52, IMG = 10 * 52;
 };
 
-template <typename GEO>
+// s_waitcnt vmcnt(VM) lgkmcnt(0) (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] = 7 (no wait) | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+template <int VM>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+    __builtin_amdgcn_s_waitcnt((VM & 15) | (7 << 4) | ((VM >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+
+// Phase timing (developer builds only: -DTIA_WINO_TIMING=1): thread 0 of two workgroups prints shader-clock cycles of the prologue,
+// of the steps' compute and of their waits (vmcnt + barrier), of the epilogue, and the shader clock against the 100 MHz clock.
+#ifndef TIA_WINO_TIMING
+#define TIA_WINO_TIMING 0
+#endif
+#if TIA_WINO_TIMING
+#define WSTAMP(var) { const long long now_ = clock64(); var += now_ - tl_; tl_ = now_; }
+#else
+#define WSTAMP(var)
+#endif
+
+template <typename GEO, int NSTAGE>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                               const float* __restrict__ bias, const float* __restrict__ res,
                                                               float* __restrict__ y, WinoDims d, int relu, int m_tiles, int tiles_x,
@@ -70,12 +89,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     constexpr int NA = (A_UNITS + NT - 1) / NT;                   // DMA pieces per patch: 4 | 5 (the last one partial)
     constexpr int A_BYTES = A_UNITS * 16;
     constexpr int W_STAGE = 8 * 4096;                             // 8 positions x [16 channels][64 columns] float32
-    constexpr int DUMP = 2 * A_BYTES + 2 * W_STAGE;               // 1 KB the idle waves of the last patch piece write their zeros to
-    constexpr int LDS_BYTES = DUMP + 1024;
-    static_assert(LDS_BYTES >= BLOCK_PX * BN * 4, "epilogue tile");
+    constexpr int DUMP = 2 * A_BYTES + NSTAGE * W_STAGE;          // 1 KB the idle waves of the last patch piece write their zeros to
+    constexpr int EPI_BYTES = 2 * BLOCK_PX * BN * 4;              // the epilogue's two float32 tiles (one per position group)
+    constexpr int LDS_BYTES = DUMP + 1024 > EPI_BYTES ? DUMP + 1024 : EPI_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
     static_assert(NA >= 2 && NA <= 6, "patch pieces are spread over the two steps of a slice");
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "weight ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#if TIA_WINO_TIMING
+    long long tm_pro = 0, tm_comp = 0, tm_wait = 0, tm_epi = 0, tl_ = clock64();
+    const long long t0c_ = tl_, t0w_ = wall_clock64();
+#endif
 
     const int bid = blockIdx.x;
     const int per_xcd = (m_tiles + 7) / 8;
@@ -115,17 +139,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     unsigned char* const abuf0 = smem;
     unsigned char* const wst0 = smem + 2 * A_BYTES;
     auto dma_a = [&](int buf, int r, int cs) {
+#if TIA_WINO_TIMING
+        if ((d.abl & 2) && cs > 0) return;
+#endif
         unsigned char* dst = (NT * r + wave * 64 >= A_UNITS) ? smem + DUMP : abuf0 + buf * A_BYTES + r * (NT * 16) + wave * 1024;
         dma16(rx, dst, cen[r], cs * 64);
     };
     // weights of flattened step s = 2 cs + half
     auto dma_w = [&](int stage, int s) {
         const int cs = s >> 1, half = s & 1;
+#if TIA_WINO_TIMING
+        if ((d.abl & 1) && s > 0) return;
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = 2 * (q >> 1) + half, j0 = 2 * (q & 1);
             const int soff = (i * 4 + j0) * d.pos_stride + (cs * n_cb + cb) * 4096;
+#if TIA_WINO_TIMING
+            if ((d.abl & 8) && (q & 1) && s > 0) continue;
+            dma16(ru, wst0 + stage * W_STAGE + q * 8192 + wave * 1024, ((d.abl & 4) && s > 0) ? OOB : w_voff, soff);
+#else
             dma16(ru, wst0 + stage * W_STAGE + q * 8192 + wave * 1024, w_voff, soff);
+#endif
         }
     };
 
@@ -160,67 +195,167 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     // weights of the lane: block (pg, j) of the stage, units [hi][kq][column]: two 16-byte reads per position
     const int fb = pg * 4 * 256 + hi * 128 + wn * 32 + (lane & 31);
 
+    // One step = position row i of the group, positions j = 0..3: 16 patch reads (two rows x four columns x two 16-byte units),
+    // 8 weight reads, 64 adds, 32 MFMAs.  Software-pipelined so that no LDS round trip is exposed inside the step (the first
+    // version read each position's operands right in front of its MFMAs: eight exposed waits per step, matrix pipe 50-65 % busy):
+    //   request columns 0 and 2 (what V_0 = R0 - R2 needs) + weights of j = 0, then column 1 + weights of j = 1;
+    //   behind the eight MFMAs of j = 0: request column 3 and the weights of j = 2, 3; form R1, V1;
+    //   j = 1 .. 3 then run out of registers.  sched_group_barrier pins that order.
     auto compute = [&](int buf, int stage, auto half_c) {
         constexpr int HALF = decltype(half_c)::value;
         const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES) + fa;
         const u32x4* sb = reinterpret_cast<const u32x4*>(wst0 + stage * W_STAGE) + fb;
+        const int ra = ra_u[HALF], rb = rb_u[HALF];
+        const float sgn = sg[HALF];
+        u32x4 pa[4][2], pb[4][2], wq[4][2];
+        auto load_col = [&](int c) {
+            pa[c][0] = sa[ra + c * PIX], pa[c][1] = sa[ra + c * PIX + 1];
+            pb[c][0] = sa[rb + c * PIX], pb[c][1] = sa[rb + c * PIX + 1];
+        };
+        auto load_w = [&](int j) { wq[j][0] = sb[j * 256], wq[j][1] = sb[j * 256 + 64]; };
         float R[4][8];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const u32x4 a0 = sa[ra_u[HALF] + c * PIX], a1 = sa[ra_u[HALF] + c * PIX + 1];
-            const u32x4 b0 = sa[rb_u[HALF] + c * PIX], b1 = sa[rb_u[HALF] + c * PIX + 1];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                R[c][k] = __builtin_fmaf(__uint_as_float(b0[k]), sg[HALF], __uint_as_float(a0[k]));
-                R[c][4 + k] = __builtin_fmaf(__uint_as_float(b1[k]), sg[HALF], __uint_as_float(a1[k]));
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // column transform: V_j = R0 - R2 | R1 + R2 | R2 - R1 | R1 - R3
-            float v[8];
+        auto row_tf = [&](int c) {
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                v[k] = j == 0 ? R[0][k] - R[2][k] : (j == 1 ? R[1][k] + R[2][k] : (j == 2 ? R[2][k] - R[1][k] : R[1][k] - R[3][k]));
-            const u32x4 w0 = sb[j * 256], w1 = sb[j * 256 + 64];
+                R[c][k] = __builtin_fmaf(__uint_as_float(pb[c][k >> 2][k & 3]), sgn, __uint_as_float(pa[c][k >> 2][k & 3]));
+        };
+        auto mma8 = [&](int j, const float (&v)[8]) {
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                acc[HALF][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], __uint_as_float(k < 4 ? w0[k & 3] : w1[k & 3]), acc[HALF][j], 0, 0, 0);
+                acc[HALF][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], __uint_as_float(wq[j][k >> 2][k & 3]), acc[HALF][j], 0, 0, 0);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        load_col(0), load_col(2), load_w(0);   // 10 reads
+        load_col(1), load_w(1);                // 6 reads
+        row_tf(0), row_tf(2);
+        float v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v0[k] = R[0][k] - R[2][k];
+        mma8(0, v0);
+        load_col(3), load_w(2), load_w(3);     // 8 reads, behind the MFMAs of j = 0
+        row_tf(1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v1[k] = R[1][k] + R[2][k];
+        mma8(1, v1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v2[k] = R[2][k] - R[1][k];
+        mma8(2, v2);
+        row_tf(3);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v3[k] = R[1][k] - R[3][k];
+        mma8(3, v3);
+        // order for the scheduler (masks: 0x100 DS read, 0x002 VALU, 0x008 MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);  // columns 0, 2, 1 + weights 0, 1
+        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);  // R0, R2, V0
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                        // j = 0: each MFMA followed by one of the 8 late reads and two of the
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 16 VALU operations of R1, V1
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                        // j = 1 (+ V2)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                        // j = 2 (+ R3, V3)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // j = 3
+        __builtin_amdgcn_sched_barrier(0);
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
-    auto step_end = [] {
+#if TIA_WINO_TIMING
+    long long tm_vm = 0;
+#endif
+    auto step_end = [&] {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if TIA_WINO_TIMING
+        { const long long now_ = clock64(); tm_vm += now_ - tl_; }
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
 
-    // prologue: patch of slice 0, weights of step 0
+    if constexpr (NSTAGE == 2) {
+        // two weight stages: the weights of step s + 1 and the next slice's patch are requested at the start of step s and must have
+        // landed by its end (vmcnt(0)): one step of look-ahead
 #pragma unroll
-    for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
-    dma_w(0, 0);
-    step_end();
-    constexpr int NA0 = (NA + 1) / 2;  // patch pieces issued in the first step of a slice; the rest in the second
-    for (int cs = 0; cs < n_cs; ++cs) {
-        const int buf = cs & 1;
-        const bool more = cs + 1 < n_cs;
-        // step 2 cs (rows i = 0 / 2): weights of step 2 cs + 1 -> stage 1, the first pieces of the next slice's patch
-        dma_w(1, 2 * cs + 1);
-        if (more) {
-#pragma unroll
-            for (int r = 0; r < NA0; ++r) dma_a(buf ^ 1, r, cs + 1);
-        }
-        compute(buf, 0, H0{});
+        for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
+        dma_w(0, 0);
         step_end();
-        // step 2 cs + 1 (rows i = 1 / 3): weights of step 2 cs + 2 -> stage 0, the remaining pieces
-        if (more) {
-            dma_w(0, 2 * cs + 2);
+        WSTAMP(tm_pro)
+        constexpr int NA0 = (NA + 1) / 2;  // patch pieces issued in the first step of a slice; the rest in the second
+        for (int cs = 0; cs < n_cs; ++cs) {
+            const int buf = cs & 1;
+            const bool more = cs + 1 < n_cs;
+            // step 2 cs (rows i = 0 / 2): weights of step 2 cs + 1 -> stage 1, the first pieces of the next slice's patch
+            dma_w(1, 2 * cs + 1);
+            if (more) {
 #pragma unroll
-            for (int r = NA0; r < NA; ++r) dma_a(buf ^ 1, r, cs + 1);
+                for (int r = 0; r < NA0; ++r) dma_a(buf ^ 1, r, cs + 1);
+            }
+            compute(buf, 0, H0{});
+            WSTAMP(tm_comp)
+            step_end();
+            WSTAMP(tm_wait)
+            // step 2 cs + 1 (rows i = 1 / 3): weights of step 2 cs + 2 -> stage 0, the remaining pieces
+            if (more) {
+                dma_w(0, 2 * cs + 2);
+#pragma unroll
+                for (int r = NA0; r < NA; ++r) dma_a(buf ^ 1, r, cs + 1);
+            }
+            compute(buf, 1, H1{});
+            WSTAMP(tm_comp)
+            step_end();
+            WSTAMP(tm_wait)
         }
-        compute(buf, 1, H1{});
+    } else {
+        // three weight stages, TWO steps of look-ahead: at step s the weights of step s + 2 go out; the next slice's whole patch goes
+        // out at the slice's first step (its buffer was released by the barrier before).  The counted waits let exactly the requests
+        // of the current step stay in flight: after an even step (4 weight rounds + NA patch pieces issued) everything older -- the
+        // weights of step s + 1 -- has landed; after an odd step (4 issued) the weights of step s + 2 and the patch have.
+#pragma unroll
+        for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
+        dma_w(0, 0);
+        dma_w(1, 1);
         step_end();
+        WSTAMP(tm_pro)
+        int st = 0;  // stage of the current step
+        for (int cs = 0; cs + 1 < n_cs; ++cs) {
+            const int buf = cs & 1;
+            const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
+            dma_w(st2, 2 * cs + 2);
+#pragma unroll
+            for (int r = 0; r < NA; ++r) dma_a(buf ^ 1, r, cs + 1);
+            compute(buf, st, H0{});
+            WSTAMP(tm_comp)
+            wait_vm_lgkm0<4 + NA>();
+            __builtin_amdgcn_s_barrier();
+            WSTAMP(tm_wait)
+            dma_w(st, 2 * cs + 3);  // (the stage this step's predecessor just finished with)
+            compute(buf, st1, H1{});
+            WSTAMP(tm_comp)
+            wait_vm_lgkm0<4>();
+            __builtin_amdgcn_s_barrier();
+            WSTAMP(tm_wait)
+            st = st2;
+        }
+        {
+            const int buf = (n_cs - 1) & 1;
+            const int st1 = st == 2 ? 0 : st + 1;
+            compute(buf, st, H0{});
+            WSTAMP(tm_comp)
+            step_end();
+            WSTAMP(tm_wait)
+            compute(buf, st1, H1{});
+            WSTAMP(tm_comp)
+            step_end();
+            WSTAMP(tm_wait)
+        }
     }
 
     // ---- output transform (A^T = [1 1 1 0; 0 1 -1 -1]) ------------------------------------------------------------------------
@@ -236,36 +371,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
             yp[0][0] = z00, yp[0][1] = z01, yp[1][0] = -z00 - z10, yp[1][1] = -z01 - z11;
         }
     }
-    float* tile = reinterpret_cast<float*>(smem);  // [BLOCK_PX][64]; block pixel m = image m / (TH TW), (ty0 + (m % (TH TW)) / TW, tx0 + m % TW)
-    auto lds_barrier = [] {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    auto to_tile = [&](bool add) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int tt = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * hi;  // MFMA result row -> tile
-            int m00;
-            if constexpr (GEO::G == 1) {
-                m00 = 2 * (tt >> 3) * GEO::TW + 2 * (tt & 7);
-            } else {
-                m00 = (tt >> 4) * (GEO::TH * GEO::TW) + 2 * ((tt >> 2) & 3) * GEO::TW + 2 * (tt & 3);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float* p = tile + (m00 + a * GEO::TW + b) * BN + wn * 32 + (lane & 31);
-                    *p = add ? *p + yp[a][b][e] : yp[a][b][e];
-                }
-        }
-    };
-    if (pg == 0) to_tile(false);
-    lds_barrier();
-    if (pg == 1) to_tile(true);
-    lds_barrier();
-
+    // The two position groups' partial sums go to TWO float32 tiles [BLOCK_PX][64] (group 0: smem + 0, group 1: smem + 64 KB), one
+    // barrier, and the read-out adds them (the first version stored, synchronised, added in place, synchronised again).  The
+    // residual and bias of all four chunks of a thread are requested BEFORE the tiles are written: one exposed round trip.
+    // block pixel m = image m / (TH TW), (ty0 + (m % (TH TW)) / TW, tx0 + m % TW)
     constexpr int CHUNKS = BLOCK_PX * BN / 8, ITER = CHUNKS / NT;  // 2048 chunks of 8 columns, 4 per thread
     static_assert(CHUNKS % NT == 0 && NT % (BN / 8) == 0, "whole chunk rounds; a thread keeps its column chunk");
     const int cc = tid % (BN / 8);
@@ -291,12 +400,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
             rq[it][1] = rp[1];
         }
     }
+    float* tile = reinterpret_cast<float*>(smem) + pg * (BLOCK_PX * BN);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int tt = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * hi;  // MFMA result row -> tile
+        int m00;
+        if constexpr (GEO::G == 1) {
+            m00 = 2 * (tt >> 3) * GEO::TW + 2 * (tt & 7);
+        } else {
+            m00 = (tt >> 4) * (GEO::TH * GEO::TW) + 2 * ((tt >> 2) & 3) * GEO::TW + 2 * (tt & 3);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) tile[(m00 + a * GEO::TW + b) * BN + wn * 32 + (lane & 31)] = yp[a][b][e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const float* t0 = reinterpret_cast<const float*>(smem);
+    const float* t1 = t0 + BLOCK_PX * BN;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int row = (tid + NT * it) / (BN / 8);
-        const float4 v0 = *reinterpret_cast<const float4*>(tile + row * BN + cc * 8);
-        const float4 v1 = *reinterpret_cast<const float4*>(tile + row * BN + cc * 8 + 4);
-        float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+        const float4 p0 = *reinterpret_cast<const float4*>(t0 + row * BN + cc * 8), p1 = *reinterpret_cast<const float4*>(t0 + row * BN + cc * 8 + 4);
+        const float4 q0 = *reinterpret_cast<const float4*>(t1 + row * BN + cc * 8), q1 = *reinterpret_cast<const float4*>(t1 + row * BN + cc * 8 + 4);
+        // (group 0's sum + group 1's sum) + bias: Y[0][b] = (Z0 + Z1) + Z2, Y[1][b] = Z1 + (-Z2 - Z3)
+        float v[8] = {(p0.x + q0.x) + b0.x, (p0.y + q0.y) + b0.y, (p0.z + q0.z) + b0.z, (p0.w + q0.w) + b0.w,
+                      (p1.x + q1.x) + b1.x, (p1.y + q1.y) + b1.y, (p1.z + q1.z) + b1.z, (p1.w + q1.w) + b1.w};
         if (mpix[it] >= 0) {
             float* yo = y + (long)mpix[it] * d.cout + col0;
             if (res) {
@@ -314,6 +445,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
             *reinterpret_cast<float4*>(yo + 4) = float4{v[4], v[5], v[6], v[7]};
         }
     }
+#if TIA_WINO_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WSTAMP(tm_epi)
+    if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 64 || blockIdx.x == 1001))
+        printf("wino wg %d (cin %d, stages %d, abl %d): prologue %lld  compute %lld  step waits %lld (of which vmcnt %lld)  epilogue %lld  (steps %d) | shader clock %.0f MHz\n",
+               (int)blockIdx.x, d.cin, NSTAGE, d.abl, tm_pro, tm_comp, tm_wait, tm_vm, tm_epi, 2 * n_cs,
+               100.0 * (double)(clock64() - t0c_) / (double)(wall_clock64() - t0w_));
+#endif
 }
 
 // U = G g G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]) in float64, rounded once; one thread per (cout, cin) pair
@@ -350,6 +489,12 @@ __global__ void wino_pack_kernel(const float* __restrict__ w_oihw, int cout, int
 
 namespace tia {
 
+// dynamic LDS of the kernel: two patch buffers + two weight stages + the dump KB, at least the epilogue's two 64 KB tiles
+static constexpr int wino_lds_bytes(int patch_units, int stages) {
+    const int main_loop = 2 * ((patch_units + 63) / 64 * 64) * 16 + stages * 32768 + 1024;
+    return main_loop > 2 * 256 * 64 * 4 ? main_loop : 2 * 256 * 64 * 4;
+}
+
 bool conv3x3_wino_serves(long nb, long h, long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo) {
     if (cin % 16 != 0 || cout % 64 != 0 || pad_top < 0 || pad_left < 0 || pad_top > 2 || pad_left > 2 || ho <= 0 || wo <= 0) return false;
     // the patch of a block must cover what its outputs read: any 3x3 / stride-1 geometry does (18 = 16 + 2)
@@ -363,28 +508,32 @@ int conv3x3_wino_launch(const float* x, const float* u_packed, const float* bias
     const long tiles_y = small ? 1 : (ho + 15) / 16, tiles_x = small ? 1 : (wo + 15) / 16;
     const long tiles = small ? (nb + 3) / 4 : nb * tiles_y * tiles_x;
     const WinoDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
-                     (unsigned)(nb * h * w * cin * 4), (unsigned)(16 * cin * cout * 4), (int)((cin / 16) * (cout / 64) * 4096)};
+                     (unsigned)(nb * h * w * cin * 4), (unsigned)(16 * cin * cout * 4), (int)((cin / 16) * (cout / 64) * 4096),
+                     getenv("TIA_WINO_ABL") ? atoi(getenv("TIA_WINO_ABL")) : 0};
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / 64));
-    static tia::DeviceOnce attr16, attr8;  // the dynamic-LDS attribute is per device
-    if (small) {
-        constexpr int lds = 2 * ((W8::G * W8::IMG + 63) / 64 * 64) * 16 + 2 * 32768 + 1024;
-        if (!attr8.ensure([] {
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<W8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           lds) == hipSuccess;
-            }))
-            return TIA_ELAUNCH;
-        hipLaunchKernelGGL(conv3x3_wino_kernel<W8>, grid, dim3(512), lds, stream, x, u_packed, bias, residual, y, d, relu, (int)tiles,
-                           (int)tiles_x, (int)(tiles_y * tiles_x));
-    } else {
-        constexpr int lds = 2 * ((W16::G * W16::IMG + 63) / 64 * 64) * 16 + 2 * 32768 + 1024;
-        if (!attr16.ensure([] {
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<W16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           lds) == hipSuccess;
-            }))
-            return TIA_ELAUNCH;
-        hipLaunchKernelGGL(conv3x3_wino_kernel<W16>, grid, dim3(512), lds, stream, x, u_packed, bias, residual, y, d, relu, (int)tiles,
-                           (int)tiles_x, (int)(tiles_y * tiles_x));
-    }
+    // weight ring: three stages (two steps of look-ahead) where the LDS holds them -- the 16 x 16 geometry; the four-image geometry's
+    // larger patch buffers leave room for two.  TIA_WINO_STAGES=2 forces two (developer switch, A/B measurements).
+    static const bool two = getenv("TIA_WINO_STAGES") != nullptr && atoi(getenv("TIA_WINO_STAGES")) == 2;
+    static tia::DeviceOnce attr16, attr16s2, attr8;  // the dynamic-LDS attribute is per device
+#define TIA_WINO_LAUNCH(GEO_, NS_, ONCE_)                                                                                            \
+    do {                                                                                                                             \
+        constexpr int lds = wino_lds_bytes(GEO_::G * GEO_::IMG, NS_);                                                                \
+        static_assert(lds <= 160 * 1024, "LDS");                                                                                     \
+        if (!ONCE_.ensure([] {                                                                                                       \
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<GEO_, NS_>),                            \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;                           \
+            }))                                                                                                                      \
+            return TIA_ELAUNCH;                                                                                                      \
+        hipLaunchKernelGGL((conv3x3_wino_kernel<GEO_, NS_>), grid, dim3(512), lds, stream, x, u_packed, bias, residual, y, d, relu,   \
+                           (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x));                                                      \
+    } while (0)
+    if (small)
+        TIA_WINO_LAUNCH(W8, 2, attr8);
+    else if (two)
+        TIA_WINO_LAUNCH(W16, 2, attr16s2);
+    else
+        TIA_WINO_LAUNCH(W16, 3, attr16);
+#undef TIA_WINO_LAUNCH
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
