@@ -17,7 +17,7 @@
 //   x 2 channel halves; a wave keeps 8 positions x (32 tiles x 32 channels) = 128 accumulator registers.  One workgroup per CU
 //   (two waves per SIMD, <= 256 registers each).
 // * the raw 18 x 18 (4 x 10 x 10) input patch of a 16-channel slice arrives by LDS-DMA exactly as in the direct kernel
-//   (pixel pitch 5 units, double-buffered); the input transform V = B^T d B is done IN REGISTERS on the way to the MFMA: per
+//   (pairs of pixels at a pitch of 9 units: conflict-free reads, see W16 / W8 below; double-buffered); the input transform V = B^T d B is done IN REGISTERS on the way to the MFMA: per
 //   step (one position row i, four positions j) a lane reads two patch rows x four columns of its tile (16 ds_read_b128),
 //   forms R_i = d[ra] +- d[rb] and V_ij = R[c] +- R[c'] (64 adds) and feeds 32 MFMAs -- no transformed tensor ever exists in
 //   memory (the non-fused form moves 4 x the input and 4 x the output through HBM and loses to the direct kernel).
@@ -36,6 +36,7 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 constexpr int OOB = (int)0x80000000;
 
 struct WinoDims {
@@ -45,20 +46,44 @@ struct WinoDims {
     int abl;         // timing builds only (TIA_WINO_ABL): 1 no weight DMA in the loop, 2 no patch DMA, 4 weight DMA out of range (zeros), 8 half of it
 };
 
+// Packed float32 add / subtract (two channels per instruction).  Inline assembly: the compiler splits a v2f32 subtraction into two
+// scalar v_sub_f32 (48 of the 56 vector instructions of a load phase), and it is the NUMBER of vector instructions issued beside the
+// SIMD partner's MFMA stream that stretches that phase.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
-// W16: one image, 16 x 16 output pixels = 8 x 8 tiles, patch 18 x 18, row pitch 96 units (2 * ROW = 0 mod 16: the 16 lanes of a
-// ds_read_b128 group fall on every even 16-byte bank group exactly twice -- a tile's pixels are two apart, so an inherent 2-way).
-// W8: FOUR images of at most 8 x 8 = 4 x (4 x 4) tiles, patch 10 x 10 each, row pitch 52 (= 4 mod 8: the same 2-way argument
-// across tile rows and images), image pitch 520.
+// LDS patch layout, in 16-byte units: a pixel is 4 units (16 float32 channels); pixels are stored in PAIRS of 9 units (two pixels +
+// one padding unit): pixel px of a row at (px >> 1) * 9 + (px & 1) * 4.  A Winograd tile's pixels are two apart, so with the direct
+// kernel's pitch of 5 units per pixel every lane of a ds_read_b128 lands on an even unit (the first version: an inherent 2-way bank
+// conflict on all 16 patch reads of a step, SQ_LDS_BANK_CONFLICT = 38 % of the LDS cycles); with 9 units per pair the tiles
+// tx = 0..3 of a row sit at units {0, 9, 2, 11} and tx = 4..7 at {4, 13, 6, 15} (mod 16), and the four translates of {0, 2, 9, 11}
+// by 0, 4, 8, 12 tile Z_16 exactly -- so the row / image pitches below make the 16 lanes of every service group of a ds_read_b128
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, the same + 32) hit 16 different 16-byte bank groups, for every row, column and
+// channel-half offset (those shift all lanes alike).
+//   W16: one image, 16 x 16 output pixels = 8 x 8 tiles, patch 18 x 18: 9 pairs = 81 units per row, ROW = 84 (2 ROW = 8 mod 16:
+//        tile rows ty = 0..3 of a group shift by {0, 8, 0, 8} -> translates {0, 12, 4, 8} and {4, 8, 0, 12})
+//   W8:  FOUR images of at most 8 x 8 = 4 x (4 x 4) tiles, patch 10 x 10 each: 5 pairs = 45 units per row, ROW = 50 (2 ROW = 4 mod
+//        16), image pitch 512 (= 0 mod 16): translates {0, 12, 4, 8} and {4, 8, 0, 12} over (image, tile row)
 struct W16 {
-    static constexpr int G = 1, TH = 16, TW = 16, PH = 18, PWD = 18, ROW = 96, IMG = 18 * 96;
+    static constexpr int G = 1, TH = 16, TW = 16, PH = 18, PWD = 18, ROW = 84, IMG = 18 * 84;
 };
 struct W8 {
-    static constexpr int G = 4, TH = 8, TW = 8, PH = 10, PWD = 10, ROW = 52, IMG = 10 * 52;
+    static constexpr int G = 4, TH = 8, TW = 8, PH = 10, PWD = 10, ROW = 50, IMG = 512;
 };
+// unit offset of pixel column px inside a row
+__device__ __forceinline__ constexpr int px_unit(int px) { return (px >> 1) * 9 + (px & 1) * 4; }
 
 // s_waitcnt vmcnt(VM) lgkmcnt(0) (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] = 7 (no wait) | lgkmcnt[11:8] | vmcnt[5:4] << 14)
 template <int VM>
@@ -74,8 +99,10 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 #endif
 #if TIA_WINO_TIMING
 #define WSTAMP(var) { const long long now_ = clock64(); var += now_ - tl_; tl_ = now_; }
+#define WSTAMP_ROLE(mfma_if_pg0) { const long long now_ = clock64(); if ((pg == 0) == (mfma_if_pg0)) tm_comp += now_ - tl_; else tm_load += now_ - tl_; tl_ = now_; }
 #else
 #define WSTAMP(var)
+#define WSTAMP_ROLE(x)
 #endif
 
 template <typename GEO, int NSTAGE>
@@ -83,10 +110,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
                                                               const float* __restrict__ bias, const float* __restrict__ res,
                                                               float* __restrict__ y, WinoDims d, int relu, int m_tiles, int tiles_x,
                                                               int tiles_per_image) {
-    constexpr int NT = 512, PIX = 5, ROW = GEO::ROW, BN = 64;
+    constexpr int NT = 512, ROW = GEO::ROW, BN = 64;
     constexpr int BLOCK_PX = GEO::G * GEO::TH * GEO::TW;          // 256 output pixels = 64 tiles
-    constexpr int A_UNITS = (GEO::G * GEO::IMG + 63) / 64 * 64;   // patch units (16 bytes), whole waves: 1728 | 2112
-    constexpr int NA = (A_UNITS + NT - 1) / NT;                   // DMA pieces per patch: 4 | 5 (the last one partial)
+    constexpr int A_UNITS = (GEO::G * GEO::IMG + 63) / 64 * 64;   // patch units (16 bytes), whole waves: 1536 | 2048
+    constexpr int NA = (A_UNITS + NT - 1) / NT;                   // DMA pieces per patch: 3 | 4
     constexpr int A_BYTES = A_UNITS * 16;
     constexpr int W_STAGE = 8 * 4096;                             // 8 positions x [16 channels][64 columns] float32
     constexpr int DUMP = 2 * A_BYTES + NSTAGE * W_STAGE;          // 1 KB the idle waves of the last patch piece write their zeros to
@@ -94,10 +121,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     constexpr int LDS_BYTES = DUMP + 1024 > EPI_BYTES ? DUMP + 1024 : EPI_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
     static_assert(NA >= 2 && NA <= 6, "patch pieces are spread over the two steps of a slice");
-    static_assert(NSTAGE == 2 || NSTAGE == 3, "weight ring");
+    static_assert(NSTAGE == 2, "weight ring: two stages (a third one was measured and lost, profiles/r05d_perf_wino256_3stage.txt)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #if TIA_WINO_TIMING
-    long long tm_pro = 0, tm_comp = 0, tm_wait = 0, tm_epi = 0, tl_ = clock64();
+    long long tm_pro = 0, tm_comp = 0, tm_load = 0, tm_wait = 0, tm_epi = 0, tl_ = clock64();
     const long long t0c_ = tl_, t0w_ = wall_clock64();
 #endif
 
@@ -110,22 +137,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     const int ty0 = (trem / tiles_x) * GEO::TH;
     const int tx0 = (trem - (trem / tiles_x) * tiles_x) * GEO::TW;
     const int cb = blockIdx.y, n0 = cb * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // (kept in a vector register: with a scalar wave index the role
+    // branches below become scalar branches and the register allocator spills 106 registers over them; 238 without)
     const int pg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;  // position group, tile half, channel half
     const int hi = lane >> 5;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)d.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(u), 0, (int)d.u_bytes, 0x00020000);
 
-    // patch staging (as the direct kernel): unit U = NT r + tid -> image U / IMG, row (U % IMG) / ROW, pixel (.. % ROW) / 5, unit-of-slice
-    // .. % 5 (4 = padding); outside the image / patch: an out-of-range offset (the DMA writes zeros)
+    // patch staging: unit U = NT r + tid -> image U / IMG, row (U % IMG) / ROW, pixel pair (.. % ROW) / 9, pixel and unit-of-slice from
+    // the rest (layout above); outside the image / patch, padding units: an out-of-range offset (the DMA writes zeros)
     int cen[NA];
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
         const int un = NT * r + tid;
         const int g = un / GEO::IMG, ug = un - g * GEO::IMG;
         const int py = ug / ROW, rem = ug - py * ROW;
-        const int px = rem / PIX, chunk = rem - px * PIX;
+        const int pair = rem / 9, r9 = rem - pair * 9;
+        const int px = 2 * pair + (r9 >> 2), chunk = r9 == 8 ? 4 : (r9 & 3);  // (unit 8 of a pair: padding)
         const int iy = ty0 - d.pad_y + py, ix = tx0 - d.pad_x + px;
         const bool inside = g < GEO::G && img + g < d.n && py < GEO::PH && px < GEO::PWD && chunk < 4 && (unsigned)iy < (unsigned)d.h &&
                             (unsigned)ix < (unsigned)d.w;
@@ -176,103 +205,101 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     const int t = 32 * wm + (lane & 31);
     int fa;
     if constexpr (GEO::G == 1) {
-        fa = 2 * (t >> 3) * ROW + 2 * (t & 7) * PIX + 2 * hi;
+        fa = 2 * (t >> 3) * ROW + (t & 7) * 9 + 2 * hi;
     } else {
-        fa = (t >> 4) * GEO::IMG + 2 * ((t >> 2) & 3) * ROW + 2 * (t & 3) * PIX + 2 * hi;
-    }
-    // row transform of position row i: R = d[ra] + sg * d[rb]   (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
-    //   i = 0: d0 - d2    1: d1 + d2    2: d2 - d1    3: d1 - d3
-    int ra_u[2], rb_u[2];
-    float sg[2];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int i = 2 * pg + half;
-        const int ra = i == 0 ? 0 : (i == 2 ? 2 : 1), rb = i == 0 ? 2 : (i == 1 ? 2 : (i == 2 ? 1 : 3));
-        ra_u[half] = __builtin_amdgcn_readfirstlane(ra * ROW);
-        rb_u[half] = __builtin_amdgcn_readfirstlane(rb * ROW);
-        sg[half] = i == 1 ? 1.0f : -1.0f;
+        fa = (t >> 4) * GEO::IMG + 2 * ((t >> 2) & 3) * ROW + (t & 3) * 9 + 2 * hi;
     }
     // weights of the lane: block (pg, j) of the stage, units [hi][kq][column]: two 16-byte reads per position
     const int fb = pg * 4 * 256 + hi * 128 + wn * 32 + (lane & 31);
 
-    // One step = position row i of the group, positions j = 0..3: 16 patch reads (two rows x four columns x two 16-byte units),
-    // 8 weight reads, 64 adds, 32 MFMAs.  Software-pipelined so that no LDS round trip is exposed inside the step (the first
-    // version read each position's operands right in front of its MFMAs: eight exposed waits per step, matrix pipe 50-65 % busy):
-    //   request columns 0 and 2 (what V_0 = R0 - R2 needs) + weights of j = 0, then column 1 + weights of j = 1;
-    //   behind the eight MFMAs of j = 0: request column 3 and the weights of j = 2, 3; form R1, V1;
-    //   j = 1 .. 3 then run out of registers.  sched_group_barrier pins that order.
-    auto compute = [&](int buf, int stage, auto half_c) {
-        constexpr int HALF = decltype(half_c)::value;
+    // One step of a wave = position row i of its group, positions j = 0..3, in two PHASES:
+    //   load phase:  16 patch reads (two rows x four columns x two 16-byte units) + 8 weight reads, the input transform
+    //                (R = d[ra] +- d[rb] per column, V_j = R0 - R2 | R1 + R2 | R2 - R1 | R1 - R3: 64 adds) -> V and the weights of
+    //                the step sit in 64 registers;
+    //   MFMA phase:  32 MFMAs out of those registers, nothing else.
+    // The two position groups run HALF A STEP APART (ping-pong): while the waves of one group are in their MFMA phase, their
+    // SIMD partners (wave w and w + 4 share a SIMD) of the other group are in their load phase, with one barrier per half-step.
+    // Measured before this (profiles/r05d_wino_phases*.txt, r05e_wino_ablation.txt): with both groups in the same phase the
+    // matrix pipes idled while all eight waves queued on the LDS at the start of every step -- a step took 6,100 cycles for
+    // 4,096 of matrix work, 1,700 of them at the barrier, with or without any DMA in the loop.
+    f32x2 vreg[4][4];  // V_j, eight channels as four pairs (the arithmetic below is packed: v_pk_add_f32, two channels per instruction)
+    u32x4 wq[4][2];
+    // `row_c` = the position row i of this step (compile time: the callers branch on the group), so the row offsets are immediates and
+    // the signs are instruction modifiers: R = d[ra] +- d[rb]: i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    auto load_phase = [&](int buf, int stage, auto row_c) {
+        constexpr int I = decltype(row_c)::value;
+        constexpr int RA = (I == 0 ? 0 : (I == 2 ? 2 : 1)) * ROW, RB = (I == 0 ? 2 : (I == 1 ? 2 : (I == 2 ? 1 : 3))) * ROW;
+        constexpr bool PLUS = I == 1;
+        // this wave's few vector and LDS instructions go first: its SIMD partner only has to place one MFMA per 64 cycles
+        __builtin_amdgcn_s_setprio(3);
         const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES) + fa;
         const u32x4* sb = reinterpret_cast<const u32x4*>(wst0 + stage * W_STAGE) + fb;
-        const int ra = ra_u[HALF], rb = rb_u[HALF];
-        const float sgn = sg[HALF];
-        u32x4 pa[4][2], pb[4][2], wq[4][2];
-        auto load_col = [&](int c) {
-            pa[c][0] = sa[ra + c * PIX], pa[c][1] = sa[ra + c * PIX + 1];
-            pb[c][0] = sa[rb + c * PIX], pb[c][1] = sa[rb + c * PIX + 1];
-        };
-        auto load_w = [&](int j) { wq[j][0] = sb[j * 256], wq[j][1] = sb[j * 256 + 64]; };
-        float R[4][8];
-        auto row_tf = [&](int c) {
+#if TIA_WINO_TIMING
+        if (d.abl & 16) {  // no patch reads, no transform: what is left is the weight reads
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                R[c][k] = __builtin_fmaf(__uint_as_float(pb[c][k >> 2][k & 3]), sgn, __uint_as_float(pa[c][k >> 2][k & 3]));
-        };
-        auto mma8 = [&](int j, const float (&v)[8]) {
+            for (int j = 0; j < 4; ++j) {
+                wq[j][0] = sb[j * 256], wq[j][1] = sb[j * 256 + 64];
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                acc[HALF][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], __uint_as_float(wq[j][k >> 2][k & 3]), acc[HALF][j], 0, 0, 0);
+                for (int k = 0; k < 4; ++k) vreg[j][k] = f32x2{(float)(lane + j + k), (float)(lane - j - k)};
+            }
+            __builtin_amdgcn_s_setprio(0);
+            return;
+        }
+#endif
+        // two batches (columns 0, 2 + the weights; then columns 1, 3): the second round trip hides behind the partner's MFMA phase, and
+        // 32 registers fewer are live (all four columns at once spilled)
+        f32x2 R[4][4];
+        auto pair_of = [](const u32x4& q, int k) { return f32x2{__uint_as_float(q[2 * k]), __uint_as_float(q[2 * k + 1])}; };
+        auto column = [&](int c) {
+            const u32x4 a0 = sa[RA + px_unit(c)], a1 = sa[RA + px_unit(c) + 1], b0 = sa[RB + px_unit(c)], b1 = sa[RB + px_unit(c) + 1];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                R[c][k] = PLUS ? pk_add(pair_of(a0, k), pair_of(b0, k)) : pk_sub(pair_of(a0, k), pair_of(b0, k));
+                R[c][2 + k] = PLUS ? pk_add(pair_of(a1, k), pair_of(b1, k)) : pk_sub(pair_of(a1, k), pair_of(b1, k));
+            }
         };
+        column(0), column(2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[j][0] = sb[j * 256], wq[j][1] = sb[j * 256 + 64];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vreg[0][k] = pk_sub(R[0][k], R[2][k]);
         __builtin_amdgcn_sched_barrier(0);
-        load_col(0), load_col(2), load_w(0);   // 10 reads
-        load_col(1), load_w(1);                // 6 reads
-        row_tf(0), row_tf(2);
-        float v0[8], v1[8], v2[8], v3[8];
+        column(1), column(3);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v0[k] = R[0][k] - R[2][k];
-        mma8(0, v0);
-        load_col(3), load_w(2), load_w(3);     // 8 reads, behind the MFMAs of j = 0
-        row_tf(1);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v1[k] = R[1][k] + R[2][k];
-        mma8(1, v1);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v2[k] = R[2][k] - R[1][k];
-        mma8(2, v2);
-        row_tf(3);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v3[k] = R[1][k] - R[3][k];
-        mma8(3, v3);
-        // order for the scheduler (masks: 0x100 DS read, 0x002 VALU, 0x008 MFMA)
-        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);  // columns 0, 2, 1 + weights 0, 1
-        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);  // R0, R2, V0
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {                        // j = 0: each MFMA followed by one of the 8 late reads and two of the
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 16 VALU operations of R1, V1
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        for (int k = 0; k < 4; ++k) {
+            vreg[1][k] = pk_add(R[1][k], R[2][k]);
+            vreg[2][k] = pk_sub(R[2][k], R[1][k]);
+            vreg[3][k] = pk_sub(R[1][k], R[3][k]);
         }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto mfma_phase = [&](auto half_c) {
+        constexpr int HALF = decltype(half_c)::value;
+#if TIA_WINO_TIMING
+        if (d.abl & 64) return;  // no MFMAs: the load phases alone
+#endif
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {                        // j = 1 (+ V2)
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-        }
+        for (int k = 0; k < 8; ++k)  // k outer: consecutive MFMAs go to different accumulators
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {                        // j = 2 (+ R3, V3)
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // j = 3
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 4; ++j)
+                acc[HALF][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[j][k >> 1][k & 1], __uint_as_float(wq[j][k >> 2][k & 3]), acc[HALF][j], 0, 0, 0);
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
+    using I0 = H0;
+    using I1 = H1;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
 #if TIA_WINO_TIMING
     long long tm_vm = 0;
 #endif
-    auto step_end = [&] {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // end of a half-step: every LDS read of the phase has returned (the stages / buffers it read may be refilled after the barrier)
+    // and -- `dma` -- every DMA this wave issued has landed (what the next half-steps read)
+    auto half_end = [&](bool dma) {
+        if (dma)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if TIA_WINO_TIMING
         { const long long now_ = clock64(); tm_vm += now_ - tl_; }
 #endif
@@ -280,82 +307,53 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         asm volatile("" ::: "memory");
     };
 
-    if constexpr (NSTAGE == 2) {
-        // two weight stages: the weights of step s + 1 and the next slice's patch are requested at the start of step s and must have
-        // landed by its end (vmcnt(0)): one step of look-ahead
+    // prologue: patch of slice 0, weights of steps 0 and 1; group 0's first load phase
 #pragma unroll
-        for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
-        dma_w(0, 0);
-        step_end();
-        WSTAMP(tm_pro)
-        constexpr int NA0 = (NA + 1) / 2;  // patch pieces issued in the first step of a slice; the rest in the second
-        for (int cs = 0; cs < n_cs; ++cs) {
-            const int buf = cs & 1;
-            const bool more = cs + 1 < n_cs;
-            // step 2 cs (rows i = 0 / 2): weights of step 2 cs + 1 -> stage 1, the first pieces of the next slice's patch
-            dma_w(1, 2 * cs + 1);
-            if (more) {
-#pragma unroll
-                for (int r = 0; r < NA0; ++r) dma_a(buf ^ 1, r, cs + 1);
-            }
-            compute(buf, 0, H0{});
-            WSTAMP(tm_comp)
-            step_end();
-            WSTAMP(tm_wait)
-            // step 2 cs + 1 (rows i = 1 / 3): weights of step 2 cs + 2 -> stage 0, the remaining pieces
-            if (more) {
-                dma_w(0, 2 * cs + 2);
-#pragma unroll
-                for (int r = NA0; r < NA; ++r) dma_a(buf ^ 1, r, cs + 1);
-            }
-            compute(buf, 1, H1{});
-            WSTAMP(tm_comp)
-            step_end();
-            WSTAMP(tm_wait)
-        }
-    } else {
-        // three weight stages, TWO steps of look-ahead: at step s the weights of step s + 2 go out; the next slice's whole patch goes
-        // out at the slice's first step (its buffer was released by the barrier before).  The counted waits let exactly the requests
-        // of the current step stay in flight: after an even step (4 weight rounds + NA patch pieces issued) everything older -- the
-        // weights of step s + 1 -- has landed; after an odd step (4 issued) the weights of step s + 2 and the patch have.
-#pragma unroll
-        for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
-        dma_w(0, 0);
-        dma_w(1, 1);
-        step_end();
-        WSTAMP(tm_pro)
-        int st = 0;  // stage of the current step
-        for (int cs = 0; cs + 1 < n_cs; ++cs) {
-            const int buf = cs & 1;
-            const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
-            dma_w(st2, 2 * cs + 2);
+    for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
+    dma_w(0, 0);
+    dma_w(1, 1);
+    half_end(true);
+    if (pg == 0) load_phase(0, 0, I0{});
+    half_end(false);
+    WSTAMP(tm_pro)
+    // slice c = steps 2 c (rows i = 0 / 2, accumulators [0]) and 2 c + 1 (rows 1 / 3, accumulators [1]) = four half-steps:
+    //   4c    group 0: MFMA(2c)           group 1: load(2c)            | all DMAs landed, barrier
+    //   4c+1  issue weights of step 2c+2 -> stage 0 and the patch of slice c+1;
+    //         group 0: load(2c+1)         group 1: MFMA(2c)            | barrier
+    //   4c+2  group 0: MFMA(2c+1)         group 1: load(2c+1)          | all DMAs landed, barrier
+    //   4c+3  issue weights of step 2c+3 -> stage 1;
+    //         group 0: load(2c+2)         group 1: MFMA(2c+1)          | barrier
+    // A weight stage is refilled right after group 1's load phase of the step it held (the barrier in between) and has two
+    // half-steps to land; the patch buffer of slice c + 1 was last read by group 1 in half-step 4c - 2.
+    for (int cs = 0; cs < n_cs; ++cs) {
+        const int buf = cs & 1;
+        const bool more = cs + 1 < n_cs;
+        if (pg == 0) mfma_phase(H0{}); else load_phase(buf, 0, I2{});
+        WSTAMP_ROLE(true)
+        half_end(true);
+        WSTAMP(tm_wait)
+        if (more) {
+            dma_w(0, 2 * cs + 2);
 #pragma unroll
             for (int r = 0; r < NA; ++r) dma_a(buf ^ 1, r, cs + 1);
-            compute(buf, st, H0{});
-            WSTAMP(tm_comp)
-            wait_vm_lgkm0<4 + NA>();
-            __builtin_amdgcn_s_barrier();
-            WSTAMP(tm_wait)
-            dma_w(st, 2 * cs + 3);  // (the stage this step's predecessor just finished with)
-            compute(buf, st1, H1{});
-            WSTAMP(tm_comp)
-            wait_vm_lgkm0<4>();
-            __builtin_amdgcn_s_barrier();
-            WSTAMP(tm_wait)
-            st = st2;
         }
-        {
-            const int buf = (n_cs - 1) & 1;
-            const int st1 = st == 2 ? 0 : st + 1;
-            compute(buf, st, H0{});
-            WSTAMP(tm_comp)
-            step_end();
-            WSTAMP(tm_wait)
-            compute(buf, st1, H1{});
-            WSTAMP(tm_comp)
-            step_end();
-            WSTAMP(tm_wait)
+        if (pg == 0) load_phase(buf, 1, I1{}); else mfma_phase(H0{});
+        WSTAMP_ROLE(false)
+        half_end(false);
+        WSTAMP(tm_wait)
+        if (pg == 0) mfma_phase(H1{}); else load_phase(buf, 1, I3{});
+        WSTAMP_ROLE(true)
+        half_end(true);
+        WSTAMP(tm_wait)
+        if (more) dma_w(1, 2 * cs + 3);
+        if (pg == 0) {
+            if (more) load_phase(buf ^ 1, 0, I0{});
+        } else {
+            mfma_phase(H1{});
         }
+        WSTAMP_ROLE(false)
+        half_end(false);
+        WSTAMP(tm_wait)
     }
 
     // ---- output transform (A^T = [1 1 1 0; 0 1 -1 -1]) ------------------------------------------------------------------------
@@ -448,9 +446,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
 #if TIA_WINO_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WSTAMP(tm_epi)
-    if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 64 || blockIdx.x == 1001))
-        printf("wino wg %d (cin %d, stages %d, abl %d): prologue %lld  compute %lld  step waits %lld (of which vmcnt %lld)  epilogue %lld  (steps %d) | shader clock %.0f MHz\n",
-               (int)blockIdx.x, d.cin, NSTAGE, d.abl, tm_pro, tm_comp, tm_wait, tm_vm, tm_epi, 2 * n_cs,
+    if ((threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.y == 0 && blockIdx.x == 64)
+        printf("wino wg %d wave %d (cin %d, abl %d): prologue %lld  MFMA phases %lld  load phases %lld  waits %lld (of which before the barrier %lld)  epilogue %lld  (steps %d) | shader clock %.0f MHz\n",
+               (int)blockIdx.x, (int)(threadIdx.x >> 6), d.cin, d.abl, tm_pro, tm_comp, tm_load, tm_wait, tm_vm, tm_epi, 2 * n_cs,
                100.0 * (double)(clock64() - t0c_) / (double)(wall_clock64() - t0w_));
 #endif
 }
@@ -511,10 +509,7 @@ int conv3x3_wino_launch(const float* x, const float* u_packed, const float* bias
                      (unsigned)(nb * h * w * cin * 4), (unsigned)(16 * cin * cout * 4), (int)((cin / 16) * (cout / 64) * 4096),
                      getenv("TIA_WINO_ABL") ? atoi(getenv("TIA_WINO_ABL")) : 0};
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / 64));
-    // weight ring: three stages (two steps of look-ahead) where the LDS holds them -- the 16 x 16 geometry; the four-image geometry's
-    // larger patch buffers leave room for two.  TIA_WINO_STAGES=2 forces two (developer switch, A/B measurements).
-    static const bool two = getenv("TIA_WINO_STAGES") != nullptr && atoi(getenv("TIA_WINO_STAGES")) == 2;
-    static tia::DeviceOnce attr16, attr16s2, attr8;  // the dynamic-LDS attribute is per device
+    static tia::DeviceOnce attr16, attr8;  // the dynamic-LDS attribute is per device
 #define TIA_WINO_LAUNCH(GEO_, NS_, ONCE_)                                                                                            \
     do {                                                                                                                             \
         constexpr int lds = wino_lds_bytes(GEO_::G * GEO_::IMG, NS_);                                                                \
@@ -529,10 +524,8 @@ int conv3x3_wino_launch(const float* x, const float* u_packed, const float* bias
     } while (0)
     if (small)
         TIA_WINO_LAUNCH(W8, 2, attr8);
-    else if (two)
-        TIA_WINO_LAUNCH(W16, 2, attr16s2);
     else
-        TIA_WINO_LAUNCH(W16, 3, attr16);
+        TIA_WINO_LAUNCH(W16, 2, attr16);
 #undef TIA_WINO_LAUNCH
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
