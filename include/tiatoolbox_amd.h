@@ -489,7 +489,7 @@ int tia_conv2d_post_nhwc_f32(const float* d_x, const float* d_w_packed, const fl
  * NOT bit-identical to it: float32 Winograd rounds differently from a direct float32 convolution (<= ~1e-5 relative, asserted in
  * tests/test_engine.py) -- which is why nothing dispatches to it implicitly.  cin % 16 == 0, cout % 64 == 0.
  *   tia_conv_pack_weights_wino_f32: OIHW [cout][cin][3][3] -> U = G g G^T, 16 * cin * cout floats in the kernel's stage layout
- *   ([pos 16][cin/16][cout/64][hi 2][kq 2][64 cout][4 channels], channel = 16 cs + 8 hi + 4 kq + c4). */
+ *   ([pos 16][cin/16][h8 2][cout/64][hi 2][64 cout][4 channels], channel = 16 cs + 8 h8 + 4 hi + c4). */
 int tia_conv_pack_weights_wino_f32(const float* d_w_oihw, int64_t cout, int64_t cin, float* d_packed, void* stream);
 int tia_conv3x3_wino_nhwc_f32(const float* d_x, const float* d_u_packed, const float* d_bias, const float* d_residual, float* d_y,
                               int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t pad_top, int64_t pad_left,

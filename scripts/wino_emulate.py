@@ -17,11 +17,11 @@ def pack(w):  # wino_pack_kernel
     for o in range(cout):
         for c in range(cin):
             U = G @ w[o, c].astype(np.float64) @ G.T
-            cs, hi, kq, c4, cb, col = c >> 4, (c >> 3) & 1, (c >> 2) & 1, c & 3, o >> 6, o & 63
+            cs, h8, hi, c4, cb, col = c >> 4, (c >> 3) & 1, (c >> 2) & 1, c & 3, o >> 6, o & 63
             for i in range(4):
                 for j in range(4):
-                    block = ((i * 4 + j) * n_cs + cs) * n_cb + cb
-                    out[block * 1024 + ((hi * 2 + kq) * 64 + col) * 4 + c4] = np.float32(U[i, j])
+                    block = (((i * 4 + j) * n_cs + cs) * 2 + h8) * n_cb + cb
+                    out[block * 512 + (hi * 64 + col) * 4 + c4] = np.float32(U[i, j])
     return out
 
 
@@ -41,7 +41,7 @@ def run_block(x, upk, geo, mt_id, cb, pad, ho, wo, tiles_x, tiles_per_image):
     trem = mt_id - img * tiles_per_image if G == 1 else 0
     ty0, tx0 = (trem // tiles_x) * TH, (trem % tiles_x) * TW
     xf = x.reshape(-1)
-    acc = np.zeros((8, 2, 4, 32, 32), np.float32)  # [wave][half][j][row][col]
+    acc = np.zeros((8, 4, 2, 32, 32), np.float32)  # [wave][j][channel tile][row][col]
     for cs in range(n_cs):
         # ---- patch image
         abuf = np.zeros((A_UNITS, 4), np.float32)
@@ -60,64 +60,74 @@ def run_block(x, upk, geo, mt_id, cb, pad, ho, wo, tiles_x, tiles_per_image):
                 if inside:
                     off = ((((img + g) * h + iy) * w + ix) * cin * 4 + 16 * chunk + cs * 64) // 4
                     abuf[un] = xf[off:off + 4]
-        for half in range(2):
+        for h8 in range(2):
+            s_step = 2 * cs + h8
             # ---- weight stage
             wst = np.zeros((2048, 4), np.float32)
             for q in range(4):
-                i, j0 = 2 * (q >> 1) + half, 2 * (q & 1)
-                soff = (i * 4 + j0) * pos_stride + (cs * n_cb + cb) * 4096
+                soff = 4 * q * pos_stride + (s_step * n_cb + cb) * 2048
                 for wave in range(8):
                     for lane in range(64):
-                        voff = (wave & 3) * 1024 + lane * 16 + (wave >> 2) * pos_stride
+                        voff = (wave & 1) * 1024 + lane * 16 + (wave >> 1) * pos_stride
                         src = (soff + voff) // 4
                         wst[q * 512 + wave * 64 + lane] = upk[src:src + 4]
             # ---- compute
             for wave in range(8):
-                pg, wm, wn = wave >> 2, (wave >> 1) & 1, wave & 1
-                i = 2 * pg + half
+                i, wm = wave >> 1, wave & 1
                 ra = 0 if i == 0 else (2 if i == 2 else 1)
                 rb = 2 if i == 0 else (2 if i == 1 else (1 if i == 2 else 3))
                 sg = 1.0 if i == 1 else -1.0
-                V = np.zeros((4, 64, 8), np.float32)
-                Wv = np.zeros((4, 64, 8), np.float32)
+                V = np.zeros((4, 64, 4), np.float32)
+                Wv = np.zeros((4, 2, 64, 4), np.float32)
                 for lane in range(64):
                     hi = lane >> 5
                     t = 32 * wm + (lane & 31)
                     if G == 1:
-                        fa = 2 * (t >> 3) * ROW + (t & 7) * 9 + 2 * hi
+                        fa = 2 * (t >> 3) * ROW + (t & 7) * 9 + hi
                     else:
-                        fa = (t >> 4) * IMG + 2 * ((t >> 2) & 3) * ROW + (t & 3) * 9 + 2 * hi
-                    fb = pg * 4 * 256 + hi * 128 + wn * 32 + (lane & 31)
-                    R = np.zeros((4, 8), np.float32)
+                        fa = (t >> 4) * IMG + 2 * ((t >> 2) & 3) * ROW + (t & 3) * 9 + hi
+                    fa += 2 * h8
+                    fb = i * 4 * 128 + hi * 64 + (lane & 31)
+                    R = np.zeros((4, 4), np.float32)
                     for c in range(4):
-                        a = np.concatenate([abuf[fa + ra * ROW + px_unit(c)], abuf[fa + ra * ROW + px_unit(c) + 1]])
-                        b = np.concatenate([abuf[fa + rb * ROW + px_unit(c)], abuf[fa + rb * ROW + px_unit(c) + 1]])
-                        R[c] = (b * np.float32(sg) + a).astype(np.float32)
+                        R[c] = (abuf[fa + rb * ROW + px_unit(c)] * np.float32(sg) + abuf[fa + ra * ROW + px_unit(c)]).astype(np.float32)
                     V[0, lane] = R[0] - R[2]
                     V[1, lane] = R[1] + R[2]
                     V[2, lane] = R[2] - R[1]
                     V[3, lane] = R[1] - R[3]
                     for j in range(4):
-                        Wv[j, lane] = np.concatenate([wst[fb + j * 256], wst[fb + j * 256 + 64]])
+                        for ct in range(2):
+                            Wv[j, ct, lane] = wst[fb + j * 128 + ct * 32]
                 for j in range(4):
-                    for k in range(8):
-                        A = np.stack([V[j, :32, k], V[j, 32:, k]], axis=1)      # [row][kidx]
-                        B = np.stack([Wv[j, :32, k], Wv[j, 32:, k]], axis=0)    # [kidx][col]
-                        acc[wave, half, j] += (A @ B).astype(np.float32)
-    # ---- output transform + tile
-    tile = np.zeros((G * TH * TW, 64), np.float32)
-    for wave in list(range(4)) + list(range(4, 8)):
-        pg, wm, wn = wave >> 2, (wave >> 1) & 1, wave & 1
-        a = acc[wave]
-        z00, z01 = a[0, 0] + a[0, 1] + a[0, 2], a[0, 1] - a[0, 2] - a[0, 3]
-        z10, z11 = a[1, 0] + a[1, 1] + a[1, 2], a[1, 1] - a[1, 2] - a[1, 3]
-        yp = [[z00 + z10, z01 + z11], [z10, z11]] if pg == 0 else [[z00, z01], [-z00 - z10, -z01 - z11]]
+                    for ct in range(2):
+                        for k in range(4):
+                            A = np.stack([V[j, :32, k], V[j, 32:, k]], axis=1)          # [row][kidx]
+                            B = np.stack([Wv[j, ct, :32, k], Wv[j, ct, 32:, k]], axis=0)  # [kidx][col]
+                            acc[wave, j, ct] += (A @ B).astype(np.float32)
+    # ---- output transform + tiles (two rounds)
+    tiles = np.zeros((2, G * TH * TW, 64), np.float32)
+
+    def to_tile(wave, a, add, neg):
+        i, wm = wave >> 1, wave & 1
+        m = acc[wave]
+        z = [[m[0, ct] + m[1, ct] + m[2, ct] for ct in range(2)], [m[1, ct] - m[2, ct] - m[3, ct] for ct in range(2)]]
         for row in range(32):
             tt = 32 * wm + row
             m00 = 2 * (tt >> 3) * TW + 2 * (tt & 7) if G == 1 else (tt >> 4) * TH * TW + 2 * ((tt >> 2) & 3) * TW + 2 * (tt & 3)
-            for aa in range(2):
-                for bb in range(2):
-                    tile[m00 + aa * TW + bb, wn * 32:wn * 32 + 32] += yp[aa][bb][row]
+            for bb in range(2):
+                for ct in range(2):
+                    v = -z[bb][ct][row] if neg else z[bb][ct][row]
+                    dst = tiles[i >> 1, m00 + a * TW + bb, ct * 32:ct * 32 + 32]
+                    dst[:] = dst + v if add else v
+
+    for wave in range(8):
+        to_tile(wave, (wave >> 1) & 1, False, (wave >> 1) == 3)
+    for wave in range(8):
+        if wave >> 1 == 1:
+            to_tile(wave, 0, True, False)
+        if wave >> 1 == 2:
+            to_tile(wave, 1, True, True)
+    tile = tiles[0] + tiles[1]
     out = {}
     for row in range(G * TH * TW):
         g, rg = divmod(row, TH * TW)

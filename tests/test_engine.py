@@ -655,10 +655,10 @@ def test_winograd_conv_matches_torch_cpu_fp32():
         res = torch.randn(ref_lin.shape, generator=g)
         dev_conv = conv.cuda()
         up = pack_conv_weights_wino(dev_conv)
-        assert up.shape == (16, cin // 16, cout // 64, 2, 2, 64, 4)
+        assert up.shape == (16, cin // 16, 2, cout // 64, 2, 64, 4)
         # the packed weights ARE G g G^T (float64 transform, rounded once): position (0, 0) is the tap (0, 0), (3, 3) the tap (2, 2)
         w = conv.weight.detach().cpu()
-        u = up.cpu().permute(0, 2, 5, 1, 3, 4, 6).reshape(16, cout, cin)  # [pos][cout][cin]
+        u = up.cpu().permute(0, 3, 5, 1, 2, 4, 6).reshape(16, cout, cin)  # [pos][cb, col][cs, h8, hi, c4] = [pos][cout][cin]
         assert torch.equal(u[0], w[:, :, 0, 0]) and torch.equal(u[15], w[:, :, 2, 2])
         gm = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
         assert torch.allclose(u.reshape(4, 4, cout, cin).permute(2, 3, 0, 1), (gm @ w.double() @ gm.T).float(), rtol=0, atol=1e-7)

@@ -9,22 +9,27 @@
 //   Y = A^T [ (G g G^T) . (B^T d B) ] A     per 2 x 2 output tile, 4 x 4 input tile d, 3 x 3 filter g   (Lavin & Gray)
 //
 // * weights: U = G g G^T computed ONCE at pack time in float64, rounded to float32 (tia_conv_pack_weights_wino_f32), stored in the
-//   exact LDS image of a weight stage: [pos 16][cin/16][cout/64] blocks of 4 KB = [hi 2][kq 2][64 cout][4 channels]
-//   (channel = 16 cs + 8 hi + 4 kq + c4): a stage is a plain contiguous LDS-DMA copy, a lane's 8 k-values of a position are two
-//   conflict-free ds_read_b128.
+//   exact LDS image of a weight stage: [pos 16][cin/16][h8 2][cout/64] blocks of 2 KB = [hi 2][64 cout][4 channels]
+//   (channel = 16 cs + 8 h8 + 4 hi + c4): a stage is a plain contiguous LDS-DMA copy, a lane's 4 k-values of a (position, channel
+//   tile) are ONE conflict-free ds_read_b128.
 // * a 512-thread workgroup owns 64 tiles (16 x 16 output pixels of one image, or four images of <= 8 x 8) x 64 output channels
-//   x all 16 Winograd positions; 8 waves = 2 position groups (rows i in {0, 1} / {2, 3} of the 4 x 4 position grid) x 2 tile halves
-//   x 2 channel halves; a wave keeps 8 positions x (32 tiles x 32 channels) = 128 accumulator registers.  One workgroup per CU
-//   (two waves per SIMD, <= 256 registers each).
-// * the raw 18 x 18 (4 x 10 x 10) input patch of a 16-channel slice arrives by LDS-DMA exactly as in the direct kernel
-//   (pairs of pixels at a pitch of 9 units: conflict-free reads, see W16 / W8 below; double-buffered); the input transform V = B^T d B is done IN REGISTERS on the way to the MFMA: per
-//   step (one position row i, four positions j) a lane reads two patch rows x four columns of its tile (16 ds_read_b128),
-//   forms R_i = d[ra] +- d[rb] and V_ij = R[c] +- R[c'] (64 adds) and feeds 32 MFMAs -- no transformed tensor ever exists in
-//   memory (the non-fused form moves 4 x the input and 4 x the output through HBM and loses to the direct kernel).
-// * per step a stage of 8 positions x 4 KB = 32 KB of weights (both position groups) streams in behind the MFMAs (two stages);
-//   one barrier + vmcnt(0) per step = per 32 MFMAs of a wave.
-// * epilogue: output transform A^T M A in registers per position group, the two groups' partial sums meet in the LDS tile
-//   [256 pixels][64 channels] (group 0 stores, group 1 adds), then + bias + residual, ReLU, 16-byte stores as in the direct kernel.
+//   x all 16 Winograd positions; 8 waves = 4 position ROWS i (positions (i, 0..3)) x 2 tile halves; a wave keeps 4 positions x
+//   (32 tiles x 64 channels) = 128 accumulator registers.  One workgroup per CU (two waves per SIMD, <= 256 registers each).
+// * the raw 18 x 18 (4 x 10 x 10) input patch of a 16-channel slice arrives by LDS-DMA (pairs of pixels at a pitch of 9 units:
+//   conflict-free reads, see W16 / W8 below; double-buffered); the input transform V = B^T d B is done IN REGISTERS on the way to the
+//   MFMA -- no transformed tensor ever exists in memory (the non-fused form moves 4 x the input and 4 x the output through HBM and
+//   loses to the direct kernel).
+// * a STEP covers 8 input channels (two per 16-channel slice): a lane reads two patch rows x four columns of its tile (8
+//   ds_read_b128: its 4 channels), forms R = d[ra] +- d[rb] and V_j = R[c] +- R[c'] (16 packed adds), reads 8 weight units and
+//   issues 32 MFMAs (4 positions x 2 channel tiles x 4 k-steps).  What bounds this kernel is the NUMBER of vector / LDS
+//   instructions per MFMA: on a SIMD they are not hidden behind float32 MFMAs but ADD to them (measured: the whole kernel without a
+//   single MFMA still takes 68 % of its time, profiles/r05j_wino_ablation.txt; ~13 cycles per instruction) -- 32 per 32 MFMAs in this
+//   form, 56 in the first one (a wave = two position rows x 32 channels: every V was computed by two waves), 20 in the direct kernel.
+// * the two halves of the position grid (rows {0, 1} / {2, 3}) run half a step apart (load phase | MFMA phase, one barrier per
+//   half-step); per step a stage of 16 positions x 2 KB = 32 KB of weights streams in (two stages).
+// * epilogue: column transform (over j) in registers, the row transform (over i = the four waves of a tile half) through two LDS
+//   tiles [256 pixels][64 channels] (rows {0, 1} -> tile A, {2, 3} -> tile B; one store round, one add round), then + bias + residual,
+//   ReLU, 16-byte stores as in the direct kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     constexpr int A_UNITS = (GEO::G * GEO::IMG + 63) / 64 * 64;   // patch units (16 bytes), whole waves: 1536 | 2048
     constexpr int NA = (A_UNITS + NT - 1) / NT;                   // DMA pieces per patch: 3 | 4
     constexpr int A_BYTES = A_UNITS * 16;
-    constexpr int W_STAGE = 8 * 4096;                             // 8 positions x [16 channels][64 columns] float32
+    constexpr int W_STAGE = 16 * 2048;                            // 16 positions x [8 channels][64 columns] float32
     constexpr int DUMP = 2 * A_BYTES + NSTAGE * W_STAGE;          // 1 KB the idle waves of the last patch piece write their zeros to
     constexpr int EPI_BYTES = 2 * BLOCK_PX * BN * 4;              // the epilogue's two float32 tiles (one per position group)
     constexpr int LDS_BYTES = DUMP + 1024 > EPI_BYTES ? DUMP + 1024 : EPI_BYTES;
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     const int cb = blockIdx.y, n0 = cb * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // (kept in a vector register: with a scalar wave index the role
     // branches below become scalar branches and the register allocator spills 106 registers over them; 238 without)
-    const int pg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;  // position group, tile half, channel half
+    const int irow = wave >> 1, wm = wave & 1, pg = wave >> 2;  // position row i, tile half; group = which half of the position grid (ping-pong)
     const int hi = lane >> 5;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)d.x_bytes, 0x00020000);
@@ -161,9 +166,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         cen[r] = inside ? (((img + g) * d.h + iy) * d.w + ix) * d.cin * 4 + 16 * chunk : OOB;
     }
     const int n_cs = d.cin >> 4, n_cb = d.cout >> 6;
-    // weight staging: a stage = 8 blocks of 4 KB in the order [pg][j]; DMA round q (0..3) moves blocks (pg = q >> 1, j = 2 (q & 1) +
-    // (wave >> 2)): per lane the offset inside the block + (wave >> 2) positions; the rest is scalar
-    const int w_voff = (wave & 3) * 1024 + lane * 16 + (wave >> 2) * d.pos_stride;
+    // weight staging: a stage = 16 position blocks of 2 KB; DMA round q (0..3) moves positions 4 q + (wave >> 1): per lane the offset
+    // inside the block + (wave >> 1) positions; the rest is scalar
+    const int w_voff = (wave & 1) * 1024 + lane * 16 + (wave >> 1) * d.pos_stride;
 
     unsigned char* const abuf0 = smem;
     unsigned char* const wst0 = smem + 2 * A_BYTES;
@@ -174,115 +179,87 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         unsigned char* dst = (NT * r + wave * 64 >= A_UNITS) ? smem + DUMP : abuf0 + buf * A_BYTES + r * (NT * 16) + wave * 1024;
         dma16(rx, dst, cen[r], cs * 64);
     };
-    // weights of flattened step s = 2 cs + half
+    // weights of flattened step s = 2 cs + h8 (h8: which 8 channels of the 16-channel slice)
     auto dma_w = [&](int stage, int s) {
-        const int cs = s >> 1, half = s & 1;
 #if TIA_WINO_TIMING
         if ((d.abl & 1) && s > 0) return;
 #endif
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = 2 * (q >> 1) + half, j0 = 2 * (q & 1);
-            const int soff = (i * 4 + j0) * d.pos_stride + (cs * n_cb + cb) * 4096;
-#if TIA_WINO_TIMING
-            if ((d.abl & 8) && (q & 1) && s > 0) continue;
-            dma16(ru, wst0 + stage * W_STAGE + q * 8192 + wave * 1024, ((d.abl & 4) && s > 0) ? OOB : w_voff, soff);
-#else
-            dma16(ru, wst0 + stage * W_STAGE + q * 8192 + wave * 1024, w_voff, soff);
-#endif
-        }
+        for (int q = 0; q < 4; ++q) dma16(ru, wst0 + stage * W_STAGE + q * 8192 + wave * 1024, w_voff, 4 * q * d.pos_stride + (s * n_cb + cb) * 2048);
     };
 
-    f32x16 acc[2][4];  // [row of the group: i = 2 pg + half][j]
+    f32x16 acc[4][2];  // [position j of the wave's row][channel tile]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][j][e] = 0.0f;
+            for (int e = 0; e < 16; ++e) acc[j][ct][e] = 0.0f;
 
-    // the lane's tile: MFMA row = lane & 31 -> tile 32 wm + (lane & 31); its 4 x 4 input tile starts at patch pixel (2 ty, 2 tx)
+    // the lane's tile: MFMA row = lane & 31 -> tile 32 wm + (lane & 31); its 4 x 4 input tile starts at patch pixel (2 ty, 2 tx); the
+    // lane's k values of a step are channels 8 h8 + 4 hi + 0..3 = unit 2 h8 + hi of the pixel
     const int t = 32 * wm + (lane & 31);
     int fa;
     if constexpr (GEO::G == 1) {
-        fa = 2 * (t >> 3) * ROW + (t & 7) * 9 + 2 * hi;
+        fa = 2 * (t >> 3) * ROW + (t & 7) * 9 + hi;
     } else {
-        fa = (t >> 4) * GEO::IMG + 2 * ((t >> 2) & 3) * ROW + (t & 3) * 9 + 2 * hi;
+        fa = (t >> 4) * GEO::IMG + 2 * ((t >> 2) & 3) * ROW + (t & 3) * 9 + hi;
     }
-    // weights of the lane: block (pg, j) of the stage, units [hi][kq][column]: two 16-byte reads per position
-    const int fb = pg * 4 * 256 + hi * 128 + wn * 32 + (lane & 31);
+    // weights of the lane: position block (i, j) of the stage, units [hi][column]: one 16-byte read per (position, channel tile)
+    const int fb = irow * 4 * 128 + hi * 64 + (lane & 31);
 
-    // One step of a wave = position row i of its group, positions j = 0..3, in two PHASES:
-    //   load phase:  16 patch reads (two rows x four columns x two 16-byte units) + 8 weight reads, the input transform
-    //                (R = d[ra] +- d[rb] per column, V_j = R0 - R2 | R1 + R2 | R2 - R1 | R1 - R3: 64 adds) -> V and the weights of
-    //                the step sit in 64 registers;
+    // A wave's step, in two PHASES:
+    //   load phase:  8 patch reads (two rows x four columns), the input transform (R = d[ra] +- d[rb] per column, V_j = R0 - R2 |
+    //                R1 + R2 | R2 - R1 | R1 - R3: 16 packed adds), 8 weight reads -> V and the weights of the step sit in 48 registers;
     //   MFMA phase:  32 MFMAs out of those registers, nothing else.
-    // The two position groups run HALF A STEP APART (ping-pong): while the waves of one group are in their MFMA phase, their
-    // SIMD partners (wave w and w + 4 share a SIMD) of the other group are in their load phase, with one barrier per half-step.
-    // Measured before this (profiles/r05d_wino_phases*.txt, r05e_wino_ablation.txt): with both groups in the same phase the
-    // matrix pipes idled while all eight waves queued on the LDS at the start of every step -- a step took 6,100 cycles for
-    // 4,096 of matrix work, 1,700 of them at the barrier, with or without any DMA in the loop.
-    f32x2 vreg[4][4];  // V_j, eight channels as four pairs (the arithmetic below is packed: v_pk_add_f32, two channels per instruction)
-    u32x4 wq[4][2];
-    // `row_c` = the position row i of this step (compile time: the callers branch on the group), so the row offsets are immediates and
-    // the signs are instruction modifiers: R = d[ra] +- d[rb]: i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
-    auto load_phase = [&](int buf, int stage, auto row_c) {
+    // The two halves of the position grid run HALF A STEP APART (ping-pong): while the waves of rows {0, 1} are in their MFMA phase,
+    // their SIMD partners (wave w and w + 4 share a SIMD) of rows {2, 3} are in their load phase, one barrier per half-step.
+    f32x2 vreg[4][2];  // V_j, four channels as two pairs
+    u32x4 wq[4][2];    // [j][channel tile]: four k values each
+    // `row_c` = the wave's position row i (compile time: the callers branch on it), so the row offsets are immediates and the signs
+    // are instruction modifiers: R = d[ra] +- d[rb]: i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    auto load_phase = [&](int buf, int stage, int h8, auto row_c) {
         constexpr int I = decltype(row_c)::value;
         constexpr int RA = (I == 0 ? 0 : (I == 2 ? 2 : 1)) * ROW, RB = (I == 0 ? 2 : (I == 1 ? 2 : (I == 2 ? 1 : 3))) * ROW;
         constexpr bool PLUS = I == 1;
-        // this wave's few vector and LDS instructions go first: its SIMD partner only has to place one MFMA per 64 cycles
         __builtin_amdgcn_s_setprio(3);
-        const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES) + fa;
+        const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES) + fa + 2 * h8;
         const u32x4* sb = reinterpret_cast<const u32x4*>(wst0 + stage * W_STAGE) + fb;
-#if TIA_WINO_TIMING
-        if (d.abl & 16) {  // no patch reads, no transform: what is left is the weight reads
+        u32x4 pa[4], pb[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                wq[j][0] = sb[j * 256], wq[j][1] = sb[j * 256 + 64];
+        for (int c = 0; c < 4; ++c) pa[c] = sa[RA + px_unit(c)], pb[c] = sa[RB + px_unit(c)];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) vreg[j][k] = f32x2{(float)(lane + j + k), (float)(lane - j - k)};
-            }
-            __builtin_amdgcn_s_setprio(0);
-            return;
-        }
-#endif
-        // two batches (columns 0, 2 + the weights; then columns 1, 3): the second round trip hides behind the partner's MFMA phase, and
-        // 32 registers fewer are live (all four columns at once spilled)
-        f32x2 R[4][4];
+        for (int j = 0; j < 4; ++j) wq[j][0] = sb[j * 128], wq[j][1] = sb[j * 128 + 32];
         auto pair_of = [](const u32x4& q, int k) { return f32x2{__uint_as_float(q[2 * k]), __uint_as_float(q[2 * k + 1])}; };
-        auto column = [&](int c) {
-            const u32x4 a0 = sa[RA + px_unit(c)], a1 = sa[RA + px_unit(c) + 1], b0 = sa[RB + px_unit(c)], b1 = sa[RB + px_unit(c) + 1];
+        f32x2 R[4][2];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                R[c][k] = PLUS ? pk_add(pair_of(a0, k), pair_of(b0, k)) : pk_sub(pair_of(a0, k), pair_of(b0, k));
-                R[c][2 + k] = PLUS ? pk_add(pair_of(a1, k), pair_of(b1, k)) : pk_sub(pair_of(a1, k), pair_of(b1, k));
-            }
-        };
-        column(0), column(2);
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wq[j][0] = sb[j * 256], wq[j][1] = sb[j * 256 + 64];
+            for (int k = 0; k < 2; ++k) R[c][k] = PLUS ? pk_add(pair_of(pa[c], k), pair_of(pb[c], k)) : pk_sub(pair_of(pa[c], k), pair_of(pb[c], k));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) vreg[0][k] = pk_sub(R[0][k], R[2][k]);
-        __builtin_amdgcn_sched_barrier(0);
-        column(1), column(3);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
+            vreg[0][k] = pk_sub(R[0][k], R[2][k]);
             vreg[1][k] = pk_add(R[1][k], R[2][k]);
             vreg[2][k] = pk_sub(R[2][k], R[1][k]);
             vreg[3][k] = pk_sub(R[1][k], R[3][k]);
         }
         __builtin_amdgcn_s_setprio(0);
     };
-    auto mfma_phase = [&](auto half_c) {
-        constexpr int HALF = decltype(half_c)::value;
+    // the wave's row is one of two per group: a wave-uniform branch picks the instantiation
+    auto load_rows = [&](int buf, int stage, int h8, auto lo_c, auto hi_c) {
+        if ((irow & 1) == 0) load_phase(buf, stage, h8, lo_c); else load_phase(buf, stage, h8, hi_c);
+    };
+    auto mfma_phase = [&] {
 #if TIA_WINO_TIMING
         if (d.abl & 64) return;  // no MFMAs: the load phases alone
 #endif
 #pragma unroll
-        for (int k = 0; k < 8; ++k)  // k outer: consecutive MFMAs go to different accumulators
+        for (int k = 0; k < 4; ++k)  // k outer: consecutive MFMAs go to different accumulators
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[HALF][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[j][k >> 1][k & 1], __uint_as_float(wq[j][k >> 2][k & 3]), acc[HALF][j], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[j][k >> 1][k & 1], __uint_as_float(wq[j][ct][k]), acc[j][ct], 0, 0, 0);
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
@@ -313,10 +290,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     dma_w(0, 0);
     dma_w(1, 1);
     half_end(true);
-    if (pg == 0) load_phase(0, 0, I0{});
+    if (pg == 0) load_rows(0, 0, 0, I0{}, I1{});
     half_end(false);
     WSTAMP(tm_pro)
-    // slice c = steps 2 c (rows i = 0 / 2, accumulators [0]) and 2 c + 1 (rows 1 / 3, accumulators [1]) = four half-steps:
+    // slice c = steps 2 c (channels 0-7 of the slice, weight stage 0) and 2 c + 1 (channels 8-15, stage 1) = four half-steps:
     //   4c    group 0: MFMA(2c)           group 1: load(2c)            | all DMAs landed, barrier
     //   4c+1  issue weights of step 2c+2 -> stage 0 and the patch of slice c+1;
     //         group 0: load(2c+1)         group 1: MFMA(2c)            | barrier
@@ -328,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     for (int cs = 0; cs < n_cs; ++cs) {
         const int buf = cs & 1;
         const bool more = cs + 1 < n_cs;
-        if (pg == 0) mfma_phase(H0{}); else load_phase(buf, 0, I2{});
+        if (pg == 0) mfma_phase(); else load_rows(buf, 0, 0, I2{}, I3{});
         WSTAMP_ROLE(true)
         half_end(true);
         WSTAMP(tm_wait)
@@ -337,19 +314,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
 #pragma unroll
             for (int r = 0; r < NA; ++r) dma_a(buf ^ 1, r, cs + 1);
         }
-        if (pg == 0) load_phase(buf, 1, I1{}); else mfma_phase(H0{});
+        if (pg == 0) load_rows(buf, 1, 1, I0{}, I1{}); else mfma_phase();
         WSTAMP_ROLE(false)
         half_end(false);
         WSTAMP(tm_wait)
-        if (pg == 0) mfma_phase(H1{}); else load_phase(buf, 1, I3{});
+        if (pg == 0) mfma_phase(); else load_rows(buf, 1, 1, I2{}, I3{});
         WSTAMP_ROLE(true)
         half_end(true);
         WSTAMP(tm_wait)
         if (more) dma_w(1, 2 * cs + 3);
         if (pg == 0) {
-            if (more) load_phase(buf ^ 1, 0, I0{});
+            if (more) load_rows(buf ^ 1, 0, 0, I0{}, I1{});
         } else {
-            mfma_phase(H1{});
+            mfma_phase();
         }
         WSTAMP_ROLE(false)
         half_end(false);
@@ -357,21 +334,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     }
 
     // ---- output transform (A^T = [1 1 1 0; 0 1 -1 -1]) ------------------------------------------------------------------------
-    // rows of the group: Z_h[b] = sum_j M[h][j] A[j][b];   group 0 (i = 0, 1): Y[0][b] += Z0 + Z1, Y[1][b] += Z1
-    //                                                       group 1 (i = 2, 3): Y[0][b] += Z0,      Y[1][b] += -Z0 - Z1
-    f32x16 yp[2][2];
-    {
-        const f32x16 z00 = acc[0][0] + acc[0][1] + acc[0][2], z01 = acc[0][1] - acc[0][2] - acc[0][3];
-        const f32x16 z10 = acc[1][0] + acc[1][1] + acc[1][2], z11 = acc[1][1] - acc[1][2] - acc[1][3];
-        if (pg == 0) {
-            yp[0][0] = z00 + z10, yp[0][1] = z01 + z11, yp[1][0] = z10, yp[1][1] = z11;
-        } else {
-            yp[0][0] = z00, yp[0][1] = z01, yp[1][0] = -z00 - z10, yp[1][1] = -z01 - z11;
-        }
+    // column transform in registers (per channel tile): Z[b] = sum_j M[i][j] A[j][b] = M0 + M1 + M2 | M1 - M2 - M3; the row transform
+    // Y[0][b] = Z(0) + Z(1) + Z(2), Y[1][b] = Z(1) - Z(2) - Z(3) runs over the four waves of a tile half, through LDS (below)
+    f32x16 z[2][2];  // [b][channel tile]
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        z[0][ct] = acc[0][ct] + acc[1][ct] + acc[2][ct];
+        z[1][ct] = acc[1][ct] - acc[2][ct] - acc[3][ct];
     }
-    // The two position groups' partial sums go to TWO float32 tiles [BLOCK_PX][64] (group 0: smem + 0, group 1: smem + 64 KB), one
-    // barrier, and the read-out adds them (the first version stored, synchronised, added in place, synchronised again).  The
-    // residual and bias of all four chunks of a thread are requested BEFORE the tiles are written: one exposed round trip.
+    // Two float32 tiles [BLOCK_PX][64]: A (smem + 0) collects rows i = 0, 1, B (smem + 64 KB) rows 2, 3.
+    //   round 1 (stores):  i = 0: A[y0] = Z(0)    i = 1: A[y1] = Z(1)     i = 2: B[y0] = Z(2)     i = 3: B[y1] = -Z(3)
+    //   round 2 (adds):                           i = 1: A[y0] += Z(1)    i = 2: B[y1] -= Z(2)
+    // (y0 / y1 = the tile's output rows 2 ty / 2 ty + 1, columns 2 tx + b), and the read-out adds A + B:
+    //   Y[0][b] = (Z0 + Z1) + Z2, Y[1][b] = Z1 + (-Z3 - Z2).  The residual and bias of all four chunks of a thread are requested BEFORE
+    // the tiles are written: one exposed round trip.
     // block pixel m = image m / (TH TW), (ty0 + (m % (TH TW)) / TW, tx0 + m % TW)
     constexpr int CHUNKS = BLOCK_PX * BN / 8, ITER = CHUNKS / NT;  // 2048 chunks of 8 columns, 4 per thread
     static_assert(CHUNKS % NT == 0 && NT % (BN / 8) == 0, "whole chunk rounds; a thread keeps its column chunk");
@@ -399,23 +375,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         }
     }
     float* tile = reinterpret_cast<float*>(smem) + pg * (BLOCK_PX * BN);
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // round r of this wave: output row `a` of its tiles, stored (sign `neg`) or added
+    auto to_tile = [&](int a, bool add, bool neg) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int tt = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * hi;  // MFMA result row -> tile
-        int m00;
-        if constexpr (GEO::G == 1) {
-            m00 = 2 * (tt >> 3) * GEO::TW + 2 * (tt & 7);
-        } else {
-            m00 = (tt >> 4) * (GEO::TH * GEO::TW) + 2 * ((tt >> 2) & 3) * GEO::TW + 2 * (tt & 3);
+        for (int e = 0; e < 16; ++e) {
+            const int tt = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * hi;  // MFMA result row -> tile
+            int m00;
+            if constexpr (GEO::G == 1) {
+                m00 = 2 * (tt >> 3) * GEO::TW + 2 * (tt & 7);
+            } else {
+                m00 = (tt >> 4) * (GEO::TH * GEO::TW) + 2 * ((tt >> 2) & 3) * GEO::TW + 2 * (tt & 3);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    float* p = tile + (m00 + a * GEO::TW + b) * BN + ct * 32 + (lane & 31);
+                    const float v = neg ? -z[b][ct][e] : z[b][ct][e];
+                    *p = add ? *p + v : v;
+                }
         }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) tile[(m00 + a * GEO::TW + b) * BN + wn * 32 + (lane & 31)] = yp[a][b][e];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    };
+    // (irow: 0 -> A[y0] = Z; 1 -> A[y1] = Z; 2 -> B[y0] = Z; 3 -> B[y1] = -Z)
+    to_tile(irow & 1, false, irow == 3);
+    lds_barrier();
+    if (irow == 1) to_tile(0, true, false);   // A[y0] += Z(1)
+    if (irow == 2) to_tile(1, true, true);    // B[y1] -= Z(2)
+    lds_barrier();
     const float* t0 = reinterpret_cast<const float*>(smem);
     const float* t1 = t0 + BLOCK_PX * BN;
 #pragma unroll
@@ -471,14 +462,14 @@ __global__ void wino_pack_kernel(const float* __restrict__ w_oihw, int cout, int
         t[3][s] = g[2][s];
     }
     const int n_cs = cin >> 4, n_cb = cout >> 6;
-    const int cs = c >> 4, hi = (c >> 3) & 1, kq = (c >> 2) & 1, c4 = c & 3, cb = o >> 6, col = o & 63;
+    const int cs = c >> 4, h8 = (c >> 3) & 1, hi = (c >> 2) & 1, c4 = c & 3, cb = o >> 6, col = o & 63;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const double uu[4] = {t[i][0], 0.5 * (t[i][0] + t[i][1] + t[i][2]), 0.5 * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long block = ((long)(i * 4 + j) * n_cs + cs) * n_cb + cb;
-            packed[block * 1024 + ((hi * 2 + kq) * 64 + col) * 4 + c4] = (float)uu[j];
+            const long block = (((long)(i * 4 + j) * n_cs + cs) * 2 + h8) * n_cb + cb;  // 2 KB = 512 floats
+            packed[block * 512 + (hi * 64 + col) * 4 + c4] = (float)uu[j];
         }
     }
 }

@@ -406,7 +406,8 @@ def pack_conv_weights(conv: nn.Conv2d) -> torch.Tensor:
 
 def pack_conv_weights_wino(conv: nn.Conv2d) -> torch.Tensor:
     """OIHW 3x3 float32 -> the Winograd-domain weights ``U = G g G^T`` in the stage layout of ``tia_conv3x3_wino_nhwc_f32``
-    (``tia_conv_pack_weights_wino_f32``: float64 transform, one rounding), ``[16, cin/16, cout/64, 2, 2, 64, 4]``."""
+    (``tia_conv_pack_weights_wino_f32``: float64 transform, one rounding), ``[16, cin/16, 2, cout/64, 2, 64, 4]``
+    (position, 16-channel slice, 8-channel half, 64-column block, 4-channel group, column, channel)."""
     from tiatoolbox_amd import _lib
 
     w = conv.weight.detach().to(torch.float32).contiguous()
@@ -414,7 +415,7 @@ def pack_conv_weights_wino(conv: nn.Conv2d) -> torch.Tensor:
     if (kh, kw) != (3, 3) or cin % 16 or cout % 64:
         msg = f"Winograd F(2x2, 3x3) needs a 3x3 kernel, cin % 16 == 0 and cout % 64 == 0; got weight {tuple(w.shape)}."
         raise ValueError(msg)
-    out = torch.empty((16, cin // 16, cout // 64, 2, 2, 64, 4), dtype=torch.float32, device=w.device)
+    out = torch.empty((16, cin // 16, 2, cout // 64, 2, 64, 4), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
         rc = _lib.load().tia_conv_pack_weights_wino_f32(w.data_ptr(), cout, cin, out.data_ptr(), _lib.current_stream())
     _lib.check(rc, "tia_conv_pack_weights_wino_f32")
@@ -434,7 +435,7 @@ def hip_conv3x3_wino(x: torch.Tensor, u_packed: torch.Tensor, bias: torch.Tensor
         msg = "hip_conv3x3_wino expects a float32 channels-last CUDA residual."
         raise ValueError(msg)
     n, cin, h, w = x.shape
-    cout = u_packed.shape[2] * 64
+    cout = u_packed.shape[3] * 64
     ho, wo = h + 2 * padding - 2, w + 2 * padding - 2
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if residual is not None and residual.shape != y.shape:
