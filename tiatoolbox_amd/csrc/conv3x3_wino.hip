@@ -208,34 +208,50 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     // weights of the lane: position block (i, j) of the stage, units [hi][column]: one 16-byte read per (position, channel tile)
     const int fb = irow * 4 * 128 + hi * 64 + (lane & 31);
 
-    // A wave's step, in two PHASES:
-    //   load phase:  8 patch reads (two rows x four columns), the input transform (R = d[ra] +- d[rb] per column, V_j = R0 - R2 |
-    //                R1 + R2 | R2 - R1 | R1 - R3: 16 packed adds), 8 weight reads -> V and the weights of the step sit in 48 registers;
-    //   MFMA phase:  32 MFMAs out of those registers, nothing else.
-    // The two halves of the position grid run HALF A STEP APART (ping-pong): while the waves of rows {0, 1} are in their MFMA phase,
-    // their SIMD partners (wave w and w + 4 share a SIMD) of rows {2, 3} are in their load phase, one barrier per half-step.
-    f32x2 vreg[4][2];  // V_j, four channels as two pairs
+    // A wave's step k (8 input channels) is software-pipelined against its own MFMAs:
+    //   top of step k (behind the barrier: every DMA issued a step ago has landed, every LDS read of the last step has returned):
+    //     DMA requests (weights of step k + 2 into the stage step k just released; at even k the patch of the next slice),
+    //     the 8 patch reads of step k + 1 (two rows x four columns of the lane's tile);
+    //   for each position j: its 8 MFMAs of step k, then the 2 weight reads of step k + 1 into the registers they just freed;
+    //   the input transform of step k + 1 (R = d[ra] +- d[rb] per column, V_j = R0 - R2 | R1 + R2 | R2 - R1 | R1 - R3: 16 packed adds);
+    //   s_waitcnt + ONE barrier.
+    // History (profiles/r05*_wino_*): reading a position's operands right in front of its MFMAs, then all reads up front, then the
+    // two halves of the position grid half a step apart ("ping-pong": load phase | MFMA phase, a barrier per half-step) all ended at
+    // ~5,700-6,100 cycles per 4,096 cycles of matrix work: beside a float32 MFMA stream the SIMD partner's vector / LDS instructions
+    // take 2-3 x as long, so phases that were meant to overlap mostly added up.  Here a wave's LDS round trips hide behind its OWN
+    // MFMAs and only ~30 vector / LDS issue slots per 32 MFMAs are exposed.
+    f32x2 vreg[4][2];  // V_j of the step whose MFMAs are next, four channels as two pairs
     u32x4 wq[4][2];    // [j][channel tile]: four k values each
-    // `row_c` = the wave's position row i (compile time: the callers branch on it), so the row offsets are immediates and the signs
-    // are instruction modifiers: R = d[ra] +- d[rb]: i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
-    auto load_phase = [&](int buf, int stage, int h8, auto row_c) {
-        constexpr int I = decltype(row_c)::value;
-        constexpr int RA = (I == 0 ? 0 : (I == 2 ? 2 : 1)) * ROW, RB = (I == 0 ? 2 : (I == 1 ? 2 : (I == 2 ? 1 : 3))) * ROW;
-        constexpr bool PLUS = I == 1;
-        __builtin_amdgcn_s_setprio(3);
-        const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + buf * A_BYTES) + fa + 2 * h8;
-        const u32x4* sb = reinterpret_cast<const u32x4*>(wst0 + stage * W_STAGE) + fb;
-        u32x4 pa[4], pb[4];
+    u32x4 pa[4], pb[4];  // raw patch units of the NEXT step (rows ra / rb, columns 0..3)
+    constexpr int RA0 = 0 * ROW, RB0 = 2 * ROW, RA1 = 1 * ROW, RB1 = 2 * ROW, RA2 = 2 * ROW, RB2 = 1 * ROW, RA3 = 1 * ROW, RB3 = 3 * ROW;
+    // R = d[ra] +- d[rb]: i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3 (per-wave constants: the row offsets go into one register each)
+    const int ra_off = irow == 0 ? RA0 : (irow == 1 ? RA1 : (irow == 2 ? RA2 : RA3));
+    const int rb_off = irow == 0 ? RB0 : (irow == 1 ? RB1 : (irow == 2 ? RB2 : RB3));
+    const bool plus = irow == 1;
+    const int fa_a = fa + ra_off, fa_b = fa + rb_off;
+    auto patch_reads = [&](int s) {  // step s: slice s >> 1 (buffer (s >> 1) & 1), channels 8 (s & 1) ..
+        const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + ((s >> 1) & 1) * A_BYTES) + 2 * (s & 1);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) pa[c] = sa[RA + px_unit(c)], pb[c] = sa[RB + px_unit(c)];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wq[j][0] = sb[j * 128], wq[j][1] = sb[j * 128 + 32];
+        for (int c = 0; c < 4; ++c) pa[c] = sa[fa_a + px_unit(c)], pb[c] = sa[fa_b + px_unit(c)];
+    };
+    auto weight_reads = [&](int s, int j) {
+        const u32x4* sb = reinterpret_cast<const u32x4*>(wst0 + (s & 1) * W_STAGE) + fb;
+        wq[j][0] = sb[j * 128], wq[j][1] = sb[j * 128 + 32];
+    };
+    auto transform = [&] {
         auto pair_of = [](const u32x4& q, int k) { return f32x2{__uint_as_float(q[2 * k]), __uint_as_float(q[2 * k + 1])}; };
         f32x2 R[4][2];
+        if (plus) {  // (wave-uniform)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) R[c][k] = PLUS ? pk_add(pair_of(pa[c], k), pair_of(pb[c], k)) : pk_sub(pair_of(pa[c], k), pair_of(pb[c], k));
+                for (int k = 0; k < 2; ++k) R[c][k] = pk_add(pair_of(pa[c], k), pair_of(pb[c], k));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) R[c][k] = pk_sub(pair_of(pa[c], k), pair_of(pb[c], k));
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             vreg[0][k] = pk_sub(R[0][k], R[2][k]);
@@ -243,40 +259,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
             vreg[2][k] = pk_sub(R[2][k], R[1][k]);
             vreg[3][k] = pk_sub(R[1][k], R[3][k]);
         }
-        __builtin_amdgcn_s_setprio(0);
     };
-    // the wave's row is one of two per group: a wave-uniform branch picks the instantiation
-    auto load_rows = [&](int buf, int stage, int h8, auto lo_c, auto hi_c) {
-        if ((irow & 1) == 0) load_phase(buf, stage, h8, lo_c); else load_phase(buf, stage, h8, hi_c);
-    };
-    auto mfma_phase = [&] {
+    auto mfma_j = [&](int j) {
 #if TIA_WINO_TIMING
-        if (d.abl & 64) return;  // no MFMAs: the load phases alone
+        if (d.abl & 64) return;  // no MFMAs
 #endif
 #pragma unroll
-        for (int k = 0; k < 4; ++k)  // k outer: consecutive MFMAs go to different accumulators
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[j][k >> 1][k & 1], __uint_as_float(wq[j][ct][k]), acc[j][ct], 0, 0, 0);
+            for (int ct = 0; ct < 2; ++ct)
+                acc[j][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[j][k >> 1][k & 1], __uint_as_float(wq[j][ct][k]), acc[j][ct], 0, 0, 0);
     };
-    using H0 = std::integral_constant<int, 0>;
-    using H1 = std::integral_constant<int, 1>;
-    using I0 = H0;
-    using I1 = H1;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
 #if TIA_WINO_TIMING
     long long tm_vm = 0;
 #endif
-    // end of a half-step: every LDS read of the phase has returned (the stages / buffers it read may be refilled after the barrier)
-    // and -- `dma` -- every DMA this wave issued has landed (what the next half-steps read)
-    auto half_end = [&](bool dma) {
-        if (dma)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto step_end = [&] {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #if TIA_WINO_TIMING
         { const long long now_ = clock64(); tm_vm += now_ - tl_; }
 #endif
@@ -284,52 +282,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         asm volatile("" ::: "memory");
     };
 
-    // prologue: patch of slice 0, weights of steps 0 and 1; group 0's first load phase
+    // prologue: patch of slice 0, weights of steps 0 and 1; the operands of step 0
+    const int n_steps = 2 * n_cs;
 #pragma unroll
     for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
     dma_w(0, 0);
     dma_w(1, 1);
-    half_end(true);
-    if (pg == 0) load_rows(0, 0, 0, I0{}, I1{});
-    half_end(false);
-    WSTAMP(tm_pro)
-    // slice c = steps 2 c (channels 0-7 of the slice, weight stage 0) and 2 c + 1 (channels 8-15, stage 1) = four half-steps:
-    //   4c    group 0: MFMA(2c)           group 1: load(2c)            | all DMAs landed, barrier
-    //   4c+1  issue weights of step 2c+2 -> stage 0 and the patch of slice c+1;
-    //         group 0: load(2c+1)         group 1: MFMA(2c)            | barrier
-    //   4c+2  group 0: MFMA(2c+1)         group 1: load(2c+1)          | all DMAs landed, barrier
-    //   4c+3  issue weights of step 2c+3 -> stage 1;
-    //         group 0: load(2c+2)         group 1: MFMA(2c+1)          | barrier
-    // A weight stage is refilled right after group 1's load phase of the step it held (the barrier in between) and has two
-    // half-steps to land; the patch buffer of slice c + 1 was last read by group 1 in half-step 4c - 2.
-    for (int cs = 0; cs < n_cs; ++cs) {
-        const int buf = cs & 1;
-        const bool more = cs + 1 < n_cs;
-        if (pg == 0) mfma_phase(); else load_rows(buf, 0, 0, I2{}, I3{});
-        WSTAMP_ROLE(true)
-        half_end(true);
-        WSTAMP(tm_wait)
-        if (more) {
-            dma_w(0, 2 * cs + 2);
+    step_end();
+    patch_reads(0);
 #pragma unroll
-            for (int r = 0; r < NA; ++r) dma_a(buf ^ 1, r, cs + 1);
+    for (int j = 0; j < 4; ++j) weight_reads(0, j);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    transform();
+    step_end();  // (every wave has read stage 0's weights: step 0 may refill it)
+    WSTAMP(tm_pro)
+    for (int k = 0; k < n_steps; ++k) {
+        const bool next = k + 1 < n_steps;
+        if (k + 2 < n_steps) dma_w(k & 1, k + 2);
+        if ((k & 1) == 0 && k + 2 < n_steps) {  // first step of slice k / 2: the next slice's patch into the other buffer
+#pragma unroll
+            for (int r = 0; r < NA; ++r) dma_a(((k >> 1) & 1) ^ 1, r, (k >> 1) + 1);
         }
-        if (pg == 0) load_rows(buf, 1, 1, I0{}, I1{}); else mfma_phase();
-        WSTAMP_ROLE(false)
-        half_end(false);
-        WSTAMP(tm_wait)
-        if (pg == 0) mfma_phase(); else load_rows(buf, 1, 1, I2{}, I3{});
-        WSTAMP_ROLE(true)
-        half_end(true);
-        WSTAMP(tm_wait)
-        if (more) dma_w(1, 2 * cs + 3);
-        if (pg == 0) {
-            if (more) load_rows(buf ^ 1, 0, 0, I0{}, I1{});
-        } else {
-            mfma_phase();
+        if (next) patch_reads(k + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mfma_j(j);
+            if (next) weight_reads(k + 1, j);
         }
-        WSTAMP_ROLE(false)
-        half_end(false);
+        WSTAMP(tm_comp)
+        if (next) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            transform();
+        }
+        WSTAMP(tm_load)
+        step_end();
         WSTAMP(tm_wait)
     }
 
