@@ -144,6 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     const int cb = blockIdx.y, n0 = cb * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // (kept in a vector register: with a scalar wave index the role
     // branches below become scalar branches and the register allocator spills 106 registers over them; 238 without)
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);  // the same number in a scalar register: LDS-DMA destinations (M0) and offsets
     const int irow = wave >> 1, wm = wave & 1, pg = wave >> 2;  // position row i, tile half; group = which half of the position grid (ping-pong)
     const int hi = lane >> 5;
 
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     const int n_cs = d.cin >> 4, n_cb = d.cout >> 6;
     // weight staging: a stage = 16 position blocks of 2 KB; DMA round q (0..3) moves positions 4 q + (wave >> 1): per lane the offset
     // inside the block + (wave >> 1) positions; the rest is scalar
-    const int w_voff = (wave & 1) * 1024 + lane * 16 + (wave >> 1) * d.pos_stride;
+    const int w_voff = (wave_s & 1) * 1024 + lane * 16 + (wave_s >> 1) * d.pos_stride;
 
     unsigned char* const abuf0 = smem;
     unsigned char* const wst0 = smem + 2 * A_BYTES;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
 #if TIA_WINO_TIMING
         if ((d.abl & 2) && cs > 0) return;
 #endif
-        unsigned char* dst = (NT * r + wave * 64 >= A_UNITS) ? smem + DUMP : abuf0 + buf * A_BYTES + r * (NT * 16) + wave * 1024;
+        unsigned char* dst = (NT * r + wave_s * 64 >= A_UNITS) ? smem + DUMP : abuf0 + buf * A_BYTES + r * (NT * 16) + wave_s * 1024;
         dma16(rx, dst, cen[r], cs * 64);
     };
     // weights of flattened step s = 2 cs + h8 (h8: which 8 channels of the 16-channel slice)
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         if ((d.abl & 1) && s > 0) return;
 #endif
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma16(ru, wst0 + stage * W_STAGE + q * 8192 + wave * 1024, w_voff, 4 * q * d.pos_stride + (s * n_cb + cb) * 2048);
+        for (int q = 0; q < 4; ++q) dma16(ru, wst0 + stage * W_STAGE + q * 8192 + wave_s * 1024, w_voff, 4 * q * d.pos_stride + (s * n_cb + cb) * 2048);
     };
 
     f32x16 acc[4][2];  // [position j of the wave's row][channel tile]
@@ -296,19 +297,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     transform();
     step_end();  // (every wave has read stage 0's weights: step 0 may refill it)
     WSTAMP(tm_pro)
+    // The two waves of a SIMD (w and w + 4: position rows {0, 1} and {2, 3}) take the step's non-MFMA work at DIFFERENT times: rows
+    // {2, 3} issue the MFMAs of j = 0, 1 first and request DMAs / patch reads after them, rows {0, 1} the other way round -- while one
+    // wave of the SIMD issues requests the other one feeds the matrix pipe (after a barrier both used to start with ~40 scalar /
+    // vector instructions of request work, the pipe idle).
     for (int k = 0; k < n_steps; ++k) {
         const bool next = k + 1 < n_steps;
-        if (k + 2 < n_steps) dma_w(k & 1, k + 2);
-        if ((k & 1) == 0 && k + 2 < n_steps) {  // first step of slice k / 2: the next slice's patch into the other buffer
+        auto requests = [&] {
+            if (k + 2 < n_steps) dma_w(k & 1, k + 2);
+            if ((k & 1) == 0 && k + 2 < n_steps) {  // first step of slice k / 2: the next slice's patch into the other buffer
 #pragma unroll
-            for (int r = 0; r < NA; ++r) dma_a(((k >> 1) & 1) ^ 1, r, (k >> 1) + 1);
-        }
-        if (next) patch_reads(k + 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+                for (int r = 0; r < NA; ++r) dma_a(((k >> 1) & 1) ^ 1, r, (k >> 1) + 1);
+            }
+            if (next) patch_reads(k + 1);
+        };
+        auto mma = [&](int j) {
             mfma_j(j);
             if (next) weight_reads(k + 1, j);
+        };
+        if (pg == 1) {
+            mma(0), mma(1);
+            requests();
+        } else {
+            requests();
+            mma(0), mma(1);
         }
+        mma(2), mma(3);
         WSTAMP(tm_comp)
         if (next) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
