@@ -312,6 +312,9 @@ def _condense(full: dict) -> dict:
     cpu = full.get("cpu_baseline")
     if cpu:
         out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cpu}
+    wino = (full.get("extras") or {}).get("cnn_winograd")
+    if wino:
+        out["cnn_winograd"] = {k: v for k, v in wino.items() if k != "note"}
     return out
 
 

@@ -101,3 +101,43 @@ def test_float32_segmentation_forwards_launch_only_handwritten_convolutions():
         kernels = _device_kernels(lambda: unet(xu))
         assert any("stem7x7_pool_kernel" in k for k in kernels) and any("head1x1_kernel" in k for k in kernels), kernels
         assert not {k for k in kernels if any(b in k for b in BANNED)}, kernels
+
+
+@pytest.mark.gpu
+def test_segmentation_forwards_with_winograd_match_direct():
+    """``conv_algo="winograd"`` on the fused segmentation networks: every plain 3x3 / stride-1 MFMA convolution of ``FusedHoVerNet``
+    (the residual units' conv2) and ``FusedUNet`` (Bottleneck conv2, the decoder's 3x3 layers; "same" and valid borders) goes through
+    ``conv3x3_wino_kernel``; head maps / logits stay within 1e-4 of the direct float32 forward (relative to the largest magnitude),
+    and the switch goes back."""
+    from tiatoolbox_amd.models.architecture import get_pretrained_model
+    from tiatoolbox_amd.models.architecture.hovernet_fused import FusedHoVerNet, set_conv_algo
+    from tiatoolbox_amd.models.architecture.unet_fused import FusedUNet
+    from tiatoolbox_amd.utils import synth
+
+    tiles = torch.from_numpy(synth.g_he(2, 256, 256, seed=7)).cuda()
+    with torch.inference_mode():
+        model, _ = get_pretrained_model("hovernet_fast-pannuke")
+        hov = FusedHoVerNet(model.eval().cuda()).cuda()
+        xin = tiles.float().permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+        direct = {k: v.clone() for k, v in hov(xin).items()}
+        assert set_conv_algo(hov, "winograd") >= 10  # noqa: PLR2004
+        kernels = _device_kernels(lambda: hov(xin))
+        assert any("conv3x3_wino_kernel" in k for k in kernels), kernels
+        wino = hov(xin)
+        for k, v in direct.items():
+            scale = v.abs().max().item()
+            assert (wino[k] - v).abs().max().item() <= 1e-4 * max(scale, 1.0), k
+        assert any(not torch.equal(wino[k], direct[k]) for k in direct)
+        set_conv_algo(hov, "direct")
+        again = hov(xin)
+        assert all(torch.equal(again[k], direct[k]) for k in direct)
+        with pytest.raises(ValueError, match="conv_algo"):
+            set_conv_algo(hov, "fft")
+        model, _ = get_pretrained_model("fcn_resnet50_unet-bcss")
+        unet = FusedUNet(model.eval().cuda()).cuda()
+        xu = tiles.permute(0, 3, 1, 2)
+        ref = unet(xu).clone()
+        assert set_conv_algo(unet, "winograd") >= 16  # noqa: PLR2004
+        got = unet(xu)
+        assert (got - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1.0)
+        assert not torch.equal(got, ref)

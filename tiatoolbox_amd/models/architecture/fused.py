@@ -423,7 +423,7 @@ def pack_conv_weights_wino(conv: nn.Conv2d) -> torch.Tensor:
 
 
 def hip_conv3x3_wino(x: torch.Tensor, u_packed: torch.Tensor, bias: torch.Tensor | None, residual: torch.Tensor | None, *,
-                     padding: int, relu: bool) -> torch.Tensor:
+                     padding: int, relu: bool, pad_hi: int | None = None) -> torch.Tensor:
     """``relu(conv3x3(x, w) + bias + residual)``, stride 1, through the Winograd F(2x2, 3x3) kernel (``tia_conv3x3_wino_nhwc_f32``):
     float32 in / float32 accumulate like :func:`hip_conv2d`, 2.25 x fewer multiplies, results within ~1e-5 (relative) of it."""
     from tiatoolbox_amd import _lib
@@ -436,7 +436,8 @@ def hip_conv3x3_wino(x: torch.Tensor, u_packed: torch.Tensor, bias: torch.Tensor
         raise ValueError(msg)
     n, cin, h, w = x.shape
     cout = u_packed.shape[3] * 64
-    ho, wo = h + 2 * padding - 2, w + 2 * padding - 2
+    behind = padding if pad_hi is None else pad_hi  # zero rows / columns behind the image (`padding` in front): "same", valid, TF-same
+    ho, wo = h + padding + behind - 2, w + padding + behind - 2
     y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if residual is not None and residual.shape != y.shape:
         msg = f"residual shape {tuple(residual.shape)} != output shape {tuple(y.shape)}"

@@ -31,6 +31,7 @@ import torch.nn.functional as F  # noqa: N812
 from torch import nn
 
 from tiatoolbox_amd.models.architecture.fused import (hip_bias_act_, hip_conv1x1_head, hip_conv1x1_pre, hip_conv2d_ex, hip_conv2d_post,
+                                                      hip_conv3x3_wino, pack_conv_weights_wino,
                                                       hip_conv2d_thin, hip_grouped_conv_valid, hip_scale_shift_act,
                                                       hip_scale_shift_act_view, hip_upsample2x_add, pack_conv_weights,
                                                       pack_thin_conv_weights)
@@ -80,6 +81,11 @@ class _Conv(nn.Module):
         self.weight = nn.Parameter(w.contiguous(), requires_grad=False)
         self.bias = nn.Parameter(bias.contiguous(), requires_grad=False) if bias is not None else None
         self._packed: torch.Tensor | None = None
+        # opt-in (`set_conv_algo(model, "winograd")`, engine kwarg `conv_algo`): plain 3x3 / stride-1 layers through the Winograd
+        # F(2x2, 3x3) kernel (float32 in / float32 accumulate; csrc/conv3x3_wino.hip)
+        self.conv_algo = "direct"
+        self.wino_ok = self.mfma_ok and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.dilation == (1, 1)
+        self._wino: torch.Tensor | None = None
 
     def forward(self, x: torch.Tensor, *, pads: tuple[int, int] = (0, 0), relu: bool = False,
                 residual: torch.Tensor | None = None, out: torch.Tensor | None = None, pre: "_BnAct | None" = None) -> torch.Tensor:
@@ -99,6 +105,10 @@ class _Conv(nn.Module):
                 g, k = self.groups, self.kernel
                 self._packed = self.weight.view(g, 8, 32, k, k).permute(0, 3, 4, 2, 1).contiguous()  # [g][ky][kx][c][j]
             return hip_grouped_conv_valid(_cl(x), self._packed, groups=self.groups, kernel=self.kernel, out=out)
+        if self.wino_ok and self.conv_algo == "winograd" and max(pads) <= 2:  # noqa: PLR2004
+            if self._wino is None or self._wino.device != self.weight.device:
+                self._wino = pack_conv_weights_wino(self)  # reads `.weight` (OIHW, BN folded)
+            return hip_conv3x3_wino(_cl(x), self._wino, self.bias, residual, padding=pads[0], pad_hi=pads[1], relu=relu)
         if self.mfma_ok:
             if self._packed is None or self._packed.device != self.weight.device:
                 self._packed = pack_conv_weights(self)  # reads `.weight` (OIHW)
@@ -115,6 +125,21 @@ class _Conv(nn.Module):
             y = y + residual if residual is not None else y
             return F.relu(y) if relu else y
         return y
+
+
+def set_conv_algo(model: nn.Module, algo: str) -> int:
+    """``"direct"`` | ``"winograd"`` for every plain 3x3 / stride-1 MFMA convolution of a fused segmentation network (``FusedHoVerNet``,
+    ``FusedUNet``); returns how many layers the switch applies to.  Layers with a second epilogue output or an activation on load
+    keep their own kernels."""
+    if algo not in ("direct", "winograd"):
+        msg = f"conv_algo must be 'direct' or 'winograd', got {algo!r}."
+        raise ValueError(msg)
+    count = 0
+    for mod in model.modules():
+        if isinstance(mod, _Conv):
+            mod.conv_algo = algo
+            count += int(mod.wino_ok)
+    return count
 
 
 def _conv_with_post(conv: "_Conv", x: torch.Tensor, residual: torch.Tensor, bn: "_BnAct", *, want_raw: bool):

@@ -415,11 +415,17 @@ class EngineABC:
                     from tiatoolbox_amd.models.architecture.hovernet_fused import FusedHoVerNet
 
                     m = FusedHoVerNet(m.to(device=self.device))
+                    from tiatoolbox_amd.models.architecture.hovernet_fused import set_conv_algo
+
+                    set_conv_algo(m, algo)
                 elif isinstance(m, UNetModel) and hasattr(m.backbone, "layer1") and m.skip_type == "add":
                     # UNet with the ResNet-50 encoder in float32: 61 of its 63 convolutions on the MFMA kernel
                     from tiatoolbox_amd.models.architecture.unet_fused import FusedUNet
 
                     m = FusedUNet(m.to(device=self.device))
+                    from tiatoolbox_amd.models.architecture.hovernet_fused import set_conv_algo
+
+                    set_conv_algo(m, algo)
             m = m.to(device=self.device)
             if on_gpu:  # hand-written trunks pack their weights (and keep float32 biases) from the float32 parameters
                 for mod in m.modules():
