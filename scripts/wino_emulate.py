@@ -25,19 +25,51 @@ def pack(w):  # wino_pack_kernel
     return out
 
 
+def plan_windows(nb, ho, wo):  # wino_plan
+    if ho <= 8 and wo <= 8:
+        return None
+    ty_, tx_ = (ho + 1) // 2, (wo + 1) // 2
+    busy16 = ho * wo / (((ho + 15) // 16) * ((wo + 15) // 16) * 256)
+    best, best_busy, bu = None, busy16, 0
+    if busy16 >= 0.9:
+        return None
+    for wty in range(1, 9):
+        for wtx in range(1, 17):
+            wt = wty * wtx
+            if wt > 64:
+                continue
+            wrow = (wtx + 1) * 9
+            wimg = ((2 * wty + 2) * wrow + 15) // 16 * 16
+            wx, wy = -(-tx_ // wtx), -(-ty_ // wty)
+            for wg in range(64 // wt, max(0, 64 // wt - 3), -1):
+                if wg * wimg > 2560 or wg > 16:
+                    continue
+                blocks = -(-nb * wx * wy // wg)
+                busy = nb * ho * wo / (blocks * 256)
+                units = wg * wimg
+                if busy > best_busy + 0.02 or (best is not None and busy > best_busy - 1e-9 and units < bu):
+                    best, best_busy, bu = dict(wg=wg, wty=wty, wtx=wtx, wrow=wrow, wimg=wimg, wins_x=wx, wins_y=wy), busy, units
+    return best
+
+
 def run_block(x, upk, geo, mt_id, cb, pad, ho, wo, tiles_x, tiles_per_image):
     n, h, w, cin = x.shape
     cout = upk.size // (16 * cin)
-    G, TH, TW, PH, PWD, ROW, IMG = geo
+    RT = isinstance(geo, dict)
+    if RT:
+        G, TH, TW, PH, PWD, ROW, IMG = 0, 16, 16, 0, 0, geo["wrow"], 2560
+        n_windows = n * geo["wins_x"] * geo["wins_y"]
+    else:
+        G, TH, TW, PH, PWD, ROW, IMG = geo
     NT = 512
 
     def px_unit(px):
         return (px >> 1) * 9 + (px & 1) * 4
-    A_UNITS = (G * IMG + 63) // 64 * 64
+    A_UNITS = ((1 if RT else G) * IMG + 63) // 64 * 64
     NA = (A_UNITS + NT - 1) // NT
     n_cs, n_cb = cin // 16, cout // 64
     pos_stride = n_cs * n_cb * 4096
-    img = mt_id // tiles_per_image if G == 1 else mt_id * G
+    img = 0 if RT else (mt_id // tiles_per_image if G == 1 else mt_id * G)
     trem = mt_id - img * tiles_per_image if G == 1 else 0
     ty0, tx0 = (trem // tiles_x) * TH, (trem % tiles_x) * TW
     xf = x.reshape(-1)
@@ -51,6 +83,23 @@ def run_block(x, upk, geo, mt_id, cb, pad, ho, wo, tiles_x, tiles_per_image):
                 wave = tid >> 6
                 if NT * r + wave * 64 >= A_UNITS:
                     continue  # dump
+                if RT:
+                    if NT * r >= geo["wg"] * geo["wimg"]:
+                        continue
+                    g, ug = divmod(un, geo["wimg"])
+                    py, rem = divmod(ug, geo["wrow"])
+                    pair, r9 = divmod(rem, 9)
+                    px, chunk = 2 * pair + (r9 >> 2), (4 if r9 == 8 else r9 & 3)
+                    win = mt_id * geo["wg"] + g
+                    wi, wr = divmod(win, geo["wins_x"] * geo["wins_y"])
+                    wy, wx = divmod(wr, geo["wins_x"])
+                    iy, ix = wy * 2 * geo["wty"] - pad + py, wx * 2 * geo["wtx"] - pad + px
+                    inside = (g < geo["wg"] and win < n_windows and py < 2 * geo["wty"] + 2 and px < 2 * geo["wtx"] + 2 and chunk < 4
+                              and 0 <= iy < h and 0 <= ix < w)
+                    if inside:
+                        off = (((wi * h + iy) * w + ix) * cin * 4 + 16 * chunk + cs * 64) // 4
+                        abuf[un] = xf[off:off + 4]
+                    continue
                 g, ug = divmod(un, IMG)
                 py, rem = divmod(ug, ROW)
                 pair, r9 = divmod(rem, 9)
@@ -82,7 +131,13 @@ def run_block(x, upk, geo, mt_id, cb, pad, ho, wo, tiles_x, tiles_per_image):
                 for lane in range(64):
                     hi = lane >> 5
                     t = 32 * wm + (lane & 31)
-                    if G == 1:
+                    if RT:
+                        wt = geo["wty"] * geo["wtx"]
+                        tv = t if t < geo["wg"] * wt else 0
+                        g_, rr = divmod(tv, wt)
+                        tyy, txx = divmod(rr, geo["wtx"])
+                        fa = g_ * geo["wimg"] + 2 * tyy * geo["wrow"] + txx * 9 + hi
+                    elif G == 1:
                         fa = 2 * (t >> 3) * ROW + (t & 7) * 9 + hi
                     else:
                         fa = (t >> 4) * IMG + 2 * ((t >> 2) & 3) * ROW + (t & 3) * 9 + hi
@@ -105,7 +160,7 @@ def run_block(x, upk, geo, mt_id, cb, pad, ho, wo, tiles_x, tiles_per_image):
                             B = np.stack([Wv[j, ct, :32, k], Wv[j, ct, 32:, k]], axis=0)  # [kidx][col]
                             acc[wave, j, ct] += (A @ B).astype(np.float32)
     # ---- output transform + tiles (two rounds)
-    tiles = np.zeros((2, G * TH * TW, 64), np.float32)
+    tiles = np.zeros((2, 256, 64), np.float32)
 
     def to_tile(wave, a, add, neg):
         i, wm = wave >> 1, wave & 1
@@ -113,11 +168,15 @@ def run_block(x, upk, geo, mt_id, cb, pad, ho, wo, tiles_x, tiles_per_image):
         z = [[m[0, ct] + m[1, ct] + m[2, ct] for ct in range(2)], [m[1, ct] - m[2, ct] - m[3, ct] for ct in range(2)]]
         for row in range(32):
             tt = 32 * wm + row
-            m00 = 2 * (tt >> 3) * TW + 2 * (tt & 7) if G == 1 else (tt >> 4) * TH * TW + 2 * ((tt >> 2) & 3) * TW + 2 * (tt & 3)
+            if RT:
+                m00, astep = 4 * tt, 2
+            else:
+                m00 = 2 * (tt >> 3) * TW + 2 * (tt & 7) if G == 1 else (tt >> 4) * TH * TW + 2 * ((tt >> 2) & 3) * TW + 2 * (tt & 3)
+                astep = TW
             for bb in range(2):
                 for ct in range(2):
                     v = -z[bb][ct][row] if neg else z[bb][ct][row]
-                    dst = tiles[i >> 1, m00 + a * TW + bb, ct * 32:ct * 32 + 32]
+                    dst = tiles[i >> 1, m00 + a * astep + bb, ct * 32:ct * 32 + 32]
                     dst[:] = dst + v if add else v
 
     for wave in range(8):
@@ -129,7 +188,18 @@ def run_block(x, upk, geo, mt_id, cb, pad, ho, wo, tiles_x, tiles_per_image):
             to_tile(wave, 1, True, True)
     tile = tiles[0] + tiles[1]
     out = {}
-    for row in range(G * TH * TW):
+    for row in range(256):
+        if RT:
+            tt, wt = row >> 2, geo["wty"] * geo["wtx"]
+            g_, rr = divmod(tt, wt)
+            tyy, txx = divmod(rr, geo["wtx"])
+            win = mt_id * geo["wg"] + g_
+            wi, wr = divmod(win, geo["wins_x"] * geo["wins_y"])
+            wy, wx = divmod(wr, geo["wins_x"])
+            oy, ox = 2 * (wy * geo["wty"] + tyy) + ((row >> 1) & 1), 2 * (wx * geo["wtx"] + txx) + (row & 1)
+            if tt < geo["wg"] * wt and win < n_windows and oy < ho and ox < wo:
+                out[(wi, oy, ox)] = tile[row]
+            continue
         g, rg = divmod(row, TH * TW)
         oy, ox = ty0 + rg // TW, tx0 + rg % TW
         if oy < ho and ox < wo and img + g < n:
@@ -145,10 +215,14 @@ def check(n, hw, cin, cout, pad, seed=0):
     ref = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(wgt), padding=pad).permute(0, 2, 3, 1).numpy()
     upk = pack(wgt)
     small = ho <= 8 and wo <= 8
-    geo = (4, 8, 8, 10, 10, 50, 512) if small else (1, 16, 16, 18, 18, 84, 18 * 84)
+    win = plan_windows(n, ho, wo)
+    geo = win if win is not None else ((4, 8, 8, 10, 10, 50, 512) if small else (1, 16, 16, 18, 18, 84, 18 * 84))
     tiles_y = 1 if small else (ho + 15) // 16
     tiles_x = 1 if small else (wo + 15) // 16
     tiles = (n + 3) // 4 if small else n * tiles_y * tiles_x
+    if win is not None:
+        tiles = -(-n * win["wins_x"] * win["wins_y"] // win["wg"])
+        print("   windows:", win)
     got = np.full_like(ref, np.nan)
     for mt in range(tiles):
         for cb in range(cout // 64):
@@ -177,8 +251,11 @@ def bank_check():
 
 if __name__ == "__main__":
     bank_check()
-    check(1, 16, 16, 64, 1)
-    check(5, 7, 32, 64, 1)       # W8 geometry, odd map, a partial block of images
+    if "--windows-only" not in __import__("sys").argv:
+        check(1, 16, 16, 64, 1)
+        check(5, 7, 32, 64, 1)       # W8 geometry, odd map, a partial block of images
+    check(8, 14, 16, 64, 1)      # window geometry: eight windows of 1 x 7 tiles, blocks across images, a partial last block
+    check(3, 28, 16, 64, 1)      # window geometry: 3 windows of 3 x 7 tiles
     if "--all" in __import__("sys").argv:
         check(1, 20, 16, 128, 1)     # partial blocks, two channel blocks
         check(2, 12, 16, 64, 0)      # valid convolution

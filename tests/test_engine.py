@@ -643,7 +643,10 @@ def test_winograd_conv_matches_torch_cpu_fp32():
     g = torch.Generator().manual_seed(5)
     cases = [(3, 64, 64, 64, 1), (2, 128, 128, 32, 1), (2, 256, 256, 16, 1), (9, 512, 512, 8, 1),      # 256^2 patches' maps
              (2, 64, 64, 56, 1), (3, 128, 128, 28, 1), (5, 256, 256, 14, 1), (6, 512, 512, 7, 1),      # 224^2 patches' maps
-             (1, 16, 64, 16, 1), (2, 32, 192, 20, 0), (2, 16, 64, 19, 2), (1, 48, 128, 9, 1), (7, 64, 64, 5, 1), (1, 64, 64, 33, 1)]
+             (1, 16, 64, 16, 1), (2, 32, 192, 20, 0), (2, 16, 64, 19, 2), (1, 48, 128, 9, 1), (7, 64, 64, 5, 1), (1, 64, 64, 33, 1),
+             # window geometry (maps 16 x 16 blocks cover badly, batches large enough for it to win): 8 x (1 x 7 tiles) on 14^2 with a
+             # partial last block, 3 x (3 x 7) on 28^2, 4 x (4 x 4) on 56^2, odd maps, a valid convolution
+             (9, 64, 64, 14, 1), (4, 32, 128, 28, 1), (4, 32, 64, 56, 1), (6, 32, 64, 21, 1), (3, 32, 64, 42, 0), (5, 16, 64, 37, 1)]
     worst = 0.0
     for n, cin, cout, hw, pad in cases:
         conv = torch.nn.Conv2d(cin, cout, 3, padding=pad, bias=True)

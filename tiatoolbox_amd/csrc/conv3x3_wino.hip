@@ -49,7 +49,20 @@ struct WinoDims {
     unsigned x_bytes, u_bytes;
     int pos_stride;  // bytes between consecutive positions of the packed weights: (cin / 16) * (cout / 64) * 4096
     int abl;         // timing builds only (TIA_WINO_ABL): 1 no weight DMA in the loop, 2 no patch DMA, 4 weight DMA out of range (zeros), 8 half of it
+    // window geometry (WR below): a block = `wg` windows of wty x wtx tiles, taken in order from the batch's window grid (wins_x x
+    // wins_y windows per image); LDS: window pitch `wimg` units, row pitch `wrow` units; the reciprocals serve fdiv()
+    int wg, wty, wtx, wrow, wimg, wins_x, wins_y, n_windows;
+    float inv_wimg, inv_wrow, inv_wt, inv_wtx, inv_wins, inv_wins_x;
 };
+
+// n / d for 0 <= n < 2^24, 0 < d < 2^24 with the reciprocal computed on the host: a float estimate and one correction step each way
+__device__ __forceinline__ int fdiv(int n, int d, float inv) {
+    int q = (int)((float)n * inv);
+    const int r = n - q * d;
+    q += r >= d ? 1 : 0;
+    q -= r < 0 ? 1 : 0;
+    return q;
+}
 
 // Packed float32 add / subtract (two channels per instruction).  Inline assembly: the compiler splits a v2f32 subtraction into two
 // scalar v_sub_f32 (48 of the 56 vector instructions of a load phase), and it is the NUMBER of vector instructions issued beside the
@@ -87,6 +100,14 @@ struct W16 {
 struct W8 {
     static constexpr int G = 4, TH = 8, TW = 8, PH = 10, PWD = 10, ROW = 50, IMG = 512;
 };
+// WR: maps that 16 x 16 blocks cover badly (56 / 28 / 14 of 224^2 patches: 76.6 %): a block is `wg` WINDOWS of wty x wtx tiles
+// (wg * wty * wtx <= 64) taken consecutively from the window grid of the whole batch -- e.g. two windows of 4 x 7 tiles on a 56^2 map,
+// four of 2 x 7 on 28^2, eight of 1 x 7 on 14^2: 87.5 % of the MFMA rows busy, blocks run across image boundaries.  Run-time
+// geometry (WinoDims), host-computed reciprocals; each window keeps its own (2 wty + 2) x (2 wtx + 2) pixel patch (pair layout, no bank
+// analysis: a few 2-way conflicts).  Block pixel m = 4 * tile + 2 a + b.
+struct WR {
+    static constexpr int G = 0, TH = 16, TW = 16, PH = 0, PWD = 0, ROW = 0, IMG = 2560;  // IMG: the LDS patch allocation in units
+};
 // unit offset of pixel column px inside a row
 __device__ __forceinline__ constexpr int px_unit(int px) { return (px >> 1) * 9 + (px & 1) * 4; }
 
@@ -115,9 +136,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
                                                               const float* __restrict__ bias, const float* __restrict__ res,
                                                               float* __restrict__ y, WinoDims d, int relu, int m_tiles, int tiles_x,
                                                               int tiles_per_image) {
-    constexpr int NT = 512, ROW = GEO::ROW, BN = 64;
-    constexpr int BLOCK_PX = GEO::G * GEO::TH * GEO::TW;          // 256 output pixels = 64 tiles
-    constexpr int A_UNITS = (GEO::G * GEO::IMG + 63) / 64 * 64;   // patch units (16 bytes), whole waves: 1536 | 2048
+    constexpr bool RT = GEO::G == 0;                              // run-time window geometry
+    constexpr int NT = 512, BN = 64;
+    const int ROW = RT ? d.wrow : GEO::ROW;                       // (a compile-time constant for the fixed geometries)
+    constexpr int BLOCK_PX = 256;                                 // 256 output pixels = 64 tiles
+    constexpr int A_UNITS = ((RT ? 1 : GEO::G) * GEO::IMG + 63) / 64 * 64;   // patch units (16 bytes), whole waves: 1536 | 2048 | 2560
     constexpr int NA = (A_UNITS + NT - 1) / NT;                   // DMA pieces per patch: 3 | 4
     constexpr int A_BYTES = A_UNITS * 16;
     constexpr int W_STAGE = 16 * 2048;                            // 16 positions x [8 channels][64 columns] float32
@@ -137,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     const int per_xcd = (m_tiles + 7) / 8;
     const int mt_id = (bid % 8) * per_xcd + bid / 8;  // every XCD walks a contiguous range of pixel blocks
     if (mt_id >= m_tiles) return;
-    const int img = GEO::G == 1 ? mt_id / tiles_per_image : mt_id * GEO::G;
+    const int img = RT ? 0 : (GEO::G == 1 ? mt_id / tiles_per_image : mt_id * GEO::G);  // (WR: windows carry their own image)
     const int trem = GEO::G == 1 ? mt_id - img * tiles_per_image : 0;
     const int ty0 = (trem / tiles_x) * GEO::TH;
     const int tx0 = (trem - (trem / tiles_x) * tiles_x) * GEO::TW;
@@ -157,14 +180,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
         const int un = NT * r + tid;
-        const int g = un / GEO::IMG, ug = un - g * GEO::IMG;
-        const int py = ug / ROW, rem = ug - py * ROW;
-        const int pair = rem / 9, r9 = rem - pair * 9;
-        const int px = 2 * pair + (r9 >> 2), chunk = r9 == 8 ? 4 : (r9 & 3);  // (unit 8 of a pair: padding)
-        const int iy = ty0 - d.pad_y + py, ix = tx0 - d.pad_x + px;
-        const bool inside = g < GEO::G && img + g < d.n && py < GEO::PH && px < GEO::PWD && chunk < 4 && (unsigned)iy < (unsigned)d.h &&
-                            (unsigned)ix < (unsigned)d.w;
-        cen[r] = inside ? (((img + g) * d.h + iy) * d.w + ix) * d.cin * 4 + 16 * chunk : OOB;
+        if constexpr (RT) {
+            const int g = fdiv(un, d.wimg, d.inv_wimg), ug = un - g * d.wimg;
+            const int py = fdiv(ug, d.wrow, d.inv_wrow), rem = ug - py * d.wrow;
+            const int pair = rem / 9, r9 = rem - pair * 9;
+            const int px = 2 * pair + (r9 >> 2), chunk = r9 == 8 ? 4 : (r9 & 3);
+            const int win = mt_id * d.wg + g;                                    // window of the batch
+            const int wi = fdiv(win, d.wins_x * d.wins_y, d.inv_wins), wr = win - wi * d.wins_x * d.wins_y;  // image, window in it
+            const int wy = fdiv(wr, d.wins_x, d.inv_wins_x), wx = wr - wy * d.wins_x;
+            const int iy = wy * 2 * d.wty - d.pad_y + py, ix = wx * 2 * d.wtx - d.pad_x + px;
+            const bool inside = g < d.wg && win < d.n_windows && py < 2 * d.wty + 2 && px < 2 * d.wtx + 2 && chunk < 4 &&
+                                (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
+            cen[r] = inside ? ((wi * d.h + iy) * d.w + ix) * d.cin * 4 + 16 * chunk : OOB;
+        } else {
+            const int g = un / GEO::IMG, ug = un - g * GEO::IMG;
+            const int py = ug / ROW, rem = ug - py * ROW;
+            const int pair = rem / 9, r9 = rem - pair * 9;
+            const int px = 2 * pair + (r9 >> 2), chunk = r9 == 8 ? 4 : (r9 & 3);  // (unit 8 of a pair: padding)
+            const int iy = ty0 - d.pad_y + py, ix = tx0 - d.pad_x + px;
+            const bool inside = g < GEO::G && img + g < d.n && py < GEO::PH && px < GEO::PWD && chunk < 4 && (unsigned)iy < (unsigned)d.h &&
+                                (unsigned)ix < (unsigned)d.w;
+            cen[r] = inside ? (((img + g) * d.h + iy) * d.w + ix) * d.cin * 4 + 16 * chunk : OOB;
+        }
     }
     const int n_cs = d.cin >> 4, n_cb = d.cout >> 6;
     // weight staging: a stage = 16 position blocks of 2 KB; DMA round q (0..3) moves positions 4 q + (wave >> 1): per lane the offset
@@ -177,6 +214,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
 #if TIA_WINO_TIMING
         if ((d.abl & 2) && cs > 0) return;
 #endif
+        if constexpr (RT) {
+            if (NT * r >= d.wg * d.wimg) return;  // (scalar) pieces past the block's windows: nothing of them is ever read
+        }
         unsigned char* dst = (NT * r + wave_s * 64 >= A_UNITS) ? smem + DUMP : abuf0 + buf * A_BYTES + r * (NT * 16) + wave_s * 1024;
         dma16(rx, dst, cen[r], cs * 64);
     };
@@ -201,7 +241,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     // lane's k values of a step are channels 8 h8 + 4 hi + 0..3 = unit 2 h8 + hi of the pixel
     const int t = 32 * wm + (lane & 31);
     int fa;
-    if constexpr (GEO::G == 1) {
+    if constexpr (RT) {
+        const int wt = d.wty * d.wtx;
+        const int tv = t < d.wg * wt ? t : 0;  // idle MFMA rows read tile 0 (their results are dropped)
+        const int g = fdiv(tv, wt, d.inv_wt), rr = tv - g * wt;
+        const int tyy = fdiv(rr, d.wtx, d.inv_wtx), txx = rr - tyy * d.wtx;
+        fa = g * d.wimg + 2 * tyy * d.wrow + txx * 9 + hi;
+    } else if constexpr (GEO::G == 1) {
         fa = 2 * (t >> 3) * ROW + (t & 7) * 9 + hi;
     } else {
         fa = (t >> 4) * GEO::IMG + 2 * ((t >> 2) & 3) * ROW + (t & 3) * 9 + hi;
@@ -224,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     f32x2 vreg[4][2];  // V_j of the step whose MFMAs are next, four channels as two pairs
     u32x4 wq[4][2];    // [j][channel tile]: four k values each
     u32x4 pa[4], pb[4];  // raw patch units of the NEXT step (rows ra / rb, columns 0..3)
-    constexpr int RA0 = 0 * ROW, RB0 = 2 * ROW, RA1 = 1 * ROW, RB1 = 2 * ROW, RA2 = 2 * ROW, RB2 = 1 * ROW, RA3 = 1 * ROW, RB3 = 3 * ROW;
+    const int RA0 = 0 * ROW, RB0 = 2 * ROW, RA1 = 1 * ROW, RB1 = 2 * ROW, RA2 = 2 * ROW, RB2 = 1 * ROW, RA3 = 1 * ROW, RB3 = 3 * ROW;
     // R = d[ra] +- d[rb]: i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3 (per-wave constants: the row offsets go into one register each)
     const int ra_off = irow == 0 ? RA0 : (irow == 1 ? RA1 : (irow == 2 ? RA2 : RA3));
     const int rb_off = irow == 0 ? RB0 : (irow == 1 ? RB1 : (irow == 2 ? RB2 : RB3));
@@ -363,10 +409,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int row = (tid + NT * it) / (BN / 8);
-        const int g = row / (GEO::TH * GEO::TW), rg = row - g * (GEO::TH * GEO::TW);
-        const int oy = ty0 + rg / GEO::TW, ox = tx0 + rg % GEO::TW;
-        const bool live = oy < d.ho && ox < d.wo && img + g < d.n;
-        mpix[it] = live ? ((img + g) * d.ho + oy) * d.wo + ox : -1;
+        if constexpr (RT) {  // block pixel = 4 * tile + 2 a + b
+            const int tt = row >> 2, wt = d.wty * d.wtx;
+            const int g = fdiv(tt, wt, d.inv_wt), rr = tt - g * wt;
+            const int tyy = fdiv(rr, d.wtx, d.inv_wtx), txx = rr - tyy * d.wtx;
+            const int win = mt_id * d.wg + g;
+            const int wi = fdiv(win, d.wins_x * d.wins_y, d.inv_wins), wr = win - wi * d.wins_x * d.wins_y;
+            const int wy = fdiv(wr, d.wins_x, d.inv_wins_x), wx = wr - wy * d.wins_x;
+            const int oy = 2 * (wy * d.wty + tyy) + ((row >> 1) & 1), ox = 2 * (wx * d.wtx + txx) + (row & 1);
+            const bool live = tt < d.wg * wt && win < d.n_windows && oy < d.ho && ox < d.wo;
+            mpix[it] = live ? (wi * d.ho + oy) * d.wo + ox : -1;
+        } else {
+            const int g = row / (GEO::TH * GEO::TW), rg = row - g * (GEO::TH * GEO::TW);
+            const int oy = ty0 + rg / GEO::TW, ox = tx0 + rg % GEO::TW;
+            const bool live = oy < d.ho && ox < d.wo && img + g < d.n;
+            mpix[it] = live ? ((img + g) * d.ho + oy) * d.wo + ox : -1;
+        }
+        const bool live = mpix[it] >= 0;
         rq[it][0] = rq[it][1] = u32x4{0u, 0u, 0u, 0u};
         if (res && live) {
             const u32x4* rp = reinterpret_cast<const u32x4*>(res + (long)mpix[it] * d.cout + col0);
@@ -386,7 +445,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         for (int e = 0; e < 16; ++e) {
             const int tt = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * hi;  // MFMA result row -> tile
             int m00;
-            if constexpr (GEO::G == 1) {
+            constexpr int ASTEP = RT ? 2 : GEO::TW;  // block pixels between the tile's two output rows
+            if constexpr (RT) {
+                m00 = 4 * tt;
+            } else if constexpr (GEO::G == 1) {
                 m00 = 2 * (tt >> 3) * GEO::TW + 2 * (tt & 7);
             } else {
                 m00 = (tt >> 4) * (GEO::TH * GEO::TW) + 2 * ((tt >> 2) & 3) * GEO::TW + 2 * (tt & 3);
@@ -395,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    float* p = tile + (m00 + a * GEO::TW + b) * BN + ct * 32 + (lane & 31);
+                    float* p = tile + (m00 + a * ASTEP + b) * BN + ct * 32 + (lane & 31);
                     const float v = neg ? -z[b][ct][e] : z[b][ct][e];
                     *p = add ? *p + v : v;
                 }
@@ -490,20 +552,65 @@ bool conv3x3_wino_serves(long nb, long h, long w, long cin, long cout, long pad_
     return nb > 0 && h > 0 && w > 0 && 16L * cin * cout * 4 <= 0x7fffffffL;
 }
 
+// Window geometry for maps that 16 x 16 blocks cover badly: the (wg, wty, wtx) with wg * wty * wtx <= 64 that keeps most MFMA rows
+// busy over the whole batch (blocks run across images), patch within the LDS allocation; ties: the smaller patch.
+struct WinoPlan {
+    int kind;  // 0: 16 x 16 blocks, 1: four images of <= 8 x 8, 2: windows
+    int wg, wty, wtx, wrow, wimg, wins_x, wins_y;
+    double busy;
+};
+static WinoPlan wino_plan(long nb, long ho, long wo) {
+    static const bool no_windows = getenv("TIA_WINO_NO_WINDOWS") != nullptr;  // developer switch (A/B measurements)
+    if (ho <= 8 && wo <= 8) return WinoPlan{1, 0, 0, 0, 0, 0, 0, 0, (double)(ho * wo) / 64.0};
+    const long tiles_y = (ho + 1) / 2, tiles_x = (wo + 1) / 2;
+    const double busy16 = (double)(ho * wo) / (double)(((ho + 15) / 16) * ((wo + 15) / 16) * 256);
+    WinoPlan best{0, 0, 0, 0, 0, 0, 0, 0, busy16};
+    if (no_windows || busy16 >= 0.9) return best;
+    long best_units = 0;
+    for (int wty = 1; wty <= 8; ++wty)
+        for (int wtx = 1; wtx <= 16; ++wtx) {
+            const int wt = wty * wtx;
+            if (wt > 64) continue;
+            const int wrow = (wtx + 1) * 9, wimg = ((2 * wty + 2) * wrow + 15) / 16 * 16;
+            const long wins_x = (tiles_x + wtx - 1) / wtx, wins_y = (tiles_y + wty - 1) / wty;
+            for (int wg = 64 / wt; wg >= 1 && wg > 64 / wt - 3; --wg) {  // (a window less than fit the MFMA rows may fit the LDS)
+                if ((long)wg * wimg > 2560 || wg > 16) continue;
+                const long blocks = (nb * wins_x * wins_y + wg - 1) / wg;
+                const double busy = (double)(nb * ho * wo) / (double)(blocks * 256);
+                const long units = (long)wg * wimg;
+                if (busy > best.busy + 0.02 || (best.kind == 2 && busy > best.busy - 1e-9 && units < best_units)) {
+                    best = WinoPlan{2, wg, wty, wtx, wrow, wimg, (int)wins_x, (int)wins_y, busy};
+                    best_units = units;
+                }
+            }
+        }
+    return best;
+}
+
 int conv3x3_wino_launch(const float* x, const float* u_packed, const float* bias, const float* residual, float* y, long nb, long h,
                         long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo, int relu, hipStream_t stream) {
     if (!conv3x3_wino_serves(nb, h, w, cin, cout, pad_top, pad_left, ho, wo)) return TIA_ESIZE;
-    const bool small = ho <= 8 && wo <= 8;
+    const WinoPlan plan = wino_plan(nb, ho, wo);
+    const bool small = plan.kind == 1;
     const long tiles_y = small ? 1 : (ho + 15) / 16, tiles_x = small ? 1 : (wo + 15) / 16;
-    const long tiles = small ? (nb + 3) / 4 : nb * tiles_y * tiles_x;
-    const WinoDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
-                     (unsigned)(nb * h * w * cin * 4), (unsigned)(16 * cin * cout * 4), (int)((cin / 16) * (cout / 64) * 4096),
-                     getenv("TIA_WINO_ABL") ? atoi(getenv("TIA_WINO_ABL")) : 0};
+    const long n_windows = plan.kind == 2 ? nb * plan.wins_x * plan.wins_y : 0;
+    const long tiles = plan.kind == 2 ? (n_windows + plan.wg - 1) / plan.wg : (small ? (nb + 3) / 4 : nb * tiles_y * tiles_x);
+    WinoDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
+               (unsigned)(nb * h * w * cin * 4), (unsigned)(16 * cin * cout * 4), (int)((cin / 16) * (cout / 64) * 4096),
+               getenv("TIA_WINO_ABL") ? atoi(getenv("TIA_WINO_ABL")) : 0,
+               1, 1, 1, 9, 16, 1, 1, 0, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+    if (plan.kind == 2) {
+        if (n_windows >= (1L << 24)) return TIA_ESIZE;  // fdiv() range (the callers keep the input below 2 GiB)
+        d.wg = plan.wg, d.wty = plan.wty, d.wtx = plan.wtx, d.wrow = plan.wrow, d.wimg = plan.wimg;
+        d.wins_x = plan.wins_x, d.wins_y = plan.wins_y, d.n_windows = (int)n_windows;
+        d.inv_wimg = 1.0f / (float)plan.wimg, d.inv_wrow = 1.0f / (float)plan.wrow, d.inv_wt = 1.0f / (float)(plan.wty * plan.wtx);
+        d.inv_wtx = 1.0f / (float)plan.wtx, d.inv_wins = 1.0f / (float)(plan.wins_x * plan.wins_y), d.inv_wins_x = 1.0f / (float)plan.wins_x;
+    }
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / 64));
-    static tia::DeviceOnce attr16, attr8;  // the dynamic-LDS attribute is per device
+    static tia::DeviceOnce attr16, attr8, attrw;  // the dynamic-LDS attribute is per device
 #define TIA_WINO_LAUNCH(GEO_, NS_, ONCE_)                                                                                            \
     do {                                                                                                                             \
-        constexpr int lds = wino_lds_bytes(GEO_::G * GEO_::IMG, NS_);                                                                \
+        constexpr int lds = wino_lds_bytes((GEO_::G == 0 ? 1 : GEO_::G) * GEO_::IMG, NS_);                                          \
         static_assert(lds <= 160 * 1024, "LDS");                                                                                     \
         if (!ONCE_.ensure([] {                                                                                                       \
                 return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<GEO_, NS_>),                            \
@@ -513,8 +620,10 @@ int conv3x3_wino_launch(const float* x, const float* u_packed, const float* bias
         hipLaunchKernelGGL((conv3x3_wino_kernel<GEO_, NS_>), grid, dim3(512), lds, stream, x, u_packed, bias, residual, y, d, relu,   \
                            (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x));                                                      \
     } while (0)
-    if (small)
+    if (plan.kind == 1)
         TIA_WINO_LAUNCH(W8, 2, attr8);
+    else if (plan.kind == 2)
+        TIA_WINO_LAUNCH(WR, 2, attrw);
     else
         TIA_WINO_LAUNCH(W16, 2, attr16);
 #undef TIA_WINO_LAUNCH
