@@ -685,6 +685,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                 t_blocks_w = ev_time(lambda: trunk_w.blocks(feat), reps=5)
             engine.conv_algo = "direct"
             wl, ws = acc["launches"] // 3, acc["seconds"] / 3
+            pmc_w = pmc_traffic("conv3x3_wino_kernel", "wino") if (mb, hw) == (1024, 256) else None
             extras["cnn_winograd"] = {
                 "value": round(n * k_extra / el_w, 2), "unit": "patches/s", "ms_per_step": round(el_w / k_extra * 1e3, 3),
                 "max_abs_dprob_vs_direct_float32": dpw, "tolerance": 1e-5, "within_tolerance": bool(dpw <= 1e-5),
@@ -698,7 +699,10 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                              "what": ("Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32: `achieved` / `frac` from the flops the MFMAs EXECUTE "
                                       "(16 multiplies per 2x2 outputs, 64-tile x 64-channel blocks as launched); `effective_tflops` = the "
                                       "direct convolution's 2*M*Cout*Cin*9 over the same time (may exceed the MFMA peak)"),
-                             "blocks_ms": round(t_blocks_w * 1e3, 3)},
+                             "blocks_ms": round(t_blocks_w * 1e3, 3),
+                             "traffic": round(pmc_w["bytes"]) if pmc_w else None,
+                             **({"traffic_source": pmc_w["source"] + " (scripts/perf_wino.py 1024 256: mean over the launches of this kernel)"}
+                                if pmc_w else {})},
                 "note": ("extra only: the float32 3x3 / stride-1 block convolutions through Winograd F(2x2, 3x3) (float32 in / float32 "
                          "accumulate, weights transformed once in float64); same stain front-end, stem, strided / 1x1 convolutions as `value`")}
         if hw != 224:
