@@ -237,6 +237,22 @@ struct ApplyCtxFast {
     }
 };
 
+// Product-of-tables form of the same float64 recomposition (round 5): the output optical density is LINEAR in the
+// three input optical densities, OD'_c = sum_j LUT[v_j] m[j][c], and each LUT[v_j] takes 256 values, so
+//   255 exp(-OD'_c) = (255 exp(-LUT[r] m[0][c])) * exp(-LUT[g] m[1][c]) * exp(-LUT[b] m[2][c]) = T_0c[r] * T_1c[g] * T_2c[b]
+// with nine 256-entry float64 tables per patch (2,304 libm `exp` per workgroup instead of three exponentials per pixel): per
+// pixel 9 LDS reads, 6 multiplies and the reference's clip -- the kernel stops being bound by float64 vector arithmetic (60
+// operations per pixel, §4.10) and runs at the memory system's pace.  Each factor is a correctly rounded-ish exp (< 1 ulp), the
+// product three roundings more: relative error <= ~3e-16, i.e. < 1e-13 on the 0..255 scale (the exponent-trick form: 1e-12).
+// Valid while every |LUT[v] m[j][c]| stays far inside exp's range (5.5414 * max |m| < 700: checked per patch, else the libm context).
+struct ApplyCtxTab {
+    const double* pt;  // [9][256]: pt[(3 j + c) * 256 + v]
+    __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, double (&o)[3]) const {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = __builtin_fmin(pt[c * 256 + r] * pt[(3 + c) * 256 + g] * pt[(6 + c) * 256 + b], 255.0);
+    }
+};
+
 // one 12-byte group (4 whole pixels) per lane and step, U independent groups in flight
 template <int OUT, int U, class Ctx, class F>
 __device__ __forceinline__ void sweep12(const Ctx& ctx, const uint8_t* __restrict__ src, typename Out<OUT>::T* __restrict__ dst,
@@ -433,7 +449,7 @@ __device__ __forceinline__ void sweep_wide(const Ctx& ctx, uint8_t* mine, const 
     }
 }
 
-template <int MATH, int OUT>
+template <int MATH, int OUT, bool PT = false>
 __global__ __launch_bounds__(AT) void stain_apply_wide_kernel(const uint8_t* __restrict__ img, long hw,
                                                                const tia_stain_tables* __restrict__ tab,
                                                                const double* __restrict__ stats, StainT tgt,
@@ -456,6 +472,30 @@ __global__ __launch_bounds__(AT) void stain_apply_wide_kernel(const uint8_t* __r
         ctx.bank = threadIdx.x & (REP - 1);
         __syncthreads();
         sweep_wide<OUT, ApplyCtx<TIA_MATH_F32>, float>(ctx, mine, src, dst, hw);
+    } else if constexpr (PT) {
+        __shared__ double ptab[9 * 256];
+        __shared__ double lut[256];  // (only the libm fall-back reads it)
+        double amax = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) amax = fmax(amax, fabs(st[TIA_ST_M + k]));
+        const bool ok = amax * 5.5414 < 700.0;  // also false for NaN / inf
+        for (int i = threadIdx.x; i < 256; i += AT) lut[i] = tab->od_lut[i];
+        if (ok) {
+            for (int i = threadIdx.x; i < 9 * 256; i += AT) {
+                const int k = i >> 8, v = i & 255;
+                const double e = exp(-(tab->od_lut[v] * st[TIA_ST_M + k]));
+                ptab[i] = k < 3 ? 255.0 * e : e;
+            }
+        }
+        __syncthreads();
+        if (ok) {
+            ApplyCtxTab ctx{ptab};
+            sweep_wide<OUT, ApplyCtxTab, double>(ctx, mine, src, dst, hw);
+        } else {
+            ApplyCtx<TIA_MATH_F64_REF> ctx;
+            load_ref_ctx(ctx, st, tgt, lut);
+            sweep12<OUT, 1, ApplyCtx<TIA_MATH_F64_REF>, double>(ctx, src, reinterpret_cast<typename Out<OUT>::T*>(dst), hw);
+        }
     } else {
         __shared__ double lut[256];
         __shared__ double etab[1024];
@@ -761,6 +801,19 @@ static int launch_apply(const uint8_t* d_img, int64_t n, long hw, const tia_stai
             const long want = (4096 + (long)n - 1) / (long)n;  // ... unless the batch already fills the chip
             if (bx > want) bx = want;
             dim3 wgrid((unsigned)(bx < 1 ? 1 : bx), (unsigned)n);
+            if constexpr (MATH == TIA_MATH_F64) {
+                // float64: the product-of-tables form (TIA_APPLY_NO_PTAB keeps the exponent-trick form: developer switch, A/B measurements)
+                static const bool no_ptab = getenv("TIA_APPLY_NO_PTAB") != nullptr;
+                if (!no_ptab) {
+                    if (out_kind == TIA_OUT_U8)
+                        hipLaunchKernelGGL((stain_apply_wide_kernel<MATH, TIA_OUT_U8, true>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, tgt, out);
+                    else if (out_kind == TIA_OUT_UNIT_F16)
+                        hipLaunchKernelGGL((stain_apply_wide_kernel<MATH, TIA_OUT_UNIT_F16, true>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, tgt, out);
+                    else
+                        hipLaunchKernelGGL((stain_apply_wide_kernel<MATH, TIA_OUT_UNIT_BF16, true>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, tgt, out);
+                    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+                }
+            }
             if (out_kind == TIA_OUT_U8)
                 hipLaunchKernelGGL((stain_apply_wide_kernel<MATH, TIA_OUT_U8>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, tgt, out);
             else if (out_kind == TIA_OUT_UNIT_F16)
