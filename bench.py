@@ -54,7 +54,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--config", default="patch", choices=["patch", "semantic", "hovernet", "vahadane"])
     ap.add_argument("--patches", type=int, default=4096, help="patches per GPU per step")
     ap.add_argument("--patch-size", type=int, default=256, help="BASELINE.json metric: 256 (configs[1]: 224)")
-    ap.add_argument("--micro-batch", type=int, default=1024, help="engine batch_size (CNN forward batch)")
+    ap.add_argument("--micro-batch", type=int, default=4096, help="engine batch_size (CNN forward batch)")
     ap.add_argument("--dtype", default=os.environ.get("TIA_BENCH_DTYPE", "float32"),
                     choices=["float32", "float16", "bfloat16"], help="CNN arithmetic (reference: float32)")
     ap.add_argument("--precision", default="f64", choices=["f32", "f64"],

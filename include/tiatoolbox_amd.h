@@ -451,8 +451,9 @@ int tia_conv2d_nhwc_f32_ex(const float* d_x, const float* d_w_packed, const floa
 /* Which block geometry tia_conv2d_nhwc_f32(_ex) / tia_conv2d_nhwc_h use for a 3x3 / stride-1 convolution of an [h, w] map to
  * [ho, wo] in float32 (diagnostics for tests and profiles; host only, no launch).  Returns 0: the slice implicit-GEMM kernel;
  * 1: tap reuse on 16 x 16 pixel blocks; 2: tap reuse, two images of at most 8 x 8 per block; 3: tap reuse on bands of geom[1]
- * rows of a geom[0]-column strip of the batch stacked into one tall image.
- * geom[0..3] = strip width, rows per band, LDS row pitch (16-byte units), strips per image row (zeros unless 3). */
+ * rows of a geom[0]-column strip of the batch stacked into one tall image with a zero row between neighbours; 4: the same with
+ * bands of geom[1] REAL rows (the zero rows are in the block's LDS patch, not among its GEMM rows).
+ * geom[0..3] = strip width, rows per band, LDS row pitch (16-byte units), strips per image row (zeros unless 3 / 4). */
 int tia_conv3x3_geometry(int64_t h, int64_t w, int64_t ho, int64_t wo, int64_t pad_top, int64_t pad_left, int32_t geom[4]);
 
 /* Convolution over a THIN input (c * kw <= 32, e.g. the 3-channel 7x7 stem of HoVer-Net, models/architecture/hovernet.py:

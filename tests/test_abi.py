@@ -124,8 +124,8 @@ def test_package_level_names_of_the_reference_layout():
 def test_host_only_dispatch_queries():
     """``tia_conv3x3_geometry`` / ``tia_stain_stats_path`` answer on the host (no launch): which block geometry a 3x3 / stride-1
     convolution gets and which statistics kernel a patch shape gets -- the dispatch the GPU tests and the bench rely on.
-    Band geometry: strips of ``bw`` columns x ``br`` rows of the stacked batch with ``bw * br <= 256``, LDS patch
-    ``(br + 2) * row_pitch <= 1728`` units, ``bw * strips == w``; only for "same" padding, only above 0.88 busy."""
+    Band geometry: strips of ``bw`` columns x ``br`` real rows of the stacked batch with ``bw * br <= 256``, LDS patch
+    ``(br + zero rows straddled + 2) * row_pitch <= 1728`` units, ``bw * strips == w``; only for "same" padding, only above 0.88 busy."""
     import ctypes
 
     import pytest
@@ -140,22 +140,25 @@ def test_host_only_dispatch_queries():
         geom = (ctypes.c_int32 * 4)()
         return lib.tia_conv3x3_geometry(h, w, ho, wo, pad, pad, geom), list(geom)
 
-    # resnet maps of 224^2 patches: 56 / 28 / 14 on bands, 7 on the slice kernel; of 256^2 patches: fixed geometries
-    assert geometry(56, 56, 56, 56, 1) == (3, [28, 9, 120, 2])
-    assert geometry(28, 28, 28, 28, 1) == (3, [28, 9, 120, 1])
-    assert geometry(14, 14, 14, 14, 1) == (3, [14, 18, 64, 1])
-    assert geometry(7, 7, 7, 7, 1)[0] == 0
+    # resnet maps of 224^2 patches: 56 / 28 / 14 / 7 on bands of real rows; of 256^2 patches: fixed geometries
+    assert geometry(56, 56, 56, 56, 1) == (4, [8, 32, 40, 7])
+    assert geometry(28, 28, 28, 28, 1) == (4, [4, 64, 24, 7])
+    assert geometry(14, 14, 14, 14, 1) == (4, [14, 18, 64, 1])
+    assert geometry(7, 7, 7, 7, 1) == (4, [7, 36, 36, 1])  # 36 real rows + the five zero rows they can straddle + 2 halo rows
+    assert geometry(3, 3, 3, 3, 1)[0] == 0
     for side in (64, 32, 16, 128, 512):
         assert geometry(side, side, side, side, 1) == (1, [0, 0, 0, 0])
     assert geometry(8, 8, 8, 8, 1)[0] == 2
     # the kernel a float32 convolution runs on (0 slice / 1 tap reuse / 2 LDS-DMA ring): resnet18 on a 1024-patch batch (a host
-    # without a GPU answers for 256 CUs) -- stride-2 3x3 on the gathering ring while its rounds are >= 85 % full, 7 x 7 maps and
-    # small batches on the slice kernel, 1x1 down-sampling on the ring
+    # without a GPU answers for 256 CUs) -- stride-2 3x3 on the gathering ring while its rounds are >= 85 % full, small
+    # batches (and a 7 x 7 launch of 1.56 workgroup rounds) on the slice kernel, 1x1 down-sampling on the ring
     def route(n, hw, cin, cout, k, stride, pad):
         ho = (hw + 2 * pad - k) // stride + 1
         return lib.tia_conv2d_route_f32(n, hw, hw, cin, cout, k, k, stride, pad, pad, ho, ho)
 
     assert route(1024, 64, 64, 64, 3, 1, 1) == 1 and route(1024, 8, 512, 512, 3, 1, 1) == 1
+    # bands of 7 x 7 maps: taken for one round of workgroups or for well-filled launches, not for 1.56 rounds (1024 patches)
+    assert route(4096, 7, 512, 512, 3, 1, 1) == 1 and route(256, 7, 512, 512, 3, 1, 1) == 1 and route(1024, 14, 256, 256, 3, 1, 1) == 1
     assert route(1024, 64, 64, 128, 3, 2, 1) == 2 and route(1024, 32, 128, 256, 3, 2, 1) == 2 and route(1024, 16, 256, 512, 3, 2, 1) == 2  # noqa: PLR2004
     assert route(1024, 56, 64, 128, 3, 2, 1) == 2 and route(1024, 28, 128, 256, 3, 2, 1) == 0 and route(1024, 7, 512, 512, 3, 1, 1) == 0  # noqa: PLR2004
     assert route(1024, 64, 64, 128, 1, 2, 0) == 2 and route(4, 64, 64, 128, 3, 2, 1) == 0 and route(1024, 64, 64, 64, 1, 1, 0) == 0  # noqa: PLR2004
@@ -168,12 +171,15 @@ def test_host_only_dispatch_queries():
     assert geometry(164, 164, 162, 162, 0)[0] == 0 and geometry(64, 64, 62, 62, 0)[0] == 1
     for h in range(9, 130):
         kind, (bw, br, pitch, strips) = geometry(h, h, h, h, 1)
-        if kind == 3:
-            assert bw * strips == h and bw * br <= 256 and (br + 2) * pitch <= 1728 and pitch >= 4 * (bw + 2)
-            assert bw * br / 256 * h / (h + 1) >= 0.88
+        if kind == 3:  # noqa: PLR2004  (zero rows among the GEMM rows: where the larger patch of kind 4 would cost a band row)
+            assert bw * strips == h and bw * br <= 256 and (br + 2) * pitch <= 1728 and pitch >= 4 * (bw + 2)  # noqa: PLR2004
+            assert bw * br / 256 * h / (h + 1) >= 0.88  # noqa: PLR2004
+        if kind == 4:  # noqa: PLR2004
+            assert bw * strips == h and bw * br <= 256 and pitch >= 4 * (bw + 2)
+            assert (br + (br + h - 2) // h + 2) * pitch <= 1728 and bw * br / 256 >= 0.88  # noqa: PLR2004
     # rectangular maps: the strip width divides the map width
     kind, (bw, br, pitch, strips) = geometry(40, 56, 40, 56, 1)
-    assert kind == 3 and bw * strips == 56
+    assert kind == 4 and bw * strips == 56  # noqa: PLR2004
 
     from tiatoolbox_amd.tools import _stain_device as dev
 

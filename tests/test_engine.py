@@ -274,10 +274,12 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
              (1, 32, 64, 9, 3, 1), (2, 64, 64, 13, 3, 2),
              # 3x3 / stride 1 on maps covered well by 16 x 16 pixel blocks: the tap-reuse kernel (whole / clipped blocks, both widths)
              (2, 64, 64, 32, 3, 1), (1, 96, 128, 30, 3, 1), (2, 32, 192, 48, 3, 1), (1, 256, 64, 16, 3, 1),
-             # band geometry (maps 16 x 16 blocks cover badly): bands that straddle images / end inside the last image, one and
-             # two strips, 64- and 128-column tiles (7 x 7 maps stay on the slice kernel)
+             # band geometry (maps 16 x 16 blocks cover badly): bands of real rows that straddle images (up to five zero rows inside a
+             # 7-wide band's patch) / end inside the last image / are the only block of the launch, one and two strips, 64- and
+             # 128-column tiles
              (1, 64, 64, 56, 3, 1), (4, 64, 128, 28, 3, 1), (9, 128, 64, 14, 3, 1), (1, 256, 256, 14, 3, 1), (11, 64, 128, 7, 3, 1),
-             (2, 96, 64, 28, 3, 1), (3, 64, 64, 42, 3, 1), (2, 64, 64, 21, 3, 1),
+             (2, 96, 64, 28, 3, 1), (3, 64, 64, 42, 3, 1), (2, 64, 64, 21, 3, 1), (37, 128, 128, 7, 3, 1), (1, 64, 64, 7, 3, 1),
+             (6, 32, 64, 5, 3, 1),
              # 8 x 8 maps: two images per block (odd batch: the last block holds one image)
              (5, 256, 512, 8, 3, 1), (4, 64, 64, 8, 3, 1), (1, 32, 128, 8, 3, 1),
              # 1x1 (the ring GEMM): stride 1 and 2, few and many channel slices, pixel counts that are no multiple of 256
@@ -285,8 +287,10 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
              # ... and large enough for the ring GEMM's dispatch rule (>= 384 workgroups of 256 pixels x 128 channels)
              (2, 64, 128, 224, 1, 1), (4, 64, 256, 224, 1, 2), (3, 96, 128, 187, 1, 1),
              # the ring gathering 3x3 taps (layers the tap-reuse kernel leaves, >= 384 workgroups): stride 2 with "same" padding on even
-             # and odd maps, 7 x 7 maps at stride 1 (every tap pattern of a border pixel), ragged last block
-             (160, 64, 128, 56, 3, 2), (48, 32, 128, 99, 3, 2), (600, 64, 512, 7, 3, 1), (2400, 96, 128, 7, 3, 1)]
+             # and odd maps, 3 x 3 maps at stride 1 (too narrow for a band; every tap pattern of a border pixel), ragged last block;
+             # then large batches of 7 x 7 maps on the band geometry (many bands, several column tiles)
+             (160, 64, 128, 56, 3, 2), (48, 32, 128, 99, 3, 2), (12500, 64, 128, 3, 3, 1), (12400, 32, 256, 3, 3, 1),
+             (600, 64, 512, 7, 3, 1), (2400, 96, 128, 7, 3, 1)]
     import ctypes
 
     from tiatoolbox_amd import _lib
@@ -296,10 +300,10 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
         return _lib.load().tia_conv3x3_geometry(hw_in, hw_in, hw_out, hw_out, pad, pad, geom), list(geom)
 
     # the dispatch the cases below rely on: 224^2 patches' maps on the band geometry, 256^2 patches' maps on the fixed ones
-    assert geometry(56, 56, 1) == (3, [28, 9, 120, 2]) and geometry(28, 28, 1) == (3, [28, 9, 120, 1])
-    assert geometry(14, 14, 1) == (3, [14, 18, 64, 1]) and geometry(7, 7, 1)[0] == 0
+    assert geometry(56, 56, 1) == (4, [8, 32, 40, 7]) and geometry(28, 28, 1) == (4, [4, 64, 24, 7])
+    assert geometry(14, 14, 1) == (4, [14, 18, 64, 1]) and geometry(7, 7, 1) == (4, [7, 36, 36, 1]) and geometry(3, 3, 1)[0] == 0
     assert geometry(64, 64, 1)[0] == 1 and geometry(16, 16, 1)[0] == 1 and geometry(8, 8, 1)[0] == 2
-    assert geometry(164, 162, 0)[0] == 0 and geometry(42, 42, 1)[0] == 3 and geometry(21, 21, 1)[0] == 3
+    assert geometry(164, 162, 0)[0] == 0 and geometry(42, 42, 1)[0] == 4 and geometry(21, 21, 1)[0] == 4 and geometry(5, 5, 1)[0] == 4
     for n, cin, cout, hw, k, stride in cases:
         pad = 1 if k == 3 else 0
         conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=True)
@@ -324,7 +328,8 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
             assert err <= 1e-4, (n, cin, cout, hw, k, stride, use_res, relu, err)
         if n >= 40:  # noqa: PLR2004
             ho_ = ref_lin.shape[2]
-            assert _lib.load().tia_conv2d_route_f32(n, hw, hw, cin, cout, k, k, stride, pad, pad, ho_, ho_) == 2  # the gathering ring  # noqa: PLR2004
+            # the gathering ring; 7 x 7 maps: the tap-reuse kernel's bands
+            assert _lib.load().tia_conv2d_route_f32(n, hw, hw, cin, cout, k, k, stride, pad, pad, ho_, ho_) == (1 if hw == 7 else 2)  # noqa: PLR2004
             # against the slice kernel (the two-output epilogue form always runs on it; its raw output is the same convolution):
             # the same float32 fmaf chains over taps and slices, channels within a 16-slice in another order -- rounding noise only
             from tiatoolbox_amd.models.architecture.fused import hip_conv2d_post

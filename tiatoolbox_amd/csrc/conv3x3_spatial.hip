@@ -44,6 +44,8 @@ struct SpDims {
     // band geometry (GB / GB7 below): strip width, rows per band, LDS row pitch in 16-byte units, image pitch h + 1, strips per row
     int bw, br, brow, bhp1, strips, bpix;
     float inv_bw, inv_brow, inv_bhp1;  // reciprocals for fdiv() below
+    int bpack;                         // 1: a band is `br` REAL rows of the batch (plan kind 4), 0: `br` virtual rows (kind 3)
+    float inv_h;
 };
 
 // n / d for 0 <= n < 2^24, 0 < d < 2^24 with the reciprocal computed on the host: a float estimate and one correction step each
@@ -189,7 +191,23 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     // band: block = (band of br virtual rows, strip); ty0 = first virtual output row
     const int img = BAND ? 0 : (GEO::G == 1 ? mt_id / tiles_per_image : mt_id * GEO::G);
     const int trem = GEO::G == 1 ? mt_id - img * tiles_per_image : 0;
-    const int ty0 = BAND ? (mt_id / d.strips) * d.br : (trem / tiles_x) * GEO::TH;
+    // band: ty0 = first VIRTUAL output row (image pitch h + 1), vlast = the virtual row of the patch's bottom halo; packed bands
+    // (d.bpack) own the real rows R0 .. R0 + br - 1 of the batch (row rr of image rr / h), virtual row v(rr) = rr + rr / h
+    int ty0, R0 = 0, vlast = 0;
+    if constexpr (BAND) {
+        const int bi = mt_id / d.strips;
+        if (d.bpack) {
+            R0 = bi * d.br;
+            ty0 = R0 + fdiv(R0, d.h, d.inv_h);
+            const int rl = min(R0 + d.br, d.n * d.h) - 1;
+            vlast = rl + fdiv(rl, d.h, d.inv_h) + 1;
+        } else {
+            ty0 = bi * d.br;
+            vlast = ty0 + d.br;
+        }
+    } else {
+        ty0 = (trem / tiles_x) * GEO::TH;
+    }
     const int tx0 = BAND ? (mt_id % d.strips) * d.bw : (trem - (trem / tiles_x) * tiles_x) * GEO::TW;
     const int n0 = blockIdx.y * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
             const int px = PIX == 4 ? rem >> 2 : rem / 5, chunk = rem - px * PIX;
             const int vy = ty0 - 1 + py, ix = tx0 - 1 + px;       // virtual input row; "same" padding: one row / column in front
             const int g = vy >= 0 ? fdiv(vy, d.bhp1, d.inv_bhp1) : 0, iy = vy - g * d.bhp1;  // image, row in it (== h: the zero row)
-            const bool inside = vy >= 0 && py < d.br + 2 && px < d.bw + 2 && chunk < 4 && g < d.n && iy < d.h && (unsigned)ix < (unsigned)d.w;
+            const bool inside = vy >= 0 && vy <= vlast && px < d.bw + 2 && chunk < 4 && g < d.n && iy < d.h && (unsigned)ix < (unsigned)d.w;
             cen[r] = inside ? ((g * d.h + iy) * d.w + ix) * d.cin * ES + 16 * chunk : OOB;
         } else {
             const int g = u / GEO::IMG, ug = u - g * GEO::IMG;
@@ -277,8 +295,13 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
         for (int i = 0; i < 2; ++i) {
             int m = wm * 64 + i * 32 + (lane & 31);  // linear pixel of the block; idle rows read pixel 0 (results dropped)
             m = m < d.br * d.bw ? m : 0;
-            const int r = fdiv(m, d.bw, d.inv_bw);
-            fa[i] = r * ROW + (m - r * d.bw) * PIX + (F32 ? 2 * hi : hi);
+            int r = fdiv(m, d.bw, d.inv_bw), col = m - r * d.bw;
+            if (d.bpack) {  // patch row of real row R0 + r (rows past the batch's end: pixel 0 again)
+                int rr = R0 + r;
+                if (rr >= d.n * d.h) rr = R0, col = 0;
+                r = rr + fdiv(rr, d.h, d.inv_h) - ty0;
+            }
+            fa[i] = r * ROW + col * PIX + (F32 ? 2 * hi : hi);
         }
     } else {
         const int wave_base = GEO::G == 1 ? (64 / GEO::TW) * wm * ROW : wm * GEO::IMG;
@@ -419,11 +442,18 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
             int g, oy, ox;
             bool live;
             if constexpr (BAND) {
-                const int r = fdiv(row, d.bw, d.inv_bw), vy = ty0 + r;
-                g = fdiv(vy, d.bhp1, d.inv_bhp1);
-                oy = vy - g * d.bhp1;
+                const int r = fdiv(row, d.bw, d.inv_bw);
                 ox = tx0 + (row - r * d.bw);
-                live = row < d.br * d.bw && oy < d.ho && g < d.n;  // (oy == ho: the zero row between two images)
+                if (d.bpack) {
+                    g = fdiv(R0 + r, d.h, d.inv_h);
+                    oy = R0 + r - g * d.h;
+                    live = row < d.br * d.bw && g < d.n;
+                } else {
+                    const int vy = ty0 + r;
+                    g = fdiv(vy, d.bhp1, d.inv_bhp1);
+                    oy = vy - g * d.bhp1;
+                    live = row < d.br * d.bw && oy < d.ho && g < d.n;  // (oy == ho: the zero row between two images)
+                }
             } else {
                 g = row / (GEO::TH * GEO::TW);
                 const int rg = row - g * (GEO::TH * GEO::TW);
@@ -706,6 +736,20 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ring_kernel(const float* __res
 
 namespace tia {
 
+// Compute units of the calling thread's CURRENT device, cached per device index (a process may drive several GPUs; the first caller
+// may be the host-only route query).  Without a usable device (build container): MI355X's 256.
+static long device_cu_count() {
+    static std::atomic<int> cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int cus = cached[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+        cached[dev].store(cus, std::memory_order_relaxed);
+    }
+    return cus;
+}
+
 bool conv3x3_spatial_serves(long nb, long h, long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo, int dtype) {
     static const bool disabled = getenv("TIA_CONV_NO_SPATIAL") != nullptr;
     const int es = dtype == TIA_DT_F32 ? 4 : 2;
@@ -713,6 +757,15 @@ bool conv3x3_spatial_serves(long nb, long h, long w, long cin, long cout, long p
     const SpPlan plan = conv3x3_spatial_plan(3, 3, 1, h, w, ho, wo, pad_top, pad_left, dtype == TIA_DT_F32);
     if (plan.kind == 0) return false;
     if (plan.kind >= 3 && nb * (h + 1) >= (1L << 24)) return false;  // fdiv() range of the band geometry (the callers keep the input below 2 GiB)
+    if (plan.kind >= 3) {
+        // A launch of between one and two rounds of workgroups (two per CU) leaves the second round mostly empty, and the band
+        // blocks are the coarsest work units of all the convolution kernels: 512 -> 512 on 7 x 7 maps of a 1024-patch batch is
+        // 800 workgroups = 1.56 rounds -- measured 113.7 TFLOP/s against 120.2 on the slice kernel (1,568 smaller workgroups),
+        // while the 4096-patch batch runs at 141.2 against 127.1 (profiles/r05zb_band_ab.txt).  One round, or three and more, are fine.
+        const long bands = plan.kind == 4 ? (nb * h + plan.br - 1) / plan.br : (nb * (h + 1) - 1 + plan.br - 1) / plan.br;
+        const long wgs = bands * plan.strips * (cout / (cout % 128 == 0 ? 128 : 64)), slots = 2 * device_cu_count();
+        if (wgs > slots && wgs <= 2 * slots && wgs * 100 < 2 * slots * 85) return false;
+    }
     return true;
 }
 
@@ -726,10 +779,14 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
     const bool band = plan.kind >= 3;
     const long tiles_y = small ? 1 : (ho + 15) / 16, tiles_x = small ? 1 : (wo + 15) / 16;
     // band: the batch as one image of nb * (h + 1) - 1 rows (no zero row behind the last image), cut into bands of br rows
-    const long tiles = band ? ((nb * (h + 1) - 1 + plan.br - 1) / plan.br) * plan.strips : (small ? (nb + 1) / 2 : nb * tiles_y * tiles_x);
+    // (kind 4: nb * h real rows in bands of br)
+    const bool pack = plan.kind == 4;
+    const long tiles = pack ? ((nb * h + plan.br - 1) / plan.br) * plan.strips
+                       : band ? ((nb * (h + 1) - 1 + plan.br - 1) / plan.br) * plan.strips : (small ? (nb + 1) / 2 : nb * tiles_y * tiles_x);
     const SpDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
                    (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es), plan.bw, plan.br, plan.brow, (int)(h + 1), plan.strips,
-                   plan.bpix, band ? 1.0f / (float)plan.bw : 0.0f, band ? 1.0f / (float)plan.brow : 0.0f, 1.0f / (float)(h + 1)};
+                   plan.bpix, band ? 1.0f / (float)plan.bw : 0.0f, band ? 1.0f / (float)plan.brow : 0.0f, 1.0f / (float)(h + 1),
+                   pack ? 1 : 0, 1.0f / (float)h};
     const bool wide = cout % 128 == 0;
     static const bool wide8 = getenv("TIA_CONV_N64_8WAVES") != nullptr;  // developer switch: 64-channel band tiles on the 8-wave (4 x 2) form
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / (wide ? 128 : 64)));
@@ -754,20 +811,6 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
 #undef TIA_LAUNCH_SP
 #undef TIA_LAUNCH_GEO
     return true;
-}
-
-// Compute units of the calling thread's CURRENT device, cached per device index (a process may drive several GPUs; the first caller
-// may be the host-only route query).  Without a usable device (build container): MI355X's 256.
-static long device_cu_count() {
-    static std::atomic<int> cached[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    int cus = cached[dev].load(std::memory_order_relaxed);
-    if (cus == 0) {
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
-        cached[dev].store(cus, std::memory_order_relaxed);
-    }
-    return cus;
 }
 
 bool conv_ring_ok(long nb, long cin, long cout, long kh, long kw, long ho, long wo) {

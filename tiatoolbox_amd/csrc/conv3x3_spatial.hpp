@@ -9,8 +9,9 @@ namespace tia {
 
 // Which block geometry of the tap-reuse kernel serves a 3x3 / stride-1 convolution, if any.
 //   kind 1: 16 x 16 pixel blocks of one image;  2: two images of at most 8 x 8;  3: bands of `br` rows of a `bw`-column strip of
-//   the batch stacked into one tall image (conv3x3_spatial.hip: "same" padding only; LDS pixel pitch `bpix` units: 4 for float32,
-//   5 = bank-conflict free for the half kernels).  The fixed geometries need >= 7/8 of their pixels on the map (measured: below that the
+//   the batch stacked into one tall image with a zero row between neighbours (conv3x3_spatial.hip: "same" padding only; LDS pixel
+//   pitch `bpix` units: 4 for float32, 5 = bank-conflict free for the half kernels);  4: the same with bands of `br` REAL rows (the
+//   zero rows are in the LDS patch but not among the GEMM rows: busy = br * bw / 256 -- 98.4 % on 56 / 28 / 14 / 7 maps).  The fixed geometries need >= 7/8 of their pixels on the map (measured: below that the
 //   slice kernels win -- e.g. 76.6 % on the 56 / 28 / 14 / 7 maps of 224^2 patches); the band geometry is taken when it keeps more
 //   of the block busy than they do: busy = (br * bw / 256) * (h / (h + 1)).
 struct SpPlan {
@@ -29,28 +30,38 @@ inline SpPlan conv3x3_spatial_plan(long kh, long kw, long stride, long h, long w
     }
     SpPlan best = (8 * num >= 7 * den) ? SpPlan{kind, 0, 0, 0, 0, 0} : none;
     double busy = best.kind ? (double)num / (double)den : 0.0;
-    static const bool no_band = getenv("TIA_CONV_NO_BAND") != nullptr;  // developer switch (A/B measurements)
+    static const bool no_band = getenv("TIA_CONV_NO_BAND") != nullptr;   // developer switches (A/B measurements)
+    static const bool no_pack = getenv("TIA_CONV_BAND_GAPS") != nullptr;  // keep the round-4 form of the band geometry (gap rows computed)
     if (!no_band && pad_top == 1 && pad_left == 1 && ho == h && wo == w && h >= 2) {
-        for (long strips = 1; strips <= 8; ++strips) {
+        SpPlan band = none;
+        double band_busy = 0.0;
+        static const long max_strips = getenv("TIA_CONV_BAND_MAX_STRIPS") ? atol(getenv("TIA_CONV_BAND_MAX_STRIPS")) : 8;
+        for (long strips = 1; strips <= max_strips; ++strips) {
             if (wo % strips) continue;
             const long bw = wo / strips;
             if (bw > 128 || bw < 4) continue;
-            const long br = 256 / bw;
             const long bpix = f32 ? 4 : 5;
             long brow = bpix * (bw + 2);
             if (!f32)
                 while (brow % 16 != (5 * bw) % 16) ++brow;  // unit address = 5 p + const (mod 16) along the linear pixel index p
-            if ((br + 2) * brow > 1728) continue;
-            const int k = 3;
-            const double b = ((double)(br * bw) / 256.0) * ((double)h / (double)(h + 1));
-            // take it only for a clear gain over a fixed geometry, and only above 0.88: measured at batch 1024 (profiles/
-            // r04e_conv_probe.txt) the tap-reuse kernel sustains ~130 TFLOP/s of raw MFMA work against ~117 for the slice kernel,
-            // so the 7-wide band (0.861 busy: 112.4 TFLOP/s) loses to the slice kernel (117.2) while 14 / 28-wide ones win
-            if (b > busy + 0.03 && b >= 0.88) {
-                busy = b;
-                best = SpPlan{k, (int)bw, (int)br, (int)brow, (int)strips, (int)bpix};
+            // kind 3: bands of the stacked batch INCLUDING the zero row between two images (computed and dropped)
+            if (const long br = 256 / bw; (br + 2) * brow <= 1728) {
+                const double b = ((double)(br * bw) / 256.0) * ((double)h / (double)(h + 1));
+                if (b > band_busy) band_busy = b, band = SpPlan{3, (int)bw, (int)br, (int)brow, (int)strips, (int)bpix};
+            }
+            // kind 4 (round 5): bands of `br` REAL rows -- the patch holds the zero rows they straddle (at most (br + h - 2) / h of
+            // them), the GEMM rows do not; the largest br whose patch fits
+            for (long br = no_pack ? 0 : 256 / bw; br >= 1; --br) {
+                if ((br + (br + h - 2) / h + 2) * brow > 1728) continue;
+                const double b = (double)(br * bw) / 256.0;
+                if (b > band_busy) band_busy = b, band = SpPlan{4, (int)bw, (int)br, (int)brow, (int)strips, (int)bpix};
+                break;
             }
         }
+        // take a band only for a clear gain over a fixed geometry, and only above 0.88: measured at batch 1024 (profiles/
+        // r04e_conv_probe.txt) the tap-reuse kernel sustains ~130 TFLOP/s of raw MFMA work against ~117 for the slice kernel, so a
+        // 0.861-busy band (7-wide strips of the round-4 form: 112.4 TFLOP/s) loses to the slice kernel (117.2)
+        if (band.kind && band_busy > busy + 0.03 && band_busy >= 0.88) best = band;
     }
     return best;
 }
