@@ -167,8 +167,9 @@ def test_host_only_dispatch_queries():
     # with the same code (TIA_ESIZE = -3), and a batch beyond 2 GiB of input is answered for one full group
     assert route(8, 16, 48, 64, 3, 1, 1) == -3 and route(8, 16, 16, 64, 3, 1, 1) == -3 and route(8, 16, 64, 96, 3, 1, 1) == -3  # noqa: PLR2004
     assert route(100000, 64, 64, 64, 3, 1, 1) == 1
-    # valid convolutions (HoVer-Net's decoder) never take the band form; 16 x 16 blocks when they cover >= 7/8
-    assert geometry(164, 164, 162, 162, 0)[0] == 0 and geometry(64, 64, 62, 62, 0)[0] == 1
+    # valid convolutions (HoVer-Net's decoder): bands of real output rows as well
+    assert geometry(164, 164, 162, 162, 0) == (4, [27, 9, 116, 6]) and geometry(64, 64, 62, 62, 0)[0] == 1  # valid: bands too, for a clear gain
+    assert geometry(48, 48, 47, 47, 0)[0] == 1 and geometry(50, 50, 49, 49, 0)[0] == 0  # (asymmetric borders: fixed geometries or none)
     for h in range(9, 130):
         kind, (bw, br, pitch, strips) = geometry(h, h, h, h, 1)
         if kind == 3:  # noqa: PLR2004  (zero rows among the GEMM rows: where the larger patch of kind 4 would cost a band row)

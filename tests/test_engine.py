@@ -303,7 +303,7 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
     assert geometry(56, 56, 1) == (4, [8, 32, 40, 7]) and geometry(28, 28, 1) == (4, [4, 64, 24, 7])
     assert geometry(14, 14, 1) == (4, [14, 18, 64, 1]) and geometry(7, 7, 1) == (4, [7, 36, 36, 1]) and geometry(3, 3, 1)[0] == 0
     assert geometry(64, 64, 1)[0] == 1 and geometry(16, 16, 1)[0] == 1 and geometry(8, 8, 1)[0] == 2
-    assert geometry(164, 162, 0)[0] == 0 and geometry(42, 42, 1)[0] == 4 and geometry(21, 21, 1)[0] == 4 and geometry(5, 5, 1)[0] == 4
+    assert geometry(164, 162, 0)[0] == 4 and geometry(42, 42, 1)[0] == 4 and geometry(21, 21, 1)[0] == 4 and geometry(5, 5, 1)[0] == 4
     for n, cin, cout, hw, k, stride in cases:
         pad = 1 if k == 3 else 0
         conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=True)
@@ -356,6 +356,21 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
     got = hip_conv2d_ex(x2.cuda().contiguous(memory_format=torch.channels_last), wp, dev_conv.bias, None, kernel=3, stride=1,
                         pad_lo=2, pad_hi=2, relu=True)
     assert got.shape == exp.shape == (1, 128, 48, 32) and (got.cpu() - exp).abs().max().item() <= 1e-4
+    # valid 3x3 convolutions on bands of real output rows (two input rows between neighbouring images inside a band's patch):
+    # HoVer-Net's decoder shapes (92 -> 90: 15-wide strips of 17 rows; 166 -> 164: 41 x 6; 64 -> 62 stays on 16 x 16 blocks), short images
+    # (several boundaries per band), rectangular maps, both column-tile widths, with residual
+    assert geometry(92, 90, 0) == (4, [15, 17, 68, 6]) and geometry(166, 164, 0) == (4, [41, 6, 172, 4]) and geometry(64, 62, 0)[0] == 1  # noqa: PLR2004
+    for nb, cin, cout, h, w in ((3, 64, 128, 92, 92), (1, 32, 64, 166, 166), (2, 64, 64, 64, 64), (9, 32, 128, 7, 9), (5, 64, 64, 12, 34),
+                                (1, 32, 64, 4, 6)):
+        conv = torch.nn.Conv2d(cin, cout, 3, bias=True)
+        x = torch.randn((nb, cin, h, w), generator=g)
+        lin = F.conv2d(x, conv.weight, conv.bias)
+        res = torch.randn(lin.shape, generator=g)
+        dev_conv = conv.cuda()
+        got = hip_conv2d_ex(x.cuda().contiguous(memory_format=torch.channels_last), pack_conv_weights(dev_conv), dev_conv.bias,
+                            res.cuda().contiguous(memory_format=torch.channels_last), kernel=3, stride=1, pad_lo=0, pad_hi=0, relu=True)
+        exp = F.relu(lin + res).detach()
+        assert got.shape == exp.shape and (got.cpu() - exp).abs().max().item() <= 1e-4, (nb, cin, cout, h, w)
 
 
 @pytest.mark.gpu

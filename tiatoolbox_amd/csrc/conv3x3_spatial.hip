@@ -44,8 +44,9 @@ struct SpDims {
     // band geometry (GB / GB7 below): strip width, rows per band, LDS row pitch in 16-byte units, image pitch h + 1, strips per row
     int bw, br, brow, bhp1, strips, bpix;
     float inv_bw, inv_brow, inv_bhp1;  // reciprocals for fdiv() below
-    int bpack;                         // 1: a band is `br` REAL rows of the batch (plan kind 4), 0: `br` virtual rows (kind 3)
-    float inv_h;
+    int bpack;                         // 1: a band is `br` REAL output rows of the batch (plan kind 4), 0: `br` virtual rows (kind 3)
+    int bgap;                          // kind 4: virtual rows per image beyond its ho output rows (1: "same", the zero row; 2: valid)
+    float inv_ho;
 };
 
 // n / d for 0 <= n < 2^24, 0 < d < 2^24 with the reciprocal computed on the host: a float estimate and one correction step each
@@ -191,16 +192,18 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
     // band: block = (band of br virtual rows, strip); ty0 = first virtual output row
     const int img = BAND ? 0 : (GEO::G == 1 ? mt_id / tiles_per_image : mt_id * GEO::G);
     const int trem = GEO::G == 1 ? mt_id - img * tiles_per_image : 0;
-    // band: ty0 = first VIRTUAL output row (image pitch h + 1), vlast = the virtual row of the patch's bottom halo; packed bands
-    // (d.bpack) own the real rows R0 .. R0 + br - 1 of the batch (row rr of image rr / h), virtual row v(rr) = rr + rr / h
+    // band: virtual rows = the batch's INPUT rows stacked with image pitch bhp1 (h + 1 for "same" padding: one zero row between
+    // neighbours; h for a valid convolution); an output row's virtual row = the input row of its centre ("same") / top (valid) tap.
+    // ty0 = first virtual output row, vlast = the last virtual row of the patch; packed bands (d.bpack) own the real output rows
+    // R0 .. R0 + br - 1 of the batch (row rr of image rr / ho), v(rr) = rr + bgap (rr / ho)
     int ty0, R0 = 0, vlast = 0;
     if constexpr (BAND) {
         const int bi = mt_id / d.strips;
         if (d.bpack) {
             R0 = bi * d.br;
-            ty0 = R0 + fdiv(R0, d.h, d.inv_h);
-            const int rl = min(R0 + d.br, d.n * d.h) - 1;
-            vlast = rl + fdiv(rl, d.h, d.inv_h) + 1;
+            ty0 = R0 + d.bgap * fdiv(R0, d.ho, d.inv_ho);
+            const int rl = min(R0 + d.br, d.n * d.ho) - 1;
+            vlast = rl + d.bgap * fdiv(rl, d.ho, d.inv_ho) - d.pad_y + 2;
         } else {
             ty0 = bi * d.br;
             vlast = ty0 + d.br;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
         if constexpr (BAND) {
             const int py = fdiv(u, ROW, d.inv_brow), rem = u - py * ROW;
             const int px = PIX == 4 ? rem >> 2 : rem / 5, chunk = rem - px * PIX;
-            const int vy = ty0 - 1 + py, ix = tx0 - 1 + px;       // virtual input row; "same" padding: one row / column in front
+            const int vy = ty0 - d.pad_y + py, ix = tx0 - d.pad_x + px;  // virtual input row; "same" padding: one row / column in front
             const int g = vy >= 0 ? fdiv(vy, d.bhp1, d.inv_bhp1) : 0, iy = vy - g * d.bhp1;  // image, row in it (== h: the zero row)
             const bool inside = vy >= 0 && vy <= vlast && px < d.bw + 2 && chunk < 4 && g < d.n && iy < d.h && (unsigned)ix < (unsigned)d.w;
             cen[r] = inside ? ((g * d.h + iy) * d.w + ix) * d.cin * ES + 16 * chunk : OOB;
@@ -298,8 +301,8 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
             int r = fdiv(m, d.bw, d.inv_bw), col = m - r * d.bw;
             if (d.bpack) {  // patch row of real row R0 + r (rows past the batch's end: pixel 0 again)
                 int rr = R0 + r;
-                if (rr >= d.n * d.h) rr = R0, col = 0;
-                r = rr + fdiv(rr, d.h, d.inv_h) - ty0;
+                if (rr >= d.n * d.ho) rr = R0, col = 0;
+                r = rr + d.bgap * fdiv(rr, d.ho, d.inv_ho) - ty0;
             }
             fa[i] = r * ROW + col * PIX + (F32 ? 2 * hi : hi);
         }
@@ -445,8 +448,8 @@ __global__ __launch_bounds__(GEO::NT, GEO::NT == 512 ? 4 : 2) void conv3x3_spati
                 const int r = fdiv(row, d.bw, d.inv_bw);
                 ox = tx0 + (row - r * d.bw);
                 if (d.bpack) {
-                    g = fdiv(R0 + r, d.h, d.inv_h);
-                    oy = R0 + r - g * d.h;
+                    g = fdiv(R0 + r, d.ho, d.inv_ho);
+                    oy = R0 + r - g * d.ho;
                     live = row < d.br * d.bw && g < d.n;
                 } else {
                     const int vy = ty0 + r;
@@ -762,7 +765,7 @@ bool conv3x3_spatial_serves(long nb, long h, long w, long cin, long cout, long p
         // blocks are the coarsest work units of all the convolution kernels: 512 -> 512 on 7 x 7 maps of a 1024-patch batch is
         // 800 workgroups = 1.56 rounds -- measured 113.7 TFLOP/s against 120.2 on the slice kernel (1,568 smaller workgroups),
         // while the 4096-patch batch runs at 141.2 against 127.1 (profiles/r05zb_band_ab.txt).  One round, or three and more, are fine.
-        const long bands = plan.kind == 4 ? (nb * h + plan.br - 1) / plan.br : (nb * (h + 1) - 1 + plan.br - 1) / plan.br;
+        const long bands = plan.kind == 4 ? (nb * ho + plan.br - 1) / plan.br : (nb * (h + 1) - 1 + plan.br - 1) / plan.br;
         const long wgs = bands * plan.strips * (cout / (cout % 128 == 0 ? 128 : 64)), slots = 2 * device_cu_count();
         if (wgs > slots && wgs <= 2 * slots && wgs * 100 < 2 * slots * 85) return false;
     }
@@ -781,12 +784,12 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
     // band: the batch as one image of nb * (h + 1) - 1 rows (no zero row behind the last image), cut into bands of br rows
     // (kind 4: nb * h real rows in bands of br)
     const bool pack = plan.kind == 4;
-    const long tiles = pack ? ((nb * h + plan.br - 1) / plan.br) * plan.strips
+    const long tiles = pack ? ((nb * ho + plan.br - 1) / plan.br) * plan.strips
                        : band ? ((nb * (h + 1) - 1 + plan.br - 1) / plan.br) * plan.strips : (small ? (nb + 1) / 2 : nb * tiles_y * tiles_x);
     const SpDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
-                   (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es), plan.bw, plan.br, plan.brow, (int)(h + 1), plan.strips,
-                   plan.bpix, band ? 1.0f / (float)plan.bw : 0.0f, band ? 1.0f / (float)plan.brow : 0.0f, 1.0f / (float)(h + 1),
-                   pack ? 1 : 0, 1.0f / (float)h};
+                   (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es), plan.bw, plan.br, plan.brow, (int)(h + pad_top), plan.strips,
+                   plan.bpix, band ? 1.0f / (float)plan.bw : 0.0f, band ? 1.0f / (float)plan.brow : 0.0f, 1.0f / (float)(h + pad_top),
+                   pack ? 1 : 0, (int)(h + pad_top - ho), 1.0f / (float)ho};
     const bool wide = cout % 128 == 0;
     static const bool wide8 = getenv("TIA_CONV_N64_8WAVES") != nullptr;  // developer switch: 64-channel band tiles on the 8-wave (4 x 2) form
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / (wide ? 128 : 64)));

@@ -10,8 +10,9 @@ namespace tia {
 // Which block geometry of the tap-reuse kernel serves a 3x3 / stride-1 convolution, if any.
 //   kind 1: 16 x 16 pixel blocks of one image;  2: two images of at most 8 x 8;  3: bands of `br` rows of a `bw`-column strip of
 //   the batch stacked into one tall image with a zero row between neighbours (conv3x3_spatial.hip: "same" padding only; LDS pixel
-//   pitch `bpix` units: 4 for float32, 5 = bank-conflict free for the half kernels);  4: the same with bands of `br` REAL rows (the
-//   zero rows are in the LDS patch but not among the GEMM rows: busy = br * bw / 256 -- 98.4 % on 56 / 28 / 14 / 7 maps).  The fixed geometries need >= 7/8 of their pixels on the map (measured: below that the
+//   pitch `bpix` units: 4 for float32, 5 = bank-conflict free for the half kernels);  4: the same with bands of `br` REAL output rows
+//   (the rows between two images are in the LDS patch but not among the GEMM rows: busy = br * bw / 256 -- 98-100 % on 56 / 28 / 14 /
+//   7 maps); "same" padding or a valid convolution (ho = h - 2: HoVer-Net's decoders, 87-94 % on 16 x 16 blocks).  The fixed geometries need >= 7/8 of their pixels on the map (measured: below that the
 //   slice kernels win -- e.g. 76.6 % on the 56 / 28 / 14 / 7 maps of 224^2 patches); the band geometry is taken when it keeps more
 //   of the block busy than they do: busy = (br * bw / 256) * (h / (h + 1)).
 struct SpPlan {
@@ -32,7 +33,10 @@ inline SpPlan conv3x3_spatial_plan(long kh, long kw, long stride, long h, long w
     double busy = best.kind ? (double)num / (double)den : 0.0;
     static const bool no_band = getenv("TIA_CONV_NO_BAND") != nullptr;   // developer switches (A/B measurements)
     static const bool no_pack = getenv("TIA_CONV_BAND_GAPS") != nullptr;  // keep the round-4 form of the band geometry (gap rows computed)
-    if (!no_band && pad_top == 1 && pad_left == 1 && ho == h && wo == w && h >= 2) {
+    // bands: "same" padding (one zero row / column all round) or, kind 4 only, a valid convolution (HoVer-Net's decoders)
+    const bool same = pad_top == 1 && pad_left == 1 && ho == h && wo == w, valid = pad_top == 0 && pad_left == 0 && ho == h - 2 && wo == w - 2;
+    if (!no_band && (same || valid) && ho >= 2) {
+        const long gap = same ? 1 : 2;  // virtual (input) rows per image beyond its ho output rows
         SpPlan band = none;
         double band_busy = 0.0;
         static const long max_strips = getenv("TIA_CONV_BAND_MAX_STRIPS") ? atol(getenv("TIA_CONV_BAND_MAX_STRIPS")) : 8;
@@ -45,14 +49,14 @@ inline SpPlan conv3x3_spatial_plan(long kh, long kw, long stride, long h, long w
             if (!f32)
                 while (brow % 16 != (5 * bw) % 16) ++brow;  // unit address = 5 p + const (mod 16) along the linear pixel index p
             // kind 3: bands of the stacked batch INCLUDING the zero row between two images (computed and dropped)
-            if (const long br = 256 / bw; (br + 2) * brow <= 1728) {
+            if (const long br = 256 / bw; same && (br + 2) * brow <= 1728) {
                 const double b = ((double)(br * bw) / 256.0) * ((double)h / (double)(h + 1));
                 if (b > band_busy) band_busy = b, band = SpPlan{3, (int)bw, (int)br, (int)brow, (int)strips, (int)bpix};
             }
-            // kind 4 (round 5): bands of `br` REAL rows -- the patch holds the zero rows they straddle (at most (br + h - 2) / h of
-            // them), the GEMM rows do not; the largest br whose patch fits
+            // kind 4 (round 5): bands of `br` REAL output rows -- the patch holds the rows between two images they straddle (at most
+            // (br + ho - 2) / ho image boundaries of `gap` rows), the GEMM rows do not; the largest br whose patch fits
             for (long br = no_pack ? 0 : 256 / bw; br >= 1; --br) {
-                if ((br + (br + h - 2) / h + 2) * brow > 1728) continue;
+                if ((br + gap * ((br + ho - 2) / ho) + 2) * brow > 1728) continue;
                 const double b = (double)(br * bw) / 256.0;
                 if (b > band_busy) band_busy = b, band = SpPlan{4, (int)bw, (int)br, (int)brow, (int)strips, (int)bpix};
                 break;
@@ -61,7 +65,9 @@ inline SpPlan conv3x3_spatial_plan(long kh, long kw, long stride, long h, long w
         // take a band only for a clear gain over a fixed geometry, and only above 0.88: measured at batch 1024 (profiles/
         // r04e_conv_probe.txt) the tap-reuse kernel sustains ~130 TFLOP/s of raw MFMA work against ~117 for the slice kernel, so a
         // 0.861-busy band (7-wide strips of the round-4 form: 112.4 TFLOP/s) loses to the slice kernel (117.2)
-        if (band.kind && band_busy > busy + 0.03 && band_busy >= 0.88) best = band;
+        // (+0.04: a valid 64 -> 62 map is 0.938 busy on 16 x 16 blocks and 0.969 on 31 x 8 bands -- measured 137.7 vs 135.3 TFLOP/s,
+        //  profiles/r05zd_hovernet_layers.txt: the fixed geometries' immediate-offset addressing is worth that much)
+        if (band.kind && band_busy > busy + 0.04 && band_busy >= 0.88) best = band;
     }
     return best;
 }
