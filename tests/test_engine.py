@@ -480,7 +480,10 @@ def test_hip_mfma_conv_half_matches_torch_cpu_fp32(dtype):
              # one clipped block, several channel slices, both tile widths)
              (3, 64, 64, 32, 32, 3, 1), (2, 128, 256, 16, 16, 3, 1), (1, 96, 128, 30, 31, 3, 1), (1, 64, 64, 15, 16, 3, 1),
              (2, 256, 128, 14, 16, 3, 1), (1, 32, 192, 64, 48, 3, 1),
-             (5, 512, 512, 8, 8, 3, 1), (3, 64, 128, 7, 8, 3, 1), (2, 128, 64, 8, 8, 3, 1)]
+             (5, 512, 512, 8, 8, 3, 1), (3, 64, 128, 7, 8, 3, 1), (2, 128, 64, 8, 8, 3, 1),
+             # the half kernels' bands (conflict-free pixel pitch of 5 units): zero rows among the GEMM rows (28-wide / 21-wide strips),
+             # and the two map sizes where bands of real rows win with that pitch (33, 55: 11-wide strips of 21 rows)
+             (3, 64, 64, 28, 28, 3, 1), (2, 32, 128, 42, 42, 3, 1), (7, 64, 128, 33, 33, 3, 1), (2, 32, 64, 55, 55, 3, 1)]
     for n, cin, cout, h, w, k, s in cases:
         pad = 1 if k == 3 else 0
         conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=pad)

@@ -125,6 +125,11 @@ struct G8 {
 // float32 takes a pixel pitch of 4 units (no padding unit, 4-way conflicts on 4 reads per 32 MFMAs: 3 % of the LDS time), which
 // is what lets the 7-wide band (38 rows) fit the patch buffer with two workgroups per CU.  A one-workgroup-per-CU form with a
 // larger patch was measured and lost to the slice kernel (profiles/r04c_*: 106.6 vs 114.0 TFLOP/s on 512 -> 512 @ 7 x 7).
+// Round 5 (plan kind 4, `bpack`): a band is `br` consecutive REAL output rows of the batch instead -- the rows between two images
+// (the zero row of "same" padding, or the two extra input rows of a VALID 3x3 convolution) are in the block's LDS patch but not
+// among its GEMM rows: 100 % busy on 56^2 (8 x 32) and 28^2 (4 x 64), 98.4 % on 14^2 (14 x 18) and 7^2 (7 x 36: up to five zero
+// rows inside the 43-row patch), 99.6 % on HoVer-Net's valid 92 -> 90 maps (15 x 17).  Measured at 4096-patch launches (profiles/
+// r05zb_band_ab.txt): 128.3 -> 131.1 / 139.4 -> 145.4 / 134.6 -> 145.5 / 127.1 (gather ring) -> 141.2 TFLOP/s on the four maps.
 struct GB {
     static constexpr int NT = 512, G = 1, TH = 16, TW = 16, PH = 0, PWD = 0, ROW = 0, IMG = 1728, MROWS = 0, WAVES_M = 4, WN = 2;
     static constexpr bool BAND = true;
