@@ -596,10 +596,12 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
             "launch_ms": round(conv["stem_seconds"] * 1e3, 4), "algorithmic_flops": conv["stem_flops"],
             "what": (f"uint8 patches -> conv7x7/2 (3->64, K = 147) + bias + ReLU + maxpool3x3/2, one launch per {mb} patches; "
                      "flops = 2*Ho*Wo*64*147 per patch (the conv rows recomputed at chunk seams are not counted)")}
-        pmc_c = pmc_traffic(dominant, "trunk") if (mb, hw) == (1024, 256) else None
-        if pmc_c is not None:  # PMC passes cannot run inside the timed process: this round's committed passes, same shapes
+        # PMC passes cannot run inside the timed process: this round's committed passes over the same shapes (stem "trunk" = 1024-patch
+        # launches, "trunk<mb>" otherwise)
+        pmc_c = pmc_traffic(dominant, "trunk" if mb == 1024 else f"trunk{mb}") if hw == 256 else None
+        if pmc_c is not None:
             roofline["traffic"] = round(pmc_c["bytes"])
-            roofline["traffic_source"] = pmc_c["source"] + " (scripts/perf_trunk.py 1024 256: mean over the launches of one forward)"
+            roofline["traffic_source"] = pmc_c["source"] + f" (scripts/perf_trunk.py {mb} 256: mean over the launches of one forward)"
     else:
         dominant = "stain_stats_kernel"  # the longest-running hand-written kernel of a step when the library convolves
         dk = kernels[dominant]
@@ -685,7 +687,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                 t_blocks_w = ev_time(lambda: trunk_w.blocks(feat), reps=5)
             engine.conv_algo = "direct"
             wl, ws = acc["launches"] // 3, acc["seconds"] / 3
-            pmc_w = pmc_traffic("conv3x3_wino_kernel", "wino") if (mb, hw) == (1024, 256) else None
+            pmc_w = pmc_traffic("conv3x3_wino_kernel", "wino" if mb == 1024 else f"wino{mb}") if hw == 256 else None
             extras["cnn_winograd"] = {
                 "value": round(n * k_extra / el_w, 2), "unit": "patches/s", "ms_per_step": round(el_w / k_extra * 1e3, 3),
                 "max_abs_dprob_vs_direct_float32": dpw, "tolerance": 1e-5, "within_tolerance": bool(dpw <= 1e-5),
@@ -701,7 +703,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                                       "direct convolution's 2*M*Cout*Cin*9 over the same time (may exceed the MFMA peak)"),
                              "blocks_ms": round(t_blocks_w * 1e3, 3),
                              "traffic": round(pmc_w["bytes"]) if pmc_w else None,
-                             **({"traffic_source": pmc_w["source"] + " (scripts/perf_wino.py 1024 256: mean over the launches of this kernel)"}
+                             **({"traffic_source": pmc_w["source"] + f" (scripts/perf_wino.py {mb} 256: mean over the launches of this kernel)"}
                                 if pmc_w else {})},
                 "note": ("extra only: the float32 3x3 / stride-1 block convolutions through Winograd F(2x2, 3x3) (float32 in / float32 "
                          "accumulate, weights transformed once in float64); same stain front-end, stem, strided / 1x1 convolutions as `value`")}

@@ -1,0 +1,55 @@
+#!/bin/bash
+# Round-5 CLOSING measurement pass (after the real-row bands / product-of-tables apply / 4096-patch engine batch; the first pass
+# of the round is final_profile_r05.sh, tag r05x).  Differences: the convolution PMC passes and tables run on 4096-patch launches (what
+# the bench launches now; stems trunk4096 / wino4096), per-layer tables at 224^2 for both batch sizes, the band A/B table; the Vahadane /
+# HoVer-Net post-processing / canvas PMC passes are not repeated (code unchanged: bench_configs reads r05x's).
+# Round-5 measurement pass on the GPU box (everything lands in gpurun_out/, copied to profiles/ afterwards): environment probe, full
+# GPU test suite, smoke, separate --pmc passes (FETCH_SIZE / WRITE_SIZE: trunk convolutions at 256^2 and 224^2, the Winograd layers, stain
+# kernels at the headline size, Vahadane statistics, HoVer-Net post-processing, canvas kernels), the default bench (+ extras.configs,
+# extras.cnn_winograd, cpu_baseline), rocprofv3 kernel trace of the bench, per-layer tables (direct vs MIOpen at 224^2, direct vs
+# Winograd at both sizes), the other bench configurations.
+#   usage: final_profile_r05.sh TAG [skip_tests]
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out
+TAG=${1:-r05zz}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cd $R
+python scripts/probe_env.py > $OUT/${TAG}_env_probe.txt 2>&1
+if [ "${2:-}" != "skip_tests" ]; then
+  timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/${TAG}_pytest_gpu.log; cat $OUT/${TAG}_pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"
+fi
+pmc() {  # pmc STEM COMMAND...: one pass per counter, summaries named ${TAG}_${STEM}_pmc_${COUNTER}.txt
+  local stem=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/rp_$stem$c; (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/rp_$stem$c -- "$@" > /dev/null 2>&1)
+    python $R/scripts/prof_summarize.py /tmp/rp_$stem$c $OUT/${TAG}_${stem}_pmc_${c}.txt > /dev/null
+  done
+}
+pmc trunk4096 python $R/scripts/perf_trunk.py 4096 256
+pmc trunk224_4096 python $R/scripts/perf_trunk.py 4096 224
+pmc wino4096 python $R/scripts/perf_wino.py 4096 256
+pmc stain python $R/scripts/perf_stain.py 4096 256
+grep -h "conv3x3\|conv_mfma\|stem7x7" $OUT/${TAG}_trunk4096_pmc_*.txt $OUT/${TAG}_wino4096_pmc_*.txt | cut -c1-130
+# the benches read the traffic of their kernels from profiles/: make this pass visible to the runs below
+cp $OUT/${TAG}_*_pmc_*.txt $R/profiles/ 2>/dev/null
+cd $R
+( time timeout 1200 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err ) 2> $OUT/${TAG}_bench.time; echo "bench rc=$?"; cat $OUT/${TAG}_bench.time | tr '\n' ' '; echo; cut -c1-300 $OUT/${TAG}_bench.json
+(cd /tmp && rm -rf /tmp/rp_bench; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_bench -- \
+    python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null)
+python $R/scripts/prof_summarize.py /tmp/rp_bench $OUT/${TAG}_bench_rocprofv3_summary.txt > /dev/null; head -14 $OUT/${TAG}_bench_rocprofv3_summary.txt | cut -c1-150
+for n in 4096 1024; do for hw in 256 224; do timeout 300 python scripts/perf_trunk.py $n $hw 2>&1 | grep -v "amdgpu\|No local"; done; done > $OUT/${TAG}_perf_trunk.txt; cat $OUT/${TAG}_perf_trunk.txt
+timeout 400 python scripts/perf_conv.py 4096 224 2>&1 | grep -v "amdgpu\|No local" > $OUT/${TAG}_perf_conv224_n4096.txt; tail -1 $OUT/${TAG}_perf_conv224_n4096.txt
+timeout 300 python scripts/perf_conv.py 1024 224 2>&1 | grep -v "amdgpu\|No local" > $OUT/${TAG}_perf_conv224_n1024.txt; tail -1 $OUT/${TAG}_perf_conv224_n1024.txt
+for n in 4096 1024; do timeout 200 python scripts/perf_band.py $n 2>&1 | grep "^n="; done > $OUT/${TAG}_perf_band.txt
+timeout 300 python scripts/perf_wino.py 4096 256 2>&1 | grep -v "amdgpu\|No local" > $OUT/${TAG}_perf_wino256.txt; tail -1 $OUT/${TAG}_perf_wino256.txt
+timeout 300 python scripts/perf_wino.py 4096 224 2>&1 | grep -v "amdgpu\|No local" > $OUT/${TAG}_perf_wino224.txt; tail -1 $OUT/${TAG}_perf_wino224.txt
+timeout 400 python scripts/perf_stain.py 4096 256 2>&1 | grep -v amdgpu > $OUT/${TAG}_perf_stain.txt; grep "^stats\|^apply" $OUT/${TAG}_perf_stain.txt
+timeout 300 python scripts/perf_hovernet_layers.py hovernet 32 2>&1 | grep -v "amdgpu\|No local" > $OUT/${TAG}_hovernet_layers.txt; head -1 $OUT/${TAG}_hovernet_layers.txt
+timeout 300 python scripts/perf_hovernet_layers.py unet 8 2>&1 | grep -v "amdgpu\|No local" > $OUT/${TAG}_unet_layers.txt; head -1 $OUT/${TAG}_unet_layers.txt
+timeout 600 python bench.py --config hovernet --steps 5 --warmup 2 > $OUT/${TAG}_bench_hovernet.json 2> /dev/null; cut -c1-200 $OUT/${TAG}_bench_hovernet.json
+timeout 600 python bench.py --config vahadane --steps 5 --warmup 2 > $OUT/${TAG}_bench_vahadane.json 2> /dev/null; cut -c1-200 $OUT/${TAG}_bench_vahadane.json
+timeout 600 python bench.py --config semantic --steps 1 --warmup 1 > $OUT/${TAG}_bench_semantic.json 2> /dev/null; cut -c1-200 $OUT/${TAG}_bench_semantic.json
+ls $OUT | grep $TAG | wc -l
