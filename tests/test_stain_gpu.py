@@ -539,6 +539,18 @@ def test_f64_table_exp_against_libm_exp(he_patches, uniform_patches, target_imag
         ub = dev.stain_apply(x, stats, norm.stain_matrix_target, out_kind=kind, math=_lib.MATH_F64_REF)
         assert torch.equal(ua[1], ub[1])
         assert float((ua[0].double() - ub[0].double()).abs().max()) <= 1e-10
+    # non-finite entries take the fall-back too (same bits as REF, NaN for NaN); entries just inside the table form's range
+    # (|m| < 126: factors down to exp(-700)) still agree to 1e-10
+    for val, exact in ((float("nan"), True), (float("inf"), True), (-float("inf"), True), (125.0, False), (-125.0, False)):
+        stats = dev.stain_stats(x, p)
+        stats[1, _lib.ST_M + 4] = val
+        ua = dev.stain_apply(x, stats, norm.stain_matrix_target, out_kind=_lib.OUT_F64, math=_lib.MATH_F64)
+        ub = dev.stain_apply(x, stats, norm.stain_matrix_target, out_kind=_lib.OUT_F64, math=_lib.MATH_F64_REF)
+        if exact:
+            assert bool(((ua[1] == ub[1]) | (ua[1].isnan() & ub[1].isnan())).all()), val
+        else:
+            assert float((ua[1] - ub[1]).abs().max()) <= 1e-10, val
+        assert float((ua[0] - ub[0]).abs().max()) <= 1e-10
 
 
 @pytest.mark.gpu

@@ -764,7 +764,7 @@ bool conv3x3_spatial_serves(long nb, long h, long w, long cin, long cout, long p
     if (disabled || cin % (64 / es) != 0 || cout % 64 != 0 || pad_top > 2 || pad_left > 2) return false;
     const SpPlan plan = conv3x3_spatial_plan(3, 3, 1, h, w, ho, wo, pad_top, pad_left, dtype == TIA_DT_F32);
     if (plan.kind == 0) return false;
-    if (plan.kind >= 3 && nb * (h + 1) >= (1L << 24)) return false;  // fdiv() range of the band geometry (the callers keep the input below 2 GiB)
+    if (plan.kind >= 3 && nb * (h + 1) + 256 >= (1L << 24)) return false;  // fdiv() range of the band geometry (rows of the last band included; the callers keep the input below 2 GiB)
     if (plan.kind >= 3) {
         // A launch of between one and two rounds of workgroups (two per CU) leaves the second round mostly empty, and the band
         // blocks are the coarsest work units of all the convolution kernels: 512 -> 512 on 7 x 7 maps of a 1024-patch batch is

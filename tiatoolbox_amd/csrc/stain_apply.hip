@@ -244,7 +244,8 @@ struct ApplyCtxFast {
 // pixel 9 LDS reads, 6 multiplies and the reference's clip -- the kernel stops being bound by float64 vector arithmetic (60
 // operations per pixel, §4.10) and runs at the memory system's pace.  Each factor is a correctly rounded-ish exp (< 1 ulp), the
 // product three roundings more: relative error <= ~3e-16, i.e. < 1e-13 on the 0..255 scale (the exponent-trick form: 1e-12).
-// Valid while every |LUT[v] m[j][c]| stays far inside exp's range (5.5414 * max |m| < 700: checked per patch, else the libm context).
+// Valid while every |LUT[v] m[j][c]| stays far inside exp's range (every |m| < 126, i.e. 5.5414 |m| < 700: checked per patch --
+// NaN / inf entries fail the test -- else the libm context).
 struct ApplyCtxTab {
     const double* pt;  // [9][256]: pt[(3 j + c) * 256 + v]
     __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, double (&o)[3]) const {
@@ -475,10 +476,9 @@ __global__ __launch_bounds__(AT) void stain_apply_wide_kernel(const uint8_t* __r
     } else if constexpr (PT) {
         __shared__ double ptab[9 * 256];
         __shared__ double lut[256];  // (only the libm fall-back reads it)
-        double amax = 0.0;
+        bool ok = true;  // every |LUT[v] m| < 5.5414 * 126 < 700: far inside exp's range; a NaN / inf entry fails the comparison
 #pragma unroll
-        for (int k = 0; k < 9; ++k) amax = fmax(amax, fabs(st[TIA_ST_M + k]));
-        const bool ok = amax * 5.5414 < 700.0;  // also false for NaN / inf
+        for (int k = 0; k < 9; ++k) ok = ok && fabs(st[TIA_ST_M + k]) < 126.0;
         for (int i = threadIdx.x; i < 256; i += AT) lut[i] = tab->od_lut[i];
         if (ok) {
             for (int i = threadIdx.x; i < 9 * 256; i += AT) {
