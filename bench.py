@@ -157,10 +157,13 @@ def cpu_baseline(target, patches, model_cpu, sample: int) -> dict:
     }
 
 
-def pmc_traffic(kernel_substr: str, stem: str) -> dict | None:
+def pmc_traffic(kernel_substr: str, stem: str, calls_per_forward: int | None = None) -> dict | None:
     """HBM-side bytes per launch of a kernel from this round's committed rocprofv3 --pmc passes
     (``profiles/*_<stem>_pmc_FETCH_SIZE.txt`` / ``..._WRITE_SIZE.txt``: separate runs over the same workload; mean over the
-    dispatches of every kernel whose name contains ``kernel_substr``, weighted by dispatch count).
+    dispatches of every kernel whose name contains ``kernel_substr``, weighted by dispatch count).  A layer call on a 4096-patch
+    batch is several dispatches (inputs go in groups of < 2 GiB), so when the pass says how many forwards it ran (``# PMC
+    forwards=N``, ``scripts/perf_trunk.py ... pmc``) and the caller knows the kernel's calls per forward, the figure is bytes per
+    CALL = counter total / (N x calls_per_forward) -- the unit ``launch_ms`` and ``algorithmic_flops`` are in.
     gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the bytes actually read -- calibrated here on the
     apply kernels, whose reads are known (2 x 301.6 MB = the 616.6 MB input); WRITE_SIZE is taken as is.  Units: KiB."""
     import re
@@ -170,18 +173,25 @@ def pmc_traffic(kernel_substr: str, stem: str) -> dict | None:
         files = sorted((ROOT / "profiles").glob(f"*_{stem}_pmc_{counter}.txt"))
         if not files:
             return None
-        tot, cnt = 0.0, 0
+        tot, cnt, forwards = 0.0, 0, None
         for line in files[-1].read_text().splitlines():
             m = re.search(rf"{counter} mean=\s*([0-9.]+) n=\s*(\d+)\s+(.*)", line)
             if m and kernel_substr in m.group(3):
                 tot += float(m.group(1)) * int(m.group(2))
                 cnt += int(m.group(2))
+            f = re.match(r"# PMC forwards=(\d+)", line)
+            if f:
+                forwards = int(f.group(1))
         if cnt == 0:
             return None
-        vals[counter] = tot / cnt * 1024.0
+        per_call = bool(forwards and calls_per_forward)
+        vals[counter] = tot / (forwards * calls_per_forward if per_call else cnt) * 1024.0
         vals["file_" + counter] = files[-1].name
+        vals["unit"] = (f"per layer call: total over {cnt} dispatches / ({forwards} forwards x {calls_per_forward} calls)" if per_call
+                        else "mean per dispatch")
     return {"bytes": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
-            "source": f"profiles/{vals['file_FETCH_SIZE']} (x2, gfx950) + profiles/{vals['file_WRITE_SIZE']}" + _pass_commit(vals["file_FETCH_SIZE"])}
+            "source": (f"profiles/{vals['file_FETCH_SIZE']} (x2, gfx950) + profiles/{vals['file_WRITE_SIZE']}, {vals['unit']}"
+                       + _pass_commit(vals["file_FETCH_SIZE"]))}
 
 
 def _pass_commit(profile_name: str) -> str:
@@ -598,7 +608,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                      "flops = 2*Ho*Wo*64*147 per patch (the conv rows recomputed at chunk seams are not counted)")}
         # PMC passes cannot run inside the timed process: this round's committed passes over the same shapes (stem "trunk" = 1024-patch
         # launches, "trunk<mb>" otherwise)
-        pmc_c = pmc_traffic(dominant, "trunk" if mb == 1024 else f"trunk{mb}") if hw == 256 else None
+        pmc_c = pmc_traffic(dominant, "trunk" if mb == 1024 else f"trunk{mb}", dk["launches"]) if hw == 256 else None
         if pmc_c is not None:
             roofline["traffic"] = round(pmc_c["bytes"])
             roofline["traffic_source"] = pmc_c["source"] + f" (scripts/perf_trunk.py {mb} 256: mean over the launches of one forward)"
@@ -692,7 +702,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                 t_blocks_w = ev_time(lambda: trunk_w.blocks(feat), reps=5)
             engine.conv_algo = "direct"
             wl, ws = acc["launches"] // 3, acc["seconds"] / 3
-            pmc_w = pmc_traffic("conv3x3_wino_kernel", "wino" if mb == 1024 else f"wino{mb}") if hw == 256 else None
+            pmc_w = pmc_traffic("conv3x3_wino_kernel", "wino" if mb == 1024 else f"wino{mb}", 13) if hw == 256 else None
             extras["cnn_winograd"] = {
                 "value": round(n * k_extra / el_w, 2), "unit": "patches/s", "ms_per_step": round(el_w / k_extra * 1e3, 3),
                 "max_abs_dprob_vs_direct_float32": dpw, "tolerance": 1e-5, "within_tolerance": bool(dpw <= 1e-5),

@@ -24,13 +24,15 @@ fi
 pmc() {  # pmc STEM COMMAND...: one pass per counter, summaries named ${TAG}_${STEM}_pmc_${COUNTER}.txt
   local stem=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/rp_$stem$c; (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/rp_$stem$c -- "$@" > /dev/null 2>&1)
+    rm -rf /tmp/rp_$stem$c; (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/rp_$stem$c -- "$@" > /tmp/rp_$stem$c.out 2>&1)
     python $R/scripts/prof_summarize.py /tmp/rp_$stem$c $OUT/${TAG}_${stem}_pmc_${c}.txt > /dev/null
+    # a workload that ran a known number of forwards says so ("PMC forwards=N"): bytes per layer CALL = total / (launches per forward x N)
+    grep -h "^PMC forwards=" /tmp/rp_$stem$c.out | head -1 | sed 's/^/# /' >> $OUT/${TAG}_${stem}_pmc_${c}.txt
   done
 }
-pmc trunk4096 python $R/scripts/perf_trunk.py 4096 256
-pmc trunk224_4096 python $R/scripts/perf_trunk.py 4096 224
-pmc wino4096 python $R/scripts/perf_wino.py 4096 256
+pmc trunk4096 python $R/scripts/perf_trunk.py 4096 256 5 pmc
+pmc trunk224_4096 python $R/scripts/perf_trunk.py 4096 224 5 pmc
+pmc wino4096 python $R/scripts/perf_wino.py 4096 256 pmc
 pmc stain python $R/scripts/perf_stain.py 4096 256
 grep -h "conv3x3\|conv_mfma\|stem7x7" $OUT/${TAG}_trunk4096_pmc_*.txt $OUT/${TAG}_wino4096_pmc_*.txt | cut -c1-130
 # the benches read the traffic of their kernels from profiles/: make this pass visible to the runs below

@@ -1,7 +1,10 @@
 """The float32 resnet18 trunk on the hand-written kernels at the bench's micro-batch: stem kernel + the 19 block
 convolutions, per-stage HIP-event times.  Also the workload of the convolution kernels' rocprofv3 passes
 (`rocprofv3 --kernel-trace --stats` / `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, one counter per run).
-usage: perf_trunk.py [batch=1024] [patch=256] [reps=5]"""
+usage: perf_trunk.py [batch=1024] [patch=256] [reps=5] [pmc]
+"pmc": the counter-pass workload -- the 19 block convolutions of exactly three forwards and nothing else (a 4096-patch layer call is
+several dispatches of < 2 GiB input each, so bytes per CALL = counter total / (launches per forward x forwards); the line
+"PMC forwards=3" tells the summary how many)."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -25,6 +28,15 @@ def ev(fn):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
+
+if len(sys.argv) > 4 and sys.argv[4] == "pmc":
+    with torch.inference_mode():
+        feat = trunk.stem_forward(x)
+        for _ in range(3):
+            trunk.blocks(feat)
+    torch.cuda.synchronize()
+    print("PMC forwards=3")
+    sys.exit(0)
 
 with torch.inference_mode():
     feat = trunk.stem_forward(x)

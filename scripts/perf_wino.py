@@ -26,6 +26,7 @@ def ev(fn, reps=10):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     patch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    pmc = len(sys.argv) > 3 and sys.argv[3] == "pmc"
     g = torch.Generator(device="cuda").manual_seed(0)
     tot_d = tot_w = 0.0
     for c, div, count in ((64, 4, 4), (128, 8, 3), (256, 16, 3), (512, 32, 3)):
@@ -37,6 +38,10 @@ def main():
         flops = 2.0 * n * hw * hw * c * c * 9
         f0 = lambda: hip_conv2d(x, wp, conv.bias, res, kernel=3, stride=1, padding=1, relu=True)  # noqa: E731
         f2 = lambda: hip_conv3x3_wino(x, up, conv.bias, res, padding=1, relu=True)  # noqa: E731
+        if pmc:  # counter-pass workload: the 13 Winograd launches of exactly two forwards (see perf_trunk.py "pmc")
+            for _ in range(2 * count):
+                f2()
+            continue
         for _ in range(30):  # the clocks ramp up over the first tens of milliseconds of load: an unwarmed first column reads 5-10 % slow
             f0()             # (the "direct" column of profiles/r05b..r05o_perf_wino*.txt was measured without this and is pessimistic)
         td, tw = ev(f0), ev(f2)
@@ -50,6 +55,10 @@ def main():
         print(f"3x3 {c:3d}->{c:3d} @{hw:3d} n={n}: direct {td:6.3f} ms {flops / td / 1e9:6.1f} TF/s | winograd {tw:6.3f} ms "
               f"{flops / tw / 1e9:6.1f} TF/s effective, {flops * 16 / 36 / tw / 1e9:6.1f} exec | x{td / tw:4.2f} | max rel diff {rel:.1e}",
               flush=True)
+    if pmc:
+        torch.cuda.synchronize()
+        print("PMC forwards=2")
+        return
     print(f"13 stride-1 3x3 launches of one resnet18 forward: direct {tot_d:.2f} ms, winograd {tot_w:.2f} ms (x{tot_d / tot_w:.2f})")
 
 

@@ -16,6 +16,15 @@ namespace tia {
 
 constexpr int kWave = 64;
 
+// A batch whose input exceeds the kernels' 32-bit byte offsets goes in groups of at most `max_group` images.  Equal groups, not
+// "full groups and a remainder": 4096 images at 2047 per group are 1366 + 1366 + 1364, not 2047 + 2047 + 2 -- a two-image
+// launch runs on whichever kernel serves tiny batches and costs a launch of its own (measured in the bench trace: 0.5 % of a step).
+inline long even_group(long n, long max_group) {
+    if (max_group < 1 || n <= max_group) return max_group;
+    const long k = (n + max_group - 1) / max_group;
+    return (n + k - 1) / k;
+}
+
 // Per-device one-time host set-up (hipFuncSetAttribute is a per-DEVICE property of a kernel; a process-wide `static bool`
 // would leave the second GPU of a process without it).  `ensure(setup)` runs `setup()` -> bool until it has succeeded once on
 // the calling thread's current device; concurrent first calls may both run it (the set-ups are idempotent), the flag itself

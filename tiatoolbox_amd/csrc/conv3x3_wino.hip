@@ -658,6 +658,8 @@ extern "C" int tia_conv3x3_wino_nhwc_f32(const float* d_x, const float* d_u_pack
     if (group * ho * wo > 0x7fffffffL / 2) group = 0x7fffffffL / 2 / (ho * wo);
     if (group < 1) return TIA_ESIZE;
     if (ho <= 8 && wo <= 8 && group > 4) group -= group % 4;  // whole blocks of four images
+    if (const long even = tia::even_group(n, group); even < group)
+        group = (ho <= 8 && wo <= 8 && even > 4) ? (even + 3) / 4 * 4 : even;  // equal groups (still whole blocks, still <= the limit)
     for (long first = 0; first < n; first += group) {
         const long nb = n - first < group ? n - first : group;
         const int rc = tia::conv3x3_wino_launch(d_x + first * h * w * cin, d_u_packed, d_bias, d_residual ? d_residual + first * ho * wo * cout : nullptr,

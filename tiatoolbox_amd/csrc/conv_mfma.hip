@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "../../include/tiatoolbox_amd.h"
+#include "common.hpp"
 #include "conv3x3_spatial.hpp"
 
 namespace {
@@ -369,7 +370,7 @@ static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d
     if ((reinterpret_cast<uintptr_t>(d_w_packed) & 15) != 0 || (reinterpret_cast<uintptr_t>(d_x) & (pstride % 4 == 0 ? 15 : 3)) != 0)
         return TIA_EINVAL;
     const long image_bytes = h * w * pstride * 4, w_bytes = kh * kw * cin * cout * 4;
-    const long group = conv2d_group(h, w, pstride, cin, cout, kh, kw, ho, wo);
+    const long group = tia::even_group(n, conv2d_group(h, w, pstride, cin, cout, kh, kw, ho, wo));
     if (group < 1) return TIA_ESIZE;
     const bool plain = !with_post && !with_pre && pstride == cin;
     hipStream_t st = (hipStream_t)stream;
@@ -448,11 +449,10 @@ extern "C" int tia_conv2d_route_f32(int64_t n, int64_t h, int64_t w, int64_t cin
     // the same checks, the same batch split and the same decision function as tia_conv2d_nhwc_f32(_ex): shapes the entry point
     // rejects are rejected here with the same code
     if (const int rc = conv2d_check_shape(n, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo); rc != TIA_OK) return rc;
-    const long group = conv2d_group(h, w, cin, cin, cout, kh, kw, ho, wo);
+    const long group = tia::even_group(n, conv2d_group(h, w, cin, cin, cout, kh, kw, ho, wo));
     if (group < 1) return TIA_ESIZE;
-    // a batch beyond 2 GiB of input runs in groups of `group` images: the answer is the route of the FIRST group (every full group
-    // takes it; a shorter last group is decided on its own image count and may take another kernel -- tia_conv2d_route_f32 with
-    // n = n % group tells which)
+    // a batch beyond 2 GiB of input runs in EQUAL groups (tia::even_group; the last one at most k - 1 images shorter): the answer
+    // is the route of the first group
     return (int)conv2d_route(true, n < group ? n : group, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo);
 }
 

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "../../include/tiatoolbox_amd.h"
+#include "common.hpp"
 #include "conv3x3_spatial.hpp"
 
 namespace {
@@ -362,6 +363,7 @@ extern "C" int tia_conv2d_nhwc_h(const void* d_x, const void* d_w_packed, const 
     long group = 0x7fffffffL / image_bytes;
     if (group * ho * wo > 0x7fffffffL / 2) group = 0x7fffffffL / 2 / (ho * wo);
     if (group < 1) return TIA_ESIZE;
+    group = tia::even_group(n, group);
     hipStream_t st = (hipStream_t)stream;
     const bool bf = dtype == TIA_DT_BF16;
     for (long first = 0; first < n; first += group) {

@@ -461,6 +461,7 @@ static int stem_impl(const void* d_x, int32_t x_is_u8, const void* d_w_packed, c
     if (image_bytes > 0x7fffffffL) return TIA_ESIZE;
     long group = 0x7fffffffL / image_bytes;  // 32-bit byte offsets inside a launch
     if (group > 0x7fffffffL / (h * w * 3)) group = 0x7fffffffL / (h * w * 3);
+    group = tia::even_group(n, group);
     const long strips = wp <= 64 ? 1 : 1 + (wp - 64 + 62) / 63;
     using Kernel = void (*)(const void*, const void*, const float*, void*, float*, StemDims);
     const Kernel kernels[3][2] = {{stem7x7_pool_kernel<false, 0>, stem7x7_pool_kernel<true, 0>},
