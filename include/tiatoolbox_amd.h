@@ -501,9 +501,9 @@ int tia_conv3x3_wino_nhwc_f32(const float* d_x, const float* d_u_packed, const f
  * which block geometry), 2: conv1x1_ring_kernel (LDS-DMA ring over 256-pixel blocks: 1x1, and kh x kw taps gathered).  For
  * tests and bench.py (they ask instead of mirroring the dispatch rule).  It runs the entry point's own shape checks, batch split
  * (< 2 GiB of input per launch) and decision function: shapes the entry point rejects return the same negative code (TIA_EINVAL /
- * TIA_ESIZE, e.g. cin % 32 != 0); for a batch that is split the answer is the route of a full group (a shorter last group is decided
- * on its own image count -- ask again with n = the remainder).  The ring's fill rule uses the CU count of the calling thread's
- * current device (256 without a device). */
+ * TIA_ESIZE, e.g. cin % 32 != 0); a batch that is split goes in EQUAL groups (ceil(n / k) images for the smallest k that fits:
+ * 4096 images of 1 MiB run as 1366 + 1366 + 1364) and the answer is the route of that group size.  The ring's and the bands' fill
+ * rules use the CU count of the calling thread's current device (256 without a device). */
 int tia_conv2d_route_f32(int64_t n, int64_t h, int64_t w, int64_t cin, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
                          int64_t pad_top, int64_t pad_left, int64_t ho, int64_t wo);
 
