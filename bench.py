@@ -611,7 +611,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
         pmc_c = pmc_traffic(dominant, "trunk" if mb == 1024 else f"trunk{mb}", dk["launches"]) if hw == 256 else None
         if pmc_c is not None:
             roofline["traffic"] = round(pmc_c["bytes"])
-            roofline["traffic_source"] = pmc_c["source"] + f" (scripts/perf_trunk.py {mb} 256: mean over the launches of one forward)"
+            roofline["traffic_source"] = pmc_c["source"] + f" (workload: scripts/perf_trunk.py {mb} 256 [5 pmc])"
     else:
         dominant = "stain_stats_kernel"  # the longest-running hand-written kernel of a step when the library convolves
         dk = kernels[dominant]
@@ -718,7 +718,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                                       "direct convolution's 2*M*Cout*Cin*9 over the same time (may exceed the MFMA peak)"),
                              "blocks_ms": round(t_blocks_w * 1e3, 3),
                              "traffic": round(pmc_w["bytes"]) if pmc_w else None,
-                             **({"traffic_source": pmc_w["source"] + f" (scripts/perf_wino.py {mb} 256: mean over the launches of this kernel)"}
+                             **({"traffic_source": pmc_w["source"] + f" (workload: scripts/perf_wino.py {mb} 256 [pmc])"}
                                 if pmc_w else {})},
                 "note": ("extra only: the float32 3x3 / stride-1 block convolutions through Winograd F(2x2, 3x3) (float32 in / float32 "
                          "accumulate, weights transformed once in float64); same stain front-end, stem, strided / 1x1 convolutions as `value`")}
