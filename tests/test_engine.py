@@ -86,6 +86,27 @@ def test_user_preproc_hook_runs_per_patch(patches):
 
 
 # ---------------------------------------------------------------------------------------- GPU
+def test_batch_cuts_ramp_the_first_host_batches():
+    """``EngineABC._batch_cuts``: ``batch_size`` patches per batch; with host input on the asynchronous feed the first
+    ``batch_size`` patches go as 1/8, 1/4 and 5/8 of a batch (the first copy is the only transfer nothing hides), every later cut
+    is a multiple of the batch size from the shard's start, the shard's end closes the list, an empty shard has no batch."""
+    from types import SimpleNamespace
+
+    from tiatoolbox_amd.models.engine.engine_abc import EngineABC
+
+    feed = SimpleNamespace(registered=True)
+    cuts = lambda bs, lo, hi, f: EngineABC._batch_cuts(SimpleNamespace(batch_size=bs, _feed=f), lo, hi)  # noqa: E731, SLF001
+    assert cuts(1024, 0, 4096, feed) == [0, 128, 384, 1024, 2048, 3072, 4096]
+    assert cuts(1024, 100, 4196, feed) == [100, 228, 484, 1124, 2148, 3172, 4196]
+    assert cuts(1024, 0, 4096, None) == [0, 1024, 2048, 3072, 4096]
+    assert cuts(1024, 0, 4096, SimpleNamespace(registered=False)) == [0, 1024, 2048, 3072, 4096]
+    assert cuts(1024, 0, 1500, feed) == [0, 1024, 1500]  # fewer than two batches: no ramp
+    assert cuts(8, 0, 20, feed) == [0, 8, 16, 20] and cuts(1024, 7, 7, feed) == [7]
+    for bs, lo, hi in ((64, 0, 130), (1000, 3, 5003), (4096, 0, 8192)):
+        c = cuts(bs, lo, hi, feed)
+        assert c[0] == lo and c[-1] == hi and all(a < b for a, b in zip(c[:-1], c[1:])) and max(b - a for a, b in zip(c[:-1], c[1:])) <= bs
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize(("dtype", "tol"), [("float32", 1e-4), ("float16", 5e-3), ("bfloat16", 3e-2)])
 def test_gpu_probabilities_match_cpu_fp32(patches, dtype, tol):
@@ -99,6 +120,25 @@ def test_gpu_probabilities_match_cpu_fp32(patches, dtype, tol):
     assert err <= tol
     if dtype == "float32":
         assert np.array_equal(gpu["predictions"], cpu["predictions"])
+
+
+@pytest.mark.gpu
+def test_host_feed_with_ramped_first_batches_equals_device_resident_input(target_image):
+    """Host NumPy patches large enough for the asynchronous feed (page-locked in place, copied one batch ahead; the first batch
+    of the run goes as 1/8 + 1/4 + 5/8 of a batch) against the same patches already resident on the device: same predictions,
+    probabilities equal up to the rounding of convolution kernels chosen per batch size."""
+    from tiatoolbox_amd.tools.stainnorm import get_normalizer
+
+    host = synth.g_he(400, 64, 64, seed=3)  # 4.9 MB: above the feed's registration threshold
+    norm = get_normalizer("macenko")
+    norm.fit(target_image)
+    eng = PatchPredictor("resnet18-kather100k", batch_size=64, device="cuda")
+    kw = {"patch_mode": True, "return_probabilities": True, "stain_normalizer": norm, "patch_input_shape": (64, 64)}
+    got = eng.run(host, **kw)
+    ref = eng.run(torch.from_numpy(host).cuda(), **kw)
+    assert got["probabilities"].shape == (400, 9)
+    assert np.array_equal(got["predictions"], ref["predictions"])
+    np.testing.assert_allclose(got["probabilities"], ref["probabilities"], atol=1e-5)
 
 
 @pytest.mark.gpu
