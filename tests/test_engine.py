@@ -86,6 +86,17 @@ def test_user_preproc_hook_runs_per_patch(patches):
 
 
 # ---------------------------------------------------------------------------------------- GPU
+def test_conv_algo_is_validated_on_every_device(patches):
+    """``conv_algo`` (run kwarg; opt-in float32 Winograd on the GPU) accepts ``"direct"`` / ``"winograd"`` only -- also on the CPU,
+    where it has no effect on the arithmetic."""
+    eng = PatchPredictor("resnet18-kather100k", batch_size=4)
+    ref = eng.run(patches, patch_mode=True, return_probabilities=True)
+    same = eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo="winograd")
+    assert np.array_equal(ref["probabilities"], same["probabilities"])
+    with pytest.raises(ValueError, match="conv_algo must be"):
+        eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo="fft")
+
+
 def test_batch_cuts_ramp_the_first_host_batches():
     """``EngineABC._batch_cuts``: ``batch_size`` patches per batch; with host input on the asynchronous feed the first
     ``batch_size`` patches go as 1/8, 1/4 and 5/8 of a batch (the first copy is the only transfer nothing hides), every later cut

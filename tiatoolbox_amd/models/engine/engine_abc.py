@@ -386,9 +386,12 @@ class EngineABC:
 
     def _inference_model(self, dtype: torch.dtype):
         """The module used for the forward pass: parameters in ``dtype``, channels-last (MIOpen NHWC)."""
+        algo = str(getattr(self, "conv_algo", None) or "direct")
+        if algo not in ("direct", "winograd"):  # (the same message on every device; on the CPU the option has no effect)
+            msg = f"conv_algo must be 'direct' or 'winograd', got {algo!r}."
+            raise ValueError(msg)
         if dtype == torch.float32 and torch.device(self.device).type != "cuda":
             return self.model
-        algo = str(getattr(self, "conv_algo", None) or "direct")
         key = (dtype, str(self.device), id(self.model), self.fold_batchnorm, _weights_version(self.model), algo)
         if self._fast_key != key:
             import copy
