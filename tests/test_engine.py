@@ -95,6 +95,8 @@ def test_conv_algo_is_validated_on_every_device(patches):
     assert np.array_equal(ref["probabilities"], same["probabilities"])
     with pytest.raises(ValueError, match="conv_algo must be"):
         eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo="fft")
+    again = eng.run(patches, patch_mode=True, return_probabilities=True)  # the rejected value does not persist
+    assert eng.conv_algo == "direct" and np.array_equal(ref["probabilities"], again["probabilities"])
 
 
 def test_batch_cuts_ramp_the_first_host_batches():

@@ -388,6 +388,7 @@ class EngineABC:
         """The module used for the forward pass: parameters in ``dtype``, channels-last (MIOpen NHWC)."""
         algo = str(getattr(self, "conv_algo", None) or "direct")
         if algo not in ("direct", "winograd"):  # (the same message on every device; on the CPU the option has no effect)
+            self.conv_algo = "direct"  # (run kwargs persist as attributes: do not leave the rejected value behind)
             msg = f"conv_algo must be 'direct' or 'winograd', got {algo!r}."
             raise ValueError(msg)
         if dtype == torch.float32 and torch.device(self.device).type != "cuda":
