@@ -145,12 +145,14 @@ int tia_stain_stats_path(int64_t h, int64_t w, const tia_stain_params* params /*
 #define TIA_OUT_UNIT_BF16 4
 #define TIA_OUT_UNIT_F32 5
 
-#define TIA_MATH_F64 0 /* float64 throughout; exp() evaluated by the kernel's own table + cubic (relative error
-                          <= 4e-15, i.e. < 1e-12 on the 0..255 scale), 3x3 matrix TIA_ST_M fused in float64  */
+#define TIA_MATH_F64 0 /* float64 throughout, 3x3 matrix TIA_ST_M fused in float64; 255 exp(-OD') evaluated as the
+                          product of three per-patch table entries T_j[c][v] = exp(-LUT[v] m[j][c]) built with libm
+                          (16-byte-access kernels, round 5; relative error <= ~1e-15) or by the kernel's own table +
+                          cubic (12-byte-access kernels; <= 4e-15): < 1e-12 on the 0..255 scale either way */
 #define TIA_MATH_F32 1 /* fused 3x3 matrix in f32: |err| <= 1e-4 on the pre-cast float            */
 #define TIA_MATH_F64_REF 2 /* the reference's order of operations in f64 (stainnorm.py:102-107) with the device
                               library's exp(): parity audit of TIA_MATH_F64, and its in-kernel fall-back for patches
-                              whose exponent range is not safe for the table arithmetic           */
+                              whose matrix is not finite / outside the table arithmetic's safe range    */
 
 /*
  * out = 255*exp(-(OD(img) . pinv . diag(scale) . S_target)), clipped to [0,255].
