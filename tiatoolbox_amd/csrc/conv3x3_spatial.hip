@@ -795,7 +795,10 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
                    (unsigned)(nb * h * w * cin * es), (unsigned)(9 * cin * cout * es), plan.bw, plan.br, plan.brow, (int)(h + pad_top), plan.strips,
                    plan.bpix, band ? 1.0f / (float)plan.bw : 0.0f, band ? 1.0f / (float)plan.brow : 0.0f, 1.0f / (float)(h + pad_top),
                    pack ? 1 : 0, (int)(h + pad_top - ho), 1.0f / (float)ho};
-    const bool wide = cout % 128 == 0;
+    // 128-channel column tiles, unless that leaves fewer workgroups than the device has CUs (small batches of small maps: UNet-R50's
+    // 512 -> 512 @ 32^2 at batch 8 is 128 workgroups for 256 CUs: 73 TFLOP/s): then 64-channel tiles, twice as many workgroups
+    static const bool no_narrow = getenv("TIA_CONV_NO_NARROW_FILL") != nullptr;  // developer switch (A/B measurements)
+    const bool wide = cout % 128 == 0 && (no_narrow || tiles * (cout / 128) >= device_cu_count());
     static const bool wide8 = getenv("TIA_CONV_N64_8WAVES") != nullptr;  // developer switch: 64-channel band tiles on the 8-wave (4 x 2) form
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / (wide ? 128 : 64)));
 #define TIA_LAUNCH_GEO(BN_, KIND_, GEO_)                                                                                           \
