@@ -327,6 +327,8 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
              (1, 32, 64, 9, 3, 1), (2, 64, 64, 13, 3, 2),
              # 3x3 / stride 1 on maps covered well by 16 x 16 pixel blocks: the tap-reuse kernel (whole / clipped blocks, both widths)
              (2, 64, 64, 32, 3, 1), (1, 96, 128, 30, 3, 1), (2, 32, 192, 48, 3, 1), (1, 256, 64, 16, 3, 1),
+             # ... with at least one workgroup per CU, so that the 128-channel column tiles are taken (fewer: 64-channel tiles)
+             (70, 32, 128, 32, 3, 1), (520, 32, 128, 8, 3, 1),
              # band geometry (maps 16 x 16 blocks cover badly): bands of real rows that straddle images (up to five zero rows inside a
              # 7-wide band's patch) / end inside the last image / are the only block of the launch, one and two strips, 64- and
              # 128-column tiles
@@ -381,8 +383,9 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
             assert err <= 1e-4, (n, cin, cout, hw, k, stride, use_res, relu, err)
         if n >= 40:  # noqa: PLR2004
             ho_ = ref_lin.shape[2]
-            # the gathering ring; 7 x 7 maps: the tap-reuse kernel's bands
-            assert _lib.load().tia_conv2d_route_f32(n, hw, hw, cin, cout, k, k, stride, pad, pad, ho_, ho_) == (1 if hw == 7 else 2)  # noqa: PLR2004
+            # the gathering ring; stride-1 3x3 on 7 x 7 maps (bands) and on 8 x 8 / 32 x 32 maps (fixed geometries): the tap-reuse kernel
+            tap_reuse = k == 3 and stride == 1 and hw in (7, 8, 32)  # noqa: PLR2004
+            assert _lib.load().tia_conv2d_route_f32(n, hw, hw, cin, cout, k, k, stride, pad, pad, ho_, ho_) == (1 if tap_reuse else 2)  # noqa: PLR2004
             # against the slice kernel (the two-output epilogue form always runs on it; its raw output is the same convolution):
             # the same float32 fmaf chains over taps and slices, channels within a 16-slice in another order -- rounding noise only
             from tiatoolbox_amd.models.architecture.fused import hip_conv2d_post
@@ -534,6 +537,8 @@ def test_hip_mfma_conv_half_matches_torch_cpu_fp32(dtype):
              (3, 64, 64, 32, 32, 3, 1), (2, 128, 256, 16, 16, 3, 1), (1, 96, 128, 30, 31, 3, 1), (1, 64, 64, 15, 16, 3, 1),
              (2, 256, 128, 14, 16, 3, 1), (1, 32, 192, 64, 48, 3, 1),
              (5, 512, 512, 8, 8, 3, 1), (3, 64, 128, 7, 8, 3, 1), (2, 128, 64, 8, 8, 3, 1),
+             # (>= 256 workgroups: 128-channel column tiles on both fixed geometries)
+             (70, 32, 128, 32, 32, 3, 1), (520, 32, 128, 8, 8, 3, 1),
              # the half kernels' bands (conflict-free pixel pitch of 5 units): zero rows among the GEMM rows (28-wide / 21-wide strips),
              # and the two map sizes where bands of real rows win with that pitch (33, 55: 11-wide strips of 21 rows)
              (3, 64, 64, 28, 28, 3, 1), (2, 32, 128, 42, 42, 3, 1), (7, 64, 128, 33, 33, 3, 1), (2, 32, 64, 55, 55, 3, 1)]
