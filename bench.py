@@ -20,7 +20,9 @@ hand-written kernels only (stem: uint8 in, ``ToTensor``'s 1/255 on load, conv7x7
 implicit GEMM -- the reference's arithmetic, ``vanilla.py:242``), softmax, argmax, the RCCL all-gather of the probabilities
 (N > 1) and the copy of the result dict to host NumPy.  For ``value`` the uint8 patches are already resident in HBM when the timed region starts
 (the engine's torch-tensor overload); the same call on HOST NumPy patches (H2D over PCIe included) is timed right after
-and reported as ``host_inclusive``.  Extras on rank 0 at N=1: the fp16 backbone with its measured max |dp| against the
+and reported as ``host_inclusive`` (engine batches of 1024 there, so that copies hide behind compute; the resident run takes its
+4096 patches as ONE engine batch: ``--micro-batch``).  Extras on rank 0 at N=1: ``cnn_winograd`` = the same call with
+``conv_algo="winograd"`` (opt-in float32 Winograd; executed and effective flops reported separately), the fp16 backbone with its measured max |dp| against the
 fp32 probabilities of the same batch (tolerance 1e-3, ``tests/engines/test_patch_predictor.py:719`` of the reference),
 the 224x224 patch size of BASELINE configs[1], and -- ``extras.configs`` -- a SHORT run of each of BASELINE configs[2]-[4]
 (``bench_configs.py``: semantic / hovernet / vahadane; value, step time, the config's roofline entry, a one-line CPU baseline), so
