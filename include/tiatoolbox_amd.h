@@ -35,7 +35,10 @@ extern "C" {
 /* Version 4 (round 4): + tia_rgb2od_u8 (the stand-alone OD transform, with the reference's in-place side effect on request),
  * tia_clear_last_error; TIA_MATH_F64 of tia_stain_apply_u8 evaluates exp() with the library's own float64 kernel
  * (TIA_MATH_F64_REF keeps the device libm's exp); tia_conv3x3_geometry, tia_stain_stats_path (dispatch diagnostics). */
-#define TIA_ABI_VERSION 5
+/* Version 6 (round 6): + tia_gray_hist_u8 / tia_otsu_threshold_u32 / tia_threshold_lt_dev_u8 (one-pass Otsu fit whose threshold
+ * stays on the device), tia_morph_mask_u8 (the morphological masker in one launch), tia_reinhard_transform_u8 /
+ * tia_lab_moments_u8 (fused Reinhard), tia_luminosity_mask_u8 / tia_stain_augment_u8 take 16-byte accesses where the shape allows. */
+#define TIA_ABI_VERSION 6
 int tia_abi_version(void);
 
 /* Reads-and-clears the HIP runtime's sticky last-error value as THIS library sees it (every entry point returns
@@ -215,6 +218,30 @@ int tia_hist256_u8(const uint8_t* d_data, int64_t n, uint32_t* d_hist, void* str
 int tia_threshold_lt_u8(const uint8_t* d_src, int64_t npix, int32_t is_rgb, int32_t thr,
                         uint8_t* d_mask, void* stream);
 
+/* OtsuTissueMasker.fit in one pass (tools/tissuemask.py:127-137): the grey conversion of tia_rgb2gray_u8 (channels == 3; a grey
+ * plane with channels == 1) fused with the 256-bin histogram, ACCUMULATED into d_hist[256] (zero it first; several calls add
+ * several images).  Nothing is written but the counts: 3 bytes read per pixel. */
+int tia_gray_hist_u8(const uint8_t* d_img, int64_t npix, int32_t channels, uint32_t* d_hist, void* stream);
+
+/* skimage.filters.threshold_otsu of a 256-bin byte histogram on the device (tools/tissuemask.py:131-134): d_out[0] = threshold
+ * (bin centre of the first maximum of the between-class variance over the occupied range; the only occupied bin when there is one),
+ * d_out[1] = number of occupied bins.  Bit-identical to the float64 NumPy arithmetic (all partial sums are exact integers). */
+int tia_otsu_threshold_u32(const uint32_t* d_hist, int32_t* d_out, void* stream);
+
+/* tia_threshold_lt_u8 with the threshold read from device memory (d_thr[0], e.g. tia_otsu_threshold_u32's output): fit and
+ * transform enqueue back to back without a host round trip (tools/tissuemask.py:139-164). */
+int tia_threshold_lt_dev_u8(const uint8_t* d_src, int64_t npix, int32_t is_rgb, const int32_t* d_thr, uint8_t* d_mask,
+                            void* stream);
+
+/* MorphologicalMasker.transform in one launch (tools/tissuemask.py:270-306): grey < thr (thr from d_thr[0] when d_thr is given),
+ * skimage remove_small_objects(min_size = min_region, connectivity 8), cv2.dilate with the element whose non-zero entries are
+ * d_offsets [n_off,2] = (dy, dx) relative to the anchor (`reach` = max |dy|, |dx|).  d_img [n,h,w,channels] (3: RGB, the grey
+ * conversion fused; 1: grey plane) -> d_mask [n,h,w] 0/1.  Tiles of 256 x 128 pixels with a halo of reach + min_region - 1 are
+ * labelled in LDS; a halo above 40 pixels returns TIA_ESIZE (use tia_threshold_lt_u8 + tia_ccl_label_i32 +
+ * tia_label_area_filter_i32 + tia_binary_morph_u8). */
+int tia_morph_mask_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w, int32_t channels, int32_t thr, const int32_t* d_thr,
+                      int32_t min_region, const int32_t* d_offsets, int32_t n_off, int32_t reach, uint8_t* d_mask, void* stream);
+
 /* Connected-component labelling of n binary planes (non-zero = foreground), connectivity 4 or 8.
  * Labels are 1..K per plane, numbered in raster order of each component's first pixel
  * (= scipy.ndimage.label, hovernet.py:543,607; cv2.connectedComponentsWithStats labelling,
@@ -386,6 +413,24 @@ int tia_reinhard_luts(const uint32_t* d_hist, int64_t n, const float* d_chan_val
 /* cv2.cvtColor 8-bit RGB2LAB (dir 0) / LAB2RGB (dir 1) of npix pixels. */
 int tia_lab_convert_u8(const uint8_t* d_src, int64_t npix, const tia_lab_tables* d_tables, int32_t dir,
                        uint8_t* d_dst, void* stream);
+
+/* ReinhardNormalizer.transform in ONE launch for a batch of patches (stainnorm.py:272-367): per patch RGB->Lab, the channel
+ * moments (cv2.meanStdDev, float64 in NumPy's pairwise order), the three float32 byte tables, table -> Lab->RGB.  The Lab image is
+ * parked as one dword per pixel in a per-workgroup slot of d_workspace (tia_reinhard_workspace_bytes; it stays in L2 / Infinity
+ * Cache), so HBM carries 3 bytes in + 3 bytes out per pixel.  Shapes it does not take (h*w not a multiple of 1024 or above 2^18
+ * pixels, buffers not 16-byte aligned) return TIA_ESIZE: use tia_lab_hist_u8 + tia_reinhard_luts + tia_reinhard_apply_u8, which
+ * split a large image over many workgroups.  d_chan_vals: float32 [3,256] channel value of every Lab byte (host-built, :295-315);
+ * target_means / target_stds: host double[3]; d_meanstd (nullable) [n,6]; d_flags (nullable) [n]: bit 0 = zero std (the reference
+ * raises ZeroDivisionError). */
+size_t tia_reinhard_workspace_bytes(int64_t n, int64_t h, int64_t w);
+int tia_reinhard_transform_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w, const tia_lab_tables* d_tables,
+                              const float* d_chan_vals, const double* target_means, const double* target_stds, uint8_t* d_out,
+                              double* d_meanstd, int32_t* d_flags, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ReinhardNormalizer.get_mean_std of n images in one launch (stainnorm.py:343-367): d_meanstd [n,6] = means of L/2.55, a-128, b-128,
+ * then the population standard deviations.  Same shape limits as tia_reinhard_transform_u8 (TIA_ESIZE otherwise). */
+int tia_lab_moments_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w, const tia_lab_tables* d_tables,
+                       const float* d_chan_vals, double* d_meanstd, int32_t* d_flags, void* stream);
 
 
 /* out[i, j] = lut[i, img[i, j]]: one 256-byte table per image -- the intensity map of contrast_enhancer

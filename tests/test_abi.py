@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in _declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"missing exports: {missing}"
     lib.tia_abi_version.restype = ctypes.c_int
-    assert lib.tia_abi_version() == 5
+    assert lib.tia_abi_version() == 6
 
 
 def test_python_binding_covers_header():

@@ -123,3 +123,53 @@ def test_hip_reinhard_device_luts_match_host_arithmetic():
     norm.fit(np.random.default_rng(0).integers(0, 255, (16, 16, 3), dtype=np.uint8))
     with pytest.raises(ZeroDivisionError):
         norm.transform(flat)
+
+
+@pytest.mark.gpu
+def test_hip_lab_conversions_exhaustive():
+    """EVERY 24-bit RGB value through RGB2LAB and every Lab triple through LAB2RGB, against the oracle's integer arithmetic: the float32
+    forward path (exact sums below 2^24, round-half-up through v_cvt_pk_u8_f32) and the 24-bit-multiply inverse are bit-exact everywhere,
+    not only on samples.  16.7 M pixels = 16384 wave steps of the 16-byte path."""
+    import torch
+
+    from tiatoolbox_amd.tools import reinhard
+
+    v = np.arange(1 << 24, dtype=np.uint32)
+    allpx = np.stack([v & 255, (v >> 8) & 255, v >> 16], axis=-1).astype(np.uint8).reshape(4096, 4096, 3)
+    dev = torch.from_numpy(allpx).cuda()
+    lab = reinhard.lab_convert(dev, 0).cpu().numpy()
+    back = reinhard.lab_convert(dev, 1).cpu().numpy()
+    for s in range(0, 4096, 512):   # the oracle in slabs (memory)
+        assert np.array_equal(lab[s:s + 512], cvref.rgb2lab_u8(allpx[s:s + 512])), s
+        assert np.array_equal(back[s:s + 512], cvref.lab2rgb_u8(allpx[s:s + 512])), s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(5, 64, 64), (3, 32, 32), (2, 224, 224), (1, 1000, 1000), (2, 37, 53), (1, 1024, 1536)])
+def test_hip_reinhard_paths_match_oracle(shape, target_image):
+    """transform / statistics on every route -- the one-launch fused kernel (h*w a multiple of 1024), the three-launch form with the
+    16-byte kernels (a large image split over many workgroups) and its scalar form (ragged sizes) -- against the oracle, bit for bit:
+    noise, a flat white region (every lane on one histogram counter), near-black pixels (the cube's linear branch)."""
+    import torch
+
+    from tiatoolbox_amd.tools.stainnorm import get_normalizer
+
+    n, h, w = shape
+    rng = np.random.default_rng(h * 7 + w)
+    imgs = synth.g_he(n, h, w, seed=h + w)
+    imgs[0, : h // 3] = 255
+    imgs[0, h // 3: h // 3 + max(1, h // 8)] = rng.integers(0, 12, (max(1, h // 8), w, 3), dtype=np.uint8)
+    imgs[-1, :, : w // 2] = rng.integers(0, 256, (h, w // 2, 3), dtype=np.uint8)
+    norm, ref = get_normalizer("reinhard"), ostain.get_normalizer("reinhard")
+    norm.fit(target_image)
+    ref.fit(target_image.copy())
+    got = norm.transform(torch.from_numpy(imgs).cuda()).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], ref.transform(imgs[i].copy())), (shape, i)
+    ms = norm.lab_statistics(torch.from_numpy(imgs).cuda()).cpu().numpy()
+    for i in range(n):
+        mean, std = ref.get_mean_std(imgs[i].copy())
+        np.testing.assert_allclose(ms[i, :3], mean, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(ms[i, 3:], std, rtol=0, atol=1e-9)
+        m2, s2 = norm.get_mean_std(imgs[i])
+        assert np.array_equal(ms[i], np.concatenate([m2, s2]))   # device moments == the host arithmetic on the device's counts

@@ -136,3 +136,105 @@ def test_large_plane_ccl_properties():
     assert int(count[0]) == n and np.array_equal(labels[0].cpu().numpy(), exp)
     relabel, count2 = img.ccl_label((labels > 0).to(torch.uint8), connectivity=4)
     assert torch.equal(relabel, labels) and int(count2[0]) == n
+
+
+@pytest.mark.gpu
+def test_device_otsu_threshold_matches_numpy_arithmetic():
+    """tia_otsu_threshold_u32 == the host's scikit-image arithmetic on the occupied range, for adversarial histograms."""
+    import torch
+
+    from tiatoolbox_amd.tools import _img_device as img
+    from tiatoolbox_amd.tools.tissuemask import _otsu_from_counts
+
+    rng = np.random.default_rng(5)
+    cases = [rng.integers(0, 1000, 256), rng.integers(0, 2, 256) * rng.integers(1, 1 << 20, 256), np.zeros(256, np.int64), np.zeros(256, np.int64),
+             np.zeros(256, np.int64), (rng.random(256) ** 8 * 4e8).astype(np.int64), np.full(256, 7), np.zeros(256, np.int64)]
+    cases[2][17] = 5                                     # one occupied bin
+    cases[3][[3, 250]] = (9, 9)                          # two bins, far apart (flat maximum: first index wins)
+    cases[4][[100, 101]] = (1, 4_000_000_000)            # two adjacent bins, counts near 2^32
+    cases[7][[0, 128, 255]] = (10, 1, 10)                # symmetric: tie between the two halves
+    for counts in cases:
+        counts = np.asarray(counts, dtype=np.int64)
+        nz = np.flatnonzero(counts)
+        if nz.size == 1:
+            exp = int(nz[0])
+        else:
+            lo, hi = int(nz[0]), int(nz[-1])
+            exp = int(_otsu_from_counts(counts[lo:hi + 1], np.arange(lo, hi + 1, dtype=np.float64)))
+        dev = torch.from_numpy(counts.astype(np.uint32).view(np.int32)).cuda()
+        out = img.otsu_threshold(dev).cpu().numpy()
+        assert int(out[0]) == exp and int(out[1]) == nz.size, (counts[nz][:8], out, exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 64, 64), (1, 37, 53), (2, 128, 96), (1, 1, 5), (5, 160, 200)])
+def test_fused_grey_histogram_and_wide_threshold(shape):
+    """One-pass grey + histogram == bincount of the oracle's grey image; the 16-byte threshold kernel == grey < thr: sizes that are
+    and are not multiples of the 1024-pixel wave step, aligned and unaligned bases, an image of one grey level."""
+    import torch
+
+    from tiatoolbox_amd.tools import _img_device as img
+
+    rng = np.random.default_rng(shape[1])
+    n, h, w = shape
+    rgb = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    rgb[0, : h // 2] = 200                                            # a flat half: every lane of a wave on one counter
+    grey = np.stack([omask._grey(i) for i in rgb])                     # noqa: SLF001
+    for off in (0, 3):                                                # offset 3 bytes: the unaligned (scalar) path
+        flat = torch.zeros(rgb.size + 16, dtype=torch.uint8, device="cuda")
+        view = flat[off:off + rgb.size].view(n, h, w, 3)
+        view.copy_(torch.from_numpy(rgb))
+        counts = img.gray_hist(view, channels=3).cpu().numpy()
+        assert np.array_equal(counts, np.bincount(grey.ravel(), minlength=256))
+        assert np.array_equal(img.gray_hist(torch.from_numpy(grey).cuda(), channels=1).cpu().numpy(), counts)
+        for thr in (0, 97, 200, 201, 256):
+            got = img.threshold_lt(view, thr, is_rgb=True).cpu().numpy()
+            assert np.array_equal(got, (grey < thr).astype(np.uint8)), (off, thr)
+        thr_dev = torch.tensor([131, 0], dtype=torch.int32, device="cuda")
+        assert np.array_equal(img.threshold_lt(view, thr_dev, is_rgb=True).cpu().numpy(), (grey < 131).astype(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize(("kw", "shape"), [({"power": 1.25}, (2, 700, 900)), ({"kernel_size": 5}, (1, 300, 1100)),
+                                            ({"kernel_size": (7, 3), "min_region_size": 30}, (1, 513, 257)),
+                                            ({"kernel_size": 1, "min_region_size": 0}, (1, 130, 260)),
+                                            ({"mpp": 2.0}, (1, 400, 400))])
+def test_one_launch_morphological_masker_matches_oracle(kw, shape):
+    """The tile kernel (threshold + small-region removal + dilation in LDS, halo = element reach + min_region_size - 1) against the
+    oracle on images of several tiles: components that cross tile borders, thin lines longer than the halo but smaller than the
+    area bound and the other way round, specks at every density, image borders; the last case (16 x 16 element: halo > 40) is the
+    multi-launch fallback."""
+    import torch
+
+    from tiatoolbox_amd.tools import tissuemask as hmask
+
+    n, h, w = shape
+    rng = np.random.default_rng(h + w)
+    grey = np.full((n, h, w), 230, np.uint8)
+    for i in range(n):
+        for p in (0.002, 0.02, 0.2):                      # specks: isolated pixels .. touching clusters
+            y0, x0 = rng.integers(0, h // 2), rng.integers(0, w // 2)
+            blk = rng.random((h // 2, w // 2)) < p
+            grey[i, y0:y0 + h // 2, x0:x0 + w // 2][blk] = 40
+        for _ in range(40):                               # lines: horizontal, vertical, diagonal, 2 .. 60 pixels
+            ln, y, x = int(rng.integers(2, 60)), int(rng.integers(0, h)), int(rng.integers(0, w))
+            dy, dx = [(0, 1), (1, 0), (1, 1), (1, -1)][int(rng.integers(0, 4))]
+            for t in range(ln):
+                yy, xx = y + t * dy, x + t * dx
+                if 0 <= yy < h and 0 <= xx < w:
+                    grey[i, yy, xx] = 40
+        grey[i, :3, : w // 3] = 40                        # on the image border
+        grey[i, h - 1, w - 5:] = 40
+        grey[i, 100:104, 200:230] = 40
+    rgb = np.repeat(grey[..., None], 3, axis=-1)
+    rgb[..., 1] = np.clip(rgb[..., 1].astype(int) + rng.integers(-3, 4, grey.shape), 0, 255).astype(np.uint8)
+    ref = omask.MorphologicalMasker(**kw)
+    exp = ref.fit_transform(rgb)
+    got_m = hmask.MorphologicalMasker(**kw)
+    got = got_m.fit_transform(torch.from_numpy(rgb).cuda())
+    assert got.dtype == torch.bool and got_m.threshold == ref.threshold
+    assert np.array_equal(got.cpu().numpy(), exp), (kw, int((got.cpu().numpy() != exp).sum()))
+    one = hmask.MorphologicalMasker(**kw)                  # grey (single-channel) input: same masks from the grey plane
+    g3 = np.stack([omask._grey(i) for i in rgb])           # noqa: SLF001
+    one.fit(torch.from_numpy(rgb).cuda())
+    assert np.array_equal(one.transform(torch.from_numpy(g3[..., None]).cuda()).cpu().numpy(), exp)

@@ -22,6 +22,7 @@ MODE_MACENKO, MODE_FIXED, MODE_VAHADANE, MODE_GIVEN = 0, 1, 2, 3
 OUT_U8, OUT_F32, OUT_F64, OUT_UNIT_F16, OUT_UNIT_BF16, OUT_UNIT_F32 = 0, 1, 2, 3, 4, 5
 MATH_F64, MATH_F32, MATH_F64_REF = 0, 1, 2
 
+TIA_EINVAL, TIA_ELAUNCH, TIA_ESIZE = -1, -2, -3
 _ERRORS = {-1: "TIA_EINVAL (bad argument)", -2: "TIA_ELAUNCH (HIP launch failed)",
            -3: "TIA_ESIZE (size not supported)"}
 
@@ -71,6 +72,10 @@ _SIGNATURES = {
     "tia_rgb2gray_u8": ([_P, _I64, _P, _P], C.c_int),
     "tia_hist256_u8": ([_P, _I64, _P, _P], C.c_int),
     "tia_threshold_lt_u8": ([_P, _I64, _I32, _I32, _P, _P], C.c_int),
+    "tia_gray_hist_u8": ([_P, _I64, _I32, _P, _P], C.c_int),
+    "tia_otsu_threshold_u32": ([_P, _P, _P], C.c_int),
+    "tia_threshold_lt_dev_u8": ([_P, _I64, _I32, _P, _P, _P], C.c_int),
+    "tia_morph_mask_u8": ([_P, _I64, _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _I32, _P, _P], C.c_int),
     "tia_lut_apply_u8": ([_P, _I64, _I64, _P, _P, _P], C.c_int),
     "tia_box_downsample_u8": ([_P, _I64, _I64, _I64, _I64, _P, _P], C.c_int),
     "tia_ccl_label_i32": ([_P, _I64, _I64, _I64, _I32, _P, _P, _P, _P], C.c_int),
@@ -90,6 +95,9 @@ _SIGNATURES = {
     "tia_reinhard_apply_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _P], C.c_int),
     "tia_reinhard_luts": ([_P, _I64, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "tia_lab_convert_u8": ([_P, _I64, _P, _I32, _P, _P], C.c_int),
+    "tia_reinhard_workspace_bytes": ([_I64, _I64, _I64], C.c_size_t),
+    "tia_reinhard_transform_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P], C.c_int),
+    "tia_lab_moments_u8": ([_P, _I64, _I64, _I64, _P, _P, _P, _P, _P], C.c_int),
     "tia_conv_pack_weights_f32": ([_P, _I64, _I64, _I64, _I64, _P, _P], C.c_int),
     "tia_conv2d_nhwc_f32": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P], C.c_int),
     "tia_conv2d_nhwc_f32_ex": ([_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P],

@@ -4,6 +4,7 @@
 // Reference call sites: tools/tissuemask.py:99-164,270-306; models/architecture/hovernet.py:541-545,
 // 604-614 (scipy.ndimage.label / binary_fill_holes, skimage remove_small_objects, cv2.morphologyEx).
 #include "common.hpp"
+#include "wide_io.hpp"
 
 namespace tia {
 
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(BT) void hist256_kernel(const uint8_t* __restrict__
 }
 
 __global__ __launch_bounds__(BT) void threshold_lt_kernel(const uint8_t* __restrict__ src, long npix, int is_rgb,
-                                                           int thr, uint8_t* __restrict__ mask) {
+                                                           int thr, const int* __restrict__ thr_dev, uint8_t* __restrict__ mask) {
+    if (thr_dev) thr = *thr_dev;
     const long stride = (long)gridDim.x * BT;
     const bool fast = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(mask)) & 3) == 0;
     long done = 0;
@@ -99,6 +101,177 @@ __global__ __launch_bounds__(BT) void threshold_lt_kernel(const uint8_t* __restr
         const int g = is_rgb ? (int)gray_of(src[3 * i], src[3 * i + 1], src[3 * i + 2]) : (int)src[i];
         mask[i] = g < thr ? 1 : 0;
     }
+}
+
+// ---- one-pass Otsu fit: grey + histogram fused, 16-byte loads, conflict-bounded LDS counters ---------------------------------------
+// Each wave keeps 16 private sub-histograms (lane & 15 picks one; 256 counters of 16 bits, two per dword, interleaved so that
+// sub-histogram s of counter pair k sits at dword 16 k + s): a ds_add of the wave touches every LDS bank exactly twice whatever
+// the pixel values are -- a smooth image (every lane on the same grey level) costs the same as noise, where one shared histogram
+// serialises up to 64 same-address updates.  16-bit counters: a sub-histogram sees 64 pixels per wave step, so a wave may run
+// kGrayHistMaxSteps steps (the host sizes the grid accordingly).
+constexpr int kGrayHistMaxSteps = 1000;
+
+__device__ __forceinline__ void sub_hist_add(unsigned* sub, uint32_t bin) {
+    // counter `bin` of this lane's sub-histogram: dword (bin >> 1) * 16, half (bin & 1)
+    atomicAdd(&sub[(bin >> 1) * 16], 1u << ((bin & 1u) * 16u));
+}
+
+template <int CH>  // 3: RGB pixels, grey conversion fused; 1: a grey plane
+__global__ __launch_bounds__(BT) void gray_hist_kernel(const uint8_t* __restrict__ img, long npix, uint32_t* __restrict__ hist) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[BT / 64][kRgbChunk];
+    __shared__ unsigned sub[BT / 64][128 * 16];
+    for (int i = threadIdx.x; i < (BT / 64) * 128 * 16; i += BT) (&sub[0][0])[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned* mine = &sub[wv][lane & 15];
+    const long waves = (long)gridDim.x * (BT / 64), wave = (long)blockIdx.x * (BT / 64) + wv;
+    long done = 0;  // pixels covered by the wide path
+    if constexpr (CH == 3) {
+        if ((reinterpret_cast<uintptr_t>(img) & 15) == 0) {
+            const long nchunks = npix / kPxChunk;
+            RgbChunk cur, nxt;
+            long c = wave;
+            if (c < nchunks) rgb_chunk_issue(cur, img + c * kRgbChunk);
+            for (; c < nchunks; c += waves) {
+                const long cn = c + waves;
+                if (cn < nchunks) rgb_chunk_issue(nxt, img + cn * kRgbChunk);
+                uint32_t w[12];
+                rgb_chunk_transpose(cur, stage[wv], w);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t p[4];
+                    group_pixels(w[3 * q], w[3 * q + 1], w[3 * q + 2], p);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sub_hist_add(mine, gray_of_px(p[i]));
+                }
+                cur = nxt;
+            }
+            done = nchunks * kPxChunk;
+        }
+    } else {
+        if ((reinterpret_cast<uintptr_t>(img) & 15) == 0) {
+            const long nv = npix >> 4;  // 16 bytes per lane and step
+            const v4u* q = reinterpret_cast<const v4u*>(img);
+            for (long i = wave * 64 + lane; i < nv; i += waves * 64) {
+                const v4u t = __builtin_nontemporal_load(q + i);
+                const uint32_t d[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    sub_hist_add(mine, d[k] & 255u);
+                    sub_hist_add(mine, (d[k] >> 8) & 255u);
+                    sub_hist_add(mine, (d[k] >> 16) & 255u);
+                    sub_hist_add(mine, d[k] >> 24);
+                }
+            }
+            done = nv << 4;
+        }
+    }
+    for (long i = done + wave * 64 + lane; i < npix; i += waves * 64) {
+        const uint32_t g = CH == 3 ? gray_of((uint32_t)img[3 * i], (uint32_t)img[3 * i + 1], (uint32_t)img[3 * i + 2]) : (uint32_t)img[i];
+        sub_hist_add(mine, g);
+    }
+    __syncthreads();
+    const int b = threadIdx.x;  // BT == 256 bins
+    unsigned t = 0;
+#pragma unroll
+    for (int wq = 0; wq < BT / 64; ++wq)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) t += (sub[wq][(b >> 1) * 16 + s] >> ((b & 1) * 16)) & 0xffffu;
+    if (t) atomicAdd(&hist[b], t);
+}
+
+// skimage.filters.threshold_otsu on a 256-bin byte histogram, on the device (tools/tissuemask.py:131-134; the arithmetic of
+// scikit-image's `threshold_otsu(hist=...)` restricted to the occupied range [lo, hi], as the reference's image path bins it):
+// weight1 = cumsum(counts), weight2 = reversed cumsum, mean1 = cumsum(counts * centers) / weight1, mean2 likewise from the top,
+// variance12 = weight1[:-1] * weight2[1:] * (mean1[:-1] - mean2[1:])**2, threshold = centers[argmax] (first maximum).  The counts and
+// their products with the integer bin centres are integers far below 2^53, so every partial sum is exact in float64 whatever the
+// order: integer prefix sums here equal NumPy's sequential float64 cumsum bit for bit; the divisions and products are the same
+// IEEE operations in the same order.  out[0] = threshold (the only occupied bin when there is just one), out[1] = occupied bins.
+__global__ __launch_bounds__(256) void otsu_threshold_kernel(const uint32_t* __restrict__ hist, int* __restrict__ out) {
+    __shared__ unsigned long long w1[256], s1[256];
+    __shared__ double var[256];
+    __shared__ int lohi[2], nz;
+    const int i = threadIdx.x;
+    const unsigned long long c = hist[i];
+    if (i == 0) {
+        lohi[0] = 256;
+        lohi[1] = -1;
+        nz = 0;
+    }
+    __syncthreads();
+    if (c) {
+        atomicMin(&lohi[0], i);
+        atomicMax(&lohi[1], i);
+        atomicAdd(&nz, 1);
+    }
+    w1[i] = c;
+    s1[i] = c * (unsigned long long)i;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {  // inclusive scans (Hillis-Steele; integer: exact)
+        const unsigned long long a = i >= o ? w1[i - o] : 0ull, b = i >= o ? s1[i - o] : 0ull;
+        __syncthreads();
+        w1[i] += a;
+        s1[i] += b;
+        __syncthreads();
+    }
+    const int lo = lohi[0], hi = lohi[1];
+    double v = -1.0;  // variance12 >= 0 inside the range
+    if (nz > 1 && i >= lo && i < hi) {
+        const double wt1 = (double)w1[i], wt2 = (double)(w1[255] - w1[i]);
+        const double m1 = (double)s1[i] / wt1, m2 = (double)(s1[255] - s1[i]) / wt2;
+        const double d = m1 - m2;
+        v = wt1 * wt2 * (d * d);
+    }
+    var[i] = v;
+    __syncthreads();
+    if (i == 0) {
+        int best = lo;
+        if (nz > 1) {
+            double bv = var[lo];
+            for (int k = lo + 1; k < hi; ++k)
+                if (var[k] > bv) {  // first maximum
+                    bv = var[k];
+                    best = k;
+                }
+        }
+        out[0] = nz == 0 ? 0 : best;
+        out[1] = nz;
+    }
+}
+
+// mask = grey < thr, 16-byte accesses: 48 bytes of RGB in, 16 mask bytes out per lane and step (a lane's 16 pixels are contiguous
+// in the mask).  thr_dev (nullable): the threshold comes from device memory (tia_otsu_threshold_u32's output).
+__global__ __launch_bounds__(BT) void threshold_wide_kernel(const uint8_t* __restrict__ src, long npix, int thr,
+                                                             const int* __restrict__ thr_dev, uint8_t* __restrict__ mask) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[BT / 64][kRgbChunk];
+    if (thr_dev) thr = *thr_dev;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long waves = (long)gridDim.x * (BT / 64), wave = (long)blockIdx.x * (BT / 64) + wv;
+    const long nchunks = npix / kPxChunk;
+    RgbChunk cur, nxt;
+    long c = wave;
+    if (c < nchunks) rgb_chunk_issue(cur, src + c * kRgbChunk);
+    for (; c < nchunks; c += waves) {
+        const long cn = c + waves;
+        if (cn < nchunks) rgb_chunk_issue(nxt, src + cn * kRgbChunk);
+        uint32_t w[12];
+        rgb_chunk_transpose(cur, stage[wv], w);
+        v4u m;
+        uint32_t* mo = reinterpret_cast<uint32_t*>(&m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t p[4];
+            group_pixels(w[3 * q], w[3 * q + 1], w[3 * q + 2], p);
+            uint32_t bits = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bits |= ((int)gray_of_px(p[i]) < thr ? 1u : 0u) << (8 * i);
+            mo[q] = bits;
+        }
+        __builtin_nontemporal_store(m, reinterpret_cast<v4u*>(mask + c * kPxChunk) + lane);
+        cur = nxt;
+    }
+    for (long i = nchunks * kPxChunk + wave * 64 + lane; i < npix; i += waves * 64)
+        mask[i] = (int)gray_of((uint32_t)src[3 * i], (uint32_t)src[3 * i + 1], (uint32_t)src[3 * i + 2]) < thr ? 1 : 0;
 }
 
 // ---- connected components ------------------------------------------------------------------------------
@@ -296,19 +469,15 @@ __device__ __forceinline__ void lds_union(int* L, int a, int b) {
         a = old;
     }
 }
-template <int SRC>
-__device__ __forceinline__ void tile_forest(const void* __restrict__ src, long plane_off, int h, int w, int conn8, int* L) {
+// fg(i): is pixel i (row-major in the h x w plane) foreground?  Called once per pixel, by whole waves.
+template <class FG>
+__device__ __forceinline__ void tile_forest_fn(int h, int w, int conn8, int* L, FG fg_of) {
     const int hw = h * w, tid = threadIdx.x, lane = tid & 63;
 #pragma unroll 4  // one workgroup per CU: several rounds of source loads in flight
     for (int base = 0; base < hw; base += 1024) {  // same trip count for every lane: the ballots need whole waves
         const int i = base + tid;
         const bool inb = i < hw;
-        bool fg = false;
-        if (inb) {
-            if constexpr (SRC == 2) fg = static_cast<const float*>(src)[plane_off + i] >= 0.5f;
-            else if constexpr (SRC == 1) fg = static_cast<const uint8_t*>(src)[plane_off + i] == 0;
-            else fg = static_cast<const uint8_t*>(src)[plane_off + i] != 0;
-        }
+        const bool fg = inb && fg_of(i);
         const int x = inb ? i % w : 0;
         const bool prev_fg = __shfl_up((int)fg, 1) != 0;
         const bool start = fg && (lane == 0 || x == 0 || !prev_fg);
@@ -341,6 +510,14 @@ __device__ __forceinline__ void tile_forest(const void* __restrict__ src, long p
     for (int i = tid; i < hw; i += 1024)
         if (L[i] >= 0) L[i] = lds_find(L, i);
     __syncthreads();
+}
+template <int SRC>
+__device__ __forceinline__ void tile_forest(const void* __restrict__ src, long plane_off, int h, int w, int conn8, int* L) {
+    tile_forest_fn(h, w, conn8, L, [&](int i) -> bool {
+        if constexpr (SRC == 2) return static_cast<const float*>(src)[plane_off + i] >= 0.5f;
+        else if constexpr (SRC == 1) return static_cast<const uint8_t*>(src)[plane_off + i] == 0;
+        else return static_cast<const uint8_t*>(src)[plane_off + i] != 0;
+    });
 }
 
 // second half of the small-plane labelling (after tile_forest): rank the roots in raster order, component areas, area filter,
@@ -528,6 +705,222 @@ __global__ __launch_bounds__(1024) void marker_tile_kernel(const uint8_t* __rest
                              atomicMax(&bb[b * 4 + 3], x + len - 1);
                          }
                      });
+}
+
+// ---- MorphologicalMasker.transform in ONE launch (tools/tissuemask.py:270-306) ---------------------------------------------------------
+// mask = dilate(remove_small_objects(grey < thr, min_size K, connectivity 8), element).  Both steps are LOCAL when K is small: a
+// component with fewer than K pixels lies inside the (2K - 1)^2 window around any of its pixels.  Each workgroup takes a core
+// rectangle of the image plus a halo of H = R + K - 1 pixels (R = the element's reach) and decides every component of that
+// extended tile exactly:
+//   * it does not touch the tile's inner frame (frame sides on the image border do not count) -> it is complete, its area is exact;
+//   * it touches the inner frame -> for any of its pixels within R of the core, the 8-connected path to the frame has at least K
+//     pixels, so the component has >= K pixels: kept.  (Pixels further out may be judged wrongly; nothing reads them.)
+// Most of the work is done on BIT ROWS (the tile's 256 x 128 foreground bits are 1024 words in LDS, one per thread):
+//   1. threshold: 12-byte pixel loads (a wave reads 768 contiguous bytes of an image row), four foreground bits per lane;
+//   2. certificates: a pixel that starts a full bw x bh rectangle (bw bh >= K) belongs to a component of >= K pixels -- an
+//      erosion of the bit rows (shifts and ANDs);
+//   3. those seeds flood their components: big |= dilate3x3(big) & foreground, a few dozen shift/OR rounds until nothing changes;
+//   4. what is left (specks, thin lines: a few per cent of the foreground) goes through the LDS union-find of the small-plane
+//      kernels, components below K pixels that are complete in the tile are dropped (if the flood did not converge within its
+//      round limit -- a maze -- the whole foreground takes this route: slower, same result);
+//   5. dilation on the bit rows (one funnel shift per element offset), then the core's mask bytes.
+// One read of the image (x the halo overlap), one write of the mask; label / area / dilation planes never exist in HBM.
+constexpr int kMorphTileW = 256, kMorphTileH = 128;  // extended tile: 32,768 pixels (128 KB of LDS for the union-find)
+constexpr int kMorphMaxHalo = 40;                    // beyond that the core is under 40 % of the tile: multi-launch form
+constexpr int kMorphWords = kMorphTileW * kMorphTileH / 32;
+constexpr int kMorphFloodRounds = 96;
+
+// word (r, wx) of a bit plane shifted so that bit x holds the plane's bit x + dx (|dx| < 32); rows / words outside the tile read 0
+__device__ __forceinline__ unsigned bit_row_shift(const unsigned* plane, int r, int wx, int dx) {
+    if (r < 0 || r >= kMorphTileH) return 0u;
+    const unsigned* row = plane + r * 8;
+    const unsigned mid = row[wx];
+    if (dx == 0) return mid;
+    if (dx > 0) {
+        const unsigned right = wx < 7 ? row[wx + 1] : 0u;
+        return (mid >> dx) | (right << (32 - dx));
+    }
+    const unsigned left = wx > 0 ? row[wx - 1] : 0u;
+    return (mid << -dx) | (left >> (32 + dx));
+}
+
+template <int CH>  // 3: RGB, grey conversion fused; 1: grey plane
+__global__ __launch_bounds__(1024) void morph_mask_tile_kernel(const uint8_t* __restrict__ img, int h, int w, int thr,
+                                                               const int* __restrict__ thr_dev, int min_keep, int halo, int bw, int bh,
+                                                               const int* __restrict__ offs, int n_off, int tiles_x, int tiles_y,
+                                                               long total_bytes, int force_uf, uint8_t* __restrict__ mask) {
+    extern __shared__ int L[];
+    __shared__ unsigned fgb[kMorphWords], big[2][kMorphWords], keepb[kMorphWords];
+    __shared__ int s_off[512];  // (dy, dx) of the element, first 256 entries
+    if (thr_dev) thr = *thr_dev;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cw = kMorphTileW - 2 * halo, chh = kMorphTileH - 2 * halo;  // core
+    const int tile = blockIdx.x % (tiles_x * tiles_y), plane = blockIdx.x / (tiles_x * tiles_y);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int y0 = ty * chh - halo, x0 = tx * cw - halo;  // image coordinates of the extended tile's corner
+    const size_t plane_off = (size_t)plane * (size_t)h * w;
+    const uint8_t* src = img + plane_off * CH;
+    constexpr int EW = kMorphTileW, EH = kMorphTileH;
+    const bool base_aligned = (reinterpret_cast<uintptr_t>(img) & 3) == 0;
+    for (int k = tid; k < 2 * n_off && k < 512; k += 1024) s_off[k] = offs[k];
+    fgb[tid] = 0u;
+    keepb[tid] = 0u;
+    __syncthreads();
+    // ---- 1. threshold -> foreground bit rows.  Wave wv takes rows wv, wv + 16, ...; lane l the pixels 4l .. 4l + 3 of the row.
+#pragma unroll  // all eight rows of a wave in flight: the HBM latency is paid once per tile
+    for (int rr = 0; rr < EH / 16; ++rr) {
+        const int r = wv + 16 * rr;
+        const int y = y0 + r, x = x0 + 4 * lane;
+        unsigned bits = 0u;
+        if (y >= 0 && y < h && x + 3 >= 0 && x < w) {
+            const size_t pix = (size_t)y * w + x;  // (may be "negative" by up to 3 at the left edge: only used when x >= 0)
+            const long byte0 = (long)(plane_off + pix) * CH;
+            if (CH == 3 && x >= 0 && x + 3 < w && base_aligned && ((byte0 & ~3L) + 16 <= total_bytes)) {
+                // the group's 12 bytes from the enclosing aligned dwords (the row start is not 4-byte aligned in general)
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(src + pix * 3) & ~(uintptr_t)3);
+                const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(src + pix * 3) & 3u);
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+                uint32_t p[4];
+                group_pixels(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                             __builtin_amdgcn_alignbyte(d3, d2, sh), p);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bits |= ((int)gray_of_px(p[k]) < thr ? 1u : 0u) << k;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (x + k < 0 || x + k >= w) continue;
+                    const uint8_t* p = src + (pix + k) * CH;
+                    const int g = CH == 3 ? (int)gray_of((uint32_t)p[0], (uint32_t)p[1], (uint32_t)p[2]) : (int)p[0];
+                    bits |= (g < thr ? 1u : 0u) << k;
+                }
+            }
+        }
+        if (bits) atomicOr(&fgb[r * 8 + (lane >> 3)], bits << (4 * (lane & 7)));
+    }
+    __syncthreads();
+    const int r = tid >> 3, wx = tid & 7;  // this thread's word of the bit planes
+    const unsigned fg = fgb[tid];
+    // ---- 2. + 3. certificates and their flood
+    int cur = 0;
+    bool converged = true;
+    if (force_uf) {
+        big[0][tid] = 0u;
+        __syncthreads();
+    } else if (min_keep <= 1) {
+        big[0][tid] = fg;  // every component is kept
+        __syncthreads();
+    } else {
+        unsigned hr = fg;  // bit x: the bw pixels x .. x + bw - 1 of the row are foreground
+        for (int sft = 1; sft < bw; ++sft) hr &= bit_row_shift(fgb, r, wx, sft);
+        big[1][tid] = hr;
+        __syncthreads();
+        unsigned seed = hr;
+        for (int d = 1; d < bh; ++d) seed &= (r + d < EH) ? big[1][tid + 8 * d] : 0u;
+        big[0][tid] = seed;
+        __syncthreads();
+        converged = false;
+        for (int it = 0; it < kMorphFloodRounds; ++it) {
+            const unsigned* b = big[cur];
+            unsigned acc = 0u;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) acc |= bit_row_shift(b, r + dy, wx, -1) | bit_row_shift(b, r + dy, wx, 0) | bit_row_shift(b, r + dy, wx, 1);
+            const unsigned nb = (acc & fg) | b[tid];
+            big[cur ^ 1][tid] = nb;
+            const int changed = __syncthreads_or(nb != b[tid]);
+            cur ^= 1;
+            if (!changed) {
+                converged = true;
+                break;
+            }
+        }
+        if (!converged) {  // a maze: label everything
+            __syncthreads();
+            big[cur][tid] = 0u;
+            __syncthreads();
+        }
+    }
+    const unsigned bigw = big[cur][tid];
+    const unsigned left = fg & ~bigw;
+    unsigned* leftp = big[cur ^ 1];
+    __syncthreads();  // everyone has read its word of big[cur ^ 1]'s predecessor state
+    leftp[tid] = left;
+    const int any_left = __syncthreads_or(left != 0u);
+    // ---- 4. the rest: union-find, areas on the roots' slots, complete small components dropped
+    if (any_left) {
+        tile_forest_fn(EH, EW, 1, L, [&](int i) -> bool { return (leftp[i >> 5] >> (i & 31)) & 1u; });
+        constexpr int EN = EW * EH;
+        // root slots: 0x80000000 | touches-the-inner-frame << 30 | area (background stays 0xffffffff: area field all ones)
+        for (int i = tid; i < EN; i += 1024)
+            if (L[i] == i) L[i] = (int)0x80000001u;
+        __syncthreads();
+        for (int base = 0; base < EN; base += 1024) {  // whole waves: one add per run of equal roots (64 lanes = a quarter row)
+            const int i = base + tid;
+            const int v = L[i];
+            const int root = v == -1 ? -1 : (v < 0 ? i : v);
+            const int prev = __shfl_up(root, 1);
+            const bool head = lane == 0 || root != prev;
+            const unsigned long long heads = __ballot(head);
+            const int ey = i >> 8, ex = i & (EW - 1);
+            const int y = y0 + ey, x = x0 + ex;
+            // the inner frame: the tile's outermost ring where the image continues beyond it
+            const bool frame = root >= 0 && ((ey == 0 && y > 0) || (ey == EH - 1 && y < h - 1) || (ex == 0 && x > 0) || (ex == EW - 1 && x < w - 1));
+            if (root >= 0) {
+                unsigned* rec = reinterpret_cast<unsigned*>(&L[root]);
+                if (head) {
+                    const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+                    const unsigned len = (unsigned)((above ? __builtin_ctzll(above) : 64) - lane);
+                    const unsigned add = len - ((v < 0 && root == i) ? 1u : 0u);  // the root counted itself
+                    if (add) atomicAdd(rec, add);
+                } else if (v < 0) {
+                    atomicAdd(rec, 0xffffffffu);  // a root inside a run: its run head counted it as well
+                }
+                if (frame) atomicOr(rec, 1u << 30);
+            }
+        }
+        __syncthreads();
+        for (int base = 0; base < EN; base += 1024) {
+            const int i = base + tid;
+            const int v = L[i];
+            bool keep = false;
+            if (v != -1) {
+                const unsigned rec = (unsigned)(v < 0 ? v : L[v]);
+                keep = (rec & (1u << 30)) || (int)(rec & 0x3fffffffu) >= min_keep;
+            }
+            const unsigned long long kb = __ballot(keep);  // 64 consecutive pixels = words (i >> 5) and (i >> 5) + 1
+            if (lane == 0) keepb[i >> 5] = (unsigned)kb;
+            if (lane == 32) keepb[i >> 5] = (unsigned)(kb >> 32);
+        }
+        __syncthreads();
+    }
+    keepb[tid] |= bigw;
+    __syncthreads();
+    // ---- 5. dilation on the bit rows: out(q) = OR over the element of keep(q + off); outside the image = 0 (cv2.dilate's default)
+    unsigned out = 0u;
+    if (r >= halo && r < EH - halo) {
+        if (n_off <= 256) {
+            for (int k = 0; k < n_off; ++k) out |= bit_row_shift(keepb, r + s_off[2 * k], wx, s_off[2 * k + 1]);
+        } else {
+            for (int k = 0; k < n_off; ++k) out |= bit_row_shift(keepb, r + offs[2 * k], wx, offs[2 * k + 1]);
+        }
+        const int y = y0 + r;
+        if (y < h) {  // (y >= 0: core rows start inside the image)
+            uint8_t* drow = mask + plane_off + (size_t)y * w;
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+                const int ex = 32 * wx + 4 * nb, x = x0 + ex;
+                if (ex + 3 < halo || ex >= EW - halo || x >= w) continue;
+                const unsigned q4 = (out >> (4 * nb)) & 0xfu;
+                const bool whole = ex >= halo && ex + 3 < EW - halo && x + 3 < w && ((reinterpret_cast<uintptr_t>(drow + x) & 3) == 0);
+                if (whole) {
+                    *reinterpret_cast<uint32_t*>(drow + x) = (q4 & 1u) | ((q4 & 2u) << 7) | ((q4 & 4u) << 14) | ((q4 & 8u) << 21);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (ex + k >= halo && ex + k < EW - halo && x + k < w) drow[x + k] = (uint8_t)((q4 >> k) & 1u);
+                }
+            }
+        }
+    }
 }
 
 // scipy.ndimage.binary_fill_holes on a small plane: background components (4-connectivity) that do not reach the frame
@@ -744,7 +1137,9 @@ bool ccl_tile_enabled() {
     const bool ok = once.ensure([] {
         const size_t cap = (size_t)kCclTileMaxPixels * sizeof(int);
         return tile_lds_ok(ccl_tile_kernel<0>, cap) && tile_lds_ok(ccl_tile_kernel<1>, cap) && tile_lds_ok(ccl_tile_kernel<2>, cap) &&
-               tile_lds_ok(fill_holes_tile_kernel, cap) && tile_lds_ok(marker_tile_kernel, (size_t)kMarkerTileMaxPixels * 5);
+               tile_lds_ok(fill_holes_tile_kernel, cap) && tile_lds_ok(marker_tile_kernel, (size_t)kMarkerTileMaxPixels * 5) &&
+               tile_lds_ok(morph_mask_tile_kernel<3>, (size_t)kMorphTileW * kMorphTileH * sizeof(int)) &&
+               tile_lds_ok(morph_mask_tile_kernel<1>, (size_t)kMorphTileW * kMorphTileH * sizeof(int));
     });
     if (!ok) {
         (void)hipGetLastError();  // the refusal is handled here (multi-launch path): do not leave it for the next launch check
@@ -851,11 +1246,81 @@ extern "C" int tia_hist256_u8(const uint8_t* d_data, int64_t n, uint32_t* d_hist
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
-extern "C" int tia_threshold_lt_u8(const uint8_t* d_src, int64_t npix, int32_t is_rgb, int32_t thr, uint8_t* d_mask,
-                                    void* stream) {
+static int launch_threshold(const uint8_t* d_src, int64_t npix, int32_t is_rgb, int32_t thr, const int32_t* d_thr, uint8_t* d_mask,
+                            void* stream) {
     if (!d_src || !d_mask || npix <= 0) return TIA_EINVAL;
-    hipLaunchKernelGGL(threshold_lt_kernel, dim3(nblocks(npix)), dim3(BT), 0, (hipStream_t)stream, d_src, (long)npix,
-                       is_rgb, thr, d_mask);
+    const bool wide = is_rgb && ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_mask)) & 15) == 0 && npix >= kPxChunk;
+    if (wide) {
+        long nb = (npix / kPxChunk + 15) / 16;  // four steps per wave
+        nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
+        hipLaunchKernelGGL(threshold_wide_kernel, dim3((unsigned)nb), dim3(BT), 0, (hipStream_t)stream, d_src, (long)npix, thr, d_thr,
+                           d_mask);
+    } else {
+        hipLaunchKernelGGL(threshold_lt_kernel, dim3(nblocks((npix + 3) / 4)), dim3(BT), 0, (hipStream_t)stream, d_src, (long)npix,
+                           is_rgb, thr, d_thr, d_mask);
+    }
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_threshold_lt_u8(const uint8_t* d_src, int64_t npix, int32_t is_rgb, int32_t thr, uint8_t* d_mask,
+                                   void* stream) {
+    return launch_threshold(d_src, npix, is_rgb, thr, nullptr, d_mask, stream);
+}
+
+extern "C" int tia_threshold_lt_dev_u8(const uint8_t* d_src, int64_t npix, int32_t is_rgb, const int32_t* d_thr, uint8_t* d_mask,
+                                       void* stream) {
+    if (!d_thr) return TIA_EINVAL;
+    return launch_threshold(d_src, npix, is_rgb, 0, d_thr, d_mask, stream);
+}
+
+extern "C" int tia_morph_mask_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w, int32_t channels, int32_t thr,
+                                 const int32_t* d_thr, int32_t min_region, const int32_t* d_offsets, int32_t n_off, int32_t reach,
+                                 uint8_t* d_mask, void* stream) {
+    if (!d_img || !d_mask || !d_offsets || n_off <= 0 || reach < 0 || min_region < 0 || (channels != 1 && channels != 3)) return TIA_EINVAL;
+    if (bad3(n, h, w)) return TIA_ESIZE;
+    const int halo = reach + (min_region > 1 ? min_region - 1 : 0);
+    if (halo > kMorphMaxHalo || reach > 31 || !ccl_tile_enabled()) return TIA_ESIZE;  // the caller takes the multi-launch form
+    const int cw = kMorphTileW - 2 * halo, ch = kMorphTileH - 2 * halo;
+    const long tiles_x = (w + cw - 1) / cw, tiles_y = (h + ch - 1) / ch;
+    const long blocks = tiles_x * tiles_y * n;
+    if (blocks > 2147483647L) return TIA_ESIZE;
+    // certificate rectangle: bw x bh >= min_region pixels, as square as possible (both <= 41 here)
+    int bw = 1;
+    while (bw * bw < min_region) ++bw;
+    const int bh = min_region > 0 ? (min_region + bw - 1) / bw : 1;
+    static const int force_uf = getenv("TIA_MORPH_FORCE_UF") ? 1 : 0;  // developer switch: every tile through the union-find
+    const size_t lds = (size_t)kMorphTileW * kMorphTileH * sizeof(int);
+    const long total_bytes = (long)n * h * w * channels;
+    if (channels == 3)
+        hipLaunchKernelGGL(morph_mask_tile_kernel<3>, dim3((unsigned)blocks), dim3(1024), lds, (hipStream_t)stream, d_img, (int)h, (int)w,
+                           thr, d_thr, min_region, halo, bw, bh, d_offsets, n_off, (int)tiles_x, (int)tiles_y, total_bytes, force_uf, d_mask);
+    else
+        hipLaunchKernelGGL(morph_mask_tile_kernel<1>, dim3((unsigned)blocks), dim3(1024), lds, (hipStream_t)stream, d_img, (int)h, (int)w,
+                           thr, d_thr, min_region, halo, bw, bh, d_offsets, n_off, (int)tiles_x, (int)tiles_y, total_bytes, force_uf, d_mask);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_gray_hist_u8(const uint8_t* d_img, int64_t npix, int32_t channels, uint32_t* d_hist, void* stream) {
+    if (!d_img || !d_hist || npix <= 0 || (channels != 1 && channels != 3)) return TIA_EINVAL;
+    // a wave may run kGrayHistMaxSteps steps of 1024 pixels (16-bit sub-histogram counters); otherwise ~8 steps per wave, at most
+    // three resident workgroups per CU
+    const long steps = (npix + kPxChunk - 1) / kPxChunk;
+    long nb = (steps + 31) / 32;
+    nb = nb > 768 ? 768 : nb;
+    const long need = (steps + 4L * kGrayHistMaxSteps - 1) / (4L * kGrayHistMaxSteps);
+    nb = nb < need ? need : nb;
+    nb = nb < 1 ? 1 : nb;
+    if (nb > 2147483647L) return TIA_ESIZE;
+    if (channels == 3)
+        hipLaunchKernelGGL(gray_hist_kernel<3>, dim3((unsigned)nb), dim3(BT), 0, (hipStream_t)stream, d_img, (long)npix, d_hist);
+    else
+        hipLaunchKernelGGL(gray_hist_kernel<1>, dim3((unsigned)nb), dim3(BT), 0, (hipStream_t)stream, d_img, (long)npix, d_hist);
+    return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_otsu_threshold_u32(const uint32_t* d_hist, int32_t* d_out, void* stream) {
+    if (!d_hist || !d_out) return TIA_EINVAL;
+    hipLaunchKernelGGL(otsu_threshold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_hist, d_out);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 

@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "wide_io.hpp"
 
 #pragma clang fp contract(off)
 
@@ -723,6 +724,52 @@ __global__ __launch_bounds__(AT) void stain_augment_kernel(const uint8_t* __rest
     }
 }
 
+// ---- luminosity mask, 16-byte accesses ------------------------------------------------------------------------------------
+// 48 bytes of RGB in / 16 mask bytes out per lane and step (wide_io.hpp); per pixel three table look-ups (the folded
+// contrast-stretch + Y-row tables of build_ty) and one comparison: tissue <=> ((t + 2^11) >> 12) < y_thr <=> t < (y_thr << 12) - 2^11
+// for the non-negative integer sum t.  Needs h*w % 1024 == 0 and 16-byte aligned buffers (the launcher checks).
+__global__ __launch_bounds__(AT) void luminosity_mask_wide_kernel(const uint8_t* __restrict__ img, long hw,
+                                                                   const tia_stain_tables* __restrict__ tab,
+                                                                   const double* __restrict__ stats, int y_thr, int z1,
+                                                                   uint8_t* __restrict__ out) {
+    __shared__ int ty[3][256];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[AT / 64][kRgbChunk];
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    build_ty(ty, tab, st[TIA_ST_PLOW], st[TIA_ST_PHIGH], z1 != 0);
+    __syncthreads();
+    const long bound = ((long)y_thr << 12) - (1 << 11);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
+    uint8_t* dst = out + (size_t)patch * (size_t)hw;
+    const long nchunks = hw / kPxChunk, wstride = (long)gridDim.x * (AT / 64);
+    RgbChunk cur, nxt;
+    long c = (long)blockIdx.x * (AT / 64) + wv;
+    if (c < nchunks) rgb_chunk_issue(cur, src + c * kRgbChunk);
+    for (; c < nchunks; c += wstride) {
+        const long cn = c + wstride;
+        if (cn < nchunks) rgb_chunk_issue(nxt, src + cn * kRgbChunk);
+        uint32_t w[12];
+        rgb_chunk_transpose(cur, stage[wv], w);
+        v4u m;
+        uint32_t* mo = reinterpret_cast<uint32_t*>(&m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t p[4];
+            group_pixels(w[3 * q], w[3 * q + 1], w[3 * q + 2], p);
+            uint32_t bits = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long t = (long)ty[0][p[i] & 255u] + ty[1][(p[i] >> 8) & 255u] + ty[2][(p[i] >> 16) & 255u];
+                bits |= (t < bound ? 1u : 0u) << (8 * i);
+            }
+            mo[q] = bits;
+        }
+        __builtin_nontemporal_store(m, reinterpret_cast<v4u*>(dst + c * kPxChunk) + lane);
+        cur = nxt;
+    }
+}
+
 // ---- stand-alone rgb2od (utils/transforms.py:209-231) ----------------------------------------------
 // One dword (4 bytes) per lane and step: 4 table look-ups, two 16-byte stores (a lane's 32 output bytes are
 // contiguous, a wave's 2 KB too).  `mutate` reproduces the reference's side effect `img[img == 0] = 1`
@@ -920,6 +967,16 @@ extern "C" int tia_luminosity_mask_u8(const uint8_t* d_img, int64_t n, int64_t h
     if (!d_img || !d_tables || !d_stats || !d_mask) return TIA_EINVAL;
     if (bad_dims(n, h, w)) return n > 65535 ? TIA_ESIZE : TIA_EINVAL;
     const long hw = (long)h * w;
+    if (hw % tia::kPxChunk == 0 && ((reinterpret_cast<uintptr_t>(d_img) | reinterpret_cast<uintptr_t>(d_mask)) & 15) == 0) {
+        // 16-byte accesses: a few steps per wave, enough workgroups to fill the chip
+        long per = hw / tia::kPxChunk / 4;  // one step per wave
+        long want = (4096 + n - 1) / n;
+        long bx = per < want ? per : want;
+        dim3 gridw((unsigned)(bx < 1 ? 1 : bx), (unsigned)n);
+        hipLaunchKernelGGL(tia::luminosity_mask_wide_kernel, gridw, dim3(tia::AT), 0, (hipStream_t)stream, d_img, hw, d_tables,
+                           d_stats, y_thr, zero_to_one, d_mask);
+        return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+    }
     dim3 grid(tia::blocks_x(hw, n), (unsigned)n);
     hipLaunchKernelGGL((tia::stain_augment_kernel<true>), grid, dim3(tia::AT), 0, (hipStream_t)stream,
                        d_img, hw, d_tables, d_stats, (const double*)nullptr, y_thr, 0, zero_to_one,

@@ -35,13 +35,62 @@ def hist256(data: torch.Tensor, hist: torch.Tensor | None = None) -> torch.Tenso
     return hist
 
 
-def threshold_lt(src: torch.Tensor, thr: int, *, is_rgb: bool) -> torch.Tensor:
+def gray_hist(img: torch.Tensor, *, channels: int, hist: torch.Tensor | None = None) -> torch.Tensor:
+    """Grey conversion fused with the 256-bin histogram: uint8 RGB pixels (``channels=3``) or a grey plane (``channels=1``) ->
+    counts accumulated into ``hist`` (int32[256]); one pass, nothing written but the counts."""
+    _lib.require_cuda(img)
+    img = img.contiguous()
+    if hist is None:
+        hist = torch.zeros(256, dtype=torch.int32, device=img.device)
+    with torch.cuda.device(img.device):
+        _call("tia_gray_hist_u8", img.data_ptr(), img.numel() // channels, channels, hist.data_ptr())
+    return hist
+
+
+def otsu_threshold(hist: torch.Tensor) -> torch.Tensor:
+    """``skimage.filters.threshold_otsu`` of byte counts on the device: int32[2] = (threshold, occupied bins)."""
+    _lib.require_cuda(hist)
+    out = torch.empty(2, dtype=torch.int32, device=hist.device)
+    with torch.cuda.device(hist.device):
+        _call("tia_otsu_threshold_u32", hist.data_ptr(), out.data_ptr())
+    return out
+
+
+def threshold_lt(src: torch.Tensor, thr: int | torch.Tensor, *, is_rgb: bool, dtype: torch.dtype = torch.uint8) -> torch.Tensor:
+    """``grey < thr`` as 0/1 bytes (``dtype`` uint8, or bool: same storage, no conversion pass); ``thr`` is a Python integer or a
+    device int32 tensor (read by the kernel: no host round trip)."""
     _lib.require_cuda(src)
     src = src.contiguous()
     shape = src.shape[:-1] if is_rgb else src.shape
-    out = torch.empty(shape, dtype=torch.uint8, device=src.device)
+    out = torch.empty(shape, dtype=dtype, device=src.device)
     with torch.cuda.device(src.device):
-        _call("tia_threshold_lt_u8", src.data_ptr(), out.numel(), int(is_rgb), int(thr), out.data_ptr())
+        if isinstance(thr, torch.Tensor):
+            _call("tia_threshold_lt_dev_u8", src.data_ptr(), out.numel(), int(is_rgb), thr.data_ptr(), out.data_ptr())
+        else:
+            _call("tia_threshold_lt_u8", src.data_ptr(), out.numel(), int(is_rgb), int(thr), out.data_ptr())
+    return out
+
+
+def morph_mask(images: torch.Tensor, thr: int | torch.Tensor, min_region: int, offsets: torch.Tensor, *,
+               channels: int) -> torch.Tensor | None:
+    """``MorphologicalMasker.transform`` in one launch: ``dilate(remove_small_objects(grey < thr, min_region, 8), element)`` of a
+    uint8 ``[n,h,w,3]`` (RGB) or ``[n,h,w]`` (grey) batch as a bool ``[n,h,w]`` tensor, or ``None`` when the element's reach +
+    ``min_region`` - 1 exceeds the 40-pixel halo of the tile kernel (the caller takes the multi-launch form)."""
+    _lib.require_cuda(images)
+    images = images.contiguous()
+    n, h, w = images.shape[:3]
+    if n > _MAX_PLANES:
+        return None
+    out = torch.empty((n, h, w), dtype=torch.bool, device=images.device)
+    reach = int(offsets.abs().max().item()) if offsets.numel() else 0
+    dev_thr = isinstance(thr, torch.Tensor)
+    with torch.cuda.device(images.device):
+        rc = _lib.load().tia_morph_mask_u8(images.data_ptr(), n, h, w, channels, 0 if dev_thr else int(thr),
+                                           thr.data_ptr() if dev_thr else 0, int(min_region), offsets.data_ptr(), offsets.shape[0],
+                                           reach, out.data_ptr(), _lib.current_stream())
+    if rc == _lib.TIA_ESIZE:
+        return None
+    _lib.check(rc, "tia_morph_mask_u8")
     return out
 
 

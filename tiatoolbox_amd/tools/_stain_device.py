@@ -174,7 +174,7 @@ def concentrations(img: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
 def luminosity_mask(img: torch.Tensor, stats: torch.Tensor, y_thr: int, *, zero_to_one: bool = False) -> torch.Tensor:
     img = as_batch(img)
     n, h, w, _ = img.shape
-    out = torch.empty((n, h, w), dtype=torch.uint8, device=img.device)
+    out = torch.empty((n, h, w), dtype=torch.bool, device=img.device)  # the kernel writes 0 / 1 bytes: a bool tensor's storage
     tab = tables(img.device)
     lib = _lib.load()
     with torch.cuda.device(img.device):
@@ -184,7 +184,7 @@ def luminosity_mask(img: torch.Tensor, stats: torch.Tensor, y_thr: int, *, zero_
                                             stats[s:s + m].data_ptr(), y_thr, int(zero_to_one),
                                             out[s:s + m].data_ptr(), _lib.current_stream())
             _lib.check(rc, "tia_luminosity_mask_u8")
-    return out.bool()
+    return out
 
 
 def augment(img: torch.Tensor, stats: torch.Tensor, alpha_beta: torch.Tensor, y_thr: int, *,

@@ -61,6 +61,17 @@ def _channel_values() -> np.ndarray:
 
 
 _CHAN_DEV: dict[int, torch.Tensor] = {}
+_WORKSPACE: dict[int, torch.Tensor] = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Per-device scratch of the fused transform (grown on demand, re-used: its lines stay in cache between calls)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _WORKSPACE.get(idx)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+        _WORKSPACE[idx] = ws
+    return ws
 
 
 def _channel_values_device(device: torch.device) -> torch.Tensor:
@@ -80,7 +91,7 @@ class ReinhardNormalizer(StainNormalizer):
 
     # ---------------------------------------------------------------------------------- device
     @staticmethod
-    def _lab_hist(batch: torch.Tensor) -> np.ndarray:
+    def _lab_hist(batch: torch.Tensor) -> np.ndarray:  # (host copy of the Lab byte counts: fit / get_mean_std of one image)
         n, h, w, _ = batch.shape
         hist = torch.zeros((n, 3, 256), dtype=torch.int32, device=batch.device)
         with torch.cuda.device(batch.device):
@@ -138,6 +149,34 @@ class ReinhardNormalizer(StainNormalizer):
         out = lab_convert(lab, 1)
         return out.cpu().numpy() if as_np else out
 
+    def lab_statistics(self, batch: torch.Tensor) -> torch.Tensor:
+        """Device-resident ``[n, 6]`` float64 (means of L/2.55, a-128, b-128, then the population stds) of a uint8 ``[n,h,w,3]``
+        CUDA batch, no host round trip (what ``transform`` computes per image, :277-279): one launch (``tia_lab_moments_u8``) for
+        patch shapes, the histogram kernel split over many workgroups per image + the moment kernel otherwise."""
+        _lib.require_cuda(batch)
+        batch = batch.contiguous()
+        n, h, w, _ = batch.shape
+        dev = batch.device
+        meanstd = torch.empty((n, 6), dtype=torch.float64, device=dev)
+        lib = _lib.load()
+        tabs, chan = lab_tables(dev).data_ptr(), _channel_values_device(dev).data_ptr()
+        with torch.cuda.device(dev):
+            rc = lib.tia_lab_moments_u8(batch.data_ptr(), n, h, w, tabs, chan, meanstd.data_ptr(), 0, _lib.current_stream())
+            if rc == 0:
+                return meanstd
+            if rc != _lib.TIA_ESIZE:
+                _lib.check(rc, "tia_lab_moments_u8")
+            hist = torch.zeros((n, 3, 256), dtype=torch.int32, device=dev)
+            luts = torch.empty((n, 3, 256), dtype=torch.uint8, device=dev)
+            one = (C.c_double * 3)(1.0, 1.0, 1.0)
+            for s in range(0, n, 65535):
+                m = min(65535, n - s)
+                rc = lib.tia_lab_hist_u8(batch[s:s + m].data_ptr(), m, h, w, tabs, hist[s:s + m].data_ptr(), _lib.current_stream())
+                _lib.check(rc, "tia_lab_hist_u8")
+            rc = lib.tia_reinhard_luts(hist.data_ptr(), n, chan, one, one, luts.data_ptr(), meanstd.data_ptr(), 0, _lib.current_stream())
+            _lib.check(rc, "tia_reinhard_luts")
+        return meanstd
+
     def get_mean_std(self, img):
         batch, _ = _tensors.to_device_batch(img)
         mean, std = self._mean_std(self._lab_hist(batch))
@@ -147,7 +186,8 @@ class ReinhardNormalizer(StainNormalizer):
         self.target_means, self.target_stds = self.get_mean_std(target)
 
     def transform(self, img, *, out: str = "uint8"):
-        """Histogram -> per-image LUTs -> fused RGB->Lab->LUT->RGB apply: three launches, no host round trip.
+        """Per image: Lab statistics -> three byte tables -> RGB->Lab->table->RGB, no host round trip: one launch for patch
+        shapes (``tia_reinhard_transform_u8``), three launches for large or ragged images.
 
         ``out``: ``"uint8"`` (reference behaviour, :342-367) or ``"unit_float16|bfloat16|float32"`` = ``ToTensor()`` of
         the uint8 result (what the engines feed the CNN; same keyword as :meth:`StainNormalizer.transform`).
@@ -161,27 +201,37 @@ class ReinhardNormalizer(StainNormalizer):
         batch, kind = _tensors.to_device_batch(img)
         n, h, w, _ = batch.shape
         dev = batch.device
-        hist = torch.zeros((n, 3, 256), dtype=torch.int32, device=dev)
-        luts = torch.empty((n, 3, 256), dtype=torch.uint8, device=dev)
         flags = torch.zeros(n, dtype=torch.int32, device=dev)
         out = torch.empty_like(batch)
         tmeans = (C.c_double * 3)(*[float(v) for v in self.target_means])
         tstds = (C.c_double * 3)(*[float(v) for v in self.target_stds])
         lib = _lib.load()
-        tabs = lab_tables(dev).data_ptr()
+        tabs, chan = lab_tables(dev).data_ptr(), _channel_values_device(dev).data_ptr()
         with torch.cuda.device(dev):
-            for s in range(0, n, 65535):
-                m = min(65535, n - s)
-                rc = lib.tia_lab_hist_u8(batch[s:s + m].data_ptr(), m, h, w, tabs, hist[s:s + m].data_ptr(), _lib.current_stream())
-                _lib.check(rc, "tia_lab_hist_u8")
-            rc = lib.tia_reinhard_luts(hist.data_ptr(), n, _channel_values_device(dev).data_ptr(), tmeans, tstds,
-                                       luts.data_ptr(), 0, flags.data_ptr(), _lib.current_stream())
-            _lib.check(rc, "tia_reinhard_luts")
-            for s in range(0, n, 65535):
-                m = min(65535, n - s)
-                rc = lib.tia_reinhard_apply_u8(batch[s:s + m].data_ptr(), m, h, w, tabs, luts[s:s + m].data_ptr(),
-                                               out[s:s + m].data_ptr(), _lib.current_stream())
-                _lib.check(rc, "tia_reinhard_apply_u8")
+            # patches: one launch (Lab kept in registers up to 256 x 256, in a cache-resident slot per workgroup above that)
+            ws_bytes = int(lib.tia_reinhard_workspace_bytes(n, h, w))
+            ws = _workspace(dev, ws_bytes) if ws_bytes else None
+            rc = lib.tia_reinhard_transform_u8(batch.data_ptr(), n, h, w, tabs, chan, tmeans, tstds, out.data_ptr(), 0,
+                                               flags.data_ptr(), ws.data_ptr() if ws is not None else 0, ws_bytes,
+                                               _lib.current_stream())
+            if rc not in (0, _lib.TIA_ESIZE):
+                _lib.check(rc, "tia_reinhard_transform_u8")
+            if rc == _lib.TIA_ESIZE:
+                # large single images / ragged shapes: histogram over many workgroups per image -> tables -> apply
+                hist = torch.zeros((n, 3, 256), dtype=torch.int32, device=dev)
+                luts = torch.empty((n, 3, 256), dtype=torch.uint8, device=dev)
+                for s in range(0, n, 65535):
+                    m = min(65535, n - s)
+                    rc = lib.tia_lab_hist_u8(batch[s:s + m].data_ptr(), m, h, w, tabs, hist[s:s + m].data_ptr(), _lib.current_stream())
+                    _lib.check(rc, "tia_lab_hist_u8")
+                rc = lib.tia_reinhard_luts(hist.data_ptr(), n, chan, tmeans, tstds, luts.data_ptr(), 0, flags.data_ptr(),
+                                           _lib.current_stream())
+                _lib.check(rc, "tia_reinhard_luts")
+                for s in range(0, n, 65535):
+                    m = min(65535, n - s)
+                    rc = lib.tia_reinhard_apply_u8(batch[s:s + m].data_ptr(), m, h, w, tabs, luts[s:s + m].data_ptr(),
+                                                   out[s:s + m].data_ptr(), _lib.current_stream())
+                    _lib.check(rc, "tia_reinhard_apply_u8")
         if bool(flags.any()):
             msg = "float division by zero"  # the reference divides Python floats (stainnorm.py:281-290)
             raise ZeroDivisionError(msg)

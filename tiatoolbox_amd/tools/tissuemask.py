@@ -1,7 +1,9 @@
 """Tissue maskers (API of reference ``tiatoolbox/tools/tissuemask.py``).
 
-``OtsuTissueMasker``: grey conversion + one global 256-bin histogram on the GPU, Otsu's
-threshold from the 256 counts on the host, thresholding fused with the grey conversion.
+``OtsuTissueMasker``: grey conversion fused with one global 256-bin histogram (one pass over
+the pixels), Otsu's threshold from the 256 counts on the device too (``fit`` and ``transform``
+enqueue back to back; the ``threshold`` attribute syncs on first read), thresholding fused with
+the grey conversion.
 ``MorphologicalMasker``: + 8-connected component labelling, small-region removal and
 elliptical dilation, all on the GPU.  uint8 RGB / single-channel inputs take the HIP path;
 other dtypes (the reference's own known-answer test feeds 0/1 floats) are histogrammed with
@@ -66,8 +68,22 @@ class OtsuTissueMasker(TissueMasker):
 
     def __init__(self) -> None:
         super().__init__()
-        self.threshold = None
+        self._threshold = None
+        self._threshold_dev: torch.Tensor | None = None
         self.fitted = False
+
+    @property
+    def threshold(self):
+        """The fitted threshold (ref. attribute ``self.threshold``).  A uint8 ``fit`` leaves it on the device (``fit`` and
+        ``transform`` enqueue back to back); reading the attribute brings the integer to the host once."""
+        if self._threshold is None and self._threshold_dev is not None:
+            self._threshold = int(self._threshold_dev[0].item())
+        return self._threshold
+
+    @threshold.setter
+    def threshold(self, value) -> None:
+        self._threshold = value
+        self._threshold_dev = None
 
     def fit(self, images, masks=None) -> None:  # noqa: ARG002
         images_shape = tuple(images.shape) if isinstance(images, torch.Tensor) else np.shape(images)
@@ -77,14 +93,11 @@ class OtsuTissueMasker(TissueMasker):
             raise ValueError(msg)
         t, _ = _to_device_images(images)
         if t.dtype == torch.uint8:
-            grey = img.rgb2gray(t) if t.shape[-1] == 3 else t[..., 0].contiguous()  # noqa: PLR2004
-            counts = img.hist256(grey).cpu().numpy().astype(np.int64)
-            nz = np.flatnonzero(counts)
-            if nz.size == 1:
-                self.threshold = int(nz[0])
-            else:
-                lo, hi = int(nz[0]), int(nz[-1])
-                self.threshold = int(_otsu_from_counts(counts[lo:hi + 1], np.arange(lo, hi + 1, dtype=np.float64)))
+            # one pass over the pixels (grey + histogram fused), Otsu's arithmetic on the 256 counts on the device
+            rgb = t.shape[-1] == 3  # noqa: PLR2004
+            counts = img.gray_hist(t if rgb else t[..., 0].contiguous(), channels=3 if rgb else 1)
+            self._threshold = None
+            self._threshold_dev = img.otsu_threshold(counts)
         else:
             grey = t[..., 0].to(torch.float64)
             lo, hi = float(grey.min()), float(grey.max())
@@ -96,22 +109,24 @@ class OtsuTissueMasker(TissueMasker):
                 self.threshold = float(_otsu_from_counts(counts, (edges[:-1] + edges[1:]) / 2.0))
         self.fitted = True
 
-    def _masks(self, t: torch.Tensor) -> torch.Tensor:
+    def _masks(self, t: torch.Tensor, dtype: torch.dtype = torch.uint8) -> torch.Tensor:
         if t.dtype == torch.uint8:
             is_rgb = t.dim() == 4 and t.shape[-1] == 3  # noqa: PLR2004
             src = t if is_rgb else (t[..., 0].contiguous() if t.dim() == 4 else t)  # noqa: PLR2004
+            if self._threshold is None and self._threshold_dev is not None:
+                return img.threshold_lt(src, self._threshold_dev, is_rgb=is_rgb, dtype=dtype)
             # grey < threshold with an integer grey: equivalent integer bound
             thr = int(np.ceil(self.threshold)) if float(self.threshold) != int(self.threshold) else int(self.threshold)
-            return img.threshold_lt(src, thr, is_rgb=is_rgb)
+            return img.threshold_lt(src, thr, is_rgb=is_rgb, dtype=dtype)
         grey = t[..., 0] if t.dim() == 4 else t  # noqa: PLR2004
-        return (grey < self.threshold).to(torch.uint8)
+        return (grey < self.threshold).to(dtype)
 
     def transform(self, images):
         if not self.fitted:
             msg = "Fit must be called before transform."
             raise SyntaxError(msg)
         t, as_numpy = _to_device_images(images)
-        masks = self._masks(t).bool()
+        masks = self._masks(t, torch.bool)  # the kernel's 0 / 1 bytes are a bool tensor's storage
         return masks.cpu().numpy() if as_numpy else masks
 
 
@@ -127,7 +142,6 @@ class MorphologicalMasker(OtsuTissueMasker):
         the number of set pixels of the element.
         """
         super().__init__()
-        self.threshold = None
         given = {name: val for name, val in (("mpp", mpp), ("power", power), ("kernel_size", kernel_size))
                  if val is not None}
         if len(given) > 1:
@@ -153,9 +167,28 @@ class MorphologicalMasker(OtsuTissueMasker):
             msg = "Fit must be called before transform."
             raise SyntaxError(msg)
         t, as_numpy = _to_device_images(images)
-        mask = self._masks(t)
-        labels, _ = img.ccl_label(mask, connectivity=8)
-        img.label_area_filter(labels, int(self.min_region_size))
-        keep = (labels > 0).to(torch.uint8)
-        out = img.binary_morph(keep, img.offsets_of(self.kernel, keep.device), "dilate").bool()
+        out = None
+        if t.dtype == torch.uint8 and t.dim() == 4 and t.shape[-1] in (1, 3):  # noqa: PLR2004
+            # one launch: threshold, small-region removal and dilation tile by tile in LDS (element + min_region_size within the halo)
+            rgb = t.shape[-1] == 3  # noqa: PLR2004
+            if self._threshold is None and self._threshold_dev is not None:
+                thr = self._threshold_dev
+            else:
+                thr = int(np.ceil(self.threshold)) if float(self.threshold) != int(self.threshold) else int(self.threshold)
+            out = img.morph_mask(t if rgb else t[..., 0].contiguous(), thr, int(self.min_region_size), self._offsets(t.device),
+                                 channels=3 if rgb else 1)
+        if out is None:
+            mask = self._masks(t)
+            labels, _ = img.ccl_label(mask, connectivity=8)
+            img.label_area_filter(labels, int(self.min_region_size))
+            keep = (labels > 0).to(torch.uint8)
+            out = img.binary_morph(keep, self._offsets(keep.device), "dilate").bool()
         return out.cpu().numpy() if as_numpy else out
+
+    def _offsets(self, device: torch.device) -> torch.Tensor:
+        """(dy, dx) offsets of the element on ``device`` (cached: a few dozen int32)."""
+        key = str(device)
+        cache = self.__dict__.setdefault("_offsets_dev", {})
+        if key not in cache:
+            cache[key] = img.offsets_of(self.kernel, device)
+        return cache[key]
