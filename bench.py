@@ -746,6 +746,18 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                     "max_abs_dprob_vs_direct_float32": float(np.abs(o224w["probabilities"].astype(np.float64)
                                                                     - o224["probabilities"].astype(np.float64)).max())}
             del x224
+        if not os.environ.get("TIA_BENCH_NO_CLASSIC"):
+            # the HBM-bound kernels SURVEY 8(d) lists beside the headline (Reinhard, Otsu / morphological maskers, luminosity mask,
+            # augmentation, Lab conversion): stage time, roofline fraction, counter traffic, one-line CPU baseline each
+            import gc
+
+            import bench_classic
+
+            gc.collect()
+            torch.cuda.empty_cache()
+            t0 = time.perf_counter()
+            extras["classic"] = bench_classic.classic(reps=10, cpu=not args.no_cpu_baseline)
+            extras["classic"]["bench_wall_s"] = round(time.perf_counter() - t0, 1)
         if not os.environ.get("TIA_BENCH_NO_CONFIGS"):
             extras["configs"] = config_extras(args)
         line["extras"] = extras

@@ -150,18 +150,17 @@ def stage_reinhard(reps: int, cpu: bool, pmc_calls: int = 0) -> dict:
         sub = [host[i].copy() for i in range(8)]
         base = _cpu(lambda: [ref.transform(p) for p in sub], len(sub), "patches/s",
                     "oracle ReinhardNormalizer.transform on 8 of the 224x224 patches")
-    names = ("reinhard_fused_kernel", "lab_hist_kernel", "reinhard_lut_kernel", "reinhard_apply_kernel")
     out["reinhard_transform"] = _entry(
         f"ReinhardNormalizer.transform on {n} x {h}x{w}x3 uint8 patches resident in HBM: Lab statistics + per-patch tables + "
         "RGB->Lab->table->RGB (stainnorm.py:222-367); bytes = read u8 + write u8",
-        _ev_time(lambda: norm.transform(x), reps), 2 * x.numel(), kernels=names, stem="classic_reinhard", per_call="reinhard_lut_kernel",
-        cpu=base)
+        _ev_time(lambda: norm.transform(x), reps), 2 * x.numel(), kernels=("reinhard_resident_kernel<13, false>",), stem="classic_reinhard",
+        cpu=base, note="one launch; bound by the vector ALU and LDS look-ups (~63 VALU instructions and ~70 LDS cycles per 64 pixels), not by HBM")
     out["lab_statistics"] = _entry(
         f"Lab mean / std of {n} x {h}x{w} patches (get_mean_std, stainnorm.py:263-279: RGB->Lab + per-channel moments); bytes = read u8",
-        _ev_time(lambda: norm.lab_statistics(x), reps), x.numel(), kernels=("lab_hist_kernel",), stem="classic_reinhard")
+        _ev_time(lambda: norm.lab_statistics(x), reps), x.numel(), kernels=("reinhard_resident_kernel<13, true>",), stem="classic_reinhard")
     out["lab_convert"] = _entry(
         f"cv2.cvtColor(RGB2LAB), 8-bit, {n} x {h}x{w}; bytes = read u8 + write u8",
-        _ev_time(lambda: rh.lab_convert(x, 0), reps), 2 * x.numel(), kernels=("lab_convert_kernel",), stem="classic_reinhard")
+        _ev_time(lambda: rh.lab_convert(x, 0), reps), 2 * x.numel(), kernels=("lab_stream_kernel<1>",), stem="classic_reinhard")
     return out
 
 
@@ -195,17 +194,18 @@ def stage_mask(reps: int, cpu: bool, pmc_calls: int = 0) -> dict:
         b_mm = _cpu(lambda: rm.transform(one), side * side / 1e6, "Mpx/s", f"oracle MorphologicalMasker.transform on one {side}^2 image", reps=1)
     out["otsu_fit"] = _entry(
         f"OtsuTissueMasker.fit on {n} x {side}^2 RGB thumbnails (grey + 256-bin histogram + threshold, tissuemask.py:99-137); bytes = read u8 RGB",
-        _ev_time(lambda: om.fit(x), reps), 3 * px, kernels=("gray_hist_kernel", "rgb2gray_kernel", "hist256_kernel"), stem="classic_mask",
-        per_call="gray_hist_kernel", cpu=b_fit, note="includes the D2H of the 256 counts and the host's Otsu arithmetic")
+        _ev_time(lambda: om.fit(x), reps), 3 * px, kernels=("gray_hist_kernel", "otsu_threshold_kernel"), stem="classic_mask",
+        per_call="gray_hist_kernel", cpu=b_fit, note="grey + histogram in one pass, Otsu's arithmetic on the 256 counts on the device; the "
+        "threshold stays on the device until the attribute is read")
     out["otsu_transform"] = _entry(
         f"OtsuTissueMasker.transform, same images (grey < threshold, tissuemask.py:139-164); bytes = read RGB + write mask",
-        _ev_time(lambda: om.transform(x), reps), 4 * px, kernels=("threshold_lt_kernel", "threshold_wide_kernel"), stem="classic_mask", cpu=b_tr)
+        _ev_time(lambda: om.transform(x), reps), 4 * px, kernels=("threshold_wide_kernel",), stem="classic_mask", cpu=b_tr)
     out["morphological_transform"] = _entry(
         f"MorphologicalMasker(power=1.25).transform, same images (threshold + 8-connected small-region removal below "
         f"{mm.min_region_size} px + {tuple(int(k) for k in mm.kernel_size)} elliptical dilation, tissuemask.py:270-306); bytes = read RGB + write mask",
         _ev_time(lambda: mm.transform(x), max(3, reps // 4), 1), 4 * px,
-        kernels=("morph_mask_tile_kernel", "threshold_lt_kernel", "threshold_wide_kernel", "ccl_", "area_", "morph_kernel"),
-        stem="classic_mask", per_call="morph_mask_tile_kernel", cpu=b_mm)
+        kernels=("morph_mask_tile_kernel",), stem="classic_mask", cpu=b_mm,
+        note="one launch: 256 x 128 tiles labelled in LDS (bit-row flood from >= min-size certificates, union-find for the rest)")
     return out
 
 
@@ -235,7 +235,7 @@ def stage_luminosity(reps: int, cpu: bool, pmc_calls: int = 0) -> dict:
     return {"luminosity_mask": _entry(
         f"get_luminosity_tissue_mask of {n} x {h}x{w} patches given their percentiles (contrast stretch + Lab L < 0.8, misc.py:261-290); "
         "bytes = read RGB + write mask", _ev_time(lambda: dev.luminosity_mask(x, stats, p.y_thr), reps), x.numel() * 4 // 3,
-        kernels=("stain_augment_kernel<true>", "luminosity_mask_wide_kernel"), stem="classic_luminosity", cpu=base)}
+        kernels=("luminosity_mask_wide_kernel",), stem="classic_luminosity", cpu=base)}
 
 
 def stage_augment(reps: int, cpu: bool, pmc_calls: int = 0) -> dict:
@@ -274,10 +274,11 @@ def stage_augment(reps: int, cpu: bool, pmc_calls: int = 0) -> dict:
         "augment_f64": _entry(
             f"StainAugmentor.apply on {n} x {h}x{w} patches given their statistics, the reference's float64 per-pixel arithmetic "
             "(stainaugment.py:177-206); bytes = read u8 + write u8", _ev_time(lambda: aug(_lib.MATH_F64), reps), 2 * x.numel(),
-            kernels=("stain_augment_kernel<false>", "stain_augment_f64_wide_kernel"), stem="classic_augment", cpu=base),
+            kernels=("stain_augment_f64_wide_kernel",), stem="classic_augment", cpu=base,
+            note="product of per-patch float64 tables (the augmented optical density is affine in the input optical densities)"),
         "augment_f32": _entry(
-            "same call, precision='f32' (opt-in: float32 per-pixel arithmetic, 16-byte accesses)", _ev_time(lambda: aug(_lib.MATH_F32), reps),
-            2 * x.numel(), kernels=("stain_augment_wide_kernel",), stem="classic_augment"),
+            "same call, precision='f32' (opt-in: float32 per-pixel arithmetic with the hardware exp2, 16-byte accesses)",
+            _ev_time(lambda: aug(_lib.MATH_F32), reps), 2 * x.numel(), kernels=("stain_augment_wide_kernel",), stem="classic_augment"),
     }
 
 

@@ -37,7 +37,8 @@ extern "C" {
  * (TIA_MATH_F64_REF keeps the device libm's exp); tia_conv3x3_geometry, tia_stain_stats_path (dispatch diagnostics). */
 /* Version 6 (round 6): + tia_gray_hist_u8 / tia_otsu_threshold_u32 / tia_threshold_lt_dev_u8 (one-pass Otsu fit whose threshold
  * stays on the device), tia_morph_mask_u8 (the morphological masker in one launch), tia_reinhard_transform_u8 /
- * tia_lab_moments_u8 (fused Reinhard), tia_luminosity_mask_u8 / tia_stain_augment_u8 take 16-byte accesses where the shape allows. */
+ * tia_reinhard_workspace_bytes / tia_lab_moments_u8 (one-launch Reinhard); tia_luminosity_mask_u8 and the float64 form of
+ * tia_stain_augment_u8 (now a product of per-patch tables) take 16-byte accesses where the shape allows. */
 #define TIA_ABI_VERSION 6
 int tia_abi_version(void);
 
@@ -179,7 +180,10 @@ int tia_stain_concentrations_f64(const uint8_t* d_img, int64_t n, int64_t h, int
  * StainAugmentor.augment (tools/stainaugment.py:177-206): C[mask,i] = C[mask,i]*alpha[i]+beta[i]
  * (all pixels if augment_background), out = uint8(clip(255*exp(-C.S),0,255)).  S = per-patch
  * TIA_ST_STAIN, mask from TIA_ST_PLOW/PHIGH + tables.  d_alpha_beta: [n,4] f64 = a0,a1,b0,b1.
- * math = TIA_MATH_F64: the reference's float64 arithmetic; TIA_MATH_F32: float32 with hardware exp2 and
+ * math = TIA_MATH_F64: float64 -- for whole 3072-byte chunks and 16-byte aligned buffers as a product of per-patch tables (the
+ * augmented optical density is affine in the three input optical densities: two sets of nine 256-entry tables replace three
+ * exponentials per pixel; < 1e-13 from the per-pixel arithmetic on the 0..255 scale), else / for degenerate stain matrices the
+ * reference's per-pixel arithmetic with the device libm's exp; TIA_MATH_F32: float32 with hardware exp2 and
  * 16-byte global accesses (needs h*w*3 % 3072 == 0 and 16-byte aligned buffers, else TIA_ESIZE).
  */
 int tia_stain_augment_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,

@@ -628,6 +628,116 @@ __global__ __launch_bounds__(AT) void stain_augment_wide_kernel(const uint8_t* _
     }
 }
 
+// ---- augment, float64 / product-of-tables / 16-byte accesses -----------------------------------------------------------------------
+// The output optical density of StainAugmentor.augment is affine in the three input optical densities, separately for the pixels the
+// augmentation selects (tissue, or all with augment_background) and for the others:
+//   selected:  OD'_c = sum_j LUT[v_j] (pinv[j][0] a0 S[0][c] + pinv[j][1] a1 S[1][c]) + (b0 S[0][c] + b1 S[1][c])
+//   others:    OD'_c = sum_j LUT[v_j] (pinv[j][0] S[0][c] + pinv[j][1] S[1][c])
+// so 255 exp(-OD'_c) is a product of three table entries (the constant folded into the first): two sets of nine 256-entry float64
+// tables per patch (4,608 libm `exp` per workgroup instead of three per pixel -- the per-pixel libm form is bound by float64
+// vector arithmetic at 16 % of the HBM roof), per pixel the tissue test (3 look-ups), 9 look-ups, 6 multiplies and the
+// reference's clip.  Same error budget as the apply kernel's table form (< 1e-13 on the 0..255 scale); valid while every exponent
+// stays far inside exp's range, else the caller launches the libm kernel.
+struct AugCtxTab {
+    const double* pt;  // [2][9][256]: set 0 = not selected, set 1 = selected; pt[(set * 9 + 3 j + c) * 256 + v]
+    const int (*ty)[256];
+    long bound;
+    int augment_background;
+    __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, double (&o)[3]) const {
+        const long t = (long)ty[0][r] + ty[1][g] + ty[2][b];
+        const double* q = pt + ((augment_background || t < bound) ? 9 * 256 : 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = __builtin_fmin(q[c * 256 + r] * q[(3 + c) * 256 + g] * q[(6 + c) * 256 + b], 255.0);
+    }
+};
+
+// the reference's per-pixel float64 arithmetic (stainaugment.py:177-206), libm exp: the table form's fall-back
+struct AugCtxRef {
+    double p[6], sm[6], al[2], be[2];
+    const double* lut;
+    const int (*ty)[256];
+    long bound;
+    int augment_background;
+    __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, double (&o)[3]) const {
+        const double x = lut[r], y = lut[g], z = lut[b];
+        const long t = (long)ty[0][r] + ty[1][g] + ty[2][b];
+        double c0 = x * p[0] + y * p[2] + z * p[4];
+        double c1 = x * p[1] + y * p[3] + z * p[5];
+        if (augment_background || t < bound) {
+            c0 *= al[0];
+            c0 += be[0];
+            c1 *= al[1];
+            c1 += be[1];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double tt = c0 * sm[c] + c1 * sm[3 + c];
+            double v = 255.0 * exp(-1.0 * tt);
+            o[c] = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);  // np.clip(., 0, 255)
+        }
+    }
+};
+
+__global__ __launch_bounds__(AT) void stain_augment_f64_wide_kernel(const uint8_t* __restrict__ img, long hw,
+                                                                     const tia_stain_tables* __restrict__ tab,
+                                                                     const double* __restrict__ stats,
+                                                                     const double* __restrict__ alpha_beta, int y_thr,
+                                                                     int augment_background, int z1, uint8_t* __restrict__ out) {
+    __shared__ double ptab[2 * 9 * 256];
+    __shared__ int ty[3][256];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[AT / 64][3072];
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    build_ty(ty, tab, st[TIA_ST_PLOW], st[TIA_ST_PHIGH], z1 != 0);
+    double m[2][9], k0[3];
+    const double a0 = alpha_beta[patch * 4 + 0], a1 = alpha_beta[patch * 4 + 1], b0 = alpha_beta[patch * 4 + 2], b1 = alpha_beta[patch * 4 + 3];
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double s0 = st[TIA_ST_STAIN + c], s1 = st[TIA_ST_STAIN + 3 + c];
+        k0[c] = b0 * s0 + b1 * s1;
+        ok = ok && fabs(k0[c]) < 600.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double p0 = st[TIA_ST_PINV + 2 * j], p1 = st[TIA_ST_PINV + 2 * j + 1];
+            m[0][3 * j + c] = p0 * s0 + p1 * s1;
+            m[1][3 * j + c] = p0 * a0 * s0 + p1 * a1 * s1;
+            ok = ok && fabs(m[0][3 * j + c]) < 18.0 && fabs(m[1][3 * j + c]) < 18.0;  // 5.5414 * 18 < 100: every factor within e^+-100
+        }
+    }
+    const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
+    uint8_t* dst = out + (size_t)patch * (size_t)hw * 3u;
+    if (!ok) {  // (uniform per workgroup) exponent range not safe for the tables, or NaN / inf: the reference's per-pixel arithmetic
+        double* lut = ptab;
+        for (int i = threadIdx.x; i < 256; i += AT) lut[i] = tab->od_lut[i];
+        __syncthreads();
+        AugCtxRef ref;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            ref.p[i] = st[TIA_ST_PINV + i];
+            ref.sm[i] = st[TIA_ST_STAIN + i];
+        }
+        ref.al[0] = a0;
+        ref.al[1] = a1;
+        ref.be[0] = b0;
+        ref.be[1] = b1;
+        ref.lut = lut;
+        ref.ty = ty;
+        ref.bound = ((long)y_thr << 12) - (1 << 11);
+        ref.augment_background = augment_background;
+        sweep_wide<TIA_OUT_U8, AugCtxRef, double>(ref, stage[threadIdx.x >> 6], src, dst, hw);
+        return;
+    }
+    for (int i = threadIdx.x; i < 2 * 9 * 256; i += AT) {
+        const int set = i / (9 * 256), kk = (i >> 8) % 9, v = i & 255;
+        const double e = exp(-(tab->od_lut[v] * m[set][kk])) * (kk < 3 ? 255.0 * (set ? exp(-k0[kk]) : 1.0) : 1.0);
+        ptab[i] = e;
+    }
+    __syncthreads();
+    AugCtxTab ctx{ptab, ty, ((long)y_thr << 12) - (1 << 11), augment_background};
+    sweep_wide<TIA_OUT_U8, AugCtxTab, double>(ctx, stage[threadIdx.x >> 6], src, dst, hw);
+}
+
 // ---- concentrations ------------------------------------------------------------------------------
 __global__ __launch_bounds__(AT) void stain_conc_kernel(const uint8_t* __restrict__ img, long hw,
                                                          const tia_stain_tables* __restrict__ tab,
@@ -953,12 +1063,29 @@ extern "C" int tia_stain_augment_u8(const uint8_t* d_img, int64_t n, int64_t h, 
                            zero_to_one, d_out);
         return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
     }
+    {
+        // float64: the product-of-tables / 16-byte-access form where the shape allows (whole 3072-byte chunks, aligned buffers);
+        // the tables cost 4,608 exponentials per workgroup: one workgroup per patch unless the batch is small
+        const bool aligned = ((reinterpret_cast<uintptr_t>(d_img) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
+        static const bool no_tab = getenv("TIA_AUGMENT_NO_TABLES") != nullptr;  // developer switch: the per-pixel libm kernel
+        if ((hw * 3) % 3072 == 0 && aligned && !no_tab) {
+            const long nchunks = hw * 3 / 3072;
+            long bx = (nchunks + 3) / 4;
+            const long want = (1024 + (long)n - 1) / (long)n;
+            if (bx > want) bx = want;
+            hipLaunchKernelGGL(tia::stain_augment_f64_wide_kernel, dim3((unsigned)(bx < 1 ? 1 : bx), (unsigned)n), dim3(tia::AT), 0,
+                               (hipStream_t)stream, d_img, hw, d_tables, d_stats, d_alpha_beta, y_thr, augment_background, zero_to_one,
+                               d_out);
+            return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+        }
+    }
     dim3 grid(tia::blocks_x(hw, n), (unsigned)n);
     hipLaunchKernelGGL((tia::stain_augment_kernel<false>), grid, dim3(tia::AT), 0, (hipStream_t)stream,
                        d_img, hw, d_tables, d_stats, d_alpha_beta, y_thr, augment_background,
                        zero_to_one, d_out);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
+
 
 extern "C" int tia_luminosity_mask_u8(const uint8_t* d_img, int64_t n, int64_t h, int64_t w,
                                        const tia_stain_tables* d_tables, const double* d_stats,
