@@ -21,8 +21,10 @@ implicit GEMM -- the reference's arithmetic, ``vanilla.py:242``), softmax, argma
 (N > 1) and the copy of the result dict to host NumPy.  For ``value`` the uint8 patches are already resident in HBM when the timed region starts
 (the engine's torch-tensor overload); the same call on HOST NumPy patches (H2D over PCIe included) is timed right after
 and reported as ``host_inclusive`` (engine batches of 1024 there, so that copies hide behind compute; the resident run takes its
-4096 patches as ONE engine batch: ``--micro-batch``).  Extras on rank 0 at N=1: ``cnn_winograd`` = the same call with
-``conv_algo="winograd"`` (opt-in float32 Winograd; executed and effective flops reported separately), the fp16 backbone with its measured max |dp| against the
+4096 patches as ONE engine batch: ``--micro-batch``).  ``value`` runs the engine's default ``conv_algo="auto"`` (float32 Winograd F(2x2, 3x3)
+for the 3x3 / stride-1 block convolutions -- float32 in, float32 accumulate, gated by a committed per-layer error-bound test; executed and
+effective flops reported separately).  Extras on rank 0 at N=1: ``cnn_direct`` = the same call with ``conv_algo="direct"`` (the audit mode:
+direct implicit GEMM everywhere) with its kernels' rooflines, the fp16 backbone with its measured max |dp| against the
 fp32 probabilities of the same batch (tolerance 1e-3, ``tests/engines/test_patch_predictor.py:719`` of the reference),
 the 224x224 patch size of BASELINE configs[1], and -- ``extras.configs`` -- a SHORT run of each of BASELINE configs[2]-[4]
 (``bench_configs.py``: semantic / hovernet / vahadane; value, step time, the config's roofline entry, a one-line CPU baseline), so
@@ -256,10 +258,14 @@ def _lib_route(n, h, w, cin, cout, k, stride, pad, ho, wo) -> int:
 
 
 def trunk_roofline(model, u8_batch):
-    """HIP-event times and algorithmic flops of the hand-written convolution kernels of one trunk forward: the stem kernel
-    (one launch) and the block convolutions, split by kernel -- ``conv3x3_spatial_kernel`` (3x3 / stride 1, tap reuse),
-    ``conv1x1_ring_kernel`` (1x1, and strided 3x3 gathered) and ``conv_mfma_f32_kernel`` (what is left), as ``tia_conv2d_route_f32`` says.  Per-launch events (one sync per launch, kernel time
-    only) give the split; the total is timed separately over whole forwards without syncs."""
+    """HIP-event times and flops of the hand-written convolution kernels of one trunk forward: the stem kernel (one launch) and the
+    block convolutions, split by kernel -- ``conv3x3_wino_kernel`` (3x3 / stride 1 through Winograd F(2x2, 3x3): the engine's default,
+    ``conv_algo="auto"``), ``conv3x3_spatial_kernel`` (the same layers in ``conv_algo="direct"``: tap reuse), ``conv1x1_ring_kernel``
+    (1x1, and strided 3x3 gathered) and ``conv_mfma_f32_kernel`` (what is left), as ``tia_conv2d_route_f32`` says.  Per-launch events
+    (one sync per launch, kernel time only) give the split; the total is timed separately over whole forwards without syncs.
+    For the Winograd kernel ``flops`` are the DIRECT convolution's 2*M*Cout*Cin*9 (what the layer computes) and ``exec_flops`` what its
+    MFMAs execute -- 16 multiplies per 2 x 2 output tile instead of 36, counted over the 64-tile x 64-channel blocks actually launched
+    (tiles beyond the map included)."""
     import torch
 
     import tiatoolbox_amd.models.architecture.fused as fused
@@ -268,8 +274,9 @@ def trunk_roofline(model, u8_batch):
     trunk = next((m for m in model.modules() if isinstance(m, MfmaResNet)), None)
     if trunk is None:
         return None
-    fam = {"conv3x3_spatial_kernel": [0, 0.0, 0], "conv1x1_ring_kernel": [0, 0.0, 0], "conv_mfma_f32_kernel": [0, 0.0, 0]}  # launches, s, flops
-    plain = fused.hip_conv2d
+    names = ("conv3x3_wino_kernel", "conv3x3_spatial_kernel", "conv1x1_ring_kernel", "conv_mfma_f32_kernel")
+    fam = {k: [0, 0.0, 0, 0] for k in names}  # launches, s, algorithmic flops, executed flops
+    plain, plain_w = fused.hip_conv2d, fused.hip_conv3x3_wino
 
     def timed(x, w, b, residual, *, kernel, stride, padding, relu):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -284,6 +291,24 @@ def trunk_roofline(model, u8_batch):
         f[0] += 1
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += 2 * n * ho * wo * co * x.shape[1] * kernel * kernel
+        f[3] += 2 * n * ho * wo * co * x.shape[1] * kernel * kernel
+        return y
+
+    def timed_w(x, u, b, residual, *, padding, relu, pad_hi=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = plain_w(x, u, b, residual, padding=padding, relu=relu, pad_hi=pad_hi)
+        e1.record()
+        e1.synchronize()
+        n, co, ho, wo = y.shape
+        cin = x.shape[1]
+        small = ho <= 8 and wo <= 8
+        blocks = -(-n // 4) if small else n * (-(-ho // 16)) * (-(-wo // 16))  # 64 tiles each
+        f = fam["conv3x3_wino_kernel"]
+        f[0] += 1
+        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[2] += 2 * n * ho * wo * co * cin * 9
+        f[3] += 2 * blocks * 64 * 16 * cin * co
         return y
 
     reps = 3
@@ -293,18 +318,19 @@ def trunk_roofline(model, u8_batch):
         ho, wo = (hin - 1) // 2 + 1, (win - 1) // 2 + 1
         stem_flops = 2 * nb * ho * wo * 64 * 147
         trunk.blocks(feat)
-        fused.hip_conv2d = timed
+        fused.hip_conv2d, fused.hip_conv3x3_wino = timed, timed_w
         try:
             for _ in range(reps):
                 trunk.blocks(feat)
         finally:
-            fused.hip_conv2d = plain
+            fused.hip_conv2d, fused.hip_conv3x3_wino = plain, plain_w
         seconds = ev_time(lambda: trunk.blocks(feat), reps=5)
         stem_seconds = ev_time(lambda: trunk.stem_forward(u8_batch), reps=5)
     launches = sum(f[0] for f in fam.values()) // reps
     flops = sum(f[2] for f in fam.values()) // reps
-    kernels = {name: {"launches": f[0] // reps, "seconds": f[1] / reps, "flops": f[2] // reps,
-                      "tflops": f[2] / f[1] / 1e12 if f[1] > 0 else 0.0} for name, f in fam.items() if f[0]}
+    kernels = {name: {"launches": f[0] // reps, "seconds": f[1] / reps, "flops": f[2] // reps, "exec_flops": f[3] // reps,
+                      "tflops": f[3] / f[1] / 1e12 if f[1] > 0 else 0.0, "effective_tflops": f[2] / f[1] / 1e12 if f[1] > 0 else 0.0}
+               for name, f in fam.items() if f[0]}
     return {"seconds": seconds, "launches": launches, "flops_per_launch": flops // launches,
             "ms_per_launch": seconds / launches * 1e3, "tflops": flops / seconds / 1e12, "kernels": kernels,
             "stem_seconds": stem_seconds, "stem_flops": stem_flops, "stem_tflops": stem_flops / stem_seconds / 1e12}
@@ -324,9 +350,10 @@ def _condense(full: dict) -> dict:
     cpu = full.get("cpu_baseline")
     if cpu:
         out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cpu}
-    wino = (full.get("extras") or {}).get("cnn_winograd")
-    if wino:
-        out["cnn_winograd"] = {k: v for k, v in wino.items() if k != "note"}
+    for key in ("cnn_direct", "cnn_winograd"):
+        alt = (full.get("extras") or {}).get(key)
+        if alt:
+            out[key] = {k: v for k, v in alt.items() if k != "note"}
     return out
 
 
@@ -355,38 +382,6 @@ def config_extras(args: argparse.Namespace) -> dict:
         gc.collect()
         torch.cuda.empty_cache()
     return out
-
-
-def winograd_roofline(model) -> tuple:  # noqa: ARG001  (accumulator, timed wrapper, the plain function to restore)
-    """HIP-event times of the ``conv3x3_wino_kernel`` launches of one trunk forward (``conv_algo="winograd"`` copy of the model) on
-    the batch the caller passes through ``model``'s trunk: ``algorithmic_flops`` = the DIRECT convolution's 2*M*Cout*Cin*9 (what the
-    layer computes), ``executed_mfma_flops`` = what the kernel's MFMAs execute -- 16 multiplies per 2 x 2 output tile instead of 36,
-    counted over the 64-tile x 64-channel blocks actually launched (tiles beyond the map included); ``frac`` is computed from the
-    EXECUTED flops (VERDICT r04 #2), ``effective_tflops`` from the algorithmic ones."""
-    import torch
-
-    import tiatoolbox_amd.models.architecture.fused as fused
-
-    acc = {"launches": 0, "seconds": 0.0, "alg": 0, "exec": 0}
-    plain = fused.hip_conv3x3_wino
-
-    def timed(x, u, b, residual, *, padding, relu):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = plain(x, u, b, residual, padding=padding, relu=relu)
-        e1.record()
-        e1.synchronize()
-        n, co, ho, wo = y.shape
-        cin = x.shape[1]
-        small = ho <= 8 and wo <= 8
-        blocks = -(-n // 4) if small else n * (-(-ho // 16)) * (-(-wo // 16))  # 64 tiles each
-        acc["launches"] += 1
-        acc["seconds"] += e0.elapsed_time(e1) * 1e-3
-        acc["alg"] += 2 * n * ho * wo * co * cin * 9
-        acc["exec"] += 2 * blocks * 64 * 16 * cin * co
-        return y
-
-    return acc, timed, plain
 
 
 def self_spawn(args: argparse.Namespace) -> None:
@@ -464,24 +459,26 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
     engine = PatchPredictor(model="resnet18-kather100k", batch_size=args.micro_batch, device=f"cuda:{local_rank}",
                             verbose=False)
 
-    def run(images, dtype: str = args.dtype):
+    def run(images, dtype: str = args.dtype, algo: str = "auto"):
+        """The API call the metric names; ``conv_algo`` is passed explicitly (run kwargs persist on the engine): "auto" is the
+        engine's default (Winograd F(2x2, 3x3) for the float32 3x3 / stride-1 block convolutions), "direct" the audit mode."""
         size = tuple(int(v) for v in images.shape[1:3])
         return engine.run(images, patch_mode=True, return_probabilities=True, stain_normalizer=norm,
-                          patch_input_shape=size, compute_dtype=dtype)
+                          patch_input_shape=size, compute_dtype=dtype, conv_algo=algo)
 
     def barrier() -> None:
         if world_size > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed(images, steps: int, warmup: int, dtype: str = args.dtype):
+    def timed(images, steps: int, warmup: int, dtype: str = args.dtype, algo: str = "auto"):
         out = None
         for _ in range(warmup):
-            out = run(images, dtype)
+            out = run(images, dtype, algo)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = run(images, dtype)
+            out = run(images, dtype, algo)
         torch.cuda.synchronize()
         own = time.perf_counter() - t0  # this rank's own time, before it waits for the others
         barrier()
@@ -523,10 +520,9 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
         "value": round(total / elapsed, 2), "unit": "patches/s", "n_gpus": world_size, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": (f"BASELINE.json metric configuration: PatchPredictor(resnet18-kather100k, seeded random "
-                                f"weights).run() on {n} synthetic {hw}x{hw}x3 uint8 patches per GPU resident in HBM, Macenko "
-                                f"pre-norm (statistics f64, per-pixel {args.precision}), CNN {args.dtype} on hand-written "
-                                f"kernels (stem + MFMA block convolutions); configs[1] (224x224): extras.patch_224"),
+        "config": {"workload": (f"{n} x {hw}x{hw}x3 u8 patches/GPU in HBM, PatchPredictor(resnet18-kather100k).run(), Macenko pre-norm "
+                                f"(f64 stats, {args.precision} apply), CNN {args.dtype} hand-written HIP, conv_algo=auto (Winograd F(2x2,3x3) "
+                                f"on 3x3/s1; direct: extras.cnn_direct); seeded random weights; configs[1] 224^2: extras.patch_224"),
                    "api": "PatchPredictor.run(images, patch_mode=True, return_probabilities=True, stain_normalizer=...)",
                    "patches_per_gpu": n, "patch_size": hw, "engine_batch_size": args.micro_batch,
                    "parallelism": f"dp{world_size} (patch-sharded, all_gather of probabilities)"},
@@ -578,17 +574,22 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
         fams = conv["kernels"]
         dominant = max(fams, key=lambda k: fams[k]["seconds"])
         dk = fams[dominant]
-        desc = {"conv3x3_spatial_kernel": "3x3 / stride-1 convolutions, 16x16 (or 2 x 8x8) pixel blocks with tap reuse (LDS-DMA patch + weight ring)",
+        desc = {"conv3x3_wino_kernel": ("3x3 / stride-1 convolutions through Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32 (float32 in / float32 "
+                                        "accumulate, weights transformed once in float64); `achieved` / `frac` from the flops the MFMAs EXECUTE (16 "
+                                        "multiplies per 2x2 outputs, 64-tile x 64-channel blocks as launched), `effective_tflops` = the direct "
+                                        "convolution's 2*M*Cout*Cin*9 over the same time (may exceed the MFMA peak)"),
+                "conv3x3_spatial_kernel": "3x3 / stride-1 convolutions, 16x16 (or 2 x 8x8) pixel blocks with tap reuse (LDS-DMA patch + weight ring)",
                 "conv1x1_ring_kernel": "1x1 and strided 3x3 convolutions as a GEMM over 256-pixel blocks, both operands by LDS-DMA (two-stage ring, taps gathered)",
                 "conv_mfma_f32_kernel": "convolutions left to the register-staged 128-pixel slice kernel (small maps / few workgroups)"}
         roofline = {
             "kernel": dominant, "bound": "mfma", "achieved": round(dk["tflops"], 2),
             "peak": MFMA_PEAK_TFLOPS["float32"], "unit": "TFLOP/s",
             "frac": round(dk["tflops"] / MFMA_PEAK_TFLOPS["float32"], 5), "traffic": None,
-            "algorithmic_flops": dk["flops"] // dk["launches"], "launch_ms": round(dk["seconds"] / dk["launches"] * 1e3, 4),
+            "algorithmic_flops": dk["flops"] // dk["launches"], "executed_mfma_flops": dk["exec_flops"] // dk["launches"],
+            "effective_tflops": round(dk["effective_tflops"], 2), "launch_ms": round(dk["seconds"] / dk["launches"] * 1e3, 4),
             "launches_per_step": dk["launches"] * steps_mb,
             "what": (f"average over the {dk['launches']} launches of this kernel in one resnet18 forward on {mb} patches of "
-                     f"{hw}x{hw} ({desc[dominant]}; 2*M*Cout*Cin*k*k flops each, fp32 MFMA 32x32x2, bias + residual + ReLU fused); "
+                     f"{hw}x{hw} ({desc[dominant]}; fp32 MFMA 32x32x2, bias + residual + ReLU fused); "
                      "per-launch HIP events on the launch stream"),
             "share_of_step": round(dk["seconds"] * steps_mb / (elapsed / args.steps), 3),
             "trunk": {"what": f"all {conv['launches']} block convolutions of one forward, timed back to back",
@@ -610,10 +611,12 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                      "flops = 2*Ho*Wo*64*147 per patch (the conv rows recomputed at chunk seams are not counted)")}
         # PMC passes cannot run inside the timed process: this round's committed passes over the same shapes (stem "trunk" = 1024-patch
         # launches, "trunk<mb>" otherwise)
-        pmc_c = pmc_traffic(dominant, "trunk" if mb == 1024 else f"trunk{mb}", dk["launches"]) if hw == 256 else None
+        stem_name = ("wino" if dominant == "conv3x3_wino_kernel" else "trunk") + ("" if mb == 1024 else str(mb))
+        pmc_c = pmc_traffic(dominant, stem_name, dk["launches"]) if hw == 256 else None
         if pmc_c is not None:
             roofline["traffic"] = round(pmc_c["bytes"])
-            roofline["traffic_source"] = pmc_c["source"] + f" (workload: scripts/perf_trunk.py {mb} 256 [5 pmc])"
+            roofline["traffic_source"] = pmc_c["source"] + (f" (workload: scripts/perf_wino.py {mb} 256 pmc)" if dominant == "conv3x3_wino_kernel"
+                                                             else f" (workload: scripts/perf_trunk.py {mb} 256 [5 pmc])")
     else:
         dominant = "stain_stats_kernel"  # the longest-running hand-written kernel of a step when the library convolves
         dk = kernels[dominant]
@@ -673,57 +676,34 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                 "argmax_agreement": float((out16["predictions"] == out["predictions"][:n]).mean()),
                 "note": "extra only: fp16 backbone (fp32 accumulate), same batch; not the reported value"}
         if args.dtype == "float32":
-            # Winograd F(2x2, 3x3) for the float32 3x3 / stride-1 block convolutions (opt-in `conv_algo="winograd"`: float32 in, float32
-            # accumulate, 2.25 x fewer multiplies; not the reference's operation ORDER, hence an extra and not `value`)
-            run_w = lambda images: engine.run(images, patch_mode=True, return_probabilities=True, stain_normalizer=norm,  # noqa: E731
-                                              patch_input_shape=tuple(int(v) for v in images.shape[1:3]), conv_algo="winograd",
-                                              compute_dtype="float32")
-            out_w = run_w(xs)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(k_extra):
-                out_w = run_w(xs)
-            torch.cuda.synchronize()
-            el_w = time.perf_counter() - t0
-            dpw = float(np.abs(out_w["probabilities"].astype(np.float64) - probs[:n].astype(np.float64)).max())
-            model_w = engine._inference_model(torch.float32)  # noqa: SLF001  (the winograd copy: the engine's conv_algo is still set)
-            import tiatoolbox_amd.models.architecture.fused as fused_mod
-            from tiatoolbox_amd.models.architecture.fused import MfmaResNet
-
-            acc, timed_w, plain_w = winograd_roofline(model_w)
-            trunk_w = next(m for m in model_w.modules() if isinstance(m, MfmaResNet))
-            with torch.inference_mode():
-                feat = trunk_w.stem_forward(unit[:mb])
-                trunk_w.blocks(feat)
-                fused_mod.hip_conv3x3_wino = timed_w
-                try:
-                    for _ in range(3):
-                        trunk_w.blocks(feat)
-                finally:
-                    fused_mod.hip_conv3x3_wino = plain_w
-                t_blocks_w = ev_time(lambda: trunk_w.blocks(feat), reps=5)
-            engine.conv_algo = "direct"
-            wl, ws = acc["launches"] // 3, acc["seconds"] / 3
-            pmc_w = pmc_traffic("conv3x3_wino_kernel", "wino" if mb == 1024 else f"wino{mb}", 13) if hw == 256 else None
-            extras["cnn_winograd"] = {
-                "value": round(n * k_extra / el_w, 2), "unit": "patches/s", "ms_per_step": round(el_w / k_extra * 1e3, 3),
-                "max_abs_dprob_vs_direct_float32": dpw, "tolerance": 1e-5, "within_tolerance": bool(dpw <= 1e-5),
-                "argmax_agreement": float((out_w["predictions"] == out["predictions"][:n]).mean()),
-                "roofline": {"kernel": "conv3x3_wino_kernel", "bound": "mfma", "launches_per_forward": wl,
-                             "launch_ms": round(ws / wl * 1e3, 4), "algorithmic_flops": acc["alg"] // 3 // wl,
-                             "executed_mfma_flops": acc["exec"] // 3 // wl,
-                             "achieved": round(acc["exec"] / 3 / ws / 1e12, 2), "peak": MFMA_PEAK_TFLOPS["float32"], "unit": "TFLOP/s",
-                             "frac": round(acc["exec"] / 3 / ws / 1e12 / MFMA_PEAK_TFLOPS["float32"], 5),
-                             "effective_tflops": round(acc["alg"] / 3 / ws / 1e12, 2),
-                             "what": ("Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32: `achieved` / `frac` from the flops the MFMAs EXECUTE "
-                                      "(16 multiplies per 2x2 outputs, 64-tile x 64-channel blocks as launched); `effective_tflops` = the "
-                                      "direct convolution's 2*M*Cout*Cin*9 over the same time (may exceed the MFMA peak)"),
-                             "blocks_ms": round(t_blocks_w * 1e3, 3),
-                             "traffic": round(pmc_w["bytes"]) if pmc_w else None,
-                             **({"traffic_source": pmc_w["source"] + f" (workload: scripts/perf_wino.py {mb} 256 [pmc])"}
-                                if pmc_w else {})},
-                "note": ("extra only: the float32 3x3 / stride-1 block convolutions through Winograd F(2x2, 3x3) (float32 in / float32 "
-                         "accumulate, weights transformed once in float64); same stain front-end, stem, strided / 1x1 convolutions as `value`")}
+            # the audit mode: every block convolution as a direct implicit GEMM (the reference's order of accumulation over taps);
+            # the same call, the same batch -- its rate, the largest probability difference to the default path, and the direct
+            # kernels' own rooflines
+            run(xs, "float32", "direct")
+            el_d, out_d, _ = timed(xs, k_extra, 1, "float32", "direct")
+            dpd = float(np.abs(out_d["probabilities"].astype(np.float64) - probs[:n].astype(np.float64)).max())
+            model_d = engine._inference_model(torch.float32)  # noqa: SLF001  (the direct copy: the engine's conv_algo is still "direct")
+            conv_d = trunk_roofline(model_d, unit[:mb])
+            engine.conv_algo = "auto"
+            dkern = {}
+            for name, k in (conv_d["kernels"] if conv_d else {}).items():
+                dkern[name] = {"bound": "mfma", "achieved": round(k["tflops"], 2), "peak": MFMA_PEAK_TFLOPS["float32"], "unit": "TFLOP/s",
+                               "frac": round(k["tflops"] / MFMA_PEAK_TFLOPS["float32"], 5), "launches_per_forward": k["launches"],
+                               "launch_ms": round(k["seconds"] / k["launches"] * 1e3, 4), "algorithmic_flops": k["flops"] // k["launches"]}
+            pmc_d = pmc_traffic("conv3x3_spatial_kernel", "trunk" if mb == 1024 else f"trunk{mb}", 13) if hw == 256 else None
+            if pmc_d and "conv3x3_spatial_kernel" in dkern:
+                dkern["conv3x3_spatial_kernel"]["traffic"] = round(pmc_d["bytes"])
+                dkern["conv3x3_spatial_kernel"]["traffic_source"] = pmc_d["source"]
+            extras["cnn_direct"] = {
+                "value": round(n * k_extra / el_d, 2), "unit": "patches/s", "ms_per_step": round(el_d / k_extra * 1e3, 3),
+                "max_abs_dprob_vs_default": dpd, "tolerance": 1e-5, "within_tolerance": bool(dpd <= 1e-5),
+                "argmax_agreement": float((out_d["predictions"] == out["predictions"][:n]).mean()),
+                "kernels": dkern,
+                "trunk": ({"achieved": round(conv_d["tflops"], 2), "frac": round(conv_d["tflops"] / MFMA_PEAK_TFLOPS["float32"], 5),
+                           "ms": round(conv_d["seconds"] * 1e3, 3)} if conv_d else None),
+                "note": ("conv_algo='direct': the audit mode (float32 implicit GEMM for every block convolution, the reference's operation "
+                         "order); `value` runs conv_algo='auto' -- Winograd F(2x2, 3x3), float32 in / float32 accumulate, on the 3x3 / "
+                         "stride-1 layers, gated by the per-layer error-bound test (tests/test_engine.py::test_winograd_conv_matches_torch_cpu_fp32)")}
         if hw != 224:
             _, x224 = workload(224, n)
             run(x224)
@@ -733,18 +713,13 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                                    "ms_per_step": round(el224 / k_extra * 1e3, 3), "dtype": args.dtype,
                                    "workload": f"BASELINE configs[1]: {n} synthetic 224x224x3 patches, same call"}
             if args.dtype == "float32":
-                run_w(x224)
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(k_extra):
-                    o224w = run_w(x224)
-                torch.cuda.synchronize()
-                el224w = time.perf_counter() - t0
-                engine.conv_algo = "direct"
-                extras["patch_224"]["cnn_winograd"] = {
-                    "value": round(n * k_extra / el224w, 2), "unit": "patches/s", "ms_per_step": round(el224w / k_extra * 1e3, 3),
-                    "max_abs_dprob_vs_direct_float32": float(np.abs(o224w["probabilities"].astype(np.float64)
-                                                                    - o224["probabilities"].astype(np.float64)).max())}
+                run(x224, "float32", "direct")
+                el224d, o224d, _ = timed(x224, k_extra, 1, "float32", "direct")
+                engine.conv_algo = "auto"
+                extras["patch_224"]["cnn_direct"] = {
+                    "value": round(n * k_extra / el224d, 2), "unit": "patches/s", "ms_per_step": round(el224d / k_extra * 1e3, 3),
+                    "max_abs_dprob_vs_default": float(np.abs(o224d["probabilities"].astype(np.float64)
+                                                             - o224["probabilities"].astype(np.float64)).max())}
             del x224
         if not os.environ.get("TIA_BENCH_NO_CLASSIC"):
             # the HBM-bound kernels SURVEY 8(d) lists beside the headline (Reinhard, Otsu / morphological maskers, luminosity mask,

@@ -317,26 +317,26 @@ def bench_semantic(args) -> dict | None:
     if per_rank is not None:
         line["per_rank"] = per_rank
     if world_size == 1:
-        # opt-in Winograd F(2x2, 3x3) for the plain 3x3 / stride-1 convolutions of the UNet: forward alone + one slide
+        # the audit mode (conv_algo="direct": no Winograd for the plain 3x3 / stride-1 convolutions of the UNet): forward alone + one slide
         xb8 = reader.read_bounds_batch(in_b[keep][:8])
         ref_logits = eng.model.infer_batch(model, xb8[:2], device=str(device)).clone()
-        eng.conv_algo = "winograd"
+        eng.conv_algo = "direct"
         model_w = eng._inference_model(torch.float32)  # noqa: SLF001
         got_logits = eng.model.infer_batch(model_w, xb8[:2], device=str(device))
         t_fwd_w = _ev(lambda: eng.model.infer_batch(model_w, xb8, device=str(device)), reps=3) / 8
         scratch_w = Path(tempfile.mkdtemp(prefix="tia_semw_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None))
         t0 = time.perf_counter()
-        eng.run([reader], patch_mode=False, save_dir=scratch_w / "out", overwrite=True, conv_algo="winograd")
+        eng.run([reader], patch_mode=False, save_dir=scratch_w / "out", overwrite=True, conv_algo="direct")
         torch.cuda.synchronize()
         t_w = time.perf_counter() - t0
         shutil.rmtree(scratch_w, ignore_errors=True)
-        eng.conv_algo = "direct"
-        line["extras"] = {"cnn_winograd": {
+        eng.conv_algo = "auto"
+        line["extras"] = {"cnn_direct": {
             "value": round(n_patches / t_w, 3), "unit": "patches/s", "ms_per_step": round(t_w * 1e3, 2),
-            "forward_ms_per_patch": round(t_fwd_w * 1e3, 3), "forward_effective_tflops": round(flops / t_fwd_w / 1e12, 2),
-            "max_abs_dprob_vs_direct_float32": float((got_logits.float() - ref_logits.float()).abs().max().item()),
-            "note": ("extra only: conv_algo='winograd' (Bottleneck conv2 and the decoder's 3x3 convolutions through conv3x3_wino_kernel); "
-                     "one timed slide")}}
+            "forward_ms_per_patch": round(t_fwd_w * 1e3, 3), "forward_tflops": round(flops / t_fwd_w / 1e12, 2),
+            "max_abs_dlogit_vs_default": float((got_logits.float() - ref_logits.float()).abs().max().item()),
+            "note": ("conv_algo='direct' (audit mode); `value` runs the default conv_algo='auto': Bottleneck conv2 and the decoder's 3x3 "
+                     "convolutions through conv3x3_wino_kernel; one timed slide")}}
     if not args.no_cpu_baseline and world_size == 1:
         from oracle import semantic as osem
         from tiatoolbox_amd.models.architecture import get_pretrained_model
@@ -438,22 +438,23 @@ def bench_hovernet(args) -> dict | None:
     if per_rank is not None:
         line["per_rank"] = per_rank
     if world_size == 1:
-        # opt-in Winograd F(2x2, 3x3) for the plain 3x3 / stride-1 convolutions (float32 in / float32 accumulate): an extra, not `value`
+        # the audit mode (conv_algo="direct": no Winograd for the plain 3x3 / stride-1 convolutions): an extra beside `value`
         heads_d = [h.clone() for h in model.infer_batch(fmodel, xb, device=str(device))]
-        eng.run(tiles, patch_mode=True, conv_algo="winograd")
+        eng.run(tiles, patch_mode=True, conv_algo="direct")
         t0 = time.perf_counter()
-        eng.run(tiles, patch_mode=True, conv_algo="winograd")
+        eng.run(tiles, patch_mode=True, conv_algo="direct")
         torch.cuda.synchronize()
         t_w = time.perf_counter() - t0
         fmodel_w = eng._inference_model(torch.float32)  # noqa: SLF001
         heads_w = model.infer_batch(fmodel_w, xb, device=str(device))
         t_fwd_w = _ev(lambda: model.infer_batch(fmodel_w, xb, device=str(device)), reps=3) / 32
-        eng.conv_algo = "direct"
-        line["extras"] = {"cnn_winograd": {
+        eng.conv_algo = "auto"
+        line["extras"] = {"cnn_direct": {
             "value": round(n / t_w, 2), "unit": "tiles/s", "ms_per_step": round(t_w * 1e3, 2),
-            "forward_ms_per_tile": round(t_fwd_w * 1e3, 3), "forward_effective_tflops": round(flops / t_fwd_w / 1e12, 2),
-            "max_abs_dhead_vs_direct_float32": float(max((a.float() - b.float()).abs().max().item() for a, b in zip(heads_w, heads_d))),
-            "note": "extra only: conv_algo='winograd' (the residual units' 3x3 convolutions through conv3x3_wino_kernel); one timed step"}}
+            "forward_ms_per_tile": round(t_fwd_w * 1e3, 3), "forward_tflops": round(flops / t_fwd_w / 1e12, 2),
+            "max_abs_dhead_vs_default": float(max((a.float() - b.float()).abs().max().item() for a, b in zip(heads_w, heads_d))),
+            "note": ("conv_algo='direct' (audit mode); `value` runs the default conv_algo='auto': the residual units' 3x3 convolutions "
+                     "through conv3x3_wino_kernel; one timed step")}}
     if not args.no_cpu_baseline and world_size == 1:
         from tiatoolbox_amd.models.architecture import get_pretrained_model
 

@@ -47,3 +47,11 @@ def target_image():
     """The reference's packaged stain-norm target, committed as a 256x256 crop fixture."""
     p = ROOT / "tests" / "golden" / "target_crop_256.npy"
     return np.load(p)
+
+
+@pytest.fixture(params=["auto", "direct"])
+def conv_algo(request):
+    """Both forms of the float32 3x3 / stride-1 block convolutions: the engines' default ``"auto"`` (Winograd F(2x2, 3x3) where the
+    per-layer error-bound test covers the layer) and the audit mode ``"direct"``; GPU parity tests take this fixture and pass it on
+    as the ``conv_algo`` run kwarg."""
+    return request.param

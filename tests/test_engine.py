@@ -85,10 +85,21 @@ def test_user_preproc_hook_runs_per_patch(patches):
     assert eng.model.preproc_func(p0) is p0
 
 
+def test_return_probabilities_is_decided_per_call(patches):
+    """Reference ``patch_predictor.py:535-537``: ``kwargs.get("return_probabilities")`` -- a run without the kwarg drops the
+    probabilities even when an earlier run of the same engine asked for them."""
+    eng = PatchPredictor("resnet18-kather100k", batch_size=4)
+    first = eng.run(patches, patch_mode=True, return_probabilities=True)
+    second = eng.run(patches, patch_mode=True)
+    third = eng.run(patches, patch_mode=True, return_probabilities=True)
+    assert "probabilities" in first and "probabilities" not in second and "probabilities" in third
+    assert np.array_equal(first["predictions"], second["predictions"])
+
+
 # ---------------------------------------------------------------------------------------- GPU
 def test_conv_algo_is_validated_on_every_device(patches):
-    """``conv_algo`` (run kwarg; opt-in float32 Winograd on the GPU) accepts ``"direct"`` / ``"winograd"`` only -- also on the CPU,
-    where it has no effect on the arithmetic."""
+    """``conv_algo`` (run kwarg; default ``"auto"``: float32 Winograd on the GPU where the per-layer error-bound test covers the layer)
+    accepts ``"auto"`` / ``"direct"`` / ``"winograd"`` only -- also on the CPU, where it has no effect on the arithmetic."""
     eng = PatchPredictor("resnet18-kather100k", batch_size=4)
     ref = eng.run(patches, patch_mode=True, return_probabilities=True)
     same = eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo="winograd")
@@ -96,7 +107,9 @@ def test_conv_algo_is_validated_on_every_device(patches):
     with pytest.raises(ValueError, match="conv_algo must be"):
         eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo="fft")
     again = eng.run(patches, patch_mode=True, return_probabilities=True)  # the rejected value does not persist
-    assert eng.conv_algo == "direct" and np.array_equal(ref["probabilities"], again["probabilities"])
+    assert eng.conv_algo == "auto" and np.array_equal(ref["probabilities"], again["probabilities"])
+    direct = eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo="direct")
+    assert eng.conv_algo == "direct" and np.array_equal(ref["probabilities"], direct["probabilities"])
 
 
 def test_batch_cuts_ramp_the_first_host_batches():
@@ -122,12 +135,12 @@ def test_batch_cuts_ramp_the_first_host_batches():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize(("dtype", "tol"), [("float32", 1e-4), ("float16", 5e-3), ("bfloat16", 3e-2)])
-def test_gpu_probabilities_match_cpu_fp32(patches, dtype, tol):
+def test_gpu_probabilities_match_cpu_fp32(patches, dtype, tol, conv_algo):
     """Seeded random weights: torch-CPU fp32 forward is the reference (reference tolerance on
     kather100k max-prob is 1e-3, tests/engines/test_patch_predictor.py:279-280)."""
     cpu = PatchPredictor("resnet18-kather100k", batch_size=6).run(patches, patch_mode=True, return_probabilities=True)
     gpu = PatchPredictor("resnet18-kather100k", batch_size=4, device="cuda").run(
-        patches, patch_mode=True, return_probabilities=True, compute_dtype=dtype)
+        patches, patch_mode=True, return_probabilities=True, compute_dtype=dtype, conv_algo=conv_algo)
     err = np.abs(gpu["probabilities"] - cpu["probabilities"]).max()
     print(f"{dtype}: max |dp| = {err:.3e}")
     assert err <= tol
@@ -155,7 +168,7 @@ def test_host_feed_with_ramped_first_batches_equals_device_resident_input(target
 
 
 @pytest.mark.gpu
-def test_gpu_macenko_prenorm_pipeline(patches, target_image):
+def test_gpu_macenko_prenorm_pipeline(patches, target_image, conv_algo):
     """Engine with the stain normaliser on the device == oracle-normalised patches through the CPU model."""
     from oracle import stain as ostain
     from tiatoolbox_amd.models.dataset.classification import StainNormPreproc
@@ -164,7 +177,7 @@ def test_gpu_macenko_prenorm_pipeline(patches, target_image):
     norm = get_normalizer("macenko")
     norm.fit(target_image)
     eng = PatchPredictor("resnet18-kather100k", batch_size=4, device="cuda")
-    got = eng.run(patches, patch_mode=True, return_probabilities=True, stain_normalizer=norm)
+    got = eng.run(patches, patch_mode=True, return_probabilities=True, stain_normalizer=norm, conv_algo=conv_algo)
     ref_norm = ostain.get_normalizer("macenko")
     ref_norm.fit(target_image.copy())
     normed = np.stack([ref_norm.transform(p.copy()) for p in patches])
@@ -431,7 +444,7 @@ def test_hip_mfma_conv_matches_torch_cpu_fp32():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["resnet18-kather100k", "resnet50-kather100k"])
-def test_mfma_resnet_matches_plain_model(patches, name):
+def test_mfma_resnet_matches_plain_model(patches, name, conv_algo):
     """resnet18 (BasicBlock) / resnet50 (Bottleneck) with every block convolution on the hand-written MFMA kernel == the
     plain torch module on the CPU."""
     from tiatoolbox_amd.models.architecture import get_pretrained_model
@@ -451,7 +464,7 @@ def test_mfma_resnet_matches_plain_model(patches, name):
         got = mfma(x.cuda().contiguous(memory_format=torch.channels_last)).cpu()
     assert (got - ref).abs().max() < 1e-4
     eng = PatchPredictor(name, batch_size=4, device="cuda")
-    a = eng.run(patches, patch_mode=True, return_probabilities=True)
+    a = eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo=conv_algo)
     assert any(type(m).__name__ == "MfmaResNet" for m in eng._inference_model(torch.float32).modules())
     b = PatchPredictor(name, batch_size=4).run(patches, patch_mode=True, return_probabilities=True)
     np.testing.assert_allclose(a["probabilities"], b["probabilities"], atol=1e-4)
@@ -643,7 +656,7 @@ def test_deferred_totensor_only_for_stock_classifiers():
 
 
 @pytest.mark.gpu
-def test_gpu_logits_match_cpu_fp32_with_spread_predictions():
+def test_gpu_logits_match_cpu_fp32_with_spread_predictions(conv_algo):
     """Logits-level parity on a model whose outputs are NOT degenerate: seeded random weights with randomised BatchNorm
     statistics and a classifier re-scaled until the CPU predictions cover several classes (an untrained network puts every
     patch in one class, which makes a 1e-4 comparison of softmax outputs weaker than it looks).  Compared: log-probabilities
@@ -675,7 +688,7 @@ def test_gpu_logits_match_cpu_fp32_with_spread_predictions():
         assert len(set(np.asarray(cpu["predictions"]).tolist())) >= 3, "the construction must spread the predictions"
         gpu_eng = PatchPredictor("resnet18-kather100k", batch_size=4, device="cuda")
         gpu_eng.model.load_state_dict(cpu_eng.model.state_dict())
-        gpu = gpu_eng.run(patches, **kw)
+        gpu = gpu_eng.run(patches, conv_algo=conv_algo, **kw)
         lp_c, lp_g = np.log(np.maximum(cpu["probabilities"], 1e-30)), np.log(np.maximum(gpu["probabilities"], 1e-30))
         spread = float(lp_c.max() - lp_c.min())
         err = float(np.abs(lp_c - lp_g).max())
@@ -768,16 +781,20 @@ def test_winograd_conv_matches_torch_cpu_fp32():
 
 @pytest.mark.gpu
 def test_winograd_patch_predictor_within_tolerance_of_direct():
-    """``PatchPredictor.run(..., conv_algo="winograd")``: the float32 3x3 / stride-1 block convolutions through F(2x2, 3x3).  The
-    probabilities stay within 1e-5 of the direct float32 path (the reference's own fp16 tolerance is 1e-3,
-    ``tests/engines/test_patch_predictor.py:719``), predictions agree, and the run really took the other kernel."""
+    """The engine's default ``conv_algo="auto"``: the float32 3x3 / stride-1 block convolutions through F(2x2, 3x3).  The
+    probabilities stay within 1e-5 of the audit mode ``conv_algo="direct"`` (the reference's own fp16 tolerance is 1e-3,
+    ``tests/engines/test_patch_predictor.py:719``), predictions agree, the run really took the other kernel, ``"winograd"`` names
+    the same path explicitly."""
     from tiatoolbox_amd.models.engine.patch_predictor import PatchPredictor
     from tiatoolbox_amd.utils import synth
 
     patches = synth.g_he(24, 224, 224, seed=9)
     eng = PatchPredictor("resnet18-kather100k", batch_size=16, device="cuda", verbose=False)
-    direct = eng.run(patches, patch_mode=True, return_probabilities=True)
+    assert eng.conv_algo == "auto"
+    auto = eng.run(patches, patch_mode=True, return_probabilities=True)
+    direct = eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo="direct")
     wino = eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo="winograd")
+    assert np.array_equal(wino["probabilities"], auto["probabilities"])
     dp = np.abs(np.asarray(wino["probabilities"], np.float64) - np.asarray(direct["probabilities"], np.float64)).max()
     assert 0.0 < dp <= 1e-5, dp
     assert np.array_equal(wino["predictions"], direct["predictions"])

@@ -481,7 +481,7 @@ def test_hovernet_state_dict_layout_and_shapes():
 
 
 @pytest.mark.gpu
-def test_nucleus_instance_segmentor_patch_mode():
+def test_nucleus_instance_segmentor_patch_mode(conv_algo):
     """Engine end to end on the GPU == CPU model forward + oracle post-processing, patch by patch."""
     import torch
 
@@ -491,7 +491,7 @@ def test_nucleus_instance_segmentor_patch_mode():
     patches = synth.g_he(3, 256, 256, seed=13)
     with pytest.warns(DeprecationWarning):
         eng = NucleusInstanceSegmentor("hovernet_fast-pannuke", batch_size=2, device="cuda")
-    out = eng.run(patches, patch_mode=True, return_probabilities=True)
+    out = eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo=conv_algo)
     assert set(out) == {"predictions", "box", "centroid", "contours", "prob", "type", "probabilities"}
     assert out["predictions"].shape == (3, 164, 164)
     npm, hv, tp = out["probabilities"]

@@ -202,14 +202,14 @@ def test_hip_postproc_end_to_end():
 
 
 @pytest.mark.gpu
-def test_multi_task_segmentor_runs_hovernetplus_patches():
+def test_multi_task_segmentor_runs_hovernetplus_patches(conv_algo):
     """Engine end to end: two tasks per patch, each with its own sub-dict (multi_task_segmentor.py:1706-1730)."""
     from tiatoolbox_amd.models.engine.multi_task_segmentor import MultiTaskSegmentor
     from tiatoolbox_amd.utils import synth
 
     patches = synth.g_he(2, 256, 256, seed=61)
     eng = MultiTaskSegmentor("hovernetplus-oed", batch_size=2, device="cuda")
-    out = eng.run(patches, patch_mode=True, return_probabilities=True)
+    out = eng.run(patches, patch_mode=True, return_probabilities=True, conv_algo=conv_algo)
     assert {"nuclei_segmentation", "layer_segmentation", "probabilities"} <= set(out)
     npm, hv, tp, ls = out["probabilities"]
     assert ls.shape == (2, 164, 164, 1)

@@ -127,7 +127,7 @@ def test_hip_wsi_stitch_bit_exact_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_semantic_segmentor_wsi_mode_matches_oracle_composition():
+def test_semantic_segmentor_wsi_mode_matches_oracle_composition(conv_algo):
     """Engine (tiling + tissue mask + UNet + device stitching) == same patches through the oracle merge."""
     import torch
 
@@ -153,7 +153,8 @@ def test_semantic_segmentor_wsi_mode_matches_oracle_composition():
     with tempfile.TemporaryDirectory() as tmp:
         with pytest.raises(OSError, match="no save directory"):  # engine_abc.py:1866-1871
             eng.run([reader], patch_mode=False, ioconfig=cfg)
-        paths = eng.run([reader], patch_mode=False, ioconfig=cfg, return_probabilities=True, save_dir=Path(tmp) / "out")
+        paths = eng.run([reader], patch_mode=False, ioconfig=cfg, return_probabilities=True, save_dir=Path(tmp) / "out",
+                        conv_algo=conv_algo)
         assert list(paths) == [0] and paths[0].name == "0.npz"
         with np.load(paths[0]) as res:
             pred, probs = res["predictions"], res["probabilities"]

@@ -435,6 +435,11 @@ def hip_conv3x3_wino(x: torch.Tensor, u_packed: torch.Tensor, bias: torch.Tensor
         msg = "hip_conv3x3_wino expects a float32 channels-last CUDA residual."
         raise ValueError(msg)
     n, cin, h, w = x.shape
+    if (u_packed.dim() != 7 or cin % 16 or tuple(u_packed.shape) != (16, cin // 16, 2, u_packed.shape[3], 2, 64, 4)  # noqa: PLR2004
+            or u_packed.dtype != torch.float32 or not u_packed.is_contiguous() or u_packed.device != x.device):
+        msg = (f"hip_conv3x3_wino: packed weights {tuple(u_packed.shape)} {u_packed.dtype} on {u_packed.device} do not match an input with "
+               f"{cin} channels on {x.device} (expected pack_conv_weights_wino's [16, cin/16, 2, cout/64, 2, 64, 4] float32, contiguous).")
+        raise ValueError(msg)
     cout = u_packed.shape[3] * 64
     behind = padding if pad_hi is None else pad_hi  # zero rows / columns behind the image (`padding` in front): "same", valid, TF-same
     ho, wo = h + padding + behind - 2, w + padding + behind - 2

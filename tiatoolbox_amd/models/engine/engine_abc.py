@@ -236,7 +236,11 @@ class EngineABC:
         self.output_type = None
         # MI355X extensions (plain attributes, settable through run(**kwargs) like every other)
         self.compute_dtype = "float32"    # arithmetic type of the CNN forward
-        self.conv_algo = "direct"         # float32 3x3 / stride-1 block convolutions: "direct" | "winograd" (F(2x2, 3x3), opt-in)
+        # float32 3x3 / stride-1 block convolutions: "auto" (default: Winograd F(2x2, 3x3) on every layer whose shape the committed
+        # per-layer error-bound test covers -- tests/test_engine.py::test_winograd_conv_matches_torch_cpu_fp32, <= 1e-5 of the
+        # output scale against torch-CPU float32 -- the direct implicit GEMM elsewhere), "direct" (audit mode: the reference's
+        # order of accumulation over taps everywhere), "winograd" (same layers as "auto"; kept for explicitness)
+        self.conv_algo = "auto"
         self.distributed = True           # shard over ranks when torch.distributed is initialised
         self.fold_batchnorm = True        # inference copy with BN folded into the convolutions
         self.miopen_find = None           # True: MIOpen solver search for graphs that still run as plain torch modules
@@ -329,6 +333,11 @@ class EngineABC:
         """ref. :1211-1372: every kwarg becomes an attribute on the engine (and persists)."""
         for key in kwargs:
             setattr(self, key, kwargs.get(key))
+        if hasattr(self, "return_probabilities"):
+            # decided per call, like the reference (`kwargs.get("return_probabilities")`, patch_predictor.py:535-537,
+            # semantic_segmentor.py:795, multi_task_segmentor.py:982): a run without the kwarg drops the probabilities even if an
+            # earlier run asked for them
+            self.return_probabilities = bool(kwargs.get("return_probabilities", False))
         if "miopen_find" not in kwargs:
             self.miopen_find = None  # the process-global solver-search switch is chosen per run, never inherited
         if input_resolutions:
@@ -386,11 +395,13 @@ class EngineABC:
 
     def _inference_model(self, dtype: torch.dtype):
         """The module used for the forward pass: parameters in ``dtype``, channels-last (MIOpen NHWC)."""
-        algo = str(getattr(self, "conv_algo", None) or "direct")
-        if algo not in ("direct", "winograd"):  # (the same message on every device; on the CPU the option has no effect)
-            self.conv_algo = "direct"  # (run kwargs persist as attributes: do not leave the rejected value behind)
-            msg = f"conv_algo must be 'direct' or 'winograd', got {algo!r}."
+        algo = str(getattr(self, "conv_algo", None) or "auto")
+        if algo not in ("auto", "direct", "winograd"):  # (the same message on every device; on the CPU the option has no effect)
+            self.conv_algo = "auto"  # (run kwargs persist as attributes: do not leave the rejected value behind)
+            msg = f"conv_algo must be 'auto', 'direct' or 'winograd', got {algo!r}."
             raise ValueError(msg)
+        if algo == "auto":  # the modules know two forms; "auto" = Winograd wherever a layer qualifies (their own shape checks)
+            algo = "winograd"
         if dtype == torch.float32 and torch.device(self.device).type != "cuda":
             return self.model
         key = (dtype, str(self.device), id(self.model), self.fold_batchnorm, _weights_version(self.model), algo)

@@ -217,7 +217,7 @@ class MultiTaskSegmentor(EngineABC):
         if kwargs.get("return_labels"):
             msg = "`return_labels` is not supported for MultiTaskSegmentor."
             raise ValueError(msg)  # ref. :2149-2156
-        self.return_probabilities = kwargs.get("return_probabilities", self.return_probabilities)
+        self.return_probabilities = bool(kwargs.get("return_probabilities", False))  # per call (ref. :982, 1710, 1824)
         return super()._update_run_params(images, **kwargs)
 
     def post_process_patches(self, raw_predictions: dict, **_) -> dict:

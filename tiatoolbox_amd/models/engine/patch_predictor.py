@@ -25,8 +25,8 @@ class PatchPredictor(EngineABC):
         self._default_preproc = self._get_model_attr("preproc_func")
 
     def _update_run_params(self, images, **kwargs):
-        """ref. :448-549: ``probabilities`` are dropped unless ``return_probabilities``."""
-        self.return_probabilities = kwargs.get("return_probabilities", self.return_probabilities)
+        """ref. :448-549: ``probabilities`` are dropped unless THIS call passes ``return_probabilities=True`` (ref. :535-537:
+        ``kwargs.get("return_probabilities")`` -- per call, not sticky)."""
         out = super()._update_run_params(images, **kwargs)
         if not self.return_probabilities:
             self.drop_keys.append("probabilities")
