@@ -397,9 +397,10 @@ def self_spawn(args: argparse.Namespace) -> None:
     os.execvp(sys.executable, cmd)  # noqa: S606
 
 
-def verify_ranks(args: argparse.Namespace, world_size: int, local_rank: int) -> None:
+def verify_ranks(args: argparse.Namespace, world_size: int, local_rank: int) -> dict | None:
     """Fail loudly instead of reporting an N-GPU number that was not measured on N GPUs: the process group must have
-    ``--gpus`` ranks, and no two ranks may sit on the same device (same host + device index, or same device UUID)."""
+    ``--gpus`` ranks, and no two ranks may sit on the same device (same host + device index, or same device UUID).  Returns what
+    the line reports as ``rccl`` for N > 1: world size, backend, every rank's host / device index / device UUID."""
     import socket
 
     import torch
@@ -408,7 +409,7 @@ def verify_ranks(args: argparse.Namespace, world_size: int, local_rank: int) -> 
     if world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the process group has {world_size} rank(s)")
     if world_size == 1:
-        return
+        return None
     if not dist.is_initialized() or dist.get_world_size() != args.gpus:
         raise SystemExit(f"--gpus {args.gpus}: torch.distributed is not initialised with that many ranks")
     if dist.get_backend() != "nccl":
@@ -421,6 +422,9 @@ def verify_ranks(args: argparse.Namespace, world_size: int, local_rank: int) -> 
     dist.all_gather_object(seen, mine)
     if len({(h, d) for h, d, _ in seen}) != world_size or (all(u for _, _, u in seen) and len({u for _, _, u in seen}) != world_size):
         raise SystemExit(f"--gpus {args.gpus}: ranks share a device: {seen}")
+    return {"world_size": world_size, "backend": dist.get_backend(), "hosts": [h for h, _, _ in seen],
+            "device_indices": [d for _, d, _ in seen], "device_uuids": [u for _, _, u in seen],
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
 
 
 def bench_patch(args: argparse.Namespace) -> dict | None:
@@ -439,7 +443,7 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
     rank, world_size, local_rank = tdist.init_from_env()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    verify_ranks(args, world_size, local_rank)
+    rccl_info = verify_ranks(args, world_size, local_rank)
     logging.getLogger("tiatoolbox_amd").setLevel(logging.ERROR)
     n, hw = args.patches, args.patch_size
     target = np.load(ROOT / "tests" / "golden" / "target_crop_256.npy")
@@ -527,8 +531,10 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                    "patches_per_gpu": n, "patch_size": hw, "engine_batch_size": args.micro_batch,
                    "parallelism": f"dp{world_size} (patch-sharded, all_gather of probabilities)"},
     }
-    if per_rank is not None:
+    if world_size > 1:
+        assert per_rank is not None and rccl_info is not None  # a multi-GPU line always explains itself
         line["per_rank"] = per_rank
+        line["rccl"] = rccl_info
 
     # ---- per-kernel timing with HIP events on the launch stream ------------------------------------------------
     dtype_t = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}[args.dtype]

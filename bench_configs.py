@@ -27,6 +27,9 @@ HBM_PEAK_GBS = 8000.0
 MFMA_PEAK_F32 = 157.3
 
 
+_RCCL: dict | None = None  # what bench.verify_ranks learned about the process group (N > 1): reported as `rccl` in every line
+
+
 def _setup(args):
     import logging
 
@@ -38,7 +41,8 @@ def _setup(args):
     torch.cuda.set_device(local_rank)
     import bench
 
-    bench.verify_ranks(args, world_size, local_rank)
+    global _RCCL  # noqa: PLW0603
+    _RCCL = bench.verify_ranks(args, world_size, local_rank)
     logging.getLogger("tiatoolbox_amd").setLevel(logging.ERROR)
     return rank, world_size, torch.device("cuda", local_rank)
 
@@ -316,6 +320,8 @@ def bench_semantic(args) -> dict | None:
     }
     if per_rank is not None:
         line["per_rank"] = per_rank
+        if _RCCL is not None:
+            line["rccl"] = _RCCL
     if world_size == 1:
         # the audit mode (conv_algo="direct": no Winograd for the plain 3x3 / stride-1 convolutions of the UNet): forward alone + one slide
         xb8 = reader.read_bounds_batch(in_b[keep][:8])
@@ -366,7 +372,6 @@ def bench_hovernet(args) -> dict | None:
     import numpy as np
     import torch
 
-    from oracle import hovernet as oh
     from tiatoolbox_amd.models.architecture import _hover_device as hd
     from tiatoolbox_amd.models.engine.multi_task_segmentor import NucleusInstanceSegmentor
     from tiatoolbox_amd.utils import synth
@@ -392,7 +397,7 @@ def bench_hovernet(args) -> dict | None:
     if rank != 0:
         return None
     # post-processing alone, on synthetic head outputs with ~60 nuclei per 164^2 tile (HIP events)
-    npm, hv, tp = oh.synth_maps(8, 164, 164, seed=1, n_blobs=60)
+    npm, hv, tp = synth.hover_head_maps(8, 164, 164, seed=1, n_blobs=60)
     reps = max(1, n // 8)
     npm_d = torch.from_numpy(npm).to(device).repeat(reps, 1, 1, 1)
     hv_d = torch.from_numpy(hv).to(device).repeat(reps, 1, 1, 1)
@@ -437,6 +442,8 @@ def bench_hovernet(args) -> dict | None:
     }
     if per_rank is not None:
         line["per_rank"] = per_rank
+        if _RCCL is not None:
+            line["rccl"] = _RCCL
     if world_size == 1:
         # the audit mode (conv_algo="direct": no Winograd for the plain 3x3 / stride-1 convolutions): an extra beside `value`
         heads_d = [h.clone() for h in model.infer_batch(fmodel, xb, device=str(device))]
@@ -460,6 +467,8 @@ def bench_hovernet(args) -> dict | None:
 
         def cpu_post():
             for i in range(4):
+                from oracle import hovernet as oh  # (the CPU baseline leg: the only place the oracle runs)
+
                 inst_i = oh.proc_np_hv(npm[i], hv[i])
                 oh.get_instance_info(inst_i, np.around(tp[i]).astype("uint8")[..., 0])
 
@@ -539,6 +548,8 @@ def bench_vahadane(args) -> dict | None:
     }
     if per_rank is not None:
         line["per_rank"] = per_rank
+        if _RCCL is not None:
+            line["rccl"] = _RCCL
     # BASELINE's "fp16 OD path": the per-pixel arithmetic exists in float64 (the reference's, reported above) and float32; half
     # precision exists as an OUTPUT format of the float32 path (the CNN's input), not as OD-space arithmetic -- 11 significand
     # bits cannot hold exp(-OD) to the 1e-4 the north star asks of normalised pixels.  Reported here: the float32 per-pixel path

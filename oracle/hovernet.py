@@ -105,27 +105,9 @@ def get_instance_info(pred_inst: np.ndarray, pred_type: np.ndarray | None = None
 
 
 def synth_maps(n: int, h: int, w: int, seed: int = 0, n_blobs: int = 30, num_types: int = 6):
-    """Synthetic HoVer-Net head outputs: ``np`` = union of Gaussian blobs,
-    ``hv`` = per-blob normalised x/y ramps in [-1, 1] plus noise, ``tp`` = blob class."""
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-    np_map = np.zeros((n, h, w, 1), np.float32)
-    hv = np.zeros((n, h, w, 2), np.float32)
-    tp = np.zeros((n, h, w, 1), np.float32)
-    for i in range(n):
-        best = np.zeros((h, w), np.float32)
-        for _ in range(n_blobs):
-            cy, cx = rng.uniform(4, h - 4), rng.uniform(4, w - 4)
-            ry, rx = rng.uniform(3.5, 9.0, 2)
-            d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
-            p = np.exp(-0.5 * d * 2.0).astype(np.float32)
-            upd = p > best
-            best = np.where(upd, p, best)
-            hv[i, ..., 0] = np.where(upd, np.clip((xx - cx) / rx, -1, 1), hv[i, ..., 0])
-            hv[i, ..., 1] = np.where(upd, np.clip((yy - cy) / ry, -1, 1), hv[i, ..., 1])
-            tp[i, ..., 0] = np.where(upd & (p > 0.3), rng.integers(1, num_types), tp[i, ..., 0])
-        np_map[i, ..., 0] = best
-        hv[i] *= (best > 0.2)[..., None]
-    np_map += rng.normal(0, 0.02, np_map.shape).astype(np.float32)
-    hv += rng.normal(0, 0.02, hv.shape).astype(np.float32)
-    return np.clip(np_map, 0, 1).astype(np.float32), hv.astype(np.float32), tp
+    """Synthetic HoVer-Net head outputs.  The generator is an INPUT source, not a checker: it lives with the
+    other synthetic inputs in ``tiatoolbox_amd.utils.synth`` (benches and profiling scripts take it from there, never from
+    ``oracle/``); this name stays for the tests."""
+    from tiatoolbox_amd.utils.synth import hover_head_maps
+
+    return hover_head_maps(n, h, w, seed=seed, n_blobs=n_blobs, num_types=num_types)

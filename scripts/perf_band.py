@@ -1,5 +1,5 @@
 """Developer A/B of the tap-reuse kernel's band geometries: the four 3x3 / stride-1 layer shapes of resnet18 at 224^2 patches
-(56 / 28 / 14 / 7 maps), hand-written kernel only, with a clock warm-up.  Run under TIA_CONV_BAND_GAPS=1 (round-4 bands with the
+(56 / 28 / 14 / 7 maps), hand-written kernel only, with a clock warm-up.  Run under TIA_DEV=1 and TIA_CONV_BAND_GAPS=1 (round-4 bands with the
 zero rows among the GEMM rows), TIA_CONV_BAND_MAX_STRIPS=k, TIA_CONV_NO_BAND=1 (slice / ring kernels) to compare."""
 import ctypes, sys
 from pathlib import Path

@@ -4,13 +4,13 @@ import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np, torch
-from oracle import hovernet as oh  # synthetic head outputs only (test / bench infrastructure)
+from tiatoolbox_amd.utils import synth
 from tiatoolbox_amd.models.architecture import _hover_device as hd
 from tiatoolbox_amd.models.architecture.hovernet import HoVerNet
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-npm, hv, tp = oh.synth_maps(8, 164, 164, seed=1, n_blobs=60)
+npm, hv, tp = synth.hover_head_maps(8, 164, 164, seed=1, n_blobs=60)
 dev = torch.device("cuda")
 npm_d = torch.from_numpy(npm).to(dev).repeat(n // 8, 1, 1, 1)
 hv_d = torch.from_numpy(hv).to(dev).repeat(n // 8, 1, 1, 1)

@@ -86,10 +86,9 @@ def sec_mask():
 
 
 def sec_hover():
-    from oracle import hovernet as oh   # synthetic head outputs only (test/bench infrastructure)
 
     n, h, w = 256, 164, 164
-    npm, hv, tp = oh.synth_maps(8, h, w, seed=4, n_blobs=60)
+    npm, hv, tp = synth.hover_head_maps(8, h, w, seed=4, n_blobs=60)
     rep = n // 8
     npm_t = torch.from_numpy(npm).cuda().repeat(rep, 1, 1, 1)
     hv_t = torch.from_numpy(hv).cuda().repeat(rep, 1, 1, 1)
@@ -103,7 +102,7 @@ def sec_hover():
     stats, _ = hd.instance_stats(inst, tp_t, mx, 6)
     report("hover contours (scan + write, incl. D2H)", timeit(lambda: hd.contours(inst, stats, mx), reps=5, warm=1), 4 * px)
     # WSI-mode tile
-    npm1, hv1, _ = oh.synth_maps(1, 1000, 1000, seed=5, n_blobs=1500)
+    npm1, hv1, _ = synth.hover_head_maps(1, 1000, 1000, seed=5, n_blobs=1500)
     a, b = torch.from_numpy(npm1).cuda(), torch.from_numpy(hv1).cuda()
     i1, n1 = hd.proc_np_hv(a, b)
     report("hover proc_np_hv, one 1000^2 tile", timeit(lambda: hd.proc_np_hv(a, b), reps=5, warm=1), 20 * 1000 * 1000,

@@ -27,10 +27,10 @@ if which == "vahadane":
     for _ in range(calls):
         dev.stain_stats(x, p)
 elif which == "hover":
-    from oracle import hovernet as oh   # synthetic head outputs only (bench infrastructure)
+    from tiatoolbox_amd.utils import synth
     from tiatoolbox_amd.models.architecture import _hover_device as hd
 
-    npm, hv, _ = oh.synth_maps(8, 164, 164, seed=1, n_blobs=60)
+    npm, hv, _ = synth.hover_head_maps(8, 164, 164, seed=1, n_blobs=60)
     npm_d = torch.from_numpy(npm).to(dev_).repeat(32, 1, 1, 1)
     hv_d = torch.from_numpy(hv).to(dev_).repeat(32, 1, 1, 1)
     for _ in range(calls):

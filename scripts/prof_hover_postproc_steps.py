@@ -3,11 +3,11 @@ import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np, torch
-from oracle import hovernet as oh
+from tiatoolbox_amd.utils import synth
 from tiatoolbox_amd.models.architecture import _hover_device as hd
 
 n = 256
-npm, hv, tp = oh.synth_maps(8, 164, 164, seed=1, n_blobs=60)
+npm, hv, tp = synth.hover_head_maps(8, 164, 164, seed=1, n_blobs=60)
 dev = torch.device("cuda")
 np_map = torch.from_numpy(npm).to(dev).repeat(n // 8, 1, 1, 1)
 hv_map = torch.from_numpy(hv).to(dev).repeat(n // 8, 1, 1, 1)

@@ -510,10 +510,19 @@ def test_rgb2od_standalone_kernel_and_side_effect(uniform_patches):
     ro = uniform_patches[0].copy()
     ro.setflags(write=False)                                                   # read-only input: values only
     assert np.array_equal(rgb2od(ro), ostain.rgb2od(uniform_patches[0].copy()))
-    with pytest.raises(TypeError, match="uint8"):                                # the byte kernel does not truncate silently
-        rgb2od(uniform_patches[0].astype(np.float32))
-    with pytest.raises(TypeError, match="uint8"):
-        rgb2od(torch.from_numpy(uniform_patches[0].copy()).cuda().float())
+    # other dtypes keep the reference's semantics (log of the values as they are, 0 -> 1 in place): float RGB, integer arrays, lists
+    f32 = uniform_patches[0].astype(np.float32)
+    theirs = f32.copy()
+    exp = ostain.rgb2od(theirs)
+    got = rgb2od(f32)
+    assert got.dtype == exp.dtype and np.allclose(got, exp, rtol=2e-6, atol=0) and np.array_equal(f32, theirs)
+    i64 = uniform_patches[0][:8, :8].astype(np.int64)
+    assert np.allclose(rgb2od(i64.copy()), ostain.rgb2od(i64.copy()), rtol=1e-14, atol=0)
+    assert np.allclose(rgb2od(i64.tolist()), ostain.rgb2od(i64.copy()), rtol=1e-14, atol=0)
+    tf = torch.from_numpy(uniform_patches[0].copy()).cuda().float()
+    assert np.allclose(rgb2od(tf).cpu().numpy(), exp, rtol=2e-6, atol=0) and int((tf == 0).sum()) == 0
+    with pytest.raises(TypeError, match="numeric"):
+        rgb2od(np.array([["a"]]))
 
 
 @pytest.mark.gpu

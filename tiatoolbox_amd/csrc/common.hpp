@@ -6,6 +6,7 @@
 
 #include <atomic>
 
+#include "dev_env.hpp"
 #include "tiatoolbox_amd.h"
 
 #ifndef TIA_UNIFORM

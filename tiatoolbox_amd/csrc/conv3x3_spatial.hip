@@ -759,7 +759,7 @@ static long device_cu_count() {
 }
 
 bool conv3x3_spatial_serves(long nb, long h, long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo, int dtype) {
-    static const bool disabled = getenv("TIA_CONV_NO_SPATIAL") != nullptr;
+    static const bool disabled = tia::dev_env("TIA_CONV_NO_SPATIAL") != nullptr;
     const int es = dtype == TIA_DT_F32 ? 4 : 2;
     if (disabled || cin % (64 / es) != 0 || cout % 64 != 0 || pad_top > 2 || pad_left > 2) return false;
     const SpPlan plan = conv3x3_spatial_plan(3, 3, 1, h, w, ho, wo, pad_top, pad_left, dtype == TIA_DT_F32);
@@ -797,9 +797,9 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
                    pack ? 1 : 0, (int)(h + pad_top - ho), 1.0f / (float)ho};
     // 128-channel column tiles, unless that leaves fewer workgroups than the device has CUs (small batches of small maps: UNet-R50's
     // 512 -> 512 @ 32^2 at batch 8 is 128 workgroups for 256 CUs: 73 TFLOP/s): then 64-channel tiles, twice as many workgroups
-    static const bool no_narrow = getenv("TIA_CONV_NO_NARROW_FILL") != nullptr;  // developer switch (A/B measurements)
+    static const bool no_narrow = tia::dev_env("TIA_CONV_NO_NARROW_FILL") != nullptr;  // developer switch (A/B measurements)
     const bool wide = cout % 128 == 0 && (no_narrow || tiles * (cout / 128) >= device_cu_count());
-    static const bool wide8 = getenv("TIA_CONV_N64_8WAVES") != nullptr;  // developer switch: 64-channel band tiles on the 8-wave (4 x 2) form
+    static const bool wide8 = tia::dev_env("TIA_CONV_N64_8WAVES") != nullptr;  // developer switch: 64-channel band tiles on the 8-wave (4 x 2) form
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / (wide ? 128 : 64)));
 #define TIA_LAUNCH_GEO(BN_, KIND_, GEO_)                                                                                           \
     hipLaunchKernelGGL((conv3x3_spatial_kernel<BN_, KIND_, GEO_>), grid, dim3(GEO_::NT), 0, stream, x, w_packed, bias, residual, y, d, \
@@ -825,8 +825,8 @@ bool conv3x3_spatial_launch(const void* x, const void* w_packed, const float* bi
 }
 
 bool conv_ring_ok(long nb, long cin, long cout, long kh, long kw, long ho, long wo) {
-    static const bool disabled = getenv("TIA_CONV_NO_RING") != nullptr;
-    static const bool no_taps = getenv("TIA_CONV_NO_GATHER_RING") != nullptr;  // developer switch (A/B measurements)
+    static const bool disabled = tia::dev_env("TIA_CONV_NO_RING") != nullptr;
+    static const bool no_taps = tia::dev_env("TIA_CONV_NO_GATHER_RING") != nullptr;  // developer switch (A/B measurements)
     if (disabled || cin % 16 != 0 || cout % 128 != 0 || kh > 16 || kw > 16) return false;
     if ((kh != 1 || kw != 1) && no_taps) return false;
     const long m_total = nb * ho * wo, tiles = (m_total + 255) / 256;

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "dev_env.hpp"
+
 namespace tia {
 
 // Which block geometry of the tap-reuse kernel serves a 3x3 / stride-1 convolution, if any.
@@ -31,15 +33,15 @@ inline SpPlan conv3x3_spatial_plan(long kh, long kw, long stride, long h, long w
     }
     SpPlan best = (8 * num >= 7 * den) ? SpPlan{kind, 0, 0, 0, 0, 0} : none;
     double busy = best.kind ? (double)num / (double)den : 0.0;
-    static const bool no_band = getenv("TIA_CONV_NO_BAND") != nullptr;   // developer switches (A/B measurements)
-    static const bool no_pack = getenv("TIA_CONV_BAND_GAPS") != nullptr;  // keep the round-4 form of the band geometry (gap rows computed)
+    static const bool no_band = tia::dev_env("TIA_CONV_NO_BAND") != nullptr;   // developer switches (A/B measurements)
+    static const bool no_pack = tia::dev_env("TIA_CONV_BAND_GAPS") != nullptr;  // keep the round-4 form of the band geometry (gap rows computed)
     // bands: "same" padding (one zero row / column all round) or, kind 4 only, a valid convolution (HoVer-Net's decoders)
     const bool same = pad_top == 1 && pad_left == 1 && ho == h && wo == w, valid = pad_top == 0 && pad_left == 0 && ho == h - 2 && wo == w - 2;
     if (!no_band && (same || valid) && ho >= 2) {
         const long gap = same ? 1 : 2;  // virtual (input) rows per image beyond its ho output rows
         SpPlan band = none;
         double band_busy = 0.0;
-        static const long max_strips = getenv("TIA_CONV_BAND_MAX_STRIPS") ? atol(getenv("TIA_CONV_BAND_MAX_STRIPS")) : 8;
+        static const long max_strips = tia::dev_env("TIA_CONV_BAND_MAX_STRIPS") ? atol(tia::dev_env("TIA_CONV_BAND_MAX_STRIPS")) : 8;
         for (long strips = 1; strips <= max_strips; ++strips) {
             if (wo % strips) continue;
             const long bw = wo / strips;

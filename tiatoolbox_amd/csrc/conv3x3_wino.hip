@@ -560,7 +560,7 @@ struct WinoPlan {
     double busy;
 };
 static WinoPlan wino_plan(long nb, long ho, long wo) {
-    static const bool no_windows = getenv("TIA_WINO_NO_WINDOWS") != nullptr;  // developer switch (A/B measurements)
+    static const bool no_windows = tia::dev_env("TIA_WINO_NO_WINDOWS") != nullptr;  // developer switch (A/B measurements)
     if (ho <= 8 && wo <= 8) return WinoPlan{1, 0, 0, 0, 0, 0, 0, 0, (double)(ho * wo) / 64.0};
     const long tiles_y = (ho + 1) / 2, tiles_x = (wo + 1) / 2;
     const double busy16 = (double)(ho * wo) / (double)(((ho + 15) / 16) * ((wo + 15) / 16) * 256);
@@ -597,7 +597,7 @@ int conv3x3_wino_launch(const float* x, const float* u_packed, const float* bias
     const long tiles = plan.kind == 2 ? (n_windows + plan.wg - 1) / plan.wg : (small ? (nb + 3) / 4 : nb * tiles_y * tiles_x);
     WinoDims d{(int)nb, (int)h, (int)w, (int)cin, (int)cout, (int)ho, (int)wo, (int)pad_top, (int)pad_left,
                (unsigned)(nb * h * w * cin * 4), (unsigned)(16 * cin * cout * 4), (int)((cin / 16) * (cout / 64) * 4096),
-               getenv("TIA_WINO_ABL") ? atoi(getenv("TIA_WINO_ABL")) : 0,
+               tia::dev_env("TIA_WINO_ABL") ? atoi(tia::dev_env("TIA_WINO_ABL")) : 0,
                1, 1, 1, 9, 16, 1, 1, 0, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
     if (plan.kind == 2) {
         if (n_windows >= (1L << 24)) return TIA_ESIZE;  // fdiv() range (the callers keep the input below 2 GiB)

@@ -392,8 +392,8 @@ static int conv2d_impl(const float* d_x, const float* d_w_packed, const float* d
             tia::conv_ring_launch(xg, d_w_packed, d_bias, rg, yg, nb, h, w, cin, cout, kh, kw, stride, pad_top, pad_left, ho, wo, relu, st))
             continue;
         const long grid_x = ((m_tiles + 7) / 8) * 8;  // whole rounds over the 8 XCDs (surplus workgroups exit at once)
-        static const bool force64 = getenv("TIA_CONV_BN64") != nullptr;  // developer switches (tile-shape experiments)
-        static const bool no_rule = getenv("TIA_CONV_NO_1X1_RULE") != nullptr;
+        static const bool force64 = tia::dev_env("TIA_CONV_BN64") != nullptr;  // developer switches (tile-shape experiments)
+        static const bool no_rule = tia::dev_env("TIA_CONV_NO_1X1_RULE") != nullptr;
         // 1x1 convolutions with few input channels have only cin / 32 slices per tile: the narrower tile (more workgroups,
         // 5 instead of 3 per CU) hides their prologue / epilogue better (+15-20 % on resnet18's down-sampling convolutions)
         const bool narrow = force64 || (!no_rule && kh == 1 && kw == 1 && cin <= 256);

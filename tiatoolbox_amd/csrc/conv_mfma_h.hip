@@ -383,7 +383,7 @@ extern "C" int tia_conv2d_nhwc_h(const void* d_x, const void* d_w_packed, const 
         // 64-channel slices (two stages, 16 MFMAs per barrier, whole cache lines per pixel) measured no faster than 32-channel
         // slices in a three-stage ring (profiles/r03e_perf_conv_h*.txt: 527 vs 539 TF/s over the resnet18 trunk; slower on the
         // 1x1 convolutions): both sit on the global -> LDS byte rate, not on latency or barriers.  Kept as a developer switch.
-        static const bool want64 = getenv("TIA_CONVH_BK64") != nullptr;
+        static const bool want64 = tia::dev_env("TIA_CONVH_BK64") != nullptr;
         const bool bk64 = cin % 64 == 0 && want64;
         const bool wide = cout % 128 == 0;
         const dim3 grid((unsigned)grid_x, (unsigned)(cout / (wide ? 128 : 64)));

@@ -1152,11 +1152,11 @@ static int launch_watershed(const int* blob_lab, const int* mark_lab, const doub
     long fx = (max_labels + 63) / 64, fcap = 65536 / n > 4 ? 65536 / n : 4;  // lanes stride over labels beyond the cap
     dim3 fgrid((unsigned)n, (unsigned)(fx < fcap ? fx : fcap));
     static const int wave_per_blob = [] {
-        const char* e = getenv("TIA_FLOOD_WAVE");  // developer switch: 0 = one lane per blob
+        const char* e = tia::dev_env("TIA_FLOOD_WAVE");  // developer switch: 0 = one lane per blob
         return e ? atoi(e) : 1;
     }();
     static const int relax = [] {
-        const char* e = getenv("TIA_FLOOD_RELAX");  // developer switch: 0 = sequential heap flood for every blob
+        const char* e = tia::dev_env("TIA_FLOOD_RELAX");  // developer switch: 0 = sequential heap flood for every blob
         return e ? atoi(e) : 1;
     }();
     if (wave_per_blob) {

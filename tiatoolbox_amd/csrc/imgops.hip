@@ -1127,7 +1127,7 @@ static bool tile_lds_ok(K kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 bool ccl_tile_enabled() {
-    static const bool on = getenv("TIA_NO_CCL_TILE") == nullptr;
+    static const bool on = tia::dev_env("TIA_NO_CCL_TILE") == nullptr;
     if (!on) return false;
     static DeviceOnce once;
     static std::atomic<unsigned char> refused[64] = {};
@@ -1288,7 +1288,7 @@ extern "C" int tia_morph_mask_u8(const uint8_t* d_img, int64_t n, int64_t h, int
     int bw = 1;
     while (bw * bw < min_region) ++bw;
     const int bh = min_region > 0 ? (min_region + bw - 1) / bw : 1;
-    static const int force_uf = getenv("TIA_MORPH_FORCE_UF") ? 1 : 0;  // developer switch: every tile through the union-find
+    static const int force_uf = tia::dev_env("TIA_MORPH_FORCE_UF") ? 1 : 0;  // developer switch: every tile through the union-find
     const size_t lds = (size_t)kMorphTileW * kMorphTileH * sizeof(int);
     const long total_bytes = (long)n * h * w * channels;
     if (channels == 3)

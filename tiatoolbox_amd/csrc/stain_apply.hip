@@ -934,7 +934,7 @@ static inline unsigned blocks_x(long work_items, long n_patches) {
     long maxb = (work_items + per_block - 1) / per_block;
     static long target = 0;
     if (target == 0) {
-        const char* e = getenv("TIA_APPLY_BLOCKS");
+        const char* e = tia::dev_env("TIA_APPLY_BLOCKS");
         target = e ? atol(e) : 4096;
     }
     long want = (target + n_patches - 1) / n_patches;
@@ -949,7 +949,7 @@ static int launch_apply(const uint8_t* d_img, int64_t n, long hw, const tia_stai
     const long ng = (hw & 3) == 0 ? (hw >> 2) : hw;
     dim3 grid(blocks_x(ng, n), (unsigned)n);
     if constexpr (MATH != TIA_MATH_F64_REF) {
-        static const bool no_wide = getenv("TIA_APPLY_NO_WIDE") != nullptr;  // developer switch (A/B measurements)
+        static const bool no_wide = tia::dev_env("TIA_APPLY_NO_WIDE") != nullptr;  // developer switch (A/B measurements)
         const bool aligned = ((reinterpret_cast<uintptr_t>(d_img) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
         if ((hw * 3) % 3072 == 0 && aligned && !(no_wide && MATH == TIA_MATH_F64) &&
             (out_kind == TIA_OUT_U8 || out_kind == TIA_OUT_UNIT_F16 || out_kind == TIA_OUT_UNIT_BF16)) {
@@ -960,7 +960,7 @@ static int launch_apply(const uint8_t* d_img, int64_t n, long hw, const tia_stai
             dim3 wgrid((unsigned)(bx < 1 ? 1 : bx), (unsigned)n);
             if constexpr (MATH == TIA_MATH_F64) {
                 // float64: the product-of-tables form (TIA_APPLY_NO_PTAB keeps the exponent-trick form: developer switch, A/B measurements)
-                static const bool no_ptab = getenv("TIA_APPLY_NO_PTAB") != nullptr;
+                static const bool no_ptab = tia::dev_env("TIA_APPLY_NO_PTAB") != nullptr;
                 if (!no_ptab) {
                     if (out_kind == TIA_OUT_U8)
                         hipLaunchKernelGGL((stain_apply_wide_kernel<MATH, TIA_OUT_U8, true>), wgrid, dim3(AT), 0, stream, d_img, hw, tab, stats, tgt, out);
@@ -1067,7 +1067,7 @@ extern "C" int tia_stain_augment_u8(const uint8_t* d_img, int64_t n, int64_t h, 
         // float64: the product-of-tables / 16-byte-access form where the shape allows (whole 3072-byte chunks, aligned buffers);
         // the tables cost 4,608 exponentials per workgroup: one workgroup per patch unless the batch is small
         const bool aligned = ((reinterpret_cast<uintptr_t>(d_img) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
-        static const bool no_tab = getenv("TIA_AUGMENT_NO_TABLES") != nullptr;  // developer switch: the per-pixel libm kernel
+        static const bool no_tab = tia::dev_env("TIA_AUGMENT_NO_TABLES") != nullptr;  // developer switch: the per-pixel libm kernel
         if ((hw * 3) % 3072 == 0 && aligned && !no_tab) {
             const long nchunks = hw * 3 / 3072;
             long bx = (nchunks + 3) / 4;

@@ -25,7 +25,7 @@ extern "C" size_t tia_stain_stats_workspace_bytes_mode(int64_t n, int64_t h, int
 // kernel alone; with the stratified sample nothing is handed back and both take the same time (2.14 ms per 4096 x 256^2,
 // profiles/r04q_*), the register-resident one with a third of the HBM-side traffic.  select_mode 2 keeps the streaming kernel.
 static bool stats_reg_shape(long hw, const tia_stain_params* params) {
-    static const bool no_reg = getenv("TIA_STATS_NO_REG") != nullptr;  // developer switch (A/B measurements)
+    static const bool no_reg = tia::dev_env("TIA_STATS_NO_REG") != nullptr;  // developer switch (A/B measurements)
     const long reg_limit = tia::stain_stats_reg_pixel_limit();
     // (>= 4096 pixels: the sample of 4096 dwords is parked in the patch's 4 hw bytes of workspace)
     return !no_reg && params->mode != TIA_MODE_VAHADANE && params->select_mode == 0 && (hw & 3) == 0 && hw <= reg_limit &&
@@ -55,7 +55,7 @@ extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, in
         if (!aligned || ws_bytes < tia_stain_stats_workspace_bytes_mode(n, h, w, TIA_MODE_VAHADANE)) return TIA_ESIZE;
         if (params->dl_max_iter < 1 || !(params->dl_alpha >= 0.0)) return TIA_EINVAL;
         dictws = (double2*)((char*)d_ws + align256s(tia_stain_stats_workspace_bytes(n, h, w)));
-        static const bool env_one = getenv("TIA_DL_ONE_KERNEL") != nullptr;  // developer switch (A/B measurements)
+        static const bool env_one = tia::dev_env("TIA_DL_ONE_KERNEL") != nullptr;  // developer switch (A/B measurements)
         if (params->dl_one_kernel || env_one)
             return tia::launch_stain_stats_stream(true, d_img, n, hw, d_tables, *params, d_stats, binws, dictws, nullptr, st);
         // the kernel pair: dictionary learning by replay (no dictionary traffic), then the common tail in MODE_VTAIL; what the first

@@ -46,6 +46,17 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     return rank, world_size, local_rank
 
 
+def agree_max(values: list[int], device: torch.device) -> list[int]:
+    """Element-wise MAX of a few integers over the ranks (one small all-reduce; identity without a process group): how ranks
+    agree on a decision that each of them would otherwise take from rank-local quantities (free memory, band height)."""
+    if not is_distributed() or dist.get_world_size() == 1:
+        return [int(v) for v in values]
+    on = device if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=on)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [int(v) for v in t.cpu().tolist()]
+
+
 def shard_bounds(n: int, rank: int, world_size: int) -> tuple[int, int]:
     """Contiguous ownership: ``[lo, hi)`` of rank ``rank`` (possibly empty for trailing ranks)."""
     per = math.ceil(n / world_size) if n else 0

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from tiatoolbox_amd import distributed as tdist
+from tiatoolbox_amd.utils import tracing
 from tiatoolbox_amd.models.architecture import get_pretrained_model
 from tiatoolbox_amd.models.dataset.dataset_abc import PatchDataset
 from tiatoolbox_amd.models.engine.io_config import ModelIOConfigABC
@@ -144,17 +145,28 @@ def _rank0_does(action) -> None:
     """Run a file-system ``action`` on rank 0 alone and make its outcome every rank's outcome: an ``OSError`` is broadcast as
     ``(class name, errno, strerror, filename)`` and re-raised everywhere as the same class with the same attributes (so
     ``exc.filename`` / ``exc.errno`` survive and the message is not doubled), instead of leaving the other ranks waiting in
-    the next collective.  The broadcast also orders the action before every rank's return.  COLLECTIVE."""
+    the next collective.  Any OTHER exception of the action (a ``ValueError`` / ``TypeError`` from the conversion work of a write
+    closure, ``MemoryError`` ...) is broadcast too and raised on every rank as ``RuntimeError("<class>: <message>")`` -- rank 0
+    re-raises the original -- so that no rank is ever left behind in ``broadcast_object_list``.  The broadcast also orders the
+    action before every rank's return.  COLLECTIVE."""
     rank, _ = tdist.world()
     outcome: list = [None]
+    original: BaseException | None = None
     if rank == 0:
         try:
             action()
         except OSError as exc:  # FileExistsError, PermissionError, disk full, ...
             outcome[0] = (type(exc).__name__, exc.errno, exc.strerror, exc.filename, str(exc))
+        except Exception as exc:  # noqa: BLE001  (anything else must reach the other ranks as well)
+            original = exc
+            outcome[0] = ("!" + type(exc).__name__, None, None, None, f"{type(exc).__name__}: {exc}")
     torch.distributed.broadcast_object_list(outcome, src=0)
     if outcome[0] is not None:
         name, errno_, strerror, filename, text = outcome[0]
+        if name.startswith("!"):
+            if original is not None:
+                raise original
+            raise RuntimeError(f"rank 0 failed while writing outputs -- {text}")
         cls = _OS_ERRORS.get(name, OSError)
         if errno_ is None:
             raise cls(text)
@@ -607,7 +619,10 @@ class EngineABC:
         """Batch boundaries of this rank's shard ``[lo, hi)``: ``batch_size`` patches each.  With host input on the asynchronous
         feed the FIRST batch's copy is the one transfer nothing can hide (1024 patches of 256 x 256 x 3 are 201 MB: ~8 ms of a 150 ms
         run), so the first ``batch_size`` patches go as batch_size / 8, / 4 and the remaining 5 / 8: 1 ms exposed, and every later copy
-        is shorter than the compute of the batch before it.  Per-patch results do not depend on the batching."""
+        is shorter than the compute of the batch before it.  Per-patch results depend on the batching only within float32 rounding: the
+        convolution route (tile shapes, round-fill rule, ring vs slice kernel) is chosen per launch from the number of images, and the
+        routes accumulate in different orders -- a ramped host-fed run and a device-resident run of the same data may differ in the
+        last ulp (the tests compare them with a tolerance, not bit for bit)."""
         bs = max(int(self.batch_size), 1)
         cuts = [lo]
         feed = getattr(self, "_feed", None)
@@ -641,8 +656,10 @@ class EngineABC:
                         self._feed.prefetch(s, e)
                         if k + 2 < len(cuts):
                             self._feed.prefetch(e, cuts[k + 2])
-                    batch = self._preprocess_batch(dataloader, s, e, dtype)
-                    outs.append(self._forward_batch(model, infer_batch, batch))
+                    with tracing.range("preprocess_batch"):  # stain pre-normalisation kernels (statistics, apply) live here
+                        batch = self._preprocess_batch(dataloader, s, e, dtype)
+                    with tracing.range("cnn_forward"):
+                        outs.append(self._forward_batch(model, infer_batch, batch))
         finally:
             if self._feed is not None:
                 self._feed.close()
@@ -662,7 +679,8 @@ class EngineABC:
             if gather_now:
                 if torch.device(self.device).type == "cuda":
                     local = local.to(self.device)
-                local = tdist.all_gather_rows(local, n)
+                with tracing.range("all_gather_rows"):
+                    local = tdist.all_gather_rows(local, n)
             gathered.append(local)
         local = tuple(gathered) if multi_head else gathered[0]
         raw_predictions = {"probabilities": local}
@@ -690,7 +708,8 @@ class EngineABC:
         self.dataloader = self.get_dataloader(images=self.images, labels=self.labels, ioconfig=self._ioconfig)
         raw = self.infer_patches(dataloader=self.dataloader,
                                  return_coordinates=output_type.lower() in ["annotationstore", "qupath"])
-        processed = self.post_process_patches(raw_predictions=raw, **kwargs)
+        with tracing.range("post_process_patches"):
+            processed = self.post_process_patches(raw_predictions=raw, **kwargs)
         return self.save_predictions(processed_predictions=processed, output_type=output_type, **kwargs)
 
     # ------------------------------------------------------------------------------ WSI mode

@@ -19,6 +19,8 @@ import warnings
 import numpy as np
 import torch
 
+from tiatoolbox_amd.utils import tracing
+
 from tiatoolbox_amd.models.engine.engine_abc import EngineABC
 from tiatoolbox_amd.tools.patchextraction import PatchExtractor
 from tiatoolbox_amd.wsicore import ArrayWSIReader
@@ -233,7 +235,8 @@ class MultiTaskSegmentor(EngineABC):
         for s in range(0, n, chunk):
             part = [h[s:s + chunk] for h in heads]
             if on_gpu and hasattr(model, "postproc_batch"):
-                results += model.postproc_batch(part[0], part[1], part[2] if len(part) > 2 else None)  # noqa: PLR2004
+                with tracing.range("hover_postproc_batch"):
+                    results += model.postproc_batch(part[0], part[1], part[2] if len(part) > 2 else None)  # noqa: PLR2004
             else:
                 postproc = self._get_model_attr("postproc_func")
                 for i in range(part[0].shape[0]):
@@ -347,12 +350,13 @@ class MultiTaskSegmentor(EngineABC):
         band = None  # CanvasBand: the heads' maps resident on the device, or streamed to page-locked host memory (slides > HBM)
 
         def open_band(channels: list[int]):
-            from tiatoolbox_amd.models.engine.semantic_segmentor import CanvasBand, _band_device_rows
+            from tiatoolbox_amd.models.engine.semantic_segmentor import CanvasBand, _band_device_rows, exchange_footprint
 
             # "pred" = the arg-max plane the finalize kernel always writes (not used by this engine); in streamed mode it exists per
             # chunk only
             maps = {f"h{j}": ((c,), torch.float32) for j, c in enumerate(channels)}
-            k = _band_device_rows(self, CanvasBand.bytes_needed(band_h, rw, maps), dev)
+            k = _band_device_rows(self, CanvasBand.bytes_needed(band_h, rw, maps), dev, world=world,
+                                  exchange_bytes=exchange_footprint(plan, rh, rw, maps))
             cb = CanvasBand(band_h, rw, y_lo, oh, dev, maps, device_rows=k)
             rows_ = oh if cb.streamed else band_h
             cb.scratch_pred = [torch.zeros((rows_, rw), dtype=torch.uint8, device=dev) for _ in range(cb.k if cb.streamed else 1)]

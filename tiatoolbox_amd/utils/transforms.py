@@ -20,16 +20,16 @@ def rgb2od(img, *, mutate: bool = True):
 
     Side effect as in the reference: ``img[img == 0] = 1`` on a writable uint8 NumPy array (applied on the HOST -- the bytes
     travel to the device once and nothing comes back but the result) and on a uint8 tensor (on the device, by the kernel).
-    The kernel reads bytes: an input of another dtype is a ``TypeError`` (the reference would take the logarithm of float values
-    as they are; cast to uint8 explicitly, as every call on the hot path does).
+    The kernel reads bytes.  Any other dtype (Python lists and integer arrays, float RGB) keeps the reference's behaviour --
+    ``img[img == 0] = 1`` in place, then ``max(-log(img / 255), 1e-6)`` in the array's own floating type (float64 for integers) --
+    evaluated with torch on the device: an API corner, not the hot path (every call there passes uint8).
     """
     from tiatoolbox_amd.tools import _stain_device as dev
 
     is_tensor = isinstance(img, torch.Tensor)
     dtype_ok = (img.dtype == torch.uint8) if is_tensor else (np.asarray(img).dtype == np.uint8)
     if not dtype_ok:
-        msg = f"rgb2od takes uint8 images on the device path, got {img.dtype if hasattr(img, 'dtype') else type(img).__name__}."
-        raise TypeError(msg)
+        return _rgb2od_any_dtype(img, mutate=mutate)
     kernel_mutates = False
     if is_tensor:
         src = img if img.is_cuda else img.to(_tensors.default_device())
@@ -54,6 +54,30 @@ def rgb2od(img, *, mutate: bool = True):
         _lib.check(rc, "tia_rgb2od_u8")
     if kernel_mutates and not same_storage:
         img.copy_(dev_img)          # host tensor / non-contiguous view: hand the edit back
+    return out if is_tensor else out.cpu().numpy()
+
+
+def _rgb2od_any_dtype(img, *, mutate: bool):
+    """Reference ``utils/transforms.py:229-231`` for non-uint8 input (see :func:`rgb2od`)."""
+    is_tensor = isinstance(img, torch.Tensor)
+    if is_tensor:
+        if mutate:
+            img[img == 0] = 1
+        t = img if img.is_cuda else img.to(_tensors.default_device())
+    else:
+        arr = img if isinstance(img, np.ndarray) else np.asarray(img)
+        if arr.dtype == bool or arr.dtype.kind not in "iuf":
+            msg = f"rgb2od takes numeric images, got {arr.dtype}."
+            raise TypeError(msg)
+        if mutate and isinstance(img, np.ndarray) and img.flags.writeable:
+            img[img == 0] = 1
+        else:
+            arr = np.where(arr == 0, 1, arr)
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(_tensors.default_device())
+    work = t if t.is_floating_point() else t.to(torch.float64)
+    if is_tensor and not mutate:
+        work = torch.where(work == 0, torch.ones_like(work), work)
+    out = torch.clamp_min(-torch.log(work / 255), 1e-6)
     return out if is_tensor else out.cpu().numpy()
 
 
