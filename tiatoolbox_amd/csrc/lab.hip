@@ -105,8 +105,12 @@ __device__ __forceinline__ void build_img_tables(LabImgLds& s, const tia_lab_tab
 // (twelve look-ups in flight, then the arithmetic): left to itself the scheduler waits for each pixel's look-ups before it
 // issues the next pixel's, and the kernel is bound by LDS round trips instead of LDS throughput.
 #define TIA_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
-__device__ __forceinline__ void lab_fwd4(const LabFwdLds& s, const LabCoef& k, const uint32_t (&p)[4], uint32_t (&o)[4]) {
-    const float* gam = s.gamma + (kGammaRep > 1 ? (threadIdx.x & (kGammaRep - 1)) : 0);
+// CR interleaved copies of the cube-root table (entry i of copy c at i * CR + c; `cbrt` already points at the lane's copy): its
+// indices scatter over ~50 consecutive entries within a wave (1 % pixel noise on 11-bit values), i.e. over the 32 banks like random
+// numbers -- 2.5 expected conflict cycles per 32-lane group with one table, 0.5 with 16 copies (each bank pair serves two lanes).
+template <int CR>
+__device__ __forceinline__ void lab_fwd4t(const float* gamma, const float* cbrt, const LabCoef& k, const uint32_t (&p)[4], uint32_t (&o)[4]) {
+    const float* gam = gamma + (kGammaRep > 1 ? (threadIdx.x & (kGammaRep - 1)) : 0);
     float R[4], G[4], B[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -132,9 +136,9 @@ __device__ __forceinline__ void lab_fwd4(const LabFwdLds& s, const LabCoef& k, c
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        fx[i] = s.cbrt[ix[0][i]];
-        fy[i] = s.cbrt[ix[1][i]];
-        fz[i] = s.cbrt[ix[2][i]];
+        fx[i] = cbrt[ix[0][i] * CR];
+        fy[i] = cbrt[ix[1][i] * CR];
+        fz[i] = cbrt[ix[2][i] * CR];
     }
     TIA_STAGE_FENCE();
     // L = descale(296 fy - 1336934, 15), a = descale(500 (fx - fy) + 128 << 15, 15), b = descale(200 (fy - fz) + 128 << 15, 15),
@@ -152,6 +156,9 @@ __device__ __forceinline__ void lab_fwd4(const LabFwdLds& s, const LabCoef& k, c
         o[2 * h] = __builtin_amdgcn_cvt_pk_u8_f32(Bf.x, 2, __builtin_amdgcn_cvt_pk_u8_f32(Af.x, 1, __builtin_amdgcn_cvt_pk_u8_f32(Lf.x, 0, 0u)));
         o[2 * h + 1] = __builtin_amdgcn_cvt_pk_u8_f32(Bf.y, 2, __builtin_amdgcn_cvt_pk_u8_f32(Af.y, 1, __builtin_amdgcn_cvt_pk_u8_f32(Lf.y, 0, 0u)));
     }
+}
+__device__ __forceinline__ void lab_fwd4(const LabFwdLds& s, const LabCoef& k, const uint32_t (&p)[4], uint32_t (&o)[4]) {
+    lab_fwd4t<1>(s.gamma, s.cbrt, k, p, o);
 }
 __device__ __forceinline__ void lab_fwd2(const LabFwdLds& s, const LabCoef& k, uint32_t p0, uint32_t p1, uint32_t& o0, uint32_t& o1) {
     const uint32_t p[4] = {p0, p1, p0, p1};
@@ -536,17 +543,21 @@ __global__ __launch_bounds__(FT) void reinhard_fused_kernel(const uint8_t* __res
 // the scratch-slot kernel above moves 8 more bytes per pixel through L2 and was bound by that.  NG = ceil(pixels / 4096) is a
 // template parameter (register arrays need static indices: both passes are fully unrolled).
 constexpr int RT = 1024;
+constexpr int kResCbrtRep = 16;  // 128 KB of dynamic LDS: one workgroup per CU has the room
 template <int NG, bool STATS_ONLY>
 __global__ __launch_bounds__(RT) void reinhard_resident_kernel(const uint8_t* __restrict__ img, long n, long hw,
                                                                 const tia_lab_tables* __restrict__ tab,
                                                                 const float* __restrict__ chan_vals, const ReinhardTarget tgt,
                                                                 uint8_t* __restrict__ out, double* __restrict__ meanstd,
                                                                 int* __restrict__ flags) {
-    __shared__ FusedLds s;
-    load_fwd(s.fwd, tab);
+    __shared__ FusedLds s;  // (its single cube-root table stays unused here)
+    extern __shared__ float cbrt_rep[];  // [kCbrtN][kResCbrtRep]
+    for (int i = threadIdx.x; i < 256 * kGammaRep; i += RT) s.fwd.gamma[i] = (float)tab->gamma[i / kGammaRep];
+    for (int i = threadIdx.x; i < kCbrtN * kResCbrtRep; i += RT) cbrt_rep[i] = (float)tab->cbrt[i / kResCbrtRep];
     if (!STATS_ONLY) load_inv(s.inv, tab);
     const LabCoef k = load_coef(tab);
     const int tid = threadIdx.x, lane = tid & 63;
+    const float* cbrt_lane = cbrt_rep + (lane & (kResCbrtRep - 1));
     const long ngroups = hw >> 2;
     unsigned* hist_lane = s.u.hist + (lane & (kLCopies - 1));
     for (long patch = blockIdx.x; patch < n; patch += gridDim.x) {
@@ -565,7 +576,7 @@ __global__ __launch_bounds__(RT) void reinhard_resident_kernel(const uint8_t* __
             if (g < ngroups) {
                 uint32_t p[4];
                 group_pixels(cur.x, cur.y, cur.z, p);
-                lab_fwd4(s.fwd, k, p, lab[j]);
+                lab_fwd4t<kResCbrtRep>(s.fwd.gamma, cbrt_lane, k, p, lab[j]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) atomicAdd(&hist_lane[(lab[j][i] & 255u) * kLCopies], 1u);
                 ab_accumulate(ab, lab[j]);
@@ -804,16 +815,23 @@ static long resident_grid(long n) {
         cus = 256;
     return n < cus ? n : cus;  // 1024 threads x up to 128 registers: one workgroup per CU
 }
+constexpr size_t kResidentDynLds = (size_t)kCbrtN * kResCbrtRep * sizeof(float);
 template <bool STATS_ONLY>
-static void launch_resident(long hw, long n, hipStream_t st, const uint8_t* img, const tia_lab_tables* tab, const float* chan,
+static bool launch_resident(long hw, long n, hipStream_t st, const uint8_t* img, const tia_lab_tables* tab, const float* chan,
                             const ReinhardTarget& t, uint8_t* out, double* meanstd, int* flags) {
     const long need = ((hw >> 2) + RT - 1) / RT;
     const dim3 grid((unsigned)resident_grid(n)), block(RT);
 #define TIA_RESIDENT(NG)                                                                                                         \
     if (need <= NG) {                                                                                                            \
-        hipLaunchKernelGGL((reinhard_resident_kernel<NG, STATS_ONLY>), grid, block, 0, st, img, n, hw, tab, chan, t, out, meanstd, \
-                           flags);                                                                                               \
-        return;                                                                                                                  \
+        static DeviceOnce once;                                                                                                  \
+        if (!once.ensure([] {                                                                                                    \
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(reinhard_resident_kernel<NG, STATS_ONLY>),            \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResidentDynLds) == hipSuccess;      \
+            }))                                                                                                                  \
+            return false;                                                                                                        \
+        hipLaunchKernelGGL((reinhard_resident_kernel<NG, STATS_ONLY>), grid, block, kResidentDynLds, st, img, n, hw, tab, chan, t, \
+                           out, meanstd, flags);                                                                                 \
+        return true;                                                                                                             \
     }
     TIA_RESIDENT(1)
     TIA_RESIDENT(2)
@@ -824,6 +842,7 @@ static void launch_resident(long hw, long n, hipStream_t st, const uint8_t* img,
     TIA_RESIDENT(13)
     TIA_RESIDENT(16)
 #undef TIA_RESIDENT
+    return false;
 }
 
 extern "C" size_t tia_reinhard_workspace_bytes(int64_t n, int64_t h, int64_t w) {
@@ -848,7 +867,10 @@ extern "C" int tia_reinhard_transform_u8(const uint8_t* d_img, int64_t n, int64_
         t.stdv[c] = target_stds[c];
     }
     if (resident_ok(hw)) {
-        launch_resident<false>(hw, (long)n, (hipStream_t)stream, d_img, d_tables, d_chan_vals, t, d_out, d_meanstd, d_flags);
+        if (!launch_resident<false>(hw, (long)n, (hipStream_t)stream, d_img, d_tables, d_chan_vals, t, d_out, d_meanstd, d_flags)) {
+            (void)hipGetLastError();
+            return TIA_ELAUNCH;
+        }
         return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
     }
     const long grid = fused_grid(n);
@@ -866,9 +888,12 @@ extern "C" int tia_lab_moments_u8(const uint8_t* d_img, int64_t n, int64_t h, in
     if ((reinterpret_cast<uintptr_t>(d_img) & 3) != 0 || !(resident_ok(hw) || scratch_ok(hw)))
         return TIA_ESIZE;  // the caller takes tia_lab_hist_u8 + tia_reinhard_luts
     ReinhardTarget t = {{0.0, 0.0, 0.0}, {1.0, 1.0, 1.0}};
-    if (resident_ok(hw))
-        launch_resident<true>(hw, (long)n, (hipStream_t)stream, d_img, d_tables, d_chan_vals, t, nullptr, d_meanstd, d_flags);
-    else
+    if (resident_ok(hw)) {
+        if (!launch_resident<true>(hw, (long)n, (hipStream_t)stream, d_img, d_tables, d_chan_vals, t, nullptr, d_meanstd, d_flags)) {
+            (void)hipGetLastError();
+            return TIA_ELAUNCH;
+        }
+    } else
         hipLaunchKernelGGL(reinhard_fused_kernel<true>, dim3((unsigned)fused_grid(n)), dim3(FT), 0, (hipStream_t)stream, d_img,
                            (long)n, hw, d_tables, d_chan_vals, t, (uint32_t*)nullptr, (uint8_t*)nullptr, d_meanstd, d_flags);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
