@@ -35,8 +35,8 @@ extern "C" {
 /* Version 4 (round 4): + tia_rgb2od_u8 (the stand-alone OD transform, with the reference's in-place side effect on request),
  * tia_clear_last_error; TIA_MATH_F64 of tia_stain_apply_u8 evaluates exp() with the library's own float64 kernel
  * (TIA_MATH_F64_REF keeps the device libm's exp); tia_conv3x3_geometry, tia_stain_stats_path (dispatch diagnostics). */
-/* Version 6 (round 6): + tia_gray_hist_u8 / tia_otsu_threshold_u32 / tia_threshold_lt_dev_u8 (one-pass Otsu fit whose threshold
- * stays on the device), tia_morph_mask_u8 (the morphological masker in one launch), tia_reinhard_transform_u8 /
+/* Version 6 (round 6): + tia_gray_hist_u8 / tia_otsu_threshold_u32 / tia_otsu_fit_u8 / tia_threshold_lt_dev_u8 (one-pass, one-launch
+ * Otsu fit whose threshold stays on the device), tia_morph_mask_u8 (the morphological masker in one launch), tia_reinhard_transform_u8 /
  * tia_reinhard_workspace_bytes / tia_lab_moments_u8 (one-launch Reinhard); tia_luminosity_mask_u8 and the float64 form of
  * tia_stain_augment_u8 (now a product of per-patch tables) take 16-byte accesses where the shape allows. */
 #define TIA_ABI_VERSION 6
@@ -231,6 +231,11 @@ int tia_gray_hist_u8(const uint8_t* d_img, int64_t npix, int32_t channels, uint3
  * (bin centre of the first maximum of the between-class variance over the occupied range; the only occupied bin when there is one),
  * d_out[1] = number of occupied bins.  Bit-identical to the float64 NumPy arithmetic (all partial sums are exact integers). */
 int tia_otsu_threshold_u32(const uint32_t* d_hist, int32_t* d_out, void* stream);
+
+/* OtsuTissueMasker.fit in ONE launch: tia_gray_hist_u8 whose last-finishing workgroup runs tia_otsu_threshold_u32's arithmetic on
+ * the completed counts.  d_hist: 257 uint32 -- the 256 bins and a ticket counter -- zeroed by the caller before the first image
+ * (the kernel leaves the counter at zero, so a later call that adds another image to the same counts recomputes d_out). */
+int tia_otsu_fit_u8(const uint8_t* d_img, int64_t npix, int32_t channels, uint32_t* d_hist, int32_t* d_out, void* stream);
 
 /* tia_threshold_lt_u8 with the threshold read from device memory (d_thr[0], e.g. tia_otsu_threshold_u32's output): fit and
  * transform enqueue back to back without a host round trip (tools/tissuemask.py:139-164). */

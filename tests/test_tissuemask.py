@@ -238,3 +238,24 @@ def test_one_launch_morphological_masker_matches_oracle(kw, shape):
     g3 = np.stack([omask._grey(i) for i in rgb])           # noqa: SLF001
     one.fit(torch.from_numpy(rgb).cuda())
     assert np.array_equal(one.transform(torch.from_numpy(g3[..., None]).cuda()).cpu().numpy(), exp)
+
+
+@pytest.mark.gpu
+def test_one_launch_otsu_fit_is_race_free():
+    """The fit kernel's LAST workgroup computes the threshold from counts the other workgroups delivered as device-scope atomics
+    (ordering by acknowledgement, no release fence).  150 fits over images of changing size / content: the threshold and the occupied
+    bin count always equal those of the two-launch form (histogram, then the threshold kernel) on the same pixels."""
+    import torch
+
+    from tiatoolbox_amd.tools import _img_device as img
+
+    rng = np.random.default_rng(11)
+    for it in range(150):
+        n, h, w = int(rng.integers(1, 5)), int(rng.integers(40, 900)), int(rng.integers(40, 900))
+        lo, hi = sorted(int(v) for v in rng.integers(0, 256, 2))
+        x = torch.from_numpy(rng.integers(lo, hi + 1, (n, h, w, 3), dtype=np.uint8)).cuda()
+        if it % 7 == 0:
+            x[0, : h // 2] = 255
+        got = img.otsu_fit(x, channels=3)
+        exp = img.otsu_threshold(img.gray_hist(x, channels=3))
+        assert torch.equal(got, exp), (it, n, h, w, got.tolist(), exp.tolist())

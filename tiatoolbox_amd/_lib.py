@@ -74,6 +74,7 @@ _SIGNATURES = {
     "tia_threshold_lt_u8": ([_P, _I64, _I32, _I32, _P, _P], C.c_int),
     "tia_gray_hist_u8": ([_P, _I64, _I32, _P, _P], C.c_int),
     "tia_otsu_threshold_u32": ([_P, _P, _P], C.c_int),
+    "tia_otsu_fit_u8": ([_P, _I64, _I32, _P, _P, _P], C.c_int),
     "tia_threshold_lt_dev_u8": ([_P, _I64, _I32, _P, _P, _P], C.c_int),
     "tia_morph_mask_u8": ([_P, _I64, _I64, _I64, _I32, _I32, _P, _I32, _P, _I32, _I32, _P, _P], C.c_int),
     "tia_lut_apply_u8": ([_P, _I64, _I64, _P, _P, _P], C.c_int),

@@ -116,8 +116,14 @@ __device__ __forceinline__ void sub_hist_add(unsigned* sub, uint32_t bin) {
     atomicAdd(&sub[(bin >> 1) * 16], 1u << ((bin & 1u) * 16u));
 }
 
+__device__ __forceinline__ void otsu_from_counts(unsigned long long c, int* __restrict__ out);  // (below)
+
+// `fit_out` (nullable): the workgroup that finishes LAST (a ticket counter in hist[256]) also runs Otsu's arithmetic on the complete
+// counts -- OtsuTissueMasker.fit is one launch; the counter is reset, so that a later call that adds another image to the same
+// counts recomputes the threshold.
 template <int CH>  // 3: RGB pixels, grey conversion fused; 1: a grey plane
-__global__ __launch_bounds__(BT) void gray_hist_kernel(const uint8_t* __restrict__ img, long npix, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(BT) void gray_hist_kernel(const uint8_t* __restrict__ img, long npix, uint32_t* __restrict__ hist,
+                                                       int* __restrict__ fit_out) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[BT / 64][kRgbChunk];
     __shared__ unsigned sub[BT / 64][128 * 16];
     for (int i = threadIdx.x; i < (BT / 64) * 128 * 16; i += BT) (&sub[0][0])[i] = 0;
@@ -178,6 +184,19 @@ __global__ __launch_bounds__(BT) void gray_hist_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int s = 0; s < 16; ++s) t += (sub[wq][(b >> 1) * 16 + s] >> ((b & 1) * 16)) & 0xffffu;
     if (t) atomicAdd(&hist[b], t);
+    if (fit_out == nullptr) return;
+    __shared__ unsigned ticket;
+    // The counts travel as device-scope atomics (performed at the memory side, coherent across the XCDs' L2s): waiting for their
+    // acknowledgements (vmcnt) orders them before the ticket -- no release fence, which on gfx950 writes the whole L2 back (measured:
+    // the fit twice as slow with a __threadfence() per workgroup).
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(&hist[256], 1u);
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    const unsigned long long c = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (L2, not this CU's L1)
+    if (threadIdx.x == 0) hist[256] = 0u;
+    otsu_from_counts(c, fit_out);
 }
 
 // skimage.filters.threshold_otsu on a 256-bin byte histogram, on the device (tools/tissuemask.py:131-134; the arithmetic of
@@ -187,12 +206,13 @@ __global__ __launch_bounds__(BT) void gray_hist_kernel(const uint8_t* __restrict
 // their products with the integer bin centres are integers far below 2^53, so every partial sum is exact in float64 whatever the
 // order: integer prefix sums here equal NumPy's sequential float64 cumsum bit for bit; the divisions and products are the same
 // IEEE operations in the same order.  out[0] = threshold (the only occupied bin when there is just one), out[1] = occupied bins.
-__global__ __launch_bounds__(256) void otsu_threshold_kernel(const uint32_t* __restrict__ hist, int* __restrict__ out) {
+// (device function: runs in one 256-thread workgroup -- the stand-alone kernel below, or the last workgroup of the fit kernel)
+__device__ __forceinline__ void otsu_from_counts(unsigned long long c, int* __restrict__ out) {
     __shared__ unsigned long long w1[256], s1[256];
-    __shared__ double var[256];
+    __shared__ unsigned long long wkey[4];
+    __shared__ int widx[4];
     __shared__ int lohi[2], nz;
-    const int i = threadIdx.x;
-    const unsigned long long c = hist[i];
+    const int i = threadIdx.x, lane = i & 63, wv = i >> 6;
     if (i == 0) {
         lohi[0] = 256;
         lohi[1] = -1;
@@ -214,29 +234,48 @@ __global__ __launch_bounds__(256) void otsu_threshold_kernel(const uint32_t* __r
         s1[i] += b;
         __syncthreads();
     }
-    const int lo = lohi[0], hi = lohi[1];
-    double v = -1.0;  // variance12 >= 0 inside the range
-    if (nz > 1 && i >= lo && i < hi) {
+    const int lo = lohi[0], hi = lohi[1], nzc = nz;
+    // first maximum of variance12 over [lo, hi): order-preserving key of the (non-negative) float64, ties to the smaller index
+    unsigned long long key = 0ull;  // below every key of a value >= 0 (f64_key(0.0) = 0x8000...)
+    int idx = i;
+    if (nzc > 1 && i >= lo && i < hi) {
         const double wt1 = (double)w1[i], wt2 = (double)(w1[255] - w1[i]);
         const double m1 = (double)s1[i] / wt1, m2 = (double)(s1[255] - s1[i]) / wt2;
         const double d = m1 - m2;
-        v = wt1 * wt2 * (d * d);
+        key = f64_key(wt1 * wt2 * (d * d));
     }
-    var[i] = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long k2 = __shfl_down(key, o, 64);
+        const int i2 = __shfl_down(idx, o, 64);
+        if (k2 > key || (k2 == key && i2 < idx)) {
+            key = k2;
+            idx = i2;
+        }
+    }
+    if (lane == 0) {
+        wkey[wv] = key;
+        widx[wv] = idx;
+    }
     __syncthreads();
     if (i == 0) {
         int best = lo;
-        if (nz > 1) {
-            double bv = var[lo];
-            for (int k = lo + 1; k < hi; ++k)
-                if (var[k] > bv) {  // first maximum
-                    bv = var[k];
-                    best = k;
+        if (nzc > 1) {
+            unsigned long long bk = wkey[0];
+            best = widx[0];
+            for (int q = 1; q < 4; ++q)
+                if (wkey[q] > bk) {  // waves hold ascending index ranges: strict > keeps the first maximum
+                    bk = wkey[q];
+                    best = widx[q];
                 }
         }
-        out[0] = nz == 0 ? 0 : best;
-        out[1] = nz;
+        out[0] = nzc == 0 ? 0 : best;
+        out[1] = nzc;
     }
+}
+
+__global__ __launch_bounds__(256) void otsu_threshold_kernel(const uint32_t* __restrict__ hist, int* __restrict__ out) {
+    otsu_from_counts((unsigned long long)hist[threadIdx.x], out);
 }
 
 // mask = grey < thr, 16-byte accesses: 48 bytes of RGB in, 16 mask bytes out per lane and step (a lane's 16 pixels are contiguous
@@ -1300,22 +1339,36 @@ extern "C" int tia_morph_mask_u8(const uint8_t* d_img, int64_t n, int64_t h, int
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
 
-extern "C" int tia_gray_hist_u8(const uint8_t* d_img, int64_t npix, int32_t channels, uint32_t* d_hist, void* stream) {
-    if (!d_img || !d_hist || npix <= 0 || (channels != 1 && channels != 3)) return TIA_EINVAL;
-    // a wave may run kGrayHistMaxSteps steps of 1024 pixels (16-bit sub-histogram counters); otherwise ~8 steps per wave, at most
-    // three resident workgroups per CU
-    const long steps = (npix + kPxChunk - 1) / kPxChunk;
+// a wave may run kGrayHistMaxSteps steps of 1024 pixels (16-bit sub-histogram counters); otherwise ~8 steps per wave, at most three
+// resident workgroups per CU
+static long gray_hist_blocks(int64_t npix) {
+    const long steps = (npix + tia::kPxChunk - 1) / tia::kPxChunk;
     long nb = (steps + 31) / 32;
     nb = nb > 768 ? 768 : nb;
-    const long need = (steps + 4L * kGrayHistMaxSteps - 1) / (4L * kGrayHistMaxSteps);
+    const long need = (steps + 4L * tia::kGrayHistMaxSteps - 1) / (4L * tia::kGrayHistMaxSteps);
     nb = nb < need ? need : nb;
-    nb = nb < 1 ? 1 : nb;
-    if (nb > 2147483647L) return TIA_ESIZE;
+    return nb < 1 ? 1 : nb;
+}
+static int launch_gray_hist(const uint8_t* d_img, int64_t npix, int32_t channels, uint32_t* d_hist, int32_t* d_fit, long nb, void* stream) {
     if (channels == 3)
-        hipLaunchKernelGGL(gray_hist_kernel<3>, dim3((unsigned)nb), dim3(BT), 0, (hipStream_t)stream, d_img, (long)npix, d_hist);
+        hipLaunchKernelGGL(tia::gray_hist_kernel<3>, dim3((unsigned)nb), dim3(tia::BT), 0, (hipStream_t)stream, d_img, (long)npix, d_hist, d_fit);
     else
-        hipLaunchKernelGGL(gray_hist_kernel<1>, dim3((unsigned)nb), dim3(BT), 0, (hipStream_t)stream, d_img, (long)npix, d_hist);
+        hipLaunchKernelGGL(tia::gray_hist_kernel<1>, dim3((unsigned)nb), dim3(tia::BT), 0, (hipStream_t)stream, d_img, (long)npix, d_hist, d_fit);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
+}
+
+extern "C" int tia_gray_hist_u8(const uint8_t* d_img, int64_t npix, int32_t channels, uint32_t* d_hist, void* stream) {
+    if (!d_img || !d_hist || npix <= 0 || (channels != 1 && channels != 3)) return TIA_EINVAL;
+    const long nb = gray_hist_blocks(npix);
+    if (nb > 2147483647L) return TIA_ESIZE;
+    return launch_gray_hist(d_img, npix, channels, d_hist, nullptr, nb, stream);
+}
+
+extern "C" int tia_otsu_fit_u8(const uint8_t* d_img, int64_t npix, int32_t channels, uint32_t* d_hist, int32_t* d_out, void* stream) {
+    if (!d_img || !d_hist || !d_out || npix <= 0 || (channels != 1 && channels != 3)) return TIA_EINVAL;
+    const long nb = gray_hist_blocks(npix);
+    if (nb > 2147483647L) return TIA_ESIZE;
+    return launch_gray_hist(d_img, npix, channels, d_hist, d_out, nb, stream);
 }
 
 extern "C" int tia_otsu_threshold_u32(const uint32_t* d_hist, int32_t* d_out, void* stream) {

@@ -47,6 +47,17 @@ def gray_hist(img: torch.Tensor, *, channels: int, hist: torch.Tensor | None = N
     return hist
 
 
+def otsu_fit(img: torch.Tensor, *, channels: int) -> torch.Tensor:
+    """``OtsuTissueMasker.fit`` of uint8 pixels in one launch (grey + histogram; the last workgroup runs Otsu's arithmetic): int32[2] =
+    (threshold, occupied bins) on the device.  One small buffer carries counts, ticket and result: one fill, one launch."""
+    _lib.require_cuda(img)
+    img = img.contiguous()
+    buf = torch.zeros(260, dtype=torch.int32, device=img.device)  # [0:256] counts, [256] ticket, [258:260] result
+    with torch.cuda.device(img.device):
+        _call("tia_otsu_fit_u8", img.data_ptr(), img.numel() // channels, channels, buf.data_ptr(), buf[258:].data_ptr())
+    return buf[258:260]
+
+
 def otsu_threshold(hist: torch.Tensor) -> torch.Tensor:
     """``skimage.filters.threshold_otsu`` of byte counts on the device: int32[2] = (threshold, occupied bins)."""
     _lib.require_cuda(hist)
@@ -72,7 +83,7 @@ def threshold_lt(src: torch.Tensor, thr: int | torch.Tensor, *, is_rgb: bool, dt
 
 
 def morph_mask(images: torch.Tensor, thr: int | torch.Tensor, min_region: int, offsets: torch.Tensor, *,
-               channels: int) -> torch.Tensor | None:
+               channels: int, reach: int | None = None) -> torch.Tensor | None:
     """``MorphologicalMasker.transform`` in one launch: ``dilate(remove_small_objects(grey < thr, min_region, 8), element)`` of a
     uint8 ``[n,h,w,3]`` (RGB) or ``[n,h,w]`` (grey) batch as a bool ``[n,h,w]`` tensor, or ``None`` when the element's reach +
     ``min_region`` - 1 exceeds the 40-pixel halo of the tile kernel (the caller takes the multi-launch form)."""
@@ -82,7 +93,8 @@ def morph_mask(images: torch.Tensor, thr: int | torch.Tensor, min_region: int, o
     if n > _MAX_PLANES:
         return None
     out = torch.empty((n, h, w), dtype=torch.bool, device=images.device)
-    reach = int(offsets.abs().max().item()) if offsets.numel() else 0
+    if reach is None:
+        reach = int(offsets.abs().max().item()) if offsets.numel() else 0
     dev_thr = isinstance(thr, torch.Tensor)
     with torch.cuda.device(images.device):
         rc = _lib.load().tia_morph_mask_u8(images.data_ptr(), n, h, w, channels, 0 if dev_thr else int(thr),

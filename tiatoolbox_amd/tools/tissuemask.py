@@ -95,9 +95,8 @@ class OtsuTissueMasker(TissueMasker):
         if t.dtype == torch.uint8:
             # one pass over the pixels (grey + histogram fused), Otsu's arithmetic on the 256 counts on the device
             rgb = t.shape[-1] == 3  # noqa: PLR2004
-            counts = img.gray_hist(t if rgb else t[..., 0].contiguous(), channels=3 if rgb else 1)
             self._threshold = None
-            self._threshold_dev = img.otsu_threshold(counts)
+            self._threshold_dev = img.otsu_fit(t if rgb else t[..., 0].contiguous(), channels=3 if rgb else 1)
         else:
             grey = t[..., 0].to(torch.float64)
             lo, hi = float(grey.min()), float(grey.max())
@@ -176,7 +175,7 @@ class MorphologicalMasker(OtsuTissueMasker):
             else:
                 thr = int(np.ceil(self.threshold)) if float(self.threshold) != int(self.threshold) else int(self.threshold)
             out = img.morph_mask(t if rgb else t[..., 0].contiguous(), thr, int(self.min_region_size), self._offsets(t.device),
-                                 channels=3 if rgb else 1)
+                                 channels=3 if rgb else 1, reach=self._reach())
         if out is None:
             mask = self._masks(t)
             labels, _ = img.ccl_label(mask, connectivity=8)
@@ -184,6 +183,12 @@ class MorphologicalMasker(OtsuTissueMasker):
             keep = (labels > 0).to(torch.uint8)
             out = img.binary_morph(keep, self._offsets(keep.device), "dilate").bool()
         return out.cpu().numpy() if as_numpy else out
+
+    def _reach(self) -> int:
+        """Largest |dy|, |dx| of the element around its anchor (host arithmetic: no device round trip per call)."""
+        kh, kw = self.kernel.shape
+        ys, xs = np.nonzero(self.kernel)
+        return int(max(np.abs(ys - kh // 2).max(initial=0), np.abs(xs - kw // 2).max(initial=0)))
 
     def _offsets(self, device: torch.device) -> torch.Tensor:
         """(dy, dx) offsets of the element on ``device`` (cached: a few dozen int32)."""
