@@ -52,6 +52,61 @@ def _stats(batch_np, torch_mod, **kw):
     return dev.stain_stats(t, params).cpu().numpy(), params
 
 
+def _large_image(h, w, seed):
+    """H&E-like image of any size: G-he blocks of 250 x 250 tiled, a white margin on two sides, a black corner (zeros: rgb2od's
+    0 -> 1 rule), cropped to (h, w)."""
+    bh, bw = -(-h // 250), -(-w // 250)
+    blocks = synth.g_he(bh * bw, 250, 250, seed=seed).reshape(bh, bw, 250, 250, 3)
+    img = blocks.transpose(0, 2, 1, 3, 4).reshape(bh * 250, bw * 250, 3)[:h, :w].copy()
+    img[: h // 16] = 250
+    img[:, : w // 20] = 252
+    img[-8:, -8:] = 0
+    return img
+
+
+@pytest.mark.parametrize("shape", [(1000, 1000), (3000, 2500), (777, 1203)])
+def test_large_single_images_take_the_multi_workgroup_path(torch_mod, shape):
+    """One image above 4 x 256 x 256 pixels: every sweep of the statistics runs over many workgroups (stain_stats_big.hip) instead of
+    one per image.  Against the oracle on the whole image (1e-9 like the per-patch kernels), against the streaming kernel's record
+    (select_mode 2 keeps it: agreement to rounding of the moment sums), and for a batch of two such images at once; fixed
+    matrices (Ruifrok) and the zero -> one rule take the same path."""
+    from tiatoolbox_amd import _lib
+    from tiatoolbox_amd.tools import _stain_device as dev
+
+    h, w = shape
+    imgs = np.stack([_large_image(h, w, seed=h + k) for k in range(2)])
+    stats, _ = _stats(imgs, torch_mod)
+    ref, _ = _stats(imgs, torch_mod, select_mode=2)
+    for i, img in enumerate(imgs):
+        s, r = stats[i], ref[i]
+        assert int(s[_lib.ST_FLAGS]) == 0 and s[_lib.ST_NTISSUE] == r[_lib.ST_NTISSUE]
+        assert s[_lib.ST_PLOW] == r[_lib.ST_PLOW] and s[_lib.ST_PHIGH] == r[_lib.ST_PHIGH]
+        for lo, n in ((_lib.ST_STAIN, 6), (_lib.ST_MAXC, 2), (_lib.ST_MINPHI, 2), (_lib.ST_COV, 6), (_lib.ST_EVEC, 6), (_lib.ST_PINV, 6)):
+            np.testing.assert_allclose(s[lo:lo + n], r[lo:lo + n], rtol=1e-9, atol=1e-10)  # (moment sums of millions of pixels in another order)
+    img = imgs[0]
+    dbg: dict = {}
+    sm = ostain.MacenkoExtractor().get_stain_matrix(img.copy(), debug=dbg)
+    s = stats[0]
+    assert int(s[_lib.ST_NTISSUE]) == dbg["n_tissue"]
+    pl, ph = np.percentile(img, (2, 98))
+    assert s[_lib.ST_PLOW] == pl and s[_lib.ST_PHIGH] == ph
+    np.testing.assert_allclose(s[_lib.ST_MINPHI], dbg["min_phi"], atol=STAT_TOL)
+    np.testing.assert_allclose(s[_lib.ST_MAXPHI], dbg["max_phi"], atol=STAT_TOL)
+    np.testing.assert_allclose(s[_lib.ST_STAIN:_lib.ST_STAIN + 6].reshape(2, 3), sm, atol=STAT_TOL)
+    conc = ostain.StainNormalizer.get_concentrations(img.copy(), sm)
+    np.testing.assert_allclose(s[_lib.ST_MAXC:_lib.ST_MAXC + 2], np.percentile(conc, 99, axis=0), atol=STAT_TOL)
+    # fixed stain matrix (Ruifrok) with a target: PINV, MAXC and the fused matrix
+    t = torch_mod.from_numpy(imgs[:1]).cuda()
+    ruifrok = np.array([[0.65, 0.70, 0.29], [0.07, 0.99, 0.11]])
+    ruifrok /= np.linalg.norm(ruifrok, axis=1, keepdims=True)
+    kw = {"mode": _lib.MODE_FIXED, "stain_fixed": ruifrok, "target_stain": ruifrok, "target_maxc": np.array([[1.5, 0.9]]), "zero_to_one": True}
+    big = dev.stain_stats(t, dev.make_params(**kw)).cpu().numpy()[0]
+    small = dev.stain_stats(t, dev.make_params(select_mode=2, **kw)).cpu().numpy()[0]
+    np.testing.assert_allclose(big[:48], small[:48], rtol=1e-12, atol=1e-13)
+    conc = ostain.StainNormalizer.get_concentrations(img.copy(), ruifrok)
+    np.testing.assert_allclose(big[_lib.ST_MAXC:_lib.ST_MAXC + 2], np.percentile(conc, 99, axis=0), atol=STAT_TOL)
+
+
 @pytest.mark.parametrize("shape", [(64, 64), (96, 96), (37, 41), (256, 256), (224, 224)])
 def test_macenko_stats_match_oracle(torch_mod, shape):
     from tiatoolbox_amd import _lib

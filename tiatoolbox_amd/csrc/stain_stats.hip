@@ -69,6 +69,13 @@ extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, in
             return rc;
         return tia::launch_stain_stats_stream(true, d_img, n, hw, d_tables, *params, d_stats, binws, dictws, redo, st);
     }
+    // LARGE images (above 4 x 256 x 256 pixels; Macenko / fixed / given matrices, default selection): every sweep over many
+    // workgroups per image, decisions between sweeps in one-workgroup kernels (stain_stats_big.hip) -- the per-patch kernels below
+    // give an image ONE workgroup.  The state lives at the front of the workspace (the bin cache is not used on this path).
+    static const bool no_big = tia::dev_env("TIA_STATS_NO_BIG") != nullptr;  // developer switch: audit against the streaming kernel
+    if (!no_big && hw > tia::kBigImagePixels && params->select_mode == 0 && aligned && ws_bytes >= tia::stain_stats_big_workspace_bytes(n) &&
+        n <= 65535)
+        return tia::launch_stain_stats_big(d_img, n, hw, d_tables, *params, d_stats, d_ws, st);
     // Patches of up to 13 x 4096 pixels (224 x 224 and smaller) in whole 4-pixel groups go through the register-resident kernel
     // (the patch is read from HBM once); whatever it hands back -- and every other case -- through the streaming kernel.  Both
     // give the same bits.  Measured on MI355X (profiles/r03d_perf_stain*.txt): both kernels are bound by the vector ALU (about 150

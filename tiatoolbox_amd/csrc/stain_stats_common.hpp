@@ -1122,5 +1122,10 @@ int launch_vahadane_dl(const uint8_t* d_img, long n, long hw, const tia_stain_ta
 int launch_stain_stats_reg(const uint8_t* d_img, long n, long hw, const tia_stain_tables* d_tables, const tia_stain_params& prm,
                            double* d_stats, int* redo, uint32_t* ws, hipStream_t st);
 long stain_stats_reg_pixel_limit();  // largest patch (pixels) the register-resident kernel holds
+// large single images: multi-workgroup sweeps (stain_stats_big.hip); d_ws holds n state blocks
+constexpr long kBigImagePixels = 4L * 256 * 256;
+size_t stain_stats_big_workspace_bytes(long n);
+int launch_stain_stats_big(const uint8_t* d_img, long n, long hw, const tia_stain_tables* d_tables, const tia_stain_params& prm,
+                           double* d_stats, void* d_ws, hipStream_t st);
 
 }  // namespace tia
