@@ -28,3 +28,4 @@ for side in (1024, 2048, 4096, 8192):
     t_otsu = bc._ev_time(lambda: om.fit(one), 5, 2)
     print(f"{side}^2: macenko stats one image {t_one*1e3:.3f} ms | {k*k} patches of 256^2 {t_batch*1e3:.3f} ms | ratio {t_one/t_batch:.2f} | apply {t_apply*1e3:.3f} ms | "
           f"reinhard.transform {t_rh*1e3:.3f} ms | otsu.fit {t_otsu*1e3:.3f} ms", flush=True)
+    print("   diag (fallback, list sizes) angles:", st[0, 48:53].cpu().tolist(), "conc:", st[0, 53:58].cpu().tolist(), flush=True)

@@ -15,6 +15,11 @@ extern "C" size_t tia_stain_stats_workspace_bytes_mode(int64_t n, int64_t h, int
     if (n <= 0 || h <= 0 || w <= 0) return 0;
     // [bin cache][dictionary (Vahadane only)][per-patch redo flags of the register-resident kernel]
     size_t total = align256s(tia_stain_stats_workspace_bytes(n, h, w));
+    const long hw = (long)h * (long)w;
+    if (mode != TIA_MODE_VAHADANE && hw > tia::kBigImagePixels) {  // large images: state, candidate lists and bin codes of the
+        const size_t big = align256s(tia::stain_stats_big_workspace_bytes(n, hw));  // multi-workgroup path (stain_stats_big.hip)
+        total = total > big ? total : big;
+    }
     if (mode == TIA_MODE_VAHADANE) total += align256s((size_t)n * (size_t)h * (size_t)w * sizeof(double2));
     return total + align256s((size_t)n * sizeof(int));
 }
@@ -73,7 +78,7 @@ extern "C" int tia_stain_stats_u8(const uint8_t* d_img, int64_t n, int64_t h, in
     // workgroups per image, decisions between sweeps in one-workgroup kernels (stain_stats_big.hip) -- the per-patch kernels below
     // give an image ONE workgroup.  The state lives at the front of the workspace (the bin cache is not used on this path).
     static const bool no_big = tia::dev_env("TIA_STATS_NO_BIG") != nullptr;  // developer switch: audit against the streaming kernel
-    if (!no_big && hw > tia::kBigImagePixels && params->select_mode == 0 && aligned && ws_bytes >= tia::stain_stats_big_workspace_bytes(n) &&
+    if (!no_big && hw > tia::kBigImagePixels && params->select_mode == 0 && aligned && ws_bytes >= tia::stain_stats_big_workspace_bytes(n, hw) &&
         n <= 65535)
         return tia::launch_stain_stats_big(d_img, n, hw, d_tables, *params, d_stats, d_ws, st);
     // Patches of up to 13 x 4096 pixels (224 x 224 and smaller) in whole 4-pixel groups go through the register-resident kernel

@@ -26,6 +26,9 @@ constexpr int kDigitBits = 11;
 constexpr int kDigitBins = 1 << kDigitBits;
 constexpr int kSelTargets = 4;
 constexpr int kMaxBigGroups = 1024;  // workgroups per image
+constexpr int kLinBins = 16384;      // linear bins of a selection's first sweep: 16384 for one key, 8192 per key for two (64 KB of LDS)
+constexpr int kCandCap = 16384;      // members of a rank's bin collected for the exact selection (per list: selected in 128 KB of LDS
+                                     // by one workgroup); more than that (a huge image, massive ties): radix passes over the image
 
 struct BigState {
     unsigned hist[256];                    // P1
@@ -35,7 +38,20 @@ struct BigState {
     int row[kSelTargets];
     int nkeys;                             // 1: every target ranks the same key; 2: targets 0, 1 rank key 0 and 2, 3 key 1
     int shift, bits;                       // current digit: key >> shift, `bits` wide; shift < 0: selection complete
+    // fast form of a selection (two sweeps instead of six): the first sweep bins every key linearly over its value range (counts in
+    // `lin`) and caches the bin code per pixel; the second collects the exact keys of the pixels in the ranks' bins (a few thousand)
+    // and one workgroup selects among them.  `fast`: 1 = binning sweep pending, 2 = collecting sweep pending, 0 = off (the radix
+    // passes run when shift >= 0: the fall-back for lists that overflow -- massive ties).
+    unsigned lin[2][kLinBins];
+    double lin_lo[2], lin_scale[2];
+    int nbins;
+    unsigned long long rank0[kSelTargets];
+    int fast;
+    int tbin[kSelTargets], tlist[kSelTargets];
+    unsigned lcount[kSelTargets];
+    unsigned diag[2][1 + kSelTargets];     // per selection (angles, concentrations): fell back to radix passes; list sizes
     int skip;                              // empty tissue mask: the record is final
+    unsigned ticket;                       // workgroups of the current sweep that have delivered (the last one runs the step)
     int bmin, bmax;
     unsigned flags;
     double plow, phigh;
@@ -74,8 +90,52 @@ __device__ __forceinline__ void big_span(long hw, long& lo, long& hi) {
     if (lo > hw) lo = hw;
 }
 
+// `f(r, g, b)` for every pixel of [lo, hi): 4-pixel groups as three dword loads per lane (lo is a multiple of 4), the rest bytewise
+template <class F>
+__device__ __forceinline__ void big_for_each_pixel(const uint8_t* __restrict__ p, long lo, long hi, F&& f) {
+    long done = lo;
+    if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+        const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
+        const long g1 = hi >> 2;
+        for (long g = (lo >> 2) + threadIdx.x; g < g1; g += GT) {
+            const uint32_t a = q[g * 3], b = q[g * 3 + 1], c = q[g * 3 + 2];
+            f(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
+            f(a >> 24, b & 255u, (b >> 8) & 255u);
+            f((b >> 16) & 255u, b >> 24, c & 255u);
+            f((c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
+        }
+        done = g1 << 2;
+        if (done < lo) done = lo;
+    }
+    for (long i = done + threadIdx.x; i < hi; i += GT) f((uint32_t)p[3 * i], (uint32_t)p[3 * i + 1], (uint32_t)p[3 * i + 2]);
+}
+
+// What a sweep's workgroups deliver to the image's state travels as device-scope atomics / write-through stores; waiting for their
+// acknowledgements orders them before the ticket (no release fence: on gfx950 that writes the whole L2 back).  Returns true in the
+// workgroup that delivered LAST: it runs the per-image decision on the merged state (coherent loads) instead of a kernel of its own.
+__device__ __forceinline__ bool big_last_workgroup(BigState& st) {
+    __shared__ unsigned s_ticket;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&st.ticket, 1u);
+    __syncthreads();
+    const bool last = s_ticket == gridDim.x - 1;
+    if (last) {
+        if (threadIdx.x == 0) st.ticket = 0u;
+        // one agent-scope acquire (drops this CU's / XCD's possibly stale lines), then PLAIN loads of the merged state: they pipeline
+        // and hit L2 on the second touch -- coherent loads one at a time cost ~1 us each and made this step 0.5-0.9 ms
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    return last;
+}
+__device__ __forceinline__ unsigned big_ld(const unsigned* p) { return *p; }
+__device__ __forceinline__ double big_ldd(const double* p) { return *p; }
+
 // ---- P1 --------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GT) void big_hist_kernel(const uint8_t* __restrict__ img, long hw, BigState* __restrict__ states, int z1) {
+__device__ void big_p1_finish(long hw, const tia_stain_params& prm, BigState& st, double* __restrict__ out);
+
+__global__ __launch_bounds__(GT) void big_hist_kernel(const uint8_t* __restrict__ img, long hw, BigState* __restrict__ states, int z1,
+                                                      tia_stain_params prm, double* __restrict__ stats) {
     __shared__ unsigned bins[256 * 32];  // 32 copies: lane l adds to copy l & 31 of bin v at v * 32 + (l & 31)
     BigState& st = states[blockIdx.y];
     const uint8_t* p = img + (size_t)blockIdx.y * (size_t)hw * 3u;
@@ -113,14 +173,13 @@ __global__ __launch_bounds__(GT) void big_hist_kernel(const uint8_t* __restrict_
         for (int c = 0; c < 32; ++c) tot += bins[threadIdx.x * 32 + ((c + threadIdx.x) & 31)];
         if (tot) atomicAdd(&st.hist[threadIdx.x], tot);
     }
+    if (big_last_workgroup(st)) big_p1_finish(hw, prm, st, stats + (size_t)blockIdx.y * TIA_STATS_STRIDE);
 }
 
 // percentiles of the contrast enhancer from the merged counts (one workgroup per image): the arithmetic of the per-patch kernels
-__global__ __launch_bounds__(256) void big_p1_finish_kernel(long hw, tia_stain_params prm, BigState* __restrict__ states, double* __restrict__ stats) {
+__device__ void big_p1_finish(long hw, const tia_stain_params& prm, BigState& st, double* __restrict__ out) {
     __shared__ unsigned cum[256];
     __shared__ int ibc[8];
-    BigState& st = states[blockIdx.x];
-    double* out = stats + (size_t)blockIdx.x * TIA_STATS_STRIDE;
     const int tid = threadIdx.x;
     // TIA_MODE_GIVEN: the caller's stain matrix arrives in the record itself
     if (prm.mode == TIA_MODE_GIVEN && tid < 6) st.S[tid] = out[TIA_ST_STAIN + tid];
@@ -128,7 +187,8 @@ __global__ __launch_bounds__(256) void big_p1_finish_kernel(long hw, tia_stain_p
     __syncthreads();
     if (tid < TIA_STATS_STRIDE) out[tid] = 0.0;
     if (tid < 64) {
-        const unsigned h0 = st.hist[tid * 4], h1 = st.hist[tid * 4 + 1], h2 = st.hist[tid * 4 + 2], h3 = st.hist[tid * 4 + 3];
+        const unsigned h0 = big_ld(&st.hist[tid * 4]), h1 = big_ld(&st.hist[tid * 4 + 1]), h2 = big_ld(&st.hist[tid * 4 + 2]),
+                       h3 = big_ld(&st.hist[tid * 4 + 3]);
         const unsigned incl = wave_incl_scan_u32(h0 + h1 + h2 + h3);
         const unsigned base = incl - (h0 + h1 + h2 + h3);
         cum[tid * 4] = base + h0;
@@ -172,8 +232,10 @@ __global__ __launch_bounds__(256) void big_p1_finish_kernel(long hw, tia_stain_p
 }
 
 // ---- P2 --------------------------------------------------------------------------------------------------------------------------
+__device__ void big_eigen(int groups, const tia_stain_params& prm, BigState& st, double* __restrict__ out);
+
 __global__ __launch_bounds__(GT) void big_moments_kernel(const uint8_t* __restrict__ img, long hw, const tia_stain_tables* __restrict__ tab,
-                                                         tia_stain_params prm, BigState* __restrict__ states) {
+                                                         tia_stain_params prm, BigState* __restrict__ states, double* __restrict__ stats) {
     __shared__ double od[256];
     __shared__ int ty[3][256];
     __shared__ double red[GT / 64][10];
@@ -187,8 +249,7 @@ __global__ __launch_bounds__(GT) void big_moments_kernel(const uint8_t* __restri
     for (int i = 0; i < 10; ++i) acc[i] = 0.0;
     long lo, hi;
     big_span(hw, lo, hi);
-    for (long i = lo + threadIdx.x; i < hi; i += GT) {
-        const uint32_t r = p[3 * i], g = p[3 * i + 1], b = p[3 * i + 2];
+    big_for_each_pixel(p, lo, hi, [&](uint32_t r, uint32_t g, uint32_t b) {
         const int t = ty[0][r] + ty[1][g] + ty[2][b];
         if (((t + (1 << 11)) >> 12) < y_thr) {
             const double x = od[r], y = od[g], z = od[b];
@@ -203,7 +264,7 @@ __global__ __launch_bounds__(GT) void big_moments_kernel(const uint8_t* __restri
             acc[8] = __builtin_fma(y, z, acc[8]);
             acc[9] = __builtin_fma(z, z, acc[9]);
         }
-    }
+    });
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const double w = wave_sum(acc[i]);
@@ -213,8 +274,9 @@ __global__ __launch_bounds__(GT) void big_moments_kernel(const uint8_t* __restri
     if (threadIdx.x < 10) {
         double t = 0.0;
         for (int w = 0; w < GT / 64; ++w) t += red[w][threadIdx.x];  // fixed order
-        st.partial[blockIdx.x][threadIdx.x] = t;
+        __hip_atomic_store(&st.partial[blockIdx.x][threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (big_last_workgroup(st)) big_eigen((int)gridDim.x, prm, st, stats + (size_t)blockIdx.y * TIA_STATS_STRIDE);
 }
 
 // targets that rank the same key and agree in the digits fixed so far count into ONE row (the smallest such target's)
@@ -229,27 +291,53 @@ __device__ __forceinline__ void big_share_rows(BigState& st) {
         st.row[t] = r;
     }
 }
-__device__ __forceinline__ void big_start_selection(BigState& st, const unsigned long long (&ranks)[kSelTargets], int nkeys) {
-    st.nkeys = nkeys;
+__device__ __forceinline__ void big_start_radix(BigState& st) {
     for (int t = 0; t < kSelTargets; ++t) {
         st.prefix[t] = 0ull;
-        st.rank[t] = ranks[t];
+        st.rank[t] = st.rank0[t];
     }
     big_share_rows(st);
     st.shift = 64 - kDigitBits;
     st.bits = kDigitBits;
+    st.fast = 0;
+}
+// lo / hi: value range of each key (anything outside lands in the edge bins: the selection stays exact)
+__device__ __forceinline__ void big_start_selection(BigState& st, const unsigned long long (&ranks)[kSelTargets], int nkeys, const double (&lo)[2],
+                                                    const double (&hi)[2]) {
+    st.nkeys = nkeys;
+    for (int t = 0; t < kSelTargets; ++t) {
+        st.rank0[t] = ranks[t];
+        st.rank[t] = ranks[t];
+        st.prefix[t] = 0ull;
+    }
+    st.nbins = kLinBins / nkeys;
+    for (int k = 0; k < 2; ++k) {
+        st.lin_lo[k] = lo[k];
+        st.lin_scale[k] = (double)st.nbins / (hi[k] - lo[k]);
+    }
+    st.shift = -1;
+    st.fast = 1;
 }
 
-__global__ __launch_bounds__(64) void big_eigen_kernel(int groups, tia_stain_params prm, BigState* __restrict__ states, double* __restrict__ stats) {
-    BigState& st = states[blockIdx.x];
-    double* out = stats + (size_t)blockIdx.x * TIA_STATS_STRIDE;
+__device__ void big_eigen(int groups, const tia_stain_params& prm, BigState& st, double* __restrict__ out) {
+    __shared__ double s_acc[10];
+    if (threadIdx.x < 10) {  // ten columns side by side, each summed in workgroup order: deterministic for a given grid
+        double t = 0.0;
+        int g = 0;
+        for (; g + 8 <= groups; g += 8) {  // eight loads in flight, added in order
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = big_ldd(&st.partial[g + k][threadIdx.x]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += v[k];
+        }
+        for (; g < groups; ++g) t += big_ldd(&st.partial[g][threadIdx.x]);
+        s_acc[threadIdx.x] = t;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
     double acc[10];
-    for (int i = 0; i < 10; ++i) {
-        double t = 0.0;
-        for (int g = 0; g < groups; ++g) t += st.partial[g][i];  // workgroup order: deterministic for a given grid
-        acc[i] = t;
-    }
+    for (int i = 0; i < 10; ++i) acc[i] = s_acc[i];
     const double nt = acc[0];
     const unsigned long long n_tissue = (unsigned long long)nt;
     st.nt = nt;
@@ -293,12 +381,357 @@ __global__ __launch_bounds__(64) void big_eigen_kernel(int groups, tia_stain_par
     np_index(n_tissue, prm.q_phi_lo, kp[0], kn[0], st.gm[0]);
     np_index(n_tissue, prm.q_phi_hi, kp[1], kn[1], st.gm[1]);
     const unsigned long long ranks[kSelTargets] = {kp[0], kn[0], kp[1], kn[1]};
-    big_start_selection(st, ranks, 1);
+    const double lo[2] = {-2.0009765625, -2.0009765625}, hi[2] = {2.0009765625, 2.0009765625};
+    big_start_selection(st, ranks, 1, lo, hi);
+}
+
+// ---- fast selection: linear bins + cached codes, then exact selection among the members of the ranks' bins -------------------------
+// key(s) of one pixel: KIND 0 = pseudo-angle in the eigen-plane (tissue pixels), KIND 1 = the two stain concentrations (all pixels)
+template <int KIND>
+__device__ __forceinline__ void big_keys(const double* od, const double (&a)[3], const double (&c)[3], uint32_t r, uint32_t g, uint32_t b,
+                                         double (&x)[2]) {
+    const double ox = od[r], oy = od[g], oz = od[b];
+    const double p0 = dot3(ox, oy, oz, a[0], a[1], a[2]);
+    const double p1 = dot3(ox, oy, oz, c[0], c[1], c[2]);
+    if (KIND == 0) {
+        x[0] = x[1] = pseudo_angle(p1, p0);
+    } else {
+        x[0] = p0;
+        x[1] = p1;
+    }
+}
+__device__ __forceinline__ int big_lin_bin(double x, double lo, double scale, int nbins) {
+    const double d = (x - lo) * scale;
+    if (!(d >= 0.0)) return 0;
+    if (d >= (double)nbins) return nbins - 1;
+    return (int)d;
+}
+
+__device__ void big_lin_step(BigState& st);
+__device__ void big_exact_step(BigState& st, const unsigned long long* __restrict__ cand);
+
+// sweep A: bin every key, count, cache the codes ([key][pixel] uint16; 0xffff = not a member, i.e. no tissue)
+template <int KIND>
+__global__ __launch_bounds__(GT) void big_lin_sweep_kernel(const uint8_t* __restrict__ img, long hw, const tia_stain_tables* __restrict__ tab,
+                                                           tia_stain_params prm, BigState* __restrict__ states, uint16_t* __restrict__ codes_all) {
+    constexpr int NK = KIND == 0 ? 1 : 2;
+    __shared__ double od[256];
+    __shared__ int ty[3][256];
+    constexpr int NBINS = kLinBins / NK;
+    __shared__ unsigned bins[NK][NBINS];
+    BigState& st = states[blockIdx.y];
+    if (st.skip || st.fast != 1) return;  // (uniform)
+    const uint8_t* p = img + (size_t)blockIdx.y * (size_t)hw * 3u;
+    uint16_t* codes = codes_all + (size_t)blockIdx.y * 2u * (size_t)hw;
+    big_build_tables(od, ty, tab, st.plow, st.phigh, prm.zero_to_one != 0);
+    for (int i = threadIdx.x; i < NK * NBINS; i += GT) (&bins[0][0])[i] = 0u;
+    double a[3], c[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a[i] = KIND == 0 ? st.e1[i] : st.P[2 * i];
+        c[i] = KIND == 0 ? st.e2[i] : st.P[2 * i + 1];
+    }
+    const double lo0 = st.lin_lo[0], sc0 = st.lin_scale[0], lo1 = st.lin_lo[1], sc1 = st.lin_scale[1];
+    __syncthreads();
+    const int y_thr = prm.y_thr;
+    long lo, hi;
+    big_span(hw, lo, hi);
+    auto one = [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
+        unsigned c0 = 0xffffu, c1 = 0xffffu;
+        bool member = true;
+        if (KIND == 0) {
+            const int t = ty[0][r] + ty[1][g] + ty[2][b];
+            member = ((t + (1 << 11)) >> 12) < y_thr;
+        }
+        if (member) {
+            double x[2];
+            big_keys<KIND>(od, a, c, r, g, b, x);
+            c0 = (unsigned)big_lin_bin(x[0], lo0, sc0, NBINS);
+            atomicAdd(&bins[0][c0], 1u);
+            if (NK == 2) {
+                c1 = (unsigned)big_lin_bin(x[1], lo1, sc1, NBINS);
+                atomicAdd(&bins[NK - 1][c1], 1u);
+            }
+        }
+        codes[idx] = (uint16_t)c0;
+        if (NK == 2) codes[(size_t)hw + idx] = (uint16_t)c1;
+    };
+    long idx = 0;
+    (void)idx;
+    // (pixel index needed for the code cache: the group form of the sweep, spelled out)
+    long done = lo;
+    if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+        const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
+        const long g1 = hi >> 2;
+        for (long g = (lo >> 2) + threadIdx.x; g < g1; g += GT) {
+            const uint32_t wa = q[g * 3], wb = q[g * 3 + 1], wc = q[g * 3 + 2];
+            one(4 * g, wa & 255u, (wa >> 8) & 255u, (wa >> 16) & 255u);
+            one(4 * g + 1, wa >> 24, wb & 255u, (wb >> 8) & 255u);
+            one(4 * g + 2, (wb >> 16) & 255u, wb >> 24, wc & 255u);
+            one(4 * g + 3, (wc >> 8) & 255u, (wc >> 16) & 255u, wc >> 24);
+        }
+        done = g1 << 2;
+        if (done < lo) done = lo;
+    }
+    for (long i = done + threadIdx.x; i < hi; i += GT) one(i, (uint32_t)p[3 * i], (uint32_t)p[3 * i + 1], (uint32_t)p[3 * i + 2]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < NK * NBINS; i += GT) {  // key k's counts at st.lin[0] + k * NBINS (the flat 8192-entry area)
+        const unsigned v = (&bins[0][0])[i];
+        if (v) atomicAdd(&(&st.lin[0][0])[i], v);
+    }
+    if (big_last_workgroup(st)) big_lin_step(st);
+}
+
+// after sweep A (one workgroup): the bin of every rank, the rank inside it, one candidate list per distinct (key, bin)
+__device__ void big_lin_step(BigState& st) {
+    __shared__ unsigned part[256];
+    __shared__ unsigned found_bin[kSelTargets];
+    __shared__ unsigned long long found_below[kSelTargets];
+    const int tid = threadIdx.x;
+    constexpr int PER = kLinBins / 256;
+    __shared__ unsigned long long c_rank[kSelTargets];
+    __shared__ int c_nb, c_nkeys;
+    if (tid < kSelTargets) c_rank[tid] = st.rank[tid];
+    if (tid == 0) {
+        c_nb = st.nbins;
+        c_nkeys = st.nkeys;
+    }
+    __syncthreads();
+    const int nb = c_nb, nkeys = c_nkeys;
+    for (int t = 0; t < kSelTargets; ++t) {
+        const unsigned* bins = &st.lin[0][0] + (nkeys == 1 ? 0 : (t >> 1) * nb);
+        unsigned loc[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            loc[j] = tid * PER + j < nb ? big_ld(&bins[tid * PER + j]) : 0u;
+            sum += loc[j];
+        }
+        part[tid] = sum;
+        __syncthreads();
+        unsigned long long before = 0;
+        for (int j = 0; j < tid; ++j) before += part[j];
+        const unsigned long long r = c_rank[t];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (before <= r && r < before + loc[j]) {
+                found_bin[t] = (unsigned)(tid * PER + j);
+                found_below[t] = before;
+            }
+            before += loc[j];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int t = 0; t < kSelTargets; ++t) {
+            st.tbin[t] = (int)found_bin[t];
+            st.rank[t] = c_rank[t] - found_below[t];
+            int l = t;
+            for (int u = 0; u < t; ++u)
+                if ((nkeys == 1 || (u >> 1) == (t >> 1)) && found_bin[u] == found_bin[t]) {
+                    l = u;
+                    break;
+                }
+            st.tlist[t] = l;
+            st.lcount[t] = 0u;
+        }
+        st.fast = 2;
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * kLinBins; i += 256) (&st.lin[0][0])[i] = 0u;
+}
+
+// sweep B: the cached codes pick the members of the ranks' bins; their exact keys go to the lists
+template <int KIND>
+__global__ __launch_bounds__(GT) void big_collect_sweep_kernel(const uint8_t* __restrict__ img, long hw, const tia_stain_tables* __restrict__ tab,
+                                                               tia_stain_params prm, BigState* __restrict__ states,
+                                                               const uint16_t* __restrict__ codes_all, unsigned long long* __restrict__ cand_all) {
+    constexpr int NK = KIND == 0 ? 1 : 2;
+    __shared__ double od[256];
+    BigState& st = states[blockIdx.y];
+    if (st.skip || st.fast != 2) return;  // (uniform)
+    const uint8_t* p = img + (size_t)blockIdx.y * (size_t)hw * 3u;
+    const uint16_t* codes = codes_all + (size_t)blockIdx.y * 2u * (size_t)hw;
+    unsigned long long* cand = cand_all + (size_t)blockIdx.y * kSelTargets * (size_t)kCandCap;
+    for (int t = threadIdx.x; t < 256; t += GT) od[t] = tab->od_lut[t];
+    double a[3], c[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a[i] = KIND == 0 ? st.e1[i] : st.P[2 * i];
+        c[i] = KIND == 0 ? st.e2[i] : st.P[2 * i + 1];
+    }
+    int tb[kSelTargets], tl[kSelTargets];
+#pragma unroll
+    for (int t = 0; t < kSelTargets; ++t) {
+        tb[t] = st.tbin[t];
+        tl[t] = st.tlist[t];
+    }
+    __syncthreads();
+    long lo, hi;
+    big_span(hw, lo, hi);
+    auto visit = [&](long i, unsigned c0, unsigned c1) {
+        bool hit = false;
+#pragma unroll
+        for (int t = 0; t < kSelTargets; ++t) hit = hit || (tl[t] == t && (int)((NK == 2 && t >= 2) ? c1 : c0) == tb[t]);
+        if (!hit) return;
+        double x[2];
+        big_keys<KIND>(od, a, c, (uint32_t)p[3 * i], (uint32_t)p[3 * i + 1], (uint32_t)p[3 * i + 2], x);
+#pragma unroll
+        for (int t = 0; t < kSelTargets; ++t) {
+            if (tl[t] != t) continue;  // lists are owned by their first target
+            const bool second = NK == 2 && t >= 2;
+            if ((int)(second ? c1 : c0) != tb[t]) continue;
+            const unsigned pos = atomicAdd(&st.lcount[t], 1u);
+            if (pos < (unsigned)kCandCap) {
+                const unsigned long long k = f64_key(x[second ? 1 : 0]);
+                __hip_atomic_store(&cand[(size_t)t * kCandCap + pos], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    // four codes per 8-byte load (the loop is bound by load latency: members are a fraction of a per cent); lo is a multiple of 4
+    long done = lo;
+    if ((hw & 3) == 0 && (reinterpret_cast<uintptr_t>(codes) & 7) == 0) {
+        const unsigned long long* q0 = reinterpret_cast<const unsigned long long*>(codes);
+        const unsigned long long* q1 = reinterpret_cast<const unsigned long long*>(codes + (size_t)hw);
+        const long g1 = hi >> 2;
+#pragma unroll 4
+        for (long g = (lo >> 2) + threadIdx.x; g < g1; g += GT) {
+            const unsigned long long w0 = q0[g], w1 = NK == 2 ? q1[g] : ~0ull;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) visit(4 * g + e, (unsigned)(w0 >> (16 * e)) & 0xffffu, (unsigned)(w1 >> (16 * e)) & 0xffffu);
+        }
+        done = g1 << 2;
+        if (done < lo) done = lo;
+    }
+    for (long i = done + threadIdx.x; i < hi; i += GT) visit(i, codes[i], NK == 2 ? (unsigned)codes[(size_t)hw + i] : 0xffffu);
+    if (big_last_workgroup(st)) big_exact_step(st, cand);
+}
+
+// after sweep B (one workgroup): each list is copied to LDS once and its ranks found by radix selection there (8-bit digits, the
+// digit counts scanned by the 256 threads); the rank right after a selected one -- the ceil neighbour of a percentile -- needs no
+// second selection: it is the same key while equal members remain, else the smallest key above it (one more pass).  A list that
+// overflowed hands the whole selection to the radix passes over the image.
+__device__ void big_exact_step(BigState& st, const unsigned long long* __restrict__ cand) {
+    __shared__ unsigned long long s_list[kCandCap];
+    __shared__ unsigned dig[256], wsum[4];
+    __shared__ unsigned long long s_prefix, s_rank, s_min[4];
+    __shared__ unsigned s_equal;
+    __shared__ int s_overflow;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // the image's state is read ONCE (global loads right after the acquire cost ~1 us each and the loops below are uniform chains)
+    __shared__ int c_list[kSelTargets];
+    __shared__ unsigned c_count[kSelTargets];
+    __shared__ unsigned long long c_rank[kSelTargets];
+    __shared__ int c_nkeys;
+    if (tid < kSelTargets) {
+        c_list[tid] = st.tlist[tid];
+        c_count[tid] = big_ld(&st.lcount[tid]);
+        c_rank[tid] = st.rank[tid];
+    }
+    if (tid == 0) c_nkeys = st.nkeys;
+    __syncthreads();
+    if (tid == 0) {
+        s_overflow = 0;
+        unsigned* dg = st.diag[c_nkeys - 1];
+        for (int t = 0; t < kSelTargets; ++t) {
+            const unsigned cnt = c_count[c_list[t]];
+            dg[1 + t] = cnt;
+            if (cnt > (unsigned)kCandCap) s_overflow = 1;
+        }
+        dg[0] = (unsigned)s_overflow;
+    }
+    __syncthreads();
+    if (s_overflow) {
+        if (tid == 0) big_start_radix(st);
+        return;
+    }
+    for (int l = 0; l < kSelTargets; ++l) {
+        bool used = false;
+        for (int t = 0; t < kSelTargets; ++t) used = used || c_list[t] == l;
+        if (!used) continue;  // (uniform)
+        const unsigned cnt = c_count[l];
+        const unsigned long long* list = cand + (size_t)l * kCandCap;
+        for (unsigned i = tid; i < cnt; i += 256) s_list[i] = list[i];
+        __syncthreads();
+        unsigned long long prev_rank = ~0ull, prev_key = 0ull;
+        unsigned prev_left = 0;  // members equal to prev_key at ranks above prev_rank
+        for (int t = 0; t < kSelTargets; ++t) {
+            if (c_list[t] != l) continue;  // (uniform)
+            const unsigned long long r = c_rank[t];
+            unsigned long long key;
+            if (r == prev_rank) {
+                key = prev_key;
+            } else if (r == prev_rank + 1 && prev_left > 0) {
+                key = prev_key;
+                prev_left -= 1;
+                prev_rank = r;
+            } else if (r == prev_rank + 1) {  // the smallest key above prev_key
+                unsigned long long m = ~0ull;
+                for (unsigned i = tid; i < cnt; i += 256) {
+                    const unsigned long long k = s_list[i];
+                    m = (k > prev_key && k < m) ? k : m;
+                }
+                m = wave_min_u64(m);
+                if (lane == 0) s_min[wv] = m;
+                __syncthreads();
+                key = s_min[0];
+                for (int q = 1; q < 4; ++q) key = s_min[q] < key ? s_min[q] : key;
+                __syncthreads();
+                // members equal to the new key: counted on demand only if yet another neighbour is asked for (not in this use)
+                prev_key = key;
+                prev_rank = r;
+                prev_left = 0;
+            } else {
+                if (tid == 0) {
+                    s_prefix = 0ull;
+                    s_rank = r;
+                }
+                for (int shift = 56; shift >= 0; shift -= 8) {
+                    dig[tid] = 0u;
+                    __syncthreads();
+                    const unsigned long long pre = s_prefix;
+                    const int hs = shift + 8;
+                    for (unsigned i = tid; i < cnt; i += 256) {
+                        const unsigned long long k = s_list[i];
+                        const bool match = hs >= 64 ? true : (k >> (hs & 63)) == (pre >> (hs & 63));
+                        if (match) atomicAdd(&dig[(unsigned)(k >> shift) & 255u], 1u);
+                    }
+                    __syncthreads();
+                    const unsigned mine = dig[tid];
+                    const unsigned incl = wave_incl_scan_u32(mine);
+                    if (lane == 63) wsum[wv] = incl;
+                    __syncthreads();
+                    unsigned before = incl - mine;
+                    for (int q = 0; q < wv; ++q) before += wsum[q];
+                    const unsigned long long rr = s_rank;
+                    __syncthreads();
+                    if ((unsigned long long)before <= rr && rr < (unsigned long long)before + mine) {
+                        s_prefix = pre | ((unsigned long long)tid << shift);
+                        s_rank = rr - before;
+                        s_equal = mine;
+                    }
+                    __syncthreads();
+                }
+                key = s_prefix;
+                prev_key = key;
+                prev_rank = r;
+                prev_left = s_equal - 1u - (unsigned)s_rank;  // equal members at higher ranks
+                __syncthreads();
+            }
+            if (tid == 0) st.prefix[t] = key;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        st.fast = 0;
+        st.shift = -1;
+    }
 }
 
 // ---- radix selection ------------------------------------------------------------------------------------------------------------
 // KIND 0: key = pseudo-angle of the tissue pixel's OD in the eigen-plane (all four targets); KIND 1: key0 / key1 = the two stain
 // concentrations of every pixel (targets 0, 1 / 2, 3).
+__device__ void big_select_step(BigState& st);
+
 template <int KIND>
 __global__ __launch_bounds__(GT) void big_select_sweep_kernel(const uint8_t* __restrict__ img, long hw, const tia_stain_tables* __restrict__ tab,
                                                               tia_stain_params prm, BigState* __restrict__ states) {
@@ -332,11 +765,10 @@ __global__ __launch_bounds__(GT) void big_select_sweep_kernel(const uint8_t* __r
     const int y_thr = prm.y_thr;
     long lo, hi;
     big_span(hw, lo, hi);
-    for (long i = lo + threadIdx.x; i < hi; i += GT) {
-        const uint32_t r = p[3 * i], g = p[3 * i + 1], b = p[3 * i + 2];
+    big_for_each_pixel(p, lo, hi, [&](uint32_t r, uint32_t g, uint32_t b) {
         if (KIND == 0) {
             const int t = ty[0][r] + ty[1][g] + ty[2][b];
-            if (!(((t + (1 << 11)) >> 12) < y_thr)) continue;
+            if (!(((t + (1 << 11)) >> 12) < y_thr)) return;
         }
         const double ox = od[r], oy = od[g], oz = od[b];
         const double p0 = dot3(ox, oy, oz, a[0], a[1], a[2]);
@@ -355,7 +787,7 @@ __global__ __launch_bounds__(GT) void big_select_sweep_kernel(const uint8_t* __r
             if (hs < 64 && (k >> hs) != pre[t]) continue;
             atomicAdd(&bins[t][(unsigned)(k >> shift) & mask], 1u);
         }
-    }
+    });
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < kSelTargets; ++t) {
@@ -365,15 +797,14 @@ __global__ __launch_bounds__(GT) void big_select_sweep_kernel(const uint8_t* __r
             if (v) atomicAdd(&st.sel[t][i], v);
         }
     }
+    if (big_last_workgroup(st)) big_select_step(st);
 }
 
 // one workgroup per image: walk each target's merged counts to the bin holding its rank, fix that digit, move to the next digit
-__global__ __launch_bounds__(256) void big_select_step_kernel(BigState* __restrict__ states) {
+__device__ void big_select_step(BigState& st) {
     __shared__ unsigned part[256];
     __shared__ unsigned found_bin[kSelTargets];
     __shared__ unsigned long long found_below[kSelTargets];
-    BigState& st = states[blockIdx.x];
-    if (st.skip || st.shift < 0) return;
     const int tid = threadIdx.x;
     const int shift = st.shift;
     constexpr int PER = kDigitBins / 256;
@@ -382,7 +813,7 @@ __global__ __launch_bounds__(256) void big_select_step_kernel(BigState* __restri
         unsigned loc[PER], sum = 0;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            loc[j] = bins[tid * PER + j];
+            loc[j] = big_ld(&bins[tid * PER + j]);
             sum += loc[j];
         }
         part[tid] = sum;
@@ -431,7 +862,9 @@ __device__ __forceinline__ void big_pinv(const double (&S)[6], double (&P)[6]) {
     }
 }
 
-__global__ __launch_bounds__(64) void big_vectors_kernel(long hw, tia_stain_params prm, BigState* __restrict__ states, double* __restrict__ stats) {
+__global__ __launch_bounds__(64) void big_vectors_kernel(long hw, tia_stain_params prm, const tia_stain_tables* __restrict__ tab,
+                                                         BigState* __restrict__ states, double* __restrict__ stats) {
+    const double* od_lut = tab->od_lut;
     BigState& st = states[blockIdx.x];
     double* out = stats + (size_t)blockIdx.x * TIA_STATS_STRIDE;
     if (threadIdx.x != 0 || st.skip) return;
@@ -471,7 +904,21 @@ __global__ __launch_bounds__(64) void big_vectors_kernel(long hw, tia_stain_para
     np_index((unsigned long long)hw, prm.q_conc, kp, kn, gm);
     st.gm[0] = st.gm[1] = gm;
     const unsigned long long ranks[kSelTargets] = {kp, kn, kp, kn};
-    big_start_selection(st, ranks, 2);
+    // rigorous value bounds from the byte range: od in [od(bmax), od(bmin)] (the OD table is decreasing in the byte)
+    double lo[2] = {0.0, 0.0}, hi[2] = {0.0, 0.0};
+    const double oa = od_lut[st.bmax], ob = od_lut[st.bmin];
+    for (int t = 0; t < 2; ++t) {
+        for (int j = 0; j < 3; ++j) {
+            const double u = P[j * 2 + t] * oa, w = P[j * 2 + t] * ob;
+            lo[t] += u < w ? u : w;
+            hi[t] += u < w ? w : u;
+        }
+        const double pad = 1e-9 * (fabs(lo[t]) + fabs(hi[t])) + 1e-12;
+        lo[t] -= pad;
+        hi[t] += pad;
+        if (!(hi[t] > lo[t])) hi[t] = lo[t] + 1.0;
+    }
+    big_start_selection(st, ranks, 2, lo, hi);
 }
 
 __global__ __launch_bounds__(64) void big_final_kernel(tia_stain_params prm, BigState* __restrict__ states, double* __restrict__ stats) {
@@ -504,9 +951,18 @@ __global__ __launch_bounds__(64) void big_final_kernel(tia_stain_params prm, Big
                 out[TIA_ST_M + j * 3 + c] = P[j * 2 + 0] * sc0 * prm.target_stain[c] + P[j * 2 + 1] * sc1 * prm.target_stain[3 + c];
     }
     out[TIA_ST_FLAGS] = (double)flags;
+    // diagnostics of this path in the instrumentation slots: per selection, whether it fell back to the radix passes and the sizes
+    // of its candidate lists
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 1 + kSelTargets; ++i) out[TIA_ST_CYCLES + k * (1 + kSelTargets) + i] = (double)st.diag[k][i];
 }
 
-size_t stain_stats_big_workspace_bytes(long n) { return (size_t)n * sizeof(BigState); }
+// [states][candidate lists: 4 x kCandCap keys per image][bin codes: 2 x pixels uint16 per image]
+static size_t big_states_bytes(long n) { return ((size_t)n * sizeof(BigState) + 255) & ~(size_t)255; }
+static size_t big_cand_bytes(long n) { return (size_t)n * kSelTargets * (size_t)kCandCap * sizeof(unsigned long long); }
+size_t stain_stats_big_workspace_bytes(long n, long hw) {
+    return big_states_bytes(n) + big_cand_bytes(n) + (size_t)n * 2u * (size_t)hw * sizeof(uint16_t);
+}
 
 // workgroups per image: one per 64 Ki pixels, more when the batch is small (>= ~768 in all), at most kMaxBigGroups
 static int big_groups(long n, long hw) {
@@ -522,26 +978,26 @@ static int big_groups(long n, long hw) {
 int launch_stain_stats_big(const uint8_t* d_img, long n, long hw, const tia_stain_tables* d_tables, const tia_stain_params& prm,
                            double* d_stats, void* d_ws, hipStream_t st) {
     BigState* states = reinterpret_cast<BigState*>(d_ws);
-    if (hipMemsetAsync(states, 0, stain_stats_big_workspace_bytes(n), st) != hipSuccess) return TIA_ELAUNCH;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>((char*)d_ws + big_states_bytes(n));
+    uint16_t* codes = reinterpret_cast<uint16_t*>((char*)d_ws + big_states_bytes(n) + big_cand_bytes(n));
+    if (hipMemsetAsync(states, 0, big_states_bytes(n), st) != hipSuccess) return TIA_ELAUNCH;
     const int groups = big_groups(n, hw);
     const dim3 grid((unsigned)groups, (unsigned)n), one((unsigned)n);
     const int z1 = prm.zero_to_one != 0 ? 1 : 0;
-    hipLaunchKernelGGL(big_hist_kernel, grid, dim3(GT), 0, st, d_img, hw, states, z1);
-    hipLaunchKernelGGL(big_p1_finish_kernel, one, dim3(256), 0, st, hw, prm, states, d_stats);
+    hipLaunchKernelGGL(big_hist_kernel, grid, dim3(GT), 0, st, d_img, hw, states, z1, prm, d_stats);
     constexpr int kPasses = (64 + kDigitBits - 1) / kDigitBits;
     if (prm.mode == TIA_MODE_MACENKO) {
-        hipLaunchKernelGGL(big_moments_kernel, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states);
-        hipLaunchKernelGGL(big_eigen_kernel, one, dim3(64), 0, st, groups, prm, states, d_stats);
-        for (int pass = 0; pass < kPasses; ++pass) {
+        hipLaunchKernelGGL(big_moments_kernel, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, d_stats);
+        hipLaunchKernelGGL(big_lin_sweep_kernel<0>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, codes);
+        hipLaunchKernelGGL(big_collect_sweep_kernel<0>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, codes, cand);
+        for (int pass = 0; pass < kPasses; ++pass)  // (no-ops unless a candidate list overflowed)
             hipLaunchKernelGGL(big_select_sweep_kernel<0>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states);
-            hipLaunchKernelGGL(big_select_step_kernel, one, dim3(256), 0, st, states);
-        }
     }
-    hipLaunchKernelGGL(big_vectors_kernel, one, dim3(64), 0, st, hw, prm, states, d_stats);
-    for (int pass = 0; pass < kPasses; ++pass) {
+    hipLaunchKernelGGL(big_vectors_kernel, one, dim3(64), 0, st, hw, prm, d_tables, states, d_stats);
+    hipLaunchKernelGGL(big_lin_sweep_kernel<1>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, codes);
+    hipLaunchKernelGGL(big_collect_sweep_kernel<1>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, codes, cand);
+    for (int pass = 0; pass < kPasses; ++pass)  // (no-ops unless a candidate list overflowed)
         hipLaunchKernelGGL(big_select_sweep_kernel<1>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states);
-        hipLaunchKernelGGL(big_select_step_kernel, one, dim3(256), 0, st, states);
-    }
     hipLaunchKernelGGL(big_final_kernel, one, dim3(64), 0, st, prm, states, d_stats);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }

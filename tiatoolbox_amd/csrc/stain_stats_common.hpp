@@ -1124,7 +1124,7 @@ int launch_stain_stats_reg(const uint8_t* d_img, long n, long hw, const tia_stai
 long stain_stats_reg_pixel_limit();  // largest patch (pixels) the register-resident kernel holds
 // large single images: multi-workgroup sweeps (stain_stats_big.hip); d_ws holds n state blocks
 constexpr long kBigImagePixels = 4L * 256 * 256;
-size_t stain_stats_big_workspace_bytes(long n);
+size_t stain_stats_big_workspace_bytes(long n, long hw);
 int launch_stain_stats_big(const uint8_t* d_img, long n, long hw, const tia_stain_tables* d_tables, const tia_stain_params& prm,
                            double* d_stats, void* d_ws, hipStream_t st);
 
