@@ -424,6 +424,12 @@ def test_window_selection_equals_histogram_selection(he_patches, target_image):
             for other in (1, 2):  # histogram selection; window selection on the streaming kernel
                 b = dev.stain_stats(x, dev.make_params(select_mode=other, target_stain=target, target_maxc=np.array([[1.9, 1.0]]), **kw))
                 b = b.cpu().numpy()[:, :_lib.ST_CYCLES]
+                if batch.shape[1] * batch.shape[2] > 4 * 256 * 256 and name != "vahadane":
+                    # large images: select_mode 0 is the multi-workgroup path (stain_stats_big.hip), whose float64 moment sums are
+                    # merged in another order than the one-workgroup kernels' -- agreement to rounding, not bit for bit (the exact
+                    # order statistics themselves are selected on keys that differ in the last ulp)
+                    np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-10, err_msg=f"{name} {other} {batch.shape}")
+                    continue
                 same = (a == b) | (np.isnan(a) & np.isnan(b))
                 assert same.all(), (name, other, batch.shape, np.argwhere(~same)[:5], a[~same][:5], b[~same][:5])
             checked += a.shape[0]
@@ -570,12 +576,13 @@ def test_rgb2od_standalone_kernel_and_side_effect(uniform_patches):
     theirs = f32.copy()
     exp = ostain.rgb2od(theirs)
     got = rgb2od(f32)
-    assert got.dtype == exp.dtype and np.allclose(got, exp, rtol=2e-6, atol=0) and np.array_equal(f32, theirs)
+    # (NumPy's float32 log of x / 255 near 1 carries the cancellation's error: compare absolutely)
+    assert got.dtype == exp.dtype and np.allclose(got, exp, rtol=1e-6, atol=4e-7) and np.array_equal(f32, theirs)
     i64 = uniform_patches[0][:8, :8].astype(np.int64)
     assert np.allclose(rgb2od(i64.copy()), ostain.rgb2od(i64.copy()), rtol=1e-14, atol=0)
     assert np.allclose(rgb2od(i64.tolist()), ostain.rgb2od(i64.copy()), rtol=1e-14, atol=0)
     tf = torch.from_numpy(uniform_patches[0].copy()).cuda().float()
-    assert np.allclose(rgb2od(tf).cpu().numpy(), exp, rtol=2e-6, atol=0) and int((tf == 0).sum()) == 0
+    assert np.allclose(rgb2od(tf).cpu().numpy(), exp, rtol=1e-6, atol=4e-7) and int((tf == 0).sum()) == 0
     with pytest.raises(TypeError, match="numeric"):
         rgb2od(np.array([["a"]]))
 

@@ -74,10 +74,11 @@ def _rgb2od_any_dtype(img, *, mutate: bool):
         else:
             arr = np.where(arr == 0, 1, arr)
         t = torch.from_numpy(np.ascontiguousarray(arr)).to(_tensors.default_device())
-    work = t if t.is_floating_point() else t.to(torch.float64)
+    out_dtype = t.dtype if t.is_floating_point() else torch.float64  # the reference computes in the array's own floating type
+    work = t.to(torch.float64)
     if is_tensor and not mutate:
         work = torch.where(work == 0, torch.ones_like(work), work)
-    out = torch.clamp_min(-torch.log(work / 255), 1e-6)
+    out = torch.clamp_min(-torch.log(work / 255), 1e-6).to(out_dtype)  # float64 on the device, rounded once to the result type
     return out if is_tensor else out.cpu().numpy()
 
 
