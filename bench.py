@@ -198,6 +198,30 @@ def pmc_traffic(kernel_substr: str, stem: str, calls_per_forward: int | None = N
                        + _pass_commit(vals["file_FETCH_SIZE"]))}
 
 
+def pmc_mfma_busy(stem: str, kernel_substr: str) -> dict | None:
+    """Fraction of the run time the matrix pipes of the 1024 SIMDs were busy under a kernel, from this round's committed counter pass
+    (``profiles/*_<stem>_pmc_MFMA.txt``, ``scripts/pmc_mfma.sh``): ``SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8)``, dispatch-
+    weighted over every kernel whose name contains ``kernel_substr`` (both counters come from the SAME pass)."""
+    import re
+
+    files = sorted((ROOT / "profiles").glob(f"*_{stem}_pmc_MFMA.txt"))
+    note = " (the busy counter advances in steps of 2^28 cycles per dispatch: +-3 % on these launches)"
+    if not files:
+        return None
+    busy = act = 0.0
+    for line in files[-1].read_text().splitlines():
+        m = re.search(r"(SQ_VALU_MFMA_BUSY_CYCLES|GRBM_GUI_ACTIVE) mean=\s*([0-9.]+) n=\s*(\d+)\s+(.*)", line)
+        if m and kernel_substr in m.group(4):
+            if m.group(1) == "GRBM_GUI_ACTIVE":
+                act += float(m.group(2)) * int(m.group(3))
+            else:
+                busy += float(m.group(2)) * int(m.group(3))
+    if act == 0.0:
+        return None
+    return {"mfma_busy": round(busy / (1024.0 * act / 8.0), 4),
+            "source": f"profiles/{files[-1].name}: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs){note}{_pass_commit(files[-1].name)}"}
+
+
 def _pass_commit(profile_name: str) -> str:
     """The commit whose code a committed counter pass measured (``profiles/<tag>_COMMIT.txt``, written when the pass is copied in)."""
     note = ROOT / "profiles" / (profile_name.split("_")[0] + "_COMMIT.txt")
@@ -619,6 +643,10 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
         # launches, "trunk<mb>" otherwise)
         stem_name = ("wino" if dominant == "conv3x3_wino_kernel" else "trunk") + ("" if mb == 1024 else str(mb))
         pmc_c = pmc_traffic(dominant, stem_name, dk["launches"]) if hw == 256 else None
+        busy = pmc_mfma_busy(stem_name, dominant) if hw == 256 else None
+        if busy is not None:
+            roofline["mfma_busy"] = busy["mfma_busy"]
+            roofline["mfma_busy_source"] = busy["source"]
         if pmc_c is not None:
             roofline["traffic"] = round(pmc_c["bytes"])
             roofline["traffic_source"] = pmc_c["source"] + (f" (workload: scripts/perf_wino.py {mb} 256 pmc)" if dominant == "conv3x3_wino_kernel"
@@ -697,6 +725,10 @@ def bench_patch(args: argparse.Namespace) -> dict | None:
                                "frac": round(k["tflops"] / MFMA_PEAK_TFLOPS["float32"], 5), "launches_per_forward": k["launches"],
                                "launch_ms": round(k["seconds"] / k["launches"] * 1e3, 4), "algorithmic_flops": k["flops"] // k["launches"]}
             pmc_d = pmc_traffic("conv3x3_spatial_kernel", "trunk" if mb == 1024 else f"trunk{mb}", 13) if hw == 256 else None
+            busy_d = pmc_mfma_busy("trunk" if mb == 1024 else f"trunk{mb}", "conv3x3_spatial_kernel") if hw == 256 else None
+            if busy_d and "conv3x3_spatial_kernel" in dkern:
+                dkern["conv3x3_spatial_kernel"]["mfma_busy"] = busy_d["mfma_busy"]
+                dkern["conv3x3_spatial_kernel"]["mfma_busy_source"] = busy_d["source"]
             if pmc_d and "conv3x3_spatial_kernel" in dkern:
                 dkern["conv3x3_spatial_kernel"]["traffic"] = round(pmc_d["bytes"])
                 dkern["conv3x3_spatial_kernel"]["traffic_source"] = pmc_d["source"]
