@@ -306,7 +306,10 @@ def bench_semantic(args) -> dict | None:
             "other_kernels": {
                 "finalize_kernel": {"bound": "hbm", "achieved": round(fin_bytes / t_fin / 1e9, 1), "unit": "GB/s",
                                     "frac": round(fin_bytes / t_fin / 1e9 / HBM_PEAK_GBS, 4), "launch_ms": round(t_fin * 1e3, 4),
-                                    "algorithmic_bytes": fin_bytes, **_traffic("canvas", ("finalize_kernel",), "finalize_kernel")},
+                                    "algorithmic_bytes": fin_bytes, **_traffic("canvas", ("finalize_kernel",), "finalize_kernel"),
+                                    "note": ("`frac` is the algorithmic bytes over the kernel time against the HBM peak; the rows it reads were written "
+                                             "by the preceding row_merge launch and are served from L2 / Infinity Cache (counter traffic BELOW the "
+                                             "algorithmic bytes): a cache-resident rate, not an HBM rate")},
                 "gather_patches_kernel": {"bound": "hbm", "achieved": round(gather_bytes / t_gather / 1e9, 1), "unit": "GB/s",
                                           "frac": round(gather_bytes / t_gather / 1e9 / HBM_PEAK_GBS, 4),
                                           "launch_ms": round(t_gather * 1e3, 4), "algorithmic_bytes": gather_bytes,
@@ -430,7 +433,9 @@ def bench_hovernet(args) -> dict | None:
             "frac": round(alg / t_proc / 1e9 / HBM_PEAK_GBS, 5),
             **_traffic("hover", ("tia::",), "sobel_energy_tile_kernel"), "algorithmic_bytes": alg,
             "launch_ms": round(t_proc * 1e3, 3),
-            "workload": f"{m} synthetic head maps of 164x164 with ~{n_inst:.0f} nuclei each, 20 B/px (SURVEY 8(d))",
+            "workload": (f"{m} synthetic head maps of 164x164 with ~{n_inst:.0f} nuclei each (utils.synth.hover_head_maps), 20 B/px (SURVEY 8(d)); "
+                         "NOT the maps `value` post-processes: the engine run feeds a seeded RANDOM-weight HoVer-Net whose noise-like heads give a few "
+                         "huge blobs per tile -- a pathological watershed (~10 x slower than on these maps), so `value` understates a trained model"),
             "postproc_incl_tables_ms": round(t_post * 1e3, 3), "postproc_tiles_per_s": round(m / t_post, 1),
             "backbone": {"bound": "mfma", "what": ("HoVer-Net fast forward per 256^2 tile, batch 32: "
                                                    + type(fmodel).__name__ + (" (every convolution hand-written: 105 on the MFMA "
@@ -535,7 +540,8 @@ def bench_vahadane(args) -> dict | None:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[4]: VahadaneNormalizer (dictionary learning on the device, sklearn "
                                 f"DictionaryLearning restated) + StainAugmentor over {n} synthetic 256x256x3 patches per GPU "
-                                f"(65 536 over 8 GPUs); statistics and dictionary f64, per-pixel {args.precision}"),
+                                f"(65 536 over 8 GPUs); statistics and dictionary f64, per-pixel {args.precision}; BASELINE's 'fp16 OD path' is served "
+                                f"as float32 / float64 ARITHMETIC with half as an OUTPUT format only (extras.per_pixel_float32): no fp16 optical densities"),
                    "patches_per_gpu": n, "parallelism": f"dp{world_size} (patch-sharded, no collective)"},
         "roofline": {"kernel": "vahadane_dl_kernel + stain_stats_kernel<false> (Vahadane statistics: dictionary learning by replay, then the common tail)",
                      "bound": "hbm", "achieved": round(px * 3 / t_stats / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
