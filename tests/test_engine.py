@@ -780,6 +780,32 @@ def test_winograd_conv_matches_torch_cpu_fp32():
 
 
 @pytest.mark.gpu
+def test_winograd_persistent_form_is_bit_identical_to_one_block_per_workgroup():
+    """Launches with at least two rounds of (pixel block, channel tile) items per CU take the PERSISTENT form of the Winograd kernel
+    (a workgroup per CU walks its items, the next item's first operands requested behind the current one's last steps, one-tile
+    epilogue); smaller launches take one block per workgroup.  Same sums in the same order: the full batch must equal the batch
+    computed in small chunks BIT FOR BIT, incl. clipped blocks, two and three channel tiles, the shortest slice count (cin 32),
+    item counts that do not divide by the workgroup count, and every epilogue variant."""
+    from tiatoolbox_amd.models.architecture.fused import hip_conv3x3_wino, pack_conv_weights_wino
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for n, cin, cout, h, w in ((41, 64, 64, 64, 64), (75, 128, 128, 32, 32), (280, 256, 192, 16, 16), (47, 32, 64, 62, 50),
+                               (33, 64, 128, 64, 64)):
+        conv = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=True).cuda()
+        up = pack_conv_weights_wino(conv)
+        x = torch.randn((n, cin, h, w), device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+        res = torch.randn((n, cout, h, w), device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+        tiles = n * ((h + 15) // 16) * ((w + 15) // 16) * (cout // 64)
+        assert tiles >= 512, "the full batch must qualify for the persistent form on a 256-CU device"
+        chunk = max(1, 400 // (tiles // n))  # chunks of fewer than 512 items: one block per workgroup
+        for use_res, relu in ((False, False), (True, True)):
+            full = hip_conv3x3_wino(x, up, conv.bias, res if use_res else None, padding=1, relu=relu)
+            parts = [hip_conv3x3_wino(x[i:i + chunk], up, conv.bias, res[i:i + chunk] if use_res else None, padding=1, relu=relu)
+                     for i in range(0, n, chunk)]
+            assert torch.equal(full, torch.cat(parts)), (n, cin, cout, h, w, use_res, relu)
+
+
+@pytest.mark.gpu
 def test_winograd_patch_predictor_within_tolerance_of_direct():
     """The engine's default ``conv_algo="auto"``: the float32 3x3 / stride-1 block convolutions through F(2x2, 3x3).  The
     probabilities stay within 1e-5 of the audit mode ``conv_algo="direct"`` (the reference's own fp16 tolerance is 1e-3,

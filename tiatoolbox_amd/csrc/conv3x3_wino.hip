@@ -34,8 +34,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../../include/tiatoolbox_amd.h"
 #include "conv3x3_wino.hpp"
+#include "dev_env.hpp"
 
 namespace {
 
@@ -123,6 +126,11 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 #ifndef TIA_WINO_TIMING
 #define TIA_WINO_TIMING 0
 #endif
+// Epilogue ablations (developer builds only: -DTIA_WINO_ABLATE=1, then TIA_WINO_ABL bits 128: nothing after the column transform,
+// 256: no exchange, 512: no read-out) -- the persistent form has no registers left for the timing build's counters.
+#ifndef TIA_WINO_ABLATE
+#define TIA_WINO_ABLATE 0
+#endif
 #if TIA_WINO_TIMING
 #define WSTAMP(var) { const long long now_ = clock64(); var += now_ - tl_; tl_ = now_; }
 #define WSTAMP_ROLE(mfma_if_pg0) { const long long now_ = clock64(); if ((pg == 0) == (mfma_if_pg0)) tm_comp += now_ - tl_; else tm_load += now_ - tl_; tl_ = now_; }
@@ -131,7 +139,11 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 #define WSTAMP_ROLE(x)
 #endif
 
-template <typename GEO, int NSTAGE>
+// PERSIST: one workgroup per CU walks a list of (pixel block, 64-channel tile) items.  The flattened step sequence simply runs on
+// across items: the last two steps of an item request the NEXT item's first patch slice and first two weight stages instead of its
+// own, so the ~8 k cycles a fresh workgroup spends waiting for its first HBM round trip (and the dispatch of a workgroup per item)
+// disappear behind matrix work; the epilogue's 64 KB (exchange area, then tile) lie over the patch buffer the next item does not need yet.
+template <typename GEO, int NSTAGE, bool PERSIST>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                               const float* __restrict__ bias, const float* __restrict__ res,
                                                               float* __restrict__ y, WinoDims d, int relu, int m_tiles, int tiles_x,
@@ -144,27 +156,56 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     constexpr int NA = (A_UNITS + NT - 1) / NT;                   // DMA pieces per patch: 3 | 4
     constexpr int A_BYTES = A_UNITS * 16;
     constexpr int W_STAGE = 16 * 2048;                            // 16 positions x [8 channels][64 columns] float32
-    constexpr int DUMP = 2 * A_BYTES + NSTAGE * W_STAGE;          // 1 KB the idle waves of the last patch piece write their zeros to
-    constexpr int EPI_BYTES = 2 * BLOCK_PX * BN * 4;              // the epilogue's two float32 tiles (one per position group)
-    constexpr int LDS_BYTES = DUMP + 1024 > EPI_BYTES ? DUMP + 1024 : EPI_BYTES;
+    // LDS map.  one block per workgroup: [patch 0][patch 1][stage 0][stage 1][dump], the epilogue's 64 KB alias the front of it.
+    // PERSIST: [patch 0][stage 0][stage 1][patch 1 ...] with the epilogue's 64 KB starting at patch 1 (patch 0 and the stages
+    // hold the next item's first operands while the epilogue runs), the dump KB behind the tile.
+    constexpr int EPI_TILE = BLOCK_PX * BN * 4;
+    constexpr int OFF_A1 = PERSIST ? A_BYTES + NSTAGE * W_STAGE : A_BYTES;
+    constexpr int OFF_W = PERSIST ? A_BYTES : 2 * A_BYTES;
+    constexpr int OFF_EPI = PERSIST ? OFF_A1 : 0;
+    constexpr int EPI_BYTES = EPI_TILE;                            // the epilogue's exchange area, then its float32 tile
+    constexpr int MAIN_END = PERSIST ? OFF_A1 + A_BYTES : 2 * A_BYTES + NSTAGE * W_STAGE;
+    constexpr int DUMP = PERSIST ? (MAIN_END > OFF_EPI + EPI_BYTES ? MAIN_END : OFF_EPI + EPI_BYTES) : MAIN_END;  // 1 KB the idle waves of the last patch piece write their zeros to
+    constexpr int LDS_BYTES = DUMP + 1024 > OFF_EPI + EPI_BYTES ? DUMP + 1024 : OFF_EPI + EPI_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
     static_assert(NA >= 2 && NA <= 6, "patch pieces are spread over the two steps of a slice");
     static_assert(NSTAGE == 2, "weight ring: two stages (a third one was measured and lost, profiles/r05d_perf_wino256_3stage.txt)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #if TIA_WINO_TIMING
-    long long tm_pro = 0, tm_comp = 0, tm_load = 0, tm_wait = 0, tm_epi = 0, tl_ = clock64();
+    long long tm_pro = 0, tm_comp = 0, tm_load = 0, tm_wait = 0, tm_epi = 0, tm_e0 = 0, tm_e1 = 0, tl_ = clock64();
+    int n_items_ = 0;
     const long long t0c_ = tl_, t0w_ = wall_clock64();
 #endif
 
     const int bid = blockIdx.x;
     const int per_xcd = (m_tiles + 7) / 8;
-    const int mt_id = (bid % 8) * per_xcd + bid / 8;  // every XCD walks a contiguous range of pixel blocks
-    if (mt_id >= m_tiles) return;
-    const int img = RT ? 0 : (GEO::G == 1 ? mt_id / tiles_per_image : mt_id * GEO::G);  // (WR: windows carry their own image)
-    const int trem = GEO::G == 1 ? mt_id - img * tiles_per_image : 0;
-    const int ty0 = (trem / tiles_x) * GEO::TH;
-    const int tx0 = (trem - (trem / tiles_x) * tiles_x) * GEO::TW;
-    const int cb = blockIdx.y, n0 = cb * BN;
+    const int n_cs = d.cin >> 4, n_cb = d.cout >> 6;
+    // an ITEM = (pixel block mt_id, channel tile cb).  One block per workgroup: the grid is the item list.  PERSIST: workgroup q of XCD x
+    // (consecutive workgroup ids go round the XCDs) takes items q, q + Q, .. of the XCD's contiguous range of pixel blocks, channel tile
+    // fastest -- the workgroups of an XCD that run at the same time share patches (one HBM read, then L2 hits).
+    int item = 0, item_end = 1, item_step = 1, mt_lo = 0;
+    if constexpr (PERSIST) {
+        mt_lo = (bid & 7) * per_xcd;
+        const int mt_hi = mt_lo + per_xcd < m_tiles ? mt_lo + per_xcd : m_tiles;
+        item = bid >> 3, item_step = (int)(gridDim.x >> 3), item_end = (mt_hi - mt_lo) * n_cb;
+        if (item >= item_end) return;
+    } else {
+        if ((bid % 8) * per_xcd + bid / 8 >= m_tiles) return;  // every XCD walks a contiguous range of pixel blocks
+    }
+    int mt_id, cb, img, ty0, tx0;
+    auto decode = [&](int it) {  // (wave-uniform: scalar registers)
+        if constexpr (PERSIST) {
+            const int q = it / n_cb;
+            mt_id = mt_lo + q, cb = it - q * n_cb;
+        } else {
+            mt_id = (bid % 8) * per_xcd + bid / 8, cb = (int)blockIdx.y;
+        }
+        img = RT ? 0 : (GEO::G == 1 ? mt_id / tiles_per_image : mt_id * GEO::G);  // (WR: windows carry their own image)
+        const int trem = GEO::G == 1 ? mt_id - img * tiles_per_image : 0;
+        ty0 = (trem / tiles_x) * GEO::TH;
+        tx0 = (trem - (trem / tiles_x) * tiles_x) * GEO::TW;
+    };
+    decode(item);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // (kept in a vector register: with a scalar wave index the role
     // branches below become scalar branches and the register allocator spills 106 registers over them; 238 without)
     const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);  // the same number in a scalar register: LDS-DMA destinations (M0) and offsets
@@ -177,6 +218,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     // patch staging: unit U = NT r + tid -> image U / IMG, row (U % IMG) / ROW, pixel pair (.. % ROW) / 9, pixel and unit-of-slice from
     // the rest (layout above); outside the image / patch, padding units: an out-of-range offset (the DMA writes zeros)
     int cen[NA];
+    auto make_cen = [&] {  // for the item `decode` has just set
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
         const int un = NT * r + tid;
@@ -203,39 +245,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
             cen[r] = inside ? (((img + g) * d.h + iy) * d.w + ix) * d.cin * 4 + 16 * chunk : OOB;
         }
     }
-    const int n_cs = d.cin >> 4, n_cb = d.cout >> 6;
+    };
+    make_cen();
     // weight staging: a stage = 16 position blocks of 2 KB; DMA round q (0..3) moves positions 4 q + (wave >> 1): per lane the offset
     // inside the block + (wave >> 1) positions; the rest is scalar
     const int w_voff = (wave_s & 1) * 1024 + lane * 16 + (wave_s >> 1) * d.pos_stride;
 
     unsigned char* const abuf0 = smem;
-    unsigned char* const wst0 = smem + 2 * A_BYTES;
+    constexpr int A_PITCH = OFF_A1;  // bytes between the two patch buffers
+    unsigned char* const wst0 = smem + OFF_W;
     auto dma_a = [&](int buf, int r, int cs) {
-#if TIA_WINO_TIMING
+#if TIA_WINO_TIMING || TIA_WINO_ABLATE
         if ((d.abl & 2) && cs > 0) return;
 #endif
         if constexpr (RT) {
             if (NT * r >= d.wg * d.wimg) return;  // (scalar) pieces past the block's windows: nothing of them is ever read
         }
-        unsigned char* dst = (NT * r + wave_s * 64 >= A_UNITS) ? smem + DUMP : abuf0 + buf * A_BYTES + r * (NT * 16) + wave_s * 1024;
+        unsigned char* dst = (NT * r + wave_s * 64 >= A_UNITS) ? smem + DUMP : abuf0 + buf * A_PITCH + r * (NT * 16) + wave_s * 1024;
         dma16(rx, dst, cen[r], cs * 64);
     };
     // weights of flattened step s = 2 cs + h8 (h8: which 8 channels of the 16-channel slice)
-    auto dma_w = [&](int stage, int s) {
-#if TIA_WINO_TIMING
+    auto dma_w = [&](int stage, int s, int cbi) {
+#if TIA_WINO_TIMING || TIA_WINO_ABLATE
         if ((d.abl & 1) && s > 0) return;
 #endif
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma16(ru, wst0 + stage * W_STAGE + q * 8192 + wave_s * 1024, w_voff, 4 * q * d.pos_stride + (s * n_cb + cb) * 2048);
+        for (int q = 0; q < 4; ++q) dma16(ru, wst0 + stage * W_STAGE + q * 8192 + wave_s * 1024, w_voff, 4 * q * d.pos_stride + (s * n_cb + cbi) * 2048);
     };
 
     f32x16 acc[4][2];  // [position j of the wave's row][channel tile]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][ct][e] = 0.0f;
+    // (a macro, not a lambda: with `acc` captured by a lambda the register allocator ends up 50 registers higher and spills)
+#define TIA_WINO_CLEAR_ACC()                                              \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                      \
+        _Pragma("unroll") for (int ct_ = 0; ct_ < 2; ++ct_)               \
+            _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) acc[j_][ct_][e_] = 0.0f
 
     // the lane's tile: MFMA row = lane & 31 -> tile 32 wm + (lane & 31); its 4 x 4 input tile starts at patch pixel (2 ty, 2 tx); the
     // lane's k values of a step are channels 8 h8 + 4 hi + 0..3 = unit 2 h8 + hi of the pixel
@@ -277,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     const bool plus = irow == 1;
     const int fa_a = fa + ra_off, fa_b = fa + rb_off;
     auto patch_reads = [&](int s) {  // step s: slice s >> 1 (buffer (s >> 1) & 1), channels 8 (s & 1) ..
-        const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + ((s >> 1) & 1) * A_BYTES) + 2 * (s & 1);
+        const u32x4* sa = reinterpret_cast<const u32x4*>(abuf0 + ((s >> 1) & 1) * A_PITCH) + 2 * (s & 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) pa[c] = sa[fa_a + px_unit(c)], pb[c] = sa[fa_b + px_unit(c)];
     };
@@ -308,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         }
     };
     auto mfma_j = [&](int j) {
-#if TIA_WINO_TIMING
+#if TIA_WINO_TIMING || TIA_WINO_ABLATE
         if (d.abl & 64) return;  // no MFMAs
 #endif
 #pragma unroll
@@ -321,7 +364,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     long long tm_vm = 0;
 #endif
     auto step_end = [&] {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // (the builtin, not inline assembly: the compiler's own wait-count bookkeeping sees it -- behind an opaque asm it assumes the LDS-DMA
+        // requests are still in flight and puts a vmcnt(0) in front of the epilogue's LDS accesses, i.e. waits for the residual loads)
+        wait_vm_lgkm0<0>();
 #if TIA_WINO_TIMING
         { const long long now_ = clock64(); tm_vm += now_ - tl_; }
 #endif
@@ -329,20 +374,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         asm volatile("" ::: "memory");
     };
 
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
     // prologue: patch of slice 0, weights of steps 0 and 1; the operands of step 0
     const int n_steps = 2 * n_cs;
 #pragma unroll
     for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
-    dma_w(0, 0);
-    dma_w(1, 1);
+    dma_w(0, 0, cb);
+    dma_w(1, 1, cb);
     step_end();
+    TIA_WINO_CLEAR_ACC();
+    for (bool first_item = true;; first_item = false) {  // (one round unless PERSIST)
     patch_reads(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) weight_reads(0, j);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     transform();
-    step_end();  // (every wave has read stage 0's weights: step 0 may refill it)
+    // (every wave has read stage 0's weights: step 0 may refill it; PERSIST, later items: every wave has left the epilogue's tile, which
+    // step 0's patch DMA overwrites -- the epilogue's global stores need not have landed for that)
+    if (first_item) step_end(); else lds_barrier();
     WSTAMP(tm_pro)
+    // PERSIST: the item after this one is decoded in step n_steps - 3 (behind that step's MFMAs: every patch request of the current item
+    // has been issued by then, so its offsets `cen` can be overwritten) and requested by the last slice
+    const int cur_mt = mt_id, cur_cb = cb, cur_img = img, cur_ty0 = ty0, cur_tx0 = tx0;
+    const bool has_next = PERSIST && item + item_step < item_end;
     // The two waves of a SIMD (w and w + 4: position rows {0, 1} and {2, 3}) take the step's non-MFMA work at DIFFERENT times: rows
     // {2, 3} issue the MFMAs of j = 0, 1 first and request DMAs / patch reads after them, rows {0, 1} the other way round -- while one
     // wave of the SIMD issues requests the other one feeds the matrix pipe (after a barrier both used to start with ~40 scalar /
@@ -350,10 +408,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     for (int k = 0; k < n_steps; ++k) {
         const bool next = k + 1 < n_steps;
         auto requests = [&] {
-            if (k + 2 < n_steps) dma_w(k & 1, k + 2);
-            if ((k & 1) == 0 && k + 2 < n_steps) {  // first step of slice k / 2: the next slice's patch into the other buffer
+            if (k + 2 < n_steps) {
+                dma_w(k & 1, k + 2, cur_cb);
+                if ((k & 1) == 0) {  // first step of slice k / 2: the next slice's patch into the other buffer
 #pragma unroll
-                for (int r = 0; r < NA; ++r) dma_a(((k >> 1) & 1) ^ 1, r, (k >> 1) + 1);
+                    for (int r = 0; r < NA; ++r) dma_a(((k >> 1) & 1) ^ 1, r, (k >> 1) + 1);
+                }
+            } else if (PERSIST && has_next) {  // the last slice (n_cs is even: it sits in buffer 1): the next item's first operands
+                dma_w(k & 1, k + 2 - n_steps, cb);
+                if ((k & 1) == 0) {
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
+                }
             }
             if (next) patch_reads(k + 1);
         };
@@ -369,6 +435,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
             mma(0), mma(1);
         }
         mma(2), mma(3);
+        if constexpr (PERSIST) {
+            if (has_next && k == n_steps - 3) {
+                item += item_step;
+                decode(item);
+                make_cen();
+            }
+        }
         WSTAMP(tm_comp)
         if (next) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -388,17 +461,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         z[0][ct] = acc[0][ct] + acc[1][ct] + acc[2][ct];
         z[1][ct] = acc[1][ct] - acc[2][ct] - acc[3][ct];
     }
-    // Two float32 tiles [BLOCK_PX][64]: A (smem + 0) collects rows i = 0, 1, B (smem + 64 KB) rows 2, 3.
-    //   round 1 (stores):  i = 0: A[y0] = Z(0)    i = 1: A[y1] = Z(1)     i = 2: B[y0] = Z(2)     i = 3: B[y1] = -Z(3)
-    //   round 2 (adds):                           i = 1: A[y0] += Z(1)    i = 2: B[y1] -= Z(2)
-    // (y0 / y1 = the tile's output rows 2 ty / 2 ty + 1, columns 2 tx + b), and the read-out adds A + B:
-    //   Y[0][b] = (Z0 + Z1) + Z2, Y[1][b] = Z1 + (-Z3 - Z2).  The residual and bias of all four chunks of a thread are requested BEFORE
-    // the tiles are written: one exposed round trip.
+    // The four waves of a tile half hold Z(i) in the SAME lane layout, so the middle rows travel lane to lane: waves i = 1, 2 park
+    // Z(1), Z(2) in a 64 KB exchange area (16 conflict-free ds_write_b128 per lane), wave i = 0 forms Y[0][b] = (Z0 + Z1) + Z2 and wave
+    // i = 3 Y[1][b] = Z1 + (-Z3 - Z2) in registers (16 + 16 ds_read_b128), and only those FINAL rows go through the float32 tile
+    // [BLOCK_PX][64] (it takes the exchange area's place) for the 16-byte read-out.  (The first form moved every Z through two such
+    // tiles with 4-byte stores and read-modify-writes: 1,024 LDS instructions per workgroup in its two rounds against 448 here, and
+    // twice the tile bytes to read out.)  (y0 / y1 = the tile's output rows 2 ty / 2 ty + 1, columns 2 tx + b.)  The residual and
+    // bias of all four chunks of a thread are requested BEFORE the exchange: one exposed round trip.
+    if (TIA_WINO_ABLATE && (d.abl & 128)) {
+        if (d.n < 0) y[tid] = z[0][0][0] + z[1][1][5] + z[0][1][3] + z[1][0][7];  // (never: keeps the accumulators alive)
+    } else {
     // block pixel m = image m / (TH TW), (ty0 + (m % (TH TW)) / TW, tx0 + m % TW)
     constexpr int CHUNKS = BLOCK_PX * BN / 8, ITER = CHUNKS / NT;  // 2048 chunks of 8 columns, 4 per thread
     static_assert(CHUNKS % NT == 0 && NT % (BN / 8) == 0, "whole chunk rounds; a thread keeps its column chunk");
     const int cc = tid % (BN / 8);
-    const int col0 = n0 + cc * 8;
+    const int col0 = cur_cb * BN + cc * 8;
     float4 b0 = float4{0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0;
     if (bias) {
         b0 = *reinterpret_cast<const float4*>(bias + col0);
@@ -413,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
             const int tt = row >> 2, wt = d.wty * d.wtx;
             const int g = fdiv(tt, wt, d.inv_wt), rr = tt - g * wt;
             const int tyy = fdiv(rr, d.wtx, d.inv_wtx), txx = rr - tyy * d.wtx;
-            const int win = mt_id * d.wg + g;
+            const int win = cur_mt * d.wg + g;
             const int wi = fdiv(win, d.wins_x * d.wins_y, d.inv_wins), wr = win - wi * d.wins_x * d.wins_y;
             const int wy = fdiv(wr, d.wins_x, d.inv_wins_x), wx = wr - wy * d.wins_x;
             const int oy = 2 * (wy * d.wty + tyy) + ((row >> 1) & 1), ox = 2 * (wx * d.wtx + txx) + (row & 1);
@@ -421,9 +498,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
             mpix[it] = live ? (wi * d.ho + oy) * d.wo + ox : -1;
         } else {
             const int g = row / (GEO::TH * GEO::TW), rg = row - g * (GEO::TH * GEO::TW);
-            const int oy = ty0 + rg / GEO::TW, ox = tx0 + rg % GEO::TW;
-            const bool live = oy < d.ho && ox < d.wo && img + g < d.n;
-            mpix[it] = live ? ((img + g) * d.ho + oy) * d.wo + ox : -1;
+            const int oy = cur_ty0 + rg / GEO::TW, ox = cur_tx0 + rg % GEO::TW;
+            const bool live = oy < d.ho && ox < d.wo && cur_img + g < d.n;
+            mpix[it] = live ? ((cur_img + g) * d.ho + oy) * d.wo + ox : -1;
         }
         const bool live = mpix[it] >= 0;
         rq[it][0] = rq[it][1] = u32x4{0u, 0u, 0u, 0u};
@@ -433,14 +510,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
             rq[it][1] = rp[1];
         }
     }
-    float* tile = reinterpret_cast<float*>(smem) + pg * (BLOCK_PX * BN);
-    auto lds_barrier = [] {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    // round r of this wave: output row `a` of its tiles, stored (sign `neg`) or added
-    auto to_tile = [&](int a, bool add, bool neg) {
+    WSTAMP(tm_e0)
+    float* tile = reinterpret_cast<float*>(smem + OFF_EPI);
+    if (!(TIA_WINO_ABLATE && (d.abl & 256))) {   // exchange area: [Z(1) | Z(2)][tile half][q 16][lane 64] float4; unit q of a lane = z[q >> 3][(q >> 2) & 1][4 (q & 3) ..]
+        unsigned xoff = OFF_EPI + (wm * (16 * 64) + lane) * 16;
+        asm volatile("" : "+v"(xoff));  // ONE base register + immediate offsets (left alone, the compiler hoists 16 addresses out of the
+                                        // item loop and spills them)
+        float4* const xch = reinterpret_cast<float4*>(smem + xoff);
+        constexpr int SLOT = 2 * 16 * 64;
+        if (irow == 1 || irow == 2) {
+            float4* dst = xch + (irow - 1) * SLOT;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x16& zz = z[q >> 3][(q >> 2) & 1];
+                dst[q * 64] = float4{zz[4 * (q & 3)], zz[4 * (q & 3) + 1], zz[4 * (q & 3) + 2], zz[4 * (q & 3) + 3]};
+            }
+        }
+        lds_barrier();
+        // Y[0] = (Z0 + Z1) + Z2 by wave i = 0, Y[1] = Z1 + (-Z3 - Z2) by wave i = 3 (two exec-masked blocks: one block with a per-lane
+        // select computes both forms for every element)
+        auto combine = [&](bool top) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 z1 = xch[q * 64], z2 = xch[SLOT + q * 64];
+                f32x16& zz = z[q >> 3][(q >> 2) & 1];
+                const float a1[4] = {z1.x, z1.y, z1.z, z1.w}, a2[4] = {z2.x, z2.y, z2.z, z2.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = zz[4 * (q & 3) + k];
+                    zz[4 * (q & 3) + k] = top ? (v + a1[k]) + a2[k] : a1[k] + (-v - a2[k]);
+                }
+            }
+        };
+        if (irow == 0) combine(true);
+        if (irow == 3) combine(false);
+        lds_barrier();  // every exchange read has returned: the tile may take the area's place
+    }
+    // output row `a` of this wave's tiles -> the tile
+    auto to_tile = [&](int a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int tt = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * hi;  // MFMA result row -> tile
@@ -456,32 +563,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    float* p = tile + (m00 + a * ASTEP + b) * BN + ct * 32 + (lane & 31);
-                    const float v = neg ? -z[b][ct][e] : z[b][ct][e];
-                    *p = add ? *p + v : v;
-                }
+                for (int ct = 0; ct < 2; ++ct) tile[(m00 + a * ASTEP + b) * BN + ct * 32 + (lane & 31)] = z[b][ct][e];
         }
     };
-    // (irow: 0 -> A[y0] = Z; 1 -> A[y1] = Z; 2 -> B[y0] = Z; 3 -> B[y1] = -Z)
-    to_tile(irow & 1, false, irow == 3);
+    if (irow == 0) to_tile(0);
+    if (irow == 3) to_tile(1);
     lds_barrier();
-    if (irow == 1) to_tile(0, true, false);   // A[y0] += Z(1)
-    if (irow == 2) to_tile(1, true, true);    // B[y1] -= Z(2)
-    lds_barrier();
-    const float* t0 = reinterpret_cast<const float*>(smem);
-    const float* t1 = t0 + BLOCK_PX * BN;
+    WSTAMP(tm_e1)
+    const float* t0 = reinterpret_cast<const float*>(smem + OFF_EPI);
+    if (!(TIA_WINO_ABLATE && (d.abl & 512)))
+    {
+        // Every chunk's value is finished (residual consumed) BEFORE the first store: loads and stores share vmcnt on gfx9 and may retire
+        // out of order against each other, so a load result used behind a store costs an s_waitcnt vmcnt(0) -- the store's round trip,
+        // once per chunk in the first form of this loop.
+        float4 o[ITER][2];
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int row = (tid + NT * it) / (BN / 8);
-        const float4 p0 = *reinterpret_cast<const float4*>(t0 + row * BN + cc * 8), p1 = *reinterpret_cast<const float4*>(t0 + row * BN + cc * 8 + 4);
-        const float4 q0 = *reinterpret_cast<const float4*>(t1 + row * BN + cc * 8), q1 = *reinterpret_cast<const float4*>(t1 + row * BN + cc * 8 + 4);
-        // (group 0's sum + group 1's sum) + bias: Y[0][b] = (Z0 + Z1) + Z2, Y[1][b] = Z1 + (-Z2 - Z3)
-        float v[8] = {(p0.x + q0.x) + b0.x, (p0.y + q0.y) + b0.y, (p0.z + q0.z) + b0.z, (p0.w + q0.w) + b0.w,
-                      (p1.x + q1.x) + b1.x, (p1.y + q1.y) + b1.y, (p1.z + q1.z) + b1.z, (p1.w + q1.w) + b1.w};
-        if (mpix[it] >= 0) {
-            float* yo = y + (long)mpix[it] * d.cout + col0;
-            if (res) {
+        for (int it = 0; it < ITER; ++it) {
+            const int row = (tid + NT * it) / (BN / 8);
+            const float4 p0 = *reinterpret_cast<const float4*>(t0 + row * BN + cc * 8), p1 = *reinterpret_cast<const float4*>(t0 + row * BN + cc * 8 + 4);
+            float v[8] = {p0.x + b0.x, p0.y + b0.y, p0.z + b0.z, p0.w + b0.w, p1.x + b1.x, p1.y + b1.y, p1.z + b1.z, p1.w + b1.w};
+            if (res) {  // (dead pixels: zeros, never stored)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     v[k] += __uint_as_float(rq[it][0][k]);
@@ -492,16 +593,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.0f ? v[k] : 0.0f;
             }
-            *reinterpret_cast<float4*>(yo) = float4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<float4*>(yo + 4) = float4{v[4], v[5], v[6], v[7]};
+            o[it][0] = float4{v[0], v[1], v[2], v[3]};
+            o[it][1] = float4{v[4], v[5], v[6], v[7]};
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            if (mpix[it] >= 0) {
+                float4* yo = reinterpret_cast<float4*>(y + (long)mpix[it] * d.cout + col0);
+                yo[0] = o[it][0];
+                yo[1] = o[it][1];
+            }
         }
     }
+    }
+#if TIA_WINO_TIMING
+    ++n_items_;
+#endif
+    if (!has_next) break;
+    TIA_WINO_CLEAR_ACC();
+    WSTAMP(tm_epi)
+    }  // items
+#undef TIA_WINO_CLEAR_ACC
 #if TIA_WINO_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WSTAMP(tm_epi)
     if ((threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.y == 0 && blockIdx.x == 64)
-        printf("wino wg %d wave %d (cin %d, abl %d): prologue %lld  MFMA phases %lld  load phases %lld  waits %lld (of which before the barrier %lld)  epilogue %lld  (steps %d) | shader clock %.0f MHz\n",
-               (int)blockIdx.x, (int)(threadIdx.x >> 6), d.cin, d.abl, tm_pro, tm_comp, tm_load, tm_wait, tm_vm, tm_epi, 2 * n_cs,
+        printf("wino wg %d wave %d (cin %d, abl %d, %d items): prologue %lld  MFMA phases %lld  load phases %lld  waits %lld (of which before the barrier %lld)  epilogue: requests + column transform %lld, rounds %lld, read-out %lld  (steps %d) | shader clock %.0f MHz\n",
+               (int)blockIdx.x, (int)(threadIdx.x >> 6), d.cin, d.abl, n_items_, tm_pro, tm_comp, tm_load, tm_wait, tm_vm, tm_e0, tm_e1, tm_epi, 2 * n_cs,
                100.0 * (double)(clock64() - t0c_) / (double)(wall_clock64() - t0w_));
 #endif
 }
@@ -540,10 +658,25 @@ __global__ void wino_pack_kernel(const float* __restrict__ w_oihw, int cout, int
 
 namespace tia {
 
-// dynamic LDS of the kernel: two patch buffers + two weight stages + the dump KB, at least the epilogue's two 64 KB tiles
-static constexpr int wino_lds_bytes(int patch_units, int stages) {
-    const int main_loop = 2 * ((patch_units + 63) / 64 * 64) * 16 + stages * 32768 + 1024;
-    return main_loop > 2 * 256 * 64 * 4 ? main_loop : 2 * 256 * 64 * 4;
+// dynamic LDS of the kernel: two patch buffers + two weight stages + the dump KB, at least the epilogue's 64 KB; the
+// persistent form keeps the epilogue's 64 KB at the second patch buffer, behind the first buffer and the stages (the kernel's map)
+static constexpr int wino_lds_bytes(int patch_units, int stages, bool persist) {
+    const int a_bytes = ((patch_units + 63) / 64 * 64) * 16, tile = 256 * 64 * 4;
+    if (persist) return a_bytes + stages * 32768 + (a_bytes > tile ? a_bytes : tile) + 1024;
+    const int main_loop = 2 * a_bytes + stages * 32768 + 1024;
+    return main_loop > tile ? main_loop : tile;
+}
+
+static long wino_cu_count() {  // compute units of the current device (MI355X: 256), cached per device index
+    static std::atomic<int> cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int cus = cached[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+        cached[dev].store(cus, std::memory_order_relaxed);
+    }
+    return cus;
 }
 
 bool conv3x3_wino_serves(long nb, long h, long w, long cin, long cout, long pad_top, long pad_left, long ho, long wo) {
@@ -606,26 +739,34 @@ int conv3x3_wino_launch(const float* x, const float* u_packed, const float* bias
         d.inv_wimg = 1.0f / (float)plan.wimg, d.inv_wrow = 1.0f / (float)plan.wrow, d.inv_wt = 1.0f / (float)(plan.wty * plan.wtx);
         d.inv_wtx = 1.0f / (float)plan.wtx, d.inv_wins = 1.0f / (float)(plan.wins_x * plan.wins_y), d.inv_wins_x = 1.0f / (float)plan.wins_x;
     }
-    const dim3 grid((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / 64));
-    static tia::DeviceOnce attr16, attr8, attrw;  // the dynamic-LDS attribute is per device
-#define TIA_WINO_LAUNCH(GEO_, NS_, ONCE_)                                                                                            \
+    // Persistent form (one workgroup per CU walks the items, the next item's first operands requested behind the current one's last
+    // steps): 16 x 16 blocks, an even number of 16-channel slices (the patch buffers alternate per slice and an item must end on
+    // buffer 1), at least two rounds of items -- everything else one block per workgroup.
+    static const bool no_persist = tia::dev_env("TIA_WINO_NO_PERSIST") != nullptr;  // developer switch (A/B measurements)
+    const long cus = wino_cu_count() / 8 * 8;
+    const bool persist = !no_persist && plan.kind == 0 && (cin / 16) % 2 == 0 && cus >= 8 && tiles * (cout / 64) >= 2 * cus;
+    const dim3 grid = persist ? dim3((unsigned)cus) : dim3((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / 64));
+    static tia::DeviceOnce attr16, attr8, attrw, attr16p;  // the dynamic-LDS attribute is per device
+#define TIA_WINO_LAUNCH(GEO_, NS_, PERSIST_, ONCE_)                                                                                  \
     do {                                                                                                                             \
-        constexpr int lds = wino_lds_bytes((GEO_::G == 0 ? 1 : GEO_::G) * GEO_::IMG, NS_);                                          \
+        constexpr int lds = wino_lds_bytes((GEO_::G == 0 ? 1 : GEO_::G) * GEO_::IMG, NS_, PERSIST_);                                \
         static_assert(lds <= 160 * 1024, "LDS");                                                                                     \
         if (!ONCE_.ensure([] {                                                                                                       \
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<GEO_, NS_>),                            \
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<GEO_, NS_, PERSIST_>),                  \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;                           \
             }))                                                                                                                      \
             return TIA_ELAUNCH;                                                                                                      \
-        hipLaunchKernelGGL((conv3x3_wino_kernel<GEO_, NS_>), grid, dim3(512), lds, stream, x, u_packed, bias, residual, y, d, relu,   \
-                           (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x));                                                      \
+        hipLaunchKernelGGL((conv3x3_wino_kernel<GEO_, NS_, PERSIST_>), grid, dim3(512), lds, stream, x, u_packed, bias, residual, y,  \
+                           d, relu, (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x));                                             \
     } while (0)
     if (plan.kind == 1)
-        TIA_WINO_LAUNCH(W8, 2, attr8);
+        TIA_WINO_LAUNCH(W8, 2, false, attr8);
     else if (plan.kind == 2)
-        TIA_WINO_LAUNCH(WR, 2, attrw);
+        TIA_WINO_LAUNCH(WR, 2, false, attrw);
+    else if (persist)
+        TIA_WINO_LAUNCH(W16, 2, true, attr16p);
     else
-        TIA_WINO_LAUNCH(W16, 2, attr16);
+        TIA_WINO_LAUNCH(W16, 2, false, attr16);
 #undef TIA_WINO_LAUNCH
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
