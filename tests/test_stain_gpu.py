@@ -107,6 +107,35 @@ def test_large_single_images_take_the_multi_workgroup_path(torch_mod, shape):
     np.testing.assert_allclose(big[_lib.ST_MAXC:_lib.ST_MAXC + 2], np.percentile(conc, 99, axis=0), atol=STAT_TOL)
 
 
+def test_large_images_with_massive_ties_take_the_radix_fall_back(torch_mod):
+    """A posterised large image (eight levels per channel: a few hundred distinct colours over 2.4 M pixels) puts far more than 16 Ki
+    equal keys into the bins of the percentile ranks: the candidate lists overflow and the selection goes to the radix passes over
+    the image -- ONE launch whose workgroups meet at a grid barrier between the digit passes (`big_select_sweep_kernel`).  The record
+    says so (the diagnostics slots), and the results equal the streaming kernel's and the oracle's; a batch of two exercises two
+    independent barriers in one launch."""
+    from tiatoolbox_amd import _lib
+
+    imgs = np.stack([_large_image(1536, 1600, seed=70 + k) for k in range(2)])
+    imgs = (np.clip(imgs.astype(int) // 32 * 32 + 16, 0, 255)).astype(np.uint8)
+    stats, _ = _stats(imgs, torch_mod)
+    ref, _ = _stats(imgs, torch_mod, select_mode=2)
+    for i in range(2):
+        s, r = stats[i], ref[i]
+        assert int(s[_lib.ST_FLAGS]) == 0
+        assert s[_lib.ST_CYCLES] == 1.0 or s[_lib.ST_CYCLES + 5] == 1.0, "no selection fell back: the image does not test what it says"
+        for lo, n in ((_lib.ST_STAIN, 6), (_lib.ST_MAXC, 2), (_lib.ST_MINPHI, 2), (_lib.ST_COV, 6), (_lib.ST_EVEC, 6), (_lib.ST_PINV, 6)):
+            np.testing.assert_allclose(s[lo:lo + n], r[lo:lo + n], rtol=1e-9, atol=1e-10)
+    img = imgs[1]
+    dbg: dict = {}
+    sm = ostain.MacenkoExtractor().get_stain_matrix(img.copy(), debug=dbg)
+    s = stats[1]
+    np.testing.assert_allclose(s[_lib.ST_MINPHI], dbg["min_phi"], atol=STAT_TOL)
+    np.testing.assert_allclose(s[_lib.ST_MAXPHI], dbg["max_phi"], atol=STAT_TOL)
+    np.testing.assert_allclose(s[_lib.ST_STAIN:_lib.ST_STAIN + 6].reshape(2, 3), sm, atol=STAT_TOL)
+    conc = ostain.StainNormalizer.get_concentrations(img.copy(), sm)
+    np.testing.assert_allclose(s[_lib.ST_MAXC:_lib.ST_MAXC + 2], np.percentile(conc, 99, axis=0), atol=STAT_TOL)
+
+
 @pytest.mark.parametrize("shape", [(64, 64), (96, 96), (37, 41), (256, 256), (224, 224)])
 def test_macenko_stats_match_oracle(torch_mod, shape):
     from tiatoolbox_amd import _lib

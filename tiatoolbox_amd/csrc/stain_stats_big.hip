@@ -42,7 +42,7 @@ struct BigState {
     // `lin`) and caches the bin code per pixel; the second collects the exact keys of the pixels in the ranks' bins (a few thousand)
     // and one workgroup selects among them.  `fast`: 1 = binning sweep pending, 2 = collecting sweep pending, 0 = off (the radix
     // passes run when shift >= 0: the fall-back for lists that overflow -- massive ties).
-    unsigned lin[2][kLinBins];
+    alignas(16) unsigned lin[2][kLinBins];  // (16-byte aligned: the decision step reads and clears it in 16-byte units)
     double lin_lo[2], lin_scale[2];
     int nbins;
     unsigned long long rank0[kSelTargets];
@@ -52,6 +52,7 @@ struct BigState {
     unsigned diag[2][1 + kSelTargets];     // per selection (angles, concentrations): fell back to radix passes; list sizes
     int skip;                              // empty tissue mask: the record is final
     unsigned ticket;                       // workgroups of the current sweep that have delivered (the last one runs the step)
+    unsigned gen;                          // radix fall-back: digit passes completed (the grid barrier of big_select_sweep_kernel)
     int bmin, bmax;
     unsigned flags;
     double plow, phigh;
@@ -84,7 +85,7 @@ __device__ __forceinline__ void big_build_tables(double* od, int (*ty)[256], con
 
 // this workgroup's share of the image: pixels [lo, hi), a multiple of 4 apart from the image's end
 __device__ __forceinline__ void big_span(long hw, long& lo, long& hi) {
-    const long per = (((hw + gridDim.x - 1) / gridDim.x) + 3) & ~3L;
+    const long per = (((hw + gridDim.x - 1) / gridDim.x) + 15) & ~15L;  // (16 pixels: whole 16-byte units of image bytes and of bin codes)
     lo = (long)blockIdx.x * per;
     hi = lo + per < hw ? lo + per : hw;
     if (lo > hw) lo = hw;
@@ -97,13 +98,23 @@ __device__ __forceinline__ void big_for_each_pixel(const uint8_t* __restrict__ p
     if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
         const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
         const long g1 = hi >> 2;
-        for (long g = (lo >> 2) + threadIdx.x; g < g1; g += GT) {
-            const uint32_t a = q[g * 3], b = q[g * 3 + 1], c = q[g * 3 + 2];
+        auto four = [&](uint32_t a, uint32_t b, uint32_t c) {
             f(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
             f(a >> 24, b & 255u, (b >> 8) & 255u);
             f((b >> 16) & 255u, b >> 24, c & 255u);
             f((c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
+        };
+        long g = (lo >> 2) + threadIdx.x;
+        for (; g + 3 * GT < g1; g += 4 * GT) {  // four groups requested before the first is used (the sweeps are latency-bound)
+            uint32_t w[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) w[u][k] = q[(g + u * GT) * 3 + k];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) four(w[u][0], w[u][1], w[u][2]);
         }
+        for (; g < g1; g += GT) four(q[g * 3], q[g * 3 + 1], q[g * 3 + 2]);
         done = g1 << 2;
         if (done < lo) done = lo;
     }
@@ -145,21 +156,28 @@ __global__ __launch_bounds__(GT) void big_hist_kernel(const uint8_t* __restrict_
     long lo, hi;
     big_span(hw, lo, hi);
     const long b0 = lo * 3, b1 = hi * 3;  // bytes: the percentiles are over the flattened image
-    const bool al = (reinterpret_cast<uintptr_t>(p) & 3) == 0;
+    const bool al = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
     long done = b0;
-    if (al) {  // b0 is a multiple of 12
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
-        const long d1 = b1 >> 2;
-        for (long d = (b0 >> 2) + threadIdx.x; d < d1; d += GT) {
-            const uint32_t wv = q[d];
+    if (al) {  // b0 is a multiple of 48: 16-byte loads, two in flight per thread (4-byte loads made this sweep issue-bound)
+        const uint4* q = reinterpret_cast<const uint4*>(p);
+        const long d1 = b1 >> 4;
+        auto sixteen = [&](const uint4& w) {
+            const uint32_t a[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                uint32_t v = (wv >> (8 * e)) & 255u;
+            for (int e = 0; e < 16; ++e) {
+                uint32_t v = (a[e >> 2] >> (8 * (e & 3))) & 255u;
                 if (z1) v = v ? v : 1u;
                 atomicAdd(hs + v * 32u, 1u);
             }
+        };
+        long d = (b0 >> 4) + threadIdx.x;
+        for (; d + GT < d1; d += 2 * GT) {
+            const uint4 w0 = q[d], w1 = q[d + GT];
+            sixteen(w0);
+            sixteen(w1);
         }
-        done = d1 << 2;
+        for (; d < d1; d += GT) sixteen(q[d]);
+        done = d1 << 4;
     }
     for (long i = done + threadIdx.x; i < b1; i += GT) {
         uint32_t v = p[i];
@@ -408,7 +426,7 @@ __device__ __forceinline__ int big_lin_bin(double x, double lo, double scale, in
 }
 
 __device__ void big_lin_step(BigState& st);
-__device__ void big_exact_step(BigState& st, const unsigned long long* __restrict__ cand);
+__device__ void big_exact_step(BigState& st, const unsigned long long* __restrict__ cand, int l);
 
 // sweep A: bin every key, count, cache the codes ([key][pixel] uint16; 0xffff = not a member, i.e. no tissue)
 template <int KIND>
@@ -418,13 +436,15 @@ __global__ __launch_bounds__(GT) void big_lin_sweep_kernel(const uint8_t* __rest
     __shared__ double od[256];
     __shared__ int ty[3][256];
     constexpr int NBINS = kLinBins / NK;
-    __shared__ unsigned bins[NK][NBINS];
+    // 16-bit counters, two per dword (32 KB: four workgroups per CU instead of two -- the sweep is float64 arithmetic behind table
+    // look-ups and needs the waves); a workgroup's span is swept in rounds of at most kRound pixels so that no counter can wrap
+    constexpr long kRound = 65528;
+    __shared__ unsigned bins[NK][NBINS / 2];
     BigState& st = states[blockIdx.y];
     if (st.skip || st.fast != 1) return;  // (uniform)
     const uint8_t* p = img + (size_t)blockIdx.y * (size_t)hw * 3u;
     uint16_t* codes = codes_all + (size_t)blockIdx.y * 2u * (size_t)hw;
     big_build_tables(od, ty, tab, st.plow, st.phigh, prm.zero_to_one != 0);
-    for (int i = threadIdx.x; i < NK * NBINS; i += GT) (&bins[0][0])[i] = 0u;
     double a[3], c[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -432,10 +452,16 @@ __global__ __launch_bounds__(GT) void big_lin_sweep_kernel(const uint8_t* __rest
         c[i] = KIND == 0 ? st.e2[i] : st.P[2 * i + 1];
     }
     const double lo0 = st.lin_lo[0], sc0 = st.lin_scale[0], lo1 = st.lin_lo[1], sc1 = st.lin_scale[1];
-    __syncthreads();
     const int y_thr = prm.y_thr;
-    long lo, hi;
-    big_span(hw, lo, hi);
+    long span_lo, span_hi;
+    big_span(hw, span_lo, span_hi);
+    for (long lo = span_lo; lo < span_hi; lo += kRound) {
+    const long hi = lo + kRound < span_hi ? lo + kRound : span_hi;
+    for (int i = threadIdx.x; i < NK * NBINS / 2; i += GT) (&bins[0][0])[i] = 0u;
+    __syncthreads();
+    // (a group's four codes leave as ONE 8-byte store per plane when the planes are 8-byte aligned)
+    const bool packed = (hw & 3) == 0 && (reinterpret_cast<uintptr_t>(codes) & 7) == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0;  // (then every pixel is in a group)
+    unsigned out0 = 0u, out1 = 0u;
     auto one = [&](long idx, uint32_t r, uint32_t g, uint32_t b) {
         unsigned c0 = 0xffffu, c1 = 0xffffu;
         bool member = true;
@@ -447,14 +473,17 @@ __global__ __launch_bounds__(GT) void big_lin_sweep_kernel(const uint8_t* __rest
             double x[2];
             big_keys<KIND>(od, a, c, r, g, b, x);
             c0 = (unsigned)big_lin_bin(x[0], lo0, sc0, NBINS);
-            atomicAdd(&bins[0][c0], 1u);
+            atomicAdd(&bins[0][c0 >> 1], 1u << (16u * (c0 & 1u)));
             if (NK == 2) {
                 c1 = (unsigned)big_lin_bin(x[1], lo1, sc1, NBINS);
-                atomicAdd(&bins[NK - 1][c1], 1u);
+                atomicAdd(&bins[NK - 1][c1 >> 1], 1u << (16u * (c1 & 1u)));
             }
         }
-        codes[idx] = (uint16_t)c0;
-        if (NK == 2) codes[(size_t)hw + idx] = (uint16_t)c1;
+        if (!packed) {
+            codes[idx] = (uint16_t)c0;
+            if (NK == 2) codes[(size_t)hw + idx] = (uint16_t)c1;
+        }
+        out0 = c0, out1 = c1;
     };
     long idx = 0;
     (void)idx;
@@ -463,32 +492,60 @@ __global__ __launch_bounds__(GT) void big_lin_sweep_kernel(const uint8_t* __rest
     if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
         const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(p);
         const long g1 = hi >> 2;
-        for (long g = (lo >> 2) + threadIdx.x; g < g1; g += GT) {
-            const uint32_t wa = q[g * 3], wb = q[g * 3 + 1], wc = q[g * 3 + 2];
+        auto four = [&](long g, uint32_t wa, uint32_t wb, uint32_t wc) {
+            unsigned k0[4], k1[4];
             one(4 * g, wa & 255u, (wa >> 8) & 255u, (wa >> 16) & 255u);
+            k0[0] = out0, k1[0] = out1;
             one(4 * g + 1, wa >> 24, wb & 255u, (wb >> 8) & 255u);
+            k0[1] = out0, k1[1] = out1;
             one(4 * g + 2, (wb >> 16) & 255u, wb >> 24, wc & 255u);
+            k0[2] = out0, k1[2] = out1;
             one(4 * g + 3, (wc >> 8) & 255u, (wc >> 16) & 255u, wc >> 24);
+            k0[3] = out0, k1[3] = out1;
+            if (packed) {
+                *reinterpret_cast<uint2*>(codes + 4 * g) = uint2{k0[0] | (k0[1] << 16), k0[2] | (k0[3] << 16)};
+                if (NK == 2) *reinterpret_cast<uint2*>(codes + (size_t)hw + 4 * g) = uint2{k1[0] | (k1[1] << 16), k1[2] | (k1[3] << 16)};
+            }
+        };
+        long g = (lo >> 2) + threadIdx.x;
+        for (; g + GT < g1; g += 2 * GT) {  // two groups requested before the first is used
+            const uint32_t a0 = q[g * 3], b0 = q[g * 3 + 1], c0 = q[g * 3 + 2];
+            const uint32_t a1 = q[(g + GT) * 3], b1 = q[(g + GT) * 3 + 1], c1 = q[(g + GT) * 3 + 2];
+            four(g, a0, b0, c0);
+            four(g + GT, a1, b1, c1);
         }
+        for (; g < g1; g += GT) four(g, q[g * 3], q[g * 3 + 1], q[g * 3 + 2]);
         done = g1 << 2;
         if (done < lo) done = lo;
     }
     for (long i = done + threadIdx.x; i < hi; i += GT) one(i, (uint32_t)p[3 * i], (uint32_t)p[3 * i + 1], (uint32_t)p[3 * i + 2]);
     __syncthreads();
-    for (int i = threadIdx.x; i < NK * NBINS; i += GT) {  // key k's counts at st.lin[0] + k * NBINS (the flat 8192-entry area)
+    for (int i = threadIdx.x; i < NK * NBINS / 2; i += GT) {  // key k's counts at st.lin[0] + k * NBINS (one flat area)
         const unsigned v = (&bins[0][0])[i];
-        if (v) atomicAdd(&(&st.lin[0][0])[i], v);
+        if (v & 0xffffu) atomicAdd(&(&st.lin[0][0])[2 * i], v & 0xffffu);
+        if (v >> 16) atomicAdd(&(&st.lin[0][0])[2 * i + 1], v >> 16);
     }
-    if (big_last_workgroup(st)) big_lin_step(st);
+    __syncthreads();  // (the next round clears the counters)
+    }
+}
+// (the decision steps of the two selection sweeps are kernels of their own, one workgroup per image: fused into the sweep by the
+// last-workgroup pattern they set its register and LDS footprint -- 248 VGPRs + scratch for the binning sweep, 131 KB of LDS = ONE
+// workgroup per CU for the collecting sweep, which then streamed its 33 MB of bin codes at 0.27 TB/s)
+__global__ __launch_bounds__(GT) void big_lin_step_kernel(BigState* __restrict__ states) {
+    BigState& st = states[blockIdx.x];
+    if (st.skip || st.fast != 1) return;  // (uniform)
+    big_lin_step(st);
 }
 
-// after sweep A (one workgroup): the bin of every rank, the rank inside it, one candidate list per distinct (key, bin)
+// after sweep A (one workgroup): the bin of every rank, the rank inside it, one candidate list per distinct (key, bin).  A key's merged
+// counts are read ONCE (16-byte loads of the thread's own run of bins), scanned across the workgroup, and serve all of its targets.
 __device__ void big_lin_step(BigState& st) {
-    __shared__ unsigned part[256];
+    __shared__ unsigned long long wtot[GT / 64];
     __shared__ unsigned found_bin[kSelTargets];
     __shared__ unsigned long long found_below[kSelTargets];
-    const int tid = threadIdx.x;
-    constexpr int PER = kLinBins / 256;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int PER = kLinBins / 256;  // bins per thread when a key has all kLinBins (a multiple of 4)
+    static_assert(PER % 4 == 0 && GT == 256, "16-byte loads of a thread's run of bins");
     __shared__ unsigned long long c_rank[kSelTargets];
     __shared__ int c_nb, c_nkeys;
     if (tid < kSelTargets) c_rank[tid] = st.rank[tid];
@@ -498,26 +555,43 @@ __device__ void big_lin_step(BigState& st) {
     }
     __syncthreads();
     const int nb = c_nb, nkeys = c_nkeys;
-    for (int t = 0; t < kSelTargets; ++t) {
-        const unsigned* bins = &st.lin[0][0] + (nkeys == 1 ? 0 : (t >> 1) * nb);
-        unsigned loc[PER], sum = 0;
+    const int per = nb / 256;  // (nbins is kLinBins or half of it: whole 16-byte units per thread)
+    for (int key = 0; key < nkeys; ++key) {
+        const uint4* bins4 = reinterpret_cast<const uint4*>(&st.lin[0][0] + key * nb + tid * per);
+        unsigned loc[PER];
+        unsigned long long sum = 0;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            loc[j] = tid * PER + j < nb ? big_ld(&bins[tid * PER + j]) : 0u;
-            sum += loc[j];
+        for (int j = 0; j < PER / 4; ++j) {
+            uint4 v = uint4{0u, 0u, 0u, 0u};
+            if (4 * j < per) v = bins4[j];
+            loc[4 * j] = v.x, loc[4 * j + 1] = v.y, loc[4 * j + 2] = v.z, loc[4 * j + 3] = v.w;
+            sum += (unsigned long long)v.x + v.y + v.z + v.w;
         }
-        part[tid] = sum;
-        __syncthreads();
-        unsigned long long before = 0;
-        for (int j = 0; j < tid; ++j) before += part[j];
-        const unsigned long long r = c_rank[t];
+        // exclusive prefix of the threads' sums: wave scan, then the waves' totals
+        unsigned long long incl = sum;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            if (before <= r && r < before + loc[j]) {
-                found_bin[t] = (unsigned)(tid * PER + j);
-                found_below[t] = before;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = (unsigned long long)__shfl_up((long long)incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        unsigned long long before0 = incl - sum;
+        for (int q = 0; q < wv; ++q) before0 += wtot[q];
+        for (int t = 0; t < kSelTargets; ++t) {
+            if (nkeys == 2 && (t >> 1) != key) continue;  // (uniform) targets 0, 1 rank key 0 and 2, 3 key 1
+            const unsigned long long r = c_rank[t];
+            unsigned long long before = before0;
+            if (before <= r && r < before + sum) {
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    if (before <= r && r < before + loc[j]) {
+                        found_bin[t] = (unsigned)(tid * per + j);
+                        found_below[t] = before;
+                    }
+                    before += loc[j];
+                }
             }
-            before += loc[j];
         }
         __syncthreads();
     }
@@ -537,7 +611,8 @@ __device__ void big_lin_step(BigState& st) {
         st.fast = 2;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * kLinBins; i += 256) (&st.lin[0][0])[i] = 0u;
+    uint4* z = reinterpret_cast<uint4*>(&st.lin[0][0]);
+    for (int i = tid; i < 2 * kLinBins / 4; i += 256) z[i] = uint4{0u, 0u, 0u, 0u};
 }
 
 // sweep B: the cached codes pick the members of the ranks' bins; their exact keys go to the lists
@@ -547,12 +622,19 @@ __global__ __launch_bounds__(GT) void big_collect_sweep_kernel(const uint8_t* __
                                                                const uint16_t* __restrict__ codes_all, unsigned long long* __restrict__ cand_all) {
     constexpr int NK = KIND == 0 ? 1 : 2;
     __shared__ double od[256];
+    // A workgroup's members are gathered in LDS and appended to the image's lists with ONE global atomic per list: every member
+    // taking its slot with a returning atomic on the list's counter serialised ~10 k same-address round trips per list at the L2
+    // (8192^2: 220 us of a sweep whose loads take 20) -- the sweep's time was the list length, whatever the loop did.
+    constexpr int kLocalCap = 192;
+    __shared__ unsigned long long l_key[kSelTargets][kLocalCap];
+    __shared__ unsigned l_cnt[kSelTargets], l_base[kSelTargets];
     BigState& st = states[blockIdx.y];
     if (st.skip || st.fast != 2) return;  // (uniform)
     const uint8_t* p = img + (size_t)blockIdx.y * (size_t)hw * 3u;
     const uint16_t* codes = codes_all + (size_t)blockIdx.y * 2u * (size_t)hw;
     unsigned long long* cand = cand_all + (size_t)blockIdx.y * kSelTargets * (size_t)kCandCap;
     for (int t = threadIdx.x; t < 256; t += GT) od[t] = tab->od_lut[t];
+    if (threadIdx.x < kSelTargets) l_cnt[threadIdx.x] = 0u;
     double a[3], c[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -580,37 +662,85 @@ __global__ __launch_bounds__(GT) void big_collect_sweep_kernel(const uint8_t* __
             if (tl[t] != t) continue;  // lists are owned by their first target
             const bool second = NK == 2 && t >= 2;
             if ((int)(second ? c1 : c0) != tb[t]) continue;
-            const unsigned pos = atomicAdd(&st.lcount[t], 1u);
-            if (pos < (unsigned)kCandCap) {
-                const unsigned long long k = f64_key(x[second ? 1 : 0]);
-                __hip_atomic_store(&cand[(size_t)t * kCandCap + pos], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long k = f64_key(x[second ? 1 : 0]);
+            const unsigned lp = atomicAdd(&l_cnt[t], 1u);
+            if (lp < (unsigned)kLocalCap) {
+                l_key[t][lp] = k;
+            } else {  // (a workgroup with more members than its LDS list holds: the rest one by one)
+                const unsigned pos = atomicAdd(&st.lcount[t], 1u);
+                if (pos < (unsigned)kCandCap) __hip_atomic_store(&cand[(size_t)t * kCandCap + pos], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
-    // four codes per 8-byte load (the loop is bound by load latency: members are a fraction of a per cent); lo is a multiple of 4
+    // eight codes per 16-byte load, four loads in flight per thread (the loop is bound by load latency: members are a fraction of a per
+    // cent); lo is a multiple of 8
     long done = lo;
-    if ((hw & 3) == 0 && (reinterpret_cast<uintptr_t>(codes) & 7) == 0) {
-        const unsigned long long* q0 = reinterpret_cast<const unsigned long long*>(codes);
-        const unsigned long long* q1 = reinterpret_cast<const unsigned long long*>(codes + (size_t)hw);
-        const long g1 = hi >> 2;
-#pragma unroll 4
-        for (long g = (lo >> 2) + threadIdx.x; g < g1; g += GT) {
-            const unsigned long long w0 = q0[g], w1 = NK == 2 ? q1[g] : ~0ull;
+    if ((hw & 7) == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0) {
+        const uint4* q0 = reinterpret_cast<const uint4*>(codes);
+        const uint4* q1 = reinterpret_cast<const uint4*>(codes + (size_t)hw);
+        const long g1 = hi >> 3;
+        // one test for the whole unit first (a code equals a list's bin in a fraction of a per cent of the pixels; testing every code
+        // against every target was 12 vector instructions per pixel and bound this sweep): x ^ pattern has a zero half-word
+        unsigned pat[kSelTargets];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) visit(4 * g + e, (unsigned)(w0 >> (16 * e)) & 0xffffu, (unsigned)(w1 >> (16 * e)) & 0xffffu);
+        for (int t = 0; t < kSelTargets; ++t) pat[t] = tl[t] == t ? ((unsigned)tb[t] | ((unsigned)tb[t] << 16)) : 0xfffefffeu;  // (0xfffe: no code)
+        auto zero_half = [](unsigned x) { return (x - 0x00010001u) & ~x & 0x80008000u; };
+        auto eight = [&](long g, const uint4& w0, const uint4& w1) {
+            const unsigned a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+            unsigned any = 0u;
+#pragma unroll
+            for (int t = 0; t < kSelTargets; ++t) {
+                if (t > 0 && pat[t] == pat[0] && (NK == 1 || t < 2)) continue;  // (uniform) the common case: two lists, two patterns
+                const unsigned* plane = (NK == 2 && t >= 2) ? a1 : a0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) any |= zero_half(plane[k] ^ pat[t]);
+            }
+            if (any == 0u) return;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                visit(8 * g + e, (a0[e >> 1] >> (16 * (e & 1))) & 0xffffu, (a1[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+        };
+        long g = (lo >> 3) + threadIdx.x;
+        for (; g + 3 * GT < g1; g += 4 * GT) {
+            uint4 w0[4], w1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w0[u] = q0[g + u * GT];
+                w1[u] = NK == 2 ? q1[g + u * GT] : uint4{~0u, ~0u, ~0u, ~0u};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) eight(g + u * GT, w0[u], w1[u]);
         }
-        done = g1 << 2;
+        for (; g < g1; g += GT) eight(g, q0[g], NK == 2 ? q1[g] : uint4{~0u, ~0u, ~0u, ~0u});
+        done = g1 << 3;
         if (done < lo) done = lo;
     }
     for (long i = done + threadIdx.x; i < hi; i += GT) visit(i, codes[i], NK == 2 ? (unsigned)codes[(size_t)hw + i] : 0xffffu);
-    if (big_last_workgroup(st)) big_exact_step(st, cand);
+    __syncthreads();
+    if (threadIdx.x < kSelTargets) {
+        const unsigned n = l_cnt[threadIdx.x] < (unsigned)kLocalCap ? l_cnt[threadIdx.x] : (unsigned)kLocalCap;
+        l_base[threadIdx.x] = n ? atomicAdd(&st.lcount[threadIdx.x], n) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kSelTargets; ++t) {
+        const unsigned n = l_cnt[t] < (unsigned)kLocalCap ? l_cnt[t] : (unsigned)kLocalCap, base = l_base[t];
+        for (unsigned i = threadIdx.x; i < n; i += GT)
+            if (base + i < (unsigned)kCandCap) cand[(size_t)t * kCandCap + base + i] = l_key[t][i];
+    }
+}
+// grid (images, kSelTargets): one workgroup per candidate LIST (the floor / ceil ranks of a percentile share one; two lists are the rule)
+__global__ __launch_bounds__(GT) void big_exact_step_kernel(BigState* __restrict__ states, const unsigned long long* __restrict__ cand_all) {
+    BigState& st = states[blockIdx.x];
+    if (st.skip || st.fast != 2) return;  // (uniform; nothing below changes `fast` unless a list overflowed)
+    big_exact_step(st, cand_all + (size_t)blockIdx.x * kSelTargets * (size_t)kCandCap, (int)blockIdx.y);
 }
 
 // after sweep B (one workgroup): each list is copied to LDS once and its ranks found by radix selection there (8-bit digits, the
 // digit counts scanned by the 256 threads); the rank right after a selected one -- the ceil neighbour of a percentile -- needs no
 // second selection: it is the same key while equal members remain, else the smallest key above it (one more pass).  A list that
 // overflowed hands the whole selection to the radix passes over the image.
-__device__ void big_exact_step(BigState& st, const unsigned long long* __restrict__ cand) {
+__device__ void big_exact_step(BigState& st, const unsigned long long* __restrict__ cand, const int l) {
     __shared__ unsigned long long s_list[kCandCap];
     __shared__ unsigned dig[256], wsum[4];
     __shared__ unsigned long long s_prefix, s_rank, s_min[4];
@@ -629,25 +759,27 @@ __device__ void big_exact_step(BigState& st, const unsigned long long* __restric
     }
     if (tid == 0) c_nkeys = st.nkeys;
     __syncthreads();
+    int first_used = kSelTargets;  // (every workgroup of the image computes the same: the lists' counts are final)
+    for (int t = kSelTargets - 1; t >= 0; --t) first_used = c_list[t] < first_used ? c_list[t] : first_used;
     if (tid == 0) {
         s_overflow = 0;
-        unsigned* dg = st.diag[c_nkeys - 1];
-        for (int t = 0; t < kSelTargets; ++t) {
-            const unsigned cnt = c_count[c_list[t]];
-            dg[1 + t] = cnt;
-            if (cnt > (unsigned)kCandCap) s_overflow = 1;
+        for (int t = 0; t < kSelTargets; ++t)
+            if (c_count[c_list[t]] > (unsigned)kCandCap) s_overflow = 1;
+        if (l == first_used) {
+            unsigned* dg = st.diag[c_nkeys - 1];
+            for (int t = 0; t < kSelTargets; ++t) dg[1 + t] = c_count[c_list[t]];
+            dg[0] = (unsigned)s_overflow;
         }
-        dg[0] = (unsigned)s_overflow;
     }
     __syncthreads();
-    if (s_overflow) {
-        if (tid == 0) big_start_radix(st);
+    if (s_overflow) {  // the whole selection goes to the radix passes over the image
+        if (tid == 0 && l == first_used) big_start_radix(st);
         return;
     }
-    for (int l = 0; l < kSelTargets; ++l) {
+    {
         bool used = false;
         for (int t = 0; t < kSelTargets; ++t) used = used || c_list[t] == l;
-        if (!used) continue;  // (uniform)
+        if (!used) return;  // (uniform)
         const unsigned cnt = c_count[l];
         const unsigned long long* list = cand + (size_t)l * kCandCap;
         for (unsigned i = tid; i < cnt; i += 256) s_list[i] = list[i];
@@ -685,10 +817,10 @@ __device__ void big_exact_step(BigState& st, const unsigned long long* __restric
                     s_prefix = 0ull;
                     s_rank = r;
                 }
-                for (int shift = 56; shift >= 0; shift -= 8) {
-                    dig[tid] = 0u;
-                    __syncthreads();
-                    const unsigned long long pre = s_prefix;
+                dig[tid] = 0u;
+                __syncthreads();
+                for (int shift = 56; shift >= 0; shift -= 8) {  // three barriers per digit (each thread clears its own counter when it reads it)
+                    const unsigned long long pre = s_prefix, rr = s_rank;
                     const int hs = shift + 8;
                     for (unsigned i = tid; i < cnt; i += 256) {
                         const unsigned long long k = s_list[i];
@@ -697,13 +829,12 @@ __device__ void big_exact_step(BigState& st, const unsigned long long* __restric
                     }
                     __syncthreads();
                     const unsigned mine = dig[tid];
+                    dig[tid] = 0u;
                     const unsigned incl = wave_incl_scan_u32(mine);
                     if (lane == 63) wsum[wv] = incl;
                     __syncthreads();
                     unsigned before = incl - mine;
                     for (int q = 0; q < wv; ++q) before += wsum[q];
-                    const unsigned long long rr = s_rank;
-                    __syncthreads();
                     if ((unsigned long long)before <= rr && rr < (unsigned long long)before + mine) {
                         s_prefix = pre | ((unsigned long long)tid << shift);
                         s_rank = rr - before;
@@ -719,12 +850,8 @@ __device__ void big_exact_step(BigState& st, const unsigned long long* __restric
             }
             if (tid == 0) st.prefix[t] = key;
         }
-        __syncthreads();
     }
-    if (tid == 0) {
-        st.fast = 0;
-        st.shift = -1;
-    }
+    // (`fast` stays 2 and `shift` -1: the next selection's start sets both, the fall-back kernel looks at `shift` alone)
 }
 
 // ---- radix selection ------------------------------------------------------------------------------------------------------------
@@ -739,9 +866,15 @@ __global__ __launch_bounds__(GT) void big_select_sweep_kernel(const uint8_t* __r
     __shared__ int ty[3][256];
     __shared__ unsigned bins[kSelTargets][kDigitBins];
     BigState& st = states[blockIdx.y];
-    if (st.skip || st.shift < 0) return;  // (uniform)
+    if (st.skip || st.shift < 0) return;  // (uniform; the common case: no list overflowed, nothing to do)
     const uint8_t* p = img + (size_t)blockIdx.y * (size_t)hw * 3u;
     big_build_tables(od, ty, tab, st.plow, st.phigh, prm.zero_to_one != 0);
+    // ALL digit passes in this one launch (the host launches the fall-back unconditionally: six launches per selection that return at
+    // once cost 4.5 us each).  Between passes the image's workgroups meet at a barrier built on `gen`: the workgroup that delivers last
+    // runs the decision step, publishes it (release fence) and advances `gen`; the others sleep-spin on it.  The workgroups of an
+    // image are at most one per CU and dispatched in index order, so the ones a spinning workgroup waits for are resident or next in line.
+    unsigned my_gen = __hip_atomic_load(&st.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
     for (int i = threadIdx.x; i < kSelTargets * kDigitBins; i += GT) (&bins[0][0])[i] = 0u;
     const int shift = st.shift, bits = st.bits;
     const unsigned mask = (1u << bits) - 1u;
@@ -797,7 +930,20 @@ __global__ __launch_bounds__(GT) void big_select_sweep_kernel(const uint8_t* __r
             if (v) atomicAdd(&st.sel[t][i], v);
         }
     }
-    if (big_last_workgroup(st)) big_select_step(st);
+    if (big_last_workgroup(st)) {
+        big_select_step(st);
+        __threadfence();  // the step's plain stores (and the cleared counters) reach the other XCDs' view before `gen` moves
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&st.gen, my_gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (threadIdx.x == 0) {
+        while (__hip_atomic_load(&st.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    my_gen += 1u;
+    if (__hip_atomic_load(&st.shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) break;  // (uniform) all 64 bits fixed
+    __syncthreads();  // (the counters are cleared at the top of the next pass)
+    }
 }
 
 // one workgroup per image: walk each target's merged counts to the bin holding its rank, fix that digit, move to the next digit
@@ -985,19 +1131,23 @@ int launch_stain_stats_big(const uint8_t* d_img, long n, long hw, const tia_stai
     const dim3 grid((unsigned)groups, (unsigned)n), one((unsigned)n);
     const int z1 = prm.zero_to_one != 0 ? 1 : 0;
     hipLaunchKernelGGL(big_hist_kernel, grid, dim3(GT), 0, st, d_img, hw, states, z1, prm, d_stats);
-    constexpr int kPasses = (64 + kDigitBits - 1) / kDigitBits;
+    // the radix fall-back is launched unconditionally (the host does not know whether a list overflowed) and returns at once in the
+    // common case; all its digit passes run inside one launch, on few workgroups per image (see the kernel)
+    const dim3 grid_fb((unsigned)(groups > 256 ? 256 : groups), (unsigned)n);
     if (prm.mode == TIA_MODE_MACENKO) {
         hipLaunchKernelGGL(big_moments_kernel, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, d_stats);
         hipLaunchKernelGGL(big_lin_sweep_kernel<0>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, codes);
+        hipLaunchKernelGGL(big_lin_step_kernel, one, dim3(GT), 0, st, states);
         hipLaunchKernelGGL(big_collect_sweep_kernel<0>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, codes, cand);
-        for (int pass = 0; pass < kPasses; ++pass)  // (no-ops unless a candidate list overflowed)
-            hipLaunchKernelGGL(big_select_sweep_kernel<0>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states);
+        hipLaunchKernelGGL(big_exact_step_kernel, dim3((unsigned)n, kSelTargets), dim3(GT), 0, st, states, cand);
+        hipLaunchKernelGGL(big_select_sweep_kernel<0>, grid_fb, dim3(GT), 0, st, d_img, hw, d_tables, prm, states);  // (returns at once unless a list overflowed)
     }
     hipLaunchKernelGGL(big_vectors_kernel, one, dim3(64), 0, st, hw, prm, d_tables, states, d_stats);
     hipLaunchKernelGGL(big_lin_sweep_kernel<1>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, codes);
+    hipLaunchKernelGGL(big_lin_step_kernel, one, dim3(GT), 0, st, states);
     hipLaunchKernelGGL(big_collect_sweep_kernel<1>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, codes, cand);
-    for (int pass = 0; pass < kPasses; ++pass)  // (no-ops unless a candidate list overflowed)
-        hipLaunchKernelGGL(big_select_sweep_kernel<1>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states);
+    hipLaunchKernelGGL(big_exact_step_kernel, dim3((unsigned)n, kSelTargets), dim3(GT), 0, st, states, cand);
+    hipLaunchKernelGGL(big_select_sweep_kernel<1>, grid_fb, dim3(GT), 0, st, d_img, hw, d_tables, prm, states);
     hipLaunchKernelGGL(big_final_kernel, one, dim3(64), 0, st, prm, states, d_stats);
     return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
 }
