@@ -645,9 +645,14 @@ struct AugCtxTab {
     int augment_background;
     __device__ __forceinline__ void pixel(uint32_t r, uint32_t g, uint32_t b, double (&o)[3]) const {
         const long t = (long)ty[0][r] + ty[1][g] + ty[2][b];
-        const double* q = pt + ((augment_background || t < bound) ? 9 * 256 : 0);
+        // (the set is an INDEX offset, not a pointer: with a selected 64-bit pointer per pixel the address arithmetic of the 36 look-ups
+        // of a group is 64-bit and the kernel needs more than 256 registers -- one wave per SIMD for a loop that lives on LDS latency)
+        // (`t` is looked up whether or not the background is augmented too: a uniform branch around the three look-ups splits the
+        // group into basic blocks, the products sink to the end of the chunk and all sixteen pixels' 144 table reads stay live)
+        const unsigned set = ((t < bound) | (augment_background != 0)) ? 9u * 256u : 0u;
+        const unsigned ir = set + r, ig = set + g, ib = set + b;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = __builtin_fmin(q[c * 256 + r] * q[(3 + c) * 256 + g] * q[(6 + c) * 256 + b], 255.0);
+        for (int c = 0; c < 3; ++c) o[c] = __builtin_fmin(pt[c * 256 + ir] * pt[(3 + c) * 256 + ig] * pt[(6 + c) * 256 + ib], 255.0);
     }
 };
 
@@ -678,18 +683,10 @@ struct AugCtxRef {
     }
 };
 
-__global__ __launch_bounds__(AT) void stain_augment_f64_wide_kernel(const uint8_t* __restrict__ img, long hw,
-                                                                     const tia_stain_tables* __restrict__ tab,
-                                                                     const double* __restrict__ stats,
-                                                                     const double* __restrict__ alpha_beta, int y_thr,
-                                                                     int augment_background, int z1, uint8_t* __restrict__ out) {
-    __shared__ double ptab[2 * 9 * 256];
-    __shared__ int ty[3][256];
-    __shared__ __attribute__((aligned(16))) uint8_t stage[AT / 64][3072];
-    const long patch = blockIdx.y;
-    const double* st = stats + patch * TIA_STATS_STRIDE;
-    build_ty(ty, tab, st[TIA_ST_PLOW], st[TIA_ST_PHIGH], z1 != 0);
-    double m[2][9], k0[3];
+// The patch's fused matrices of the table form (m[set][3 j + c]: tissue / background set), the constant exponent k0, and whether every
+// factor stays within e^+-100 (otherwise, or for NaN / inf, the patch takes the reference's per-pixel arithmetic).
+__device__ __forceinline__ bool augment_tables_ok(const double* __restrict__ st, const double* __restrict__ alpha_beta, long patch,
+                                                  double (&m)[2][9], double (&k0)[3]) {
     const double a0 = alpha_beta[patch * 4 + 0], a1 = alpha_beta[patch * 4 + 1], b0 = alpha_beta[patch * 4 + 2], b1 = alpha_beta[patch * 4 + 3];
     bool ok = true;
 #pragma unroll
@@ -705,37 +702,80 @@ __global__ __launch_bounds__(AT) void stain_augment_f64_wide_kernel(const uint8_
             ok = ok && fabs(m[0][3 * j + c]) < 18.0 && fabs(m[1][3 * j + c]) < 18.0;  // 5.5414 * 18 < 100: every factor within e^+-100
         }
     }
+    return ok;
+}
+
+// Two kernels, launched back to back over the same grid: the table form for the patches whose exponents are safe, the reference's
+// per-pixel libm arithmetic for the rest (a workgroup of the other kind returns at once).  As ONE kernel the libm path set the register
+// allocation of both: 256 VGPRs + 160 bytes of scratch, one wave per SIMD for a loop that lives on LDS look-up latency.
+__global__ __launch_bounds__(AT) void stain_augment_f64_wide_kernel(const uint8_t* __restrict__ img, long hw,
+                                                                     const tia_stain_tables* __restrict__ tab,
+                                                                     const double* __restrict__ stats,
+                                                                     const double* __restrict__ alpha_beta, int y_thr,
+                                                                     int augment_background, int z1, uint8_t* __restrict__ out) {
+    __shared__ double ptab[2 * 9 * 256];
+    __shared__ int ty[3][256];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[AT / 64][3072];
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    double m[2][9], k0[3];
+    if (!augment_tables_ok(st, alpha_beta, patch, m, k0)) return;  // (uniform per workgroup) -> stain_augment_f64_ref_wide_kernel
+    build_ty(ty, tab, st[TIA_ST_PLOW], st[TIA_ST_PHIGH], z1 != 0);
     const uint8_t* src = img + (size_t)patch * (size_t)hw * 3u;
     uint8_t* dst = out + (size_t)patch * (size_t)hw * 3u;
-    if (!ok) {  // (uniform per workgroup) exponent range not safe for the tables, or NaN / inf: the reference's per-pixel arithmetic
-        double* lut = ptab;
-        for (int i = threadIdx.x; i < 256; i += AT) lut[i] = tab->od_lut[i];
-        __syncthreads();
-        AugCtxRef ref;
+    // The 4,608 entries in a ROLLED loop (one exp call site: unrolled, eighteen inlined libm exponentials push the kernel past 256
+    // registers and its main loop to one wave per SIMD), the matrices read from LDS (indexed by a run-time (set, kk) in registers they
+    // would live in scratch memory).
+    __shared__ double s_m[2 * 9], s_k[3];
+    if (threadIdx.x == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            ref.p[i] = st[TIA_ST_PINV + i];
-            ref.sm[i] = st[TIA_ST_STAIN + i];
-        }
-        ref.al[0] = a0;
-        ref.al[1] = a1;
-        ref.be[0] = b0;
-        ref.be[1] = b1;
-        ref.lut = lut;
-        ref.ty = ty;
-        ref.bound = ((long)y_thr << 12) - (1 << 11);
-        ref.augment_background = augment_background;
-        sweep_wide<TIA_OUT_U8, AugCtxRef, double>(ref, stage[threadIdx.x >> 6], src, dst, hw);
-        return;
+        for (int i = 0; i < 18; ++i) s_m[i] = m[i / 9][i % 9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s_k[c] = 255.0 * exp(-k0[c]);
     }
+    __syncthreads();
+#pragma unroll 1
     for (int i = threadIdx.x; i < 2 * 9 * 256; i += AT) {
-        const int set = i / (9 * 256), kk = (i >> 8) % 9, v = i & 255;
-        const double e = exp(-(tab->od_lut[v] * m[set][kk])) * (kk < 3 ? 255.0 * (set ? exp(-k0[kk]) : 1.0) : 1.0);
-        ptab[i] = e;
+        const int sk = i >> 8, kk = sk >= 9 ? sk - 9 : sk, v = i & 255;
+        const double scale = kk < 3 ? (sk >= 9 ? s_k[kk] : 255.0) : 1.0;
+        ptab[i] = exp(-(tab->od_lut[v] * s_m[sk])) * scale;
     }
     __syncthreads();
     AugCtxTab ctx{ptab, ty, ((long)y_thr << 12) - (1 << 11), augment_background};
     sweep_wide<TIA_OUT_U8, AugCtxTab, double>(ctx, stage[threadIdx.x >> 6], src, dst, hw);
+}
+
+__global__ __launch_bounds__(AT) void stain_augment_f64_ref_wide_kernel(const uint8_t* __restrict__ img, long hw,
+                                                                         const tia_stain_tables* __restrict__ tab,
+                                                                         const double* __restrict__ stats,
+                                                                         const double* __restrict__ alpha_beta, int y_thr,
+                                                                         int augment_background, int z1, uint8_t* __restrict__ out) {
+    __shared__ double lut[256];
+    __shared__ int ty[3][256];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[AT / 64][3072];
+    const long patch = blockIdx.y;
+    const double* st = stats + patch * TIA_STATS_STRIDE;
+    double m[2][9], k0[3];
+    if (augment_tables_ok(st, alpha_beta, patch, m, k0)) return;  // (uniform per workgroup) the table form has done this patch
+    build_ty(ty, tab, st[TIA_ST_PLOW], st[TIA_ST_PHIGH], z1 != 0);
+    for (int i = threadIdx.x; i < 256; i += AT) lut[i] = tab->od_lut[i];
+    __syncthreads();
+    AugCtxRef ref;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        ref.p[i] = st[TIA_ST_PINV + i];
+        ref.sm[i] = st[TIA_ST_STAIN + i];
+    }
+    ref.al[0] = alpha_beta[patch * 4 + 0];
+    ref.al[1] = alpha_beta[patch * 4 + 1];
+    ref.be[0] = alpha_beta[patch * 4 + 2];
+    ref.be[1] = alpha_beta[patch * 4 + 3];
+    ref.lut = lut;
+    ref.ty = ty;
+    ref.bound = ((long)y_thr << 12) - (1 << 11);
+    ref.augment_background = augment_background;
+    sweep_wide<TIA_OUT_U8, AugCtxRef, double>(ref, stage[threadIdx.x >> 6], img + (size_t)patch * (size_t)hw * 3u,
+                                             out + (size_t)patch * (size_t)hw * 3u, hw);
 }
 
 // ---- concentrations ------------------------------------------------------------------------------
@@ -1073,9 +1113,11 @@ extern "C" int tia_stain_augment_u8(const uint8_t* d_img, int64_t n, int64_t h, 
             long bx = (nchunks + 3) / 4;
             const long want = (1024 + (long)n - 1) / (long)n;
             if (bx > want) bx = want;
-            hipLaunchKernelGGL(tia::stain_augment_f64_wide_kernel, dim3((unsigned)(bx < 1 ? 1 : bx), (unsigned)n), dim3(tia::AT), 0,
-                               (hipStream_t)stream, d_img, hw, d_tables, d_stats, d_alpha_beta, y_thr, augment_background, zero_to_one,
-                               d_out);
+            const dim3 grid_w((unsigned)(bx < 1 ? 1 : bx), (unsigned)n);
+            hipLaunchKernelGGL(tia::stain_augment_f64_wide_kernel, grid_w, dim3(tia::AT), 0, (hipStream_t)stream, d_img, hw, d_tables,
+                               d_stats, d_alpha_beta, y_thr, augment_background, zero_to_one, d_out);
+            hipLaunchKernelGGL(tia::stain_augment_f64_ref_wide_kernel, grid_w, dim3(tia::AT), 0, (hipStream_t)stream, d_img, hw, d_tables,
+                               d_stats, d_alpha_beta, y_thr, augment_background, zero_to_one, d_out);
             return hipGetLastError() == hipSuccess ? TIA_OK : TIA_ELAUNCH;
         }
     }
