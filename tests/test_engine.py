@@ -789,20 +789,25 @@ def test_winograd_persistent_form_is_bit_identical_to_one_block_per_workgroup():
     from tiatoolbox_amd.models.architecture.fused import hip_conv3x3_wino, pack_conv_weights_wino
 
     g = torch.Generator(device="cuda").manual_seed(11)
-    for n, cin, cout, h, w in ((41, 64, 64, 64, 64), (75, 128, 128, 32, 32), (280, 256, 192, 16, 16), (47, 32, 64, 62, 50),
-                               (33, 64, 128, 64, 64)):
-        conv = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=True).cuda()
+    # 16 x 16 blocks (incl. a valid 64 -> 62 map); maps of at most 8 x 8 (four images per block: the second weight stage requested
+    # behind the epilogue); the window geometry of 56^2 / 28^2 / 14^2 maps (one block per workgroup at every size: chunking must not
+    # change its results either)
+    for n, cin, cout, h, w, pad in ((41, 64, 64, 64, 64, 1), (75, 128, 128, 32, 32, 1), (280, 256, 192, 16, 16, 1), (47, 32, 64, 62, 50, 1),
+                                    (33, 64, 128, 64, 64, 1), (301, 512, 512, 8, 8, 1), (530, 256, 256, 7, 7, 1), (70, 64, 64, 56, 56, 1),
+                                    (150, 128, 128, 28, 28, 1), (330, 256, 256, 14, 14, 1), (21, 64, 128, 64, 64, 0)):
+        conv = torch.nn.Conv2d(cin, cout, 3, padding=pad, bias=True).cuda()
         up = pack_conv_weights_wino(conv)
+        ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
         x = torch.randn((n, cin, h, w), device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
-        res = torch.randn((n, cout, h, w), device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
-        tiles = n * ((h + 15) // 16) * ((w + 15) // 16) * (cout // 64)
-        assert tiles >= 512, "the full batch must qualify for the persistent form on a 256-CU device"
-        chunk = max(1, 400 // (tiles // n))  # chunks of fewer than 512 items: one block per workgroup
+        res = torch.randn((n, cout, ho, wo), device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+        blocks = -(-n // 4) if max(ho, wo) <= 8 else n * ((ho + 15) // 16) * ((wo + 15) // 16)  # (a lower bound for the window geometry)
+        assert blocks * (cout // 64) >= 512, "the full batch must qualify for the persistent form on a 256-CU device"
+        chunk = max(1, min(n // 3, 400 * n // (blocks * (cout // 64)) // 2))  # chunks far below 512 items: one block per workgroup
         for use_res, relu in ((False, False), (True, True)):
-            full = hip_conv3x3_wino(x, up, conv.bias, res if use_res else None, padding=1, relu=relu)
-            parts = [hip_conv3x3_wino(x[i:i + chunk], up, conv.bias, res[i:i + chunk] if use_res else None, padding=1, relu=relu)
+            full = hip_conv3x3_wino(x, up, conv.bias, res if use_res else None, padding=pad, relu=relu)
+            parts = [hip_conv3x3_wino(x[i:i + chunk], up, conv.bias, res[i:i + chunk] if use_res else None, padding=pad, relu=relu)
                      for i in range(0, n, chunk)]
-            assert torch.equal(full, torch.cat(parts)), (n, cin, cout, h, w, use_res, relu)
+            assert torch.equal(full, torch.cat(parts)), (n, cin, cout, h, w, pad, use_res, relu)
 
 
 @pytest.mark.gpu

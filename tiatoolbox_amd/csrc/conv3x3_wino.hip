@@ -160,11 +160,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     // PERSIST: [patch 0][stage 0][stage 1][patch 1 ...] with the epilogue's 64 KB starting at patch 1 (patch 0 and the stages
     // hold the next item's first operands while the epilogue runs), the dump KB behind the tile.
     constexpr int EPI_TILE = BLOCK_PX * BN * 4;
-    constexpr int OFF_A1 = PERSIST ? A_BYTES + NSTAGE * W_STAGE : A_BYTES;
+    // LATE (the larger patches of the 8 x 8 and window geometries): [patch 0][stage 0][patch 1][stage 1] -- the epilogue's 64 KB also
+    // cover the front of stage 1, whose first refill for the next item is requested BEHIND the epilogue (one more barrier per item, and
+    // part of that round trip exposed) instead of in the item's last step.
+    constexpr bool LATE = PERSIST && A_BYTES + NSTAGE * W_STAGE + (A_BYTES > EPI_TILE ? A_BYTES : EPI_TILE) + 1024 > 160 * 1024;
     constexpr int OFF_W = PERSIST ? A_BYTES : 2 * A_BYTES;
+    constexpr int OFF_A1 = PERSIST ? (LATE ? A_BYTES + W_STAGE : A_BYTES + NSTAGE * W_STAGE) : A_BYTES;
+    constexpr int OFF_W1 = LATE ? OFF_A1 + A_BYTES : OFF_W + W_STAGE;
     constexpr int OFF_EPI = PERSIST ? OFF_A1 : 0;
     constexpr int EPI_BYTES = EPI_TILE;                            // the epilogue's exchange area, then its float32 tile
-    constexpr int MAIN_END = PERSIST ? OFF_A1 + A_BYTES : 2 * A_BYTES + NSTAGE * W_STAGE;
+    constexpr int MAIN_END = PERSIST ? (LATE ? OFF_W1 + W_STAGE : OFF_A1 + A_BYTES) : 2 * A_BYTES + NSTAGE * W_STAGE;
     constexpr int DUMP = PERSIST ? (MAIN_END > OFF_EPI + EPI_BYTES ? MAIN_END : OFF_EPI + EPI_BYTES) : MAIN_END;  // 1 KB the idle waves of the last patch piece write their zeros to
     constexpr int LDS_BYTES = DUMP + 1024 > OFF_EPI + EPI_BYTES ? DUMP + 1024 : OFF_EPI + EPI_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
 
     unsigned char* const abuf0 = smem;
     constexpr int A_PITCH = OFF_A1;  // bytes between the two patch buffers
-    unsigned char* const wst0 = smem + OFF_W;
+    auto wst = [&](int stage) -> unsigned char* { return smem + (stage ? OFF_W1 : OFF_W); };  // (stage: 0 | 1)
     auto dma_a = [&](int buf, int r, int cs) {
 #if TIA_WINO_TIMING || TIA_WINO_ABLATE
         if ((d.abl & 2) && cs > 0) return;
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         if ((d.abl & 1) && s > 0) return;
 #endif
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma16(ru, wst0 + stage * W_STAGE + q * 8192 + wave_s * 1024, w_voff, 4 * q * d.pos_stride + (s * n_cb + cbi) * 2048);
+        for (int q = 0; q < 4; ++q) dma16(ru, wst(stage) + q * 8192 + wave_s * 1024, w_voff, 4 * q * d.pos_stride + (s * n_cb + cbi) * 2048);
     };
 
     f32x16 acc[4][2];  // [position j of the wave's row][channel tile]
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
         for (int c = 0; c < 4; ++c) pa[c] = sa[fa_a + px_unit(c)], pb[c] = sa[fa_b + px_unit(c)];
     };
     auto weight_reads = [&](int s, int j) {
-        const u32x4* sb = reinterpret_cast<const u32x4*>(wst0 + (s & 1) * W_STAGE) + fb;
+        const u32x4* sb = reinterpret_cast<const u32x4*>(wst(s & 1)) + fb;
         wq[j][0] = sb[j * 128], wq[j][1] = sb[j * 128 + 32];
     };
     auto transform = [&] {
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     transform();
     // (every wave has read stage 0's weights: step 0 may refill it; PERSIST, later items: every wave has left the epilogue's tile, which
     // step 0's patch DMA overwrites -- the epilogue's global stores need not have landed for that)
-    if (first_item) step_end(); else lds_barrier();
+    if (first_item || LATE) step_end(); else lds_barrier();  // (LATE: stage 1's refill, requested behind the epilogue, has to have landed)
     WSTAMP(tm_pro)
     // PERSIST: the item after this one is decoded in step n_steps - 3 (behind that step's MFMAs: every patch request of the current item
     // has been issued by then, so its offsets `cen` can be overwritten) and requested by the last slice
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
                     for (int r = 0; r < NA; ++r) dma_a(((k >> 1) & 1) ^ 1, r, (k >> 1) + 1);
                 }
             } else if (PERSIST && has_next) {  // the last slice (n_cs is even: it sits in buffer 1): the next item's first operands
-                dma_w(k & 1, k + 2 - n_steps, cb);
+                if (!LATE || (k & 1) == 0) dma_w(k & 1, k + 2 - n_steps, cb);  // (LATE: stage 1 lies under the epilogue -- requested behind it)
                 if ((k & 1) == 0) {
 #pragma unroll
                     for (int r = 0; r < NA; ++r) dma_a(0, r, 0);
@@ -483,9 +488,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     }
     int mpix[ITER];
     u32x4 rq[ITER][2];
+    int tid_e = tid;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid_e));  // (keeps the rows' item-independent index arithmetic INSIDE the item loop: hoisted
+                                                            // out of it, a dozen values per thread are spilled and reloaded in every epilogue)
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int row = (tid + NT * it) / (BN / 8);
+        const int row = (tid_e + NT * it) / (BN / 8);
         if constexpr (RT) {  // block pixel = 4 * tile + 2 a + b
             const int tt = row >> 2, wt = d.wty * d.wtx;
             const int g = fdiv(tt, wt, d.inv_wt), rr = tt - g * wt;
@@ -610,6 +618,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     ++n_items_;
 #endif
     if (!has_next) break;
+    if constexpr (LATE) {  // every wave has read the tile: stage 1 may take the next item's second step
+        lds_barrier();
+        dma_w(1, 1, cb);
+    }
     TIA_WINO_CLEAR_ACC();
     WSTAMP(tm_epi)
     }  // items
@@ -662,7 +674,11 @@ namespace tia {
 // persistent form keeps the epilogue's 64 KB at the second patch buffer, behind the first buffer and the stages (the kernel's map)
 static constexpr int wino_lds_bytes(int patch_units, int stages, bool persist) {
     const int a_bytes = ((patch_units + 63) / 64 * 64) * 16, tile = 256 * 64 * 4;
-    if (persist) return a_bytes + stages * 32768 + (a_bytes > tile ? a_bytes : tile) + 1024;
+    if (persist) {
+        const int full = a_bytes + stages * 32768 + (a_bytes > tile ? a_bytes : tile) + 1024;
+        if (full <= 160 * 1024) return full;
+        return a_bytes + 32768 + (a_bytes + 32768 > tile ? a_bytes + 32768 : tile) + 1024;  // LATE: [patch 0][stage 0][patch 1][stage 1]
+    }
     const int main_loop = 2 * a_bytes + stages * 32768 + 1024;
     return main_loop > tile ? main_loop : tile;
 }
@@ -740,13 +756,15 @@ int conv3x3_wino_launch(const float* x, const float* u_packed, const float* bias
         d.inv_wtx = 1.0f / (float)plan.wtx, d.inv_wins = 1.0f / (float)(plan.wins_x * plan.wins_y), d.inv_wins_x = 1.0f / (float)plan.wins_x;
     }
     // Persistent form (one workgroup per CU walks the items, the next item's first operands requested behind the current one's last
-    // steps): 16 x 16 blocks, an even number of 16-channel slices (the patch buffers alternate per slice and an item must end on
-    // buffer 1), at least two rounds of items -- everything else one block per workgroup.
+    // steps): 16 x 16 blocks and the four-image blocks of small maps, an even number of 16-channel slices (the patch buffers alternate
+    // per slice and an item must end on buffer 1), at least two rounds of items -- everything else one block per workgroup.
     static const bool no_persist = tia::dev_env("TIA_WINO_NO_PERSIST") != nullptr;  // developer switch (A/B measurements)
     const long cus = wino_cu_count() / 8 * 8;
-    const bool persist = !no_persist && plan.kind == 0 && (cin / 16) % 2 == 0 && cus >= 8 && tiles * (cout / 64) >= 2 * cus;
+    // (the window geometry keeps one block per workgroup: measured on the 56^2 / 28^2 / 14^2 maps of 224^2 patches the persistent form
+    // is -1 % / +1.6 % / +4 % there -- its per-item decode is all run-time divisions -- profiles/r06k_wino_persist_ab_224.txt)
+    const bool persist = !no_persist && plan.kind != 2 && (cin / 16) % 2 == 0 && cus >= 8 && tiles * (cout / 64) >= 2 * cus;
     const dim3 grid = persist ? dim3((unsigned)cus) : dim3((unsigned)(((tiles + 7) / 8) * 8), (unsigned)(cout / 64));
-    static tia::DeviceOnce attr16, attr8, attrw, attr16p;  // the dynamic-LDS attribute is per device
+    static tia::DeviceOnce attr16, attr8, attrw, attr16p, attr8p;  // the dynamic-LDS attribute is per device
 #define TIA_WINO_LAUNCH(GEO_, NS_, PERSIST_, ONCE_)                                                                                  \
     do {                                                                                                                             \
         constexpr int lds = wino_lds_bytes((GEO_::G == 0 ? 1 : GEO_::G) * GEO_::IMG, NS_, PERSIST_);                                \
@@ -759,7 +777,9 @@ int conv3x3_wino_launch(const float* x, const float* u_packed, const float* bias
         hipLaunchKernelGGL((conv3x3_wino_kernel<GEO_, NS_, PERSIST_>), grid, dim3(512), lds, stream, x, u_packed, bias, residual, y,  \
                            d, relu, (int)tiles, (int)tiles_x, (int)(tiles_y * tiles_x));                                             \
     } while (0)
-    if (plan.kind == 1)
+    if (plan.kind == 1 && persist)
+        TIA_WINO_LAUNCH(W8, 2, true, attr8p);
+    else if (plan.kind == 1)
         TIA_WINO_LAUNCH(W8, 2, false, attr8);
     else if (plan.kind == 2)
         TIA_WINO_LAUNCH(WR, 2, false, attrw);
