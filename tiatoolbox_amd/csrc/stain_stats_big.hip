@@ -191,7 +191,9 @@ __global__ __launch_bounds__(GT) void big_hist_kernel(const uint8_t* __restrict_
         for (int c = 0; c < 32; ++c) tot += bins[threadIdx.x * 32 + ((c + threadIdx.x) & 31)];
         if (tot) atomicAdd(&st.hist[threadIdx.x], tot);
     }
-    if (big_last_workgroup(st)) big_p1_finish(hw, prm, st, stats + (size_t)blockIdx.y * TIA_STATS_STRIDE);
+}
+__global__ __launch_bounds__(GT) void big_p1_finish_kernel(long hw, tia_stain_params prm, BigState* __restrict__ states, double* __restrict__ stats) {
+    big_p1_finish(hw, prm, states[blockIdx.x], stats + (size_t)blockIdx.x * TIA_STATS_STRIDE);
 }
 
 // percentiles of the contrast enhancer from the merged counts (one workgroup per image): the arithmetic of the per-patch kernels
@@ -294,7 +296,11 @@ __global__ __launch_bounds__(GT) void big_moments_kernel(const uint8_t* __restri
         for (int w = 0; w < GT / 64; ++w) t += red[w][threadIdx.x];  // fixed order
         __hip_atomic_store(&st.partial[blockIdx.x][threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (big_last_workgroup(st)) big_eigen((int)gridDim.x, prm, st, stats + (size_t)blockIdx.y * TIA_STATS_STRIDE);
+}
+__global__ __launch_bounds__(GT) void big_eigen_kernel(int groups, tia_stain_params prm, BigState* __restrict__ states, double* __restrict__ stats) {
+    BigState& st = states[blockIdx.x];
+    if (st.skip) return;  // (uniform)
+    big_eigen(groups, prm, st, stats + (size_t)blockIdx.x * TIA_STATS_STRIDE);
 }
 
 // targets that rank the same key and agree in the digits fixed so far count into ONE row (the smallest such target's)
@@ -339,17 +345,17 @@ __device__ __forceinline__ void big_start_selection(BigState& st, const unsigned
 
 __device__ void big_eigen(int groups, const tia_stain_params& prm, BigState& st, double* __restrict__ out) {
     __shared__ double s_acc[10];
-    if (threadIdx.x < 10) {  // ten columns side by side, each summed in workgroup order: deterministic for a given grid
+    __shared__ double s_part[kMaxBigGroups * 10];
+    // the partial sums come in with all 256 threads at once and are added from LDS: ten columns side by side, each in workgroup order
+    // (deterministic for a given grid).  Ten threads walking global memory eight loads at a time took 35 us for 768 workgroups.
+    {
+        const double* flat = &st.partial[0][0];
+        for (int i = threadIdx.x; i < groups * 10; i += GT) s_part[i] = big_ldd(&flat[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
         double t = 0.0;
-        int g = 0;
-        for (; g + 8 <= groups; g += 8) {  // eight loads in flight, added in order
-            double v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = big_ldd(&st.partial[g + k][threadIdx.x]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t += v[k];
-        }
-        for (; g < groups; ++g) t += big_ldd(&st.partial[g][threadIdx.x]);
+        for (int g = 0; g < groups; ++g) t += s_part[g * 10 + threadIdx.x];
         s_acc[threadIdx.x] = t;
     }
     __syncthreads();
@@ -1131,11 +1137,13 @@ int launch_stain_stats_big(const uint8_t* d_img, long n, long hw, const tia_stai
     const dim3 grid((unsigned)groups, (unsigned)n), one((unsigned)n);
     const int z1 = prm.zero_to_one != 0 ? 1 : 0;
     hipLaunchKernelGGL(big_hist_kernel, grid, dim3(GT), 0, st, d_img, hw, states, z1, prm, d_stats);
+    hipLaunchKernelGGL(big_p1_finish_kernel, one, dim3(GT), 0, st, hw, prm, states, d_stats);
     // the radix fall-back is launched unconditionally (the host does not know whether a list overflowed) and returns at once in the
     // common case; all its digit passes run inside one launch, on few workgroups per image (see the kernel)
     const dim3 grid_fb((unsigned)(groups > 256 ? 256 : groups), (unsigned)n);
     if (prm.mode == TIA_MODE_MACENKO) {
         hipLaunchKernelGGL(big_moments_kernel, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, d_stats);
+        hipLaunchKernelGGL(big_eigen_kernel, one, dim3(GT), 0, st, groups, prm, states, d_stats);
         hipLaunchKernelGGL(big_lin_sweep_kernel<0>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, codes);
         hipLaunchKernelGGL(big_lin_step_kernel, one, dim3(GT), 0, st, states);
         hipLaunchKernelGGL(big_collect_sweep_kernel<0>, grid, dim3(GT), 0, st, d_img, hw, d_tables, prm, states, codes, cand);
