@@ -488,12 +488,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(const float* __res
     }
     int mpix[ITER];
     u32x4 rq[ITER][2];
-    int tid_e = tid;
-    if constexpr (PERSIST) asm volatile("" : "+v"(tid_e));  // (keeps the rows' item-independent index arithmetic INSIDE the item loop: hoisted
-                                                            // out of it, a dozen values per thread are spilled and reloaded in every epilogue)
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int row = (tid_e + NT * it) / (BN / 8);
+        const int row = (tid + NT * it) / (BN / 8);
         if constexpr (RT) {  // block pixel = 4 * tile + 2 a + b
             const int tt = row >> 2, wt = d.wty * d.wtx;
             const int g = fdiv(tt, wt, d.inv_wt), rr = tt - g * wt;
