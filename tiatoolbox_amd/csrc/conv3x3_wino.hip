@@ -3,7 +3,7 @@
 // (conv3x3_spatial.hip), which sits at ~90 % of a float32 MFMA wall that equals the vector rate.  float32 Winograd is what the
 // vendor libraries run for exactly these layers, so it is the reference's arithmetic CLASS (float32 in, float32 accumulate), not
 // its operation order: results differ from a direct float32 convolution in the last bits (measured and bounded in
-// tests/test_engine.py; the engines take this path only when asked: `conv_algo="winograd"`).
+// tests/test_engine.py; the engines' default `conv_algo="auto"` takes this path on every layer it serves, `"direct"` never).
 // Call sites in the reference: the 3x3 convolutions behind CNNModel.forward (models/architecture/vanilla.py:242-253,300-316).
 //
 //   Y = A^T [ (G g G^T) . (B^T d B) ] A     per 2 x 2 output tile, 4 x 4 input tile d, 3 x 3 filter g   (Lavin & Gray)

@@ -680,10 +680,11 @@ class MfmaResNet(nn.Module):
         return self.blocks(self.stem_forward(x))
 
     def set_conv_algo(self, algo: str) -> None:
-        """``"direct"`` (default: float32 implicit GEMM, the reference's operation class AND order of accumulation over taps) or
-        ``"winograd"``: the float32 3x3 / stride-1 block convolutions through F(2x2, 3x3) -- float32 in, float32 accumulate,
-        2.25 x fewer multiplies, log-probabilities within the engine's smoke tolerance of the direct path (an opt-in, like the
-        vendor libraries' own Winograd solvers for these layers)."""
+        """``"direct"`` (the module's own default: float32 implicit GEMM, the reference's operation class AND order of accumulation over
+        taps) or ``"winograd"``: the float32 3x3 / stride-1 block convolutions through F(2x2, 3x3) -- float32 in, float32 accumulate,
+        2.25 x fewer multiplies, log-probabilities within the engine's smoke tolerance of the direct path (the class of arithmetic
+        of the vendor libraries' own solvers for these layers).  The ENGINES choose: their default ``conv_algo="auto"`` sets
+        ``"winograd"`` here, ``conv_algo="direct"`` is the audit mode (``EngineABC._inference_model``)."""
         if algo not in ("direct", "winograd"):
             msg = f"conv_algo must be 'direct' or 'winograd', got {algo!r}."
             raise ValueError(msg)
